@@ -1,0 +1,215 @@
+"""TEST INFRASTRUCTURE ONLY.  Generates tests/golden/*.npz by running the REAL
+reference (/root/reference, imported through oracle/ref_stubs.py) on CPU.
+
+    python -m oracle.make_golden            # from the repo root, build container only
+
+The reference holds no golden vectors of its own, so these
+files are the pin for oracle/swapnet_oracle.py (tests/test_oracle_golden.py) and,
+through it, for the HIP path.  Because a WarpModule is 137.6 M parameters the
+fixtures do not store tensors: weights are reproduced from the seed on both
+sides (same torch build in the container and on the GPU box) and every tensor
+is recorded as (L2 norm, sum, 24 sampled elements at fixed flat indices).
+"""
+import argparse
+import os
+import sys
+import tempfile
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+from oracle import ref_stubs  # noqa: E402
+
+from oracle.golden_io import summarize  # noqa: E402
+
+
+def base_opt(tmp, **kw):
+    o = dict(
+        gpu_id=None, is_train=True, checkpoints_dir=tmp, name="golden", no_confirm=True,
+        body_channels=12, body_representation="rgb", cloth_channels=19,
+        cloth_representation="labels", texture_channels=3, init_type="kaiming",
+        init_gain=0.02, discriminator="basic", n_layers_D=3, norm="instance",
+        gan_label_mode="smooth", gan_mode="vanilla", lambda_discriminator=1.0,
+        lambda_gan=1.0, lambda_gp=10, optimizer_G="AdamW", optimizer_D="AdamW",
+        lr=1e-4, d_lr=4e-4, weight_decay=0.0, d_weight_decay=0.01, b1=0.9, b2=0.999,
+        beta1=0.5, verbose=False, continue_train=False, load_epoch="latest",
+        body_norm_stats=((0.0,) * 3, (1.0,) * 3), texture_norm_stats=((0.0,) * 3, (1.0,) * 3),
+    )
+    o.update(kw)
+    return argparse.Namespace(**o)
+
+
+def hook_taps(net, names):
+    taps, handles = OrderedDict(), []
+    for n in names:
+        mod = dict(net.named_modules())[n]
+        handles.append(mod.register_forward_hook(
+            lambda m, i, o, n=n: taps.__setitem__(n, o.detach().clone())))
+    return taps, handles
+
+
+def golden_warp(path, H=64, B=2, init_seed=0, step_seeds=(100, 101)):
+    from oracle.swapnet_oracle import synth_warp_batch
+    from models.warp_model import WarpModel
+    out = OrderedDict()
+    with tempfile.TemporaryDirectory() as tmp:
+        opt = base_opt(tmp, warp_mode="gan", lambda_ce=100.0, model="warp")
+        torch.manual_seed(init_seed)
+        model = WarpModel(opt)
+        model.eval()                      # dropout off; IN has no running stats
+        for k, v in model.net_generator.state_dict().items():
+            summarize(out, "init/G/" + k, v)
+        for k, v in model.net_discriminator.state_dict().items():
+            summarize(out, "init/D/" + k, v)
+        bodys, inputs, targets = synth_warp_batch(B, H, H, seed=1234)
+        tap_names = ["body_down1", "body_down2", "body_down3", "body_down4", "cloth_down1",
+                     "cloth_down2", "cloth_down3", "cloth_down4", "cloth_down5", "cloth_down6",
+                     "cloth_up1", "cloth_up2", "resblocks.0", "resblocks.1", "resblocks.2",
+                     "resblocks.3", "dual_up1", "dual_up2", "dual_up3"]
+        taps, handles = hook_taps(model.net_generator, tap_names)
+        for si, seed in enumerate(step_seeds):
+            model.set_input(dict(bodys=bodys, input_cloths=inputs, target_cloths=targets,
+                                 cloth_paths=[""] * B, body_paths=[""] * B))
+            torch.manual_seed(seed)
+            # record the three smooth-label draws the step is about to make
+            st = torch.get_rng_state()
+            lows = [float(torch.rand(1) * (torch.tensor(1.1) - torch.tensor(0.7)) + torch.tensor(0.7))
+                    for _ in range(3)]
+            torch.set_rng_state(st)
+            # capture D grads before optimizer_G.zero_grad is irrelevant: D grads are
+            # overwritten by backward_G (quirk 5), so snapshot them via a hook on step
+            d_grads = {}
+            orig_step = model.optimizer_D.step
+
+            def step_and_snap(*a, **k):
+                for n, p in model.net_discriminator.named_parameters():
+                    d_grads[n] = p.grad.detach().clone()
+                return orig_step(*a, **k)
+            model.optimizer_D.step = step_and_snap
+            model.optimize_parameters()
+            model.optimizer_D.step = orig_step
+            pre = "step%d/" % si
+            out[pre + "labels"] = np.array(lows, dtype=np.float64)
+            for k, v in model.get_current_losses().items():
+                out[pre + "loss/" + k] = np.float64(v)
+            summarize(out, pre + "fakes", model.fakes)
+            if si == 0:
+                for n, t in taps.items():
+                    summarize(out, "fwd/" + n, t)
+            for n, p in model.net_generator.named_parameters():
+                summarize(out, pre + "gradG/" + n, p.grad)
+                summarize(out, pre + "postG/" + n, p)
+            for n, p in model.net_discriminator.named_parameters():
+                summarize(out, pre + "gradD/" + n, d_grads[n])
+                summarize(out, pre + "postD/" + n, p)
+        for h in handles:
+            h.remove()
+        # integer work: label decode of the generated batch (util/decode_labels.py)
+        dec = model.__class__.compute_visuals
+        from util.decode_labels import decode_cloth_labels
+        out["decode/fakes_rgb"] = decode_cloth_labels(model.fakes[:1, :, :16, :16]).numpy()
+        out["decode/argmax"] = model.fakes[:1, :, :16, :16].argmax(dim=1).numpy()
+    out["meta/H"] = np.int64(H)
+    out["meta/B"] = np.int64(B)
+    out["meta/init_seed"] = np.int64(init_seed)
+    out["meta/step_seeds"] = np.array(step_seeds, dtype=np.int64)
+    out["meta/torch"] = np.array(torch.__version__)
+    np.savez_compressed(path, **out)
+    print("wrote", path, len(out), "entries")
+
+
+def golden_texture(path, H=64, B=2, init_seed=1, step_seeds=(200, 201)):
+    from oracle.swapnet_oracle import synth_texture_batch
+    from models.texture_model import TextureModel
+    out = OrderedDict()
+    with tempfile.TemporaryDirectory() as tmp:
+        opt = base_opt(tmp, model="texture", netG="swapnet", crop_size=H, lambda_l1=10.0,
+                       lambda_content=20.0, lambda_style=1e-8)
+        torch.manual_seed(init_seed)
+        model = TextureModel(opt)
+        model.eval()
+        for k, v in model.net_generator.state_dict().items():
+            summarize(out, "init/G/" + k, v)
+        for k, v in model.net_discriminator.state_dict().items():
+            summarize(out, "init/D/" + k, v)
+        tex, rois, cloths, tgt = synth_texture_batch(B, H, H, seed=4321)
+        taps, handles = hook_taps(model.net_generator, ["roi_align", "encode"])
+        for si, seed in enumerate(step_seeds):
+            model.set_input(dict(input_textures=tex, rois=rois, cloths=cloths, target_textures=tgt,
+                                 cloth_paths=[""] * B, texture_paths=[""] * B))
+            torch.manual_seed(seed)
+            st = torch.get_rng_state()
+            lows = [float(torch.rand(1) * (torch.tensor(1.1) - torch.tensor(0.7)) + torch.tensor(0.7))
+                    for _ in range(3)]
+            torch.set_rng_state(st)
+            d_grads = {}
+            orig_step = model.optimizer_D.step
+
+            def step_and_snap(*a, **k):
+                for n, p in model.net_discriminator.named_parameters():
+                    d_grads[n] = p.grad.detach().clone()
+                return orig_step(*a, **k)
+            model.optimizer_D.step = step_and_snap
+            model.optimize_parameters()
+            model.optimizer_D.step = orig_step
+            pre = "step%d/" % si
+            out[pre + "labels"] = np.array(lows, dtype=np.float64)
+            for k, v in model.get_current_losses().items():
+                out[pre + "loss/" + k] = np.float64(v)
+            summarize(out, pre + "fakes", model.fakes)
+            if si == 0:
+                for n, t in taps.items():
+                    summarize(out, "fwd/" + n, t)
+            for n, p in model.net_generator.named_parameters():
+                summarize(out, pre + "gradG/" + n, p.grad)
+                summarize(out, pre + "postG/" + n, p)
+            for n, p in model.net_discriminator.named_parameters():
+                summarize(out, pre + "gradD/" + n, d_grads[n])
+                summarize(out, pre + "postD/" + n, p)
+        for h in handles:
+            h.remove()
+    out["meta/H"] = np.int64(H)
+    out["meta/B"] = np.int64(B)
+    out["meta/init_seed"] = np.int64(init_seed)
+    out["meta/step_seeds"] = np.array(step_seeds, dtype=np.int64)
+    out["meta/torch"] = np.array(torch.__version__)
+    np.savez_compressed(path, **out)
+    print("wrote", path, len(out), "entries")
+
+
+def golden_roi(path):
+    """The only recorded real-data value in the reference: the (4,12,4) ROI tensor
+    printed in `test/Test TextureDataset Draw ROIs.ipynb` cell 9 -- stored so the
+    RoIAlign kernel is exercised on realistic (incl. degenerate) boxes."""
+    import json
+    nb = json.load(open(os.path.join(ref_stubs.REFERENCE_ROOT, "test",
+                                     "Test TextureDataset Draw ROIs.ipynb")))
+    text = None
+    for cell in nb["cells"]:
+        for o in cell.get("outputs", []):
+            t = "".join(o.get("text", []) or o.get("data", {}).get("text/plain", []))
+            if "tensor([[[" in t and text is None:
+                text = t
+    assert text is not None, "ROI tensor printout not found in the notebook"
+    nums = [float(x) for x in __import__("re").findall(r"-?\d+\.?\d*(?:e[+-]?\d+)?", text.replace("tensor", ""))]
+    rois = np.array(nums[: 4 * 12 * 4], dtype=np.float32).reshape(4, 12, 4)
+    np.savez_compressed(path, rois=rois)
+    print("wrote", path, rois.shape, "degenerate boxes:",
+          int(((rois[..., 0] == rois[..., 2]) | (rois[..., 1] == rois[..., 3])).sum()))
+
+
+if __name__ == "__main__":
+    ref_stubs.install()
+    torch.set_num_threads(8)
+    gold = os.path.join(REPO, "tests", "golden")
+    os.makedirs(gold, exist_ok=True)
+    which = sys.argv[1:] or ["warp", "texture", "roi"]
+    if "warp" in which:
+        golden_warp(os.path.join(gold, "warp_step_64.npz"))
+    if "texture" in which:
+        golden_texture(os.path.join(gold, "texture_step_64.npz"))
+    if "roi" in which:
+        golden_roi(os.path.join(gold, "notebook_rois.npz"))

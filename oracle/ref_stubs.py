@@ -1,0 +1,136 @@
+"""TEST INFRASTRUCTURE ONLY -- never imported by the swapnet_amd product path.
+
+Makes the *real* reference (andrewjong/SwapNet, mounted read-only at
+/root/reference) importable inside the build container so that
+oracle/make_golden.py can run its own WarpModel / TextureModel on CPU and
+record golden vectors.  /root/reference does not exist
+on the GPU box: nothing under tests/ -m gpu, bench.py or smoke() imports this.
+
+Five third-party modules the reference imports are absent from this image
+(torchvision, adabound, seaborn, dominate, visdom).  They are replaced by
+stand-ins in sys.modules *before* the reference is imported:
+
+  torchvision.ops.RoIAlign     -> oracle.swapnet_oracle.roi_align  (restatement of
+                                  torchvision 0.4.0 ROIAlign_cpu.cpp, "parity unpinned")
+  torchvision.models.vgg16/19  -> same layer list (cfg D / E), seeded random weights
+                                  (pretrained weights are not obtainable offline)
+  torchvision.transforms, adabound, seaborn, dominate, visdom -> inert placeholders
+"""
+import sys
+import types
+
+import torch
+from torch import nn
+
+REFERENCE_ROOT = "/root/reference"
+
+VGG19_CFG = [64, 64, "M", 128, 128, "M", 256, 256, 256, 256, "M",
+             512, 512, 512, 512, "M", 512, 512, 512, 512, "M"]
+
+
+def make_vgg_features(cfg=None):
+    """torchvision.models.vgg16().features layer list (conv3x3 pad1 + ReLU(inplace),
+    maxpool 2x2) filled with the oracle's *seeded random* weights
+    (oracle.swapnet_oracle.vgg16_feature_params; private generator, so the global
+    RNG stream used for kaiming init and the smooth labels is untouched)."""
+    from oracle.swapnet_oracle import VGG16_CFG, vgg16_feature_params
+    cfg = cfg or VGG16_CFG
+    params = vgg16_feature_params() if cfg == VGG16_CFG else None
+    layers, cin, ci = [], 3, 0
+    for v in cfg:
+        if v == "M":
+            layers.append(nn.MaxPool2d(kernel_size=2, stride=2))
+        else:
+            conv = nn.Conv2d(cin, v, kernel_size=3, padding=1)
+            if params is not None:
+                with torch.no_grad():
+                    conv.weight.copy_(params[ci][0])
+                    conv.bias.copy_(params[ci][1])
+            layers += [conv, nn.ReLU(inplace=True)]
+            cin = v
+            ci += 1
+    return nn.Sequential(*layers)
+
+
+class _VGG(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        self.features = make_vgg_features(cfg)
+
+
+def _vgg16(pretrained=False, **kw):
+    return _VGG(None)
+
+
+def _vgg19(pretrained=False, **kw):
+    return _VGG(VGG19_CFG)
+
+
+class _RoIAlignStub(nn.Module):
+    """Signature of torchvision.ops.RoIAlign @0.4.0 (no `aligned` argument)."""
+
+    def __init__(self, output_size, spatial_scale, sampling_ratio):
+        super().__init__()
+        self.output_size = output_size
+        self.spatial_scale = spatial_scale
+        self.sampling_ratio = sampling_ratio
+
+    def forward(self, input, rois):
+        from oracle.swapnet_oracle import roi_align
+        return roi_align(input, rois, self.output_size, self.spatial_scale,
+                         self.sampling_ratio)
+
+
+def _mod(name, **attrs):
+    m = types.ModuleType(name)
+    for k, v in attrs.items():
+        setattr(m, k, v)
+    sys.modules[name] = m
+    return m
+
+
+class _Inert:
+    def __init__(self, *a, **k):
+        pass
+
+    def __call__(self, *a, **k):
+        return self
+
+    def __getattr__(self, name):
+        return _Inert()
+
+
+def install():
+    """Install the stand-ins and put the reference first on sys.path."""
+    if "torchvision" not in sys.modules:
+        tv = _mod("torchvision")
+        tv.ops = _mod("torchvision.ops", RoIAlign=_RoIAlignStub)
+        tv.models = _mod("torchvision.models", vgg16=_vgg16, vgg19=_vgg19)
+        tf = _mod("torchvision.transforms")
+        for n in ("Compose", "ToTensor", "Normalize", "RandomAffine", "RandomPerspective",
+                  "RandomHorizontalFlip", "Resize", "CenterCrop", "RandomCrop", "Lambda",
+                  "ToPILImage", "ColorJitter", "Pad"):
+            setattr(tf, n, _Inert)
+        tf.functional = _mod("torchvision.transforms.functional")
+        tf.transforms = tf                      # `from torchvision.transforms import transforms`
+        sys.modules["torchvision.transforms.transforms"] = tf
+        tv.transforms = tf
+        tv.utils = _mod("torchvision.utils", make_grid=_Inert(), save_image=_Inert())
+    if "adabound" not in sys.modules:
+        _mod("adabound", AdaBound=_Inert)
+    if "seaborn" not in sys.modules:
+        _mod("seaborn", color_palette=lambda *a, **k: [(0, 0, 0)] * 12)
+    if "dominate" not in sys.modules:
+        d = _mod("dominate", document=_Inert)
+        d.tags = _mod("dominate.tags")
+        for n in ("meta", "h3", "table", "tr", "td", "p", "a", "img", "br"):
+            setattr(d.tags, n, _Inert)
+    if "visdom" not in sys.modules:
+        _mod("visdom", Visdom=_Inert)
+    if REFERENCE_ROOT not in sys.path:
+        sys.path.insert(0, REFERENCE_ROOT)
+    # the pip package `datasets` (HuggingFace) would shadow the reference's datasets/
+    for name in list(sys.modules):
+        if name == "datasets" or name.startswith("datasets."):
+            if not getattr(sys.modules[name], "__file__", "").startswith(REFERENCE_ROOT):
+                del sys.modules[name]

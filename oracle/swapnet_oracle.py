@@ -1,0 +1,704 @@
+"""CPU ORACLE -- TEST INFRASTRUCTURE ONLY.
+
+A functional, CPU-only restatement (torch fp32 on CPU for the floating-point
+arithmetic, numpy for the integer / index work) of the one hot path of
+andrewjong/SwapNet that swapnet_amd re-implements in HIP: the warp-stage and
+texture-stage G+D training step.  Every function cites the reference file:line
+(relative to /root/reference) whose behaviour it restates.
+
+Allowed importers: tests/, __graft_entry__.smoke() and bench.py's `cpu_baseline`
+leg -- as the checker or the timed CPU baseline, never as the product path.
+swapnet_amd itself must never import this module (tests/test_no_oracle_in_product.py
+enforces it).
+
+Pinning: tests/test_oracle_golden.py checks this restatement against golden
+vectors recorded from the *real* reference executed on CPU in the build
+container (oracle/make_golden.py -> tests/golden/*.npz).  Two third-party
+pieces are absent from /root/reference AND from this image, so for them parity
+is UNPINNED:
+  * torchvision.ops.RoIAlign (torchvision==0.4.0, environment.yml:94): restated
+    here from its published algorithm (ROIAlign_cpu.cpp, legacy/unaligned);
+    pinned only by hand-computed cases + the notebook ROI fixture.
+  * torchvision.models.vgg16(pretrained=True) weights: not obtainable offline;
+    both sides use the same seeded random weights.
+"""
+from collections import OrderedDict
+import math
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+# ----------------------------------------------------------------------------
+# Parameter construction (RNG-faithful restatement of the constructors + init)
+# ----------------------------------------------------------------------------
+
+
+class _ParamFactory:
+    """Creates conv / conv-transpose parameters in the reference's *construction*
+    order (each torch layer constructor consumes the global CPU RNG), then
+    re-initialises them in the reference's *module-tree* order the way
+    modules.init_weights does (modules/__init__.py:7-45: kaiming_normal_(a=0,
+    mode="fan_in") on every Conv*/Linear weight, bias := 0)."""
+
+    def __init__(self):
+        self.layers = OrderedDict()
+
+    def conv(self, name, cin, cout, k, bias):
+        self.layers[name] = nn.Conv2d(cin, cout, k, bias=bias)
+
+    def convT(self, name, cin, cout, k, bias):
+        self.layers[name] = nn.ConvTranspose2d(cin, cout, k, bias=bias)
+
+    def init_weights(self, order, init_type="kaiming", init_gain=0.02):
+        for name in order:
+            m = self.layers[name]
+            if init_type == "normal":
+                nn.init.normal_(m.weight.data, 0.0, init_gain)
+            elif init_type == "xavier":
+                nn.init.xavier_normal_(m.weight.data, gain=init_gain)
+            elif init_type == "kaiming":
+                nn.init.kaiming_normal_(m.weight.data, a=0, mode="fan_in")
+            elif init_type == "orthogonal":
+                nn.init.orthogonal_(m.weight.data, gain=init_gain)
+            else:
+                raise NotImplementedError(
+                    "initialization method [%s] is not implemented" % init_type)
+            if m.bias is not None:
+                nn.init.constant_(m.bias.data, 0.0)
+
+    def state_dict(self, order=None):
+        sd = OrderedDict()
+        for name in (order or self.layers):
+            m = self.layers[name]
+            sd[name + ".weight"] = m.weight.data
+            if m.bias is not None:
+                sd[name + ".bias"] = m.bias.data
+        return sd
+
+
+def warp_module_params(body_channels=3, cloth_channels=19, init_type="kaiming",
+                       init_gain=0.02):
+    """WarpModule.__init__ (modules/swapnet_modules.py:28-90) followed by
+    modules.init_weights (modules/__init__.py:7-45).  Returns an OrderedDict with
+    the reference's state_dict keys (33 tensors)."""
+    P = _ParamFactory()
+    P.conv("body_down1.model.0", body_channels, 64, 4, False)      # :34 UNetDown, layers.py:15
+    P.conv("body_down2.model.0", 64, 128, 4, False)
+    P.conv("body_down3.model.0", 128, 256, 4, False)
+    P.conv("body_down4.model.0", 256, 512, 4, False)
+    P.conv("cloth_down1.model.0", cloth_channels, 64, 4, False)    # :42
+    P.conv("cloth_down2.model.0", 64, 128, 4, False)
+    P.conv("cloth_down3.model.0", 128, 256, 4, False)
+    P.conv("cloth_down4.model.0", 256, 512, 4, False)
+    P.conv("cloth_down5.model.0", 512, 1024, 4, False)
+    P.conv("cloth_down6.model.0", 1024, 1024, 4, False)
+    P.convT("cloth_up1.model.0", 1024, 1024, 4, False)             # :50 UNetUp, layers.py:31
+    P.convT("cloth_up2.model.0", 1024, 512, 4, False)
+    for i in range(4):                                             # :56-62 ResidualBlock
+        P.conv("resblocks.%d.conv_block.1" % i, 1024, 1024, 3, True)   # layers.py:132
+        P.conv("resblocks.%d.conv_block.6" % i, 1024, 1024, 3, True)   # layers.py:137
+    P.convT("dual_up1.model.0", 1024, 256, 4, False)               # :72
+    P.convT("dual_up2.model.0", 3 * 256, 128, 4, False)
+    P.convT("dual_up3.model.0", 3 * 128, 64, 4, False)
+    P.conv("upsample_and_pad.2", 3 * 64, cloth_channels, 4, True)  # :85-90
+    order = list(P.layers)          # registration order == construction order here
+    P.init_weights(order, init_type, init_gain)
+    return P.state_dict(order)
+
+
+def patchgan_params(input_nc, ndf=64, n_layers=3, init_type="kaiming", init_gain=0.02):
+    """NLayerDiscriminator.__init__ under instance norm (modules/discriminators.py:
+    91-136; use_bias is True because norm_layer.func == InstanceNorm2d, :103-106)."""
+    P = _ParamFactory()
+    P.conv("model.0", input_nc, ndf, 4, True)                      # :110
+    idx, nf_mult = 2, 1
+    for n in range(1, n_layers):                                   # :113-120
+        nf_prev, nf_mult = nf_mult, min(2 ** n, 8)
+        P.conv("model.%d" % idx, ndf * nf_prev, ndf * nf_mult, 4, True)
+        idx += 3
+    nf_prev, nf_mult = nf_mult, min(2 ** n_layers, 8)
+    P.conv("model.%d" % idx, ndf * nf_prev, ndf * nf_mult, 4, True)    # :124-128 (stride 1)
+    idx += 3
+    P.conv("model.%d" % idx, ndf * nf_mult, 1, 4, True)            # :131
+    order = list(P.layers)
+    P.init_weights(order, init_type, init_gain)
+    return P.state_dict(order)
+
+
+def texture_module_params(texture_channels=3, cloth_channels=19, num_roi=12,
+                          img_size=128, ngf=64, init_type="kaiming", init_gain=0.02):
+    """TextureModule.__init__ with unet_type="pix2pix" under instance norm
+    (modules/swapnet_modules.py:155-187) -> UnetGenerator.__init__
+    (modules/pix2pix_modules.py:113-177).  Blocks are *constructed* innermost
+    first (downconv then upconv per block, :208-246) but *initialised* in
+    module-tree order (outer down convs first, up convs on the way back)."""
+    P = _ParamFactory()
+    ch = texture_channels * num_roi
+    P.conv("encode.model.0", ch, ch, 4, False)                     # :170 UNetDown
+    num_downs = math.frexp(img_size)[1] - 1                        # :178
+    # block list outermost -> innermost: (outer_nc, inner_nc, input_nc)
+    blocks = [(texture_channels, ngf, ch + cloth_channels),        # outermost :169-176
+              (ngf, ngf * 2, ngf), (ngf * 2, ngf * 4, ngf * 2), (ngf * 4, ngf * 8, ngf * 4)]
+    blocks += [(ngf * 8, ngf * 8, ngf * 8)] * (num_downs - 5)      # :144-152
+    blocks += [(ngf * 8, ngf * 8, ngf * 8)]                        # innermost :135-142
+    depth = len(blocks)
+
+    def prefix(d):      # state-dict prefix of block d (0 = outermost)
+        p = "unet.model"
+        for j in range(d):
+            p += ".model.%d" % (1 if j == 0 else 3)
+        return p
+
+    names_down, names_up = [], []
+    for d in range(depth):
+        outermost, innermost = d == 0, d == depth - 1
+        names_down.append(prefix(d) + ".model.%d" % (0 if outermost else 1))
+        names_up.append(prefix(d) + ".model.%d" % (3 if (outermost or innermost) else 5))
+    for d in reversed(range(depth)):                               # construction order
+        outer_nc, inner_nc, input_nc = blocks[d]
+        P.conv(names_down[d], input_nc, inner_nc, 4, True)         # :216-218 (use_bias)
+        up_in = inner_nc if d == depth - 1 else inner_nc * 2       # :226-246
+        P.convT(names_up[d], up_in, outer_nc, 4, True)
+    order = ["encode.model.0"] + names_down + list(reversed(names_up))
+    P.init_weights(order, init_type, init_gain)
+    return P.state_dict(order)
+
+
+VGG16_CFG = [64, 64, "M", 128, 128, "M", 256, 256, 256, "M",
+             512, 512, 512, "M", 512, 512, 512, "M"]
+VGG_SEED = 4242
+
+
+def vgg16_feature_params(seed=VGG_SEED):
+    """Seeded *random* stand-in for torchvision.models.vgg16(pretrained=True).features
+    (call site modules/losses/perceptual.py:26; PARITY UNPINNED for the pretrained
+    values).  Returns [(weight(Co,Ci,3,3), bias(Co))] x 13, private generator."""
+    g = torch.Generator().manual_seed(seed)
+    out, cin = [], 3
+    for v in VGG16_CFG:
+        if v == "M":
+            continue
+        std = (2.0 / (v * 9)) ** 0.5
+        w = torch.randn((v, cin, 3, 3), generator=g) * std
+        b = torch.randn((v,), generator=g) * 0.05
+        out.append((w, b))
+        cin = v
+    return out
+
+
+# ----------------------------------------------------------------------------
+# Layers (modules/layers.py)
+# ----------------------------------------------------------------------------
+
+def _inorm(x):
+    # nn.InstanceNorm2d(affine=False, track_running_stats=False), eps 1e-5, biased var
+    # (modules/__init__.py:66-69)
+    return F.instance_norm(x, eps=1e-5)
+
+
+def unet_down(x, w, normalize=True, dropout=0.0, training=False):
+    """UNetDown.forward (modules/layers.py:12-24)."""
+    x = F.conv2d(x, w, None, stride=2, padding=1)
+    if normalize:
+        x = _inorm(x)
+    x = F.leaky_relu(x, 0.2)
+    if dropout:
+        x = F.dropout(x, dropout, training)
+    return x
+
+
+def unet_up(x, w, skips=(), dropout=0.0, training=False):
+    """UNetUp / DualUNetUp.forward (modules/layers.py:27-63)."""
+    x = F.conv_transpose2d(x, w, None, stride=2, padding=1)
+    x = F.relu(_inorm(x))
+    if dropout:
+        x = F.dropout(x, dropout, training)
+    if skips:
+        x = torch.cat((x,) + tuple(skips), 1)
+    return x
+
+
+def residual_block(x, w1, b1, w2, b2, dropout=0.0, training=False):
+    """ResidualBlock.forward (modules/layers.py:126-144)."""
+    h = F.conv2d(F.pad(x, (1, 1, 1, 1), mode="reflect"), w1, b1)
+    h = F.relu(_inorm(h))
+    h = F.dropout(h, dropout, training)
+    h = F.conv2d(F.pad(h, (1, 1, 1, 1), mode="reflect"), w2, b2)
+    return x + _inorm(h)
+
+
+def warp_module_forward(P, body, cloth, dropout=0.5, training=False, taps=None):
+    """WarpModule.forward (modules/swapnet_modules.py:92-151).  `taps`, if a dict,
+    receives the named intermediate activations (for per-level parity tests)."""
+    t = taps if taps is not None else {}
+    w = lambda n: P[n + ".weight"]
+    b_d1 = t["body_d1"] = unet_down(body, w("body_down1.model.0"), normalize=False)
+    b_d2 = t["body_d2"] = unet_down(b_d1, w("body_down2.model.0"))
+    b_d3 = t["body_d3"] = unet_down(b_d2, w("body_down3.model.0"))
+    b_d4 = t["body_d4"] = unet_down(b_d3, w("body_down4.model.0"), dropout=dropout, training=training)
+    c_d1 = t["cloth_d1"] = unet_down(cloth, w("cloth_down1.model.0"), normalize=False)
+    c_d2 = t["cloth_d2"] = unet_down(c_d1, w("cloth_down2.model.0"))
+    c_d3 = t["cloth_d3"] = unet_down(c_d2, w("cloth_down3.model.0"))
+    c_d4 = t["cloth_d4"] = unet_down(c_d3, w("cloth_down4.model.0"))
+    c_d5 = t["cloth_d5"] = unet_down(c_d4, w("cloth_down5.model.0"), dropout=dropout, training=training)
+    c_d6 = t["cloth_d6"] = unet_down(c_d5, w("cloth_down6.model.0"), normalize=False,
+                                     dropout=dropout, training=training)
+    c_u1 = t["cloth_u1"] = unet_up(c_d6, w("cloth_up1.model.0"))
+    c_u2 = t["cloth_u2"] = unet_up(c_u1, w("cloth_up2.model.0"))
+    x = torch.cat((b_d4, c_u2), dim=1)                                  # :131
+    for i in range(4):                                                  # :135
+        p = "resblocks.%d.conv_block." % i
+        x = residual_block(x, P[p + "1.weight"], P[p + "1.bias"], P[p + "6.weight"],
+                           P[p + "6.bias"], dropout=dropout, training=training)
+        t["res%d" % i] = x
+    u1 = t["dual_u1"] = unet_up(x, w("dual_up1.model.0"), (b_d3, c_d3))
+    u2 = t["dual_u2"] = unet_up(u1, w("dual_up2.model.0"), (b_d2, c_d2))
+    u3 = t["dual_u3"] = unet_up(u2, w("dual_up3.model.0"), (b_d1, c_d1))
+    # upsample_and_pad (:85-90): Upsample(x2 nearest), ZeroPad2d((1,0,1,0)), Conv k4 p1, Tanh
+    up = F.interpolate(u3, scale_factor=2)
+    up = F.pad(up, (1, 0, 1, 0))
+    out = F.conv2d(up, P["upsample_and_pad.2.weight"], P["upsample_and_pad.2.bias"], padding=1)
+    return torch.tanh(out)
+
+
+def patchgan_forward(P, x, n_layers=3, taps=None):
+    """NLayerDiscriminator.forward (modules/discriminators.py:110-136)."""
+    t = taps if taps is not None else {}
+    x = t["d0"] = F.leaky_relu(F.conv2d(x, P["model.0.weight"], P["model.0.bias"], stride=2, padding=1), 0.2)
+    idx = 2
+    for n in range(1, n_layers):
+        x = F.conv2d(x, P["model.%d.weight" % idx], P["model.%d.bias" % idx], stride=2, padding=1)
+        x = t["d%d" % n] = F.leaky_relu(_inorm(x), 0.2)
+        idx += 3
+    x = F.conv2d(x, P["model.%d.weight" % idx], P["model.%d.bias" % idx], stride=1, padding=1)
+    x = t["d%d" % n_layers] = F.leaky_relu(_inorm(x), 0.2)
+    idx += 3
+    return F.conv2d(x, P["model.%d.weight" % idx], P["model.%d.bias" % idx], stride=1, padding=1)
+
+
+# ----------------------------------------------------------------------------
+# RoIAlign (third-party torchvision 0.4.0, call site swapnet_modules.py:166-168,234)
+# ----------------------------------------------------------------------------
+
+def roi_align_indices(rois, H, W, pooled=(128, 128), spatial_scale=1.0):
+    """Integer / index part of legacy (unaligned) RoIAlign with sampling_ratio=1
+    (ROIAlign_cpu.cpp pre_calc_for_bilinear_interpolate).  float32 arithmetic in
+    the published order.  Returns dict of arrays shaped (K, PH, PW):
+    b (K,), valid, yl, yh, xl, xh (int32) and the weights w1..w4 (float32)."""
+    rois = np.asarray(rois, dtype=np.float32)
+    K = rois.shape[0]
+    PH, PW = pooled
+    f32 = np.float32
+    b = rois[:, 0].astype(np.int32)
+    sw = rois[:, 1] * f32(spatial_scale)
+    sh = rois[:, 2] * f32(spatial_scale)
+    ew = rois[:, 3] * f32(spatial_scale)
+    eh = rois[:, 4] * f32(spatial_scale)
+    rw = np.maximum(ew - sw, f32(1.0))
+    rh = np.maximum(eh - sh, f32(1.0))
+    bw = (rw / f32(PW)).astype(np.float32)
+    bh = (rh / f32(PH)).astype(np.float32)
+    ph = np.arange(PH, dtype=np.float32)
+    pw = np.arange(PW, dtype=np.float32)
+    # y = roi_start_h + ph*bin_size_h + (iy + .5f) * bin_size_h / roi_bin_grid_h   (iy=0, grid=1)
+    y = (sh[:, None] + ph[None, :] * bh[:, None] + f32(0.5) * bh[:, None] / f32(1.0)).astype(np.float32)
+    x = (sw[:, None] + pw[None, :] * bw[:, None] + f32(0.5) * bw[:, None] / f32(1.0)).astype(np.float32)
+    y = np.broadcast_to(y[:, :, None], (K, PH, PW)).copy()
+    x = np.broadcast_to(x[:, None, :], (K, PH, PW)).copy()
+    valid = ~((y < -1.0) | (y > H) | (x < -1.0) | (x > W))
+    y = np.maximum(y, f32(0.0))
+    x = np.maximum(x, f32(0.0))
+    yl = y.astype(np.int32)
+    xl = x.astype(np.int32)
+    ycl = yl >= H - 1
+    xcl = xl >= W - 1
+    yh = np.where(ycl, H - 1, yl + 1).astype(np.int32)
+    xh = np.where(xcl, W - 1, xl + 1).astype(np.int32)
+    yl = np.where(ycl, H - 1, yl).astype(np.int32)
+    xl = np.where(xcl, W - 1, xl).astype(np.int32)
+    y = np.where(ycl, yl.astype(np.float32), y)
+    x = np.where(xcl, xl.astype(np.float32), x)
+    ly = (y - yl.astype(np.float32)).astype(np.float32)
+    lx = (x - xl.astype(np.float32)).astype(np.float32)
+    hy = (f32(1.0) - ly).astype(np.float32)
+    hx = (f32(1.0) - lx).astype(np.float32)
+    return dict(b=b, valid=valid, yl=yl, yh=yh, xl=xl, xh=xh,
+                w1=hy * hx, w2=hy * lx, w3=ly * hx, w4=ly * lx)
+
+
+def roi_align(inp, rois, output_size=(128, 128), spatial_scale=1.0, sampling_ratio=1):
+    """torchvision.ops.RoIAlign(output_size, spatial_scale, sampling_ratio=1) forward,
+    legacy semantics.  inp (N,C,H,W) f32, rois (K,5)."""
+    assert sampling_ratio == 1, "reference uses sampling_ratio=1 (swapnet_modules.py:167)"
+    x = inp.detach().cpu().numpy().astype(np.float32)
+    N, C, H, W = x.shape
+    r = rois.detach().cpu().numpy().astype(np.float32)
+    I = roi_align_indices(r, H, W, output_size, spatial_scale)
+    K = r.shape[0]
+    PH, PW = output_size
+    out = np.zeros((K, C, PH, PW), dtype=np.float32)
+    for k in range(K):
+        img = x[I["b"][k]]                      # (C,H,W)
+        v1 = img[:, I["yl"][k], I["xl"][k]]
+        v2 = img[:, I["yl"][k], I["xh"][k]]
+        v3 = img[:, I["yh"][k], I["xl"][k]]
+        v4 = img[:, I["yh"][k], I["xh"][k]]
+        val = (I["w1"][k] * v1 + I["w2"][k] * v2 + I["w3"][k] * v3 + I["w4"][k] * v4).astype(np.float32)
+        out[k] = np.where(I["valid"][k][None], val, np.float32(0.0))   # count == 1
+    return torch.from_numpy(out)
+
+
+def reshape_rois(rois):
+    """TextureModule.reshape_rois (modules/swapnet_modules.py:210-229): (B,R,4)->(B*R,5)."""
+    B, R = rois.shape[0], rois.shape[1]
+    b_idx = torch.arange(B).unsqueeze(-1).expand(B, R).reshape(-1, 1).type(rois.dtype)
+    return torch.cat((b_idx, rois.reshape(-1, rois.shape[-1])), dim=1)
+
+
+# ----------------------------------------------------------------------------
+# TextureModule (modules/swapnet_modules.py:231-260) + pix2pix U-Net
+# ----------------------------------------------------------------------------
+
+def unet_generator_forward(P, x, num_downs, prefix="unet.model", dropout=True, training=False):
+    """UnetGenerator.forward (modules/pix2pix_modules.py:113-177,180-262) under
+    instance norm.  Reproduces the in-place LeakyReLU quirk: the skip tensor of
+    every non-outermost block is LeakyReLU(x), not x (:220,262)."""
+    depth = num_downs
+
+    def pre(d):
+        p = prefix
+        for j in range(d):
+            p += ".model.%d" % (1 if j == 0 else 3)
+        return p
+
+    def block(d, x):
+        outermost, innermost = d == 0, d == depth - 1
+        p = pre(d)
+        if outermost:
+            h = F.conv2d(x, P[p + ".model.0.weight"], P[p + ".model.0.bias"], stride=2, padding=1)
+            h = block(d + 1, h)
+            h = F.relu(h)
+            h = F.conv_transpose2d(h, P[p + ".model.3.weight"], P[p + ".model.3.bias"], stride=2, padding=1)
+            return torch.tanh(h)
+        xl = F.leaky_relu(x, 0.2)                 # in-place in the reference: x itself becomes xl
+        h = F.conv2d(xl, P[p + ".model.1.weight"], P[p + ".model.1.bias"], stride=2, padding=1)
+        if innermost:
+            h = F.relu(h)
+            h = F.conv_transpose2d(h, P[p + ".model.3.weight"], P[p + ".model.3.bias"], stride=2, padding=1)
+            h = _inorm(h)
+        else:
+            h = _inorm(h)
+            h = block(d + 1, h)
+            h = F.relu(h)
+            h = F.conv_transpose2d(h, P[p + ".model.5.weight"], P[p + ".model.5.bias"], stride=2, padding=1)
+            h = _inorm(h)
+            # Dropout(0.5) on the num_downs-5 inner ngf*8 blocks (:144-152,251-252)
+            if dropout and 4 <= d < depth - 1:
+                h = F.dropout(h, 0.5, training)
+        return torch.cat([xl, h], 1)
+
+    return block(0, x)
+
+
+def texture_module_forward(P, input_tex, rois, cloth, num_roi=12, training=False, taps=None):
+    """TextureModule.forward (modules/swapnet_modules.py:231-260)."""
+    t = taps if taps is not None else {}
+    r = reshape_rois(rois)
+    pooled = roi_align(input_tex, r, (128, 128), 1.0, 1)                      # :234
+    B = pooled.shape[0] // num_roi
+    pooled = t["pooled"] = pooled.view(B, -1, pooled.shape[2], pooled.shape[3])   # :237-240
+    enc = t["encoded"] = unet_down(pooled, P["encode.model.0.weight"])        # :242
+    scale = input_tex.shape[2] / enc.shape[2]
+    up = F.interpolate(enc, scale_factor=scale)                               # :244-247 nearest
+    x = torch.cat((up, cloth), 1)                                             # :258
+    num_downs = math.frexp(input_tex.shape[2])[1] - 1
+    return unet_generator_forward(P, x, num_downs, training=training)
+
+
+# ----------------------------------------------------------------------------
+# Losses
+# ----------------------------------------------------------------------------
+
+REAL_SMOOTH = (0.7, 1.1)      # modules/loss.py:21
+FAKE_SMOOTH = (0.0, 0.3)      # modules/loss.py:22 (never used for sampling: bug at :102)
+
+
+def smooth_label():
+    """GANLoss.get_target_tensor with smooth labels (modules/loss.py:79-108).  BOTH
+    the real and the fake branch sample from the REAL range (the fake branch reads
+    `self.real_label`, :102).  One torch.rand(1) draw from the global CPU RNG."""
+    low, high = torch.tensor(REAL_SMOOTH)
+    return torch.rand(1) * (high - low) + low           # rand_between, :65-77
+
+
+def gan_loss(pred, label, gan_mode="vanilla", target_is_real=True):
+    """GANLoss.__call__ (modules/loss.py:110-130)."""
+    if gan_mode in ("vanilla", "dragan-gp", "dragan-lp"):
+        return F.binary_cross_entropy_with_logits(pred, label.expand_as(pred))
+    if gan_mode == "lsgan":
+        return F.mse_loss(pred, label.expand_as(pred))
+    if "wgan" in gan_mode:
+        return -pred.mean() if target_is_real else pred.mean()
+    raise ValueError(f"{gan_mode} not recognized")
+
+
+def gram_matrix(t):
+    """modules/losses/perceptual.py:6-10."""
+    b, c, h, w = t.size()
+    t = t.view(b * c, h * w)
+    return torch.mm(t, t.t())
+
+
+VGG_SLICES = [(0, 4), (4, 9), (9, 16), (16, 23), (23, 30)]     # perceptual.py:28-34
+
+
+def vgg_slice_features(vgg, x):
+    """PerceptualLoss.get_features (modules/losses/perceptual.py:68-79): x <- 2x-1,
+    5 VGG16 slices, each output divided by (channel L2 norm + 1e-8)."""
+    x = 2.0 * x - 1.0
+    feats = []
+    # torchvision vgg16.features index -> op
+    ops, ci = [], 0
+    for v in VGG16_CFG:
+        if v == "M":
+            ops.append(("pool", None))
+        else:
+            ops.append(("conv", ci))
+            ops.append(("relu", None))
+            ci += 1
+    for lo, hi in VGG_SLICES:
+        for kind, i in ops[lo:hi]:
+            if kind == "conv":
+                x = F.conv2d(x, vgg[i][0], vgg[i][1], padding=1)
+            elif kind == "relu":
+                x = F.relu(x)
+            else:
+                x = F.max_pool2d(x, 2, 2)
+        feats.append(x / (torch.sqrt(torch.pow(x, 2).sum(1, keepdim=True)) + 1e-8))
+    return feats
+
+
+def perceptual_loss(vgg, output, target, use_style=True):
+    """PerceptualLoss.forward (modules/losses/perceptual.py:49-66).  Style term is
+    the Gram of the raw IMAGES added once per VGG slice (5x), :58-63."""
+    out_f = vgg_slice_features(vgg, output)
+    with torch.no_grad():
+        tgt_f = vgg_slice_features(vgg, target)
+    content = sum(F.mse_loss(o, t) for o, t in zip(out_f, tgt_f))
+    style = 0
+    if use_style:
+        for _ in out_f:
+            style = style + F.mse_loss(gram_matrix(output), gram_matrix(target))
+    return content, style
+
+
+# ----------------------------------------------------------------------------
+# AdamW (optimizers/__init__.py:37-60 -> torch.optim.AdamW, decoupled decay)
+# ----------------------------------------------------------------------------
+
+class AdamWState:
+    def __init__(self, params, lr, weight_decay, betas=(0.9, 0.999), eps=1e-8):
+        self.lr, self.wd, self.b1, self.b2, self.eps = lr, weight_decay, betas[0], betas[1], eps
+        self.step = 0
+        self.m = OrderedDict((k, torch.zeros_like(v)) for k, v in params.items())
+        self.v = OrderedDict((k, torch.zeros_like(v)) for k, v in params.items())
+
+    @torch.no_grad()
+    def apply(self, params, grads):
+        """One torch.optim.AdamW step (amsgrad=False): p*=1-lr*wd; m,v EMA;
+        p -= lr/bc1 * m / (sqrt(v)/sqrt(bc2) + eps)."""
+        self.step += 1
+        bc1 = 1.0 - self.b1 ** self.step
+        bc2 = 1.0 - self.b2 ** self.step
+        for k, p in params.items():
+            g = grads[k]
+            if g is None:
+                continue
+            p.mul_(1.0 - self.lr * self.wd)
+            self.m[k].mul_(self.b1).add_(g, alpha=1.0 - self.b1)
+            self.v[k].mul_(self.b2).addcmul_(g, g, value=1.0 - self.b2)
+            denom = (self.v[k].sqrt() / math.sqrt(bc2)).add_(self.eps)
+            p.addcdiv_(self.m[k], denom, value=-(self.lr / bc1))
+
+
+# ----------------------------------------------------------------------------
+# Training steps (models/base_gan.py:194-203)
+# ----------------------------------------------------------------------------
+
+DEFAULT_HYPER = dict(
+    lr=1e-4, d_lr=4e-4, weight_decay=0.0, d_weight_decay=0.01, b1=0.9, b2=0.999,
+    lambda_gan=1.0, lambda_ce=100.0, lambda_l1=10.0, lambda_content=20.0,
+    lambda_style=1e-8, gan_mode="vanilla",
+)
+
+
+def _leaf(P):
+    return OrderedDict((k, v.detach().clone().requires_grad_(True)) for k, v in P.items())
+
+
+class WarpStepOracle:
+    """WarpModel (models/warp_model.py) + BaseGAN.optimize_parameters restated
+    functionally.  Holds G/D params and both AdamW states."""
+
+    def __init__(self, G, D, hyper=None, training=False):
+        self.h = dict(DEFAULT_HYPER, **(hyper or {}))
+        self.G = OrderedDict((k, v.clone()) for k, v in G.items())
+        self.D = OrderedDict((k, v.clone()) for k, v in D.items())
+        self.optG = AdamWState(self.G, self.h["lr"], self.h["weight_decay"], (self.h["b1"], self.h["b2"]))
+        self.optD = AdamWState(self.D, self.h["d_lr"], self.h["d_weight_decay"], (self.h["b1"], self.h["b2"]))
+        self.training = training
+        self.losses = OrderedDict()
+        self.labels = []
+
+    def step(self, bodys, inputs, targets, labels=None):
+        """optimize_parameters (base_gan.py:194-203; warp_model.py:106-167).
+        `labels` = the three smooth-label scalars (fake_D, real_D, real_G); drawn
+        from the global CPU RNG in the reference's order when None."""
+        h = self.h
+        G, D = _leaf(self.G), _leaf(self.D)
+        fakes = warp_module_forward(G, bodys, inputs, training=self.training)         # :106-107
+        draw = (lambda i: smooth_label()) if labels is None else (lambda i: torch.tensor([labels[i]], dtype=torch.float32))
+        # ---- backward_D (warp_model.py:109-139)
+        cond_fake = torch.cat((bodys, fakes), 1)
+        pred_fake = patchgan_forward(D, cond_fake.detach())
+        l_fake = draw(0)
+        loss_D_fake = gan_loss(pred_fake, l_fake, h["gan_mode"], False)
+        pred_real = patchgan_forward(D, torch.cat((bodys, targets), 1))
+        l_real = draw(1)
+        loss_D_real = gan_loss(pred_real, l_real, h["gan_mode"], True)
+        loss_D = 0.5 * (loss_D_fake + loss_D_real)          # lambda_discriminator ignored (:123)
+        gD = torch.autograd.grad(loss_D, list(D.values()))
+        self.grads_D = OrderedDict(zip(D.keys(), gD))
+        self.optD.apply(self.D, self.grads_D)                                          # base_gan.py:199
+        # ---- backward_G (warp_model.py:141-167) with the UPDATED D
+        D2 = OrderedDict((k, v.detach()) for k, v in self.D.items())
+        loss_ce = F.cross_entropy(fakes, torch.argmax(targets, dim=1)) * h["lambda_ce"]
+        pred = patchgan_forward(D2, torch.cat((bodys, fakes), 1))
+        l_g = draw(2)
+        loss_G_gan = gan_loss(pred, l_g, h["gan_mode"], True) * h["lambda_gan"]
+        loss_G = loss_G_gan + loss_ce
+        gG = torch.autograd.grad(loss_G, list(G.values()))
+        self.grads_G = OrderedDict(zip(G.keys(), gG))
+        self.optG.apply(self.G, self.grads_G)                                          # base_gan.py:203
+        self.fakes = fakes.detach()
+        self.labels = [float(l_fake), float(l_real), float(l_g)]
+        self.losses = OrderedDict(D=float(loss_D.detach()), D_real=float(loss_D_real.detach()), D_fake=float(loss_D_fake.detach()),
+                                  G=float(loss_G.detach()), G_gan=float(loss_G_gan.detach()), G_ce=float(loss_ce.detach()))
+        return self.losses
+
+
+class TextureStepOracle:
+    """TextureModel (models/texture_model.py:121-180) restated functionally."""
+
+    def __init__(self, G, D, vgg=None, hyper=None, training=False):
+        self.h = dict(DEFAULT_HYPER, **(hyper or {}))
+        self.G = OrderedDict((k, v.clone()) for k, v in G.items())
+        self.D = OrderedDict((k, v.clone()) for k, v in D.items())
+        self.vgg = vgg if vgg is not None else vgg16_feature_params()
+        self.optG = AdamWState(self.G, self.h["lr"], self.h["weight_decay"], (self.h["b1"], self.h["b2"]))
+        self.optD = AdamWState(self.D, self.h["d_lr"], self.h["d_weight_decay"], (self.h["b1"], self.h["b2"]))
+        self.training = training
+
+    def step(self, textures, rois, cloths, targets, labels=None):
+        h = self.h
+        G, D = _leaf(self.G), _leaf(self.D)
+        fakes = texture_module_forward(G, textures, rois, cloths, training=self.training)   # :121-125
+        draw = (lambda i: smooth_label()) if labels is None else (lambda i: torch.tensor([labels[i]], dtype=torch.float32))
+        # ---- backward_D (:127-155)
+        pred_fake = patchgan_forward(D, torch.cat((cloths, fakes), 1).detach())
+        l_fake = draw(0)
+        loss_D_fake = gan_loss(pred_fake, l_fake, h["gan_mode"], False)
+        pred_real = patchgan_forward(D, torch.cat((cloths, targets), 1))
+        l_real = draw(1)
+        loss_D_real = gan_loss(pred_real, l_real, h["gan_mode"], True)
+        loss_D = 0.5 * (loss_D_fake + loss_D_real)
+        gD = torch.autograd.grad(loss_D, list(D.values()))
+        self.grads_D = OrderedDict(zip(D.keys(), gD))
+        self.optD.apply(self.D, self.grads_D)
+        # ---- backward_G (:157-180)
+        D2 = OrderedDict((k, v.detach()) for k, v in self.D.items())
+        pred = patchgan_forward(D2, torch.cat((cloths, fakes), 1))
+        l_g = draw(2)
+        loss_G_gan = gan_loss(pred, l_g, h["gan_mode"], True) * h["lambda_gan"]
+        loss_G_l1 = F.l1_loss(fakes, targets) * h["lambda_l1"]
+        content, style = perceptual_loss(self.vgg, fakes, targets, use_style=h["lambda_style"] != 0)
+        loss_G_content = content * h["lambda_content"]
+        loss_G_style = style * h["lambda_style"]
+        loss_G = loss_G_gan + loss_G_l1 + loss_G_content + loss_G_style
+        gG = torch.autograd.grad(loss_G, list(G.values()))
+        self.grads_G = OrderedDict(zip(G.keys(), gG))
+        self.optG.apply(self.G, self.grads_G)
+        self.fakes = fakes.detach()
+        self.labels = [float(l_fake), float(l_real), float(l_g)]
+        self.losses = OrderedDict(D=float(loss_D.detach()), D_real=float(loss_D_real.detach()), D_fake=float(loss_D_fake.detach()),
+                                  G=float(loss_G.detach()), G_gan=float(loss_G_gan.detach()), G_l1=float(loss_G_l1.detach()),
+                                  G_content=float(loss_G_content.detach()), G_style=float(loss_G_style.detach()))
+        return self.losses
+
+
+# ----------------------------------------------------------------------------
+# Integer work: label decode (util/decode_labels.py) and cloth one-hot format
+# ----------------------------------------------------------------------------
+
+LABEL_COLOURS = [(0, 0, 0), (128, 0, 0), (255, 0, 0), (0, 85, 0),            # sunglasses removed
+                 (255, 85, 0), (0, 0, 85), (0, 119, 221), (85, 85, 0), (0, 85, 85),
+                 (85, 51, 0), (52, 86, 128), (0, 128, 0), (0, 0, 255), (51, 170, 221),
+                 (0, 255, 255), (85, 255, 170), (170, 255, 85), (255, 255, 0), (255, 170, 0)]
+
+
+def decode_cloth_labels(t, num_classes=19):
+    """util/decode_labels.py:24-55: argmax over channels -> 19-colour palette, labels
+    >= n_classes stay black.  Returns uint8 (B,3,H,W)."""
+    arg = t.argmax(dim=1).cpu().numpy()                       # first maximal index
+    pal = np.zeros((max(int(arg.max()) + 1, num_classes), 3), dtype=np.uint8)
+    pal[:num_classes] = np.array(LABEL_COLOURS[:num_classes], dtype=np.uint8)
+    return torch.from_numpy(pal[arg]).permute(0, 3, 1, 2).contiguous()
+
+
+def labels_to_onehot(labels, n_labels=19):
+    """datasets/data_utils.py:330-343 (to_onehot_tensor): a scipy sparse label matrix
+    drops its zeros, so label 0 (background) becomes the ALL-ZERO vector; label l>0
+    sets channel l.  labels: int array (..., H, W) -> float32 (..., n_labels, H, W)."""
+    lab = torch.as_tensor(labels).long()
+    oh = F.one_hot(lab, n_labels).movedim(-1, -3).float()
+    oh[..., 0, :, :] = 0.0
+    return oh
+
+
+def onehot_to_labels(t):
+    """datasets/data_utils.py:311-327 (compress_and_save_cloth): argmax over dim 0/1."""
+    return t.argmax(dim=-3)
+
+
+# ----------------------------------------------------------------------------
+# Synthetic batches -- shared by tests, smoke() and bench.py
+# ----------------------------------------------------------------------------
+
+def synth_warp_batch(B, H, W, seed=1234, n_labels=19, tile=8):
+    g = torch.Generator().manual_seed(seed)
+    bodys = torch.randn((B, 3, H, W), generator=g)
+    lab = torch.randint(0, n_labels, (B, max(H // tile, 1), max(W // tile, 1)), generator=g)
+    lab = lab.repeat_interleave(tile, 1).repeat_interleave(tile, 2)[:, :H, :W]
+    targets = labels_to_onehot(lab, n_labels)
+    inputs = labels_to_onehot(torch.roll(lab.flip(2), shifts=(3, -2), dims=(1, 2)), n_labels)
+    return bodys, inputs, targets
+
+
+def synth_texture_batch(B, H, W, seed=1234, n_labels=19, num_roi=12, tile=8):
+    g = torch.Generator().manual_seed(seed)
+    tex = torch.randn((B, 3, H, W), generator=g).clamp_(-3, 3)
+    tgt = torch.randn((B, 3, H, W), generator=g).clamp_(-3, 3)
+    lab = torch.randint(0, n_labels, (B, max(H // tile, 1), max(W // tile, 1)), generator=g)
+    lab = lab.repeat_interleave(tile, 1).repeat_interleave(tile, 2)[:, :H, :W]
+    cloths = labels_to_onehot(lab, n_labels)
+    x1 = torch.randint(0, W - 1, (B, num_roi), generator=g)
+    y1 = torch.randint(0, H - 1, (B, num_roi), generator=g)
+    w = torch.randint(0, W // 2 + 1, (B, num_roi), generator=g)
+    hh = torch.randint(0, H // 2 + 1, (B, num_roi), generator=g)
+    x2 = (x1 + w).clamp_(max=W - 1)
+    y2 = (y1 + hh).clamp_(max=H - 1)
+    rois = torch.stack((x1, y1, x2, y2), dim=-1).float()
+    rois[:, 0] = torch.tensor([W - 1, 0, W - 1, 0], dtype=torch.float32)    # degenerate box per sample
+    return tex, rois, cloths, tgt
