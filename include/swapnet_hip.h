@@ -1,0 +1,141 @@
+/* swapnet_hip.h -- C ABI of libswapnet_hip.so, the MI355X (gfx950) back end of the SwapNet
+ * two-stage GAN training hot path.
+ *
+ * The reference (andrewjong/SwapNet) has no native boundary of its own: it is pure Python
+ * on torch.nn.  Each entry point below therefore cites the reference
+ * *Python* interface it stands in for; swapnet_amd/_C.py is the ctypes binding and
+ * INTEGRATION.md shows the stub a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - every function returns 0 on success, non-zero on failure; swn_last_error() returns
+ *     the message of the last failure on the calling thread (the Python shim re-raises it
+ *     as the exception type the reference would raise: ValueError / NotImplementedError /
+ *     RuntimeError).
+ *   - all tensor arguments are raw DEVICE pointers to fp32 (NCHW, contiguous -- the layout
+ *     of the reference's torch tensors) unless the name says host; the library borrows them
+ *     for the duration of the call and never frees caller memory.
+ *   - one context per process/GPU, driven by one host thread; all work is enqueued on the
+ *     context's HIP stream.
+ */
+#ifndef SWAPNET_HIP_H
+#define SWAPNET_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct swn_ctx swn_ctx;
+typedef struct swn_model swn_model;
+
+int swn_abi_version(void);
+const char* swn_last_error(void);
+/* 1 when this library executes on a HIP device (libswapnet_hip.so), 0 for the CI simulator */
+int swn_is_device_build(void);
+
+/* ---- context ------------------------------------------------------------------------
+ * replaces BaseModel.__init__'s device selection (models/base_model.py:36-40).
+ * `hip_stream` may be NULL (the library creates its own stream) or an existing hipStream_t
+ * (e.g. torch.cuda.current_stream().cuda_stream) so torch-side copies stay ordered. */
+int swn_ctx_create(int device, void* hip_stream, size_t workspace_bytes, swn_ctx** out);
+int swn_ctx_destroy(swn_ctx* ctx);
+int swn_ctx_sync(swn_ctx* ctx);
+int swn_ctx_bytes_allocated(swn_ctx* ctx, size_t* out);
+
+/* ---- models ---------------------------------------------------------------------------
+ * swn_warp_model_create    <-> models.create_model(opt) with --model warp
+ *                              (models/__init__.py:33-44, models/warp_model.py:42-76,
+ *                               models/base_gan.py:130-176): WarpModule generator and, when
+ *                               is_train, the 22-channel conditional PatchGAN + both AdamW states.
+ * swn_texture_model_create <-> --model texture (models/texture_model.py:54-111): TextureModule
+ *                              generator (RoIAlign -> UNetDown -> pix2pix U-Net), PatchGAN,
+ *                              VGG16 perceptual network. */
+int swn_warp_model_create(swn_ctx* ctx, int batch, int height, int width, int is_train, float dropout,
+                          swn_model** out);
+int swn_texture_model_create(swn_ctx* ctx, int batch, int height, int width, int is_train, int num_roi,
+                             swn_model** out);
+int swn_model_destroy(swn_model* m);
+
+/* hyper-parameters = the opt.* fields read by the step (models/base_gan.py:87-120,
+ * optimizers/__init__.py:25-59, models/warp_model.py:27-34, models/texture_model.py:31-50) */
+typedef struct swn_hyper {
+  float lr, d_lr, weight_decay, d_weight_decay, b1, b2;
+  float lambda_gan, lambda_ce, lambda_l1, lambda_content, lambda_style;
+  int gan_mode;      /* 0 vanilla, 1 lsgan, 2 wgan */
+  int warp_mode_ce;  /* 1 = --warp_mode ce (generator only) */
+} swn_hyper;
+int swn_model_set_hyper(swn_model* m, const swn_hyper* h);
+
+/* parameters: net 0 = generator, 1 = discriminator, 2 = VGG16 features (texture model).
+ * Names and shapes are the reference's state_dict() keys (SURVEY.md 8(b) "Checkpoint
+ * format").  which: 0 weight, 1 grad, 2 exp_avg, 3 exp_avg_sq (torch.optim.AdamW state). */
+int swn_model_param_count(swn_model* m, int net, int* out);
+int swn_model_param_info(swn_model* m, int net, int index, char* name, int name_len, int shape[4], int* ndim);
+int swn_model_param_set(swn_model* m, int net, int which, const char* name, const float* dev_src);
+int swn_model_param_get(swn_model* m, int net, int which, const char* name, float* dev_dst);
+int swn_model_optim_step_get(swn_model* m, int net, int* step);   /* AdamW `step` counter */
+int swn_model_optim_step_set(swn_model* m, int net, int step);
+
+/* BaseModel.set_input (models/warp_model.py:99-104, models/texture_model.py:113-119).
+ * warp slots: 0 bodys (B,3,H,W), 1 input_cloths (B,19,H,W), 2 target_cloths (B,19,H,W)
+ * texture slots: 0 input_textures (B,3,H,W), 1 rois (B,R,4 as N=B,C=R,H=4,W=1), 2 cloths
+ * (B,19,H,W), 3 target_textures (B,3,H,W) */
+int swn_model_set_input(swn_model* m, int slot, const float* dev_nchw, int n, int c, int h, int w);
+/* slot 0: self.fakes (B,19,H,W) warp / (B,3,H,W) texture */
+int swn_model_get_output(swn_model* m, int slot, float* dev_nchw);
+/* named intermediate activation (debug / per-level parity tests), copied out as NCHW */
+int swn_model_get_tap(swn_model* m, int net, const char* name, float* dev_nchw, int shape[4]);
+
+/* BaseModel.forward (models/warp_model.py:106-107, models/texture_model.py:121-125) */
+int swn_model_forward(swn_model* m, int training, uint64_t dropout_seed);
+/* WarpModel.backward_D / TextureModel.backward_D (warp_model.py:109-139, texture_model.py:
+ * 127-155); the two labels are the smooth-label scalars GANLoss draws (modules/loss.py:79-108) */
+int swn_model_backward_D(swn_model* m, float label_fake, float label_real);
+/* backward_G (warp_model.py:141-167, texture_model.py:157-180) */
+int swn_model_backward_G(swn_model* m, float label_real);
+/* optimizer_{G,D}.step() (models/base_gan.py:199,203): fused AdamW over the net's arena */
+int swn_model_optimizer_step(swn_model* m, int net);
+/* BaseGAN.optimize_parameters (models/base_gan.py:194-203; warp_model.py:169-183) in one call */
+int swn_model_step(swn_model* m, const float labels[3], int training, uint64_t dropout_seed);
+/* BaseModel.get_current_losses (models/base_model.py:139-147): host array of 9 floats
+ * D, D_real, D_fake, G, G_gan, G_ce, G_l1, G_content, G_style  (one small D2H + sync) */
+int swn_model_get_losses(swn_model* m, float* host_out, int n);
+
+/* data-parallel hook: flat gradient arena of a net (device pointer, float count) so the host
+ * can all-reduce it with RCCL (torch.distributed, backend "nccl") between backward and step */
+int swn_model_grad_arena(swn_model* m, int net, float** dev_ptr, size_t* count);
+int swn_model_weight_arena(swn_model* m, int net, float** dev_ptr, size_t* count);
+
+/* ---- operator-level entry points (parity tests, integer work, inference helpers) --------- */
+/* torchvision.ops.RoIAlign((128,128),1,1) as used at modules/swapnet_modules.py:166-168,234.
+ * tex (B,C,H,W) NCHW, rois (B,R,4) -> out (B,R*C,PH,PW) NCHW */
+int swn_op_roi_align(swn_ctx* ctx, const float* tex, int b, int c, int h, int w, const float* rois, int r,
+                     int ph, int pw, float* out);
+/* integer part only: idx (B*R,PH,PW,4) int32 = yl,yh,xl,xh ; valid (B*R,PH,PW) uint8 */
+int swn_op_roi_align_indices(swn_ctx* ctx, const float* rois, int k, int h, int w, int ph, int pw, int32_t* idx,
+                             uint8_t* valid);
+/* util.decode_labels.decode_cloth_labels (util/decode_labels.py:24-55): (B,C,H,W) f32 -> (B,3,H,W) u8 */
+int swn_op_decode_labels(swn_ctx* ctx, const float* x, int b, int c, int h, int w, uint8_t* rgb);
+/* datasets/data_utils.py:322 (argmax for compress_and_save_cloth) and :330-343 (to_onehot_tensor) */
+int swn_op_argmax_labels(swn_ctx* ctx, const float* x, int b, int c, int h, int w, int32_t* labels);
+int swn_op_labels_to_onehot(swn_ctx* ctx, const int32_t* labels, int b, int c, int h, int w, float* out);
+/* a single convolution through the MFMA implicit-GEMM kernel (or the naive checker):
+ * kind 0 k4s2p1, 1 k3s1 reflect, 2 k4s1p1, 3 k3s1 zero-pad, 4 upsample-pad-conv tail;
+ * transposed!=0 -> ConvTranspose2d k4s2p1 (weight (Ci,Co,4,4)).  x (N,Ci,H,W), y NCHW.
+ * what: 0 forward, 1 weight gradient (y = dY in, w = dW out), 2 input gradient (y = dY in, x = dX out) */
+int swn_op_conv(swn_ctx* ctx, int kind, int transposed, int what, int naive, float* x, int n, int ci, int h, int w,
+                float* wgt, int co, const float* bias, int act, float* y);
+/* InstanceNorm(+act) forward / backward on NCHW tensors (modules/__init__.py:66-69) */
+int swn_op_instance_norm_act(swn_ctx* ctx, const float* x, int n, int c, int h, int w, int act, float* y);
+int swn_op_instance_norm_act_bwd(swn_ctx* ctx, const float* x, const float* dy, int n, int c, int h, int w, int act,
+                                 float* dx);
+/* torch.optim.AdamW single step on flat arrays (optimizers/__init__.py:52-59) */
+int swn_op_adamw(swn_ctx* ctx, float* p, const float* g, float* m, float* v, size_t n, float lr, float b1, float b2,
+                 float eps, float wd, int step);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SWAPNET_HIP_H */

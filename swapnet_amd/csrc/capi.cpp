@@ -1,0 +1,369 @@
+// swapnet_amd -- extern "C" boundary (include/swapnet_hip.h).  Plain pointers and sizes only.
+#include <cstring>
+#include <memory>
+#include <string>
+
+#include "../../include/swapnet_hip.h"
+#include "engine.h"
+
+using namespace swn;
+
+struct swn_ctx {
+  std::unique_ptr<Ctx> c;
+  void* owned_stream = nullptr;
+};
+struct swn_model {
+  std::unique_ptr<Model> m;
+};
+
+static thread_local std::string g_err;
+
+template <typename F>
+static int guard(F f) {
+  try {
+    f();
+    return 0;
+  } catch (const Error& e) {
+    g_err = e.what();
+    return e.code ? e.code : 1;
+  } catch (const std::exception& e) {
+    g_err = e.what();
+    return 1;
+  } catch (...) {
+    g_err = "unknown error";
+    return 1;
+  }
+}
+#define REQUIRE(cond, msg) \
+  do { if (!(cond)) throw Error(1, msg); } while (0)
+
+extern "C" {
+
+int swn_abi_version(void) { return 1; }
+const char* swn_last_error(void) { return g_err.c_str(); }
+int swn_is_device_build(void) { return is_device_build(); }
+
+int swn_ctx_create(int device, void* hip_stream, size_t workspace_bytes, swn_ctx** out) {
+  return guard([&] {
+    REQUIRE(out, "swn_ctx_create: out is NULL");
+    auto h = std::make_unique<swn_ctx>();
+    void* st = hip_stream;
+    if (!st) { st = stream_create(device); h->owned_stream = st; }
+    if (workspace_bytes < (size_t)64 << 20) workspace_bytes = (size_t)64 << 20;
+    h->c = std::make_unique<Ctx>(st, workspace_bytes);
+    *out = h.release();
+  });
+}
+int swn_ctx_destroy(swn_ctx* ctx) {
+  return guard([&] {
+    if (!ctx) return;
+    ctx->c.reset();
+    if (ctx->owned_stream) stream_destroy(ctx->owned_stream);
+    delete ctx;
+  });
+}
+int swn_ctx_sync(swn_ctx* ctx) {
+  return guard([&] { REQUIRE(ctx, "ctx is NULL"); stream_sync(ctx->c->s); });
+}
+int swn_ctx_bytes_allocated(swn_ctx* ctx, size_t* out) {
+  return guard([&] { REQUIRE(ctx && out, "NULL argument"); *out = ctx->c->bytes_allocated; });
+}
+
+int swn_warp_model_create(swn_ctx* ctx, int batch, int height, int width, int is_train, float dropout,
+                          swn_model** out) {
+  return guard([&] {
+    REQUIRE(ctx && out, "NULL argument");
+    REQUIRE(batch > 0 && height > 0 && width > 0, "bad shape");
+    auto h = std::make_unique<swn_model>();
+    h->m.reset(create_warp_model(*ctx->c, batch, height, width, is_train != 0, dropout));
+    *out = h.release();
+  });
+}
+int swn_texture_model_create(swn_ctx* ctx, int batch, int height, int width, int is_train, int num_roi,
+                             swn_model** out) {
+  return guard([&] {
+    REQUIRE(ctx && out, "NULL argument");
+    auto h = std::make_unique<swn_model>();
+    h->m.reset(create_texture_model(*ctx->c, batch, height, width, is_train != 0, num_roi));
+    *out = h.release();
+  });
+}
+int swn_model_destroy(swn_model* m) {
+  return guard([&] { delete m; });
+}
+
+int swn_model_set_hyper(swn_model* m, const swn_hyper* h) {
+  return guard([&] {
+    REQUIRE(m && h, "NULL argument");
+    Hyper& y = m->m->hyper;
+    y.lr = h->lr; y.d_lr = h->d_lr; y.weight_decay = h->weight_decay; y.d_weight_decay = h->d_weight_decay;
+    y.b1 = h->b1; y.b2 = h->b2; y.lambda_gan = h->lambda_gan; y.lambda_ce = h->lambda_ce; y.lambda_l1 = h->lambda_l1;
+    y.lambda_content = h->lambda_content; y.lambda_style = h->lambda_style;
+    REQUIRE(h->gan_mode >= 0 && h->gan_mode <= 2, "gan mode not implemented");
+    y.gan_mode = h->gan_mode; y.warp_mode_ce_only = h->warp_mode_ce;
+  });
+}
+
+static ParamArena& arena_of(swn_model* m, int net) {
+  REQUIRE(m, "model is NULL");
+  ParamArena* a = m->m->arena_ptr(net);
+  REQUIRE(a, "this model has no such network");
+  return *a;
+}
+
+int swn_model_param_count(swn_model* m, int net, int* out) {
+  return guard([&] { REQUIRE(out, "NULL"); *out = (int)arena_of(m, net).params.size(); });
+}
+int swn_model_param_info(swn_model* m, int net, int index, char* name, int name_len, int shape[4], int* ndim) {
+  return guard([&] {
+    ParamArena& a = arena_of(m, net);
+    REQUIRE(index >= 0 && index < (int)a.params.size(), "param index out of range");
+    const ParamDesc& d = a.params[index];
+    if (name && name_len > 0) { std::strncpy(name, d.name.c_str(), name_len - 1); name[name_len - 1] = 0; }
+    if (d.is_bias) {
+      if (shape) { shape[0] = d.n_logical; shape[1] = shape[2] = shape[3] = 1; }
+      if (ndim) *ndim = 1;
+    } else {
+      if (shape) {
+        if (d.ws.kind == WK_CONV) { shape[0] = d.ws.Co; shape[1] = d.ws.Ci; }
+        else { shape[0] = d.ws.Ci; shape[1] = d.ws.Co; }
+        shape[2] = d.ws.KH; shape[3] = d.ws.KW;
+      }
+      if (ndim) *ndim = 4;
+    }
+  });
+}
+static const ParamDesc& find_param(ParamArena& a, const char* name) {
+  REQUIRE(name, "name is NULL");
+  auto it = a.index.find(name);
+  if (it == a.index.end()) throw Error(1, std::string("unknown parameter ") + name);
+  return a.params[it->second];
+}
+int swn_model_param_set(swn_model* m, int net, int which, const char* name, const float* src) {
+  return guard([&] {
+    ParamArena& a = arena_of(m, net);
+    REQUIRE(which >= 0 && which <= 3 && src, "bad argument");
+    const ParamDesc& d = find_param(a, name);
+    Stream& s = m->m->ctx->s;
+    if (d.is_bias) dev_copy(s, a.base(which) + d.off, src, d.n_logical * sizeof(float));
+    else pack_weight(s, d.ws, src, a.base(which) + d.off);
+    if (which == 0) a.version += 1;
+  });
+}
+int swn_model_param_get(swn_model* m, int net, int which, const char* name, float* dst) {
+  return guard([&] {
+    ParamArena& a = arena_of(m, net);
+    REQUIRE(which >= 0 && which <= 3 && dst, "bad argument");
+    const ParamDesc& d = find_param(a, name);
+    Stream& s = m->m->ctx->s;
+    if (d.is_bias) dev_copy(s, dst, a.base(which) + d.off, d.n_logical * sizeof(float));
+    else unpack_weight(s, d.ws, a.base(which) + d.off, dst);
+  });
+}
+int swn_model_optim_step_get(swn_model* m, int net, int* step) {
+  return guard([&] { REQUIRE(step, "NULL"); *step = arena_of(m, net).step; });
+}
+int swn_model_optim_step_set(swn_model* m, int net, int step) {
+  return guard([&] { arena_of(m, net).step = step; });
+}
+
+int swn_model_set_input(swn_model* m, int slot, const float* src, int n, int c, int h, int w) {
+  return guard([&] { REQUIRE(m && src, "NULL argument"); m->m->set_input(slot, src, n, c, h, w); });
+}
+int swn_model_get_output(swn_model* m, int slot, float* dst) {
+  return guard([&] { REQUIRE(m && dst, "NULL argument"); m->m->get_output(slot, dst); });
+}
+int swn_model_get_tap(swn_model* m, int net, const char* name, float* dst, int shape[4]) {
+  return guard([&] {
+    REQUIRE(m && name, "NULL argument");
+    Net* n = m->m->net_for_taps(net);
+    REQUIRE(n, "no such network");
+    auto it = n->taps.find(name);
+    if (it == n->taps.end()) throw Error(1, std::string("unknown tap ") + name);
+    const TView& v = it->second.v;
+    if (shape) { shape[0] = v.N; shape[1] = v.C; shape[2] = v.H; shape[3] = v.W; }
+    if (dst) nhwc_to_nchw(m->m->ctx->s, v, dst, v.C);
+  });
+}
+int swn_model_forward(swn_model* m, int training, uint64_t seed) {
+  return guard([&] { REQUIRE(m, "NULL"); m->m->forward(training != 0, seed); });
+}
+int swn_model_backward_D(swn_model* m, float lf, float lr) {
+  return guard([&] { REQUIRE(m && m->m->is_train, "model was not created for training"); m->m->backward_D(lf, lr); });
+}
+int swn_model_backward_G(swn_model* m, float lr) {
+  return guard([&] { REQUIRE(m && m->m->is_train, "model was not created for training"); m->m->backward_G(lr); });
+}
+int swn_model_optimizer_step(swn_model* m, int net) {
+  return guard([&] {
+    REQUIRE(m && m->m->is_train, "model was not created for training");
+    REQUIRE(net == 0 || net == 1, "net must be 0 (G) or 1 (D)");
+    m->m->optimizer_step(net);
+  });
+}
+int swn_model_step(swn_model* m, const float labels[3], int training, uint64_t seed) {
+  return guard([&] {
+    REQUIRE(m && labels && m->m->is_train, "model was not created for training");
+    m->m->step(labels, training != 0, seed);
+  });
+}
+int swn_model_get_losses(swn_model* m, float* host_out, int n) {
+  return guard([&] {
+    REQUIRE(m && host_out && n > 0 && n <= L_COUNT, "bad argument");
+    dev_download(m->m->ctx->s, host_out, m->m->losses, n * sizeof(float));
+  });
+}
+int swn_model_grad_arena(swn_model* m, int net, float** p, size_t* count) {
+  return guard([&] { ParamArena& a = arena_of(m, net); REQUIRE(p && count, "NULL"); *p = a.g; *count = a.n; });
+}
+int swn_model_weight_arena(swn_model* m, int net, float** p, size_t* count) {
+  return guard([&] { ParamArena& a = arena_of(m, net); REQUIRE(p && count, "NULL"); *p = a.w; *count = a.n; a.version += 1; });
+}
+
+// ---- operator level -----------------------------------------------------------------------
+int swn_op_roi_align(swn_ctx* ctx, const float* tex, int b, int c, int h, int w, const float* rois, int r, int ph,
+                     int pw, float* out) {
+  return guard([&] {
+    REQUIRE(ctx && tex && rois && out, "NULL argument");
+    Ctx tmp(ctx->c->s);
+    ParamArena A; Net net(tmp, A);
+    Var t = net.alloc_var(b, h, w, round_up(c, 4), false);
+    Var o = net.alloc_var(b, ph, pw, round_up(r * c, 4), false);
+    nchw_to_nhwc(tmp.s, tex, b, c, h, w, t.v);
+    roi_align_fwd(tmp.s, t.v, c, rois, r, o.v);
+    nhwc_to_nchw(tmp.s, o.v, out, r * c);
+    stream_sync(tmp.s);
+  });
+}
+int swn_op_roi_align_indices(swn_ctx* ctx, const float* rois, int k, int h, int w, int ph, int pw, int32_t* idx,
+                             uint8_t* valid) {
+  return guard([&] {
+    REQUIRE(ctx && rois && idx && valid, "NULL argument");
+    roi_align_indices(ctx->c->s, rois, k, h, w, ph, pw, idx, valid);
+    stream_sync(ctx->c->s);
+  });
+}
+int swn_op_decode_labels(swn_ctx* ctx, const float* x, int b, int c, int h, int w, uint8_t* rgb) {
+  return guard([&] {
+    REQUIRE(ctx && x && rgb, "NULL argument");
+    Ctx tmp(ctx->c->s);
+    ParamArena A; Net net(tmp, A);
+    Var t = net.alloc_var(b, h, w, round_up(c, 4), false);
+    nchw_to_nhwc(tmp.s, x, b, c, h, w, t.v);
+    decode_labels(tmp.s, t.v, c, rgb);
+    stream_sync(tmp.s);
+  });
+}
+int swn_op_argmax_labels(swn_ctx* ctx, const float* x, int b, int c, int h, int w, int32_t* labels) {
+  return guard([&] {
+    REQUIRE(ctx && x && labels, "NULL argument");
+    Ctx tmp(ctx->c->s);
+    ParamArena A; Net net(tmp, A);
+    Var t = net.alloc_var(b, h, w, round_up(c, 4), false);
+    nchw_to_nhwc(tmp.s, x, b, c, h, w, t.v);
+    argmax_labels(tmp.s, t.v, c, labels);
+    stream_sync(tmp.s);
+  });
+}
+int swn_op_labels_to_onehot(swn_ctx* ctx, const int32_t* labels, int b, int c, int h, int w, float* out) {
+  return guard([&] {
+    REQUIRE(ctx && labels && out, "NULL argument");
+    Ctx tmp(ctx->c->s);
+    ParamArena A; Net net(tmp, A);
+    Var t = net.alloc_var(b, h, w, round_up(c, 4), false);
+    labels_to_onehot(tmp.s, labels, t.v, c);
+    nhwc_to_nchw(tmp.s, t.v, out, c);
+    stream_sync(tmp.s);
+  });
+}
+
+int swn_op_conv(swn_ctx* ctx, int kind, int transposed, int what, int naive, float* x, int n, int ci, int h, int w,
+                float* wgt, int co, const float* bias, int act, float* y) {
+  return guard([&] {
+    REQUIRE(ctx && x && wgt && y, "NULL argument");
+    REQUIRE(kind >= 0 && kind <= 4 && what >= 0 && what <= 2, "bad kind/what");
+    REQUIRE(what == 0 || act == ACT_NONE, "backward entry points take the gradient of the pre-activation output");
+    Ctx tmp(ctx->c->s);
+    ParamArena A;
+    Net net(tmp, A);
+    const int Cip = round_up(ci, 4), Cop = round_up(co, 4);
+    int Ho, Wo;
+    if (transposed) { Ho = 2 * h; Wo = 2 * w; }
+    else if (kind == CK_K4S2) { Ho = h / 2; Wo = w / 2; }
+    else if (kind == CK_K4S1) { Ho = h - 1; Wo = w - 1; }
+    else if (kind == CK_TAIL_UP) { Ho = 2 * h; Wo = 2 * w; }
+    else { Ho = h; Wo = w; }
+    Var xv = net.alloc_var(n, h, w, Cip, true);
+    Var yv = net.alloc_var(n, Ho, Wo, Cop, true);
+    if (transposed) { REQUIRE(Cip == ci, "transposed conv needs Ci % 4 == 0"); net.convT("l", xv, yv, co, bias != nullptr); }
+    else net.conv("l", xv, yv, (ConvKind)kind, ci, co, bias != nullptr, act);
+    A.allocate(tmp);
+    net.finalize({});
+    Stream& s = tmp.s;
+    const ParamDesc& wd = A.params[A.index.at("l.weight")];
+    struct Restore { ~Restore() { conv_force_naive(0); } } restore;
+    conv_force_naive(naive);
+    if (what != 2) nchw_to_nhwc(s, x, n, ci, h, w, xv.v);
+    if (what != 1) pack_weight(s, wd.ws, wgt, A.w + wd.off);
+    if (bias) dev_copy(s, A.w + A.params[A.index.at("l.bias")].off, bias, co * sizeof(float));
+    if (what == 0) {
+      net.forward();
+      nhwc_to_nchw(s, yv.v, y, co);
+    } else {
+      nchw_to_nhwc(s, y, n, co, Ho, Wo, yv.g);
+      if (what == 1) {
+        net.backward(true, false);
+        unpack_weight(s, wd.ws, A.g + wd.off, wgt);
+      } else {
+        A.version += 1;
+        net.refresh_dgrad();
+        net.backward(false, true);
+        nhwc_to_nchw(s, xv.g, x, ci);
+      }
+    }
+    stream_sync(s);
+  });
+}
+
+int swn_op_instance_norm_act(swn_ctx* ctx, const float* x, int n, int c, int h, int w, int act, float* y) {
+  return guard([&] {
+    REQUIRE(ctx && x && y && c % 4 == 0, "bad argument (C must be a multiple of 4)");
+    Ctx tmp(ctx->c->s);
+    ParamArena A; Net net(tmp, A);
+    Var xv = net.alloc_var(n, h, w, c, true), yv = net.alloc_var(n, h, w, c, true);
+    net.norm_act(xv, yv, true, act, 0.f);
+    net.finalize({});
+    nchw_to_nhwc(tmp.s, x, n, c, h, w, xv.v);
+    net.forward();
+    nhwc_to_nchw(tmp.s, yv.v, y, c);
+    stream_sync(tmp.s);
+  });
+}
+int swn_op_instance_norm_act_bwd(swn_ctx* ctx, const float* x, const float* dy, int n, int c, int h, int w, int act,
+                                 float* dx) {
+  return guard([&] {
+    REQUIRE(ctx && x && dy && dx && c % 4 == 0, "bad argument (C must be a multiple of 4)");
+    Ctx tmp(ctx->c->s);
+    ParamArena A; Net net(tmp, A);
+    Var xv = net.alloc_var(n, h, w, c, true), yv = net.alloc_var(n, h, w, c, true);
+    net.norm_act(xv, yv, true, act, 0.f);
+    net.finalize({});
+    nchw_to_nhwc(tmp.s, x, n, c, h, w, xv.v);
+    net.forward();
+    nchw_to_nhwc(tmp.s, dy, n, c, h, w, yv.g);
+    net.backward(false, true);
+    nhwc_to_nchw(tmp.s, xv.g, dx, c);
+    stream_sync(tmp.s);
+  });
+}
+int swn_op_adamw(swn_ctx* ctx, float* p, const float* g, float* m, float* v, size_t n, float lr, float b1, float b2,
+                 float eps, float wd, int step) {
+  return guard([&] {
+    REQUIRE(ctx && p && g && m && v, "NULL argument");
+    AdamWArgs a{p, g, m, v, n, lr, b1, b2, eps, wd, step};
+    adamw_step(ctx->c->s, a);
+    stream_sync(ctx->c->s);
+  });
+}
+
+}  // extern "C"

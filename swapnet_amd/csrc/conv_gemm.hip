@@ -1,0 +1,585 @@
+// swapnet_amd -- fp32 implicit-GEMM convolution for gfx950 (CDNA4).
+//
+// One kernel family serves every dense contraction of the SwapNet G+D step
+// (reference: modules/layers.py:15,31,132,137; modules/discriminators.py:110-131;
+// modules/swapnet_modules.py:85-90; modules/pix2pix_modules.py:216-246 and the autograd
+// backward of each):
+//   * conv_fwd_kernel   C[m][n] = sum_k A[m][k] W[k][n]   m = output pixel, k = (kh,kw,ci)
+//       - Conv2d forward (k4s2p1, k3s1 reflect, k4s1p1, x2-upsampled tail conv)
+//       - ConvTranspose2d k4s2p1 forward as 4 sub-pixel phases of a 2x2 conv (OutMap scatter)
+//       - every dgrad (the transposed op is again a gather conv over dY with re-packed weights)
+//   * conv_wgrad_kernel dW[k][n] = sum_m A[m][k] dY[m][n]  (reduction over pixels)
+// A is never materialised: the im2col tile is gathered from the NHWC activation straight
+// into LDS (16-byte loads along the channel axis = full 128-B lines per 8 lanes).
+//
+// CDNA4 mapping: 256-thread workgroup = 4 wave64, one per SIMD; v_mfma_f32_32x32x2_f32
+// (exact fp32, 64 FLOP/clk/SIMD); BK = 32 per LDS stage, double-buffered LDS with the next
+// stage prefetched into VGPRs while the current one feeds the matrix pipe (one barrier per
+// stage).  A-tile rows are padded to 33 floats so the 32 lanes of a half-wave (one output
+// row each, same k) hit 32 distinct banks on ds_read_b32; the W / dY tile is read along its
+// contiguous axis.  Small-M x large-K layers (cloth_down5/6, cloth_up1) are split along K
+// (wgrad: along pixels) into deterministic slabs that a reduce kernel sums in fixed order.
+#include "hip_util.h"
+
+namespace swn {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct GemmP {
+  const float* x; int xH, xW, xC, xcs;
+  int KH, KW, stride, pad_t, pad_l, pad_mode, ups;
+  int Ho, Wo, M, K;
+  const float* w; int Npad;
+  const float* bias; int act; int accumulate;
+  float* y; int yH, yW, ycs; int ymul, yoff, xmul, xoff; int Cout; int yC;
+  int splits; int per_split; float* slab;
+  int tiles_n; int ntiles;
+};
+
+__device__ __forceinline__ int src_coord(int e, int ext, int pad_mode, int ups) {
+  if (pad_mode == PAD_REFLECT) {
+    if (e < 0) e = -e;
+    else if (e >= ext) e = 2 * ext - 2 - e;
+  } else if (e < 0 || e >= ext) {
+    return -1;
+  }
+  return e >> ups;
+}
+
+// XCD-aware tile order: the dispatcher round-robins consecutive workgroups over the 8
+// XCDs; give each XCD a contiguous run of tiles so neighbouring tiles (same A rows /
+// same weight panel) share one L2.  Bijective for any tile count.
+__device__ __forceinline__ int xcd_swizzle(int bid, int n) {
+  const int q = n >> 3, r = n & 7, xcd = bid & 7, i = bid >> 3;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + i;
+}
+
+template <int MT, int NT, int WGM, int WGN>
+struct Tile {
+  static constexpr int BM = 32 * MT * WGM;
+  static constexpr int BN = 32 * NT * WGN;
+  static constexpr int BK = 32;
+  static constexpr int AS = BK + 1;
+  static constexpr int A_FLOATS = ((BM * AS + 3) / 4) * 4;
+  static constexpr int B_FLOATS = BK * BN;
+  static constexpr int SMEM_FWD = (2 * A_FLOATS + 2 * B_FLOATS + BM) * 4;
+  // wgrad: A' tile [32 pixels][BM], B' tile [32 pixels][BN]
+  static constexpr int SMEM_WG = (2 * BK * BM + 2 * BK * BN) * 4;
+};
+
+// ---------------------------------------------------------------------------------------
+// forward-type kernel
+// ---------------------------------------------------------------------------------------
+template <int MT, int NT, int WGM, int WGN, bool FAST>
+__global__ __launch_bounds__(256) void conv_fwd_kernel(GemmP p) {
+  using T = Tile<MT, NT, WGM, WGN>;
+  constexpr int BM = T::BM, BN = T::BN, AS = T::AS;
+  constexpr int RA = BM / 32;
+  constexpr int RB = BN / 32;
+  constexpr int BROWS = 1024 / BN;     // rows of the B tile covered by one pass of 256 threads
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* As = smem;
+  float* Bs = smem + 2 * T::A_FLOATS;
+  int* rowoff = (int*)(Bs + 2 * T::B_FLOATS);
+
+  const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
+  const int wm = wid / WGN, wn = wid % WGN;
+  const int tile = xcd_swizzle(blockIdx.x, p.ntiles);
+  const int tile_n = tile % p.tiles_n, tile_m = tile / p.tiles_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int split = blockIdx.y;
+
+  const int q = t & 7, p0 = t >> 3;
+  int a_iy0[RA], a_ix0[RA], a_base[RA];
+  const int HoWo = p.Ho * p.Wo;
+#pragma unroll
+  for (int r = 0; r < RA; ++r) {
+    const int m = m0 + p0 + 32 * r;
+    if (m < p.M) {
+      const int n = m / HoWo, rem = m - n * HoWo;
+      const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+      a_iy0[r] = oy * p.stride - p.pad_t;
+      a_ix0[r] = ox * p.stride - p.pad_l;
+      a_base[r] = n * p.xH * p.xW * p.xcs;
+    } else {
+      a_iy0[r] = 0; a_ix0[r] = 0; a_base[r] = -1;
+    }
+  }
+  const int bcol = (t % (BN / 4)) * 4, brow0 = t / (BN / 4);
+  const int He = p.xH << p.ups, We = p.xW << p.ups;
+
+  float4 ra[RA], rb[RB];
+  auto load_tiles = [&](int kb) {
+    const int k0 = kb * 32;
+    int kh, kw, ci;
+    bool kvalid = true;
+    if (FAST) {
+      const int tap = k0 / p.xC;           // wave-uniform: a 32-wide k block never straddles a tap
+      ci = k0 - tap * p.xC + 4 * q;
+      kh = tap / p.KW; kw = tap - kh * p.KW;
+    } else {
+      const int k = k0 + 4 * q;
+      kvalid = k < p.K;
+      const int tap = k / p.xC;
+      ci = k - tap * p.xC;
+      kh = tap / p.KW; kw = tap - kh * p.KW;
+    }
+#pragma unroll
+    for (int r = 0; r < RA; ++r) {
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (a_base[r] >= 0 && kvalid) {
+        const int sy = src_coord(a_iy0[r] + kh, He, p.pad_mode, p.ups);
+        const int sx = src_coord(a_ix0[r] + kw, We, p.pad_mode, p.ups);
+        if (sy >= 0 && sx >= 0)
+          v = *reinterpret_cast<const float4*>(p.x + (size_t)a_base[r] + (size_t)(sy * p.xW + sx) * p.xcs + ci);
+      }
+      ra[r] = v;
+    }
+#pragma unroll
+    for (int r = 0; r < RB; ++r) {
+      const int krow = k0 + brow0 + r * BROWS;
+      const int n = n0 + bcol;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (krow < p.K && n < p.Npad) v = *reinterpret_cast<const float4*>(p.w + (size_t)krow * p.Npad + n);
+      rb[r] = v;
+    }
+  };
+  auto store_tiles = [&](int buf) {
+    float* A = As + buf * T::A_FLOATS;
+#pragma unroll
+    for (int r = 0; r < RA; ++r) {
+      float* d = A + (p0 + 32 * r) * AS + 4 * q;
+      d[0] = ra[r].x; d[1] = ra[r].y; d[2] = ra[r].z; d[3] = ra[r].w;
+    }
+    float* B = Bs + buf * T::B_FLOATS;
+#pragma unroll
+    for (int r = 0; r < RB; ++r)
+      *reinterpret_cast<float4*>(B + (brow0 + r * BROWS) * BN + bcol) = rb[r];
+  };
+
+  f32x16 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  auto compute = [&](int buf) {
+    const float* A = As + buf * T::A_FLOATS + (wm * MT * 32 + (lane & 31)) * AS + (lane >> 5);
+    const float* B = Bs + buf * T::B_FLOATS + (lane >> 5) * BN + wn * NT * 32 + (lane & 31);
+#pragma unroll
+    for (int kk = 0; kk < 32; kk += 2) {
+      float a[MT], b[NT];
+#pragma unroll
+      for (int i = 0; i < MT; ++i) a[i] = A[i * 32 * AS + kk];
+#pragma unroll
+      for (int j = 0; j < NT; ++j) b[j] = B[kk * BN + j * 32];
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+  };
+
+  const int nkb = (p.K + 31) / 32;
+  const int kb_begin = split * p.per_split;
+  const int kb_end = min(nkb, kb_begin + p.per_split);
+  if (kb_begin < kb_end) {
+    load_tiles(kb_begin);
+    store_tiles(0);
+    __syncthreads();
+    int cur = 0;
+    for (int kb = kb_begin; kb < kb_end; ++kb) {
+      const bool more = kb + 1 < kb_end;
+      if (more) load_tiles(kb + 1);
+      compute(cur);
+      if (more) store_tiles(cur ^ 1);
+      __syncthreads();
+      cur ^= 1;
+    }
+  }
+
+  // ---- epilogue
+  if (t < BM) {
+    const int m = m0 + t;
+    int off = -1;
+    if (m < p.M) {
+      const int n = m / HoWo, rem = m - n * HoWo;
+      const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+      off = ((n * p.yH + oy * p.ymul + p.yoff) * p.yW + ox * p.xmul + p.xoff) * p.ycs;
+    }
+    rowoff[t] = off;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int col = n0 + wn * NT * 32 + j * 32 + (lane & 31);
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = wm * MT * 32 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+        float v = acc[i][j][e];
+        if (p.splits > 1) {
+          if (m0 + row < p.M && col < p.Npad)
+            p.slab[((size_t)split * p.M + (m0 + row)) * p.Npad + col] = v;
+        } else {
+          const int off = rowoff[row];
+          if (off >= 0 && col < p.Cout) {
+            if (p.bias) v += p.bias[col];
+            v = act_apply(v, p.act);
+            float* dst = p.y + (size_t)off + col;
+            if (p.accumulate) v += *dst;
+            *dst = v;
+          }
+        }
+      }
+    }
+  }
+}
+
+// sums the K-split slabs in fixed order and applies the epilogue
+__global__ void conv_fwd_reduce_kernel(GemmP p) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t total = (size_t)p.M * p.Cout;
+  if (i >= total) return;
+  const int m = (int)(i / p.Cout), col = (int)(i - (size_t)m * p.Cout);
+  float v = 0.f;
+  for (int s = 0; s < p.splits; ++s) v += p.slab[((size_t)s * p.M + m) * p.Npad + col];
+  if (p.bias) v += p.bias[col];
+  v = act_apply(v, p.act);
+  const int HoWo = p.Ho * p.Wo;
+  const int n = m / HoWo, rem = m - n * HoWo;
+  const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+  float* dst = p.y + (size_t)((n * p.yH + oy * p.ymul + p.yoff) * p.yW + ox * p.xmul + p.xoff) * p.ycs + col;
+  if (p.accumulate) v += *dst;
+  *dst = v;
+}
+
+// ---------------------------------------------------------------------------------------
+// wgrad-type kernel: rows = k (BM of them), cols = co, reduction over pixels
+// ---------------------------------------------------------------------------------------
+template <int MT, int NT, int WGM, int WGN>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(GemmP p) {
+  using T = Tile<MT, NT, WGM, WGN>;
+  constexpr int BM = T::BM, BN = T::BN;
+  constexpr int RA = BM / 32;          // float4 per thread for the [32][BM] tile
+  constexpr int RB = BN / 32;
+  constexpr int AROWS = 1024 / BM, BROWS = 1024 / BN;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* As = smem;                    // [2][32*BM]
+  float* Bs = smem + 2 * 32 * BM;      // [2][32*BN]
+
+  const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
+  const int wm = wid / WGN, wn = wid % WGN;
+  const int tile = xcd_swizzle(blockIdx.x, p.ntiles);
+  const int tile_n = tile % p.tiles_n, tile_k = tile / p.tiles_n;
+  const int kt0 = tile_k * BM, n0 = tile_n * BN;
+  const int split = blockIdx.y;
+
+  // this thread's k (fixed for the whole kernel)
+  const int acol = (t % (BM / 4)) * 4, arow0 = t / (BM / 4);
+  const int k = kt0 + acol;
+  const bool kvalid = k < p.K;
+  const int tap = k / p.xC, ci = k - tap * p.xC;
+  const int kh = tap / p.KW, kw = tap - kh * p.KW;
+  const int bcol = (t % (BN / 4)) * 4, brow0 = t / (BN / 4);
+  const bool nvalid = (n0 + bcol) < p.yC;
+  const int He = p.xH << p.ups, We = p.xW << p.ups;
+  const int HoWo = p.Ho * p.Wo;
+
+  float4 ra[RA], rb[RB];
+  auto load_tiles = [&](int mb) {
+    const int mbase = mb * 32;
+#pragma unroll
+    for (int r = 0; r < RA; ++r) {
+      const int m = mbase + arow0 + r * AROWS;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (m < p.M && kvalid) {
+        const int n = m / HoWo, rem = m - n * HoWo;
+        const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+        const int sy = src_coord(oy * p.stride - p.pad_t + kh, He, p.pad_mode, p.ups);
+        const int sx = src_coord(ox * p.stride - p.pad_l + kw, We, p.pad_mode, p.ups);
+        if (sy >= 0 && sx >= 0)
+          v = *reinterpret_cast<const float4*>(p.x + (size_t)n * p.xH * p.xW * p.xcs +
+                                               (size_t)(sy * p.xW + sx) * p.xcs + ci);
+      }
+      ra[r] = v;
+    }
+#pragma unroll
+    for (int r = 0; r < RB; ++r) {
+      const int m = mbase + brow0 + r * BROWS;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (m < p.M && nvalid) {
+        const int n = m / HoWo, rem = m - n * HoWo;
+        const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+        v = *reinterpret_cast<const float4*>(
+            p.y + (size_t)((n * p.yH + oy * p.ymul + p.yoff) * p.yW + ox * p.xmul + p.xoff) * p.ycs + n0 + bcol);
+      }
+      rb[r] = v;
+    }
+  };
+  auto store_tiles = [&](int buf) {
+    float* A = As + buf * 32 * BM;
+#pragma unroll
+    for (int r = 0; r < RA; ++r) *reinterpret_cast<float4*>(A + (arow0 + r * AROWS) * BM + acol) = ra[r];
+    float* B = Bs + buf * 32 * BN;
+#pragma unroll
+    for (int r = 0; r < RB; ++r) *reinterpret_cast<float4*>(B + (brow0 + r * BROWS) * BN + bcol) = rb[r];
+  };
+
+  f32x16 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  auto compute = [&](int buf) {
+    const float* A = As + buf * 32 * BM + (lane >> 5) * BM + wm * MT * 32 + (lane & 31);
+    const float* B = Bs + buf * 32 * BN + (lane >> 5) * BN + wn * NT * 32 + (lane & 31);
+#pragma unroll
+    for (int kk = 0; kk < 32; kk += 2) {
+      float a[MT], b[NT];
+#pragma unroll
+      for (int i = 0; i < MT; ++i) a[i] = A[kk * BM + i * 32];
+#pragma unroll
+      for (int j = 0; j < NT; ++j) b[j] = B[kk * BN + j * 32];
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+  };
+
+  const int nmb = (p.M + 31) / 32;
+  const int mb_begin = split * p.per_split;
+  const int mb_end = min(nmb, mb_begin + p.per_split);
+  if (mb_begin < mb_end) {
+    load_tiles(mb_begin);
+    store_tiles(0);
+    __syncthreads();
+    int cur = 0;
+    for (int mb = mb_begin; mb < mb_end; ++mb) {
+      const bool more = mb + 1 < mb_end;
+      if (more) load_tiles(mb + 1);
+      compute(cur);
+      if (more) store_tiles(cur ^ 1);
+      __syncthreads();
+      cur ^= 1;
+    }
+  }
+  float* out = p.splits > 1 ? p.slab + (size_t)split * p.K * p.Npad : const_cast<float*>(p.w);
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int col = n0 + wn * NT * 32 + j * 32 + (lane & 31);
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = kt0 + wm * MT * 32 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+        if (row < p.K && col < p.Npad) out[(size_t)row * p.Npad + col] = acc[i][j][e];
+      }
+    }
+}
+
+__global__ void slab_sum_kernel(const float* slab, float* out, size_t n, int splits) {
+  const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (i >= n) return;
+  float4 a = *reinterpret_cast<const float4*>(slab + i);
+  for (int s = 1; s < splits; ++s) {
+    const float4 b = *reinterpret_cast<const float4*>(slab + (size_t)s * n + i);
+    a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+  }
+  *reinterpret_cast<float4*>(out + i) = a;
+}
+
+// ---------------------------------------------------------------------------------------
+// naive references (verification only)
+// ---------------------------------------------------------------------------------------
+__global__ void conv_fwd_naive_kernel(GemmP p) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)p.M * p.Cout) return;
+  const int m = (int)(i / p.Cout), co = (int)(i - (size_t)m * p.Cout);
+  const int HoWo = p.Ho * p.Wo;
+  const int n = m / HoWo, rem = m - n * HoWo;
+  const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+  const int He = p.xH << p.ups, We = p.xW << p.ups;
+  float acc = 0.f;
+  for (int kh = 0; kh < p.KH; ++kh)
+    for (int kw = 0; kw < p.KW; ++kw) {
+      const int sy = src_coord(oy * p.stride - p.pad_t + kh, He, p.pad_mode, p.ups);
+      const int sx = src_coord(ox * p.stride - p.pad_l + kw, We, p.pad_mode, p.ups);
+      if (sy < 0 || sx < 0) continue;
+      const float* xp = p.x + (size_t)n * p.xH * p.xW * p.xcs + (size_t)(sy * p.xW + sx) * p.xcs;
+      const float* wp = p.w + (size_t)((kh * p.KW + kw) * p.xC) * p.Npad + co;
+      for (int ci = 0; ci < p.xC; ++ci) acc = fmaf(xp[ci], wp[(size_t)ci * p.Npad], acc);
+    }
+  if (p.bias) acc += p.bias[co];
+  acc = act_apply(acc, p.act);
+  float* dst = p.y + (size_t)((n * p.yH + oy * p.ymul + p.yoff) * p.yW + ox * p.xmul + p.xoff) * p.ycs + co;
+  if (p.accumulate) acc += *dst;
+  *dst = acc;
+}
+
+__global__ void conv_wgrad_naive_kernel(GemmP p) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)p.K * p.Npad) return;
+  const int k = (int)(i / p.Npad), co = (int)(i - (size_t)k * p.Npad);
+  float* dw = const_cast<float*>(p.w);
+  if (co >= p.Cout) { dw[i] = 0.f; return; }
+  const int tap = k / p.xC, ci = k - tap * p.xC;
+  const int kh = tap / p.KW, kw = tap - kh * p.KW;
+  const int He = p.xH << p.ups, We = p.xW << p.ups;
+  const int HoWo = p.Ho * p.Wo;
+  double acc = 0.0;
+  for (int m = 0; m < p.M; ++m) {
+    const int n = m / HoWo, rem = m - n * HoWo;
+    const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+    const int sy = src_coord(oy * p.stride - p.pad_t + kh, He, p.pad_mode, p.ups);
+    const int sx = src_coord(ox * p.stride - p.pad_l + kw, We, p.pad_mode, p.ups);
+    if (sy < 0 || sx < 0) continue;
+    const float xv = p.x[(size_t)n * p.xH * p.xW * p.xcs + (size_t)(sy * p.xW + sx) * p.xcs + ci];
+    const float dv = p.y[(size_t)((n * p.yH + oy * p.ymul + p.yoff) * p.yW + ox * p.xmul + p.xoff) * p.ycs + co];
+    acc += (double)xv * dv;
+  }
+  dw[i] = (float)acc;
+}
+
+// ---------------------------------------------------------------------------------------
+// host launchers
+// ---------------------------------------------------------------------------------------
+static GemmP make_params(const TView& x, const Gather& g, const TView& y, const OutMap& om) {
+  if (x.C % 4 || x.cs % 4 || y.cs % 4) throw Error(1, "conv: channel counts/strides must be multiples of 4");
+  if (((uintptr_t)x.p & 15) || ((uintptr_t)y.p & 15)) throw Error(1, "conv: views must be 16-byte aligned");
+  GemmP p{};
+  p.x = x.p; p.xH = x.H; p.xW = x.W; p.xC = x.C; p.xcs = x.cs;
+  p.KH = g.KH; p.KW = g.KW; p.stride = g.stride; p.pad_t = g.pad_t; p.pad_l = g.pad_l;
+  p.pad_mode = g.pad_mode; p.ups = g.ups; p.Ho = g.Ho; p.Wo = g.Wo;
+  p.M = x.N * g.Ho * g.Wo;
+  p.K = g.KH * g.KW * x.C;
+  p.y = y.p; p.yH = y.H; p.yW = y.W; p.ycs = y.cs; p.yC = y.C;
+  p.ymul = om.ymul; p.yoff = om.yoff; p.xmul = om.xmul; p.xoff = om.xoff;
+  p.splits = 1; p.per_split = 1 << 30;
+  if ((g.Ho - 1) * om.ymul + om.yoff >= y.H || (g.Wo - 1) * om.xmul + om.xoff >= y.W || y.N != x.N)
+    throw Error(1, "conv: output map exceeds the output view");
+  return p;
+}
+
+template <typename K>
+static void set_smem(K kernel, int bytes) {
+  SWN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+}
+
+template <int MT, int NT, int WGM, int WGN>
+static void launch_fwd(Stream& s, GemmP& p, bool fast) {
+  using T = Tile<MT, NT, WGM, WGN>;
+  const int tiles_m = ceil_div(p.M, T::BM);
+  p.tiles_n = ceil_div(p.Npad, T::BN);
+  p.ntiles = tiles_m * p.tiles_n;
+  const int nkb = ceil_div(p.K, 32);
+  int splits = 1;
+  if (p.ntiles < 384 && nkb >= 16) {
+    splits = std::min(nkb / 8, ceil_div(768, p.ntiles));
+    const size_t per = (size_t)p.M * p.Npad * 4;
+    if (per * splits > s.ws_bytes) splits = (int)(s.ws_bytes / per);
+    if (splits < 2) splits = 1;
+  }
+  p.splits = splits;
+  p.per_split = ceil_div(nkb, splits);
+  p.splits = ceil_div(nkb, p.per_split);
+  p.slab = reinterpret_cast<float*>(s.ws);
+  dim3 grid(p.ntiles, p.splits);
+  if (fast) {
+    static bool once = (set_smem(conv_fwd_kernel<MT, NT, WGM, WGN, true>, T::SMEM_FWD), true);
+    (void)once;
+    hipLaunchKernelGGL((conv_fwd_kernel<MT, NT, WGM, WGN, true>), grid, dim3(256), T::SMEM_FWD, hs(s), p);
+  } else {
+    static bool once = (set_smem(conv_fwd_kernel<MT, NT, WGM, WGN, false>, T::SMEM_FWD), true);
+    (void)once;
+    hipLaunchKernelGGL((conv_fwd_kernel<MT, NT, WGM, WGN, false>), grid, dim3(256), T::SMEM_FWD, hs(s), p);
+  }
+  check_launch("conv_fwd");
+  if (p.splits > 1) {
+    const size_t total = (size_t)p.M * p.Cout;
+    hipLaunchKernelGGL(conv_fwd_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, hs(s), p);
+    check_launch("conv_fwd_reduce");
+  }
+}
+
+static int g_force_naive = 0;
+void conv_force_naive(int on) { g_force_naive = on; }
+
+void conv_fwd(Stream& s, const ConvFwdArgs& a) {
+  if (g_force_naive) { conv_fwd_naive(s, a); return; }
+  GemmP p = make_params(a.x, a.g, a.y, a.om);
+  p.w = a.w; p.Npad = a.Npad; p.bias = a.bias; p.act = a.act; p.accumulate = a.accumulate; p.Cout = a.Cout;
+  if (a.Npad % 4 || a.Cout > a.Npad) throw Error(1, "conv_fwd: bad Npad/Cout");
+  if (a.accumulate && a.act != ACT_NONE) throw Error(1, "conv_fwd: accumulate with activation");
+  const bool fast = (a.x.C % 32) == 0;
+  if (a.Npad > 64) launch_fwd<2, 2, 2, 2>(s, p, fast);
+  else if (a.Npad > 32) launch_fwd<2, 1, 2, 2>(s, p, fast);
+  else launch_fwd<1, 1, 4, 1>(s, p, fast);
+}
+
+template <int MT, int NT, int WGM, int WGN>
+static void launch_wgrad(Stream& s, GemmP& p) {
+  using T = Tile<MT, NT, WGM, WGN>;
+  const int tiles_k = ceil_div(p.K, T::BM);
+  p.tiles_n = ceil_div(p.Npad, T::BN);
+  p.ntiles = tiles_k * p.tiles_n;
+  const int nmb = ceil_div(p.M, 32);
+  int splits = 1;
+  if (p.ntiles < 512 && nmb >= 16) {
+    splits = std::min(nmb / 8, ceil_div(1024, p.ntiles));
+    const size_t per = (size_t)p.K * p.Npad * 4;
+    if (per * splits > s.ws_bytes) splits = (int)(s.ws_bytes / per);
+    if (splits < 2) splits = 1;
+  }
+  p.per_split = ceil_div(nmb, splits);
+  p.splits = ceil_div(nmb, p.per_split);
+  p.slab = reinterpret_cast<float*>(s.ws);
+  static bool once = (set_smem(conv_wgrad_kernel<MT, NT, WGM, WGN>, T::SMEM_WG), true);
+  (void)once;
+  hipLaunchKernelGGL((conv_wgrad_kernel<MT, NT, WGM, WGN>), dim3(p.ntiles, p.splits), dim3(256), T::SMEM_WG, hs(s), p);
+  check_launch("conv_wgrad");
+  if (p.splits > 1) {
+    const size_t n = (size_t)p.K * p.Npad;
+    hipLaunchKernelGGL(slab_sum_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, hs(s), p.slab,
+                       const_cast<float*>(p.w), n, p.splits);
+    check_launch("slab_sum");
+  }
+}
+
+void conv_wgrad(Stream& s, const ConvWgradArgs& a) {
+  if (g_force_naive) { conv_wgrad_naive(s, a); return; }
+  GemmP p = make_params(a.x, a.g, a.dy, a.om);
+  p.w = a.dw; p.Npad = a.Npad; p.Cout = a.Cout;
+  if (a.Npad % 4 || a.Cout > a.Npad || a.dy.C % 4) throw Error(1, "conv_wgrad: bad Npad/Cout");
+  if (a.Npad > 64) launch_wgrad<2, 2, 2, 2>(s, p);
+  else if (a.Npad > 32) launch_wgrad<2, 1, 2, 2>(s, p);
+  else launch_wgrad<1, 1, 4, 1>(s, p);
+}
+
+void conv_fwd_naive(Stream& s, const ConvFwdArgs& a) {
+  GemmP p = make_params(a.x, a.g, a.y, a.om);
+  p.w = a.w; p.Npad = a.Npad; p.bias = a.bias; p.act = a.act; p.accumulate = a.accumulate; p.Cout = a.Cout;
+  const size_t total = (size_t)p.M * p.Cout;
+  hipLaunchKernelGGL(conv_fwd_naive_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, hs(s), p);
+  check_launch("conv_fwd_naive");
+}
+
+void conv_wgrad_naive(Stream& s, const ConvWgradArgs& a) {
+  GemmP p = make_params(a.x, a.g, a.dy, a.om);
+  p.w = a.dw; p.Npad = a.Npad; p.Cout = a.Cout;
+  const size_t total = (size_t)p.K * p.Npad;
+  hipLaunchKernelGGL(conv_wgrad_naive_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, hs(s), p);
+  check_launch("conv_wgrad_naive");
+}
+
+}  // namespace swn

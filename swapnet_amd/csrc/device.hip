@@ -1,0 +1,44 @@
+// swapnet_amd -- device memory / stream primitives of ops.h (HIP implementation).
+#include "hip_util.h"
+
+namespace swn {
+
+void* dev_alloc(size_t bytes) {
+  void* p = nullptr;
+  if (bytes == 0) bytes = 16;
+  SWN_HIP_CHECK(hipMalloc(&p, bytes));
+  SWN_HIP_CHECK(hipMemset(p, 0, bytes));
+  return p;
+}
+void dev_free(void* p) {
+  if (p) (void)hipFree(p);
+}
+void dev_memset(Stream& s, void* p, int v, size_t bytes) { SWN_HIP_CHECK(hipMemsetAsync(p, v, bytes, hs(s))); }
+void dev_copy(Stream& s, void* dst, const void* src, size_t bytes) {
+  SWN_HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, hs(s)));
+}
+void dev_upload(Stream& s, void* dst, const void* src, size_t bytes) {
+  SWN_HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, hs(s)));
+  SWN_HIP_CHECK(hipStreamSynchronize(hs(s)));
+}
+void dev_download(Stream& s, void* dst, const void* src, size_t bytes) {
+  SWN_HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, hs(s)));
+  SWN_HIP_CHECK(hipStreamSynchronize(hs(s)));
+}
+void stream_sync(Stream& s) { SWN_HIP_CHECK(hipStreamSynchronize(hs(s))); }
+void* stream_create(int device) {
+  int count = 0;
+  SWN_HIP_CHECK(hipGetDeviceCount(&count));
+  if (count <= 0) throw Error(3, "swapnet_hip: no HIP device visible (this library has no CPU path)");
+  if (device < 0 || device >= count) throw Error(1, "swapnet_hip: bad device index");
+  SWN_HIP_CHECK(hipSetDevice(device));
+  hipStream_t st;
+  SWN_HIP_CHECK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+  return (void*)st;
+}
+void stream_destroy(void* h) {
+  if (h) (void)hipStreamDestroy((hipStream_t)h);
+}
+int is_device_build() { return 1; }
+
+}  // namespace swn

@@ -1,0 +1,458 @@
+// swapnet_amd -- engine core: arenas, op tape, accumulate planner.
+#include "engine.h"
+
+#include <algorithm>
+#include <cstring>
+
+namespace swn {
+
+// ---------------------------------------------------------------------------------------
+Ctx::Ctx(void* stream, size_t ws_bytes) {
+  s.handle = stream;
+  s.ws_bytes = ws_bytes;
+  s.ws = static_cast<char*>(dev_alloc(ws_bytes));
+}
+Ctx::Ctx(const Stream& shared) : s(shared), owns_ws(false) {}
+Ctx::~Ctx() {
+  for (void* p : allocs) dev_free(p);
+  if (owns_ws) dev_free(s.ws);
+}
+void* Ctx::alloc(size_t bytes) {
+  void* p = dev_alloc(bytes);
+  allocs.push_back(p);
+  bytes_allocated += bytes;
+  return p;
+}
+
+Var Var::slice(int c0, int c) const {
+  Var r = *this;
+  r.v = v.slice(c0, c);
+  if (has_grad) r.g = g.slice(c0, c);
+  return r;
+}
+Var Var::batch(int n0, int n) const {
+  Var r = *this;
+  const size_t off = (size_t)n0 * v.H * v.W * v.cs;
+  r.v.p = v.p + off; r.v.N = n;
+  if (has_grad) { r.g.p = g.p + off; r.g.N = n; }
+  return r;
+}
+
+// ---------------------------------------------------------------------------------------
+int ParamArena::add_weight(const std::string& name, int kind, int Co, int Ci, int KH, int KW, int Cip,
+                           const std::vector<int32_t>* cimap) {
+  if (frozen) {
+    auto it = index.find(name);
+    if (it == index.end()) throw Error(1, "shared arena has no parameter " + name);
+    const WShape& e = params[it->second].ws;
+    if (e.kind != kind || e.Co != Co || e.Ci != Ci || e.KH != KH || e.KW != KW || e.Cip != Cip)
+      throw Error(1, "shared arena: shape mismatch for " + name);
+    return it->second;
+  }
+  ParamDesc d;
+  d.name = name;
+  d.ws.kind = kind; d.ws.Co = Co; d.ws.Ci = Ci; d.ws.KH = KH; d.ws.KW = KW; d.ws.Cip = Cip;
+  d.ws.Npad = round_up(Co, 4);
+  if (cimap) d.cimap = *cimap;
+  d.elems = packed_elems(d.ws);
+  d.off = n;
+  n += (d.elems + 3) / 4 * 4;
+  index[name] = (int)params.size();
+  params.push_back(d);
+  return (int)params.size() - 1;
+}
+int ParamArena::add_bias(const std::string& name, int nb) {
+  if (frozen) {
+    auto it = index.find(name);
+    if (it == index.end() || params[it->second].n_logical != nb) throw Error(1, "shared arena: bad bias " + name);
+    return it->second;
+  }
+  ParamDesc d;
+  d.name = name; d.is_bias = true; d.n_logical = nb;
+  d.elems = round_up(nb, 4);
+  d.off = n;
+  n += d.elems;
+  index[name] = (int)params.size();
+  params.push_back(d);
+  return (int)params.size() - 1;
+}
+void ParamArena::allocate(Ctx& c) {
+  const size_t bytes = std::max<size_t>(n, 4) * sizeof(float);
+  w = static_cast<float*>(c.alloc(bytes));
+  g = static_cast<float*>(c.alloc(bytes));
+  m = static_cast<float*>(c.alloc(bytes));
+  v = static_cast<float*>(c.alloc(bytes));
+  for (auto& d : params) {
+    if (!d.cimap.empty()) {
+      int32_t* dev = static_cast<int32_t*>(c.alloc(d.cimap.size() * sizeof(int32_t)));
+      dev_upload(c.s, dev, d.cimap.data(), d.cimap.size() * sizeof(int32_t));
+      d.ws.cimap = dev;
+    }
+  }
+  frozen = true;
+}
+
+// ---------------------------------------------------------------------------------------
+Var Net::alloc_var(int N, int H, int W, int C, bool need_grad) {
+  if (C % 4) throw Error(1, "alloc_var: C must be a multiple of 4");
+  Var r;
+  const size_t bytes = (size_t)N * H * W * C * sizeof(float);
+  r.v.p = static_cast<float*>(ctx.alloc(bytes));
+  r.v.N = N; r.v.H = H; r.v.W = W; r.v.C = C; r.v.cs = C;
+  r.has_grad = need_grad;
+  if (need_grad) {
+    r.g = r.v;
+    r.g.p = static_cast<float*>(ctx.alloc(bytes));
+    r.gbase = r.g.p;
+  }
+  return r;
+}
+
+size_t Net::reserve_dg(Op* op, size_t elems) {
+  const size_t off = dg_n;
+  dg_n += (elems + 3) / 4 * 4;
+  dg_layout.push_back({op, off});
+  return off;
+}
+
+namespace {
+struct ConvGeom {
+  Gather fwd;       // forward gather (Ho,Wo filled)
+  int Ho, Wo;
+};
+ConvGeom conv_geom(ConvKind kind, int H, int W) {
+  ConvGeom c;
+  Gather& g = c.fwd;
+  switch (kind) {
+    case CK_K4S2: g.KH = g.KW = 4; g.stride = 2; g.pad_t = g.pad_l = 1; c.Ho = H / 2; c.Wo = W / 2; break;
+    case CK_K3S1_REFLECT: g.KH = g.KW = 3; g.stride = 1; g.pad_t = g.pad_l = 1; g.pad_mode = PAD_REFLECT; c.Ho = H; c.Wo = W; break;
+    case CK_K3S1_ZERO: g.KH = g.KW = 3; g.stride = 1; g.pad_t = g.pad_l = 1; c.Ho = H; c.Wo = W; break;
+    case CK_K4S1: g.KH = g.KW = 4; g.stride = 1; g.pad_t = g.pad_l = 1; c.Ho = H - 1; c.Wo = W - 1; break;
+    case CK_TAIL_UP:   // Upsample(x2) + ZeroPad2d((1,0,1,0)) + Conv(k4,p1): pad 2 top/left in upsampled coords
+      g.KH = g.KW = 4; g.stride = 1; g.pad_t = g.pad_l = 2; g.ups = 1; c.Ho = H * 2; c.Wo = W * 2; break;
+  }
+  g.Ho = c.Ho; g.Wo = c.Wo;
+  return c;
+}
+}  // namespace
+
+// ---- Conv2d ---------------------------------------------------------------------------
+// y.v receives act(conv(x)+bias).  In backward y.g is the gradient w.r.t. that output.
+void Net::conv(const std::string& name, const Var& x, const Var& y, ConvKind kind, int Ci, int Co, bool bias,
+               int actf, const std::vector<int32_t>* cimap, bool x_is_input) {
+  const int KH = (kind == CK_K3S1_REFLECT || kind == CK_K3S1_ZERO) ? 3 : 4;
+  const ConvGeom geo = conv_geom(kind, x.v.H, x.v.W);
+  if (y.v.H != geo.Ho || y.v.W != geo.Wo) throw Error(1, "conv " + name + ": output view has the wrong size");
+  const int Cip = x.v.C;
+  if (Ci > Cip) throw Error(1, "conv " + name + ": Ci exceeds the input view's channels");
+  const int wi = arena.add_weight(name + ".weight", WK_CONV, Co, Ci, KH, KH, Cip, cimap);
+  const int bi = bias ? arena.add_bias(name + ".bias", Co) : -1;
+  const int Cop = round_up(Co, 4);
+  if (y.v.C != Cop) throw Error(1, "conv " + name + ": output view must have round_up(Co,4) channels");
+
+  auto op = std::make_unique<Op>();
+  Op* self = op.get();
+  op->label = name;
+  op->reads_net_input = x_is_input;
+  ParamArena* A = &arena;
+  const Gather gf = geo.fwd;
+  const TView xv = x.v, yv = y.v;
+  op->fwd = [=](Net& n) {
+    const ParamDesc& wd = A->params[wi];
+    ConvFwdArgs a;
+    a.x = xv; a.g = gf; a.w = A->w + wd.off; a.Npad = wd.ws.Npad;
+    a.bias = bi >= 0 ? A->w + A->params[bi].off : nullptr;
+    a.act = actf; a.y = yv; a.Cout = Co;
+    conv_fwd(n.ctx.s, a);
+  };
+
+  // ---- backward plan
+  Var scratch;       // dR when an activation is fused into the epilogue
+  if (y.has_grad && actf != ACT_NONE) scratch = alloc_var(yv.N, yv.H, yv.W, Cop, false);
+  Var dxpad;
+  int dg_mode = 0;
+  Gather gd;         // dgrad gather over dY
+  OutMap dmap;
+  int dHo = x.v.H, dWo = x.v.W;
+  switch (kind) {
+    case CK_K4S2: dg_mode = 0; break;
+    case CK_K3S1_REFLECT:
+      dg_mode = 1; gd.KH = gd.KW = 3; gd.stride = 1; gd.pad_t = gd.pad_l = 2; dHo = x.v.H + 2; dWo = x.v.W + 2; break;
+    case CK_K3S1_ZERO: dg_mode = 1; gd.KH = gd.KW = 3; gd.stride = 1; gd.pad_t = gd.pad_l = 1; break;
+    case CK_K4S1: dg_mode = 1; gd.KH = gd.KW = 4; gd.stride = 1; gd.pad_t = gd.pad_l = 2; break;
+    case CK_TAIL_UP: dg_mode = 3; gd.KH = gd.KW = 5; gd.stride = 2; gd.pad_t = gd.pad_l = 1; break;
+  }
+  gd.Ho = dHo; gd.Wo = dWo;
+  const bool want_dx = x.has_grad && y.has_grad;
+  size_t dg_off = 0;
+  const int Ndg = Cip;   // dgrad output channels = input buffer channels
+  if (want_dx) {
+    dg_off = reserve_dg(self, dgrad_elems(arena.params[wi].ws, dg_mode, Cop, Ndg));
+    if (kind == CK_K3S1_REFLECT) dxpad = alloc_var(x.v.N, dHo, dWo, Cip, false);
+    op->grad_targets.push_back(x);
+    op->repack = [=](Net& n) {
+      const ParamDesc& wd = A->params[wi];
+      repack_dgrad(n.ctx.s, wd.ws, dg_mode, Cop, Ndg, A->w + wd.off, n.dg + dg_off);
+    };
+  }
+  const TView ygv = y.g, xgv = x.g, scr = scratch.v, dxp = dxpad.v;
+  const bool has_ygrad = y.has_grad;
+  op->bwd = [=](Net& n, Op& me, bool wgrad, bool igrad) {
+    if (!has_ygrad) return;
+    TView dY = ygv;
+    if (actf != ACT_NONE) { act_bwd(n.ctx.s, ygv, yv, scr, actf, 0); dY = scr; }
+    const ParamDesc& wd = A->params[wi];
+    if (wgrad) {
+      ConvWgradArgs wa;
+      wa.x = xv; wa.g = gf; wa.dy = dY; wa.dw = A->g + wd.off; wa.Npad = wd.ws.Npad; wa.Cout = Co;
+      conv_wgrad(n.ctx.s, wa);
+      if (bi >= 0) bias_grad(n.ctx.s, dY, A->g + A->params[bi].off);
+    }
+    if (!want_dx || (me.reads_net_input && !igrad)) return;
+    const int accf = me.acc.empty() ? 0 : me.acc[0];
+    if (kind == CK_K4S2) {
+      for (int ph = 0; ph < 4; ++ph) {
+        const int a = ph >> 1, b = ph & 1;
+        ConvFwdArgs d;
+        d.x = dY; d.g.KH = d.g.KW = 2; d.g.stride = 1; d.g.pad_t = 1 - a; d.g.pad_l = 1 - b;
+        d.g.Ho = dY.H; d.g.Wo = dY.W;
+        d.w = n.dg + dg_off + (size_t)ph * 4 * Cop * Ndg; d.Npad = Ndg;
+        d.y = xgv; d.om.ymul = 2; d.om.yoff = a; d.om.xmul = 2; d.om.xoff = b; d.Cout = Ndg; d.accumulate = accf;
+        conv_fwd(n.ctx.s, d);
+      }
+    } else {
+      ConvFwdArgs d;
+      d.x = dY; d.g = gd; d.w = n.dg + dg_off; d.Npad = Ndg; d.Cout = Ndg;
+      if (kind == CK_K3S1_REFLECT) {
+        d.y = dxp; d.accumulate = 0;
+        conv_fwd(n.ctx.s, d);
+        reflect_fold(n.ctx.s, dxp, xgv, accf);
+      } else {
+        d.y = xgv; d.accumulate = accf;
+        conv_fwd(n.ctx.s, d);
+      }
+    }
+  };
+  ops.push_back(std::move(op));
+}
+
+// ---- ConvTranspose2d k4 s2 p1 (modules/layers.py:31, pix2pix_modules.py:226-246) ------
+void Net::convT(const std::string& name, const Var& x, const Var& y, int Co, bool bias) {
+  if (y.v.H != x.v.H * 2 || y.v.W != x.v.W * 2) throw Error(1, "convT " + name + ": output view has the wrong size");
+  const int Cip = x.v.C, Cop = round_up(Co, 4);
+  if (y.v.C != Cop) throw Error(1, "convT " + name + ": output view must have round_up(Co,4) channels");
+  const int wi = arena.add_weight(name + ".weight", WK_CONVT, Co, Cip, 4, 4, Cip, nullptr);
+  const int bi = bias ? arena.add_bias(name + ".bias", Co) : -1;
+  auto op = std::make_unique<Op>();
+  Op* self = op.get();
+  op->label = name;
+  ParamArena* A = &arena;
+  const TView xv = x.v, yv = y.v, ygv = y.g, xgv = x.g;
+  const size_t phase_elems = (size_t)4 * Cip * round_up(Co, 4);
+  op->fwd = [=](Net& n) {
+    const ParamDesc& wd = A->params[wi];
+    for (int ph = 0; ph < 4; ++ph) {
+      const int a = ph >> 1, b = ph & 1;
+      ConvFwdArgs f;
+      f.x = xv; f.g.KH = f.g.KW = 2; f.g.stride = 1; f.g.pad_t = 1 - a; f.g.pad_l = 1 - b; f.g.Ho = xv.H; f.g.Wo = xv.W;
+      f.w = A->w + wd.off + ph * phase_elems; f.Npad = wd.ws.Npad;
+      f.bias = bi >= 0 ? A->w + A->params[bi].off : nullptr;
+      f.y = yv; f.om.ymul = 2; f.om.yoff = a; f.om.xmul = 2; f.om.xoff = b; f.Cout = Co;
+      conv_fwd(n.ctx.s, f);
+    }
+  };
+  const bool want_dx = x.has_grad && y.has_grad;
+  size_t dg_off = 0;
+  if (want_dx) {
+    dg_off = reserve_dg(self, dgrad_elems(arena.params[wi].ws, 2, Cop, Cip));
+    op->grad_targets.push_back(x);
+    op->repack = [=](Net& n) {
+      const ParamDesc& wd = A->params[wi];
+      repack_dgrad(n.ctx.s, wd.ws, 2, Cop, Cip, A->w + wd.off, n.dg + dg_off);
+    };
+  }
+  const bool has_ygrad = y.has_grad;
+  op->bwd = [=](Net& n, Op& me, bool wgrad, bool igrad) {
+    if (!has_ygrad) return;
+    const ParamDesc& wd = A->params[wi];
+    if (wgrad) {
+      for (int ph = 0; ph < 4; ++ph) {
+        const int a = ph >> 1, b = ph & 1;
+        ConvWgradArgs wa;
+        wa.x = xv; wa.g.KH = wa.g.KW = 2; wa.g.stride = 1; wa.g.pad_t = 1 - a; wa.g.pad_l = 1 - b;
+        wa.g.Ho = xv.H; wa.g.Wo = xv.W;
+        wa.dy = ygv; wa.om.ymul = 2; wa.om.yoff = a; wa.om.xmul = 2; wa.om.xoff = b;
+        wa.dw = A->g + wd.off + ph * phase_elems; wa.Npad = wd.ws.Npad; wa.Cout = Co;
+        conv_wgrad(n.ctx.s, wa);
+      }
+      if (bi >= 0) bias_grad(n.ctx.s, ygv, A->g + A->params[bi].off);
+    }
+    if (!want_dx || (me.reads_net_input && !igrad)) return;
+    ConvFwdArgs d;
+    d.x = ygv; d.g.KH = d.g.KW = 4; d.g.stride = 2; d.g.pad_t = d.g.pad_l = 1; d.g.Ho = xv.H; d.g.Wo = xv.W;
+    d.w = n.dg + dg_off; d.Npad = Cip; d.Cout = Cip; d.y = xgv; d.accumulate = me.acc.empty() ? 0 : me.acc[0];
+    conv_fwd(n.ctx.s, d);
+  };
+  ops.push_back(std::move(op));
+}
+
+// ---- [InstanceNorm] -> act -> [dropout] (+ residual) -----------------------------------
+void Net::norm_act(const Var& raw, const Var& y, bool norm, int actf, float drop_p, const Var* residual) {
+  auto op = std::make_unique<Op>();
+  op->label = "norm_act";
+  float* stats = norm ? static_cast<float*>(ctx.alloc((size_t)raw.v.N * raw.v.C * 2 * sizeof(float))) : nullptr;
+  const uint64_t salt = ops.size() + 1;
+  const TView rv = raw.v, rg = raw.g, yv = y.v, yg = y.g;
+  const bool has_res = residual != nullptr;
+  const Var res = has_res ? *residual : Var();
+  op->fwd = [=](Net& n) {
+    NormActArgs a;
+    a.x = rv; a.y = yv; a.stats = stats; a.norm = norm; a.act = actf;
+    a.drop_p = n.training ? drop_p : 0.f; a.seed = n.seed * 0x9E3779B1ull + salt;
+    a.residual = has_res ? &res.v : nullptr;
+    norm_act_fwd(n.ctx.s, a);
+  };
+  if (has_res && res.has_grad && y.has_grad) op->grad_targets.push_back(res);
+  const bool do_bwd = y.has_grad && raw.has_grad;
+  op->bwd = [=](Net& n, Op& me, bool, bool) {
+    if (!do_bwd) return;
+    if (has_res && res.has_grad) axpy(n.ctx.s, yg, res.g, 1.f, me.acc.empty() ? 0 : me.acc[0]);
+    NormActBwdArgs b;
+    b.dy = yg; b.x = rv; b.stats = stats; b.dx = rg; b.norm = norm; b.act = actf;
+    b.drop_p = n.training ? drop_p : 0.f; b.seed = n.seed * 0x9E3779B1ull + salt;
+    norm_act_bwd(n.ctx.s, b);
+  };
+  ops.push_back(std::move(op));
+}
+
+void Net::act(const Var& x, const Var& y, int actf) {
+  auto op = std::make_unique<Op>();
+  op->label = "act";
+  const TView xv = x.v, yv = y.v, xg = x.g, yg = y.g;
+  op->fwd = [=](Net& n) { act_fwd(n.ctx.s, xv, yv, actf); };
+  const bool do_bwd = x.has_grad && y.has_grad;
+  if (do_bwd) op->grad_targets.push_back(x);
+  op->bwd = [=](Net& n, Op& me, bool, bool) {
+    if (do_bwd) act_bwd(n.ctx.s, yg, yv, xg, actf, me.acc.empty() ? 0 : me.acc[0]);
+  };
+  ops.push_back(std::move(op));
+}
+
+void Net::affine(const Var& x, const Var& y, float alpha, float shift) {
+  auto op = std::make_unique<Op>();
+  op->label = "affine";
+  const TView xv = x.v, yv = y.v, xg = x.g, yg = y.g;
+  op->fwd = [=](Net& n) { axpy(n.ctx.s, xv, yv, alpha, 0, shift); };
+  const bool do_bwd = x.has_grad && y.has_grad;
+  if (do_bwd) op->grad_targets.push_back(x);
+  op->bwd = [=](Net& n, Op& me, bool, bool) {
+    if (do_bwd) axpy(n.ctx.s, yg, xg, alpha, me.acc.empty() ? 0 : me.acc[0], 0.f);
+  };
+  ops.push_back(std::move(op));
+}
+
+void Net::upsample(const Var& x, const Var& y, int f) {
+  auto op = std::make_unique<Op>();
+  op->label = "upsample";
+  const TView xv = x.v, yv = y.v, xg = x.g, yg = y.g;
+  op->fwd = [=](Net& n) { upsample_nearest_fwd(n.ctx.s, xv, yv, f); };
+  const bool do_bwd = x.has_grad && y.has_grad;
+  if (do_bwd) op->grad_targets.push_back(x);
+  op->bwd = [=](Net& n, Op& me, bool, bool) {
+    if (do_bwd) upsample_nearest_bwd(n.ctx.s, yg, xg, f, me.acc.empty() ? 0 : me.acc[0]);
+  };
+  ops.push_back(std::move(op));
+}
+
+void Net::maxpool(const Var& x, const Var& y) {
+  auto op = std::make_unique<Op>();
+  op->label = "maxpool";
+  const TView xv = x.v, yv = y.v, xg = x.g, yg = y.g;
+  op->fwd = [=](Net& n) { maxpool2_fwd(n.ctx.s, xv, yv); };
+  const bool do_bwd = x.has_grad && y.has_grad;
+  if (do_bwd) op->grad_targets.push_back(x);
+  op->bwd = [=](Net& n, Op& me, bool, bool) {
+    if (!do_bwd) return;
+    if (!me.acc.empty() && me.acc[0]) throw Error(1, "maxpool bwd cannot accumulate");
+    maxpool2_bwd(n.ctx.s, yg, xv, yv, xg);
+  };
+  ops.push_back(std::move(op));
+}
+
+// ---- accumulate planner -----------------------------------------------------------------
+// Walk the tape backwards (the order backward() executes) and decide, per gradient write,
+// whether it is the first producer of that (buffer, channel range) -> overwrite, or a later
+// one -> accumulate.  A write that covers a partly-initialised range is a builder bug.
+void Net::finalize(const std::vector<Var>& pre) {
+  std::map<float*, std::vector<char>> seen;
+  auto range = [&](const Var& v, int& c0, int& c1) -> std::vector<char>& {
+    std::vector<char>& s = seen[v.gbase];
+    if (s.empty()) s.assign(v.g.cs, 0);
+    c0 = (int)((v.g.p - v.gbase) % v.g.cs);
+    c1 = c0 + v.g.C;
+    return s;
+  };
+  for (const Var& v : pre) {
+    if (!v.has_grad) continue;
+    int c0, c1;
+    auto& s = range(v, c0, c1);
+    for (int c = c0; c < c1; ++c) s[c] = 1;
+  }
+  for (int i = (int)ops.size() - 1; i >= 0; --i) {
+    Op& op = *ops[i];
+    op.acc.assign(op.grad_targets.size(), 0);
+    for (size_t t = 0; t < op.grad_targets.size(); ++t) {
+      const Var& v = op.grad_targets[t];
+      int c0, c1;
+      auto& s = range(v, c0, c1);
+      int nset = 0;
+      for (int c = c0; c < c1; ++c) nset += s[c];
+      if (nset != 0 && nset != c1 - c0)
+        throw Error(1, "accumulate planner: op '" + op.label + "' writes a partially initialised gradient range");
+      op.acc[t] = nset ? 1 : 0;
+      for (int c = c0; c < c1; ++c) s[c] = 1;
+    }
+  }
+  dg = dg_n ? static_cast<float*>(ctx.alloc(dg_n * sizeof(float))) : nullptr;
+  finalized_ = true;
+}
+
+void Net::forward() {
+  if (!finalized_) throw Error(1, "Net::forward before finalize");
+  for (auto& op : ops) op->fwd(*this);
+}
+void Net::refresh_dgrad() {
+  if (dg_version == arena.version) return;
+  for (auto& op : ops)
+    if (op->repack) op->repack(*this);
+  dg_version = arena.version;
+}
+void Net::backward(bool wgrad, bool igrad) {
+  for (int i = (int)ops.size() - 1; i >= 0; --i) ops[i]->bwd(*this, *ops[i], wgrad, igrad);
+}
+
+// ---------------------------------------------------------------------------------------
+void Model::optimizer_step(int net) {
+  ParamArena& A = arena(net);
+  A.step += 1;
+  AdamWArgs a;
+  a.p = A.w; a.g = A.g; a.m = A.m; a.v = A.v; a.n = A.n;
+  a.lr = net == 0 ? hyper.lr : hyper.d_lr;
+  a.weight_decay = net == 0 ? hyper.weight_decay : hyper.d_weight_decay;
+  a.beta1 = hyper.b1; a.beta2 = hyper.b2; a.eps = 1e-8f; a.step = A.step;
+  adamw_step(ctx->s, a);
+  A.version += 1;
+}
+
+// BaseGAN.optimize_parameters (models/base_gan.py:194-203): forward, D step, G step.
+void Model::step(const float labels[3], bool training, uint64_t seed) {
+  forward(training, seed);
+  if (!hyper.warp_mode_ce_only) {
+    backward_D(labels[0], labels[1]);
+    optimizer_step(1);
+  }
+  backward_G(labels[2]);
+  optimizer_step(0);
+}
+
+}  // namespace swn

@@ -1,0 +1,162 @@
+// swapnet_amd -- native execution engine: parameter arenas, a small tape of fused ops over
+// NHWC views, and the network builders for the SwapNet hot path.  Host C++ only; every
+// device action goes through ops.h.
+#pragma once
+#include <functional>
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "ops.h"
+
+namespace swn {
+
+struct Ctx {
+  Stream s;
+  std::vector<void*> allocs;
+  size_t bytes_allocated = 0;
+  explicit Ctx(void* stream, size_t ws_bytes);
+  explicit Ctx(const Stream& shared);      // borrows stream + workspace of another context
+  bool owns_ws = true;
+  ~Ctx();
+  void* alloc(size_t bytes);
+  Ctx(const Ctx&) = delete;
+  Ctx& operator=(const Ctx&) = delete;
+};
+
+// activation + its gradient (same geometry).  gbase = start of the gradient allocation
+// (identifies the buffer for the accumulate planner).
+struct Var {
+  TView v, g;
+  float* gbase = nullptr;
+  bool has_grad = false;
+  Var slice(int c0, int c) const;
+  Var batch(int n0, int n) const;
+};
+
+struct ParamDesc {
+  std::string name;
+  bool is_bias = false;
+  WShape ws{};
+  size_t off = 0, elems = 0;   // floats in the arena (elems multiple of 4)
+  int n_logical = 0;           // bias length
+  std::vector<int32_t> cimap;
+};
+
+// One contiguous arena per network: weights, grads and both Adam moments share offsets, so
+// AdamW is a single launch and the data-parallel gradient exchange is one flat buffer.
+struct ParamArena {
+  std::vector<ParamDesc> params;
+  std::map<std::string, int> index;
+  size_t n = 0;
+  float *w = nullptr, *g = nullptr, *m = nullptr, *v = nullptr;
+  int step = 0;
+  int version = 1;        // bumped whenever the weights change (dgrad operands follow it)
+  bool frozen = false;    // after allocate(): builders may only re-bind existing params (shared nets)
+  int add_weight(const std::string& name, int kind, int Co, int Ci, int KH, int KW, int Cip,
+                 const std::vector<int32_t>* cimap);
+  int add_bias(const std::string& name, int n);
+  void allocate(Ctx& c);
+  float* base(int which) const { return which == 0 ? w : which == 1 ? g : which == 2 ? m : v; }
+};
+
+enum ConvKind { CK_K4S2 = 0, CK_K3S1_REFLECT, CK_K4S1, CK_K3S1_ZERO, CK_TAIL_UP };
+
+class Net;
+struct Op {
+  std::string label;
+  std::function<void(Net&)> fwd;
+  std::function<void(Net&, Op&, bool wgrad, bool igrad)> bwd;
+  std::vector<Var> grad_targets;   // gradients this op writes in bwd, in execution order
+  std::vector<int> acc;            // planned: 0 overwrite / 1 accumulate
+  bool reads_net_input = false;
+  std::function<void(Net&)> repack;   // refresh the dgrad operand from the arena
+};
+
+class Net {
+ public:
+  Net(Ctx& c, ParamArena& a) : ctx(c), arena(a) {}
+  Ctx& ctx;
+  ParamArena& arena;
+  std::vector<std::unique_ptr<Op>> ops;
+  std::map<std::string, Var> taps;
+  bool training = false;
+  uint64_t seed = 0;
+  float* dg = nullptr;      // dgrad operands of this net's convs
+  size_t dg_n = 0;
+  int dg_version = 0;       // arena.version the operands were derived from
+  std::vector<std::pair<Op*, size_t>> dg_layout;
+
+  Var alloc_var(int N, int H, int W, int C, bool need_grad);
+  // layers
+  // Ci = logical input channels of the reference layer (<= x.v.C, the padded buffer channels)
+  void conv(const std::string& name, const Var& x, const Var& y, ConvKind kind, int Ci, int Co, bool bias, int act,
+            const std::vector<int32_t>* cimap = nullptr, bool x_is_input = false);
+  void convT(const std::string& name, const Var& x, const Var& y, int Co, bool bias);
+  void norm_act(const Var& raw, const Var& y, bool norm, int act, float drop_p, const Var* residual = nullptr);
+  void act(const Var& x, const Var& y, int act);
+  void upsample(const Var& x, const Var& y, int factor);
+  void maxpool(const Var& x, const Var& y);
+  void affine(const Var& x, const Var& y, float alpha, float shift);
+  // bookkeeping
+  void finalize(const std::vector<Var>& pre_initialised_grads);
+  void forward();
+  void backward(bool wgrad, bool igrad);
+  void refresh_dgrad();     // no-op when the operands are current
+
+ private:
+  size_t reserve_dg(Op* op, size_t elems);
+  bool finalized_ = false;
+};
+
+// ---- network builders (reference layouts in the .cpp) ----------------------------------
+void build_warp_generator(Net& net, const Var& body, const Var& cloth, const Var& out, float dropout);
+Var build_patchgan(Net& net, const Var& x, int n_layers, const std::vector<int32_t>& cimap);
+void build_texture_generator(Net& net, const Var& tex, const float* rois_dev, int num_roi, const Var& cloth_cat,
+                             const Var& unet_in, const Var& out, int img_size);
+std::vector<Var> build_vgg16_slices(Net& net, const Var& img);
+
+// ---- trainers: the fused optimize_parameters() of models/{warp,texture}_model.py -----
+struct Hyper {
+  float lr = 1e-4f, d_lr = 4e-4f, weight_decay = 0.f, d_weight_decay = 0.01f, b1 = 0.9f, b2 = 0.999f;
+  float lambda_gan = 1.f, lambda_ce = 100.f, lambda_l1 = 10.f, lambda_content = 20.f, lambda_style = 1e-8f;
+  int gan_mode = 0;          // 0 vanilla (BCE), 1 lsgan, 2 wgan
+  int warp_mode_ce_only = 0; // --warp_mode ce
+};
+
+enum LossSlot {
+  L_D = 0, L_D_REAL, L_D_FAKE, L_G, L_G_GAN, L_G_CE, L_G_L1, L_G_CONTENT, L_G_STYLE, L_TMP0, L_TMP1, L_TMP2, L_TMP3,
+  L_TMP4, L_TMP5, L_COUNT = 32
+};
+
+class Model {
+ public:
+  virtual ~Model() {}
+  Ctx* ctx = nullptr;
+  int B = 0, H = 0, W = 0;
+  bool is_train = true;
+  ParamArena arenaG, arenaD;
+  std::unique_ptr<Net> G, D2, D1;
+  float* losses = nullptr;       // device [L_COUNT]
+  Hyper hyper;
+  virtual void set_input(int slot, const float* dev_nchw, int N, int C, int Hh, int Ww) = 0;
+  virtual void get_output(int slot, float* dev_nchw) = 0;
+  virtual void forward(bool training, uint64_t seed) = 0;
+  virtual void backward_D(float label_fake, float label_real) = 0;
+  virtual void backward_G(float label_real) = 0;
+  void optimizer_step(int net);
+  void step(const float labels[3], bool training, uint64_t seed);
+  ParamArena& arena(int net) { return net == 0 ? arenaG : arenaD; }
+  virtual ParamArena* arena_ptr(int net) {
+    if (net == 0) return &arenaG;
+    if (net == 1 && is_train) return &arenaD;
+    return nullptr;
+  }
+  Net* net_for_taps(int net) { return net == 0 ? G.get() : D2.get(); }
+};
+
+Model* create_warp_model(Ctx& ctx, int B, int H, int W, bool is_train, float dropout);
+Model* create_texture_model(Ctx& ctx, int B, int H, int W, bool is_train, int num_roi);
+
+}  // namespace swn

@@ -1,0 +1,269 @@
+// swapnet_amd -- gather / resampling / layout / integer kernels (all HBM- or gather-bound).
+// Reference: torchvision.ops.RoIAlign @0.4.0 (call site modules/swapnet_modules.py:166-168,234;
+// SURVEY.md Appendix B), nn.functional.interpolate nearest (:244-247), MaxPool2d(2,2) of
+// VGG16 (modules/losses/perceptual.py:26-42), util/decode_labels.py:24-55,
+// datasets/data_utils.py:311-343.
+#include "hip_util.h"
+
+namespace swn {
+namespace {
+
+inline unsigned egrid(size_t total) {
+  return (unsigned)std::min<size_t>(std::max<size_t>((total + 255) / 256, 1), 256 * 32);
+}
+
+struct RoiSample { int yl, yh, xl, xh; float w1, w2, w3, w4; bool valid; };
+
+// legacy (unaligned) RoIAlign sample for bin (ph,pw), sampling_ratio 1, spatial_scale 1.
+// fp32 arithmetic in the published order, contraction disabled so the truncations that
+// produce the integer corner indices are bit-identical to the CPU reference.
+__device__ __forceinline__ RoiSample roi_sample(const float* roi, int ph, int pw, int PH, int PW, int H, int W) {
+  RoiSample r;
+  const float sw = roi[0], sh = roi[1], ew = roi[2], eh = roi[3];
+  const float rw = fmaxf(__fsub_rn(ew, sw), 1.0f);
+  const float rh = fmaxf(__fsub_rn(eh, sh), 1.0f);
+  const float bw = __fdiv_rn(rw, (float)PW);
+  const float bh = __fdiv_rn(rh, (float)PH);
+  float y = __fadd_rn(__fadd_rn(sh, __fmul_rn((float)ph, bh)), __fdiv_rn(__fmul_rn(0.5f, bh), 1.0f));
+  float x = __fadd_rn(__fadd_rn(sw, __fmul_rn((float)pw, bw)), __fdiv_rn(__fmul_rn(0.5f, bw), 1.0f));
+  r.valid = !(y < -1.0f || y > (float)H || x < -1.0f || x > (float)W);
+  y = fmaxf(y, 0.f); x = fmaxf(x, 0.f);
+  int yl = (int)y, xl = (int)x, yh, xh;
+  if (yl >= H - 1) { yh = yl = H - 1; y = (float)yl; } else { yh = yl + 1; }
+  if (xl >= W - 1) { xh = xl = W - 1; x = (float)xl; } else { xh = xl + 1; }
+  const float ly = __fsub_rn(y, (float)yl), lx = __fsub_rn(x, (float)xl);
+  const float hy = __fsub_rn(1.f, ly), hx = __fsub_rn(1.f, lx);
+  r.yl = yl; r.yh = yh; r.xl = xl; r.xh = xh;
+  r.w1 = __fmul_rn(hy, hx); r.w2 = __fmul_rn(hy, lx); r.w3 = __fmul_rn(ly, hx); r.w4 = __fmul_rn(ly, lx);
+  return r;
+}
+
+// one thread per (b, ph, pw, roi): the 12 ROI threads of a pixel write 36 contiguous floats
+__global__ __launch_bounds__(256) void roi_align_kernel(const float* tex, int tcs, int H, int W, int C,
+                                                        const float* rois, int B, int R, float* out, int ocs, int PH,
+                                                        int PW) {
+  const size_t total = (size_t)B * PH * PW * R;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int r = (int)(i % R); size_t q = i / R;
+    const int pw = (int)(q % PW); q /= PW;
+    const int ph = (int)(q % PH); const int b = (int)(q / PH);
+    const RoiSample sm = roi_sample(rois + ((size_t)b * R + r) * 4, ph, pw, PH, PW, H, W);
+    float* o = out + (((size_t)b * PH + ph) * PW + pw) * ocs + r * C;
+    const float* img = tex + (size_t)b * H * W * tcs;
+    for (int c = 0; c < C; ++c) {
+      float v = 0.f;
+      if (sm.valid) {
+        const float v1 = img[((size_t)sm.yl * W + sm.xl) * tcs + c], v2 = img[((size_t)sm.yl * W + sm.xh) * tcs + c];
+        const float v3 = img[((size_t)sm.yh * W + sm.xl) * tcs + c], v4 = img[((size_t)sm.yh * W + sm.xh) * tcs + c];
+        // (w1*v1 + w2*v2 + w3*v3 + w4*v4) evaluated left to right, unfused (ROIAlign_cpu.cpp)
+        v = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(sm.w1, v1), __fmul_rn(sm.w2, v2)), __fmul_rn(sm.w3, v3)),
+                      __fmul_rn(sm.w4, v4));
+      }
+      o[c] = v;
+    }
+  }
+}
+
+__global__ void roi_indices_kernel(const float* rois, int K, int H, int W, int PH, int PW, int32_t* idx,
+                                   uint8_t* valid) {
+  const size_t total = (size_t)K * PH * PW;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int pw = (int)(i % PW); size_t q = i / PW;
+    const int ph = (int)(q % PH); const int k = (int)(q / PH);
+    const RoiSample sm = roi_sample(rois + (size_t)k * 4, ph, pw, PH, PW, H, W);
+    idx[i * 4 + 0] = sm.yl; idx[i * 4 + 1] = sm.yh; idx[i * 4 + 2] = sm.xl; idx[i * 4 + 3] = sm.xh;
+    valid[i] = sm.valid ? 1 : 0;
+  }
+}
+
+__global__ __launch_bounds__(256) void upsample_fwd_kernel(const float* x, int xcs, float* y, int ycs, int N, int Ho,
+                                                           int Wo, int C, int f) {
+  const int C4 = C >> 2, Hi = Ho / f, Wi = Wo / f;
+  const size_t total = (size_t)N * Ho * Wo * C4;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int c = (int)(i % C4) * 4; size_t q = i / C4;
+    const int ox = (int)(q % Wo); q /= Wo;
+    const int oy = (int)(q % Ho); const int n = (int)(q / Ho);
+    const float4 v = *reinterpret_cast<const float4*>(x + (((size_t)n * Hi + oy / f) * Wi + ox / f) * xcs + c);
+    *reinterpret_cast<float4*>(y + (((size_t)n * Ho + oy) * Wo + ox) * ycs + c) = v;
+  }
+}
+__global__ __launch_bounds__(256) void upsample_bwd_kernel(const float* dy, int dycs, float* dx, int dxcs, int N,
+                                                           int Hi, int Wi, int C, int f, int accumulate) {
+  const int C4 = C >> 2, Ho = Hi * f, Wo = Wi * f;
+  const size_t total = (size_t)N * Hi * Wi * C4;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int c = (int)(i % C4) * 4; size_t q = i / C4;
+    const int ix = (int)(q % Wi); q /= Wi;
+    const int iy = (int)(q % Hi); const int n = (int)(q / Hi);
+    float4 a = make_float4(0, 0, 0, 0);
+    for (int dyy = 0; dyy < f; ++dyy)
+      for (int dxx = 0; dxx < f; ++dxx) {
+        const float4 v = *reinterpret_cast<const float4*>(
+            dy + (((size_t)n * Ho + iy * f + dyy) * Wo + ix * f + dxx) * dycs + c);
+        a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+      }
+    float* d = dx + (((size_t)n * Hi + iy) * Wi + ix) * dxcs + c;
+    if (accumulate) { const float4 o = *reinterpret_cast<const float4*>(d); a.x += o.x; a.y += o.y; a.z += o.z; a.w += o.w; }
+    *reinterpret_cast<float4*>(d) = a;
+  }
+}
+
+// MaxPool2d(2,2).  bwd recomputes the arg-max with the forward's scan order (kh,kw) and
+// strict '>' so ties go to the first element, like ATen's max_pool2d.
+__global__ __launch_bounds__(256) void maxpool_kernel(const float* x, int xcs, float* y, int ycs, const float* dy,
+                                                      int dycs, float* dx, int dxcs, int N, int Ho, int Wo, int C,
+                                                      int bwd) {
+  const int C4 = C >> 2, Hi = Ho * 2, Wi = Wo * 2;
+  const size_t total = (size_t)N * Ho * Wo * C4;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int c = (int)(i % C4) * 4; size_t q = i / C4;
+    const int ox = (int)(q % Wo); q /= Wo;
+    const int oy = (int)(q % Ho); const int n = (int)(q / Ho);
+    float4 v[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+      v[t] = *reinterpret_cast<const float4*>(x + (((size_t)n * Hi + oy * 2 + (t >> 1)) * Wi + ox * 2 + (t & 1)) * xcs + c);
+    float m[4]; int am[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float* f0 = &v[0].x;
+      m[j] = f0[j]; am[j] = 0;
+#pragma unroll
+      for (int t = 1; t < 4; ++t) {
+        const float val = (&v[t].x)[j];
+        if (val > m[j] || val != val) { m[j] = val; am[j] = t; }
+      }
+    }
+    if (!bwd) {
+      *reinterpret_cast<float4*>(y + (((size_t)n * Ho + oy) * Wo + ox) * ycs + c) = make_float4(m[0], m[1], m[2], m[3]);
+    } else {
+      const float4 g = *reinterpret_cast<const float4*>(dy + (((size_t)n * Ho + oy) * Wo + ox) * dycs + c);
+      const float ga[4] = {g.x, g.y, g.z, g.w};
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        float4 o;
+        o.x = am[0] == t ? ga[0] : 0.f; o.y = am[1] == t ? ga[1] : 0.f;
+        o.z = am[2] == t ? ga[2] : 0.f; o.w = am[3] == t ? ga[3] : 0.f;
+        *reinterpret_cast<float4*>(dx + (((size_t)n * Hi + oy * 2 + (t >> 1)) * Wi + ox * 2 + (t & 1)) * dxcs + c) = o;
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* src, int N, int C, int HW, float* dst, int dcs) {
+  const size_t total = (size_t)N * C * HW;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int pix = (int)(i % HW); size_t q = i / HW;
+    const int c = (int)(q % C); const int n = (int)(q / C);
+    dst[((size_t)n * HW + pix) * dcs + c] = src[i];
+  }
+}
+__global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const float* src, int scs, int N, int C, int HW, float* dst) {
+  const size_t total = (size_t)N * C * HW;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int pix = (int)(i % HW); size_t q = i / HW;
+    const int c = (int)(q % C); const int n = (int)(q / C);
+    dst[i] = src[((size_t)n * HW + pix) * scs + c];
+  }
+}
+
+__constant__ uint8_t kPalette[19][3] = {
+    {0, 0, 0}, {128, 0, 0}, {255, 0, 0}, {0, 85, 0}, {255, 85, 0}, {0, 0, 85}, {0, 119, 221}, {85, 85, 0},
+    {0, 85, 85}, {85, 51, 0}, {52, 86, 128}, {0, 128, 0}, {0, 0, 255}, {51, 170, 221}, {0, 255, 255},
+    {85, 255, 170}, {170, 255, 85}, {255, 255, 0}, {255, 170, 0}};
+
+// MODE 0: palette decode -> uint8 NCHW rgb ; MODE 1: int32 labels
+template <int MODE>
+__global__ __launch_bounds__(256) void argmax_kernel(const float* x, int xcs, int N, int HW, int C, uint8_t* rgb,
+                                                     int32_t* labels) {
+  const size_t total = (size_t)N * HW;
+  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+    const float* p = x + e * xcs;
+    int best = 0; float m = p[0];
+    for (int c = 1; c < C; ++c) { const float v = p[c]; if (v > m) { m = v; best = c; } }
+    if (MODE == 1) {
+      labels[e] = best;
+    } else {
+      const int n = (int)(e / HW), pix = (int)(e - (size_t)n * HW);
+#pragma unroll
+      for (int ch = 0; ch < 3; ++ch)
+        rgb[((size_t)n * 3 + ch) * HW + pix] = best < 19 ? kPalette[best][ch] : 0;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void onehot_kernel(const int32_t* labels, size_t pixels, int C, float* y, int ycs) {
+  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < pixels; e += (size_t)gridDim.x * 256) {
+    const int l = labels[e];
+    float* p = y + e * ycs;
+    for (int c = 0; c < C; ++c) p[c] = (c == l && l != 0) ? 1.f : 0.f;   // label 0 -> all-zero vector
+  }
+}
+
+}  // namespace
+
+void roi_align_fwd(Stream& s, const TView& tex, int C, const float* rois, int R, const TView& out) {
+  if (out.C < R * C || out.N != tex.N) throw Error(1, "roi_align_fwd: output view too small");
+  const size_t total = (size_t)tex.N * out.H * out.W * R;
+  hipLaunchKernelGGL(roi_align_kernel, dim3(egrid(total)), dim3(256), 0, hs(s), tex.p, tex.cs, tex.H, tex.W, C, rois,
+                     tex.N, R, out.p, out.cs, out.H, out.W);
+  check_launch("roi_align_fwd");
+}
+void roi_align_indices(Stream& s, const float* rois, int K, int H, int W, int PH, int PW, int32_t* idx,
+                       uint8_t* valid) {
+  hipLaunchKernelGGL(roi_indices_kernel, dim3(egrid((size_t)K * PH * PW)), dim3(256), 0, hs(s), rois, K, H, W, PH, PW,
+                     idx, valid);
+  check_launch("roi_align_indices");
+}
+
+void upsample_nearest_fwd(Stream& s, const TView& x, const TView& y, int f) {
+  if (y.H != x.H * f || y.W != x.W * f || x.C % 4 || y.C != x.C) throw Error(1, "upsample_nearest_fwd: shape mismatch");
+  hipLaunchKernelGGL(upsample_fwd_kernel, dim3(egrid(y.pixels() * (x.C / 4))), dim3(256), 0, hs(s), x.p, x.cs, y.p, y.cs,
+                     x.N, y.H, y.W, x.C, f);
+  check_launch("upsample_nearest_fwd");
+}
+void upsample_nearest_bwd(Stream& s, const TView& dy, const TView& dx, int f, int accumulate) {
+  if (dy.H != dx.H * f || dy.W != dx.W * f || dx.C % 4 || dy.C != dx.C) throw Error(1, "upsample_nearest_bwd: shape mismatch");
+  hipLaunchKernelGGL(upsample_bwd_kernel, dim3(egrid(dx.pixels() * (dx.C / 4))), dim3(256), 0, hs(s), dy.p, dy.cs, dx.p,
+                     dx.cs, dx.N, dx.H, dx.W, dx.C, f, accumulate);
+  check_launch("upsample_nearest_bwd");
+}
+void maxpool2_fwd(Stream& s, const TView& x, const TView& y) {
+  if (x.H != y.H * 2 || x.W != y.W * 2 || x.C % 4 || x.C != y.C) throw Error(1, "maxpool2_fwd: shape mismatch");
+  hipLaunchKernelGGL(maxpool_kernel, dim3(egrid(y.pixels() * (y.C / 4))), dim3(256), 0, hs(s), x.p, x.cs, y.p, y.cs,
+                     (const float*)nullptr, 0, (float*)nullptr, 0, y.N, y.H, y.W, y.C, 0);
+  check_launch("maxpool2_fwd");
+}
+void maxpool2_bwd(Stream& s, const TView& dy, const TView& x, const TView& y, const TView& dx) {
+  hipLaunchKernelGGL(maxpool_kernel, dim3(egrid(y.pixels() * (y.C / 4))), dim3(256), 0, hs(s), x.p, x.cs, y.p, y.cs, dy.p,
+                     dy.cs, dx.p, dx.cs, y.N, y.H, y.W, y.C, 1);
+  check_launch("maxpool2_bwd");
+}
+
+void nchw_to_nhwc(Stream& s, const float* src, int N, int C, int H, int W, const TView& dst) {
+  if (dst.N != N || dst.H != H || dst.W != W || dst.C < C) throw Error(1, "nchw_to_nhwc: shape mismatch");
+  hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(egrid((size_t)N * C * H * W)), dim3(256), 0, hs(s), src, N, C, H * W, dst.p, dst.cs);
+  check_launch("nchw_to_nhwc");
+}
+void nhwc_to_nchw(Stream& s, const TView& src, float* dst, int C) {
+  hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(egrid(src.pixels() * C)), dim3(256), 0, hs(s), src.p, src.cs, src.N, C,
+                     src.H * src.W, dst);
+  check_launch("nhwc_to_nchw");
+}
+void decode_labels(Stream& s, const TView& x, int C, uint8_t* rgb) {
+  hipLaunchKernelGGL(argmax_kernel<0>, dim3(egrid(x.pixels())), dim3(256), 0, hs(s), x.p, x.cs, x.N, x.H * x.W, C, rgb,
+                     (int32_t*)nullptr);
+  check_launch("decode_labels");
+}
+void argmax_labels(Stream& s, const TView& x, int C, int32_t* labels) {
+  hipLaunchKernelGGL(argmax_kernel<1>, dim3(egrid(x.pixels())), dim3(256), 0, hs(s), x.p, x.cs, x.N, x.H * x.W, C,
+                     (uint8_t*)nullptr, labels);
+  check_launch("argmax_labels");
+}
+void labels_to_onehot(Stream& s, const int32_t* labels, const TView& y, int C) {
+  hipLaunchKernelGGL(onehot_kernel, dim3(egrid(y.pixels())), dim3(256), 0, hs(s), labels, y.pixels(), C, y.p, y.cs);
+  check_launch("labels_to_onehot");
+}
+
+}  // namespace swn

@@ -1,0 +1,356 @@
+// swapnet_amd -- loss reductions fused with their gradients (one pass over the data
+// produces the scalar and dL/dx).  HBM-bound; fp64 block partials combined in fixed order.
+// Reference: modules/loss.py:12-130 (GANLoss), models/warp_model.py:147-150 (CE on tanh
+// outputs vs argmax(target)), models/texture_model.py:168-170 (L1),
+// modules/losses/perceptual.py:6-10,49-79 (content / style).
+#include "hip_util.h"
+
+namespace swn {
+namespace {
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_sum_f(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+// sum over a 256-thread block; result valid in thread 0
+__device__ __forceinline__ double block_sum(double v, double* sh) {
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (lane == 0) sh[w] = v;
+  __syncthreads();
+  double r = 0;
+  if (threadIdx.x == 0) r = sh[0] + sh[1] + sh[2] + sh[3];
+  __syncthreads();
+  return r;
+}
+
+__global__ void finalize_kernel(const double* partial, int n, double mul, float* out) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    double a = 0;
+    for (int i = 0; i < n; ++i) a += partial[i];
+    out[0] = (float)(a * mul);
+  }
+}
+
+inline int loss_grid(size_t work) { return (int)std::min<size_t>(std::max<size_t>((work + 255) / 256, 1), 1024); }
+
+// ---- GAN losses on a 1-channel prediction map (channel 0 of a C-padded view) -----------
+// MODE 0 BCE-with-logits, 1 LSGAN (MSE), 2 WGAN (sign * mean)
+template <int MODE>
+__global__ __launch_bounds__(256) void gan_loss_kernel(const float* pred, int pcs, size_t numel, float label,
+                                                       float gscale, float* dpred, int dcs, double* partial) {
+  __shared__ double sh[4];
+  double acc = 0;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < numel; i += (size_t)gridDim.x * 256) {
+    const float x = pred[i * pcs];
+    float l, g;
+    if (MODE == 0) {
+      // max(x,0) - x*t + log1p(exp(-|x|))   (numerically stable BCEWithLogits)
+      l = fmaxf(x, 0.f) - x * label + log1pf(expf(-fabsf(x)));
+      g = 1.f / (1.f + expf(-x)) - label;
+    } else if (MODE == 1) {
+      const float d = x - label;
+      l = d * d; g = 2.f * d;
+    } else {
+      l = label * x; g = label;        // label carries the sign (+1 fake, -1 real)
+    }
+    acc += l;
+    if (dpred) dpred[i * dcs] = g * gscale;
+  }
+  const double r = block_sum(acc, sh);
+  if (threadIdx.x == 0) partial[blockIdx.x] = r;
+}
+
+// ---- cross entropy vs argmax(target) ----------------------------------------------------
+__global__ __launch_bounds__(256) void ce_kernel(const float* logits, int lcs, const float* target, int tcs, int C,
+                                                 size_t pixels, float gscale, float* dl, int dcs, int accumulate,
+                                                 double* partial) {
+  __shared__ double sh[4];
+  double acc = 0;
+  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < pixels; e += (size_t)gridDim.x * 256) {
+    const float* lp = logits + e * lcs;
+    const float* tp = target + e * tcs;
+    int label = 0; float tmax = tp[0];
+    float lmax = lp[0];
+    for (int c = 1; c < C; ++c) {
+      const float tv = tp[c];
+      if (tv > tmax) { tmax = tv; label = c; }     // first maximal index (torch.argmax)
+      lmax = fmaxf(lmax, lp[c]);
+    }
+    float se = 0.f;
+    for (int c = 0; c < C; ++c) se += expf(lp[c] - lmax);
+    const float lse = lmax + logf(se);
+    acc += (double)(lse - lp[label]);
+    if (dl) {
+      float* dp = dl + e * dcs;
+      const float inv = 1.f / se;
+      for (int c = 0; c < C; ++c) {
+        float g = (expf(lp[c] - lmax) * inv - (c == label ? 1.f : 0.f)) * gscale;
+        if (accumulate) g += dp[c];
+        dp[c] = g;
+      }
+    }
+  }
+  const double r = block_sum(acc, sh);
+  if (threadIdx.x == 0) partial[blockIdx.x] = r;
+}
+
+// ---- L1 ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void l1_kernel(const float* a, int acs, const float* b, int bcs, int C, size_t pixels,
+                                                 float gscale, float* da, int dcs, int accumulate, double* partial) {
+  __shared__ double sh[4];
+  double acc = 0;
+  const size_t total = pixels * C;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const size_t e = i / C; const int c = (int)(i - e * C);
+    const float d = a[e * acs + c] - b[e * bcs + c];
+    acc += fabsf(d);
+    if (da) {
+      float g = (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f)) * gscale;
+      float* dp = da + e * dcs + c;
+      if (accumulate) g += *dp;
+      *dp = g;
+    }
+  }
+  const double r = block_sum(acc, sh);
+  if (threadIdx.x == 0) partial[blockIdx.x] = r;
+}
+
+// ---- content: MSE of channel-L2-normalised features, one wave per pixel -------------------
+// f/(|f|+1e-8) vs t/(|t|+1e-8); C <= 512 (2 float4 per lane)
+__global__ __launch_bounds__(256) void normed_mse_kernel(const float* f, int fcs, const float* t, int tcs, int C,
+                                                         size_t pixels, float gscale, float* df, int dcs,
+                                                         int accumulate, double* partial) {
+  __shared__ double sh[4];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int C4 = C >> 2;
+  double acc = 0;
+  for (size_t e = (size_t)blockIdx.x * 4 + wv; e < pixels; e += (size_t)gridDim.x * 4) {
+    float4 fv[2], tv[2];
+    float sf = 0.f, st = 0.f;
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const int c4 = lane + 64 * r;
+      fv[r] = make_float4(0, 0, 0, 0); tv[r] = make_float4(0, 0, 0, 0);
+      if (c4 < C4) {
+        fv[r] = *reinterpret_cast<const float4*>(f + e * fcs + c4 * 4);
+        tv[r] = *reinterpret_cast<const float4*>(t + e * tcs + c4 * 4);
+      }
+      sf += fv[r].x * fv[r].x + fv[r].y * fv[r].y + fv[r].z * fv[r].z + fv[r].w * fv[r].w;
+      st += tv[r].x * tv[r].x + tv[r].y * tv[r].y + tv[r].z * tv[r].z + tv[r].w * tv[r].w;
+    }
+    sf = sqrtf(wave_sum_f(sf)); st = sqrtf(wave_sum_f(st));
+    const float inf = 1.f / (sf + 1e-8f), intt = 1.f / (st + 1e-8f);
+    float l = 0.f, dot = 0.f;
+    float4 g[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      g[r].x = fv[r].x * inf - tv[r].x * intt; g[r].y = fv[r].y * inf - tv[r].y * intt;
+      g[r].z = fv[r].z * inf - tv[r].z * intt; g[r].w = fv[r].w * inf - tv[r].w * intt;
+      l += g[r].x * g[r].x + g[r].y * g[r].y + g[r].z * g[r].z + g[r].w * g[r].w;
+      dot += g[r].x * fv[r].x + g[r].y * fv[r].y + g[r].z * fv[r].z + g[r].w * fv[r].w;
+    }
+    l = wave_sum_f(l);
+    if (lane == 0) acc += l;
+    if (df) {
+      dot = wave_sum_f(dot);
+      // y = x/(s+eps): dx = g/(s+eps) - x * (x.g) / (s (s+eps)^2)   (s>0; s==0 -> first term only)
+      const float k2 = sf > 0.f ? dot * inf * inf / sf : 0.f;
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        const int c4 = lane + 64 * r;
+        if (c4 < C4) {
+          float4 o;
+          o.x = (g[r].x * inf - fv[r].x * k2) * gscale; o.y = (g[r].y * inf - fv[r].y * k2) * gscale;
+          o.z = (g[r].z * inf - fv[r].z * k2) * gscale; o.w = (g[r].w * inf - fv[r].w * k2) * gscale;
+          float* dp = df + e * dcs + c4 * 4;
+          if (accumulate) {
+            const float4 d = *reinterpret_cast<const float4*>(dp);
+            o.x += d.x; o.y += d.y; o.z += d.z; o.w += d.w;
+          }
+          *reinterpret_cast<float4*>(dp) = o;
+        }
+      }
+    }
+  }
+  const double r = block_sum(acc, sh);
+  if (threadIdx.x == 0) partial[blockIdx.x] = r;
+}
+
+// ---- style: Gram of the raw images viewed (N*C) x (H*W) ----------------------------------
+// stage 1: per pixel-chunk partial Gram of both images (R = N*C rows, R <= 128)
+__global__ __launch_bounds__(256) void gram_partial_kernel(const float* a, int acs, const float* b, int bcs, int N,
+                                                           int HW, int C, int chunk, float* partial) {
+  extern __shared__ float xs[];        // [2][R][chunk]
+  const int R = N * C;
+  const int p0 = blockIdx.x * chunk;
+  const int np = min(chunk, HW - p0);
+  for (int i = threadIdx.x; i < R * chunk; i += 256) {
+    const int r = i / chunk, pp = i - r * chunk;
+    const int n = r / C, c = r - n * C;
+    float va = 0.f, vb = 0.f;
+    if (pp < np) {
+      va = a[((size_t)n * HW + p0 + pp) * acs + c];
+      vb = b[((size_t)n * HW + p0 + pp) * bcs + c];
+    }
+    xs[i] = va; xs[R * chunk + i] = vb;
+  }
+  __syncthreads();
+  float* out = partial + (size_t)blockIdx.x * 2 * R * R;
+  for (int i = threadIdx.x; i < R * R; i += 256) {
+    const int r1 = i / R, r2 = i - r1 * R;
+    float s1 = 0.f, s2 = 0.f;
+    for (int pp = 0; pp < chunk; ++pp) {
+      s1 = fmaf(xs[r1 * chunk + pp], xs[r2 * chunk + pp], s1);
+      s2 = fmaf(xs[R * chunk + r1 * chunk + pp], xs[R * chunk + r2 * chunk + pp], s2);
+    }
+    out[i] = s1; out[R * R + i] = s2;
+  }
+}
+// stage 2: G = sum of partials (fp64), dG = gscale * 2 * (Ga - Gb); loss partial
+__global__ __launch_bounds__(256) void gram_final_kernel(const float* partial, int nchunk, int R, float gscale,
+                                                         float* dG, double* losspartial) {
+  __shared__ double sh[4];
+  double acc = 0;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < R * R; i += gridDim.x * 256) {
+    double ga = 0, gb = 0;
+    for (int ch = 0; ch < nchunk; ++ch) {
+      ga += partial[(size_t)ch * 2 * R * R + i];
+      gb += partial[(size_t)ch * 2 * R * R + R * R + i];
+    }
+    const double d = ga - gb;
+    acc += d * d;
+    dG[i] = (float)(2.0 * d) * gscale;
+  }
+  const double r = block_sum(acc, sh);
+  if (threadIdx.x == 0) losspartial[blockIdx.x] = r;
+}
+// stage 3: dA[r][p] (+)= sum_r' (dG[r][r'] + dG[r'][r]) * A[r'][p]
+__global__ __launch_bounds__(256) void gram_bwd_kernel(const float* a, int acs, const float* dG, int N, int HW, int C,
+                                                       float* da, int dcs, int accumulate) {
+  extern __shared__ float g[];       // [R][R] symmetrised
+  const int R = N * C;
+  for (int i = threadIdx.x; i < R * R; i += 256) {
+    const int r1 = i / R, r2 = i - r1 * R;
+    g[i] = dG[i] + dG[r2 * R + r1];
+  }
+  __syncthreads();
+  const size_t total = (size_t)HW * R;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int pp = (int)(i / R), r = (int)(i - (size_t)pp * R);
+    const int n = r / C, c = r - n * C;
+    float s = 0.f;
+    for (int r2 = 0; r2 < R; ++r2) {
+      const int n2 = r2 / C, c2 = r2 - n2 * C;
+      s = fmaf(g[r * R + r2], a[((size_t)n2 * HW + pp) * acs + c2], s);
+    }
+    float* dp = da + ((size_t)n * HW + pp) * dcs + c;
+    if (accumulate) s += *dp;
+    *dp = s;
+  }
+}
+
+__global__ void scalar_axpby_kernel(const float* a, float ca, const float* b, float cb, float* out) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) out[0] = (a ? a[0] * ca : 0.f) + (b ? b[0] * cb : 0.f);
+}
+
+template <int MODE>
+void gan_loss(Stream& s, const TView& pred, float label, float scale, float* loss_out, const TView* dpred) {
+  const size_t numel = pred.pixels();
+  const int grid = loss_grid(numel);
+  double* partial = reinterpret_cast<double*>(s.ws);
+  const float gs = scale / (float)numel;
+  hipLaunchKernelGGL(gan_loss_kernel<MODE>, dim3(grid), dim3(256), 0, hs(s), pred.p, pred.cs, numel, label, gs,
+                     dpred ? dpred->p : nullptr, dpred ? dpred->cs : 0, partial);
+  hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(64), 0, hs(s), partial, grid, 1.0 / (double)numel, loss_out);
+  check_launch("gan_loss");
+}
+
+}  // namespace
+
+void bce_logits_loss(Stream& s, const TView& pred, float label, float scale, float* loss_out, const TView* dpred) {
+  gan_loss<0>(s, pred, label, scale, loss_out, dpred);
+}
+void lsgan_loss(Stream& s, const TView& pred, float label, float scale, float* loss_out, const TView* dpred) {
+  gan_loss<1>(s, pred, label, scale, loss_out, dpred);
+}
+void wgan_loss(Stream& s, const TView& pred, float sign, float scale, float* loss_out, const TView* dpred) {
+  gan_loss<2>(s, pred, sign, scale, loss_out, dpred);
+}
+
+void ce_argmax_loss(Stream& s, const TView& logits, const TView& target, int C, float scale, float* loss_out,
+                    const TView* dlogits, int accumulate) {
+  const size_t pixels = logits.pixels();
+  const int grid = loss_grid(pixels);
+  double* partial = reinterpret_cast<double*>(s.ws);
+  hipLaunchKernelGGL(ce_kernel, dim3(grid), dim3(256), 0, hs(s), logits.p, logits.cs, target.p, target.cs, C, pixels,
+                     scale / (float)pixels, dlogits ? dlogits->p : nullptr, dlogits ? dlogits->cs : 0, accumulate, partial);
+  hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(64), 0, hs(s), partial, grid, 1.0 / (double)pixels, loss_out);
+  check_launch("ce_argmax_loss");
+}
+
+void l1_loss(Stream& s, const TView& a, const TView& b, int C, float scale, float* loss_out, const TView* da,
+             int accumulate) {
+  const size_t pixels = a.pixels();
+  const size_t numel = pixels * C;
+  const int grid = loss_grid(numel);
+  double* partial = reinterpret_cast<double*>(s.ws);
+  hipLaunchKernelGGL(l1_kernel, dim3(grid), dim3(256), 0, hs(s), a.p, a.cs, b.p, b.cs, C, pixels, scale / (float)numel,
+                     da ? da->p : nullptr, da ? da->cs : 0, accumulate, partial);
+  hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(64), 0, hs(s), partial, grid, 1.0 / (double)numel, loss_out);
+  check_launch("l1_loss");
+}
+
+void normed_mse_loss(Stream& s, const TView& f, const TView& t, float scale, float* loss_out, const TView* df,
+                     int accumulate) {
+  if (f.C % 4 || f.C > 512 || t.C != f.C) throw Error(1, "normed_mse_loss: C must be a multiple of 4, <= 512");
+  const size_t pixels = f.pixels();
+  const size_t numel = pixels * f.C;
+  const int grid = (int)std::min<size_t>((pixels + 3) / 4, 2048);
+  double* partial = reinterpret_cast<double*>(s.ws);
+  hipLaunchKernelGGL(normed_mse_kernel, dim3(grid), dim3(256), 0, hs(s), f.p, f.cs, t.p, t.cs, f.C, pixels,
+                     2.f * scale / (float)numel, df ? df->p : nullptr, df ? df->cs : 0, accumulate, partial);
+  hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(64), 0, hs(s), partial, grid, 1.0 / (double)numel, loss_out);
+  check_launch("normed_mse_loss");
+}
+
+void gram_style_loss(Stream& s, const TView& a, const TView& b, int C, float scale, float* loss_out, const TView* da,
+                     int accumulate) {
+  const int R = a.N * C, HW = a.H * a.W;
+  if (R > 128) throw Error(1, "gram_style_loss: N*C > 128 unsupported");
+  const int chunk = 64;
+  const int nchunk = ceil_div(HW, chunk);
+  const size_t pbytes = (size_t)nchunk * 2 * R * R * 4;
+  const size_t off_dG = (pbytes + 255) / 256 * 256;
+  const size_t off_lp = off_dG + (size_t)R * R * 4 + 256;
+  if (off_lp + 64 * 8 > s.ws_bytes) throw Error(1, "gram_style_loss: workspace too small");
+  float* partial = reinterpret_cast<float*>(s.ws);
+  float* dG = reinterpret_cast<float*>(s.ws + off_dG);
+  double* lp = reinterpret_cast<double*>(s.ws + (off_lp + 255) / 256 * 256);
+  const double numel = (double)R * R;
+  hipLaunchKernelGGL(gram_partial_kernel, dim3(nchunk), dim3(256), 2 * R * chunk * 4, hs(s), a.p, a.cs, b.p, b.cs, a.N,
+                     HW, C, chunk, partial);
+  const int fgrid = std::min(ceil_div(R * R, 256), 64);
+  hipLaunchKernelGGL(gram_final_kernel, dim3(fgrid), dim3(256), 0, hs(s), partial, nchunk, R, (float)(scale / numel),
+                     dG, lp);
+  hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(64), 0, hs(s), lp, fgrid, 1.0 / numel, loss_out);
+  if (da) {
+    const size_t total = (size_t)HW * R;
+    hipLaunchKernelGGL(gram_bwd_kernel, dim3(loss_grid(total)), dim3(256), R * R * 4, hs(s), a.p, a.cs, dG, a.N, HW, C,
+                       da->p, da->cs, accumulate);
+  }
+  check_launch("gram_style_loss");
+}
+
+void scalar_axpby(Stream& s, const float* a, float ca, const float* b, float cb, float* out) {
+  hipLaunchKernelGGL(scalar_axpby_kernel, dim3(1), dim3(64), 0, hs(s), a, ca, b, cb, out);
+  check_launch("scalar_axpby");
+}
+
+}  // namespace swn

@@ -1,0 +1,382 @@
+// swapnet_amd -- InstanceNorm2d (eps 1e-5, biased variance, no affine) + activation +
+// dropout (+ residual add), forward and backward, on NHWC views.  HBM-bound kernels:
+// every access is a 16-byte channel-contiguous load/store, statistics are accumulated in
+// fp64 (no E[x^2]-E[x]^2 cancellation), partial sums are combined in a fixed order so the
+// result is run-to-run deterministic.
+// Reference: modules/layers.py:12-44,126-144 (UNetDown / UNetUp / ResidualBlock),
+// modules/__init__.py:66-69 (InstanceNorm2d(affine=False, track_running_stats=False)).
+#include "hip_util.h"
+
+namespace swn {
+
+namespace {
+
+constexpr float IN_EPS = 1e-5f;
+
+__device__ __forceinline__ float act_grad_from_in(float v, int act) {
+  switch (act) {
+    case ACT_LRELU: return v > 0.f ? 1.f : 0.2f;
+    case ACT_RELU: return v > 0.f ? 1.f : 0.f;
+    case ACT_TANH: { const float th = tanhf(v); return 1.f - th * th; }
+    default: return 1.f;
+  }
+}
+
+struct NAp {
+  const float* x; int xcs;
+  float* y; int ycs;            // fwd: y ; bwd: dx
+  const float* dy; int dycs;    // bwd only
+  const float* res; int rescs;  // fwd residual
+  float* stats;                 // [N][C][2]
+  double* partial;              // [N][nchunk][C][2]
+  float* sums;                  // bwd: [N][C][2] = mean(dxh), mean(dxh*xh)
+  int N, HW, C, nchunk, chunk;
+  int norm, act;
+  float drop_p; uint64_t seed;
+};
+
+// partial sums over a pixel chunk: mode 0 -> (sum x, sum x^2); mode 1 -> (sum dxh, sum dxh*xh)
+template <int MODE>
+__global__ __launch_bounds__(256) void in_partial_kernel(NAp p) {
+  __shared__ double red[256 * 8];
+  const int C4 = p.C >> 2;
+  const int rows = 256 / C4;
+  const int t = threadIdx.x, tx = t % C4, ty = t / C4;
+  const int n = blockIdx.y, ch = blockIdx.x;
+  const int c0 = ch * p.chunk, c1 = min(p.HW, c0 + p.chunk);
+  double s[4] = {0, 0, 0, 0}, ss[4] = {0, 0, 0, 0};
+  if (ty < rows) {
+    float mean[4] = {0, 0, 0, 0}, rstd[4] = {1, 1, 1, 1};
+    if (MODE == 1 && p.norm) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        mean[j] = p.stats[((size_t)n * p.C + tx * 4 + j) * 2];
+        rstd[j] = p.stats[((size_t)n * p.C + tx * 4 + j) * 2 + 1];
+      }
+    }
+    for (int pix = c0 + ty; pix < c1; pix += rows) {
+      const size_t e = (size_t)n * p.HW + pix;
+      const float4 xv = *reinterpret_cast<const float4*>(p.x + e * p.xcs + tx * 4);
+      const float xa[4] = {xv.x, xv.y, xv.z, xv.w};
+      if (MODE == 0) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { s[j] += xa[j]; ss[j] += (double)xa[j] * xa[j]; }
+      } else {
+        const float4 gv = *reinterpret_cast<const float4*>(p.dy + e * p.dycs + tx * 4);
+        const float ga[4] = {gv.x, gv.y, gv.z, gv.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float xh = (xa[j] - mean[j]) * rstd[j];
+          float g = ga[j] * act_grad_from_in(xh, p.act);
+          if (p.drop_p > 0.f) g *= drop_scale(p.seed, e * p.C + tx * 4 + j, p.drop_p);
+          s[j] += g; ss[j] += (double)g * xh;
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { red[t * 8 + j] = s[j]; red[t * 8 + 4 + j] = ss[j]; }
+  __syncthreads();
+  if (ty == 0) {
+    for (int r = 1; r < rows; ++r)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) red[t * 8 + j] += red[(r * C4 + tx) * 8 + j];
+    double* o = p.partial + (((size_t)n * p.nchunk + ch) * p.C + tx * 4) * 2;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { o[j * 2] = red[t * 8 + j]; o[j * 2 + 1] = red[t * 8 + 4 + j]; }
+  }
+}
+
+template <int MODE>
+__global__ void in_finalize_kernel(NAp p) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;     // over N*C
+  if (i >= p.N * p.C) return;
+  const int n = i / p.C, c = i - n * p.C;
+  double a = 0, b = 0;
+  for (int ch = 0; ch < p.nchunk; ++ch) {
+    const double* o = p.partial + (((size_t)n * p.nchunk + ch) * p.C + c) * 2;
+    a += o[0]; b += o[1];
+  }
+  if (MODE == 0) {
+    const double mean = a / p.HW;
+    double var = b / p.HW - mean * mean;
+    if (var < 0) var = 0;
+    p.stats[(size_t)i * 2] = (float)mean;
+    p.stats[(size_t)i * 2 + 1] = (float)(1.0 / sqrt(var + (double)IN_EPS));
+  } else {
+    p.sums[(size_t)i * 2] = (float)(a / p.HW);
+    p.sums[(size_t)i * 2 + 1] = (float)(b / p.HW);
+  }
+}
+
+__global__ __launch_bounds__(256) void norm_act_apply_kernel(NAp p) {
+  const int C4 = p.C >> 2;
+  const size_t total = (size_t)p.N * p.HW * C4;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t e = i / C4;
+    const int c = (int)(i - e * C4) * 4;
+    const int n = (int)(e / p.HW);
+    const float4 xv = *reinterpret_cast<const float4*>(p.x + e * p.xcs + c);
+    float v[4] = {xv.x, xv.y, xv.z, xv.w};
+    if (p.norm) {
+      const float4 s0 = *reinterpret_cast<const float4*>(p.stats + ((size_t)n * p.C + c) * 2);
+      const float4 s1 = *reinterpret_cast<const float4*>(p.stats + ((size_t)n * p.C + c) * 2 + 4);
+      v[0] = (v[0] - s0.x) * s0.y; v[1] = (v[1] - s0.z) * s0.w;
+      v[2] = (v[2] - s1.x) * s1.y; v[3] = (v[3] - s1.z) * s1.w;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      v[j] = act_apply(v[j], p.act);
+      if (p.drop_p > 0.f) v[j] *= drop_scale(p.seed, e * p.C + c + j, p.drop_p);
+    }
+    if (p.res) {
+      const float4 r = *reinterpret_cast<const float4*>(p.res + e * p.rescs + c);
+      v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w;
+    }
+    *reinterpret_cast<float4*>(p.y + e * p.ycs + c) = make_float4(v[0], v[1], v[2], v[3]);
+  }
+}
+
+__global__ __launch_bounds__(256) void norm_act_bwd_apply_kernel(NAp p) {
+  const int C4 = p.C >> 2;
+  const size_t total = (size_t)p.N * p.HW * C4;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t e = i / C4;
+    const int c = (int)(i - e * C4) * 4;
+    const int n = (int)(e / p.HW);
+    const float4 xv = *reinterpret_cast<const float4*>(p.x + e * p.xcs + c);
+    const float4 gv = *reinterpret_cast<const float4*>(p.dy + e * p.dycs + c);
+    const float xa[4] = {xv.x, xv.y, xv.z, xv.w};
+    const float ga[4] = {gv.x, gv.y, gv.z, gv.w};
+    float o[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float mean = 0.f, rstd = 1.f, m1 = 0.f, m2 = 0.f;
+      if (p.norm) {
+        mean = p.stats[((size_t)n * p.C + c + j) * 2];
+        rstd = p.stats[((size_t)n * p.C + c + j) * 2 + 1];
+        m1 = p.sums[((size_t)n * p.C + c + j) * 2];
+        m2 = p.sums[((size_t)n * p.C + c + j) * 2 + 1];
+      }
+      const float xh = (xa[j] - mean) * rstd;
+      float g = ga[j] * act_grad_from_in(xh, p.act);
+      if (p.drop_p > 0.f) g *= drop_scale(p.seed, e * p.C + c + j, p.drop_p);
+      o[j] = p.norm ? rstd * (g - m1 - xh * m2) : g;
+    }
+    *reinterpret_cast<float4*>(p.y + e * p.ycs + c) = make_float4(o[0], o[1], o[2], o[3]);
+  }
+}
+
+struct EWp {
+  const float* a; int acs;
+  const float* b; int bcs;
+  float* o; int ocs;
+  size_t pixels; int C;
+  int act; int accumulate; float alpha; float shift;
+};
+
+// MODE 0: o = act(a);  1: o (+)= a * act'(.) expressed through b = the activation OUTPUT;  2: o (+)= alpha*a
+template <int MODE>
+__global__ __launch_bounds__(256) void ew_kernel(EWp p) {
+  const int C4 = p.C >> 2;
+  const size_t total = p.pixels * C4;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t e = i / C4;
+    const int c = (int)(i - e * C4) * 4;
+    const float4 av = *reinterpret_cast<const float4*>(p.a + e * p.acs + c);
+    float v[4] = {av.x, av.y, av.z, av.w};
+    if (MODE == 0) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = act_apply(v[j], p.act);
+    } else if (MODE == 1) {
+      const float4 bv = *reinterpret_cast<const float4*>(p.b + e * p.bcs + c);
+      v[0] *= act_grad_from_out(bv.x, p.act); v[1] *= act_grad_from_out(bv.y, p.act);
+      v[2] *= act_grad_from_out(bv.z, p.act); v[3] *= act_grad_from_out(bv.w, p.act);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = v[j] * p.alpha + p.shift;
+    }
+    float* dst = p.o + e * p.ocs + c;
+    if (MODE != 0 && p.accumulate) {
+      const float4 d = *reinterpret_cast<const float4*>(dst);
+      v[0] += d.x; v[1] += d.y; v[2] += d.z; v[3] += d.w;
+    }
+    *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+  }
+}
+
+// column sums of dy (bias gradient): stage 1 per pixel-chunk partials (fp64), stage 2 sum
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const float* dy, int cs, size_t pixels, int C,
+                                                             size_t chunk, double* partial) {
+  __shared__ double red[256 * 4];
+  const int C4 = C >> 2, rows = 256 / C4;
+  const int t = threadIdx.x, tx = t % C4, ty = t / C4;
+  const size_t p0 = (size_t)blockIdx.x * chunk, p1 = min(pixels, p0 + chunk);
+  double s[4] = {0, 0, 0, 0};
+  if (ty < rows)
+    for (size_t e = p0 + ty; e < p1; e += rows) {
+      const float4 v = *reinterpret_cast<const float4*>(dy + e * cs + tx * 4);
+      s[0] += v.x; s[1] += v.y; s[2] += v.z; s[3] += v.w;
+    }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) red[t * 4 + j] = s[j];
+  __syncthreads();
+  if (ty == 0) {
+    for (int r = 1; r < rows; ++r)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) red[t * 4 + j] += red[(r * C4 + tx) * 4 + j];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) partial[(size_t)blockIdx.x * C + tx * 4 + j] = red[t * 4 + j];
+  }
+}
+__global__ void colsum_final_kernel(const double* partial, int nchunk, int C, float* out) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double a = 0;
+  for (int i = 0; i < nchunk; ++i) a += partial[(size_t)i * C + c];
+  out[c] = (float)a;
+}
+
+__global__ __launch_bounds__(256) void reflect_fold_kernel(const float* src, int scs, float* dst, int dcs, int N,
+                                                           int H, int W, int C, int accumulate) {
+  const int C4 = C >> 2;
+  const size_t total = (size_t)N * H * W * C4;
+  const int Hp = H + 2, Wp = W + 2;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t e = i / C4;
+    const int c = (int)(i - e * C4) * 4;
+    const int n = (int)(e / ((size_t)H * W));
+    const int rem = (int)(e - (size_t)n * H * W);
+    const int y = rem / W, x = rem - y * W;
+    // padded coordinates u with reflect(u-1) == y : u = y+1, plus u=0 when y==1, u=H+1 when y==H-2
+    // (H,W >= 4 so the two border rows never fold onto the same row)
+    int ys[2], xs[2], ny = 1, nx = 1;
+    ys[0] = y + 1; xs[0] = x + 1;
+    if (y == 1) ys[ny++] = 0;
+    if (y == H - 2) ys[ny++] = H + 1;
+    if (x == 1) xs[nx++] = 0;
+    if (x == W - 2) xs[nx++] = W + 1;
+    float4 acc = make_float4(0, 0, 0, 0);
+    for (int a = 0; a < ny; ++a)
+      for (int b = 0; b < nx; ++b) {
+        const float4 v = *reinterpret_cast<const float4*>(src + ((size_t)(n * Hp + ys[a]) * Wp + xs[b]) * scs + c);
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+      }
+    float* d = dst + e * dcs + c;
+    if (accumulate) {
+      const float4 o = *reinterpret_cast<const float4*>(d);
+      acc.x += o.x; acc.y += o.y; acc.z += o.z; acc.w += o.w;
+    }
+    *reinterpret_cast<float4*>(d) = acc;
+  }
+}
+
+inline unsigned ew_grid(size_t total) {
+  size_t b = (total + 255) / 256;
+  return (unsigned)std::min<size_t>(std::max<size_t>(b, 1), 256 * 16);
+}
+
+void check_view4(const TView& v, const char* what) {
+  if (v.C % 4 || v.cs % 4 || ((uintptr_t)v.p & 15)) throw Error(1, std::string(what) + ": view not 16-byte tileable");
+}
+
+void plan_chunks(int HW, int N, int C, int& nchunk, int& chunk) {
+  const int rows = std::max(1, 256 / (C / 4));
+  int want = std::max(1, 1024 / std::max(N, 1));                   // ~1024 blocks in flight
+  int maxchunks = std::max(1, HW / std::max(rows * 4, 1));          // >= 4 pixels per thread row
+  nchunk = std::min(std::min(want, maxchunks), 256);
+  chunk = ceil_div(HW, nchunk);
+  nchunk = ceil_div(HW, chunk);
+}
+
+}  // namespace
+
+void norm_act_fwd(Stream& s, const NormActArgs& a) {
+  check_view4(a.x, "norm_act_fwd x"); check_view4(a.y, "norm_act_fwd y");
+  if (a.x.C > 1024) throw Error(1, "norm_act: C > 1024 unsupported");
+  NAp p{};
+  p.x = a.x.p; p.xcs = a.x.cs; p.y = a.y.p; p.ycs = a.y.cs;
+  p.res = a.residual ? a.residual->p : nullptr; p.rescs = a.residual ? a.residual->cs : 0;
+  p.stats = a.stats; p.N = a.x.N; p.HW = a.x.H * a.x.W; p.C = a.x.C;
+  p.norm = a.norm; p.act = a.act; p.drop_p = a.drop_p; p.seed = a.seed;
+  if (a.norm) {
+    if (!a.stats) throw Error(1, "norm_act_fwd: stats buffer required");
+    plan_chunks(p.HW, p.N, p.C, p.nchunk, p.chunk);
+    p.partial = reinterpret_cast<double*>(s.ws);
+    if ((size_t)p.N * p.nchunk * p.C * 16 > s.ws_bytes) throw Error(1, "norm_act: workspace too small");
+    hipLaunchKernelGGL(in_partial_kernel<0>, dim3(p.nchunk, p.N), dim3(256), 0, hs(s), p);
+    hipLaunchKernelGGL(in_finalize_kernel<0>, dim3(ceil_div(p.N * p.C, 256)), dim3(256), 0, hs(s), p);
+  }
+  hipLaunchKernelGGL(norm_act_apply_kernel, dim3(ew_grid((size_t)p.N * p.HW * (p.C / 4))), dim3(256), 0, hs(s), p);
+  check_launch("norm_act_fwd");
+}
+
+void norm_act_bwd(Stream& s, const NormActBwdArgs& a) {
+  check_view4(a.x, "norm_act_bwd x"); check_view4(a.dy, "norm_act_bwd dy"); check_view4(a.dx, "norm_act_bwd dx");
+  NAp p{};
+  p.x = a.x.p; p.xcs = a.x.cs; p.dy = a.dy.p; p.dycs = a.dy.cs; p.y = a.dx.p; p.ycs = a.dx.cs;
+  p.stats = const_cast<float*>(a.stats); p.N = a.x.N; p.HW = a.x.H * a.x.W; p.C = a.x.C;
+  p.norm = a.norm; p.act = a.act; p.drop_p = a.drop_p; p.seed = a.seed;
+  if (a.norm) {
+    plan_chunks(p.HW, p.N, p.C, p.nchunk, p.chunk);
+    p.partial = reinterpret_cast<double*>(s.ws);
+    const size_t pbytes = (size_t)p.N * p.nchunk * p.C * 16;
+    p.sums = reinterpret_cast<float*>(s.ws + round_up((int)pbytes, 256));
+    if (pbytes + 256 + (size_t)p.N * p.C * 8 > s.ws_bytes) throw Error(1, "norm_act: workspace too small");
+    hipLaunchKernelGGL(in_partial_kernel<1>, dim3(p.nchunk, p.N), dim3(256), 0, hs(s), p);
+    hipLaunchKernelGGL(in_finalize_kernel<1>, dim3(ceil_div(p.N * p.C, 256)), dim3(256), 0, hs(s), p);
+  }
+  hipLaunchKernelGGL(norm_act_bwd_apply_kernel, dim3(ew_grid((size_t)p.N * p.HW * (p.C / 4))), dim3(256), 0, hs(s), p);
+  check_launch("norm_act_bwd");
+}
+
+static EWp ew_params(const TView& a, const TView* b, const TView& o) {
+  check_view4(a, "elementwise a"); check_view4(o, "elementwise out");
+  if (b) check_view4(*b, "elementwise b");
+  if (a.pixels() != o.pixels() || a.C != o.C) throw Error(1, "elementwise: shape mismatch");
+  EWp p{};
+  p.a = a.p; p.acs = a.cs; p.b = b ? b->p : nullptr; p.bcs = b ? b->cs : 0;
+  p.o = o.p; p.ocs = o.cs; p.pixels = a.pixels(); p.C = a.C; p.alpha = 1.f;
+  return p;
+}
+
+void act_fwd(Stream& s, const TView& x, const TView& y, int act) {
+  EWp p = ew_params(x, nullptr, y); p.act = act;
+  hipLaunchKernelGGL(ew_kernel<0>, dim3(ew_grid(p.pixels * (p.C / 4))), dim3(256), 0, hs(s), p);
+  check_launch("act_fwd");
+}
+void act_bwd(Stream& s, const TView& dy, const TView& y, const TView& dx, int act, int accumulate) {
+  EWp p = ew_params(dy, &y, dx); p.act = act; p.accumulate = accumulate;
+  hipLaunchKernelGGL(ew_kernel<1>, dim3(ew_grid(p.pixels * (p.C / 4))), dim3(256), 0, hs(s), p);
+  check_launch("act_bwd");
+}
+void axpy(Stream& s, const TView& src, const TView& dst, float alpha, int accumulate, float shift) {
+  EWp p = ew_params(src, nullptr, dst); p.alpha = alpha; p.accumulate = accumulate; p.shift = shift;
+  hipLaunchKernelGGL(ew_kernel<2>, dim3(ew_grid(p.pixels * (p.C / 4))), dim3(256), 0, hs(s), p);
+  check_launch("axpy");
+}
+
+void bias_grad(Stream& s, const TView& dy, float* db) {
+  check_view4(dy, "bias_grad dy");
+  const size_t pixels = dy.pixels();
+  const int rows = std::max(1, 256 / (dy.C / 4));
+  int nchunk = (int)std::min<size_t>(1024, std::max<size_t>(1, pixels / (rows * 4)));
+  const size_t chunk = (pixels + nchunk - 1) / nchunk;
+  nchunk = (int)((pixels + chunk - 1) / chunk);
+  double* partial = reinterpret_cast<double*>(s.ws);
+  if ((size_t)nchunk * dy.C * 8 > s.ws_bytes) throw Error(1, "bias_grad: workspace too small");
+  hipLaunchKernelGGL(colsum_partial_kernel, dim3(nchunk), dim3(256), 0, hs(s), dy.p, dy.cs, pixels, dy.C, chunk, partial);
+  hipLaunchKernelGGL(colsum_final_kernel, dim3(ceil_div(dy.C, 256)), dim3(256), 0, hs(s), partial, nchunk, dy.C, db);
+  check_launch("bias_grad");
+}
+
+void reflect_fold(Stream& s, const TView& dxpad, const TView& dx, int accumulate) {
+  check_view4(dxpad, "reflect_fold src"); check_view4(dx, "reflect_fold dst");
+  if (dxpad.H != dx.H + 2 || dxpad.W != dx.W + 2 || dxpad.C != dx.C || dx.H < 4 || dx.W < 4)
+    throw Error(1, "reflect_fold: shape mismatch");
+  hipLaunchKernelGGL(reflect_fold_kernel, dim3(ew_grid(dx.pixels() * (dx.C / 4))), dim3(256), 0, hs(s), dxpad.p,
+                     dxpad.cs, dx.p, dx.cs, dx.N, dx.H, dx.W, dx.C, accumulate);
+  check_launch("reflect_fold");
+}
+
+}  // namespace swn

@@ -1,0 +1,176 @@
+// swapnet_amd -- device op launchers.  The engine (engine.cpp) is written against this
+// header only.  The product implementation is the set of HIP translation units in this
+// directory (conv_gemm.hip, norm_act.hip, losses.hip, optim.hip, gather.hip).
+// tests/hostsim/hostsim_ops.cpp implements the same signatures with plain loops so that
+// the engine's graph / backward / packing logic can be checked in CI without a GPU; it is
+// never part of the shipped library.
+#pragma once
+#include "common.h"
+
+namespace swn {
+
+struct Stream {
+  void* handle = nullptr;   // hipStream_t
+  char* ws = nullptr;       // scratch for split-K slabs / reduction partials (device)
+  size_t ws_bytes = 0;
+};
+
+// ---- memory -------------------------------------------------------------------------
+void* dev_alloc(size_t bytes);            // zero-filled
+void dev_free(void* p);
+void dev_memset(Stream& s, void* p, int v, size_t bytes);
+void dev_copy(Stream& s, void* dst, const void* src, size_t bytes);        // device->device
+void dev_upload(Stream& s, void* dst, const void* src, size_t bytes);      // host->device
+void dev_download(Stream& s, void* dst, const void* src, size_t bytes);    // device->host (syncs)
+void stream_sync(Stream& s);
+void* stream_create(int device);          // selects the device, returns a new stream handle
+void stream_destroy(void* handle);
+int is_device_build();                    // 1: HIP library, 0: CI host simulator
+void conv_force_naive(int on);            // route conv_fwd/conv_wgrad to the naive checkers (tests)
+
+// ---- implicit-GEMM convolution (MFMA) -----------------------------------------------
+// y[map(m)][co] (=|+=) act( sum_k A[m][k] * w[k][co] + bias[co] ),  A = gather(x)
+struct ConvFwdArgs {
+  TView x;
+  Gather g;
+  const float* w = nullptr;   // [K = KH*KW*x.C][Npad]
+  int Npad = 0;
+  const float* bias = nullptr;
+  int act = ACT_NONE;
+  int accumulate = 0;         // 1: y += result (act must be NONE)
+  TView y;                    // y.C = Cout (logical), may be a slice
+  OutMap om;
+  int Cout = 0;               // valid output channels (<= Npad)
+};
+void conv_fwd(Stream& s, const ConvFwdArgs& a);
+
+// dw[k][co] = sum_m A[m][k] * dy[map(m)][co]      (dw: [K][Npad], overwritten)
+struct ConvWgradArgs {
+  TView x;
+  Gather g;
+  TView dy;
+  OutMap om;
+  float* dw = nullptr;
+  int Npad = 0;
+  int Cout = 0;
+};
+void conv_wgrad(Stream& s, const ConvWgradArgs& a);
+
+// reference implementations of the two launches above (one thread per output element,
+// no MFMA): used by tests to cross-check the tiled kernels at sizes the CPU cannot reach.
+void conv_fwd_naive(Stream& s, const ConvFwdArgs& a);
+void conv_wgrad_naive(Stream& s, const ConvWgradArgs& a);
+
+// db[c] = sum over pixels of dy[.,c]   (db overwritten)
+void bias_grad(Stream& s, const TView& dy, float* db);
+
+// dx[i] (+)= sum_{u: reflect(u-1)==i} dxpad[u]   -- folds the (H+2)x(W+2) gradient of a
+// ReflectionPad2d(1) back onto the HxW tensor.
+void reflect_fold(Stream& s, const TView& dxpad, const TView& dx, int accumulate);
+
+// ---- InstanceNorm / activation / dropout -------------------------------------------
+struct NormActArgs {
+  TView x;                    // raw conv output (dense)
+  TView y;                    // destination (may be a channel slice)
+  float* stats = nullptr;     // [N][C][2] (mean, rstd); written when norm
+  int norm = 1;
+  int act = ACT_NONE;
+  float drop_p = 0.f;         // 0 => no dropout
+  uint64_t seed = 0;          // dropout stream for this call (ignored if drop_p==0)
+  const TView* residual = nullptr;   // y = ... + residual
+};
+void norm_act_fwd(Stream& s, const NormActArgs& a);
+
+struct NormActBwdArgs {
+  TView dy;                   // grad wrt y (view, same geometry as y)
+  TView x;                    // raw conv output saved by forward (norm) or y itself (!norm)
+  const float* stats = nullptr;
+  TView dx;                   // grad wrt raw conv output (dense), overwritten
+  int norm = 1;
+  int act = ACT_NONE;
+  float drop_p = 0.f;
+  uint64_t seed = 0;
+};
+void norm_act_bwd(Stream& s, const NormActBwdArgs& a);
+
+// y = act(x) elementwise on views; bwd: dx (+)= dy * act'  (derivative expressed through the
+// activation OUTPUT y: lrelu y>0?1:.2, relu y>0, tanh 1-y^2)
+void act_fwd(Stream& s, const TView& x, const TView& y, int act);
+void act_bwd(Stream& s, const TView& dy, const TView& y, const TView& dx, int act, int accumulate);
+// dst (+)= alpha * src + shift   (views)
+void axpy(Stream& s, const TView& src, const TView& dst, float alpha, int accumulate, float shift = 0.f);
+
+// ---- resampling / gather ---------------------------------------------------------------
+void upsample_nearest_fwd(Stream& s, const TView& x, const TView& y, int factor);
+void upsample_nearest_bwd(Stream& s, const TView& dy, const TView& dx, int factor, int accumulate);
+void maxpool2_fwd(Stream& s, const TView& x, const TView& y);
+void maxpool2_bwd(Stream& s, const TView& dy, const TView& x, const TView& y, const TView& dx);
+// legacy RoIAlign (torchvision 0.4.0), sampling_ratio 1, spatial_scale 1.  tex: (B,H,W,C);
+// rois: device float [B*R][4] = x1,y1,x2,y2 (batch index = k / R); out: (B,PH,PW,R*C) with
+// channel index r*C + c (the reference's view(B,-1,PH,PW), swapnet_modules.py:237-240).
+void roi_align_fwd(Stream& s, const TView& tex, int C, const float* rois, int R, const TView& out);
+// bit-exact debug dump of the integer part: idx[k][ph][pw][4] = yl,yh,xl,xh ; valid[k][ph][pw]
+void roi_align_indices(Stream& s, const float* rois, int K, int H, int W, int PH, int PW,
+                       int32_t* idx, uint8_t* valid);
+
+// layout conversion at the Python boundary (NCHW fp32 <-> NHWC view)
+void nchw_to_nhwc(Stream& s, const float* src, int N, int C, int H, int W, const TView& dst);
+void nhwc_to_nchw(Stream& s, const TView& src, float* dst, int C);
+// integer work
+void decode_labels(Stream& s, const TView& x, int C, uint8_t* rgb_nchw);            // util/decode_labels.py
+void argmax_labels(Stream& s, const TView& x, int C, int32_t* labels);              // data_utils.py:322
+void labels_to_onehot(Stream& s, const int32_t* labels, const TView& y, int C);     // data_utils.py:330-343
+
+// ---- losses: each writes the plain MEAN loss into *loss_out (device float) and, if a grad
+// view is given, scale * d(mean loss)/dx into it (scale carries lambda and the 0.5 of loss_D).
+// BCEWithLogits(pred, label) mean over N*H*W of channel 0;  dpred = scale*(sigmoid-t)/numel
+void bce_logits_loss(Stream& s, const TView& pred, float label, float scale, float* loss_out,
+                     const TView* dpred);
+void lsgan_loss(Stream& s, const TView& pred, float label, float scale, float* loss_out, const TView* dpred);
+void wgan_loss(Stream& s, const TView& pred, float sign, float scale, float* loss_out, const TView* dpred);
+// CrossEntropy(logits, argmax_c(target)) mean over pixels; dlogits (+)= scale*(softmax-onehot)/P
+void ce_argmax_loss(Stream& s, const TView& logits, const TView& target, int C, float scale,
+                    float* loss_out, const TView* dlogits, int accumulate);
+void l1_loss(Stream& s, const TView& a, const TView& b, int C, float scale, float* loss_out,
+             const TView* da, int accumulate);
+// content term of PerceptualLoss for one VGG slice: MSE of channel-L2-normalised features
+void normed_mse_loss(Stream& s, const TView& f, const TView& t, float scale, float* loss_out,
+                     const TView* df, int accumulate);
+// style term: scale * MSE(Gram(a), Gram(b)), Gram over (N*C) x (H*W) of the raw images
+void gram_style_loss(Stream& s, const TView& a, const TView& b, int C, float scale, float* loss_out,
+                     const TView* da, int accumulate);
+// out[0] = a[0]*ca + b[0]*cb (device scalars; used to combine loss terms without a sync)
+void scalar_axpby(Stream& s, const float* a, float ca, const float* b, float cb, float* out);
+
+// ---- optimizer / parameter layout ------------------------------------------------------
+struct AdamWArgs {
+  float* p; const float* g; float* m; float* v; size_t n;
+  float lr, beta1, beta2, eps, weight_decay;
+  int step;   // 1-based
+};
+void adamw_step(Stream& s, const AdamWArgs& a);
+
+enum WKind : int { WK_CONV = 0, WK_CONVT = 1 };
+// Packed weight layouts (all [K][Npad], row-major):
+//  conv  (Co,Ci,KH,KW) : k = (kh*KW+kw)*Cip + ci , n = co
+//  convT (Ci,Co,4,4)   : 4 phase blocks p=(a*2+b) of k = (dy*2+dx)*Cip + ci , n = co,
+//                        tap (ky,kx) = (3-a-2dy, 3-b-2dx)
+struct WShape {
+  int kind, Co, Ci, KH, KW, Cip, Npad;
+  // optional device table [Cip]: buffer channel -> reference input channel (or -1 = zero pad);
+  // used where the NHWC buffer orders a torch.cat differently (D's conditional input).
+  const int32_t* cimap = nullptr;
+};
+size_t packed_elems(const WShape& w);
+void pack_weight(Stream& s, const WShape& w, const float* nchw, float* packed);
+void unpack_weight(Stream& s, const WShape& w, const float* packed, float* nchw);
+// dgrad operand derived from the forward-packed weights.  mode:
+//  0 conv stride-2 k4 : 4 phase blocks [ (dy*2+dx)*Cop + co ][ci]        (Ndg = Ci)
+//  1 conv stride-1    : [ ((KH-1-kh)*KW + (KW-1-kw))*Cop + co ][ci]
+//  2 convT k4 s2      : [ (ky*4+kx)*Cop + co ][ci]
+//  3 tail (x2 nearest upsample + ZeroPad(1,0,1,0) + conv k4 p1): 5x5 stride-2 effective
+//    kernel  [ (r*5+c)*Cop + co ][ci] = sum_{a-ky+3=r, b-kx+3=c; a,b in {0,1}} W[ky][kx]
+void repack_dgrad(Stream& s, const WShape& w, int mode, int Cop, int Ndgpad, const float* packed, float* dg);
+size_t dgrad_elems(const WShape& w, int mode, int Cop, int Ndgpad);
+
+}  // namespace swn

@@ -1,0 +1,237 @@
+"""Thin Python handles over the C-ABI objects (swn_ctx / swn_model).
+
+torch is used here only for device memory (tensors whose raw pointers are handed to the
+library) and, in swapnet_amd.parallel, for torch.distributed.  No arithmetic of the hot path
+happens in torch.
+"""
+import ctypes as C
+from collections import OrderedDict
+
+import torch
+
+from . import _C
+
+NET_G, NET_D, NET_VGG = 0, 1, 2
+W_WEIGHT, W_GRAD, W_EXP_AVG, W_EXP_AVG_SQ = 0, 1, 2, 3
+
+
+class Context:
+    """One per process / GPU (models/base_model.py:36-40 picks the device in the reference)."""
+
+    def __init__(self, device=None, lib=None, workspace_mb=512, use_torch_stream=True):
+        self.lib = lib or _C.lib()
+        if self.lib.is_device:
+            if not torch.cuda.is_available():
+                raise _C.SwapnetHipError("no HIP device visible; swapnet_amd has no CPU path")
+            self.device = torch.device("cuda", torch.cuda.current_device() if device is None else int(device))
+            torch.cuda.set_device(self.device)
+            stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream) if use_torch_stream else None
+            dev_index = self.device.index
+        else:                       # CI host simulator (tests only)
+            self.device = torch.device("cpu")
+            stream, dev_index = None, 0
+        h = C.c_void_p()
+        self.lib.call("swn_ctx_create", dev_index, stream, C.c_size_t(workspace_mb << 20), C.byref(h))
+        self.handle = h
+
+    def sync(self):
+        self.lib.call("swn_ctx_sync", self.handle)
+
+    def bytes_allocated(self):
+        n = C.c_size_t()
+        self.lib.call("swn_ctx_bytes_allocated", self.handle, C.byref(n))
+        return n.value
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.call("swn_ctx_destroy", self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+_default_ctx = {}
+
+
+def default_context(device=None, lib=None):
+    key = (id(lib) if lib is not None else 0, str(device))
+    if key not in _default_ctx:
+        _default_ctx[key] = Context(device=device, lib=lib)
+    return _default_ctx[key]
+
+
+class NativeModel:
+    """swn_model handle: generator (+ discriminator, optimizers) living in library-owned
+    NHWC arenas.  Tensors cross the boundary as NCHW fp32, exactly as the reference holds them."""
+
+    def __init__(self, ctx, kind, batch, height, width, is_train=True, dropout=0.5, num_roi=12):
+        self.ctx, self.lib, self.kind = ctx, ctx.lib, kind
+        self.B, self.H, self.W, self.is_train = batch, height, width, is_train
+        h = C.c_void_p()
+        if kind == "warp":
+            self.lib.call("swn_warp_model_create", ctx.handle, batch, height, width, int(is_train),
+                          C.c_float(dropout), C.byref(h))
+            self.out_channels = 19
+        elif kind == "texture":
+            self.lib.call("swn_texture_model_create", ctx.handle, batch, height, width, int(is_train), num_roi,
+                          C.byref(h))
+            self.out_channels = 3
+        else:
+            raise ValueError("unknown model kind " + kind)
+        self.handle = h
+        self._keep = []
+
+    # ---- parameters ---------------------------------------------------------------------
+    def param_infos(self, net):
+        n = C.c_int()
+        self.lib.call("swn_model_param_count", self.handle, net, C.byref(n))
+        out = OrderedDict()
+        buf = C.create_string_buffer(256)
+        for i in range(n.value):
+            shape = (C.c_int * 4)()
+            nd = C.c_int()
+            self.lib.call("swn_model_param_info", self.handle, net, i, buf, 256, C.byref(shape), C.byref(nd))
+            out[buf.value.decode()] = tuple(shape[: nd.value])
+        return out
+
+    def _dev(self, t):
+        return t.detach().to(device=self.ctx.device, dtype=torch.float32).contiguous()
+
+    def set_param(self, net, name, tensor, which=W_WEIGHT):
+        t = self._dev(tensor)
+        self.lib.call("swn_model_param_set", self.handle, net, which, name.encode(), _C.ptr(t))
+        self._sync_if_needed()
+
+    def get_param(self, net, name, shape, which=W_WEIGHT):
+        t = torch.empty(shape, dtype=torch.float32, device=self.ctx.device)
+        self.lib.call("swn_model_param_get", self.handle, net, which, name.encode(), _C.ptr(t))
+        self._sync_if_needed()
+        return t
+
+    def _sync_if_needed(self):
+        # the library runs on torch's current stream, so torch frees/reuses are ordered; a
+        # private stream would need an explicit sync before temporaries die
+        pass
+
+    def load_state_dict(self, net, sd, which=W_WEIGHT, strict=True):
+        infos = self.param_infos(net)
+        missing = [k for k in infos if k not in sd]
+        unexpected = [k for k in sd if k not in infos]
+        if strict and (missing or unexpected):
+            raise RuntimeError(f"Error(s) in loading state_dict: missing {missing}, unexpected {unexpected}")
+        for k, shape in infos.items():
+            if k in sd:
+                if tuple(sd[k].shape) != tuple(shape):
+                    raise RuntimeError(f"size mismatch for {k}: {tuple(sd[k].shape)} vs {tuple(shape)}")
+                self.set_param(net, k, sd[k], which)
+        self.ctx.sync()
+
+    def state_dict(self, net, which=W_WEIGHT, to_cpu=False):
+        out = OrderedDict()
+        for k, shape in self.param_infos(net).items():
+            t = self.get_param(net, k, shape, which)
+            out[k] = t.cpu() if to_cpu else t
+        self.ctx.sync()
+        return out
+
+    def optim_step_count(self, net, value=None):
+        if value is None:
+            n = C.c_int()
+            self.lib.call("swn_model_optim_step_get", self.handle, net, C.byref(n))
+            return n.value
+        self.lib.call("swn_model_optim_step_set", self.handle, net, int(value))
+
+    def set_hyper(self, **kw):
+        h = _C.SwnHyper(lr=1e-4, d_lr=4e-4, weight_decay=0.0, d_weight_decay=0.01, b1=0.9, b2=0.999,
+                        lambda_gan=1.0, lambda_ce=100.0, lambda_l1=10.0, lambda_content=20.0,
+                        lambda_style=1e-8, gan_mode=0, warp_mode_ce=0)
+        for k, v in kw.items():
+            setattr(h, k, v)
+        self.lib.call("swn_model_set_hyper", self.handle, C.byref(h))
+
+    # ---- data / step ----------------------------------------------------------------------
+    def set_input(self, slot, tensor):
+        t = self._dev(tensor)
+        if t.dim() == 3:                       # rois (B,R,4)
+            n, c, h, w = t.shape[0], t.shape[1], t.shape[2], 1
+        else:
+            n, c, h, w = t.shape
+        self.lib.call("swn_model_set_input", self.handle, slot, _C.ptr(t), n, c, h, w)
+        self._keep = [t]
+
+    def forward(self, training=False, seed=0):
+        self.lib.call("swn_model_forward", self.handle, int(training), C.c_uint64(seed))
+
+    def output(self, slot=0):
+        t = torch.empty((self.B, self.out_channels, self.H, self.W), dtype=torch.float32, device=self.ctx.device)
+        self.lib.call("swn_model_get_output", self.handle, slot, _C.ptr(t))
+        self.ctx.sync()
+        return t
+
+    def tap(self, net, name):
+        shape = (C.c_int * 4)()
+        self.lib.call("swn_model_get_tap", self.handle, net, name.encode(), None, C.byref(shape))
+        t = torch.empty(tuple(shape), dtype=torch.float32, device=self.ctx.device)
+        self.lib.call("swn_model_get_tap", self.handle, net, name.encode(), _C.ptr(t), C.byref(shape))
+        self.ctx.sync()
+        return t
+
+    def backward_D(self, label_fake, label_real):
+        self.lib.call("swn_model_backward_D", self.handle, C.c_float(label_fake), C.c_float(label_real))
+
+    def backward_G(self, label_real):
+        self.lib.call("swn_model_backward_G", self.handle, C.c_float(label_real))
+
+    def optimizer_step(self, net):
+        self.lib.call("swn_model_optimizer_step", self.handle, net)
+
+    def step(self, labels, training=True, seed=0):
+        arr = (C.c_float * 3)(*[float(x) for x in labels])
+        self.lib.call("swn_model_step", self.handle, C.byref(arr), int(training), C.c_uint64(seed))
+
+    def losses(self):
+        buf = (C.c_float * len(_C.LOSS_NAMES))()
+        self.lib.call("swn_model_get_losses", self.handle, C.cast(buf, C.POINTER(C.c_float)), len(_C.LOSS_NAMES))
+        return OrderedDict(zip(_C.LOSS_NAMES, [float(x) for x in buf]))
+
+    def grad_arena(self, net):
+        """Flat fp32 view of the net's gradient arena as a torch tensor (zero-copy on GPU)."""
+        p, n = C.c_void_p(), C.c_size_t()
+        self.lib.call("swn_model_grad_arena", self.handle, net, C.byref(p), C.byref(n))
+        return _wrap_pointer(p.value, n.value, self.ctx.device)
+
+    def weight_arena(self, net):
+        p, n = C.c_void_p(), C.c_size_t()
+        self.lib.call("swn_model_weight_arena", self.handle, net, C.byref(p), C.byref(n))
+        return _wrap_pointer(p.value, n.value, self.ctx.device)
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.call("swn_model_destroy", self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class _ArrayIface:
+    def __init__(self, ptr, n, cuda):
+        d = dict(shape=(n,), typestr="<f4", data=(ptr, False), version=2 if cuda else 3)
+        if cuda:
+            self.__cuda_array_interface__ = d
+        else:
+            self.__array_interface__ = d
+
+
+def _wrap_pointer(ptr, n, device):
+    if device.type == "cuda":
+        return torch.as_tensor(_ArrayIface(ptr, n, True), device=device)
+    import numpy as np
+    return torch.from_numpy(np.asarray(_ArrayIface(ptr, n, False)))

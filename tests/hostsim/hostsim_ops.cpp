@@ -1,0 +1,469 @@
+// TEST INFRASTRUCTURE ONLY -- never linked into libswapnet_hip.so, never loaded by the
+// swapnet_amd package.
+//
+// Plain-loop host implementation of swapnet_amd/csrc/ops.h.  Linked with the real
+// engine.cpp / nets.cpp / texture.cpp / capi.cpp it yields libswapnet_hostsim.so, which lets
+// the CPU-only CI (pytest -m "not gpu") check the engine's graph wiring, accumulate planner,
+// weight packing / dgrad re-packing and loss plumbing against the oracle at small sizes
+// without a GPU.  The loops are written independently of the HIP kernels (they do not share
+// index math), so they also serve as a second opinion on the gather geometry.
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "../../swapnet_amd/csrc/ops.h"
+
+namespace swn {
+
+void* dev_alloc(size_t bytes) { if (!bytes) bytes = 16; void* p = std::calloc(1, bytes); if (!p) throw Error(2, "hostsim: out of memory"); return p; }
+void dev_free(void* p) { std::free(p); }
+void dev_memset(Stream&, void* p, int v, size_t bytes) { std::memset(p, v, bytes); }
+void dev_copy(Stream&, void* d, const void* s, size_t b) { std::memcpy(d, s, b); }
+void dev_upload(Stream&, void* d, const void* s, size_t b) { std::memcpy(d, s, b); }
+void dev_download(Stream&, void* d, const void* s, size_t b) { std::memcpy(d, s, b); }
+void stream_sync(Stream&) {}
+void* stream_create(int) { return nullptr; }
+void stream_destroy(void*) {}
+int is_device_build() { return 0; }
+void conv_force_naive(int) {}
+
+static inline float actf(float v, int a) {
+  switch (a) { case ACT_LRELU: return v > 0 ? v : 0.2f * v; case ACT_RELU: return v > 0 ? v : 0.f;
+               case ACT_TANH: return std::tanh(v); default: return v; }
+}
+static inline float actg_in(float v, int a) {
+  switch (a) { case ACT_LRELU: return v > 0 ? 1.f : 0.2f; case ACT_RELU: return v > 0 ? 1.f : 0.f;
+               case ACT_TANH: { float t = std::tanh(v); return 1.f - t * t; } default: return 1.f; }
+}
+static inline float actg_out(float y, int a) {
+  switch (a) { case ACT_LRELU: return y > 0 ? 1.f : 0.2f; case ACT_RELU: return y > 0 ? 1.f : 0.f;
+               case ACT_TANH: return 1.f - y * y; default: return 1.f; }
+}
+static inline int srcc(int e, int ext, int mode, int ups) {
+  if (mode == PAD_REFLECT) { if (e < 0) e = -e; else if (e >= ext) e = 2 * ext - 2 - e; }
+  else if (e < 0 || e >= ext) return -1;
+  return e >> ups;
+}
+static inline float* at(const TView& v, int n, int y, int x) { return v.p + ((size_t)(n * v.H + y) * v.W + x) * v.cs; }
+
+void conv_fwd(Stream&, const ConvFwdArgs& a) {
+  const TView& X = a.x; const Gather& g = a.g;
+  const int He = X.H << g.ups, We = X.W << g.ups;
+#pragma omp parallel for collapse(2) schedule(static)
+  for (int n = 0; n < X.N; ++n)
+    for (int oy = 0; oy < g.Ho; ++oy) {
+      std::vector<double> acc(a.Cout);
+      for (int ox = 0; ox < g.Wo; ++ox) {
+        std::fill(acc.begin(), acc.end(), 0.0);
+        for (int kh = 0; kh < g.KH; ++kh)
+          for (int kw = 0; kw < g.KW; ++kw) {
+            const int sy = srcc(oy * g.stride - g.pad_t + kh, He, g.pad_mode, g.ups);
+            const int sx = srcc(ox * g.stride - g.pad_l + kw, We, g.pad_mode, g.ups);
+            if (sy < 0 || sx < 0) continue;
+            const float* xp = at(X, n, sy, sx);
+            const float* wp = a.w + (size_t)((kh * g.KW + kw) * X.C) * a.Npad;
+            for (int ci = 0; ci < X.C; ++ci) {
+              const float xv = xp[ci];
+              if (xv == 0.f) continue;
+              const float* wr = wp + (size_t)ci * a.Npad;
+              for (int co = 0; co < a.Cout; ++co) acc[co] += (double)xv * wr[co];
+            }
+          }
+        float* yp = at(a.y, n, oy * a.om.ymul + a.om.yoff, ox * a.om.xmul + a.om.xoff);
+        for (int co = 0; co < a.Cout; ++co) {
+          float v = (float)acc[co];
+          if (a.bias) v += a.bias[co];
+          v = actf(v, a.act);
+          if (a.accumulate) v += yp[co];
+          yp[co] = v;
+        }
+      }
+    }
+}
+void conv_fwd_naive(Stream& s, const ConvFwdArgs& a) { conv_fwd(s, a); }
+
+void conv_wgrad(Stream&, const ConvWgradArgs& a) {
+  const TView& X = a.x; const Gather& g = a.g;
+  const int He = X.H << g.ups, We = X.W << g.ups;
+  const int K = g.KH * g.KW * X.C;
+  std::vector<double> acc((size_t)K * a.Npad, 0.0);
+#pragma omp parallel
+  {
+    std::vector<double> loc((size_t)K * a.Npad, 0.0);
+#pragma omp for collapse(2) schedule(static) nowait
+    for (int n = 0; n < X.N; ++n)
+      for (int oy = 0; oy < g.Ho; ++oy)
+        for (int ox = 0; ox < g.Wo; ++ox) {
+          const float* dp = at(a.dy, n, oy * a.om.ymul + a.om.yoff, ox * a.om.xmul + a.om.xoff);
+          for (int kh = 0; kh < g.KH; ++kh)
+            for (int kw = 0; kw < g.KW; ++kw) {
+              const int sy = srcc(oy * g.stride - g.pad_t + kh, He, g.pad_mode, g.ups);
+              const int sx = srcc(ox * g.stride - g.pad_l + kw, We, g.pad_mode, g.ups);
+              if (sy < 0 || sx < 0) continue;
+              const float* xp = at(X, n, sy, sx);
+              double* lr = loc.data() + (size_t)((kh * g.KW + kw) * X.C) * a.Npad;
+              for (int ci = 0; ci < X.C; ++ci) {
+                const float xv = xp[ci];
+                if (xv == 0.f) continue;
+                double* l2 = lr + (size_t)ci * a.Npad;
+                for (int co = 0; co < a.Cout; ++co) l2[co] += (double)xv * dp[co];
+              }
+            }
+        }
+#pragma omp critical
+    for (size_t i = 0; i < acc.size(); ++i) acc[i] += loc[i];
+  }
+  for (size_t i = 0; i < acc.size(); ++i) a.dw[i] = (float)acc[i];
+}
+void conv_wgrad_naive(Stream& s, const ConvWgradArgs& a) { conv_wgrad(s, a); }
+
+void bias_grad(Stream&, const TView& dy, float* db) {
+  std::vector<double> acc(dy.C, 0.0);
+  for (size_t e = 0; e < dy.pixels(); ++e)
+    for (int c = 0; c < dy.C; ++c) acc[c] += dy.p[e * dy.cs + c];
+  for (int c = 0; c < dy.C; ++c) db[c] = (float)acc[c];
+}
+
+void reflect_fold(Stream&, const TView& sp, const TView& d, int accumulate) {
+  const int H = d.H, W = d.W;
+  if (!accumulate)
+    for (size_t e = 0; e < d.pixels(); ++e) std::memset(d.p + e * d.cs, 0, d.C * sizeof(float));
+  for (int n = 0; n < d.N; ++n)
+    for (int u = 0; u < H + 2; ++u)
+      for (int v = 0; v < W + 2; ++v) {
+        int y = u - 1, x = v - 1;
+        if (y < 0) y = -y; else if (y >= H) y = 2 * H - 2 - y;
+        if (x < 0) x = -x; else if (x >= W) x = 2 * W - 2 - x;
+        const float* s = at(sp, n, u, v);
+        float* o = at(d, n, y, x);
+        for (int c = 0; c < d.C; ++c) o[c] += s[c];
+      }
+}
+
+static inline float hdrop(uint64_t seed, uint64_t idx, float p) {
+  uint64_t z = seed * 0xD1342543DE82EF95ull + idx + 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; z ^= z >> 31;
+  const float u = (float)((uint32_t)(z >> 11) & 0xFFFFFFu) * (1.0f / 16777216.0f);
+  return u >= p ? 1.0f / (1.0f - p) : 0.0f;
+}
+
+void norm_act_fwd(Stream&, const NormActArgs& a) {
+  const int N = a.x.N, HW = a.x.H * a.x.W, C = a.x.C;
+  for (int n = 0; n < N; ++n)
+    for (int c = 0; c < C; ++c) {
+      float mean = 0.f, rstd = 1.f;
+      if (a.norm) {
+        double s = 0, ss = 0;
+        for (int p = 0; p < HW; ++p) { const double v = a.x.p[((size_t)n * HW + p) * a.x.cs + c]; s += v; ss += v * v; }
+        const double m = s / HW; double var = ss / HW - m * m; if (var < 0) var = 0;
+        mean = (float)m; rstd = (float)(1.0 / std::sqrt(var + 1e-5));
+        a.stats[((size_t)n * C + c) * 2] = mean; a.stats[((size_t)n * C + c) * 2 + 1] = rstd;
+      }
+      for (int p = 0; p < HW; ++p) {
+        const size_t e = (size_t)n * HW + p;
+        float v = (a.x.p[e * a.x.cs + c] - mean) * rstd;
+        v = actf(v, a.act);
+        if (a.drop_p > 0.f) v *= hdrop(a.seed, e * C + c, a.drop_p);
+        if (a.residual) v += a.residual->p[e * a.residual->cs + c];
+        a.y.p[e * a.y.cs + c] = v;
+      }
+    }
+}
+void norm_act_bwd(Stream&, const NormActBwdArgs& a) {
+  const int N = a.x.N, HW = a.x.H * a.x.W, C = a.x.C;
+  for (int n = 0; n < N; ++n)
+    for (int c = 0; c < C; ++c) {
+      float mean = 0.f, rstd = 1.f;
+      if (a.norm) { mean = a.stats[((size_t)n * C + c) * 2]; rstd = a.stats[((size_t)n * C + c) * 2 + 1]; }
+      double s1 = 0, s2 = 0;
+      std::vector<float> gh(HW), xh(HW);
+      for (int p = 0; p < HW; ++p) {
+        const size_t e = (size_t)n * HW + p;
+        xh[p] = (a.x.p[e * a.x.cs + c] - mean) * rstd;
+        float g = a.dy.p[e * a.dy.cs + c] * actg_in(xh[p], a.act);
+        if (a.drop_p > 0.f) g *= hdrop(a.seed, e * C + c, a.drop_p);
+        gh[p] = g; s1 += g; s2 += (double)g * xh[p];
+      }
+      const float m1 = (float)(s1 / HW), m2 = (float)(s2 / HW);
+      for (int p = 0; p < HW; ++p) {
+        const size_t e = (size_t)n * HW + p;
+        a.dx.p[e * a.dx.cs + c] = a.norm ? rstd * (gh[p] - m1 - xh[p] * m2) : gh[p];
+      }
+    }
+}
+
+void act_fwd(Stream&, const TView& x, const TView& y, int act) {
+  for (size_t e = 0; e < x.pixels(); ++e)
+    for (int c = 0; c < x.C; ++c) y.p[e * y.cs + c] = actf(x.p[e * x.cs + c], act);
+}
+void act_bwd(Stream&, const TView& dy, const TView& y, const TView& dx, int act, int accumulate) {
+  for (size_t e = 0; e < dy.pixels(); ++e)
+    for (int c = 0; c < dy.C; ++c) {
+      float v = dy.p[e * dy.cs + c] * actg_out(y.p[e * y.cs + c], act);
+      if (accumulate) v += dx.p[e * dx.cs + c];
+      dx.p[e * dx.cs + c] = v;
+    }
+}
+void axpy(Stream&, const TView& src, const TView& dst, float alpha, int accumulate, float shift) {
+  for (size_t e = 0; e < src.pixels(); ++e)
+    for (int c = 0; c < src.C; ++c) {
+      float v = src.p[e * src.cs + c] * alpha + shift;
+      if (accumulate) v += dst.p[e * dst.cs + c];
+      dst.p[e * dst.cs + c] = v;
+    }
+}
+
+void upsample_nearest_fwd(Stream&, const TView& x, const TView& y, int f) {
+  for (int n = 0; n < y.N; ++n) for (int oy = 0; oy < y.H; ++oy) for (int ox = 0; ox < y.W; ++ox)
+    std::memcpy(at(y, n, oy, ox), at(x, n, oy / f, ox / f), x.C * sizeof(float));
+}
+void upsample_nearest_bwd(Stream&, const TView& dy, const TView& dx, int f, int accumulate) {
+  for (int n = 0; n < dx.N; ++n) for (int iy = 0; iy < dx.H; ++iy) for (int ix = 0; ix < dx.W; ++ix) {
+    float* o = at(dx, n, iy, ix);
+    for (int c = 0; c < dx.C; ++c) {
+      float s = 0;
+      for (int a = 0; a < f; ++a) for (int b = 0; b < f; ++b) s += at(dy, n, iy * f + a, ix * f + b)[c];
+      o[c] = accumulate ? o[c] + s : s;
+    }
+  }
+}
+void maxpool2_fwd(Stream&, const TView& x, const TView& y) {
+  for (int n = 0; n < y.N; ++n) for (int oy = 0; oy < y.H; ++oy) for (int ox = 0; ox < y.W; ++ox)
+    for (int c = 0; c < y.C; ++c) {
+      float m = at(x, n, oy * 2, ox * 2)[c];
+      for (int t = 1; t < 4; ++t) { const float v = at(x, n, oy * 2 + (t >> 1), ox * 2 + (t & 1))[c]; if (v > m) m = v; }
+      at(y, n, oy, ox)[c] = m;
+    }
+}
+void maxpool2_bwd(Stream&, const TView& dy, const TView& x, const TView& y, const TView& dx) {
+  for (int n = 0; n < y.N; ++n) for (int oy = 0; oy < y.H; ++oy) for (int ox = 0; ox < y.W; ++ox)
+    for (int c = 0; c < y.C; ++c) {
+      float m = at(x, n, oy * 2, ox * 2)[c]; int am = 0;
+      for (int t = 1; t < 4; ++t) { const float v = at(x, n, oy * 2 + (t >> 1), ox * 2 + (t & 1))[c]; if (v > m) { m = v; am = t; } }
+      for (int t = 0; t < 4; ++t) at(dx, n, oy * 2 + (t >> 1), ox * 2 + (t & 1))[c] = t == am ? at(dy, n, oy, ox)[c] : 0.f;
+    }
+}
+
+struct RoiS { int yl, yh, xl, xh; float w1, w2, w3, w4; bool valid; };
+static RoiS roi_s(const float* roi, int ph, int pw, int PH, int PW, int H, int W) {
+  RoiS r;
+  volatile float sw = roi[0], sh = roi[1], ew = roi[2], eh = roi[3];
+  volatile float rw = std::fmax((float)(ew - sw), 1.0f), rh = std::fmax((float)(eh - sh), 1.0f);
+  volatile float bw = rw / (float)PW, bh = rh / (float)PH;
+  volatile float t1 = (float)ph * bh, t2 = 0.5f * bh; volatile float t3 = t2 / 1.0f; volatile float t4 = sh + t1;
+  float y = t4 + t3;
+  volatile float u1 = (float)pw * bw, u2 = 0.5f * bw; volatile float u3 = u2 / 1.0f; volatile float u4 = sw + u1;
+  float x = u4 + u3;
+  r.valid = !(y < -1.0f || y > (float)H || x < -1.0f || x > (float)W);
+  y = std::fmax(y, 0.f); x = std::fmax(x, 0.f);
+  int yl = (int)y, xl = (int)x, yh, xh;
+  if (yl >= H - 1) { yh = yl = H - 1; y = (float)yl; } else yh = yl + 1;
+  if (xl >= W - 1) { xh = xl = W - 1; x = (float)xl; } else xh = xl + 1;
+  volatile float ly = y - (float)yl, lx = x - (float)xl; volatile float hy = 1.f - ly, hx = 1.f - lx;
+  r.yl = yl; r.yh = yh; r.xl = xl; r.xh = xh;
+  volatile float w1 = hy * hx, w2 = hy * lx, w3 = ly * hx, w4 = ly * lx;
+  r.w1 = w1; r.w2 = w2; r.w3 = w3; r.w4 = w4;
+  return r;
+}
+void roi_align_fwd(Stream&, const TView& tex, int C, const float* rois, int R, const TView& out) {
+  for (int b = 0; b < tex.N; ++b) for (int r = 0; r < R; ++r) for (int ph = 0; ph < out.H; ++ph) for (int pw = 0; pw < out.W; ++pw) {
+    const RoiS s = roi_s(rois + ((size_t)b * R + r) * 4, ph, pw, out.H, out.W, tex.H, tex.W);
+    float* o = at(out, b, ph, pw) + r * C;
+    for (int c = 0; c < C; ++c) {
+      float v = 0.f;
+      if (s.valid) {
+        volatile float a1 = s.w1 * at(tex, b, s.yl, s.xl)[c], a2 = s.w2 * at(tex, b, s.yl, s.xh)[c];
+        volatile float a3 = s.w3 * at(tex, b, s.yh, s.xl)[c], a4 = s.w4 * at(tex, b, s.yh, s.xh)[c];
+        volatile float s12 = a1 + a2; volatile float s123 = s12 + a3;
+        v = s123 + a4;
+      }
+      o[c] = v;
+    }
+  }
+}
+void roi_align_indices(Stream&, const float* rois, int K, int H, int W, int PH, int PW, int32_t* idx, uint8_t* valid) {
+  for (int k = 0; k < K; ++k) for (int ph = 0; ph < PH; ++ph) for (int pw = 0; pw < PW; ++pw) {
+    const RoiS s = roi_s(rois + (size_t)k * 4, ph, pw, PH, PW, H, W);
+    const size_t i = ((size_t)k * PH + ph) * PW + pw;
+    idx[i * 4] = s.yl; idx[i * 4 + 1] = s.yh; idx[i * 4 + 2] = s.xl; idx[i * 4 + 3] = s.xh; valid[i] = s.valid;
+  }
+}
+
+void nchw_to_nhwc(Stream&, const float* src, int N, int C, int H, int W, const TView& dst) {
+  const int HW = H * W;
+  for (int n = 0; n < N; ++n) for (int c = 0; c < C; ++c) for (int p = 0; p < HW; ++p)
+    dst.p[((size_t)n * HW + p) * dst.cs + c] = src[((size_t)n * C + c) * HW + p];
+}
+void nhwc_to_nchw(Stream&, const TView& src, float* dst, int C) {
+  const int HW = src.H * src.W;
+  for (int n = 0; n < src.N; ++n) for (int c = 0; c < C; ++c) for (int p = 0; p < HW; ++p)
+    dst[((size_t)n * C + c) * HW + p] = src.p[((size_t)n * HW + p) * src.cs + c];
+}
+static const uint8_t kPal[19][3] = {{0,0,0},{128,0,0},{255,0,0},{0,85,0},{255,85,0},{0,0,85},{0,119,221},{85,85,0},{0,85,85},
+  {85,51,0},{52,86,128},{0,128,0},{0,0,255},{51,170,221},{0,255,255},{85,255,170},{170,255,85},{255,255,0},{255,170,0}};
+static int amax(const float* p, int C) { int b = 0; float m = p[0]; for (int c = 1; c < C; ++c) if (p[c] > m) { m = p[c]; b = c; } return b; }
+void decode_labels(Stream&, const TView& x, int C, uint8_t* rgb) {
+  const int HW = x.H * x.W;
+  for (int n = 0; n < x.N; ++n) for (int p = 0; p < HW; ++p) {
+    const int b = amax(x.p + ((size_t)n * HW + p) * x.cs, C);
+    for (int ch = 0; ch < 3; ++ch) rgb[((size_t)n * 3 + ch) * HW + p] = b < 19 ? kPal[b][ch] : 0;
+  }
+}
+void argmax_labels(Stream&, const TView& x, int C, int32_t* labels) {
+  for (size_t e = 0; e < x.pixels(); ++e) labels[e] = amax(x.p + e * x.cs, C);
+}
+void labels_to_onehot(Stream&, const int32_t* labels, const TView& y, int C) {
+  for (size_t e = 0; e < y.pixels(); ++e)
+    for (int c = 0; c < C; ++c) y.p[e * y.cs + c] = (c == labels[e] && labels[e] != 0) ? 1.f : 0.f;
+}
+
+// ---- losses ----------------------------------------------------------------------------
+static void gan(const TView& pred, float label, float scale, float* out, const TView* dp, int mode) {
+  const size_t n = pred.pixels(); double acc = 0;
+  for (size_t i = 0; i < n; ++i) {
+    const float x = pred.p[i * pred.cs]; float l, g;
+    if (mode == 0) { l = std::fmax(x, 0.f) - x * label + std::log1p(std::exp(-std::fabs(x))); g = 1.f / (1.f + std::exp(-x)) - label; }
+    else if (mode == 1) { const float d = x - label; l = d * d; g = 2 * d; }
+    else { l = label * x; g = label; }
+    acc += l;
+    if (dp) dp->p[i * dp->cs] = g * scale / (float)n;
+  }
+  *out = (float)(acc / n);
+}
+void bce_logits_loss(Stream&, const TView& p, float l, float s, float* o, const TView* d) { gan(p, l, s, o, d, 0); }
+void lsgan_loss(Stream&, const TView& p, float l, float s, float* o, const TView* d) { gan(p, l, s, o, d, 1); }
+void wgan_loss(Stream&, const TView& p, float l, float s, float* o, const TView* d) { gan(p, l, s, o, d, 2); }
+
+void ce_argmax_loss(Stream&, const TView& lg, const TView& tg, int C, float scale, float* out, const TView* dl, int accumulate) {
+  const size_t P = lg.pixels(); double acc = 0;
+  for (size_t e = 0; e < P; ++e) {
+    const float* lp = lg.p + e * lg.cs; const float* tp = tg.p + e * tg.cs;
+    const int label = amax(tp, C);
+    float lmax = lp[0]; for (int c = 1; c < C; ++c) lmax = std::fmax(lmax, lp[c]);
+    float se = 0; for (int c = 0; c < C; ++c) se += std::exp(lp[c] - lmax);
+    acc += (lmax + std::log(se)) - lp[label];
+    if (dl) { float* dp = dl->p + e * dl->cs;
+      for (int c = 0; c < C; ++c) { float g = (std::exp(lp[c] - lmax) / se - (c == label)) * scale / (float)P; dp[c] = accumulate ? dp[c] + g : g; } }
+  }
+  *out = (float)(acc / P);
+}
+void l1_loss(Stream&, const TView& a, const TView& b, int C, float scale, float* out, const TView* da, int accumulate) {
+  const size_t P = a.pixels(); double acc = 0; const float n = (float)(P * C);
+  for (size_t e = 0; e < P; ++e) for (int c = 0; c < C; ++c) {
+    const float d = a.p[e * a.cs + c] - b.p[e * b.cs + c]; acc += std::fabs(d);
+    if (da) { float g = (d > 0 ? 1.f : d < 0 ? -1.f : 0.f) * scale / n; float* dp = da->p + e * da->cs + c; *dp = accumulate ? *dp + g : g; }
+  }
+  *out = (float)(acc / n);
+}
+void normed_mse_loss(Stream&, const TView& f, const TView& t, float scale, float* out, const TView* df, int accumulate) {
+  const size_t P = f.pixels(); const int C = f.C; double acc = 0; const float numel = (float)(P * C);
+  std::vector<float> g(C);
+  for (size_t e = 0; e < P; ++e) {
+    const float* fp = f.p + e * f.cs; const float* tp = t.p + e * t.cs;
+    float sf = 0, st = 0; for (int c = 0; c < C; ++c) { sf += fp[c] * fp[c]; st += tp[c] * tp[c]; }
+    sf = std::sqrt(sf); st = std::sqrt(st);
+    const float inf = 1.f / (sf + 1e-8f), intt = 1.f / (st + 1e-8f);
+    float dot = 0;
+    for (int c = 0; c < C; ++c) { g[c] = fp[c] * inf - tp[c] * intt; acc += (double)g[c] * g[c]; dot += g[c] * fp[c]; }
+    if (df) { const float k2 = sf > 0 ? dot * inf * inf / sf : 0.f; float* dp = df->p + e * df->cs;
+      for (int c = 0; c < C; ++c) { float o = (g[c] * inf - fp[c] * k2) * 2.f * scale / numel; dp[c] = accumulate ? dp[c] + o : o; } }
+  }
+  *out = (float)(acc / numel);
+}
+void gram_style_loss(Stream&, const TView& a, const TView& b, int C, float scale, float* out, const TView* da, int accumulate) {
+  const int R = a.N * C, HW = a.H * a.W;
+  std::vector<double> Ga((size_t)R * R, 0.0), Gb((size_t)R * R, 0.0);
+  auto val = [&](const TView& v, int r, int p) { return v.p[((size_t)(r / C) * HW + p) * v.cs + (r % C)]; };
+  for (int r1 = 0; r1 < R; ++r1) for (int r2 = 0; r2 < R; ++r2) { double s1 = 0, s2 = 0;
+    for (int p = 0; p < HW; ++p) { s1 += (double)val(a, r1, p) * val(a, r2, p); s2 += (double)val(b, r1, p) * val(b, r2, p); }
+    Ga[(size_t)r1 * R + r2] = s1; Gb[(size_t)r1 * R + r2] = s2; }
+  double acc = 0; std::vector<float> dG((size_t)R * R);
+  for (size_t i = 0; i < Ga.size(); ++i) { const double d = Ga[i] - Gb[i]; acc += d * d; dG[i] = (float)(2.0 * d) * scale / (float)(R * R); }
+  *out = (float)(acc / ((double)R * R));
+  if (da) for (int p = 0; p < HW; ++p) for (int r = 0; r < R; ++r) { float s = 0;
+    for (int r2 = 0; r2 < R; ++r2) s += (dG[(size_t)r * R + r2] + dG[(size_t)r2 * R + r]) * val(a, r2, p);
+    float* dp = da->p + ((size_t)(r / C) * HW + p) * da->cs + (r % C); *dp = accumulate ? *dp + s : s; }
+}
+void scalar_axpby(Stream&, const float* a, float ca, const float* b, float cb, float* out) {
+  out[0] = (a ? a[0] * ca : 0.f) + (b ? b[0] * cb : 0.f);
+}
+
+// ---- optimizer / layouts -----------------------------------------------------------------
+void adamw_step(Stream&, const AdamWArgs& a) {
+  const double bc1 = 1.0 - std::pow((double)a.beta1, a.step), bc2 = 1.0 - std::pow((double)a.beta2, a.step);
+  const float decay = 1.f - a.lr * a.weight_decay, ss = (float)(a.lr / bc1), isb = (float)(1.0 / std::sqrt(bc2));
+  for (size_t i = 0; i < a.n; ++i) {
+    float p = a.p[i] * decay;
+    const float m = a.m[i] * a.beta1 + (1.f - a.beta1) * a.g[i];
+    const float v = a.v[i] * a.beta2 + (1.f - a.beta2) * a.g[i] * a.g[i];
+    p -= ss * (m / (std::sqrt(v) * isb + a.eps));
+    a.p[i] = p; a.m[i] = m; a.v[i] = v;
+  }
+}
+size_t packed_elems(const WShape& w) {
+  return w.kind == WK_CONV ? (size_t)w.KH * w.KW * w.Cip * w.Npad : (size_t)16 * w.Cip * w.Npad;
+}
+static int refch(const WShape& w, int cb) { return w.cimap ? w.cimap[cb] : (cb < w.Ci ? cb : -1); }
+void pack_weight(Stream&, const WShape& w, const float* src, float* dst) {
+  std::memset(dst, 0, packed_elems(w) * sizeof(float));
+  for (int cb = 0; cb < w.Cip; ++cb) {
+    const int ci = refch(w, cb);
+    if (ci < 0) continue;
+    for (int co = 0; co < w.Co; ++co) for (int ky = 0; ky < w.KH; ++ky) for (int kx = 0; kx < w.KW; ++kx) {
+      if (w.kind == WK_CONV) {
+        dst[((size_t)(ky * w.KW + kx) * w.Cip + cb) * w.Npad + co] = src[(((size_t)co * w.Ci + ci) * w.KH + ky) * w.KW + kx];
+      } else {   // out[2i+a] += in[i + a - 1 + dy] * W[3 - a - 2dy]
+        const int a = (3 - ky) & 1, dy = (3 - ky) >> 1, b = (3 - kx) & 1, dx = (3 - kx) >> 1;
+        dst[((size_t)(a * 2 + b) * 4 * w.Cip + (dy * 2 + dx) * w.Cip + cb) * w.Npad + co] =
+            src[(((size_t)ci * w.Co + co) * 4 + ky) * 4 + kx];
+      }
+    }
+  }
+}
+void unpack_weight(Stream&, const WShape& w, const float* src, float* dst) {
+  for (int cb = 0; cb < w.Cip; ++cb) {
+    const int ci = refch(w, cb);
+    if (ci < 0) continue;
+    for (int co = 0; co < w.Co; ++co) for (int ky = 0; ky < w.KH; ++ky) for (int kx = 0; kx < w.KW; ++kx) {
+      if (w.kind == WK_CONV) {
+        dst[(((size_t)co * w.Ci + ci) * w.KH + ky) * w.KW + kx] = src[((size_t)(ky * w.KW + kx) * w.Cip + cb) * w.Npad + co];
+      } else {
+        const int a = (3 - ky) & 1, dy = (3 - ky) >> 1, b = (3 - kx) & 1, dx = (3 - kx) >> 1;
+        dst[(((size_t)ci * w.Co + co) * 4 + ky) * 4 + kx] =
+            src[((size_t)(a * 2 + b) * 4 * w.Cip + (dy * 2 + dx) * w.Cip + cb) * w.Npad + co];
+      }
+    }
+  }
+}
+size_t dgrad_elems(const WShape& w, int mode, int Cop, int Ndg) {
+  switch (mode) { case 0: return (size_t)16 * Cop * Ndg; case 1: return (size_t)w.KH * w.KW * Cop * Ndg;
+                  case 2: return (size_t)16 * Cop * Ndg; default: return (size_t)25 * Cop * Ndg; }
+}
+// source-indexed scatter (the HIP kernel is destination-indexed)
+void repack_dgrad(Stream&, const WShape& w, int mode, int Cop, int Ndg, const float* src, float* dg) {
+  std::memset(dg, 0, dgrad_elems(w, mode, Cop, Ndg) * sizeof(float));
+  auto W = [&](int ky, int kx, int ci, int co) -> float {
+    if (w.kind == WK_CONV) return src[((size_t)(ky * w.KW + kx) * w.Cip + ci) * w.Npad + co];
+    const int a = (3 - ky) & 1, dy = (3 - ky) >> 1, b = (3 - kx) & 1, dx = (3 - kx) >> 1;
+    return src[((size_t)(a * 2 + b) * 4 * w.Cip + (dy * 2 + dx) * w.Cip + ci) * w.Npad + co];
+  };
+  for (int ky = 0; ky < w.KH; ++ky) for (int kx = 0; kx < w.KW; ++kx) for (int ci = 0; ci < w.Cip; ++ci) for (int co = 0; co < w.Co; ++co) {
+    const float v = W(ky, kx, ci, co);
+    if (mode == 0) {          // dX[2i+a] += dY[i + a - 1 + dy] * W[3 - a - 2dy]
+      const int a = (3 - ky) & 1, dy = (3 - ky) >> 1, b = (3 - kx) & 1, dx = (3 - kx) >> 1;
+      dg[((size_t)(a * 2 + b) * 4 * Cop + (dy * 2 + dx) * Cop + co) * Ndg + ci] = v;
+    } else if (mode == 1) {
+      dg[((size_t)((w.KH - 1 - ky) * w.KW + (w.KW - 1 - kx)) * Cop + co) * Ndg + ci] = v;
+    } else if (mode == 2) {
+      dg[((size_t)(ky * 4 + kx) * Cop + co) * Ndg + ci] = v;
+    } else {                  // tail: tap r = a - ky + 3 for a in {0,1}
+      for (int a = 0; a < 2; ++a) for (int b = 0; b < 2; ++b) {
+        const int r = a - ky + 3, c = b - kx + 3;
+        dg[((size_t)(r * 5 + c) * Cop + co) * Ndg + ci] += v;
+      }
+    }
+  }
+}
+
+}  // namespace swn
