@@ -1,0 +1,196 @@
+#!/usr/bin/env python
+"""bench.py -- images/sec of the full warp-stage G+D step (BaseGAN.optimize_parameters,
+models/base_gan.py:194-203 of the reference) at 256x256, bs 32 per GPU, fp32, on N MI355X.
+
+    python bench.py --gpus 1 --steps 10 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" = forward, backward_D, AdamW(D), backward_G, AdamW(G) on one synthetic batch that is
+already resident in HBM (config C2 of BASELINE.json: "Warp stage, 256x256 synthetic, bs=32,
+1xMI355X, fp32").  Train mode (dropout on), random-init weights of the reference architecture
+(kaiming, the reference's default), smooth GAN labels redrawn every step like the reference.
+N > 1: pure data parallel, weak scaling (bs 32 per GPU), RCCL all-reduce of the two flat
+gradient arenas; the D exchange overlaps with D1-forward/G-side work, the G exchange is
+issued right after backward_G.
+
+Prints ONE JSON line (rank 0).  Extra objects:
+  roofline     -- dominant kernel family (conv_fwd 128x128 MFMA tile): algorithmic FLOPs
+                  (2*M*N*K per launch) / HIP-event time of those launches vs the 157.3 TFLOP/s
+                  fp32 MFMA peak; `step_frac` = whole-step algorithmic FLOPs (251.34 GFLOP/img,
+                  BASELINE.md section 3) / step time / peak.
+  cpu_baseline -- the CPU oracle (a port of the reference step, oracle/swapnet_oracle.py) timed
+                  on this box's host cores on a bounded sample (N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+GFLOP_PER_IMG_256 = 251.34          # BASELINE.md section 3 (dense-conv definition)
+PEAK_FP32_MFMA_TFLOPS = 157.3       # MI355X_MICROARCH.md "Peak FP32 (matrix)"
+
+
+def cpu_baseline(sample_bs=4, size=256, warm=1, timed=2):
+    """Oracle = functional port of the reference's WarpModel step on torch CPU ("kind": "port")."""
+    from oracle import swapnet_oracle as O
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    torch.manual_seed(0)
+    G, D = O.warp_module_params(), O.patchgan_params(22)
+    batch = O.synth_warp_batch(sample_bs, size, size, seed=1234)
+    st = O.WarpStepOracle(G, D, training=True)
+    for _ in range(warm):
+        st.step(*batch)
+    t0 = time.time()
+    for _ in range(timed):
+        st.step(*batch)
+    dt = (time.time() - t0) / timed
+    return {"value": round(sample_bs / dt, 4), "unit": "images/sec", "cores": cores, "kind": "port",
+            "sample": f"warp G+D step {size}x{size} bs {sample_bs}, {warm} warm-up + {timed} timed steps, "
+                      f"torch {torch.__version__} CPU fp32, {cores} threads"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=32, help="per-GPU batch (config C2: 32)")
+    ap.add_argument("--size", type=int, default=256)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    from swapnet_amd import _C, engine, parallel, synthetic
+    from swapnet_amd.modules import init_tensor
+
+    rank, world = parallel.init_from_env()
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (swapnet_amd has no CPU path)")
+    torch.cuda.set_device(local_rank)
+    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    import torch.distributed as dist
+
+    ctx = engine.Context(device=local_rank, workspace_mb=1024)
+    B, S = args.batch, args.size
+    model = engine.NativeModel(ctx, "warp", B, S, S, is_train=True, dropout=0.5)
+    torch.manual_seed(0)                                   # identical init on every rank
+    for net in (engine.NET_G, engine.NET_D):
+        sd = {}
+        for name, shape in model.param_infos(net).items():
+            sd[name] = torch.zeros(shape) if name.endswith(".bias") else init_tensor(torch.empty(shape), "kaiming")
+        model.load_state_dict(net, sd)
+    model.set_hyper(grad_scale=1.0 / world)
+    batch = synthetic.warp_batch(B, S, S, seed=1234 + rank)
+    model.set_input(0, batch["bodys"]); model.set_input(1, batch["input_cloths"]); model.set_input(2, batch["target_cloths"])
+    gG, gD = model.grad_arena(engine.NET_G), model.grad_arena(engine.NET_D)
+    xchg = parallel.GradExchange(world)
+    label_rng = torch.Generator().manual_seed(4321)        # same on every rank (SURVEY.md 8(e) caveat 2)
+
+    def draw_labels():
+        # GANLoss smooth labels: real AND fake drawn from U(0.7, 1.1) (modules/loss.py:93,102)
+        return [float(torch.rand(1, generator=label_rng) * 0.4 + 0.7) for _ in range(3)]
+
+    step_no = [0]
+
+    def one_step():
+        lab = draw_labels()
+        step_no[0] += 1
+        seed = step_no[0] * 1000 + rank
+        if world == 1:
+            model.step(lab, training=True, seed=seed)
+            return
+        model.forward(True, seed)
+        model.backward_D(lab[0], lab[1])
+        xchg.allreduce_mean(gD)
+        model.optimizer_step(engine.NET_D)
+        model.backward_G(lab[2])
+        xchg.allreduce_mean(gG)
+        model.optimizer_step(engine.NET_G)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        one_step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one_step()
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    losses = model.losses()
+    ms = dt / args.steps * 1e3
+    ips = world * B * args.steps / dt
+    flop_per_img = GFLOP_PER_IMG_256 * 1e9 * (S * S) / (256 * 256)
+
+    out = {
+        "metric": "images/sec full G+D step, warp-stage 256x256 bs=32/GPU",
+        "value": round(ips, 3), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"warp-stage G+D optimize_parameters step, {S}x{S}, bs {B}/GPU, fp32, "
+                               f"train mode (dropout 0.5), WarpModule 137.6M + PatchGAN 2.8M params, AdamW",
+                   "global_batch": world * B, "parallelism": f"dp{world}"},
+        "losses_finite": all(v == v and abs(v) < 1e30 for v in losses.values()),
+    }
+
+    if rank == 0 and not args.no_roofline:
+        # HIP events around every implicit-GEMM launch, on the stream they are launched on
+        ctx.lib.call("swn_prof_reset")
+        ctx.lib.call("swn_prof_enable", 1)
+        nprof = 2
+        for _ in range(nprof):
+            lab = draw_labels()
+            model.step(lab, training=True, seed=99) if world == 1 else (
+                model.forward(True, 99), model.backward_D(lab[0], lab[1]), model.backward_G(lab[2]))
+        torch.cuda.synchronize()
+        ctx.lib.call("swn_prof_enable", 0)
+        import ctypes
+        need = ctx.lib.dll.swn_prof_report(None, 0)
+        buf = ctypes.create_string_buffer(need + 16)
+        ctx.lib.dll.swn_prof_report(buf, need + 16)
+        kernels = {}
+        for line in buf.value.decode().splitlines():
+            name, n, tms, fl = line.split()
+            kernels[name] = {"launches": int(float(n)), "ms": float(tms), "flops": float(fl)}
+        ctx.lib.call("swn_prof_reset")
+        dom = max(kernels, key=lambda k: kernels[k]["ms"]) if kernels else None
+        if dom:
+            k = kernels[dom]
+            ach = k["flops"] / (k["ms"] * 1e-3) / 1e12
+            gemm_ms = sum(v["ms"] for v in kernels.values()) / nprof
+            out["roofline"] = {
+                "bound": "mfma", "kernel": dom, "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS,
+                "unit": "TFLOP/s", "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+                "avg_launch_ms": round(k["ms"] / k["launches"], 4), "launches_per_step": k["launches"] // nprof,
+                "step_frac": round(flop_per_img * B / (ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
+                "gemm_ms_per_step": round(gemm_ms, 2),
+                "all_gemm_kernels": {n: {"tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2),
+                                         "ms_per_step": round(v["ms"] / nprof, 3)} for n, v in sorted(kernels.items())},
+            }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline()
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

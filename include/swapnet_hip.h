@@ -37,12 +37,21 @@ int swn_is_device_build(void);
 
 /* ---- context ------------------------------------------------------------------------
  * replaces BaseModel.__init__'s device selection (models/base_model.py:36-40).
- * `hip_stream` may be NULL (the library creates its own stream) or an existing hipStream_t
- * (e.g. torch.cuda.current_stream().cuda_stream) so torch-side copies stay ordered. */
-int swn_ctx_create(int device, void* hip_stream, size_t workspace_bytes, swn_ctx** out);
+ * create_stream == 0: all work is enqueued on `hip_stream` exactly as given -- pass
+ * torch.cuda.current_stream().cuda_stream so torch-side copies / allocator reuse stay ordered
+ * with the library's kernels (NULL is the legacy default stream, which IS torch's default).
+ * create_stream != 0: the library creates and owns a private non-blocking stream. */
+int swn_ctx_create(int device, void* hip_stream, int create_stream, size_t workspace_bytes, swn_ctx** out);
 int swn_ctx_destroy(swn_ctx* ctx);
 int swn_ctx_sync(swn_ctx* ctx);
 int swn_ctx_bytes_allocated(swn_ctx* ctx, size_t* out);
+
+/* per-launch timing of the implicit-GEMM kernels with HIP events on the context's stream
+ * (bench.py's roofline leg).  report: one line per kernel variant "<name> <launches> <total_ms>
+ * <total_flops>"; returns the number of bytes the full report needs. */
+int swn_prof_enable(int on);
+int swn_prof_reset(void);
+int swn_prof_report(char* buf, int len);
 
 /* ---- models ---------------------------------------------------------------------------
  * swn_warp_model_create    <-> models.create_model(opt) with --model warp
@@ -65,6 +74,8 @@ typedef struct swn_hyper {
   float lambda_gan, lambda_ce, lambda_l1, lambda_content, lambda_style;
   int gan_mode;      /* 0 vanilla, 1 lsgan, 2 wgan */
   int warp_mode_ce;  /* 1 = --warp_mode ce (generator only) */
+  float grad_scale;  /* multiplies every loss gradient: 1/world_size under data parallelism so the
+                        RCCL all-reduce(SUM) of the arenas yields the mean without an extra pass */
 } swn_hyper;
 int swn_model_set_hyper(swn_model* m, const swn_hyper* h);
 

@@ -18,7 +18,7 @@ LOSS_NAMES = ("D", "D_real", "D_fake", "G", "G_gan", "G_ce", "G_l1", "G_content"
 class SwnHyper(C.Structure):
     _fields_ = [(n, C.c_float) for n in ("lr", "d_lr", "weight_decay", "d_weight_decay", "b1", "b2",
                                          "lambda_gan", "lambda_ce", "lambda_l1", "lambda_content",
-                                         "lambda_style")] + [("gan_mode", C.c_int), ("warp_mode_ce", C.c_int)]
+                                         "lambda_style")] + [("gan_mode", C.c_int), ("warp_mode_ce", C.c_int), ("grad_scale", C.c_float)]
 
 
 class SwapnetHipError(RuntimeError):
@@ -30,10 +30,13 @@ _vp, _fp, _i, _f = C.c_void_p, C.c_void_p, C.c_int, C.c_float     # device float
 _PROTOS = {
     "swn_abi_version": ([], _i),
     "swn_is_device_build": ([], _i),
-    "swn_ctx_create": ([_i, _vp, C.c_size_t, C.POINTER(_vp)], _i),
+    "swn_ctx_create": ([_i, _vp, _i, C.c_size_t, C.POINTER(_vp)], _i),
     "swn_ctx_destroy": ([_vp], _i),
     "swn_ctx_sync": ([_vp], _i),
     "swn_ctx_bytes_allocated": ([_vp, C.POINTER(C.c_size_t)], _i),
+    "swn_prof_enable": ([_i], _i),
+    "swn_prof_reset": ([], _i),
+    "swn_prof_report": ([C.c_char_p, _i], _i),
     "swn_warp_model_create": ([_vp, _i, _i, _i, _i, _f, C.POINTER(_vp)], _i),
     "swn_texture_model_create": ([_vp, _i, _i, _i, _i, _i, C.POINTER(_vp)], _i),
     "swn_model_destroy": ([_vp], _i),

@@ -43,12 +43,13 @@ int swn_abi_version(void) { return 1; }
 const char* swn_last_error(void) { return g_err.c_str(); }
 int swn_is_device_build(void) { return is_device_build(); }
 
-int swn_ctx_create(int device, void* hip_stream, size_t workspace_bytes, swn_ctx** out) {
+int swn_ctx_create(int device, void* hip_stream, int create_stream, size_t workspace_bytes, swn_ctx** out) {
   return guard([&] {
     REQUIRE(out, "swn_ctx_create: out is NULL");
     auto h = std::make_unique<swn_ctx>();
     void* st = hip_stream;
-    if (!st) { st = stream_create(device); h->owned_stream = st; }
+    if (create_stream) { st = stream_create(device); h->owned_stream = st; }
+    else device_check(device);
     if (workspace_bytes < (size_t)64 << 20) workspace_bytes = (size_t)64 << 20;
     h->c = std::make_unique<Ctx>(st, workspace_bytes);
     *out = h.release();
@@ -68,6 +69,10 @@ int swn_ctx_sync(swn_ctx* ctx) {
 int swn_ctx_bytes_allocated(swn_ctx* ctx, size_t* out) {
   return guard([&] { REQUIRE(ctx && out, "NULL argument"); *out = ctx->c->bytes_allocated; });
 }
+
+int swn_prof_enable(int on) { return guard([&] { prof_enable(on); }); }
+int swn_prof_reset(void) { return guard([&] { prof_reset(); }); }
+int swn_prof_report(char* buf, int len) { return prof_report(buf, len); }
 
 int swn_warp_model_create(swn_ctx* ctx, int batch, int height, int width, int is_train, float dropout,
                           swn_model** out) {
@@ -101,6 +106,7 @@ int swn_model_set_hyper(swn_model* m, const swn_hyper* h) {
     y.lambda_content = h->lambda_content; y.lambda_style = h->lambda_style;
     REQUIRE(h->gan_mode >= 0 && h->gan_mode <= 2, "gan mode not implemented");
     y.gan_mode = h->gan_mode; y.warp_mode_ce_only = h->warp_mode_ce;
+    y.grad_scale = h->grad_scale > 0.f ? h->grad_scale : 1.f;
   });
 }
 

@@ -19,6 +19,12 @@
 // row each, same k) hit 32 distinct banks on ds_read_b32; the W / dY tile is read along its
 // contiguous axis.  Small-M x large-K layers (cloth_down5/6, cloth_up1) are split along K
 // (wgrad: along pixels) into deterministic slabs that a reduce kernel sums in fixed order.
+#include <array>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <vector>
+
 #include "hip_util.h"
 
 namespace swn {
@@ -451,6 +457,52 @@ __global__ void conv_wgrad_naive_kernel(GemmP p) {
 }
 
 // ---------------------------------------------------------------------------------------
+// per-launch profiling (HIP events on the launch stream)
+// ---------------------------------------------------------------------------------------
+namespace {
+struct ProfRec { std::string name; double flops; hipEvent_t a, b; };
+int g_prof = 0;
+std::vector<ProfRec> g_recs;
+struct ProfScope {
+  hipStream_t st; bool on; ProfRec r;
+  ProfScope(const Stream& s, const char* name, double flops) : st(hs(s)), on(g_prof != 0) {
+    if (!on) return;
+    r.name = name; r.flops = flops;
+    (void)hipEventCreate(&r.a); (void)hipEventCreate(&r.b);
+    (void)hipEventRecord(r.a, st);
+  }
+  ~ProfScope() {
+    if (!on) return;
+    (void)hipEventRecord(r.b, st);
+    g_recs.push_back(r);
+  }
+};
+}  // namespace
+void prof_enable(int on) { g_prof = on; }
+void prof_reset() {
+  for (auto& r : g_recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+  g_recs.clear();
+}
+int prof_report(char* buf, int len) {
+  std::map<std::string, std::array<double, 3>> agg;
+  for (auto& r : g_recs) {
+    (void)hipEventSynchronize(r.b);
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, r.a, r.b);
+    auto& a = agg[r.name];
+    a[0] += 1; a[1] += ms; a[2] += r.flops;
+  }
+  std::string out;
+  for (auto& kv : agg) {
+    char line[256];
+    snprintf(line, sizeof line, "%s %.0f %.6f %.6e\n", kv.first.c_str(), kv.second[0], kv.second[1], kv.second[2]);
+    out += line;
+  }
+  if (buf && len > 0) { strncpy(buf, out.c_str(), len - 1); buf[len - 1] = 0; }
+  return (int)out.size();
+}
+
+// ---------------------------------------------------------------------------------------
 // host launchers
 // ---------------------------------------------------------------------------------------
 static GemmP make_params(const TView& x, const Gather& g, const TView& y, const OutMap& om) {
@@ -495,6 +547,9 @@ static void launch_fwd(Stream& s, GemmP& p, bool fast) {
   p.splits = ceil_div(nkb, p.per_split);
   p.slab = reinterpret_cast<float*>(s.ws);
   dim3 grid(p.ntiles, p.splits);
+  char pname[64];
+  snprintf(pname, sizeof pname, "conv_fwd_%dx%d_%s", T::BM, T::BN, fast ? "fast" : "generic");
+  ProfScope prof(s, pname, 2.0 * p.M * p.Cout * p.K);
   if (fast) {
     static bool once = (set_smem(conv_fwd_kernel<MT, NT, WGM, WGN, true>, T::SMEM_FWD), true);
     (void)once;
@@ -546,6 +601,9 @@ static void launch_wgrad(Stream& s, GemmP& p) {
   p.slab = reinterpret_cast<float*>(s.ws);
   static bool once = (set_smem(conv_wgrad_kernel<MT, NT, WGM, WGN>, T::SMEM_WG), true);
   (void)once;
+  char pname[64];
+  snprintf(pname, sizeof pname, "conv_wgrad_%dx%d", T::BM, T::BN);
+  ProfScope prof(s, pname, 2.0 * p.M * p.Cout * p.K);
   hipLaunchKernelGGL((conv_wgrad_kernel<MT, NT, WGM, WGN>), dim3(p.ntiles, p.splits), dim3(256), T::SMEM_WG, hs(s), p);
   check_launch("conv_wgrad");
   if (p.splits > 1) {

@@ -36,6 +36,13 @@ void* stream_create(int device) {
   SWN_HIP_CHECK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
   return (void*)st;
 }
+void device_check(int device) {
+  int count = 0;
+  SWN_HIP_CHECK(hipGetDeviceCount(&count));
+  if (count <= 0) throw Error(3, "swapnet_hip: no HIP device visible (this library has no CPU path)");
+  if (device < 0 || device >= count) throw Error(1, "swapnet_hip: bad device index");
+  SWN_HIP_CHECK(hipSetDevice(device));
+}
 void stream_destroy(void* h) {
   if (h) (void)hipStreamDestroy((hipStream_t)h);
 }

@@ -123,6 +123,7 @@ struct Hyper {
   float lambda_gan = 1.f, lambda_ce = 100.f, lambda_l1 = 10.f, lambda_content = 20.f, lambda_style = 1e-8f;
   int gan_mode = 0;          // 0 vanilla (BCE), 1 lsgan, 2 wgan
   int warp_mode_ce_only = 0; // --warp_mode ce
+  float grad_scale = 1.f;    // multiplies every loss gradient (1/world_size under data parallelism)
 };
 
 enum LossSlot {

@@ -213,8 +213,8 @@ class WarpModel final : public Model {
     TView pf = pred2.batch(0, B).v, pr = pred2.batch(B, B).v;
     TView gf = pred2.batch(0, B).g, gr = pred2.batch(B, B).g;
     // loss_D = 0.5 * (loss_D_fake + loss_D_real); lambda_discriminator is ignored here (:123)
-    gan_loss_op(s, hyper.gan_mode, pf, label_fake, false, 0.5f, losses + L_D_FAKE, &gf);
-    gan_loss_op(s, hyper.gan_mode, pr, label_real, true, 0.5f, losses + L_D_REAL, &gr);
+    gan_loss_op(s, hyper.gan_mode, pf, label_fake, false, 0.5f * hyper.grad_scale, losses + L_D_FAKE, &gf);
+    gan_loss_op(s, hyper.gan_mode, pr, label_real, true, 0.5f * hyper.grad_scale, losses + L_D_REAL, &gr);
     scalar_axpby(s, losses + L_D_FAKE, 0.5f, losses + L_D_REAL, 0.5f, losses + L_D);
     D2->backward(true, false);
   }
@@ -227,13 +227,13 @@ class WarpModel final : public Model {
       D1->refresh_dgrad();
       D1->training = false;
       D1->forward();                                   // D was just updated (base_gan.py:199)
-      gan_loss_op(s, hyper.gan_mode, pred1.v, label_real, true, hyper.lambda_gan, losses + L_TMP0, &pred1.g);
+      gan_loss_op(s, hyper.gan_mode, pred1.v, label_real, true, hyper.lambda_gan * hyper.grad_scale, losses + L_TMP0, &pred1.g);
       scalar_axpby(s, losses + L_TMP0, hyper.lambda_gan, nullptr, 0.f, losses + L_G_GAN);
       D1->backward(false, true);                       // D weight grads would be discarded (quirk 5)
-      ce_argmax_loss(s, fakes, targets, 19, hyper.lambda_ce, losses + L_TMP1, &dfakes, 1);
+      ce_argmax_loss(s, fakes, targets, 19, hyper.lambda_ce * hyper.grad_scale, losses + L_TMP1, &dfakes, 1);
     } else {
       dev_memset(s, losses + L_G_GAN, 0, sizeof(float));
-      ce_argmax_loss(s, fakes, targets, 19, hyper.lambda_ce, losses + L_TMP1, &dfakes, 0);
+      ce_argmax_loss(s, fakes, targets, 19, hyper.lambda_ce * hyper.grad_scale, losses + L_TMP1, &dfakes, 0);
     }
     scalar_axpby(s, losses + L_TMP1, hyper.lambda_ce, nullptr, 0.f, losses + L_G_CE);
     scalar_axpby(s, losses + L_G_GAN, 1.f, losses + L_G_CE, 1.f, losses + L_G);

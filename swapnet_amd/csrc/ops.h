@@ -25,8 +25,15 @@ void dev_download(Stream& s, void* dst, const void* src, size_t bytes);    // de
 void stream_sync(Stream& s);
 void* stream_create(int device);          // selects the device, returns a new stream handle
 void stream_destroy(void* handle);
+void device_check(int device);            // throws unless `device` is a usable HIP device; makes it current
 int is_device_build();                    // 1: HIP library, 0: CI host simulator
 void conv_force_naive(int on);            // route conv_fwd/conv_wgrad to the naive checkers (tests)
+// optional per-launch timing of the implicit-GEMM kernels (bench.py's roofline leg): when on,
+// every conv_fwd / conv_wgrad launch is bracketed by HIP events recorded on the launch stream.
+void prof_enable(int on);
+void prof_reset();
+// one line per kernel variant: "<name> <launches> <total_ms> <total_flops>\n"; returns bytes written
+int prof_report(char* buf, int len);
 
 // ---- implicit-GEMM convolution (MFMA) -----------------------------------------------
 // y[map(m)][co] (=|+=) act( sum_k A[m][k] * w[k][co] + bias[co] ),  A = gather(x)

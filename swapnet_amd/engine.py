@@ -25,13 +25,16 @@ class Context:
                 raise _C.SwapnetHipError("no HIP device visible; swapnet_amd has no CPU path")
             self.device = torch.device("cuda", torch.cuda.current_device() if device is None else int(device))
             torch.cuda.set_device(self.device)
-            stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream) if use_torch_stream else None
-            dev_index = self.device.index
+            # enqueue on torch's current stream: H2D copies, allocator reuse of the temporaries whose
+            # pointers we borrow, and RCCL collectives are then ordered with our kernels for free
+            self.torch_stream = torch.cuda.current_stream(self.device)
+            stream = C.c_void_p(self.torch_stream.cuda_stream)
+            dev_index, create = self.device.index, int(not use_torch_stream)
         else:                       # CI host simulator (tests only)
             self.device = torch.device("cpu")
-            stream, dev_index = None, 0
+            stream, dev_index, create = None, 0, 0
         h = C.c_void_p()
-        self.lib.call("swn_ctx_create", dev_index, stream, C.c_size_t(workspace_mb << 20), C.byref(h))
+        self.lib.call("swn_ctx_create", dev_index, stream, create, C.c_size_t(workspace_mb << 20), C.byref(h))
         self.handle = h
 
     def sync(self):
@@ -148,7 +151,7 @@ class NativeModel:
     def set_hyper(self, **kw):
         h = _C.SwnHyper(lr=1e-4, d_lr=4e-4, weight_decay=0.0, d_weight_decay=0.01, b1=0.9, b2=0.999,
                         lambda_gan=1.0, lambda_ce=100.0, lambda_l1=10.0, lambda_content=20.0,
-                        lambda_style=1e-8, gan_mode=0, warp_mode_ce=0)
+                        lambda_style=1e-8, gan_mode=0, warp_mode_ce=0, grad_scale=1.0)
         for k, v in kw.items():
             setattr(h, k, v)
         self.lib.call("swn_model_set_hyper", self.handle, C.byref(h))

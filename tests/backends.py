@@ -1,0 +1,42 @@
+"""Test helpers: the product (HIP) context and the CI-only host-simulator context."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HOSTSIM_DIR = os.path.join(REPO, "tests", "hostsim")
+HOSTSIM_SO = os.path.join(HOSTSIM_DIR, "build", "libswapnet_hostsim.so")
+_CSRC = os.path.join(REPO, "swapnet_amd", "csrc")
+_HOST_SOURCES = [os.path.join(_CSRC, f) for f in ("engine.cpp", "nets.cpp", "texture.cpp", "capi.cpp")] + \
+    [os.path.join(HOSTSIM_DIR, "hostsim_ops.cpp")]
+
+
+def build_hostsim():
+    deps = _HOST_SOURCES + [os.path.join(_CSRC, h) for h in ("ops.h", "common.h", "engine.h")]
+    if os.path.exists(HOSTSIM_SO) and all(os.path.getmtime(d) <= os.path.getmtime(HOSTSIM_SO) for d in deps):
+        return HOSTSIM_SO
+    os.makedirs(os.path.dirname(HOSTSIM_SO), exist_ok=True)
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-fopenmp", "-shared", "-o", HOSTSIM_SO] + _HOST_SOURCES)
+    return HOSTSIM_SO
+
+
+_ctx = {}
+
+
+def hostsim_ctx():
+    from swapnet_amd import _C, engine
+    if "sim" not in _ctx:
+        _ctx["sim"] = engine.Context(lib=_C.Lib(build_hostsim()), workspace_mb=256)
+    return _ctx["sim"]
+
+
+def gpu_ctx():
+    import torch
+    from swapnet_amd import engine
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU visible")
+    if "gpu" not in _ctx:
+        _ctx["gpu"] = engine.Context(workspace_mb=1024)
+    return _ctx["gpu"]

@@ -25,8 +25,12 @@ void dev_download(Stream&, void* d, const void* s, size_t b) { std::memcpy(d, s,
 void stream_sync(Stream&) {}
 void* stream_create(int) { return nullptr; }
 void stream_destroy(void*) {}
+void device_check(int) {}
 int is_device_build() { return 0; }
 void conv_force_naive(int) {}
+void prof_enable(int) {}
+void prof_reset() {}
+int prof_report(char* buf, int len) { if (buf && len > 0) buf[0] = 0; return 0; }
 
 static inline float actf(float v, int a) {
   switch (a) { case ACT_LRELU: return v > 0 ? v : 0.2f * v; case ACT_RELU: return v > 0 ? v : 0.f;

@@ -1,0 +1,215 @@
+"""Operator-level parity: each C-ABI operator against a plain PyTorch fp32 CPU reference of
+the same op (and, on the GPU, the MFMA-tiled convolution against the naive checker kernel).
+
+Every test body runs twice: on the CI host simulator (small shapes, `-m "not gpu"`: checks
+the engine-side geometry / packing logic) and on the real MI355X (`-m gpu`: the HIP kernels).
+Tolerance: 1e-3 relative (north_star), bit-exact for the integer work.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import swapnet_oracle as O
+from swapnet_amd import _C
+from tests import backends
+
+K4S2, K3REFL, K4S1, K3ZERO, TAIL = 0, 1, 2, 3, 4
+
+
+def _ctx(kind):
+    return backends.gpu_ctx() if kind == "gpu" else backends.hostsim_ctx()
+
+
+BACKENDS = [pytest.param("sim", id="hostsim"), pytest.param("gpu", id="mi355x", marks=pytest.mark.gpu)]
+
+
+def rel(a, b):
+    return float((a.double() - b.double()).norm() / (b.double().norm() + 1e-30))
+
+
+def ref_conv(x, w, b, kind, transposed):
+    if transposed:
+        return F.conv_transpose2d(x, w, b, stride=2, padding=1)
+    if kind == K4S2:
+        return F.conv2d(x, w, b, stride=2, padding=1)
+    if kind == K3REFL:
+        return F.conv2d(F.pad(x, (1, 1, 1, 1), mode="reflect"), w, b)
+    if kind == K4S1:
+        return F.conv2d(x, w, b, stride=1, padding=1)
+    if kind == K3ZERO:
+        return F.conv2d(x, w, b, stride=1, padding=1)
+    up = F.pad(F.interpolate(x, scale_factor=2), (1, 0, 1, 0))        # swapnet_modules.py:85-88
+    return F.conv2d(up, w, b, padding=1)
+
+
+def run_conv(ctx, kind, transposed, what, naive, x, w, b, act, y_shape=None, dy=None):
+    dev = ctx.device
+    xd = x.to(dev).contiguous()
+    wd = w.to(dev).contiguous()
+    bd = b.to(dev).contiguous() if b is not None else None
+    n, ci, h, ww = x.shape
+    co = w.shape[1] if transposed else w.shape[0]
+    if what == 0:
+        yd = torch.empty(y_shape, device=dev)
+    else:
+        yd = dy.to(dev).contiguous()
+    ctx.lib.call("swn_op_conv", ctx.handle, kind, int(transposed), what, int(naive), _C.ptr(xd), n, ci, h, ww,
+                 _C.ptr(wd), co, _C.ptr(bd), act, _C.ptr(yd))
+    ctx.sync()
+    return {0: yd, 1: wd, 2: xd}[what].cpu()
+
+
+# (kind, transposed, N, Ci, H, Co, bias)   -- sim cases are tiny, gpu cases cover every tile path
+CONV_CASES_SIM = [
+    (K4S2, 0, 2, 3, 16, 8, False), (K4S2, 0, 1, 32, 8, 36, True), (K3REFL, 0, 2, 8, 6, 8, True),
+    (K4S1, 0, 2, 8, 9, 5, True), (K3ZERO, 0, 1, 3, 8, 8, True), (TAIL, 0, 1, 12, 6, 19, True),
+    (K4S2, 1, 2, 8, 5, 12, False), (K4S2, 1, 1, 4, 3, 3, True),
+]
+CONV_CASES_GPU = CONV_CASES_SIM + [
+    (K4S2, 0, 3, 64, 40, 128, False),        # fast path, M = 3*400 (ragged tile), N = 128
+    (K4S2, 0, 2, 19, 64, 64, False),         # generic path (Ci=19 -> 20), N = 64 tile
+    (K4S2, 0, 2, 512, 8, 1024, False),       # split-K (M = 32, K = 8192)
+    (K4S2, 0, 1, 22, 64, 64, True),
+    (K3REFL, 0, 2, 256, 16, 256, True),      # reflect pad, K = 2304
+    (K4S1, 0, 2, 256, 32, 512, True),        # PatchGAN model.8 shape (31x31 out, ragged M)
+    (K4S1, 0, 2, 512, 31, 1, True),          # PatchGAN model.11: N = 1
+    (K3ZERO, 0, 1, 64, 64, 64, True),        # VGG
+    (TAIL, 0, 1, 192, 32, 19, True),         # upsample_and_pad, N = 19
+    (K4S2, 1, 2, 1024, 4, 512, False),       # convT, split-K per phase
+    (K4S2, 1, 2, 384, 32, 64, False),        # dual_up3
+    (K4S2, 1, 1, 128, 64, 3, True),          # texture outermost up conv
+]
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_conv_forward(backend):
+    ctx = _ctx(backend)
+    cases = CONV_CASES_GPU if backend == "gpu" else CONV_CASES_SIM
+    g = torch.Generator().manual_seed(0)
+    for kind, tr, n, ci, h, co, bias in cases:
+        k = 3 if kind in (K3REFL, K3ZERO) else 4
+        x = torch.randn(n, ci, h, h, generator=g)
+        w = torch.randn((ci, co, k, k) if tr else (co, ci, k, k), generator=g) * (2.0 / (ci * k * k)) ** 0.5
+        b = torch.randn(co, generator=g) * 0.1 if bias else None
+        ref = ref_conv(x, w, b, kind, tr)
+        for act, fn in ((0, lambda t: t), (1, lambda t: F.leaky_relu(t, 0.2)), (3, torch.tanh)):
+            if tr and act != 0:
+                continue            # ConvTranspose2d is always followed by IN in the reference
+            out = run_conv(ctx, kind, tr, 0, False, x, w, b, act, ref.shape)
+            assert rel(out, fn(ref)) < 1e-4, (backend, kind, tr, n, ci, h, co, act, rel(out, fn(ref)))
+            if act != 0:
+                continue
+            if backend == "gpu":       # tiled MFMA kernel vs the one-thread-per-output checker
+                chk = run_conv(ctx, kind, tr, 0, True, x, w, b, act, ref.shape)
+                assert rel(out, chk) < 1e-5, ("tiled vs naive", kind, tr, n, ci, h, co)
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_conv_backward(backend):
+    ctx = _ctx(backend)
+    cases = CONV_CASES_GPU if backend == "gpu" else CONV_CASES_SIM
+    g = torch.Generator().manual_seed(1)
+    for kind, tr, n, ci, h, co, bias in cases:
+        k = 3 if kind in (K3REFL, K3ZERO) else 4
+        x = torch.randn(n, ci, h, h, generator=g, requires_grad=True)
+        w = (torch.randn((ci, co, k, k) if tr else (co, ci, k, k), generator=g) * (2.0 / (ci * k * k)) ** 0.5).requires_grad_(True)
+        ref = ref_conv(x, w, None, kind, tr)
+        dy = torch.randn(ref.shape, generator=g)
+        gx, gw = torch.autograd.grad(ref, (x, w), dy)
+        dw = run_conv(ctx, kind, tr, 1, False, x.detach(), torch.zeros_like(w), None, 0, dy=dy)
+        assert rel(dw, gw) < 2e-4, ("wgrad", backend, kind, tr, n, ci, h, co, rel(dw, gw))
+        dx = run_conv(ctx, kind, tr, 2, False, torch.zeros_like(x), w.detach(), None, 0, dy=dy)
+        assert rel(dx, gx) < 2e-4, ("dgrad", backend, kind, tr, n, ci, h, co, rel(dx, gx))
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_instance_norm_act(backend):
+    ctx = _ctx(backend)
+    g = torch.Generator().manual_seed(2)
+    shapes = [(2, 8, 5, 7), (3, 36, 4, 4), (1, 1024, 2, 2)] + ([(4, 64, 128, 128), (2, 512, 31, 31)] if backend == "gpu" else [])
+    for n, c, h, w in shapes:
+        x = (torch.randn(n, c, h, w, generator=g) * 3 + 1.5).requires_grad_(True)
+        for act, fn in ((0, lambda t: t), (1, lambda t: F.leaky_relu(t, 0.2)), (2, F.relu)):
+            ref = fn(F.instance_norm(x, eps=1e-5))
+            xd = x.detach().to(ctx.device).contiguous()
+            yd = torch.empty_like(xd)
+            ctx.lib.call("swn_op_instance_norm_act", ctx.handle, _C.ptr(xd), n, c, h, w, act, _C.ptr(yd))
+            assert rel(yd.cpu(), ref.detach()) < 1e-5
+            dy = torch.randn(ref.shape, generator=g)
+            gx, = torch.autograd.grad(ref, x, dy)
+            dyd = dy.to(ctx.device).contiguous()
+            dxd = torch.empty_like(xd)
+            ctx.lib.call("swn_op_instance_norm_act_bwd", ctx.handle, _C.ptr(xd), _C.ptr(dyd), n, c, h, w, act, _C.ptr(dxd))
+            assert rel(dxd.cpu(), gx) < 1e-4, (n, c, h, w, act, rel(dxd.cpu(), gx))
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_adamw_matches_torch(backend):
+    ctx = _ctx(backend)
+    g = torch.Generator().manual_seed(3)
+    n = 4096 + 8
+    p = torch.randn(n, generator=g)
+    ref_p = p.clone().requires_grad_(True)
+    opt = torch.optim.AdamW([ref_p], lr=4e-4, betas=(0.9, 0.999), weight_decay=0.01)
+    pd = p.to(ctx.device).contiguous()
+    md, vd = torch.zeros_like(pd), torch.zeros_like(pd)
+    for step in range(1, 4):
+        grad = torch.randn(n, generator=g) * 10 ** float(torch.randint(-6, 1, (1,), generator=g))
+        ref_p.grad = grad.clone()
+        opt.step()
+        gd = grad.to(ctx.device).contiguous()
+        ctx.lib.call("swn_op_adamw", ctx.handle, _C.ptr(pd), _C.ptr(gd), _C.ptr(md), _C.ptr(vd), C.c_size_t(n),
+                     C.c_float(4e-4), C.c_float(0.9), C.c_float(0.999), C.c_float(1e-8), C.c_float(0.01), step)
+        assert torch.allclose(pd.cpu(), ref_p.detach(), rtol=1e-5, atol=1e-7)
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_roi_align_bit_exact_indices_and_values(backend, golden_dir):
+    """Integer work must be bit-exact: corner indices + validity of every sample, and (since
+    the bilinear arithmetic is evaluated unfused in the published order) the values too."""
+    import os
+    ctx = _ctx(backend)
+    rois = torch.from_numpy(np.load(os.path.join(golden_dir, "notebook_rois.npz"))["rois"])     # (4,12,4), degenerate boxes
+    H = W = 256
+    PH = PW = 128 if backend == "gpu" else 16
+    extra = torch.tensor([[[0, 0, 255, 255], [255, 0, 255, 0], [10.5, 3.25, 200.75, 77.5], [254, 254, 255, 255]]])
+    for r in (rois, extra):
+        B, R = r.shape[0], r.shape[1]
+        flat = O.reshape_rois(r)
+        I = O.roi_align_indices(flat.numpy(), H, W, (PH, PW))
+        rd = r.to(ctx.device).contiguous()
+        idx = torch.empty((B * R, PH, PW, 4), dtype=torch.int32, device=ctx.device)
+        valid = torch.empty((B * R, PH, PW), dtype=torch.uint8, device=ctx.device)
+        ctx.lib.call("swn_op_roi_align_indices", ctx.handle, _C.ptr(rd), B * R, H, W, PH, PW, _C.ptr(idx), _C.ptr(valid))
+        idx, valid = idx.cpu().numpy(), valid.cpu().numpy().astype(bool)
+        assert np.array_equal(valid, I["valid"])
+        for j, k in enumerate(("yl", "yh", "xl", "xh")):
+            assert np.array_equal(idx[..., j], I[k]), k
+        x = torch.randn(B, 3, H, W, generator=torch.Generator().manual_seed(5))
+        ref = O.roi_align(x, flat, (PH, PW), 1.0, 1).view(B, R * 3, PH, PW)
+        xd = x.to(ctx.device).contiguous()
+        out = torch.empty((B, R * 3, PH, PW), device=ctx.device)
+        ctx.lib.call("swn_op_roi_align", ctx.handle, _C.ptr(xd), B, 3, H, W, _C.ptr(rd), R, PH, PW, _C.ptr(out))
+        assert torch.equal(out.cpu(), ref)
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_label_decode_and_onehot_bit_exact(backend):
+    ctx = _ctx(backend)
+    g = torch.Generator().manual_seed(6)
+    B, Cn, H = (4, 19, 256) if backend == "gpu" else (2, 19, 12)
+    x = torch.tanh(torch.randn(B, Cn, H, H, generator=g))
+    x[:, :, :3, :3] = 0.0                      # ties -> first index
+    xd = x.to(ctx.device).contiguous()
+    rgb = torch.empty((B, 3, H, H), dtype=torch.uint8, device=ctx.device)
+    ctx.lib.call("swn_op_decode_labels", ctx.handle, _C.ptr(xd), B, Cn, H, H, _C.ptr(rgb))
+    assert torch.equal(rgb.cpu(), O.decode_cloth_labels(x))
+    lab = torch.empty((B, H, H), dtype=torch.int32, device=ctx.device)
+    ctx.lib.call("swn_op_argmax_labels", ctx.handle, _C.ptr(xd), B, Cn, H, H, _C.ptr(lab))
+    assert torch.equal(lab.cpu().long(), O.onehot_to_labels(x))
+    oh = torch.empty((B, Cn, H, H), device=ctx.device)
+    ctx.lib.call("swn_op_labels_to_onehot", ctx.handle, _C.ptr(lab), B, Cn, H, H, _C.ptr(oh))
+    assert torch.equal(oh.cpu(), O.labels_to_onehot(lab.cpu().long(), Cn))

@@ -1,0 +1,220 @@
+"""Warp-stage parity: the native G+D step
+against (i) the CPU oracle on the same seeded inputs and (ii) the golden vectors recorded
+from the real reference (tests/golden/warp_step_64.npz, config C1 shape 64x64).
+
+fp32 tolerances (north_star: 1e-3 relative):
+  forward activations / fakes / losses : 1e-3 (observed ~1e-6 .. 1e-5)
+  post-step weights                    : 1e-3 rel-L2 per tensor
+  gradients                            : 5e-3 (D) / 1e-2 (G) rel-L2 per tensor -- the reference's own fp32 CPU
+    backward differs from an fp64-accumulated evaluation by ~1e-3 on the deep layers, so a
+    tighter bound would test the oracle's round-off, not our kernels.
+Biases that feed an InstanceNorm are excluded from grad / post-step checks: their true
+gradient is 0, the reference's is round-off noise that Adam normalises to +-lr.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import swapnet_oracle as O
+from oracle.golden_io import compare
+from swapnet_amd import engine
+from tests import backends
+
+BACKENDS = [pytest.param("sim", id="hostsim"), pytest.param("gpu", id="mi355x", marks=pytest.mark.gpu)]
+
+
+def _ctx(kind):
+    return backends.gpu_ctx() if kind == "gpu" else backends.hostsim_ctx()
+
+
+def rel(a, b):
+    return float((a.double().cpu() - b.double()).norm() / (b.double().norm() + 1e-30))
+
+
+def noise_bias(name):
+    return name.endswith(".bias") and ("resblocks" in name or name.startswith(("model.2.", "model.5.", "model.8.")))
+
+
+@pytest.fixture(scope="module")
+def gold(golden_dir):
+    return np.load(os.path.join(golden_dir, "warp_step_64.npz"))
+
+
+@pytest.fixture(scope="module")
+def oracle_run(gold):
+    torch.manual_seed(int(gold["meta/init_seed"]))
+    G, D = O.warp_module_params(), O.patchgan_params(22)
+    B, H = int(gold["meta/B"]), int(gold["meta/H"])
+    batch = O.synth_warp_batch(B, H, H, seed=1234)
+    taps = {}
+    with torch.no_grad():
+        O.warp_module_forward(G, *batch[:2], taps=taps)
+    st = O.WarpStepOracle(G, D)
+    steps = []
+    for seed in gold["meta/step_seeds"]:
+        torch.manual_seed(int(seed))
+        st.step(*batch)
+        steps.append(dict(losses=dict(st.losses), labels=list(st.labels), fakes=st.fakes.clone(),
+                          gG={k: v.clone() for k, v in st.grads_G.items()},
+                          gD={k: v.clone() for k, v in st.grads_D.items()},
+                          pG={k: v.clone() for k, v in st.G.items()}, pD={k: v.clone() for k, v in st.D.items()},
+                          mG={k: v.clone() for k, v in st.optG.m.items()}, vG={k: v.clone() for k, v in st.optG.v.items()},
+                          mD={k: v.clone() for k, v in st.optD.m.items()}, vD={k: v.clone() for k, v in st.optD.v.items()}))
+    return G, D, batch, taps, steps
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_warp_forward_levels(backend, oracle_run, gold):
+    G, D, batch, taps, _ = oracle_run
+    ctx = _ctx(backend)
+    B, H = batch[0].shape[0], batch[0].shape[2]
+    m = engine.NativeModel(ctx, "warp", B, H, H, is_train=False)
+    m.load_state_dict(engine.NET_G, G)
+    m.set_input(0, batch[0]); m.set_input(1, batch[1])
+    m.forward(False, 0)
+    for name, ref in taps.items():
+        t = m.tap(engine.NET_G, name)
+        assert rel(t[:, :ref.shape[1]], ref) < 1e-3, (name, rel(t[:, :ref.shape[1]], ref))
+    out = m.output()
+    ok, msg = compare(gold, "step0/fakes", out, rtol=1e-3, atol_frac=1e-3)
+    assert ok, msg
+    # state_dict round trip is exact (pack -> unpack)
+    sd = m.state_dict(engine.NET_G, to_cpu=True)
+    assert list(sd.keys()) == list(G.keys())
+    for k in G:
+        assert torch.equal(sd[k], G[k]), k
+    m.close()
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_warp_two_steps_match_oracle_and_reference(backend, oracle_run, gold):
+    G, D, batch, _, steps = oracle_run
+    ctx = _ctx(backend)
+    B, H = batch[0].shape[0], batch[0].shape[2]
+    m = engine.NativeModel(ctx, "warp", B, H, H, is_train=True)
+    m.load_state_dict(engine.NET_G, G)
+    m.load_state_dict(engine.NET_D, D)
+    m.set_hyper()
+    for i, t in enumerate(batch):
+        m.set_input(i, t)
+    for si, s in enumerate(steps):
+        pre = "step%d/" % si
+        if si > 0:
+            # Adam's first update is +-lr * sign(g): round-off-level gradient differences flip
+            # signs of near-zero entries and GAN dynamics amplify that chaotically, so a free-
+            # running second step would compare trajectories, not kernels.  Re-synchronise the
+            # full training state (weights + both Adam moments + step count) with the oracle's
+            # and check the step>1 path (bias corrections, moment EMA) from identical state.
+            p = steps[si - 1]
+            for net, wk, mk, vk in ((engine.NET_G, "pG", "mG", "vG"), (engine.NET_D, "pD", "mD", "vD")):
+                m.load_state_dict(net, p[wk])
+                m.load_state_dict(net, p[mk], which=engine.W_EXP_AVG)
+                m.load_state_dict(net, p[vk], which=engine.W_EXP_AVG_SQ)
+                m.optim_step_count(net, si)
+        # phase by phase, in the reference's order (models/base_gan.py:194-203)
+        m.forward(False, 0)
+        m.backward_D(s["labels"][0], s["labels"][1])
+        gD = m.state_dict(engine.NET_D, which=engine.W_GRAD, to_cpu=True)
+        m.optimizer_step(engine.NET_D)
+        m.backward_G(s["labels"][2])
+        gG = m.state_dict(engine.NET_G, which=engine.W_GRAD, to_cpu=True)
+        m.optimizer_step(engine.NET_G)
+        L = m.losses()
+        for k, v in s["losses"].items():
+            assert abs(L[k] - v) <= 1e-3 * abs(v) + 1e-6, (si, k, L[k], v)
+            assert abs(L[k] - float(gold[pre + "loss/" + k])) <= 1e-3 * abs(v) + 1e-6, (si, k, "vs reference")
+        out = m.output()
+        assert rel(out, s["fakes"]) < 1e-3
+        ok, msg = compare(gold, pre + "fakes", out, 1e-3, 1e-3)
+        assert ok, msg
+        for k, v in s["gD"].items():
+            if not noise_bias(k):
+                assert rel(gD[k], v) < 5e-3, (si, "gradD", k, rel(gD[k], v))
+        for k, v in s["gG"].items():
+            if not noise_bias(k):
+                # G's gradient flows through the D that was Adam-updated inside this very step
+                # (base_gan.py:199 precedes backward_G), which amplifies gradD round-off once more
+                assert rel(gG[k], v) < 1e-2, (si, "gradG", k, rel(gG[k], v))
+        pG = m.state_dict(engine.NET_G, to_cpu=True)
+        pD = m.state_dict(engine.NET_D, to_cpu=True)
+        for k, v in s["pG"].items():
+            if not noise_bias(k):
+                assert rel(pG[k], v) < 1e-3, (si, "postG", k, rel(pG[k], v))
+                ok, msg = compare(gold, pre + "postG/" + k, pG[k], 1e-3, 3e-3)
+                assert ok, msg
+        for k, v in s["pD"].items():
+            if not noise_bias(k):
+                assert rel(pD[k], v) < 1e-3, (si, "postD", k, rel(pD[k], v))
+    # Adam moments come back in the reference's state-dict layout
+    ea = m.state_dict(engine.NET_G, which=engine.W_EXP_AVG, to_cpu=True)
+    assert ea["body_down1.model.0.weight"].shape == (64, 3, 4, 4)
+    assert m.optim_step_count(engine.NET_G) == len(steps)
+    m.close()
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_fused_step_equals_phased_step(backend, oracle_run):
+    """swn_model_step == forward; backward_D; step D; backward_G; step G (bitwise)."""
+    G, D, batch, _, steps = oracle_run
+    ctx = _ctx(backend)
+    B, H = batch[0].shape[0], batch[0].shape[2]
+    outs = []
+    for fused in (False, True):
+        m = engine.NativeModel(ctx, "warp", B, H, H, is_train=True)
+        m.load_state_dict(0, G); m.load_state_dict(1, D); m.set_hyper()
+        for i, t in enumerate(batch):
+            m.set_input(i, t)
+        lab = steps[0]["labels"]
+        if fused:
+            m.step(lab, training=False, seed=0)
+        else:
+            m.forward(False, 0); m.backward_D(lab[0], lab[1]); m.optimizer_step(1); m.backward_G(lab[2]); m.optimizer_step(0)
+        outs.append((m.losses(), m.state_dict(0, to_cpu=True)["upsample_and_pad.2.weight"]))
+        m.close()
+    assert outs[0][0] == outs[1][0]
+    assert torch.equal(outs[0][1], outs[1][1])
+
+
+@pytest.mark.gpu
+def test_warp_full_size_properties():
+    """Config C2 shape (256x256, bs 32): size-independent properties the oracle cannot reach.
+    (1) run-to-run bitwise determinism of a full training step (fixed-order reductions);
+    (2) batch-permutation equivariance of the generator (every layer is per-sample);
+    (3) dropout: train-mode forward differs from eval, and is reproducible for a fixed seed."""
+    ctx = backends.gpu_ctx()
+    B, H = 32, 256
+    torch.manual_seed(0)
+    G, D = O.warp_module_params(), O.patchgan_params(22)
+    batch = O.synth_warp_batch(B, H, H, seed=1234)
+    m = engine.NativeModel(ctx, "warp", B, H, H, is_train=True)
+    res = []
+    for _ in range(2):
+        m.load_state_dict(0, G); m.load_state_dict(1, D); m.set_hyper()
+        for w in (engine.W_EXP_AVG, engine.W_EXP_AVG_SQ):
+            m.load_state_dict(0, {k: torch.zeros_like(v) for k, v in G.items()}, which=w)
+            m.load_state_dict(1, {k: torch.zeros_like(v) for k, v in D.items()}, which=w)
+        m.optim_step_count(0, 0); m.optim_step_count(1, 0)
+        for i, t in enumerate(batch):
+            m.set_input(i, t)
+        m.step([0.9, 0.8, 1.0], training=True, seed=7)
+        res.append((m.losses(), m.output().cpu(), m.weight_arena(0).clone().cpu()))
+    assert res[0][0] == res[1][0]
+    assert torch.equal(res[0][1], res[1][1]) and torch.equal(res[0][2], res[1][2])
+    assert all(np.isfinite(v) for v in res[0][0].values())
+    # (2) permutation equivariance in eval mode
+    m.forward(False, 0)
+    a = m.output().cpu()
+    perm = torch.randperm(B, generator=torch.Generator().manual_seed(1))
+    m.set_input(0, batch[0][perm]); m.set_input(1, batch[1][perm])
+    m.forward(False, 0)
+    b = m.output().cpu()
+    assert torch.equal(a[perm], b)
+    # (3) dropout
+    m.forward(True, 5); d1 = m.output().cpu()
+    m.forward(True, 5); d2 = m.output().cpu()
+    m.forward(True, 6); d3 = m.output().cpu()
+    assert torch.equal(d1, d2) and not torch.equal(d1, d3) and not torch.equal(d1, b)
+    assert a.abs().max() <= 1.0
+    m.close()
