@@ -40,7 +40,13 @@ PEAK_FP32_MFMA_TFLOPS = 157.3       # MI355X_MICROARCH.md "Peak FP32 (matrix)"
 def cpu_baseline(sample_bs=4, size=256, warm=1, timed=2):
     """Oracle = functional port of the reference's WarpModel step on torch CPU ("kind": "port")."""
     from oracle import swapnet_oracle as O
-    cores = os.cpu_count() or 1
+    # threads actually usable by this process (cgroup / affinity aware), capped: beyond ~32 threads
+    # torch-CPU convolutions at this size stop scaling and oversubscription only slows them down
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    cores = max(1, min(avail, 32))
     torch.set_num_threads(cores)
     torch.manual_seed(0)
     G, D = O.warp_module_params(), O.patchgan_params(22)
