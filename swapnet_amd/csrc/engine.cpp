@@ -373,9 +373,18 @@ void Net::maxpool(const Var& x, const Var& y) {
   if (do_bwd) op->grad_targets.push_back(x);
   op->bwd = [=](Net& n, Op& me, bool, bool) {
     if (!do_bwd) return;
-    if (!me.acc.empty() && me.acc[0]) throw Error(1, "maxpool bwd cannot accumulate");
-    maxpool2_bwd(n.ctx.s, yg, xv, yv, xg);
+    maxpool2_bwd(n.ctx.s, yg, xv, yv, xg, me.acc.empty() ? 0 : me.acc[0]);
   };
+  ops.push_back(std::move(op));
+}
+
+void Net::custom(const std::string& label, std::function<void(Net&)> fwd,
+                 std::function<void(Net&, const std::vector<int>& acc)> bwd, const std::vector<Var>& grad_targets) {
+  auto op = std::make_unique<Op>();
+  op->label = label;
+  op->fwd = fwd ? fwd : [](Net&) {};
+  op->grad_targets = grad_targets;
+  op->bwd = [bwd](Net& n, Op& me, bool, bool) { if (bwd) bwd(n, me.acc); };
   ops.push_back(std::move(op));
 }
 

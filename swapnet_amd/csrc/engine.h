@@ -99,6 +99,9 @@ class Net {
   void upsample(const Var& x, const Var& y, int factor);
   void maxpool(const Var& x, const Var& y);
   void affine(const Var& x, const Var& y, float alpha, float shift);
+  // free-form op (RoIAlign gather, loss taps): bwd receives the planned accumulate flags
+  void custom(const std::string& label, std::function<void(Net&)> fwd,
+              std::function<void(Net&, const std::vector<int>& acc)> bwd, const std::vector<Var>& grad_targets);
   // bookkeeping
   void finalize(const std::vector<Var>& pre_initialised_grads);
   void forward();

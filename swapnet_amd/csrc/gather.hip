@@ -113,7 +113,7 @@ __global__ __launch_bounds__(256) void upsample_bwd_kernel(const float* dy, int 
 // strict '>' so ties go to the first element, like ATen's max_pool2d.
 __global__ __launch_bounds__(256) void maxpool_kernel(const float* x, int xcs, float* y, int ycs, const float* dy,
                                                       int dycs, float* dx, int dxcs, int N, int Ho, int Wo, int C,
-                                                      int bwd) {
+                                                      int bwd, int accumulate) {
   const int C4 = C >> 2, Hi = Ho * 2, Wi = Wo * 2;
   const size_t total = (size_t)N * Ho * Wo * C4;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
@@ -145,7 +145,9 @@ __global__ __launch_bounds__(256) void maxpool_kernel(const float* x, int xcs, f
         float4 o;
         o.x = am[0] == t ? ga[0] : 0.f; o.y = am[1] == t ? ga[1] : 0.f;
         o.z = am[2] == t ? ga[2] : 0.f; o.w = am[3] == t ? ga[3] : 0.f;
-        *reinterpret_cast<float4*>(dx + (((size_t)n * Hi + oy * 2 + (t >> 1)) * Wi + ox * 2 + (t & 1)) * dxcs + c) = o;
+        float* d = dx + (((size_t)n * Hi + oy * 2 + (t >> 1)) * Wi + ox * 2 + (t & 1)) * dxcs + c;
+        if (accumulate) { const float4 e = *reinterpret_cast<const float4*>(d); o.x += e.x; o.y += e.y; o.z += e.z; o.w += e.w; }
+        *reinterpret_cast<float4*>(d) = o;
       }
     }
   }
@@ -232,12 +234,12 @@ void upsample_nearest_bwd(Stream& s, const TView& dy, const TView& dx, int f, in
 void maxpool2_fwd(Stream& s, const TView& x, const TView& y) {
   if (x.H != y.H * 2 || x.W != y.W * 2 || x.C % 4 || x.C != y.C) throw Error(1, "maxpool2_fwd: shape mismatch");
   hipLaunchKernelGGL(maxpool_kernel, dim3(egrid(y.pixels() * (y.C / 4))), dim3(256), 0, hs(s), x.p, x.cs, y.p, y.cs,
-                     (const float*)nullptr, 0, (float*)nullptr, 0, y.N, y.H, y.W, y.C, 0);
+                     (const float*)nullptr, 0, (float*)nullptr, 0, y.N, y.H, y.W, y.C, 0, 0);
   check_launch("maxpool2_fwd");
 }
-void maxpool2_bwd(Stream& s, const TView& dy, const TView& x, const TView& y, const TView& dx) {
+void maxpool2_bwd(Stream& s, const TView& dy, const TView& x, const TView& y, const TView& dx, int accumulate) {
   hipLaunchKernelGGL(maxpool_kernel, dim3(egrid(y.pixels() * (y.C / 4))), dim3(256), 0, hs(s), x.p, x.cs, y.p, y.cs, dy.p,
-                     dy.cs, dx.p, dx.cs, y.N, y.H, y.W, y.C, 1);
+                     dy.cs, dx.p, dx.cs, y.N, y.H, y.W, y.C, 1, accumulate);
   check_launch("maxpool2_bwd");
 }
 

@@ -111,7 +111,7 @@ void axpy(Stream& s, const TView& src, const TView& dst, float alpha, int accumu
 void upsample_nearest_fwd(Stream& s, const TView& x, const TView& y, int factor);
 void upsample_nearest_bwd(Stream& s, const TView& dy, const TView& dx, int factor, int accumulate);
 void maxpool2_fwd(Stream& s, const TView& x, const TView& y);
-void maxpool2_bwd(Stream& s, const TView& dy, const TView& x, const TView& y, const TView& dx);
+void maxpool2_bwd(Stream& s, const TView& dy, const TView& x, const TView& y, const TView& dx, int accumulate);
 // legacy RoIAlign (torchvision 0.4.0), sampling_ratio 1, spatial_scale 1.  tex: (B,H,W,C);
 // rois: device float [B*R][4] = x1,y1,x2,y2 (batch index = k / R); out: (B,PH,PW,R*C) with
 // channel index r*C + c (the reference's view(B,-1,PH,PW), swapnet_modules.py:237-240).

@@ -240,12 +240,12 @@ void maxpool2_fwd(Stream&, const TView& x, const TView& y) {
       at(y, n, oy, ox)[c] = m;
     }
 }
-void maxpool2_bwd(Stream&, const TView& dy, const TView& x, const TView& y, const TView& dx) {
+void maxpool2_bwd(Stream&, const TView& dy, const TView& x, const TView& y, const TView& dx, int accumulate) {
   for (int n = 0; n < y.N; ++n) for (int oy = 0; oy < y.H; ++oy) for (int ox = 0; ox < y.W; ++ox)
     for (int c = 0; c < y.C; ++c) {
       float m = at(x, n, oy * 2, ox * 2)[c]; int am = 0;
       for (int t = 1; t < 4; ++t) { const float v = at(x, n, oy * 2 + (t >> 1), ox * 2 + (t & 1))[c]; if (v > m) { m = v; am = t; } }
-      for (int t = 0; t < 4; ++t) at(dx, n, oy * 2 + (t >> 1), ox * 2 + (t & 1))[c] = t == am ? at(dy, n, oy, ox)[c] : 0.f;
+      for (int t = 0; t < 4; ++t) { float* d = at(dx, n, oy * 2 + (t >> 1), ox * 2 + (t & 1)) + c; const float v = t == am ? at(dy, n, oy, ox)[c] : 0.f; *d = accumulate ? *d + v : v; }
     }
 }
 

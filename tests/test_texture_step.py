@@ -1,0 +1,157 @@
+"""Texture-stage parity: RoIAlign -> UNetDown -> pix2pix
+U-Net generator, PatchGAN, L1 + VGG16 content + image-Gram style losses, AdamW -- the native
+step against the CPU oracle and the golden vectors of the real reference
+(tests/golden/texture_step_64.npz; 64x64 so the U-Net has 6 levels, VGG16 with the shared
+seeded-random weights because pretrained weights are not obtainable offline: parity unpinned
+for the pretrained values, pinned for the arithmetic).
+Tolerances as in test_warp_step.py."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import swapnet_oracle as O
+from oracle.golden_io import compare
+from swapnet_amd import engine
+from tests import backends
+
+BACKENDS = [pytest.param("sim", id="hostsim"), pytest.param("gpu", id="mi355x", marks=pytest.mark.gpu)]
+
+
+def _ctx(kind):
+    return backends.gpu_ctx() if kind == "gpu" else backends.hostsim_ctx()
+
+
+def rel(a, b):
+    return float((a.double().cpu() - b.double()).norm() / (b.double().norm() + 1e-30))
+
+
+def noise_bias(name, keys):
+    """conv biases that feed an InstanceNorm (true gradient 0)."""
+    if not name.endswith(".bias"):
+        return False
+    if name.startswith(("model.2.", "model.5.", "model.8.")):
+        return True
+    if not name.startswith("unet."):
+        return False
+    if name.startswith("unet.model.model.0.") or name.startswith("unet.model.model.3."):
+        return False
+    deepest = max(k.count(".model.") for k in keys if k.startswith("unet."))
+    if name.count(".model.") == deepest and name.endswith(".model.1.bias"):
+        return False
+    return True
+
+
+def vgg_state_dict(model, vgg):
+    names = list(model.param_infos(engine.NET_VGG).keys())
+    sd = {}
+    for i, (w, b) in enumerate(vgg):
+        sd[names[2 * i]] = w
+        sd[names[2 * i + 1]] = b
+    return sd
+
+
+@pytest.fixture(scope="module")
+def gold(golden_dir):
+    return np.load(os.path.join(golden_dir, "texture_step_64.npz"))
+
+
+@pytest.fixture(scope="module")
+def oracle_run(gold):
+    B, H = int(gold["meta/B"]), int(gold["meta/H"])
+    torch.manual_seed(int(gold["meta/init_seed"]))
+    G, D = O.texture_module_params(img_size=H), O.patchgan_params(22)
+    vgg = O.vgg16_feature_params()
+    batch = O.synth_texture_batch(B, H, H, seed=4321)
+    taps = {}
+    with torch.no_grad():
+        O.texture_module_forward(G, batch[0], batch[1], batch[2], taps=taps)
+    st = O.TextureStepOracle(G, D, vgg)
+    torch.manual_seed(int(gold["meta/step_seeds"][0]))
+    st.step(*batch)
+    s = dict(losses=dict(st.losses), labels=list(st.labels), fakes=st.fakes.clone(),
+             gG={k: v.clone() for k, v in st.grads_G.items()}, gD={k: v.clone() for k, v in st.grads_D.items()},
+             pG={k: v.clone() for k, v in st.G.items()}, pD={k: v.clone() for k, v in st.D.items()})
+    return G, D, vgg, batch, taps, s
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_texture_step_matches_oracle_and_reference(backend, oracle_run, gold):
+    G, D, vgg, batch, taps, s = oracle_run
+    ctx = _ctx(backend)
+    B, H = batch[0].shape[0], batch[0].shape[2]
+    m = engine.NativeModel(ctx, "texture", B, H, H, is_train=True)
+    assert list(m.param_infos(engine.NET_G).keys()) == list(G.keys())       # reference state-dict keys
+    m.load_state_dict(engine.NET_G, G)
+    m.load_state_dict(engine.NET_D, D)
+    m.load_state_dict(engine.NET_VGG, vgg_state_dict(m, vgg))
+    m.set_hyper()
+    for i, t in enumerate(batch):
+        m.set_input(i, t)
+    m.forward(False, 0)
+    # RoIAlign output is bit-exact, the rest within 1e-3
+    assert torch.equal(m.tap(engine.NET_G, "pooled").cpu(), taps["pooled"])
+    assert rel(m.tap(engine.NET_G, "encoded"), taps["encoded"]) < 1e-3
+    m.backward_D(s["labels"][0], s["labels"][1])
+    gD = m.state_dict(engine.NET_D, which=engine.W_GRAD, to_cpu=True)
+    m.optimizer_step(engine.NET_D)
+    m.backward_G(s["labels"][2])
+    gG = m.state_dict(engine.NET_G, which=engine.W_GRAD, to_cpu=True)
+    m.optimizer_step(engine.NET_G)
+    L = m.losses()
+    for k, v in s["losses"].items():
+        assert abs(L[k] - v) <= 1e-3 * abs(v) + 1e-6, (k, L[k], v)
+        assert abs(L[k] - float(gold["step0/loss/" + k])) <= 1e-3 * abs(v) + 1e-6, (k, "vs reference")
+    out = m.output()
+    assert rel(out, s["fakes"]) < 1e-3
+    ok, msg = compare(gold, "step0/fakes", out, 1e-3, 1e-3)
+    assert ok, msg
+    keys = list(G.keys())
+    for k, v in s["gD"].items():
+        if not noise_bias(k, keys):
+            assert rel(gD[k], v) < 5e-3, ("gradD", k, rel(gD[k], v))
+    for k, v in s["gG"].items():
+        if not noise_bias(k, keys):
+            assert rel(gG[k], v) < 1e-2, ("gradG", k, rel(gG[k], v))
+    pG = m.state_dict(engine.NET_G, to_cpu=True)
+    pD = m.state_dict(engine.NET_D, to_cpu=True)
+    for k, v in s["pG"].items():
+        if not noise_bias(k, keys):
+            assert rel(pG[k], v) < 1e-3, ("postG", k, rel(pG[k], v))
+            ok, msg = compare(gold, "step0/postG/" + k, pG[k], 1e-3, 3e-3)
+            assert ok, msg
+    for k, v in s["pD"].items():
+        if not noise_bias(k, keys):
+            assert rel(pD[k], v) < 1e-3, ("postD", k, rel(pD[k], v))
+    m.close()
+
+
+@pytest.mark.gpu
+def test_texture_full_size_properties():
+    """Config C3 shape (256x256, bs 16, ROIs, perceptual + style on): determinism of a full
+    step, finite losses, RoIAlign output bit-exact vs the CPU restatement at full size."""
+    ctx = backends.gpu_ctx()
+    B, H = 16, 256
+    torch.manual_seed(1)
+    G, D = O.texture_module_params(img_size=H), O.patchgan_params(22)
+    vgg = O.vgg16_feature_params()
+    batch = O.synth_texture_batch(B, H, H, seed=4321)
+    m = engine.NativeModel(ctx, "texture", B, H, H, is_train=True)
+    res = []
+    for _ in range(2):
+        m.load_state_dict(0, G); m.load_state_dict(1, D); m.load_state_dict(2, vgg_state_dict(m, vgg)); m.set_hyper()
+        for w in (engine.W_EXP_AVG, engine.W_EXP_AVG_SQ):
+            m.load_state_dict(0, {k: torch.zeros_like(v) for k, v in G.items()}, which=w)
+            m.load_state_dict(1, {k: torch.zeros_like(v) for k, v in D.items()}, which=w)
+        m.optim_step_count(0, 0); m.optim_step_count(1, 0)
+        for i, t in enumerate(batch):
+            m.set_input(i, t)
+        m.step([0.9, 0.8, 1.0], training=True, seed=3)
+        res.append((m.losses(), m.output().cpu(), m.weight_arena(0).clone().cpu()))
+    assert res[0][0] == res[1][0] and torch.equal(res[0][1], res[1][1]) and torch.equal(res[0][2], res[1][2])
+    assert all(np.isfinite(v) for v in res[0][0].values()), res[0][0]
+    pooled = m.tap(engine.NET_G, "pooled").cpu()
+    ref = O.roi_align(batch[0], O.reshape_rois(batch[1]), (128, 128), 1.0, 1).view(B, 36, 128, 128)
+    assert torch.equal(pooled, ref)
+    m.close()
