@@ -118,6 +118,9 @@ int swn_model_get_losses(swn_model* m, float* host_out, int n);
  * can all-reduce it with RCCL (torch.distributed, backend "nccl") between backward and step */
 int swn_model_grad_arena(swn_model* m, int net, float** dev_ptr, size_t* count);
 int swn_model_weight_arena(swn_model* m, int net, float** dev_ptr, size_t* count);
+/* any of the four arenas (which: 0 weight, 1 grad, 2 exp_avg, 3 exp_avg_sq); the layout does
+ * not depend on the batch shape, so a whole training state moves with flat copies */
+int swn_model_arena(swn_model* m, int net, int which, float** dev_ptr, size_t* count);
 
 /* ---- operator-level entry points (parity tests, integer work, inference helpers) --------- */
 /* torchvision.ops.RoIAlign((128,128),1,1) as used at modules/swapnet_modules.py:166-168,234.

@@ -58,6 +58,7 @@ _PROTOS = {
     "swn_model_get_losses": ([_vp, C.POINTER(_f), _i], _i),
     "swn_model_grad_arena": ([_vp, _i, C.POINTER(_vp), C.POINTER(C.c_size_t)], _i),
     "swn_model_weight_arena": ([_vp, _i, C.POINTER(_vp), C.POINTER(C.c_size_t)], _i),
+    "swn_model_arena": ([_vp, _i, _i, C.POINTER(_vp), C.POINTER(C.c_size_t)], _i),
     "swn_op_roi_align": ([_vp, _fp, _i, _i, _i, _i, _fp, _i, _i, _i, _fp], _i),
     "swn_op_roi_align_indices": ([_vp, _fp, _i, _i, _i, _i, _i, _vp, _vp], _i),
     "swn_op_decode_labels": ([_vp, _fp, _i, _i, _i, _i, _vp], _i),

@@ -226,6 +226,15 @@ int swn_model_weight_arena(swn_model* m, int net, float** p, size_t* count) {
   return guard([&] { ParamArena& a = arena_of(m, net); REQUIRE(p && count, "NULL"); *p = a.w; *count = a.n; a.version += 1; });
 }
 
+int swn_model_arena(swn_model* m, int net, int which, float** p, size_t* count) {
+  return guard([&] {
+    ParamArena& a = arena_of(m, net);
+    REQUIRE(p && count && which >= 0 && which <= 3, "bad argument");
+    *p = a.base(which); *count = a.n;
+    if (which == 0) a.version += 1;
+  });
+}
+
 // ---- operator level -----------------------------------------------------------------------
 int swn_op_roi_align(swn_ctx* ctx, const float* tex, int b, int c, int h, int w, const float* rois, int r, int ph,
                      int pw, float* out) {

@@ -212,6 +212,11 @@ class NativeModel:
         self.lib.call("swn_model_weight_arena", self.handle, net, C.byref(p), C.byref(n))
         return _wrap_pointer(p.value, n.value, self.ctx.device)
 
+    def arena(self, net, which):
+        p, n = C.c_void_p(), C.c_size_t()
+        self.lib.call("swn_model_arena", self.handle, net, which, C.byref(p), C.byref(n))
+        return _wrap_pointer(p.value, n.value, self.ctx.device)
+
     def close(self):
         if getattr(self, "handle", None):
             self.lib.call("swn_model_destroy", self.handle)

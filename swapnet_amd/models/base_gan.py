@@ -1,0 +1,157 @@
+"""BaseGAN of the reference (/root/reference/models/base_gan.py:14-231): GAN flags, the G / D /
+GANLoss / optimizer wiring and `optimize_parameters` -- here one fused native step."""
+from abc import ABC, abstractmethod
+from argparse import ArgumentParser
+
+import torch
+
+from .. import engine, modules, optimizers, parallel
+from ..modules import discriminators
+from ..modules.loss import GANLoss
+from ..modules.native import NativeBackend
+from .base_model import BaseModel
+
+
+class BaseGAN(BaseModel, ABC):
+    KIND = None
+
+    @staticmethod
+    def modify_commandline_options(parser: ArgumentParser, is_train):
+        """Same flags, defaults and aliases as base_gan.py:16-128."""
+        if is_train:
+            parser.add_argument("--gan_mode", help="gan regularization to use", default="vanilla",
+                                choices=("vanilla", "wgan", "wgan-gp", "lsgan", "dragan-gp", "dragan-lp",
+                                         "mescheder-r1-gp", "mescheder-r2-gp"))
+            parser.add_argument("--lambda_gan", type=float, default=1.0, help="weight for adversarial loss")
+            parser.add_argument("--lambda_discriminator", type=float, default=1.0, help="weight for discriminator loss")
+            parser.add_argument("--lambda_gp", help="weight parameter for gradient penalty", type=float, default=10)
+            parser.add_argument("--discriminator", default="basic", choices=("basic", "pixel", "n_layers"),
+                                help="what discriminator type to use")
+            parser.add_argument("--n_layers_D", type=int, default=3, help="only used if discriminator==n_layers")
+            parser.add_argument("--norm", type=str, default="instance",
+                                help="instance normalization or batch normalization [instance | batch | none]")
+            parser.add_argument("--optimizer_G", "--opt_G", "--optim_G", help="optimizer for generator",
+                                default="AdamW", choices=("AdamW", "AdaBound"))
+            parser.add_argument("--lr", "--g_lr", "--learning_rate", type=float, default=0.0001,
+                                help="initial learning rate for generator")
+            parser.add_argument("--beta1", type=float, default=0.5, help="momentum term of adam")
+            parser.add_argument("--optimizer_D", "--opt_D", "--optim_D", help="optimizer for discriminator",
+                                default="AdamW", choices=("AdamW", "AdaBound"))
+            parser.add_argument("--d_lr", type=float, default=0.0004, help="initial learning rate for Discriminator")
+            parser.add_argument("--d_wt_decay", "--d_weight_decay", dest="d_weight_decay", default=0.01, type=float,
+                                help="optimizer L2 weight decay")
+            parser.add_argument("--gan_label_mode", default="smooth", choices=("hard", "smooth"),
+                                help="whether to use hard (real 1.0 and fake 0.0) or smooth "
+                                     "(real [0.7, 1.1] and fake [0., 0.3]) values for labels")
+        return parser
+
+    def __init__(self, opt):
+        super().__init__(opt)
+        self.backend = NativeBackend(self.KIND, is_train=self.is_train, dropout=0.5,
+                                     num_roi=getattr(opt, "body_channels", 12), device=self.gpu_id,
+                                     lib=getattr(opt, "_swapnet_lib", None),
+                                     default_shape=(getattr(opt, "batch_size", 1), getattr(opt, "crop_size", 128),
+                                                    getattr(opt, "crop_size", 128)))
+        self.net_generator = self.define_G()
+        modules.init_weights(self.net_generator, opt.init_type, opt.init_gain)      # base_gan.py:141
+        self.model_names = ["generator"]
+        self._step = 0
+        self.world = 1
+        self._xchg = None
+        if self.is_train:
+            self.net_discriminator = discriminators.define_D(
+                self.get_D_inchannels(), 64, opt.discriminator, opt.n_layers_D, opt.norm, backend=self.backend)
+            modules.init_weights(self.net_discriminator, opt.init_type, opt.init_gain)
+            self.model_names.append("discriminator")
+            use_smooth = opt.gan_label_mode == "smooth"
+            self.criterion_GAN = GANLoss(opt.gan_mode, smooth_labels=use_smooth)
+            if opt.lambda_discriminator:
+                self.loss_names = ["D", "D_real", "D_fake"]
+            self.loss_names += ["G"]
+            if opt.lambda_gan:
+                self.loss_names += ["G_gan"]
+            self.optimizer_G = optimizers.define_optimizer(self.net_generator, opt, "G")
+            self.optimizer_D = optimizers.define_optimizer(self.net_discriminator, opt, "D")
+            self.optimizer_names = ("G", "D")
+            self.backend.set_hyper(gan_mode=self.criterion_GAN.native_mode, lambda_gan=opt.lambda_gan)
+            for n in ("D", "D_real", "D_fake", "G", "G_gan", "G_ce", "G_l1", "G_content", "G_style"):
+                setattr(self, "loss_" + n, 0.0)
+
+    # ---- data parallel (new design; the reference is single-device: SURVEY.md 2a) ---------
+    def enable_data_parallel(self):
+        """One process per GPU: average the two flat gradient arenas over RCCL between each
+        backward and its optimizer step.  Call after torch.distributed is initialised."""
+        import torch.distributed as dist
+        self.world = dist.get_world_size() if dist.is_initialized() else 1
+        self._xchg = parallel.GradExchange(self.world)
+        self.backend.set_hyper(grad_scale=1.0 / self.world)
+        for net in (engine.NET_G, engine.NET_D):
+            parallel.broadcast_arena(self.backend.cur.weight_arena(net) if self.backend.cur else
+                                     self.backend.any_model().weight_arena(net))
+        return self
+
+    @abstractmethod
+    def get_D_inchannels(self):
+        pass
+
+    @abstractmethod
+    def define_G(self):
+        pass
+
+    def _native(self):
+        return self.backend.cur
+
+    def _draw_labels(self):
+        """The three smooth-label scalars in the reference's draw order: backward_D fake, real
+        (warp_model.py:116,120), backward_G real (:158)."""
+        c = self.criterion_GAN
+        return [c.sample_label(False), c.sample_label(True), c.sample_label(True)]
+
+    def optimize_parameters(self):
+        """base_gan.py:194-203: forward, D step, G step."""
+        m = self._native()
+        self._step += 1
+        training = bool(self.net_generator.training)
+        seed = (self._step * 1000003 + torch.initial_seed()) % (2 ** 62)
+        labels = self._draw_labels()
+        if self.world == 1:
+            m.step(labels, training=training, seed=seed)
+        else:
+            rank = torch.distributed.get_rank()
+            m.forward(training, seed + rank)
+            m.backward_D(labels[0], labels[1])
+            self._xchg.allreduce_mean(m.grad_arena(engine.NET_D))
+            m.optimizer_step(engine.NET_D)
+            m.backward_G(labels[2])
+            self._xchg.allreduce_mean(m.grad_arena(engine.NET_G))
+            m.optimizer_step(engine.NET_G)
+        self._losses_stale = True
+        self._fakes = None
+
+    # individual phases keep working too (the reference exposes them as methods)
+    def backward_D(self):
+        c = self.criterion_GAN
+        self._native().backward_D(c.sample_label(False), c.sample_label(True))
+        self._losses_stale = True
+
+    def backward_G(self):
+        self._native().backward_G(self.criterion_GAN.sample_label(True))
+        self._losses_stale = True
+
+    def _fetch_losses(self):
+        if getattr(self, "_losses_stale", False):
+            for k, v in self._native().losses().items():
+                setattr(self, "loss_" + k, v)
+            self._losses_stale = False
+
+    @property
+    def fakes(self):
+        """self.fakes of the reference: (B,C,H,W) tensor, materialised from the NHWC buffer on
+        demand (display ticks, inference) instead of every step."""
+        if getattr(self, "_fakes", None) is None:
+            self._fakes = self._native().output()
+        return self._fakes
+
+    @fakes.setter
+    def fakes(self, v):
+        self._fakes = v

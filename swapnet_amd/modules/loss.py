@@ -1,0 +1,49 @@
+"""GANLoss label logic of the reference (/root/reference/modules/loss.py:12-130).  The loss
+value and its gradient are computed by the library (losses.hip); this class reproduces what
+is host-side in the reference: WHICH scalar target each call uses, drawn from the global torch
+CPU RNG in the reference's order so seeded runs see identical labels."""
+import torch
+
+
+class GANLoss:
+    default_real = 1.0
+    default_fake = 0.0
+    default_smooth_real = (0.7, 1.1)
+    default_smooth_fake = (0.0, 0.3)
+    MODES = {"vanilla": 0, "dragan": 0, "lsgan": 1, "wgan": 2}
+
+    def __init__(self, gan_mode, smooth_labels=True, target_real_label=None, target_fake_label=None):
+        if gan_mode not in self.MODES:
+            if any(k in gan_mode for k in ("gp", "lp")):
+                raise NotImplementedError("gan mode %s not implemented (gradient-penalty modes need a "
+                                          "double backward through D: SURVEY.md 8(f) rank 4)" % gan_mode)
+            raise NotImplementedError("gan mode %s not implemented" % gan_mode)
+        self.gan_mode = gan_mode
+        self.native_mode = self.MODES[gan_mode]
+        self.smooth = smooth_labels
+        self.real_label = target_real_label if target_real_label is not None else (
+            self.default_smooth_real if smooth_labels else self.default_real)
+        self.fake_label = target_fake_label if target_fake_label is not None else (
+            self.default_smooth_fake if smooth_labels else self.default_fake)
+
+    def to(self, device):
+        return self
+
+    @staticmethod
+    def rand_between(low, high):
+        """loss.py:65-77: torch.rand(1) * (high - low) + low in fp32 tensor arithmetic."""
+        low, high = torch.tensor(low), torch.tensor(high)
+        return float(torch.rand(1) * (high - low) + low)
+
+    def sample_label(self, target_is_real):
+        """get_target_tensor (loss.py:79-108).  With smooth labels BOTH branches sample from the
+        REAL range -- the fake branch unpacks self.real_label (loss.py:102); reproduced as is.
+        (The reference's hard mode crashes on len() of a 0-d tensor, loss.py:92; here it simply
+        returns the constants.)"""
+        if self.native_mode == 2:
+            return 0.0
+        label = self.real_label if target_is_real else self.fake_label
+        if isinstance(label, (tuple, list)):
+            low, high = self.real_label
+            return self.rand_between(low, high)
+        return float(label)

@@ -1,0 +1,178 @@
+"""Drop-in boundary: the reference's model API -- create_model(opt), set_input,
+optimize_parameters, get_current_losses, fakes, save_checkpoint / load, optimizer state dicts --
+served by swapnet_amd.  With the same torch seed the model draws the same three smooth labels
+as the reference and must therefore reproduce the golden losses of the REAL reference."""
+import argparse
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import swapnet_oracle as O
+from oracle.golden_io import compare
+from swapnet_amd import engine
+from tests import backends
+
+BACKENDS = [pytest.param("sim", id="hostsim"), pytest.param("gpu", id="mi355x", marks=pytest.mark.gpu)]
+
+
+def make_opt(tmp, backend, **kw):
+    lib = None
+    if backend == "sim":
+        lib = backends.hostsim_ctx().lib
+    else:
+        backends.gpu_ctx()
+    o = dict(gpu_id=0, is_train=True, checkpoints_dir=str(tmp), name="t", no_confirm=True, model="warp",
+             body_channels=12, body_representation="rgb", cloth_channels=19, cloth_representation="labels",
+             texture_channels=3, init_type="kaiming", init_gain=0.02, discriminator="basic", n_layers_D=3,
+             norm="instance", gan_label_mode="smooth", gan_mode="vanilla", lambda_discriminator=1.0, lambda_gan=1.0,
+             lambda_gp=10, optimizer_G="AdamW", optimizer_D="AdamW", lr=1e-4, d_lr=4e-4, weight_decay=0.0,
+             d_weight_decay=0.01, b1=0.9, b2=0.999, beta1=0.5, verbose=False, continue_train=False,
+             load_epoch="latest", batch_size=2, crop_size=64, warp_mode="gan", lambda_ce=100.0,
+             body_norm_stats=((0.0,) * 3, (1.0,) * 3), texture_norm_stats=((0.0,) * 3, (1.0,) * 3),
+             netG="swapnet", lambda_l1=10.0, lambda_content=20.0, lambda_style=1e-8, _swapnet_lib=lib)
+    o.update(kw)
+    return argparse.Namespace(**o)
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_warp_model_reproduces_reference_losses_and_checkpoints(backend, tmp_path, golden_dir):
+    from swapnet_amd.models import create_model
+    gold = np.load(os.path.join(golden_dir, "warp_step_64.npz"))
+    opt = make_opt(tmp_path, backend)
+    model = create_model(opt)
+    model.setup(opt)
+    assert model.loss_names == ["D", "D_real", "D_fake", "G", "G_gan", "G_ce"]          # base_gan.py:161-167, warp_model.py:76
+    assert model.model_names == ["generator", "discriminator"]
+    # weights of the reference run (same seed => same kaiming draws in the oracle's RNG-faithful builder)
+    torch.manual_seed(int(gold["meta/init_seed"]))
+    G, D = O.warp_module_params(), O.patchgan_params(22)
+    model.net_generator.load_state_dict(G)
+    model.net_discriminator.load_state_dict(D)
+    model.eval()                                                   # dropout off, like the golden run
+    bodys, inputs, targets = O.synth_warp_batch(2, 64, 64, seed=1234)
+    data = dict(bodys=bodys, input_cloths=inputs, target_cloths=targets, cloth_paths=["c0", "c1"], body_paths=["b0", "b1"])
+    model.set_input(data)
+    torch.manual_seed(int(gold["meta/step_seeds"][0]))            # the step draws its 3 labels from here
+    model.optimize_parameters()
+    losses = model.get_current_losses()
+    assert list(losses.keys()) == model.loss_names
+    for k, v in losses.items():
+        ref = float(gold["step0/loss/" + k])
+        assert abs(v - ref) <= 1e-3 * abs(ref) + 1e-6, (k, v, ref)
+    ok, msg = compare(gold, "step0/fakes", model.fakes, 1e-3, 1e-3)
+    assert ok, msg
+    assert model.fakes[0].argmax(dim=0).shape == (64, 64)           # inference.py:149 / data_utils.py:322
+    assert model.get_image_paths() == (("c0", "b0"), ("c1", "b1"))
+    model.compute_visuals()
+    vis = model.get_current_visuals()
+    assert set(vis) == {"inputs_decoded", "bodys_unnormalized", "fakes_decoded", "targets_decoded"}
+    assert torch.equal(vis["fakes_decoded"], O.decode_cloth_labels(model.fakes.cpu()))
+    # ---- checkpoints: reference file names + key layout, loadable by plain torch ----------
+    model.save_checkpoint("latest")
+    for f in ("latest_net_generator.pth", "latest_net_discriminator.pth", "latest_optim_G.pth", "latest_optim_D.pth"):
+        assert os.path.exists(os.path.join(model.save_dir, f)), f
+    sd = torch.load(os.path.join(model.save_dir, "latest_net_generator.pth"))
+    assert list(sd.keys()) == list(G.keys()) and sd["upsample_and_pad.2.weight"].shape == (19, 192, 4, 4)
+    osd = torch.load(os.path.join(model.save_dir, "latest_optim_D.pth"))
+    ps = [torch.nn.Parameter(v.clone()) for v in D.values()]
+    topt = torch.optim.AdamW(ps, lr=4e-4, weight_decay=0.01)
+    topt.load_state_dict(osd)                                      # torch accepts our optimizer state dict
+    assert float(topt.state[ps[0]]["step"]) == 1.0
+    # resume: a fresh model restored from the checkpoint continues bit-identically
+    opt2 = make_opt(tmp_path, backend, continue_train=True)
+    m2 = create_model(opt2)
+    m2.setup(opt2)
+    m2.eval()
+    for m in (model, m2):
+        m.set_input(data)
+        torch.manual_seed(7)
+        m.optimize_parameters()
+    assert model.get_current_losses() == m2.get_current_losses()
+    a = model.net_generator.state_dict()["body_down2.model.0.weight"]
+    b = m2.net_generator.state_dict()["body_down2.model.0.weight"]
+    assert torch.equal(a, b)
+    # a smaller last batch (CappedDataLoader tail) keeps training on the same state
+    small = {k: (v[:1] if torch.is_tensor(v) else v[:1]) for k, v in data.items()}
+    model.set_input(small)
+    torch.manual_seed(8)
+    model.optimize_parameters()
+    assert model.fakes.shape == (1, 19, 64, 64) and all(np.isfinite(v) for v in model.get_current_losses().values())
+    assert model.optimizer_G.state_dict()["state"][0]["step"] == 3
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_inference_only_generator_and_error_conventions(backend, tmp_path):
+    from swapnet_amd.models import create_model, find_model_using_name
+    opt = make_opt(tmp_path, backend, is_train=False, batch_size=1)
+    model = create_model(opt)
+    assert model.model_names == ["generator"] and not hasattr(model, "net_discriminator")   # base_gan.py:145
+    torch.manual_seed(0)
+    G = O.warp_module_params()
+    model.net_generator.load_state_dict(G)
+    model.eval()
+    bodys, inputs, _ = O.synth_warp_batch(1, 64, 64, seed=5)
+    model.set_input(dict(bodys=bodys, input_cloths=inputs, cloth_paths=[""], body_paths=[""]))
+    model.test()                                                   # base_model.py:103-110
+    with torch.no_grad():
+        ref = O.warp_module_forward(G, bodys, inputs)
+    assert float((model.fakes.cpu() - ref).norm() / ref.norm()) < 1e-3
+    # error conventions
+    with pytest.raises(NotImplementedError):
+        find_model_using_name("pix2pix")
+    from swapnet_amd.modules.loss import GANLoss
+    with pytest.raises(NotImplementedError):
+        GANLoss("wgan-gp")
+    with pytest.raises(NotImplementedError):
+        GANLoss("nonsense")
+    from swapnet_amd import optimizers
+    with pytest.raises(ValueError):
+        optimizers.define_optimizer(model.net_generator, opt, "X")
+    with pytest.raises(RuntimeError):
+        model.net_generator.load_state_dict({"bogus": torch.zeros(1)})
+    with pytest.raises(RuntimeError):
+        create_model(make_opt(tmp_path, backend, gpu_id=None))
+
+
+def test_gan_label_draw_order_matches_reference(golden_dir):
+    """GANLoss draws: fake-D, real-D, real-G, all from U(0.7,1.1) (loss.py:93,102)."""
+    from swapnet_amd.modules.loss import GANLoss
+    gold = np.load(os.path.join(golden_dir, "warp_step_64.npz"))
+    c = GANLoss("vanilla", smooth_labels=True)
+    torch.manual_seed(int(gold["meta/step_seeds"][0]))
+    got = [c.sample_label(False), c.sample_label(True), c.sample_label(True)]
+    np.testing.assert_allclose(got, gold["step0/labels"], rtol=0, atol=1e-7)
+    assert all(0.7 <= v <= 1.1 for v in got)
+    h = GANLoss("vanilla", smooth_labels=False)
+    assert h.sample_label(True) == 1.0 and h.sample_label(False) == 0.0
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/options"), reason="reference tree not mounted")
+def test_reference_options_and_entry_points_resolve_to_native_packages(tmp_path, monkeypatch):
+    """train.py / options/ of the reference, unchanged, against swapnet_amd's packages: the
+    reference's own TrainOptions two-pass parse pulls the model/optimizer flag modifiers from
+    `models` / `optimizers` (options/base_options.py:171-187)."""
+    import swapnet_amd
+    from oracle import ref_stubs
+    saved = dict(sys.modules)
+    try:
+        ref_stubs.install()                      # torchvision/visdom/... stand-ins for datasets/ and util/
+        swapnet_amd.install_as_reference_packages()
+        sys.modules.pop("options", None)
+        for k in [k for k in sys.modules if k.startswith("options.")]:
+            sys.modules.pop(k)
+        monkeypatch.setattr(sys, "argv", ["train.py", "--name", "x", "--model", "warp", "--dataroot", str(tmp_path),
+                                          "--checkpoints_dir", str(tmp_path), "--no_confirm", "--lambda_ce", "50"])
+        from options.train_options import TrainOptions
+        opt = TrainOptions().parse(print_options=False, store_options=False)
+        assert opt.lambda_ce == 50 and opt.gan_mode == "vanilla" and opt.d_lr == 4e-4 and opt.b1 == 0.9
+        assert opt.lr == 1e-4                    # model flag overrides train flag (conflict_handler="resolve")
+        import models
+        assert models.create_model.__module__.startswith("swapnet_amd")
+    finally:
+        for k in list(sys.modules):
+            if k not in saved:
+                del sys.modules[k]
+        sys.modules.update(saved)
