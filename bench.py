@@ -180,9 +180,18 @@ def main():
             k = kernels[dom]
             ach = k["flops"] / (k["ms"] * 1e-3) / 1e12
             gemm_ms = sum(v["ms"] for v in kernels.values()) / nprof
+            traffic = None
+            tpath = os.path.join(REPO, "profiles", "traffic_r01.json")
+            rp_name = {"conv_fwd_128x128_fast": "conv_fwd_kernel<2, 2, 2, 2, true>"}.get(dom)
+            if os.path.exists(tpath) and rp_name:
+                # HBM bytes per launch from the committed rocprofv3 PMC passes of this same command
+                # (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE; see profiles/README.md)
+                t = json.load(open(tpath))["kernels"].get(rp_name)
+                if t:
+                    traffic = t["fetch_bytes_per_launch"] + t["write_bytes_per_launch"]
             out["roofline"] = {
                 "bound": "mfma", "kernel": dom, "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS,
-                "unit": "TFLOP/s", "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+                "unit": "TFLOP/s", "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic,
                 "avg_launch_ms": round(k["ms"] / k["launches"], 4), "launches_per_step": k["launches"] // nprof,
                 "step_frac": round(flop_per_img * B / (ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
                 "gemm_ms_per_step": round(gemm_ms, 2),

@@ -15,8 +15,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 
 
 def short(name):
+    name = name.replace("(anonymous namespace)::", "").replace("void swn::", "").replace("swn::", "")
     name = re.sub(r"\(.*", "", name)
-    name = name.replace("void swn::", "").replace("swn::", "").replace("(anonymous namespace)::", "")
     return name[:90]
 
 
