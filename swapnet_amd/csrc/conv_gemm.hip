@@ -20,7 +20,9 @@
 // contiguous axis.  Small-M x large-K layers (cloth_down5/6, cloth_up1) are split along K
 // (wgrad: along pixels) into deterministic slabs that a reduce kernel sums in fixed order.
 #include <array>
+#include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <vector>
@@ -296,6 +298,27 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(GemmP p) {
   const int He = p.xH << p.ups, We = p.xW << p.ups;
   const int HoWo = p.Ho * p.Wo;
 
+  // per-row pixel cursors (n, oy, ox), advanced by 32 pixels per stage instead of being
+  // re-derived with two integer divisions per row per stage
+  const int nmb = (p.M + 31) / 32;
+  const int mb_begin = split * p.per_split;
+  const int mb_end = min(nmb, mb_begin + p.per_split);
+  int an[RA], aoy[RA], aox[RA], bn[RB], boy[RB], box[RB];
+  auto decode = [&](int m, int& n, int& oy, int& ox) {
+    n = m / HoWo; const int rem = m - n * HoWo;
+    oy = rem / p.Wo; ox = rem - oy * p.Wo;
+  };
+  auto advance = [&](int& n, int& oy, int& ox) {
+    ox += 32;
+    while (ox >= p.Wo) { ox -= p.Wo; ++oy; }
+    while (oy >= p.Ho) { oy -= p.Ho; ++n; }
+  };
+#pragma unroll
+  for (int r = 0; r < RA; ++r) decode(mb_begin * 32 + arow0 + r * AROWS, an[r], aoy[r], aox[r]);
+#pragma unroll
+  for (int r = 0; r < RB; ++r) decode(mb_begin * 32 + brow0 + r * BROWS, bn[r], boy[r], box[r]);
+  const int ximg = p.xH * p.xW * p.xcs;
+
   float4 ra[RA], rb[RB];
   auto load_tiles = [&](int mb) {
     const int mbase = mb * 32;
@@ -304,27 +327,23 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(GemmP p) {
       const int m = mbase + arow0 + r * AROWS;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       if (m < p.M && kvalid) {
-        const int n = m / HoWo, rem = m - n * HoWo;
-        const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
-        const int sy = src_coord(oy * p.stride - p.pad_t + kh, He, p.pad_mode, p.ups);
-        const int sx = src_coord(ox * p.stride - p.pad_l + kw, We, p.pad_mode, p.ups);
+        const int sy = src_coord(aoy[r] * p.stride - p.pad_t + kh, He, p.pad_mode, p.ups);
+        const int sx = src_coord(aox[r] * p.stride - p.pad_l + kw, We, p.pad_mode, p.ups);
         if (sy >= 0 && sx >= 0)
-          v = *reinterpret_cast<const float4*>(p.x + (size_t)n * p.xH * p.xW * p.xcs +
-                                               (size_t)(sy * p.xW + sx) * p.xcs + ci);
+          v = *reinterpret_cast<const float4*>(p.x + (size_t)an[r] * ximg + (size_t)(sy * p.xW + sx) * p.xcs + ci);
       }
       ra[r] = v;
+      advance(an[r], aoy[r], aox[r]);
     }
 #pragma unroll
     for (int r = 0; r < RB; ++r) {
       const int m = mbase + brow0 + r * BROWS;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (m < p.M && nvalid) {
-        const int n = m / HoWo, rem = m - n * HoWo;
-        const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+      if (m < p.M && nvalid)
         v = *reinterpret_cast<const float4*>(
-            p.y + (size_t)((n * p.yH + oy * p.ymul + p.yoff) * p.yW + ox * p.xmul + p.xoff) * p.ycs + n0 + bcol);
-      }
+            p.y + (size_t)((bn[r] * p.yH + boy[r] * p.ymul + p.yoff) * p.yW + box[r] * p.xmul + p.xoff) * p.ycs + n0 + bcol);
       rb[r] = v;
+      advance(bn[r], boy[r], box[r]);
     }
   };
   auto store_tiles = [&](int buf) {
@@ -362,9 +381,6 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(GemmP p) {
     }
   };
 
-  const int nmb = (p.M + 31) / 32;
-  const int mb_begin = split * p.per_split;
-  const int mb_end = min(nmb, mb_begin + p.per_split);
   if (mb_begin < mb_end) {
     load_tiles(mb_begin);
     store_tiles(0);
@@ -522,6 +538,33 @@ static GemmP make_params(const TView& x, const Gather& g, const TView& y, const 
   return p;
 }
 
+// Wave-quantisation-aware split factor.  `ntiles` output tiles, each `work` reduction steps
+// long, run on `slots` concurrently resident workgroups (CUs x workgroups/CU).  A tile count just
+// above a multiple of `slots` leaves most of the chip idle in the last round (e.g. 576 wgrad
+// tiles of a resblock conv on 512 slots = 56 % efficiency); splitting the reduction s ways
+// trades that for s slabs summed by a cheap second kernel.  Cost model: rounds x (steps per
+// block + fixed prologue/epilogue) + slab traffic.
+static int choose_splits(int ntiles, int work, int slots, int min_work, size_t slab_bytes, size_t ws_bytes) {
+  int best = 1;
+  double best_cost = 1e300;
+  const int max_s = std::max(1, std::min(512, work / std::max(min_work, 1)));
+  for (int sp = 1; sp <= max_s; ++sp) {
+    if (sp > 1 && slab_bytes * sp > ws_bytes) break;
+    const int per = ceil_div(work, sp);
+    const int eff = ceil_div(work, per);
+    const double rounds = std::ceil((double)ntiles * eff / slots);
+    double cost = rounds * (per + 4.0);
+    if (eff > 1) cost += 0.02 * eff * ((double)ntiles / slots) + 1.0;   // slab write + reduce launch
+    if (cost < best_cost * 0.97) { best_cost = cost; best = eff; }
+  }
+  return best;
+}
+
+static bool prof_detail() {
+  static const bool on = getenv("SWN_PROF_DETAIL") != nullptr;
+  return on;
+}
+
 template <typename K>
 static void set_smem(K kernel, int bytes) {
   SWN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
@@ -535,20 +578,19 @@ static void launch_fwd(Stream& s, GemmP& p, bool fast) {
   p.tiles_n = ceil_div(p.Npad, T::BN);
   p.ntiles = tiles_m * p.tiles_n;
   const int nkb = ceil_div(p.K, 32);
-  int splits = 1;
-  if (p.ntiles < 384 && nkb >= 16) {
-    splits = std::min(nkb / 8, ceil_div(768, p.ntiles));
-    const size_t per = (size_t)p.M * p.Npad * 4;
-    if (per * splits > s.ws_bytes) splits = (int)(s.ws_bytes / per);
-    if (splits < 2) splits = 1;
-  }
+  const int slots = 256 * (T::SMEM_FWD > 64 * 1024 ? 2 : 3);
+  const int splits = choose_splits(p.ntiles, nkb, slots, 8, (size_t)p.M * p.Npad * 4, s.ws_bytes);
   p.splits = splits;
   p.per_split = ceil_div(nkb, splits);
   p.splits = ceil_div(nkb, p.per_split);
   p.slab = reinterpret_cast<float*>(s.ws);
   dim3 grid(p.ntiles, p.splits);
-  char pname[64];
-  snprintf(pname, sizeof pname, "conv_fwd_%dx%d_%s", T::BM, T::BN, fast ? "fast" : "generic");
+  char pname[96];
+  if (prof_detail())
+    snprintf(pname, sizeof pname, "conv_fwd_%dx%d_%s[M%d,N%d,K%d,s%d]", T::BM, T::BN, fast ? "fast" : "generic", p.M,
+             p.Cout, p.K, p.splits);
+  else
+    snprintf(pname, sizeof pname, "conv_fwd_%dx%d_%s", T::BM, T::BN, fast ? "fast" : "generic");
   ProfScope prof(s, pname, 2.0 * p.M * p.Cout * p.K);
   if (fast) {
     static bool once = (set_smem(conv_fwd_kernel<MT, NT, WGM, WGN, true>, T::SMEM_FWD), true);
@@ -589,20 +631,18 @@ static void launch_wgrad(Stream& s, GemmP& p) {
   p.tiles_n = ceil_div(p.Npad, T::BN);
   p.ntiles = tiles_k * p.tiles_n;
   const int nmb = ceil_div(p.M, 32);
-  int splits = 1;
-  if (p.ntiles < 512 && nmb >= 16) {
-    splits = std::min(nmb / 8, ceil_div(1024, p.ntiles));
-    const size_t per = (size_t)p.K * p.Npad * 4;
-    if (per * splits > s.ws_bytes) splits = (int)(s.ws_bytes / per);
-    if (splits < 2) splits = 1;
-  }
+  const int slots = 256 * (T::SMEM_WG >= 64 * 1024 ? 2 : (T::SMEM_WG >= 48 * 1024 ? 3 : 4));
+  const int splits = choose_splits(p.ntiles, nmb, slots, 8, (size_t)p.K * p.Npad * 4, s.ws_bytes);
   p.per_split = ceil_div(nmb, splits);
   p.splits = ceil_div(nmb, p.per_split);
   p.slab = reinterpret_cast<float*>(s.ws);
   static bool once = (set_smem(conv_wgrad_kernel<MT, NT, WGM, WGN>, T::SMEM_WG), true);
   (void)once;
-  char pname[64];
-  snprintf(pname, sizeof pname, "conv_wgrad_%dx%d", T::BM, T::BN);
+  char pname[96];
+  if (prof_detail())
+    snprintf(pname, sizeof pname, "conv_wgrad_%dx%d[M%d,N%d,K%d,s%d]", T::BM, T::BN, p.M, p.Cout, p.K, p.splits);
+  else
+    snprintf(pname, sizeof pname, "conv_wgrad_%dx%d", T::BM, T::BN);
   ProfScope prof(s, pname, 2.0 * p.M * p.Cout * p.K);
   hipLaunchKernelGGL((conv_wgrad_kernel<MT, NT, WGM, WGN>), dim3(p.ntiles, p.splits), dim3(256), T::SMEM_WG, hs(s), p);
   check_launch("conv_wgrad");

@@ -157,13 +157,35 @@ void Net::conv(const std::string& name, const Var& x, const Var& y, ConvKind kin
   ParamArena* A = &arena;
   const Gather gf = geo.fwd;
   const TView xv = x.v, yv = y.v;
+  // tail conv: run as 4 folded sub-pixel phases on the un-upsampled input (25 instead of 64
+  // taps per 2x2 outputs; see ops.h tail_fold_weights).  The folded weights and the folded
+  // weight-gradient scratch live next to the dgrad operands and follow arena.version.
+  const bool folded = kind == CK_TAIL_UP;
+  size_t fold_off = 0, dfold_off = 0;
+  if (folded) {
+    const size_t fe = tail_fold_offset(arena.params[wi].ws, 4);
+    fold_off = reserve_dg(self, fe);
+    dfold_off = reserve_dg(self, fe);
+  }
+  auto phase_geom = [=](int ph, Gather& g, OutMap& om) {
+    const int a = ph >> 1, b = ph & 1;
+    g = Gather();
+    g.KH = 2 + a; g.KW = 2 + b; g.stride = 1; g.pad_t = 1; g.pad_l = 1; g.Ho = xv.H; g.Wo = xv.W;
+    om.ymul = 2; om.yoff = a; om.xmul = 2; om.xoff = b;
+  };
   op->fwd = [=](Net& n) {
     const ParamDesc& wd = A->params[wi];
     ConvFwdArgs a;
     a.x = xv; a.g = gf; a.w = A->w + wd.off; a.Npad = wd.ws.Npad;
     a.bias = bi >= 0 ? A->w + A->params[bi].off : nullptr;
     a.act = actf; a.y = yv; a.Cout = Co;
-    conv_fwd(n.ctx.s, a);
+    if (!folded) { conv_fwd(n.ctx.s, a); return; }
+    n.refresh_dgrad();                       // folded weights are derived operands too
+    for (int ph = 0; ph < 4; ++ph) {
+      phase_geom(ph, a.g, a.om);
+      a.w = n.dg + fold_off + tail_fold_offset(wd.ws, ph);
+      conv_fwd(n.ctx.s, a);
+    }
   };
 
   // ---- backward plan
@@ -195,6 +217,14 @@ void Net::conv(const std::string& name, const Var& x, const Var& y, ConvKind kin
       repack_dgrad(n.ctx.s, wd.ws, dg_mode, Cop, Ndg, A->w + wd.off, n.dg + dg_off);
     };
   }
+  if (folded) {
+    auto prev = op->repack;
+    op->repack = [=](Net& n) {
+      if (prev) prev(n);
+      const ParamDesc& wd = A->params[wi];
+      tail_fold_weights(n.ctx.s, wd.ws, A->w + wd.off, n.dg + fold_off);
+    };
+  }
   const TView ygv = y.g, xgv = x.g, scr = scratch.v, dxp = dxpad.v;
   const bool has_ygrad = y.has_grad;
   op->bwd = [=](Net& n, Op& me, bool wgrad, bool igrad) {
@@ -205,7 +235,16 @@ void Net::conv(const std::string& name, const Var& x, const Var& y, ConvKind kin
     if (wgrad) {
       ConvWgradArgs wa;
       wa.x = xv; wa.g = gf; wa.dy = dY; wa.dw = A->g + wd.off; wa.Npad = wd.ws.Npad; wa.Cout = Co;
-      conv_wgrad(n.ctx.s, wa);
+      if (!folded) {
+        conv_wgrad(n.ctx.s, wa);
+      } else {
+        for (int ph = 0; ph < 4; ++ph) {
+          phase_geom(ph, wa.g, wa.om);
+          wa.dw = n.dg + dfold_off + tail_fold_offset(wd.ws, ph);
+          conv_wgrad(n.ctx.s, wa);
+        }
+        tail_unfold_wgrad(n.ctx.s, wd.ws, n.dg + dfold_off, A->g + wd.off);
+      }
       if (bi >= 0) bias_grad(n.ctx.s, dY, A->g + A->params[bi].off);
     }
     if (!want_dx || (me.reads_net_input && !igrad)) return;

@@ -68,33 +68,59 @@ __global__ __launch_bounds__(256) void gan_loss_kernel(const float* pred, int pc
 }
 
 // ---- cross entropy vs argmax(target) ----------------------------------------------------
+// one thread per pixel; logits / target / gradient rows are moved as float4 (the views are
+// 16-byte aligned with C padded to a multiple of 4), C <= 32
 __global__ __launch_bounds__(256) void ce_kernel(const float* logits, int lcs, const float* target, int tcs, int C,
                                                  size_t pixels, float gscale, float* dl, int dcs, int accumulate,
                                                  double* partial) {
   __shared__ double sh[4];
   double acc = 0;
+  const int C4 = (C + 3) >> 2;
   for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < pixels; e += (size_t)gridDim.x * 256) {
-    const float* lp = logits + e * lcs;
-    const float* tp = target + e * tcs;
-    int label = 0; float tmax = tp[0];
-    float lmax = lp[0];
-    for (int c = 1; c < C; ++c) {
-      const float tv = tp[c];
-      if (tv > tmax) { tmax = tv; label = c; }     // first maximal index (torch.argmax)
-      lmax = fmaxf(lmax, lp[c]);
-    }
-    float se = 0.f;
-    for (int c = 0; c < C; ++c) se += expf(lp[c] - lmax);
-    const float lse = lmax + logf(se);
-    acc += (double)(lse - lp[label]);
-    if (dl) {
-      float* dp = dl + e * dcs;
-      const float inv = 1.f / se;
-      for (int c = 0; c < C; ++c) {
-        float g = (expf(lp[c] - lmax) * inv - (c == label ? 1.f : 0.f)) * gscale;
-        if (accumulate) g += dp[c];
-        dp[c] = g;
+    float l[32], tg[32];
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      if (j < C4) {
+        const float4 a = *reinterpret_cast<const float4*>(logits + e * lcs + 4 * j);
+        const float4 b = *reinterpret_cast<const float4*>(target + e * tcs + 4 * j);
+        l[4 * j] = a.x; l[4 * j + 1] = a.y; l[4 * j + 2] = a.z; l[4 * j + 3] = a.w;
+        tg[4 * j] = b.x; tg[4 * j + 1] = b.y; tg[4 * j + 2] = b.z; tg[4 * j + 3] = b.w;
       }
+    int label = 0; float tmax = tg[0], lmax = l[0];
+#pragma unroll
+    for (int c = 1; c < 32; ++c)
+      if (c < C) {
+        if (tg[c] > tmax) { tmax = tg[c]; label = c; }     // first maximal index (torch.argmax)
+        lmax = fmaxf(lmax, l[c]);
+      }
+    float se = 0.f, ll = 0.f;
+#pragma unroll
+    for (int c = 0; c < 32; ++c)
+      if (c < C) {
+        const float d = l[c] - lmax;
+        if (c == label) ll = d;
+        l[c] = expf(d); se += l[c];
+      }
+    // -log softmax[label] = log(se) - (logit[label] - lmax)
+    acc += (double)(logf(se) - ll);
+    if (dl) {
+      const float inv = gscale / se;
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        if (j < C4) {
+          float* dp = dl + e * dcs + 4 * j;
+          float g[4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int c = 4 * j + i;
+            g[i] = c < C ? l[c] * inv - (c == label ? gscale : 0.f) : 0.f;
+          }
+          if (accumulate) {
+            const float4 o = *reinterpret_cast<const float4*>(dp);
+            g[0] += o.x; g[1] += o.y; g[2] += o.z; g[3] += o.w;
+          }
+          *reinterpret_cast<float4*>(dp) = make_float4(g[0], g[1], g[2], g[3]);
+        }
     }
   }
   const double r = block_sum(acc, sh);
@@ -287,6 +313,9 @@ void wgan_loss(Stream& s, const TView& pred, float sign, float scale, float* los
 void ce_argmax_loss(Stream& s, const TView& logits, const TView& target, int C, float scale, float* loss_out,
                     const TView* dlogits, int accumulate) {
   const size_t pixels = logits.pixels();
+  if (C > 32 || logits.cs % 4 || target.cs % 4 || ((uintptr_t)logits.p & 15) || ((uintptr_t)target.p & 15) ||
+      (dlogits && (dlogits->cs % 4 || ((uintptr_t)dlogits->p & 15))))
+    throw Error(1, "ce_argmax_loss: needs C <= 32 and 16-byte aligned views");
   const int grid = loss_grid(pixels);
   double* partial = reinterpret_cast<double*>(s.ws);
   hipLaunchKernelGGL(ce_kernel, dim3(grid), dim3(256), 0, hs(s), logits.p, logits.cs, target.p, target.cs, C, pixels,

@@ -229,12 +229,17 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* dy, in
     for (int j = 0; j < 4; ++j) partial[(size_t)blockIdx.x * C + tx * 4 + j] = red[t * 4 + j];
   }
 }
-__global__ void colsum_final_kernel(const double* partial, int nchunk, int C, float* out) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+// 64 channels x 4 lanes per block: each lane sums a quarter of the chunk partials (fixed order)
+__global__ __launch_bounds__(256) void colsum_final_kernel(const double* partial, int nchunk, int C, float* out) {
+  __shared__ double red[256];
+  const int cl = threadIdx.x & 63, lane4 = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
   double a = 0;
-  for (int i = 0; i < nchunk; ++i) a += partial[(size_t)i * C + c];
-  out[c] = (float)a;
+  if (c < C)
+    for (int i = lane4; i < nchunk; i += 4) a += partial[(size_t)i * C + c];
+  red[threadIdx.x] = a;
+  __syncthreads();
+  if (lane4 == 0 && c < C) out[c] = (float)(red[cl] + red[64 + cl] + red[128 + cl] + red[192 + cl]);
 }
 
 __global__ __launch_bounds__(256) void reflect_fold_kernel(const float* src, int scs, float* dst, int dcs, int N,
@@ -360,13 +365,13 @@ void bias_grad(Stream& s, const TView& dy, float* db) {
   check_view4(dy, "bias_grad dy");
   const size_t pixels = dy.pixels();
   const int rows = std::max(1, 256 / (dy.C / 4));
-  int nchunk = (int)std::min<size_t>(1024, std::max<size_t>(1, pixels / (rows * 4)));
+  int nchunk = (int)std::min<size_t>(512, std::max<size_t>(1, pixels / (rows * 4)));
   const size_t chunk = (pixels + nchunk - 1) / nchunk;
   nchunk = (int)((pixels + chunk - 1) / chunk);
   double* partial = reinterpret_cast<double*>(s.ws);
   if ((size_t)nchunk * dy.C * 8 > s.ws_bytes) throw Error(1, "bias_grad: workspace too small");
   hipLaunchKernelGGL(colsum_partial_kernel, dim3(nchunk), dim3(256), 0, hs(s), dy.p, dy.cs, pixels, dy.C, chunk, partial);
-  hipLaunchKernelGGL(colsum_final_kernel, dim3(ceil_div(dy.C, 256)), dim3(256), 0, hs(s), partial, nchunk, dy.C, db);
+  hipLaunchKernelGGL(colsum_final_kernel, dim3(ceil_div(dy.C, 64)), dim3(256), 0, hs(s), partial, nchunk, dy.C, db);
   check_launch("bias_grad");
 }
 

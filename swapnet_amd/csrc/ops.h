@@ -179,5 +179,13 @@ void unpack_weight(Stream& s, const WShape& w, const float* packed, float* nchw)
 //    kernel  [ (r*5+c)*Cop + co ][ci] = sum_{a-ky+3=r, b-kx+3=c; a,b in {0,1}} W[ky][kx]
 void repack_dgrad(Stream& s, const WShape& w, int mode, int Cop, int Ndgpad, const float* packed, float* dg);
 size_t dgrad_elems(const WShape& w, int mode, int Cop, int Ndgpad);
+// Tail conv (x2 nearest upsample + ZeroPad(1,0,1,0) + conv k4 p1, swapnet_modules.py:85-90) folded
+// onto the un-upsampled input: output phase (a,b) = (y&1, x&1) is a (2+a)x(2+b) conv with
+// pre-summed taps  r(a,ky) = a ? (ky+1)>>1 : ky>>1  (25 instead of 64 taps per 2x2 outputs).
+// Layout: 4 phase blocks p = a*2+b, each [ (r*(2+b)+c)*Cip + ci ][Npad], at tail_fold_offset(p).
+size_t tail_fold_offset(const WShape& w, int phase);       // in floats; phase 4 = total size
+void tail_fold_weights(Stream& s, const WShape& w, const float* packed, float* folded);
+// inverse for the weight gradient: dW[ky][kx] = sum over the 4 phases of dWfold[p][r(a,ky)][c(b,kx)]
+void tail_unfold_wgrad(Stream& s, const WShape& w, const float* dfolded, float* dpacked);
 
 }  // namespace swn

@@ -146,6 +146,46 @@ __global__ void repack_dgrad_kernel(PackP p) {
   p.dst[i] = v;
 }
 
+__device__ __forceinline__ int fold_tap(int a, int k) { return a ? (k + 1) >> 1 : k >> 1; }
+
+// MODE 0: folded[p][r][c][ci][n] = sum of the packed taps that fold onto (r,c); MODE 1: unfold grads
+template <int MODE>
+__global__ void tail_fold_kernel(WShape w, const float* src, float* dst, size_t total) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const size_t per_tap = (size_t)w.Cip * w.Npad;
+  if (MODE == 0) {
+    // locate phase
+    size_t off = i; int ph = 0;
+    for (; ph < 4; ++ph) {
+      const size_t sz = (size_t)(2 + (ph >> 1)) * (2 + (ph & 1)) * per_tap;
+      if (off < sz) break;
+      off -= sz;
+    }
+    const int a = ph >> 1, b = ph & 1, KWp = 2 + b;
+    const int tap = (int)(off / per_tap); const size_t rem = off - (size_t)tap * per_tap;
+    const int r = tap / KWp, c = tap - r * KWp;
+    float v = 0.f;
+    for (int ky = 0; ky < 4; ++ky) {
+      if (fold_tap(a, ky) != r) continue;
+      for (int kx = 0; kx < 4; ++kx)
+        if (fold_tap(b, kx) == c) v += src[(size_t)(ky * 4 + kx) * per_tap + rem];
+    }
+    dst[i] = v;
+  } else {
+    const int tap = (int)(i / per_tap); const size_t rem = i - (size_t)tap * per_tap;
+    const int ky = tap >> 2, kx = tap & 3;
+    float v = 0.f;
+    size_t base = 0;
+    for (int ph = 0; ph < 4; ++ph) {
+      const int a = ph >> 1, b = ph & 1, KWp = 2 + b;
+      v += src[base + (size_t)(fold_tap(a, ky) * KWp + fold_tap(b, kx)) * per_tap + rem];
+      base += (size_t)(2 + a) * KWp * per_tap;
+    }
+    dst[i] = v;
+  }
+}
+
 inline unsigned blocks(size_t n) { return (unsigned)((n + 255) / 256); }
 
 }  // namespace
@@ -176,6 +216,22 @@ void unpack_weight(Stream& s, const WShape& w, const float* packed, float* nchw)
   PackP p{}; p.w = w; p.src = packed; p.dst = nchw; p.total = (size_t)w.Co * w.Ci * w.KH * w.KW;
   hipLaunchKernelGGL(unpack_kernel, dim3(blocks(p.total)), dim3(256), 0, hs(s), p);
   check_launch("unpack_weight");
+}
+
+size_t tail_fold_offset(const WShape& w, int phase) {
+  size_t off = 0;
+  for (int p = 0; p < phase && p < 4; ++p) off += (size_t)(2 + (p >> 1)) * (2 + (p & 1)) * w.Cip * w.Npad;
+  return off;
+}
+void tail_fold_weights(Stream& s, const WShape& w, const float* packed, float* folded) {
+  const size_t total = tail_fold_offset(w, 4);
+  hipLaunchKernelGGL(tail_fold_kernel<0>, dim3(blocks(total)), dim3(256), 0, hs(s), w, packed, folded, total);
+  check_launch("tail_fold_weights");
+}
+void tail_unfold_wgrad(Stream& s, const WShape& w, const float* dfolded, float* dpacked) {
+  const size_t total = (size_t)16 * w.Cip * w.Npad;
+  hipLaunchKernelGGL(tail_fold_kernel<1>, dim3(blocks(total)), dim3(256), 0, hs(s), w, dfolded, dpacked, total);
+  check_launch("tail_unfold_wgrad");
 }
 
 size_t dgrad_elems(const WShape& w, int mode, int Cop, int Ndgpad) {

@@ -440,6 +440,32 @@ void unpack_weight(Stream&, const WShape& w, const float* src, float* dst) {
     }
   }
 }
+static int ftap(int a, int k) { return a ? (k + 1) >> 1 : k >> 1; }
+size_t tail_fold_offset(const WShape& w, int phase) {
+  size_t off = 0;
+  for (int p = 0; p < phase && p < 4; ++p) off += (size_t)(2 + (p >> 1)) * (2 + (p & 1)) * w.Cip * w.Npad;
+  return off;
+}
+void tail_fold_weights(Stream&, const WShape& w, const float* src, float* dst) {
+  const size_t pt = (size_t)w.Cip * w.Npad;
+  std::memset(dst, 0, tail_fold_offset(w, 4) * sizeof(float));
+  for (int ph = 0; ph < 4; ++ph) { const int a = ph >> 1, b = ph & 1;
+    float* d = dst + tail_fold_offset(w, ph);
+    for (int ky = 0; ky < 4; ++ky) for (int kx = 0; kx < 4; ++kx) {
+      float* dd = d + (size_t)(ftap(a, ky) * (2 + b) + ftap(b, kx)) * pt;
+      const float* ss = src + (size_t)(ky * 4 + kx) * pt;
+      for (size_t i = 0; i < pt; ++i) dd[i] += ss[i]; } }
+}
+void tail_unfold_wgrad(Stream&, const WShape& w, const float* src, float* dst) {
+  const size_t pt = (size_t)w.Cip * w.Npad;
+  std::memset(dst, 0, 16 * pt * sizeof(float));
+  for (int ph = 0; ph < 4; ++ph) { const int a = ph >> 1, b = ph & 1;
+    const float* sp = src + tail_fold_offset(w, ph);
+    for (int ky = 0; ky < 4; ++ky) for (int kx = 0; kx < 4; ++kx) {
+      const float* ss = sp + (size_t)(ftap(a, ky) * (2 + b) + ftap(b, kx)) * pt;
+      float* dd = dst + (size_t)(ky * 4 + kx) * pt;
+      for (size_t i = 0; i < pt; ++i) dd[i] += ss[i]; } }
+}
 size_t dgrad_elems(const WShape& w, int mode, int Cop, int Ndg) {
   switch (mode) { case 0: return (size_t)16 * Cop * Ndg; case 1: return (size_t)w.KH * w.KW * Cop * Ndg;
                   case 2: return (size_t)16 * Cop * Ndg; default: return (size_t)25 * Cop * Ndg; }
