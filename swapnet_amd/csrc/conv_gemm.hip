@@ -67,7 +67,7 @@ struct Tile {
   static constexpr int BM = 32 * MT * WGM;
   static constexpr int BN = 32 * NT * WGN;
   static constexpr int BK = 32;
-  static constexpr int AS = BK + 1;
+  static constexpr int AS = BK + 4;   // 16-byte aligned rows; 36*i mod 64 banks distinct for 16 rows (b128)
   static constexpr int A_FLOATS = ((BM * AS + 3) / 4) * 4;
   static constexpr int B_FLOATS = BK * BN;
   static constexpr int SMEM_FWD = (2 * A_FLOATS + 2 * B_FLOATS + BM) * 4;
@@ -79,12 +79,14 @@ struct Tile {
 // forward-type kernel
 // ---------------------------------------------------------------------------------------
 template <int MT, int NT, int WGM, int WGN, bool FAST>
-__global__ __launch_bounds__(256) void conv_fwd_kernel(GemmP p) {
+__global__ __launch_bounds__(64 * WGM * WGN) void conv_fwd_kernel(GemmP p) {
   using T = Tile<MT, NT, WGM, WGN>;
   constexpr int BM = T::BM, BN = T::BN, AS = T::AS;
-  constexpr int RA = BM / 32;
-  constexpr int RB = BN / 32;
-  constexpr int BROWS = 1024 / BN;     // rows of the B tile covered by one pass of 256 threads
+  constexpr int NTHR = 64 * WGM * WGN;
+  constexpr int AROWS = NTHR / 8;        // A-tile rows covered by one pass (8 lanes x 16 B per row)
+  constexpr int RA = BM / AROWS;
+  constexpr int BROWS = NTHR / (BN / 4);  // B-tile rows covered by one pass
+  constexpr int RB = 32 / BROWS;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* As = smem;
   float* Bs = smem + 2 * T::A_FLOATS;
@@ -102,7 +104,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(GemmP p) {
   const int HoWo = p.Ho * p.Wo;
 #pragma unroll
   for (int r = 0; r < RA; ++r) {
-    const int m = m0 + p0 + 32 * r;
+    const int m = m0 + p0 + AROWS * r;
     if (m < p.M) {
       const int n = m / HoWo, rem = m - n * HoWo;
       const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
@@ -155,10 +157,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(GemmP p) {
   auto store_tiles = [&](int buf) {
     float* A = As + buf * T::A_FLOATS;
 #pragma unroll
-    for (int r = 0; r < RA; ++r) {
-      float* d = A + (p0 + 32 * r) * AS + 4 * q;
-      d[0] = ra[r].x; d[1] = ra[r].y; d[2] = ra[r].z; d[3] = ra[r].w;
-    }
+    for (int r = 0; r < RA; ++r) *reinterpret_cast<float4*>(A + (p0 + AROWS * r) * AS + 4 * q) = ra[r];
     float* B = Bs + buf * T::B_FLOATS;
 #pragma unroll
     for (int r = 0; r < RB; ++r)
@@ -173,22 +172,35 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(GemmP p) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
+  // One LDS stage = 16 MFMA k-steps.  The reduction order inside the stage is permuted so that
+  // step s consumes k = s (lanes 0-31) and k = 16 + s (lanes 32-63): a lane's 16 A values are
+  // then contiguous in its row -> 4 ds_read_b128 instead of 16 ds_read_b32.  All fragments of the
+  // stage are fetched before the first MFMA (64 VGPRs) so LDS latency is paid once per stage,
+  // not once per k-step.
   auto compute = [&](int buf) {
-    const float* A = As + buf * T::A_FLOATS + (wm * MT * 32 + (lane & 31)) * AS + (lane >> 5);
-    const float* B = Bs + buf * T::B_FLOATS + (lane >> 5) * BN + wn * NT * 32 + (lane & 31);
+    const int h = lane >> 5;
+    const float* A = As + buf * T::A_FLOATS + (wm * MT * 32 + (lane & 31)) * AS + 16 * h;
+    const float* B = Bs + buf * T::B_FLOATS + (16 * h) * BN + wn * NT * 32 + (lane & 31);
+    float af[MT][16], bf[NT][16];
 #pragma unroll
-    for (int kk = 0; kk < 32; kk += 2) {
-      float a[MT], b[NT];
+    for (int i = 0; i < MT; ++i)
 #pragma unroll
-      for (int i = 0; i < MT; ++i) a[i] = A[i * 32 * AS + kk];
+      for (int g = 0; g < 4; ++g) {
+        const float4 v = *reinterpret_cast<const float4*>(A + i * 32 * AS + 4 * g);
+        af[i][4 * g] = v.x; af[i][4 * g + 1] = v.y; af[i][4 * g + 2] = v.z; af[i][4 * g + 3] = v.w;
+      }
 #pragma unroll
-      for (int j = 0; j < NT; ++j) b[j] = B[kk * BN + j * 32];
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int st = 0; st < 16; ++st) bf[j][st] = B[st * BN + j * 32];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int st = 0; st < 16; ++st)
 #pragma unroll
       for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int j = 0; j < NT; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
-    }
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][st], bf[j][st], acc[i][j], 0, 0, 0);
   };
 
   const int nkb = (p.K + 31) / 32;
@@ -366,19 +378,22 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(GemmP p) {
   auto compute = [&](int buf) {
     const float* A = As + buf * 32 * BM + (lane >> 5) * BM + wm * MT * 32 + (lane & 31);
     const float* B = Bs + buf * 32 * BN + (lane >> 5) * BN + wn * NT * 32 + (lane & 31);
+    float af[MT][16], bf[NT][16];
 #pragma unroll
-    for (int kk = 0; kk < 32; kk += 2) {
-      float a[MT], b[NT];
+    for (int st = 0; st < 16; ++st) {
 #pragma unroll
-      for (int i = 0; i < MT; ++i) a[i] = A[kk * BM + i * 32];
+      for (int i = 0; i < MT; ++i) af[i][st] = A[2 * st * BM + i * 32];
 #pragma unroll
-      for (int j = 0; j < NT; ++j) b[j] = B[kk * BN + j * 32];
+      for (int j = 0; j < NT; ++j) bf[j][st] = B[2 * st * BN + j * 32];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int st = 0; st < 16; ++st)
 #pragma unroll
       for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int j = 0; j < NT; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
-    }
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][st], bf[j][st], acc[i][j], 0, 0, 0);
   };
 
   if (mb_begin < mb_end) {
@@ -578,7 +593,7 @@ static void launch_fwd(Stream& s, GemmP& p, bool fast) {
   p.tiles_n = ceil_div(p.Npad, T::BN);
   p.ntiles = tiles_m * p.tiles_n;
   const int nkb = ceil_div(p.K, 32);
-  const int slots = 256 * (T::SMEM_FWD > 64 * 1024 ? 2 : 3);
+  const int slots = 256 * (T::SMEM_FWD > 80 * 1024 ? 1 : (T::SMEM_FWD > 64 * 1024 ? 2 : 3));
   const int splits = choose_splits(p.ntiles, nkb, slots, 8, (size_t)p.M * p.Npad * 4, s.ws_bytes);
   p.splits = splits;
   p.per_split = ceil_div(nkb, splits);
@@ -595,11 +610,11 @@ static void launch_fwd(Stream& s, GemmP& p, bool fast) {
   if (fast) {
     static bool once = (set_smem(conv_fwd_kernel<MT, NT, WGM, WGN, true>, T::SMEM_FWD), true);
     (void)once;
-    hipLaunchKernelGGL((conv_fwd_kernel<MT, NT, WGM, WGN, true>), grid, dim3(256), T::SMEM_FWD, hs(s), p);
+    hipLaunchKernelGGL((conv_fwd_kernel<MT, NT, WGM, WGN, true>), grid, dim3(64 * WGM * WGN), T::SMEM_FWD, hs(s), p);
   } else {
     static bool once = (set_smem(conv_fwd_kernel<MT, NT, WGM, WGN, false>, T::SMEM_FWD), true);
     (void)once;
-    hipLaunchKernelGGL((conv_fwd_kernel<MT, NT, WGM, WGN, false>), grid, dim3(256), T::SMEM_FWD, hs(s), p);
+    hipLaunchKernelGGL((conv_fwd_kernel<MT, NT, WGM, WGN, false>), grid, dim3(64 * WGM * WGN), T::SMEM_FWD, hs(s), p);
   }
   check_launch("conv_fwd");
   if (p.splits > 1) {
@@ -619,7 +634,9 @@ void conv_fwd(Stream& s, const ConvFwdArgs& a) {
   if (a.Npad % 4 || a.Cout > a.Npad) throw Error(1, "conv_fwd: bad Npad/Cout");
   if (a.accumulate && a.act != ACT_NONE) throw Error(1, "conv_fwd: accumulate with activation");
   const bool fast = (a.x.C % 32) == 0;
-  if (a.Npad > 64) launch_fwd<2, 2, 2, 2>(s, p, fast);
+  static const int big = getenv("SWN_TILE256") ? atoi(getenv("SWN_TILE256")) : 1;
+  if (a.Npad > 64 && big && fast && p.M >= 2048) launch_fwd<2, 2, 4, 2>(s, p, fast);
+  else if (a.Npad > 64) launch_fwd<2, 2, 2, 2>(s, p, fast);
   else if (a.Npad > 32) launch_fwd<2, 1, 2, 2>(s, p, fast);
   else launch_fwd<1, 1, 4, 1>(s, p, fast);
 }
