@@ -70,6 +70,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=32, help="per-GPU batch (config C2: 32)")
     ap.add_argument("--size", type=int, default=256)
+    ap.add_argument("--stage", choices=("warp", "texture"), default="warp",
+                    help="warp = config C2 (the headline metric); texture = config C3 (256x256, bs 16, ROIs, "
+                         "perceptual + style losses on), reported for reference")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -86,17 +89,23 @@ def main():
     import torch.distributed as dist
 
     ctx = engine.Context(device=local_rank, workspace_mb=1024)
-    B, S = args.batch, args.size
-    model = engine.NativeModel(ctx, "warp", B, S, S, is_train=True, dropout=0.5)
+    texture = args.stage == "texture"
+    B, S = (16 if texture and args.batch == 32 else args.batch), args.size
+    model = engine.NativeModel(ctx, args.stage, B, S, S, is_train=True, dropout=0.5)
     torch.manual_seed(0)                                   # identical init on every rank
-    for net in (engine.NET_G, engine.NET_D):
+    for net in (engine.NET_G, engine.NET_D) + ((engine.NET_VGG,) if texture else ()):
         sd = {}
         for name, shape in model.param_infos(net).items():
             sd[name] = torch.zeros(shape) if name.endswith(".bias") else init_tensor(torch.empty(shape), "kaiming")
         model.load_state_dict(net, sd)
     model.set_hyper(grad_scale=1.0 / world)
-    batch = synthetic.warp_batch(B, S, S, seed=1234 + rank)
-    model.set_input(0, batch["bodys"]); model.set_input(1, batch["input_cloths"]); model.set_input(2, batch["target_cloths"])
+    if texture:
+        batch = synthetic.texture_batch(B, S, S, seed=1234 + rank)
+        for i, k in enumerate(("input_textures", "rois", "cloths", "target_textures")):
+            model.set_input(i, batch[k])
+    else:
+        batch = synthetic.warp_batch(B, S, S, seed=1234 + rank)
+        model.set_input(0, batch["bodys"]); model.set_input(1, batch["input_cloths"]); model.set_input(2, batch["target_cloths"])
     gG, gD = model.grad_arena(engine.NET_G), model.grad_arena(engine.NET_D)
     xchg = parallel.GradExchange(world)
     label_rng = torch.Generator().manual_seed(4321)        # same on every rank (SURVEY.md 8(e) caveat 2)
@@ -142,15 +151,19 @@ def main():
     losses = model.losses()
     ms = dt / args.steps * 1e3
     ips = world * B * args.steps / dt
-    flop_per_img = GFLOP_PER_IMG_256 * 1e9 * (S * S) / (256 * 256)
+    flop_per_img = (217.8 if texture else GFLOP_PER_IMG_256) * 1e9 * (S * S) / (256 * 256)
 
     out = {
-        "metric": "images/sec full G+D step, warp-stage 256x256 bs=32/GPU",
+        "metric": ("images/sec full G+D step, texture-stage 256x256 bs=16/GPU" if texture else
+                   "images/sec full G+D step, warp-stage 256x256 bs=32/GPU"),
         "value": round(ips, 3), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"warp-stage G+D optimize_parameters step, {S}x{S}, bs {B}/GPU, fp32, "
-                               f"train mode (dropout 0.5), WarpModule 137.6M + PatchGAN 2.8M params, AdamW",
+        "config": {"workload": (f"texture-stage G+D optimize_parameters step, {S}x{S}, bs {B}/GPU, fp32, 12 ROIs/img, "
+                                f"L1 + VGG16 content + style losses, TextureModule 54.5M + PatchGAN 2.8M params, AdamW"
+                                if texture else
+                                f"warp-stage G+D optimize_parameters step, {S}x{S}, bs {B}/GPU, fp32, "
+                                f"train mode (dropout 0.5), WarpModule 137.6M + PatchGAN 2.8M params, AdamW"),
                    "global_batch": world * B, "parallelism": f"dp{world}"},
         "losses_finite": all(v == v and abs(v) < 1e30 for v in losses.values()),
     }
@@ -198,7 +211,7 @@ def main():
                 "all_gemm_kernels": {n: {"tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2),
                                          "ms_per_step": round(v["ms"] / nprof, 3)} for n, v in sorted(kernels.items())},
             }
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not texture:
         out["cpu_baseline"] = cpu_baseline()
     if rank == 0:
         print(json.dumps(out), flush=True)

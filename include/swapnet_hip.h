@@ -94,6 +94,11 @@ int swn_model_optim_step_set(swn_model* m, int net, int step);
  * texture slots: 0 input_textures (B,3,H,W), 1 rois (B,R,4 as N=B,C=R,H=4,W=1), 2 cloths
  * (B,19,H,W), 3 target_textures (B,3,H,W) */
 int swn_model_set_input(swn_model* m, int slot, const float* dev_nchw, int n, int c, int h, int w);
+/* Same slots, but for the cloth segmentations (warp 1, 2; texture 2) the caller hands over the
+ * integer label map (B,H,W) int32 -- the on-disk format, datasets/data_utils.py:298-343 -- and the
+ * one-hot expansion (label 0 -> all-zero vector) happens on the device: 1/19 of the H2D bytes of
+ * set_input(one_hot).  Bit-identical to to_onehot_tensor + set_input. */
+int swn_model_set_input_labels(swn_model* m, int slot, const int32_t* dev_labels, int n, int h, int w);
 /* slot 0: self.fakes (B,19,H,W) warp / (B,3,H,W) texture */
 int swn_model_get_output(swn_model* m, int slot, float* dev_nchw);
 /* named intermediate activation (debug / per-level parity tests), copied out as NCHW */

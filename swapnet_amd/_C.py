@@ -48,6 +48,7 @@ _PROTOS = {
     "swn_model_optim_step_get": ([_vp, _i, C.POINTER(_i)], _i),
     "swn_model_optim_step_set": ([_vp, _i, _i], _i),
     "swn_model_set_input": ([_vp, _i, _fp, _i, _i, _i, _i], _i),
+    "swn_model_set_input_labels": ([_vp, _i, _vp, _i, _i, _i], _i),
     "swn_model_get_output": ([_vp, _i, _fp], _i),
     "swn_model_get_tap": ([_vp, _i, C.c_char_p, _fp, C.POINTER(_i * 4)], _i),
     "swn_model_forward": ([_vp, _i, C.c_uint64], _i),

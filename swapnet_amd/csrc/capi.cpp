@@ -176,6 +176,9 @@ int swn_model_optim_step_set(swn_model* m, int net, int step) {
 int swn_model_set_input(swn_model* m, int slot, const float* src, int n, int c, int h, int w) {
   return guard([&] { REQUIRE(m && src, "NULL argument"); m->m->set_input(slot, src, n, c, h, w); });
 }
+int swn_model_set_input_labels(swn_model* m, int slot, const int32_t* lab, int n, int h, int w) {
+  return guard([&] { REQUIRE(m && lab, "NULL argument"); m->m->set_input_labels(slot, lab, n, h, w); });
+}
 int swn_model_get_output(swn_model* m, int slot, float* dst) {
   return guard([&] { REQUIRE(m && dst, "NULL argument"); m->m->get_output(slot, dst); });
 }

@@ -145,6 +145,7 @@ class Model {
   float* losses = nullptr;       // device [L_COUNT]
   Hyper hyper;
   virtual void set_input(int slot, const float* dev_nchw, int N, int C, int Hh, int Ww) = 0;
+  virtual void set_input_labels(int slot, const int32_t* dev_labels, int N, int Hh, int Ww) = 0;
   virtual void get_output(int slot, float* dev_nchw) = 0;
   virtual void forward(bool training, uint64_t seed) = 0;
   virtual void backward_D(float label_fake, float label_real) = 0;

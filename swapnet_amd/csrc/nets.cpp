@@ -197,6 +197,12 @@ class WarpModel final : public Model {
       throw Error(1, "set_input: unknown slot");
     }
   }
+  void set_input_labels(int slot, const int32_t* lab, int N, int Hh, int Ww) override {
+    if (N != B || Hh != H || Ww != W) throw Error(1, "set_input_labels: shape mismatch with the model's (B,H,W)");
+    if (slot == 1) labels_to_onehot(ctx->s, lab, cloth.v, 19);
+    else if (slot == 2 && is_train) labels_to_onehot(ctx->s, lab, Dx.batch(B, B).v.slice(0, 20), 19);
+    else throw Error(1, "set_input_labels: slot has no label form");
+  }
   void get_output(int slot, float* dst) override {
     if (slot != 0) throw Error(1, "get_output: unknown slot");
     nhwc_to_nchw(ctx->s, Dx.batch(0, B).v.slice(0, 20), dst, 19);

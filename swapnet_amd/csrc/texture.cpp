@@ -203,6 +203,13 @@ class TextureModel final : public Model {
       throw Error(1, "set_input: unknown slot");
     }
   }
+  void set_input_labels(int slot, const int32_t* lab, int N, int Hh, int Ww) override {
+    if (N != B || Hh != H || Ww != W) throw Error(1, "set_input_labels: shape mismatch with the model's (B,H,W)");
+    if (slot != 2) throw Error(1, "set_input_labels: slot has no label form");
+    labels_to_onehot(ctx->s, lab, unet_in.v.slice(36, 20), 19);
+    labels_to_onehot(ctx->s, lab, Dx.batch(0, B).v.slice(4, 20), 19);
+    if (is_train) labels_to_onehot(ctx->s, lab, Dx.batch(B, B).v.slice(4, 20), 19);
+  }
   void get_output(int slot, float* dst) override {
     if (slot != 0) throw Error(1, "get_output: unknown slot");
     nhwc_to_nchw(ctx->s, Dx.batch(0, B).v.slice(0, 4), dst, 3);

@@ -166,6 +166,13 @@ class NativeModel:
         self.lib.call("swn_model_set_input", self.handle, slot, _C.ptr(t), n, c, h, w)
         self._keep = [t]
 
+    def set_input_labels(self, slot, labels):
+        """Integer cloth label map (B,H,W) -> one-hot expansion on the device."""
+        t = labels.detach().to(device=self.ctx.device, dtype=torch.int32).contiguous()
+        n, h, w = t.shape
+        self.lib.call("swn_model_set_input_labels", self.handle, slot, _C.ptr(t), n, h, w)
+        self._keep_labels = t
+
     def forward(self, training=False, seed=0):
         self.lib.call("swn_model_forward", self.handle, int(training), C.c_uint64(seed))
 

@@ -101,6 +101,16 @@ class BaseGAN(BaseModel, ABC):
     def _native(self):
         return self.backend.cur
 
+    @staticmethod
+    def _set_cloth(m, slot, t):
+        """Cloth segmentations may arrive one-hot (B,19,H,W) float -- the reference dataloader's format --
+        or as the integer label map (B,H,W) of the on-disk .npz: the latter is
+        expanded on the device (1/19 of the host-to-device bytes)."""
+        if t.dim() == 3 and not t.is_floating_point():
+            m.set_input_labels(slot, t)
+        else:
+            m.set_input(slot, t)
+
     def _draw_labels(self):
         """The three smooth-label scalars in the reference's draw order: backward_D fake, real
         (warp_model.py:116,120), backward_G real (:158)."""

@@ -6,7 +6,7 @@ from argparse import ArgumentParser
 from .. import engine
 from ..modules.losses import PerceptualLoss
 from ..modules.swapnet_modules import TextureModule
-from ..util.decode_labels import decode_cloth_labels
+from ..util.decode_labels import decode_cloth_labels, labels_to_onehot
 from ..util.util import scale_tensor, unnormalize
 from .base_gan import BaseGAN
 
@@ -58,7 +58,8 @@ class TextureModel(BaseGAN):
     def compute_visuals(self):
         self.textures_unnormalized = unnormalize(self.textures.cpu(), *self.opt.texture_norm_stats)
         # util/draw_rois (ROI rectangle overlay, display only) is out of scope
-        self.cloths_decoded = decode_cloth_labels(self.cloths, ctx=self.backend.ctx)
+        cl = labels_to_onehot(self.cloths, self.opt.cloth_channels, ctx=self.backend.ctx) if self.cloths.dim() == 3 else self.cloths
+        self.cloths_decoded = decode_cloth_labels(cl, ctx=self.backend.ctx)
         self.fakes_scaled = scale_tensor(self.fakes.cpu(), scale_each=True)
         if self.is_train:
             self.targets_unnormalized = unnormalize(self.targets.cpu(), *self.opt.texture_norm_stats)
@@ -83,7 +84,7 @@ class TextureModel(BaseGAN):
         m = self.backend.ensure(B, H, W)
         m.set_input(0, self.textures)
         m.set_input(1, self.rois)
-        m.set_input(2, self.cloths)
+        self._set_cloth(m, 2, self.cloths)
         if self.is_train:
             self.targets = input["target_textures"]
             m.set_input(3, self.targets)

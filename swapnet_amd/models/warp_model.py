@@ -5,7 +5,7 @@ from argparse import ArgumentParser
 
 from .. import engine
 from ..modules.swapnet_modules import WarpModule
-from ..util.decode_labels import decode_cloth_labels
+from ..util.decode_labels import decode_cloth_labels, labels_to_onehot
 from ..util.util import unnormalize
 from .base_gan import BaseGAN
 
@@ -37,10 +37,11 @@ class WarpModel(BaseGAN):
                 self.loss_names += ["G_ce"]
 
     def compute_visuals(self):
-        self.inputs_decoded = decode_cloth_labels(self.inputs, ctx=self.backend.ctx)
+        as_onehot = lambda t: labels_to_onehot(t, self.cloth_channels, ctx=self.backend.ctx) if t.dim() == 3 else t
+        self.inputs_decoded = decode_cloth_labels(as_onehot(self.inputs), ctx=self.backend.ctx)
         self.bodys_unnormalized = unnormalize(self.bodys.cpu(), *self.opt.body_norm_stats)
         if self.is_train:
-            self.targets_decoded = decode_cloth_labels(self.targets, ctx=self.backend.ctx)
+            self.targets_decoded = decode_cloth_labels(as_onehot(self.targets), ctx=self.backend.ctx)
         self.fakes_decoded = decode_cloth_labels(self.fakes, ctx=self.backend.ctx)
 
     def define_G(self):
@@ -56,10 +57,10 @@ class WarpModel(BaseGAN):
         B, _, H, W = self.bodys.shape
         m = self.backend.ensure(B, H, W)
         m.set_input(0, self.bodys)
-        m.set_input(1, self.inputs)
+        self._set_cloth(m, 1, self.inputs)
         if self.is_train:
             self.targets = input["target_cloths"]
-            m.set_input(2, self.targets)
+            self._set_cloth(m, 2, self.targets)
         self.image_paths = tuple(zip(input["cloth_paths"], input["body_paths"]))
         self._fakes = None
 

@@ -176,3 +176,25 @@ def test_reference_options_and_entry_points_resolve_to_native_packages(tmp_path,
             if k not in saved:
                 del sys.modules[k]
         sys.modules.update(saved)
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_integer_label_inputs_equal_onehot_inputs(backend, tmp_path):
+    """cloth segmentations handed over as the on-disk integer label map
+    (datasets/data_utils.py:298-343) and expanded on the device give bit-identical results to the
+    reference dataloader's one-hot tensors."""
+    from swapnet_amd.models import create_model
+    opt = make_opt(tmp_path, backend, is_train=False, batch_size=2)
+    model = create_model(opt)
+    torch.manual_seed(0)
+    model.net_generator.load_state_dict(O.warp_module_params())
+    model.eval()
+    bodys, inputs, _ = O.synth_warp_batch(2, 64, 64, seed=5)
+    labels = O.onehot_to_labels(inputs)                      # (2,64,64) int64; background rows are all-zero -> 0
+    assert torch.equal(O.labels_to_onehot(labels, 19), inputs)
+    model.set_input(dict(bodys=bodys, input_cloths=inputs, cloth_paths=[""] * 2, body_paths=[""] * 2))
+    model.test()
+    a = model.fakes.cpu().clone()
+    model.set_input(dict(bodys=bodys, input_cloths=labels, cloth_paths=[""] * 2, body_paths=[""] * 2))
+    model.test()
+    assert torch.equal(a, model.fakes.cpu())
