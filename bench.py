@@ -81,7 +81,7 @@ def main():
     from swapnet_amd.modules import init_tensor
 
     rank, world = parallel.init_from_env()
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    local_rank = int(os.environ.get("SWAPNET_FORCE_DEVICE", os.environ.get("LOCAL_RANK", "0")))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (swapnet_amd has no CPU path)")
     torch.cuda.set_device(local_rank)
@@ -127,8 +127,13 @@ def main():
         model.backward_D(lab[0], lab[1])
         xchg.allreduce_mean(gD)
         model.optimizer_step(engine.NET_D)
-        model.backward_G(lab[2])
-        xchg.allreduce_mean(gG)
+        # generator backward in two parts: the decoder + residual-block gradients (59 % of the arena)
+        # travel over xGMI while the encoders are still being back-propagated
+        off, cnt = model.backward_G_part(lab[2], 0)
+        xchg.begin(gG[off:off + cnt])
+        _, cnt2 = model.backward_G_part(lab[2], 1)
+        xchg.begin(gG[:cnt2])
+        xchg.finish()
         model.optimizer_step(engine.NET_G)
 
     def fence():

@@ -111,6 +111,11 @@ int swn_model_forward(swn_model* m, int training, uint64_t dropout_seed);
 int swn_model_backward_D(swn_model* m, float label_fake, float label_real);
 /* backward_G (warp_model.py:141-167, texture_model.py:157-180) */
 int swn_model_backward_G(swn_model* m, float label_real);
+/* backward_G in two parts so the data-parallel exchange of the generator gradients overlaps the
+ * rest of the backward pass: part 0 runs the loss head and the generator backward down to a
+ * split layer (decoder + residual blocks; their arena range [off, off+count) is final on return),
+ * part 1 the remaining encoder layers ([0, off)). */
+int swn_model_backward_G_part(swn_model* m, float label_real, int part, size_t* ready_off, size_t* ready_count);
 /* optimizer_{G,D}.step() (models/base_gan.py:199,203): fused AdamW over the net's arena */
 int swn_model_optimizer_step(swn_model* m, int net);
 /* BaseGAN.optimize_parameters (models/base_gan.py:194-203; warp_model.py:169-183) in one call */

@@ -153,6 +153,7 @@ void Net::conv(const std::string& name, const Var& x, const Var& y, ConvKind kin
   auto op = std::make_unique<Op>();
   Op* self = op.get();
   op->label = name;
+  op->param_off = arena.params[wi].off;
   op->reads_net_input = x_is_input;
   ParamArena* A = &arena;
   const Gather gf = geo.fwd;
@@ -285,6 +286,7 @@ void Net::convT(const std::string& name, const Var& x, const Var& y, int Co, boo
   auto op = std::make_unique<Op>();
   Op* self = op.get();
   op->label = name;
+  op->param_off = arena.params[wi].off;
   ParamArena* A = &arena;
   const TView xv = x.v, yv = y.v, ygv = y.g, xgv = x.g;
   const size_t phase_elems = (size_t)4 * Cip * round_up(Co, 4);
@@ -475,8 +477,35 @@ void Net::refresh_dgrad() {
     if (op->repack) op->repack(*this);
   dg_version = arena.version;
 }
-void Net::backward(bool wgrad, bool igrad) {
-  for (int i = (int)ops.size() - 1; i >= 0; --i) ops[i]->bwd(*this, *ops[i], wgrad, igrad);
+void Net::backward(bool wgrad, bool igrad) { backward_range(wgrad, igrad, 0, (int)ops.size()); }
+void Net::backward_range(bool wgrad, bool igrad, int op_begin, int op_end) {
+  for (int i = op_end - 1; i >= op_begin; --i) ops[i]->bwd(*this, *ops[i], wgrad, igrad);
+}
+int Net::split_point(double frac, size_t* arena_off) const {
+  const size_t want = (size_t)(frac * (double)arena.n);
+  for (size_t i = 0; i < ops.size(); ++i)
+    if (ops[i]->param_off != (size_t)-1 && ops[i]->param_off >= want) {
+      if (arena_off) *arena_off = ops[i]->param_off;
+      return (int)i;
+    }
+  if (arena_off) *arena_off = arena.n;
+  return (int)ops.size();
+}
+
+void Model::backward_G_part(float label_real, int part, size_t* ready_off, size_t* ready_count) {
+  size_t off = 0;
+  const int sp = G->split_point(0.35, &off);
+  if (part == 0) {
+    backward_G_head(label_real);
+    G->refresh_dgrad();
+    G->backward_range(true, false, sp, (int)G->ops.size());
+    if (ready_off) *ready_off = off;
+    if (ready_count) *ready_count = arenaG.n - off;
+  } else {
+    G->backward_range(true, false, 0, sp);
+    if (ready_off) *ready_off = 0;
+    if (ready_count) *ready_count = off;
+  }
 }
 
 // ---------------------------------------------------------------------------------------

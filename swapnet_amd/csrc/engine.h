@@ -71,6 +71,7 @@ struct Op {
   std::vector<Var> grad_targets;   // gradients this op writes in bwd, in execution order
   std::vector<int> acc;            // planned: 0 overwrite / 1 accumulate
   bool reads_net_input = false;
+  size_t param_off = (size_t)-1;   // arena offset of this op's weight (ops without parameters: -1)
   std::function<void(Net&)> repack;   // refresh the dgrad operand from the arena
 };
 
@@ -106,6 +107,9 @@ class Net {
   void finalize(const std::vector<Var>& pre_initialised_grads);
   void forward();
   void backward(bool wgrad, bool igrad);
+  void backward_range(bool wgrad, bool igrad, int op_begin, int op_end);   // ops [begin,end) in reverse
+  // first op whose parameters start at or after `frac` of the arena (ops are registered in arena order)
+  int split_point(double frac, size_t* arena_off) const;
   void refresh_dgrad();     // no-op when the operands are current
 
  private:
@@ -150,6 +154,10 @@ class Model {
   virtual void forward(bool training, uint64_t seed) = 0;
   virtual void backward_D(float label_fake, float label_real) = 0;
   virtual void backward_G(float label_real) = 0;
+  // backward_G in two parts for gradient-exchange overlap: part 0 = everything down to the split
+  // op (its arena range [off, n) is final on return), part 1 = the rest ([0, off)).
+  virtual void backward_G_head(float label_real) = 0;
+  void backward_G_part(float label_real, int part, size_t* ready_off, size_t* ready_count);
   void optimizer_step(int net);
   void step(const float labels[3], bool training, uint64_t seed);
   ParamArena& arena(int net) { return net == 0 ? arenaG : arenaD; }

@@ -225,6 +225,11 @@ class WarpModel final : public Model {
     D2->backward(true, false);
   }
   void backward_G(float label_real) override {                        // warp_model.py:141-167
+    backward_G_head(label_real);
+    G->refresh_dgrad();
+    G->backward(true, false);
+  }
+  void backward_G_head(float label_real) override {
     Stream& s = ctx->s;
     TView fakes = Dx.batch(0, B).v.slice(0, 20);
     TView dfakes = Dx.batch(0, B).g.slice(0, 20);
@@ -243,8 +248,6 @@ class WarpModel final : public Model {
     }
     scalar_axpby(s, losses + L_TMP1, hyper.lambda_ce, nullptr, 0.f, losses + L_G_CE);
     scalar_axpby(s, losses + L_G_GAN, 1.f, losses + L_G_CE, 1.f, losses + L_G);
-    G->refresh_dgrad();
-    G->backward(true, false);
   }
 };
 

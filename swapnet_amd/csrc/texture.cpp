@@ -232,6 +232,11 @@ class TextureModel final : public Model {
     D2->backward(true, false);
   }
   void backward_G(float label_real) override {                          // texture_model.py:157-180
+    backward_G_head(label_real);
+    G->refresh_dgrad();
+    G->backward(true, false);
+  }
+  void backward_G_head(float label_real) override {
     Stream& s = ctx->s;
     const float gsc = hyper.grad_scale;
     TView fakes = Dx.batch(0, B).v.slice(0, 4), dfakes = Dx.batch(0, B).g.slice(0, 4);
@@ -266,8 +271,6 @@ class TextureModel final : public Model {
     scalar_axpby(s, losses + L_G_GAN, 1.f, losses + L_G_L1, 1.f, losses + L_TMP4);
     scalar_axpby(s, losses + L_G_CONTENT, 1.f, losses + L_G_STYLE, 1.f, losses + L_TMP5);
     scalar_axpby(s, losses + L_TMP4, 1.f, losses + L_TMP5, 1.f, losses + L_G);
-    G->refresh_dgrad();
-    G->backward(true, false);
   }
 };
 

@@ -196,6 +196,12 @@ class NativeModel:
     def backward_G(self, label_real):
         self.lib.call("swn_model_backward_G", self.handle, C.c_float(label_real))
 
+    def backward_G_part(self, label_real, part):
+        """Returns (offset, count) of the generator gradient-arena range that is final after this part."""
+        off, cnt = C.c_size_t(), C.c_size_t()
+        self.lib.call("swn_model_backward_G_part", self.handle, C.c_float(label_real), part, C.byref(off), C.byref(cnt))
+        return off.value, cnt.value
+
     def optimizer_step(self, net):
         self.lib.call("swn_model_optimizer_step", self.handle, net)
 

@@ -132,8 +132,12 @@ class BaseGAN(BaseModel, ABC):
             m.backward_D(labels[0], labels[1])
             self._xchg.allreduce_mean(m.grad_arena(engine.NET_D))
             m.optimizer_step(engine.NET_D)
-            m.backward_G(labels[2])
-            self._xchg.allreduce_mean(m.grad_arena(engine.NET_G))
+            gG = m.grad_arena(engine.NET_G)
+            off, cnt = m.backward_G_part(labels[2], 0)       # decoder + resblocks: exchange overlaps part 1
+            self._xchg.begin(gG[off:off + cnt])
+            _, cnt2 = m.backward_G_part(labels[2], 1)
+            self._xchg.begin(gG[:cnt2])
+            self._xchg.finish()
             m.optimizer_step(engine.NET_G)
         self._losses_stale = True
         self._fakes = None

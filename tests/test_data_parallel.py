@@ -37,8 +37,14 @@ def _worker(rank, world, port, out_dir):
     m.backward_D(lab[0], lab[1])
     x.allreduce_mean(m.grad_arena(engine.NET_D))
     m.optimizer_step(engine.NET_D)
-    m.backward_G(lab[2])
-    x.begin(m.grad_arena(engine.NET_G)); x.finish()
+    gG = m.grad_arena(engine.NET_G)
+    off, cnt = m.backward_G_part(lab[2], 0)            # split backward: exchange part 0 while part 1 runs
+    assert 0 < off and off + cnt == gG.numel()
+    x.begin(gG[off:off + cnt])
+    off2, cnt2 = m.backward_G_part(lab[2], 1)
+    assert off2 == 0 and cnt2 == off
+    x.begin(gG[:cnt2])
+    x.finish()
     m.optimizer_step(engine.NET_G)
     if rank == 0:
         torch.save({"G": m.state_dict(0, to_cpu=True), "D": m.state_dict(1, to_cpu=True)}, os.path.join(out_dir, "dp.pt"))
