@@ -200,7 +200,8 @@ def main():
             gemm_ms = sum(v["ms"] for v in kernels.values()) / nprof
             traffic = None
             tpath = os.path.join(REPO, "profiles", "traffic_r01.json")
-            rp_name = {"conv_fwd_128x128_fast": "conv_fwd_kernel<2, 2, 2, 2, true>"}.get(dom)
+            rp_name = {"conv_fwd_128x128_fast": "conv_fwd_kernel<2, 2, 2, 2, true>",
+                       "conv_fwd_256x128_fast": "conv_fwd_kernel<2, 2, 4, 2, true>"}.get(dom)
             if os.path.exists(tpath) and rp_name:
                 # HBM bytes per launch from the committed rocprofv3 PMC passes of this same command
                 # (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE; see profiles/README.md)
