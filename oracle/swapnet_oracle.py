@@ -560,6 +560,16 @@ class WarpStepOracle:
         G, D = _leaf(self.G), _leaf(self.D)
         fakes = warp_module_forward(G, bodys, inputs, training=self.training)         # :106-107
         draw = (lambda i: smooth_label()) if labels is None else (lambda i: torch.tensor([labels[i]], dtype=torch.float32))
+        if h.get("warp_mode", "gan") == "ce":
+            # --warp_mode ce (warp_model.py:169-183): generator only, loss = lambda_ce * CE
+            loss_G = F.cross_entropy(fakes, torch.argmax(targets, dim=1)) * h["lambda_ce"]
+            gG = torch.autograd.grad(loss_G, list(G.values()))
+            self.grads_G = OrderedDict(zip(G.keys(), gG))
+            self.optG.apply(self.G, self.grads_G)
+            self.fakes = fakes.detach()
+            self.labels = [0.0, 0.0, 0.0]
+            self.losses = OrderedDict(G=float(loss_G.detach()))
+            return self.losses
         # ---- backward_D (warp_model.py:109-139)
         cond_fake = torch.cat((bodys, fakes), 1)
         pred_fake = patchgan_forward(D, cond_fake.detach())

@@ -195,7 +195,6 @@ void Net::conv(const std::string& name, const Var& x, const Var& y, ConvKind kin
   Var dxpad;
   int dg_mode = 0;
   Gather gd;         // dgrad gather over dY
-  OutMap dmap;
   int dHo = x.v.H, dWo = x.v.W;
   switch (kind) {
     case CK_K4S2: dg_mode = 0; break;

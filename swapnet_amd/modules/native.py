@@ -4,13 +4,10 @@ A reference model holds `net_generator` / `net_discriminator` (nn.Modules) and t
 optimizers.  Here all of them are views onto ONE `NativeBackend`, which owns the swn_model
 handles (one per batch shape seen, all sharing the same flat parameter arenas' contents).
 """
-from collections import OrderedDict
-
 import torch
 from torch import nn
 
 from .. import engine
-from . import init_weights as _init_weights  # noqa: F401  (re-export for callers)
 
 
 class NativeBackend:

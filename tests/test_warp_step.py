@@ -218,3 +218,35 @@ def test_warp_full_size_properties():
     assert torch.equal(d1, d2) and not torch.equal(d1, d3) and not torch.equal(d1, b)
     assert a.abs().max() <= 1.0
     m.close()
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("mode", ["lsgan", "wgan", "ce"])
+def test_other_gan_objectives_and_ce_mode(backend, mode, oracle_run):
+    """--gan_mode lsgan / wgan (modules/loss.py:55-62,117-128) and --warp_mode ce
+    (warp_model.py:169-183) against the oracle (the non-gp part)."""
+    G, D, batch, _, steps = oracle_run
+    ctx = _ctx(backend)
+    B, H = batch[0].shape[0], batch[0].shape[2]
+    hyper = dict(gan_mode="vanilla" if mode == "ce" else mode, warp_mode="ce" if mode == "ce" else "gan")
+    st = O.WarpStepOracle(G, D, hyper=hyper)
+    lab = steps[0]["labels"]
+    st.step(*batch, labels=lab)
+    m = engine.NativeModel(ctx, "warp", B, H, H, is_train=True)
+    m.load_state_dict(0, G); m.load_state_dict(1, D)
+    m.set_hyper(gan_mode={"lsgan": 1, "wgan": 2, "ce": 0}[mode], warp_mode_ce=int(mode == "ce"))
+    for i, t in enumerate(batch):
+        m.set_input(i, t)
+    m.step(lab, training=False, seed=0)
+    L = m.losses()
+    for k, v in st.losses.items():
+        assert abs(L[k] - v) <= 1e-3 * abs(v) + 1e-6, (mode, k, L[k], v)
+    pG = m.state_dict(0, to_cpu=True)
+    for k, v in st.G.items():
+        if not noise_bias(k):
+            assert rel(pG[k], v) < 1e-3, (mode, "postG", k, rel(pG[k], v))
+    if mode == "ce":      # the discriminator is untouched
+        pD = m.state_dict(1, to_cpu=True)
+        assert all(torch.equal(pD[k], D[k]) for k in D)
+        assert m.optim_step_count(1) == 0
+    m.close()
