@@ -42,6 +42,7 @@ struct GemmP {
   float* y; int yH, yW, ycs; int ymul, yoff, xmul, xoff; int Cout; int yC;
   int splits; int per_split; float* slab;
   int tiles_n; int ntiles;
+  size_t x_bs, w_bs, y_bs, slab_bs;   // batched mode (blockIdx.z)
 };
 
 __device__ __forceinline__ int src_coord(int e, int ext, int pad_mode, int ups) {
@@ -98,6 +99,8 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_fwd_kernel(GemmP p) {
   const int tile_n = tile % p.tiles_n, tile_m = tile / p.tiles_n;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
   const int split = blockIdx.y;
+  p.x += (size_t)blockIdx.z * p.x_bs; p.w += (size_t)blockIdx.z * p.w_bs;
+  p.y += (size_t)blockIdx.z * p.y_bs; p.slab += (size_t)blockIdx.z * p.slab_bs;
 
   const int q = t & 7, p0 = t >> 3;
   int a_iy0[RA], a_ix0[RA], a_base[RA];
@@ -262,6 +265,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_fwd_kernel(GemmP p) {
 
 // sums the K-split slabs in fixed order and applies the epilogue
 __global__ void conv_fwd_reduce_kernel(GemmP p) {
+  p.y += (size_t)blockIdx.z * p.y_bs; p.slab += (size_t)blockIdx.z * p.slab_bs;
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t total = (size_t)p.M * p.Cout;
   if (i >= total) return;
@@ -298,6 +302,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(GemmP p) {
   const int tile_n = tile % p.tiles_n, tile_k = tile / p.tiles_n;
   const int kt0 = tile_k * BM, n0 = tile_n * BN;
   const int split = blockIdx.y;
+  p.x += (size_t)blockIdx.z * p.x_bs; p.y += (size_t)blockIdx.z * p.y_bs;
+  p.w += (size_t)blockIdx.z * p.w_bs; p.slab += (size_t)blockIdx.z * p.slab_bs;
 
   // this thread's k (fixed for the whole kernel)
   const int acol = (t % (BM / 4)) * 4, arow0 = t / (BM / 4);
@@ -322,8 +328,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(GemmP p) {
   };
   auto advance = [&](int& n, int& oy, int& ox) {
     ox += 32;
-    while (ox >= p.Wo) { ox -= p.Wo; ++oy; }
-    while (oy >= p.Ho) { oy -= p.Ho; ++n; }
+    if (ox >= p.Wo) {
+      const int q = ox / p.Wo;
+      ox -= q * p.Wo; oy += q;
+      if (oy >= p.Ho) { const int r = oy / p.Ho; oy -= r * p.Ho; n += r; }
+    }
   };
 #pragma unroll
   for (int r = 0; r < RA; ++r) decode(mb_begin * 32 + arow0 + r * AROWS, an[r], aoy[r], aox[r]);
@@ -587,26 +596,28 @@ static void set_smem(K kernel, int bytes) {
 }
 
 template <int MT, int NT, int WGM, int WGN>
-static void launch_fwd(Stream& s, GemmP& p, bool fast) {
+static void launch_fwd(Stream& s, GemmP& p, bool fast, int batch) {
   using T = Tile<MT, NT, WGM, WGN>;
   const int tiles_m = ceil_div(p.M, T::BM);
   p.tiles_n = ceil_div(p.Npad, T::BN);
   p.ntiles = tiles_m * p.tiles_n;
   const int nkb = ceil_div(p.K, 32);
   const int slots = 256 * (T::SMEM_FWD > 80 * 1024 ? 1 : (T::SMEM_FWD > 64 * 1024 ? 2 : 3));
-  const int splits = choose_splits(p.ntiles, nkb, slots, 8, (size_t)p.M * p.Npad * 4, s.ws_bytes);
+  p.slab_bs = (size_t)p.M * p.Npad;      // per batch, per split
+  const int splits = choose_splits(p.ntiles * batch, nkb, slots, 8, (size_t)p.M * p.Npad * 4 * batch, s.ws_bytes);
   p.splits = splits;
   p.per_split = ceil_div(nkb, splits);
   p.splits = ceil_div(nkb, p.per_split);
   p.slab = reinterpret_cast<float*>(s.ws);
-  dim3 grid(p.ntiles, p.splits);
+  p.slab_bs = (size_t)p.M * p.Npad * p.splits;
+  dim3 grid(p.ntiles, p.splits, batch);
   char pname[96];
   if (prof_detail())
     snprintf(pname, sizeof pname, "conv_fwd_%dx%d_%s[M%d,N%d,K%d,s%d]", T::BM, T::BN, fast ? "fast" : "generic", p.M,
              p.Cout, p.K, p.splits);
   else
     snprintf(pname, sizeof pname, "conv_fwd_%dx%d_%s", T::BM, T::BN, fast ? "fast" : "generic");
-  ProfScope prof(s, pname, 2.0 * p.M * p.Cout * p.K);
+  ProfScope prof(s, pname, 2.0 * p.M * p.Cout * p.K * batch);
   if (fast) {
     static bool once = (set_smem(conv_fwd_kernel<MT, NT, WGM, WGN, true>, T::SMEM_FWD), true);
     (void)once;
@@ -619,7 +630,7 @@ static void launch_fwd(Stream& s, GemmP& p, bool fast) {
   check_launch("conv_fwd");
   if (p.splits > 1) {
     const size_t total = (size_t)p.M * p.Cout;
-    hipLaunchKernelGGL(conv_fwd_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, hs(s), p);
+    hipLaunchKernelGGL(conv_fwd_reduce_kernel, dim3((unsigned)((total + 255) / 256), 1, batch), dim3(256), 0, hs(s), p);
     check_launch("conv_fwd_reduce");
   }
 }
@@ -635,24 +646,27 @@ void conv_fwd(Stream& s, const ConvFwdArgs& a) {
   if (a.accumulate && a.act != ACT_NONE) throw Error(1, "conv_fwd: accumulate with activation");
   const bool fast = (a.x.C % 32) == 0;
   static const int big = getenv("SWN_TILE256") ? atoi(getenv("SWN_TILE256")) : 1;
-  if (a.Npad > 64 && big && fast && p.M >= 2048) launch_fwd<2, 2, 4, 2>(s, p, fast);
-  else if (a.Npad > 64) launch_fwd<2, 2, 2, 2>(s, p, fast);
-  else if (a.Npad > 32) launch_fwd<2, 1, 2, 2>(s, p, fast);
-  else launch_fwd<1, 1, 4, 1>(s, p, fast);
+  p.x_bs = a.x_bs; p.w_bs = a.w_bs; p.y_bs = a.y_bs;
+  const int nb = std::max(a.batch, 1);
+  if (a.Npad > 64 && big && fast && p.M >= 2048) launch_fwd<2, 2, 4, 2>(s, p, fast, nb);
+  else if (a.Npad > 64) launch_fwd<2, 2, 2, 2>(s, p, fast, nb);
+  else if (a.Npad > 32) launch_fwd<2, 1, 2, 2>(s, p, fast, nb);
+  else launch_fwd<1, 1, 4, 1>(s, p, fast, nb);
 }
 
 template <int MT, int NT, int WGM, int WGN>
-static void launch_wgrad(Stream& s, GemmP& p) {
+static void launch_wgrad(Stream& s, GemmP& p, int batch) {
   using T = Tile<MT, NT, WGM, WGN>;
   const int tiles_k = ceil_div(p.K, T::BM);
   p.tiles_n = ceil_div(p.Npad, T::BN);
   p.ntiles = tiles_k * p.tiles_n;
   const int nmb = ceil_div(p.M, 32);
   const int slots = 256 * (T::SMEM_WG >= 64 * 1024 ? 2 : (T::SMEM_WG >= 48 * 1024 ? 3 : 4));
-  const int splits = choose_splits(p.ntiles, nmb, slots, 8, (size_t)p.K * p.Npad * 4, s.ws_bytes);
+  const int splits = choose_splits(p.ntiles * batch, nmb, slots, 8, (size_t)p.K * p.Npad * 4 * batch, s.ws_bytes);
   p.per_split = ceil_div(nmb, splits);
   p.splits = ceil_div(nmb, p.per_split);
   p.slab = reinterpret_cast<float*>(s.ws);
+  p.slab_bs = (size_t)p.K * p.Npad * p.splits;
   static bool once = (set_smem(conv_wgrad_kernel<MT, NT, WGM, WGN>, T::SMEM_WG), true);
   (void)once;
   char pname[96];
@@ -660,13 +674,14 @@ static void launch_wgrad(Stream& s, GemmP& p) {
     snprintf(pname, sizeof pname, "conv_wgrad_%dx%d[M%d,N%d,K%d,s%d]", T::BM, T::BN, p.M, p.Cout, p.K, p.splits);
   else
     snprintf(pname, sizeof pname, "conv_wgrad_%dx%d", T::BM, T::BN);
-  ProfScope prof(s, pname, 2.0 * p.M * p.Cout * p.K);
-  hipLaunchKernelGGL((conv_wgrad_kernel<MT, NT, WGM, WGN>), dim3(p.ntiles, p.splits), dim3(256), T::SMEM_WG, hs(s), p);
+  ProfScope prof(s, pname, 2.0 * p.M * p.Cout * p.K * batch);
+  hipLaunchKernelGGL((conv_wgrad_kernel<MT, NT, WGM, WGN>), dim3(p.ntiles, p.splits, batch), dim3(256), T::SMEM_WG, hs(s), p);
   check_launch("conv_wgrad");
   if (p.splits > 1) {
     const size_t n = (size_t)p.K * p.Npad;
-    hipLaunchKernelGGL(slab_sum_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, hs(s), p.slab,
-                       const_cast<float*>(p.w), n, p.splits);
+    for (int b = 0; b < batch; ++b)
+      hipLaunchKernelGGL(slab_sum_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, hs(s),
+                         p.slab + (size_t)b * p.slab_bs, const_cast<float*>(p.w) + (size_t)b * p.w_bs, n, p.splits);
     check_launch("slab_sum");
   }
 }
@@ -676,16 +691,22 @@ void conv_wgrad(Stream& s, const ConvWgradArgs& a) {
   GemmP p = make_params(a.x, a.g, a.dy, a.om);
   p.w = a.dw; p.Npad = a.Npad; p.Cout = a.Cout;
   if (a.Npad % 4 || a.Cout > a.Npad || a.dy.C % 4) throw Error(1, "conv_wgrad: bad Npad/Cout");
-  if (a.Npad > 64) launch_wgrad<2, 2, 2, 2>(s, p);
-  else if (a.Npad > 32) launch_wgrad<2, 1, 2, 2>(s, p);
-  else launch_wgrad<1, 1, 4, 1>(s, p);
+  p.x_bs = a.x_bs; p.y_bs = a.dy_bs; p.w_bs = a.dw_bs;
+  const int nb = std::max(a.batch, 1);
+  if (a.Npad > 64) launch_wgrad<2, 2, 2, 2>(s, p, nb);
+  else if (a.Npad > 32) launch_wgrad<2, 1, 2, 2>(s, p, nb);
+  else launch_wgrad<1, 1, 4, 1>(s, p, nb);
 }
 
 void conv_fwd_naive(Stream& s, const ConvFwdArgs& a) {
   GemmP p = make_params(a.x, a.g, a.y, a.om);
   p.w = a.w; p.Npad = a.Npad; p.bias = a.bias; p.act = a.act; p.accumulate = a.accumulate; p.Cout = a.Cout;
   const size_t total = (size_t)p.M * p.Cout;
-  hipLaunchKernelGGL(conv_fwd_naive_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, hs(s), p);
+  for (int b = 0; b < std::max(a.batch, 1); ++b) {
+    GemmP q = p;
+    q.x += (size_t)b * a.x_bs; q.w += (size_t)b * a.w_bs; q.y += (size_t)b * a.y_bs;
+    hipLaunchKernelGGL(conv_fwd_naive_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, hs(s), q);
+  }
   check_launch("conv_fwd_naive");
 }
 
@@ -693,7 +714,11 @@ void conv_wgrad_naive(Stream& s, const ConvWgradArgs& a) {
   GemmP p = make_params(a.x, a.g, a.dy, a.om);
   p.w = a.dw; p.Npad = a.Npad; p.Cout = a.Cout;
   const size_t total = (size_t)p.K * p.Npad;
-  hipLaunchKernelGGL(conv_wgrad_naive_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, hs(s), p);
+  for (int b = 0; b < std::max(a.batch, 1); ++b) {
+    GemmP q = p;
+    q.x += (size_t)b * a.x_bs; q.y += (size_t)b * a.dy_bs; q.w += (size_t)b * a.dw_bs;
+    hipLaunchKernelGGL(conv_wgrad_naive_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, hs(s), q);
+  }
   check_launch("conv_wgrad_naive");
 }
 

@@ -2,6 +2,7 @@
 #include "engine.h"
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 
 namespace swn {
@@ -174,12 +175,44 @@ void Net::conv(const std::string& name, const Var& x, const Var& y, ConvKind kin
     g.KH = 2 + a; g.KW = 2 + b; g.stride = 1; g.pad_t = 1; g.pad_l = 1; g.Ho = xv.H; g.Wo = xv.W;
     om.ymul = 2; om.yoff = a; om.xmul = 2; om.xoff = b;
   };
+  // 3x3 stride-1 convs with MFMA-friendly channel counts run as Winograd F(2x2,3x3): transform,
+  // 16 batched GEMMs, inverse transform (wino.hip) -- 2.25x fewer multiplies than the direct form.
+  static const bool wino_on = !(getenv("SWN_WINOGRAD") && atoi(getenv("SWN_WINOGRAD")) == 0);
+  const bool wino = wino_on && (kind == CK_K3S1_REFLECT || kind == CK_K3S1_ZERO) && Cip % 32 == 0 && Co % 32 == 0 &&
+                    x.v.H % 2 == 0 && x.v.W % 2 == 0 && x.v.H >= 4 && x.v.W >= 4;
+  const int wN = x.v.N, wTh = x.v.H / 2, wTw = x.v.W / 2;
+  const size_t wT = (size_t)wN * wTh * wTw;
+  const int wpad2 = kind == CK_K3S1_REFLECT ? 2 : 1;                       // dgrad: pad of the transposed conv
+  const int wTh2 = kind == CK_K3S1_REFLECT ? (x.v.H + 2) / 2 : wTh, wTw2 = kind == CK_K3S1_REFLECT ? (x.v.W + 2) / 2 : wTw;
+  const size_t wT2 = (size_t)wN * wTh2 * wTw2;
+  size_t uf_off = 0, ub_off = 0;
+  if (wino) {
+    uf_off = reserve_dg(self, (size_t)16 * Cip * Cop);
+    wsV_need = std::max(wsV_need, std::max((size_t)16 * wT * Cip, (size_t)16 * wT2 * Cop));
+    wsM_need = std::max(wsM_need, std::max((size_t)16 * wT * Cop, (size_t)16 * wT2 * Cip));
+    wsU_need = std::max(wsU_need, (size_t)16 * Cip * Cop);
+  }
+  auto plane_view = [](float* p, size_t T, int C) {
+    TView v; v.p = p; v.N = 1; v.H = 1; v.W = (int)T; v.C = C; v.cs = C; return v;   // T x C matrix
+  };
   op->fwd = [=](Net& n) {
     const ParamDesc& wd = A->params[wi];
     ConvFwdArgs a;
     a.x = xv; a.g = gf; a.w = A->w + wd.off; a.Npad = wd.ws.Npad;
     a.bias = bi >= 0 ? A->w + A->params[bi].off : nullptr;
     a.act = actf; a.y = yv; a.Cout = Co;
+    if (wino) {
+      n.refresh_dgrad();
+      wino_input_transform(n.ctx.s, xv, 1, gf.pad_mode, wTh, wTw, n.wsV);
+      ConvFwdArgs g;
+      g.x = plane_view(n.wsV, wT, Cip); g.g.Ho = 1; g.g.Wo = (int)wT;
+      g.w = n.dg + uf_off; g.Npad = Cop; g.Cout = Co;
+      g.y = plane_view(n.wsM, wT, Cop);
+      g.batch = 16; g.x_bs = wT * Cip; g.w_bs = (size_t)Cip * Cop; g.y_bs = wT * Cop;
+      conv_fwd(n.ctx.s, g);
+      wino_output_transform(n.ctx.s, n.wsM, Cop, wTh, wTw, a.bias, actf, yv, Co, 0);
+      return;
+    }
     if (!folded) { conv_fwd(n.ctx.s, a); return; }
     n.refresh_dgrad();                       // folded weights are derived operands too
     for (int ph = 0; ph < 4; ++ph) {
@@ -209,12 +242,22 @@ void Net::conv(const std::string& name, const Var& x, const Var& y, ConvKind kin
   size_t dg_off = 0;
   const int Ndg = Cip;   // dgrad output channels = input buffer channels
   if (want_dx) {
-    dg_off = reserve_dg(self, dgrad_elems(arena.params[wi].ws, dg_mode, Cop, Ndg));
+    if (wino) ub_off = reserve_dg(self, (size_t)16 * Cop * Cip);
+    else dg_off = reserve_dg(self, dgrad_elems(arena.params[wi].ws, dg_mode, Cop, Ndg));
     if (kind == CK_K3S1_REFLECT) dxpad = alloc_var(x.v.N, dHo, dWo, Cip, false);
     op->grad_targets.push_back(x);
+    if (!wino)
+      op->repack = [=](Net& n) {
+        const ParamDesc& wd = A->params[wi];
+        repack_dgrad(n.ctx.s, wd.ws, dg_mode, Cop, Ndg, A->w + wd.off, n.dg + dg_off);
+      };
+  }
+  if (wino) {
+    const bool wdx = want_dx;
     op->repack = [=](Net& n) {
       const ParamDesc& wd = A->params[wi];
-      repack_dgrad(n.ctx.s, wd.ws, dg_mode, Cop, Ndg, A->w + wd.off, n.dg + dg_off);
+      wino_filter_transform(n.ctx.s, wd.ws, 0, A->w + wd.off, n.dg + uf_off);
+      if (wdx) wino_filter_transform(n.ctx.s, wd.ws, 1, A->w + wd.off, n.dg + ub_off);
     };
   }
   if (folded) {
@@ -235,7 +278,18 @@ void Net::conv(const std::string& name, const Var& x, const Var& y, ConvKind kin
     if (wgrad) {
       ConvWgradArgs wa;
       wa.x = xv; wa.g = gf; wa.dy = dY; wa.dw = A->g + wd.off; wa.Npad = wd.ws.Npad; wa.Cout = Co;
-      if (!folded) {
+      if (wino) {
+        // dU[t] = V[t]^T dM[t] (16 batched reductions over the tiles), then dW = G^T dU G
+        wino_input_transform(n.ctx.s, xv, 1, gf.pad_mode, wTh, wTw, n.wsV);
+        wino_dy_transform(n.ctx.s, dY, wTh, wTw, n.wsM);
+        ConvWgradArgs g;
+        g.x = plane_view(n.wsV, wT, Cip); g.g.Ho = 1; g.g.Wo = (int)wT;
+        g.dy = plane_view(n.wsM, wT, Cop);
+        g.dw = n.wsU; g.Npad = Cop; g.Cout = Co;
+        g.batch = 16; g.x_bs = wT * Cip; g.dy_bs = wT * Cop; g.dw_bs = (size_t)Cip * Cop;
+        conv_wgrad(n.ctx.s, g);
+        wino_filter_grad(n.ctx.s, wd.ws, n.wsU, A->g + wd.off);
+      } else if (!folded) {
         conv_wgrad(n.ctx.s, wa);
       } else {
         for (int ph = 0; ph < 4; ++ph) {
@@ -249,6 +303,23 @@ void Net::conv(const std::string& name, const Var& x, const Var& y, ConvKind kin
     }
     if (!want_dx || (me.reads_net_input && !igrad)) return;
     const int accf = me.acc.empty() ? 0 : me.acc[0];
+    if (wino) {
+      // input gradient = the transposed 3x3 conv over dY (flipped, channel-transposed filter)
+      wino_input_transform(n.ctx.s, dY, wpad2, PAD_ZERO, wTh2, wTw2, n.wsV);
+      ConvFwdArgs g;
+      g.x = plane_view(n.wsV, wT2, Cop); g.g.Ho = 1; g.g.Wo = (int)wT2;
+      g.w = n.dg + ub_off; g.Npad = Cip; g.Cout = Cip;
+      g.y = plane_view(n.wsM, wT2, Cip);
+      g.batch = 16; g.x_bs = wT2 * Cop; g.w_bs = (size_t)Cop * Cip; g.y_bs = wT2 * Cip;
+      conv_fwd(n.ctx.s, g);
+      if (kind == CK_K3S1_REFLECT) {
+        wino_output_transform(n.ctx.s, n.wsM, Cip, wTh2, wTw2, nullptr, ACT_NONE, dxp, Cip, 0);
+        reflect_fold(n.ctx.s, dxp, xgv, accf);
+      } else {
+        wino_output_transform(n.ctx.s, n.wsM, Cip, wTh2, wTw2, nullptr, ACT_NONE, xgv, Cip, accf);
+      }
+      return;
+    }
     if (kind == CK_K4S2) {
       for (int ph = 0; ph < 4; ++ph) {
         const int a = ph >> 1, b = ph & 1;
@@ -463,6 +534,9 @@ void Net::finalize(const std::vector<Var>& pre) {
     }
   }
   dg = dg_n ? static_cast<float*>(ctx.alloc(dg_n * sizeof(float))) : nullptr;
+  if (wsV_need) wsV = static_cast<float*>(ctx.alloc(wsV_need * sizeof(float)));
+  if (wsM_need) wsM = static_cast<float*>(ctx.alloc(wsM_need * sizeof(float)));
+  if (wsU_need) wsU = static_cast<float*>(ctx.alloc(wsU_need * sizeof(float)));
   finalized_ = true;
 }
 

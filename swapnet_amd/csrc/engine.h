@@ -87,6 +87,9 @@ class Net {
   float* dg = nullptr;      // dgrad operands of this net's convs
   size_t dg_n = 0;
   int dg_version = 0;       // arena.version the operands were derived from
+  // Winograd scratch shared by all 3x3 layers of the net (V/M planes, dU): sized in finalize()
+  size_t wsV_need = 0, wsM_need = 0, wsU_need = 0;
+  float *wsV = nullptr, *wsM = nullptr, *wsU = nullptr;
   std::vector<std::pair<Op*, size_t>> dg_layout;
 
   Var alloc_var(int N, int H, int W, int C, bool need_grad);

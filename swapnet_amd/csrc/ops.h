@@ -9,6 +9,8 @@
 
 namespace swn {
 
+struct WShape;
+
 struct Stream {
   void* handle = nullptr;   // hipStream_t
   char* ws = nullptr;       // scratch for split-K slabs / reduction partials (device)
@@ -48,6 +50,9 @@ struct ConvFwdArgs {
   TView y;                    // y.C = Cout (logical), may be a slice
   OutMap om;
   int Cout = 0;               // valid output channels (<= Npad)
+  // batched mode (Winograd: 16 independent GEMMs in one launch): element strides between batches
+  int batch = 1;
+  size_t x_bs = 0, w_bs = 0, y_bs = 0;
 };
 void conv_fwd(Stream& s, const ConvFwdArgs& a);
 
@@ -60,6 +65,8 @@ struct ConvWgradArgs {
   float* dw = nullptr;
   int Npad = 0;
   int Cout = 0;
+  int batch = 1;
+  size_t x_bs = 0, dy_bs = 0, dw_bs = 0;
 };
 void conv_wgrad(Stream& s, const ConvWgradArgs& a);
 
@@ -74,6 +81,16 @@ void bias_grad(Stream& s, const TView& dy, float* db);
 // dx[i] (+)= sum_{u: reflect(u-1)==i} dxpad[u]   -- folds the (H+2)x(W+2) gradient of a
 // ReflectionPad2d(1) back onto the HxW tensor.
 void reflect_fold(Stream& s, const TView& dxpad, const TView& dx, int accumulate);
+
+// ---- Winograd F(2x2,3x3) transforms (3x3 stride-1 convolutions; see wino.hip) -------------------
+// tile (n,ty,tx) covers outputs (2ty..2ty+1, 2tx..2tx+1) and input rows 2ty-pad .. 2ty-pad+3
+void wino_input_transform(Stream& s, const TView& x, int pad, int pad_mode, int Th, int Tw, float* V);   // V[16][T][x.C]
+// mode 0: U[16][Cip][Npad] for the forward conv; mode 1: U[16][Npad][Cip] (flipped, transposed) for dgrad
+void wino_filter_transform(Stream& s, const WShape& w, int mode, const float* packed, float* U);
+void wino_output_transform(Stream& s, const float* M, int Cm, int Th, int Tw, const float* bias, int act,
+                           const TView& y, int Cout, int accumulate);                                      // M[16][T][Cm]
+void wino_dy_transform(Stream& s, const TView& dy, int Th, int Tw, float* dM);                             // dM[16][T][dy.C]
+void wino_filter_grad(Stream& s, const WShape& w, const float* dU, float* dpacked);                        // dU[16][Cip][Npad]
 
 // ---- InstanceNorm / activation / dropout -------------------------------------------
 struct NormActArgs {

@@ -1,0 +1,267 @@
+// swapnet_amd -- Winograd F(2x2, 3x3) transforms for the 3x3 stride-1 convolutions
+// (ResidualBlock convs, modules/layers.py:131-138 = 59 % of WarpModule's FLOPs; VGG16 convs of
+// PerceptualLoss, modules/losses/perceptual.py:26-42).
+//
+//   Y = A^T [ (G g G^T) .* (B^T d B) ] A        2.25x fewer multiplies than the direct form
+//
+// The element-wise products summed over input channels are 16 independent GEMMs
+// M[t] = V[t] (T x C) * U[t] (C x Co), t = 0..15, executed by the MFMA implicit-GEMM kernel in
+// batched mode (conv_gemm.hip); this file holds the HBM-bound transforms around them:
+//   wino_input_transform   d (4x4 input patches, reflect / zero padding) -> V[16][T][C]
+//   wino_filter_transform  packed W -> U[16][K][N]      (forward, or flipped+transposed for dgrad)
+//   wino_output_transform  M[16][T][Co] -> y (2x2 per tile) + bias + activation
+//   wino_dy_transform      dY (2x2 per tile) -> dM[16][T][Co] = A dY A^T        (weight gradient)
+//   wino_filter_grad       dU[16][K][N] -> dW packed = G^T dU G
+// All 16-byte vectorised along the channel axis; fp32 throughout.
+#include "hip_util.h"
+
+namespace swn {
+namespace {
+
+__device__ __forceinline__ float4 f4add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+__device__ __forceinline__ float4 f4sub(float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
+
+__device__ __forceinline__ int wsrc(int e, int ext, int pad_mode) {
+  if (pad_mode == PAD_REFLECT) {
+    if (e < 0) e = -e;
+    else if (e >= ext) e = 2 * ext - 2 - e;
+    return e;
+  }
+  return (e < 0 || e >= ext) ? -1 : e;
+}
+
+// one thread per (tile, 4 channels)
+__global__ __launch_bounds__(256) void wino_input_kernel(const float* x, int xcs, int N, int H, int W, int C, int pad,
+                                                         int pad_mode, int Th, int Tw, float* V) {
+  const int C4 = C >> 2;
+  const size_t T = (size_t)N * Th * Tw;
+  const size_t total = T * C4;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const size_t tile = i / C4;
+    const int c = (int)(i - tile * C4) * 4;
+    const int tx = (int)(tile % Tw); size_t q = tile / Tw;
+    const int ty = (int)(q % Th); const int n = (int)(q / Th);
+    float4 d[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      const int sy = wsrc(2 * ty - pad + a, H, pad_mode);
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const int sx = wsrc(2 * tx - pad + b, W, pad_mode);
+        d[a][b] = (sy >= 0 && sx >= 0)
+                      ? *reinterpret_cast<const float4*>(x + ((size_t)(n * H + sy) * W + sx) * xcs + c)
+                      : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+    float4 t[4][4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {          // B^T d  (rows)
+      t[0][b] = f4sub(d[0][b], d[2][b]);
+      t[1][b] = f4add(d[1][b], d[2][b]);
+      t[2][b] = f4sub(d[2][b], d[1][b]);
+      t[3][b] = f4sub(d[1][b], d[3][b]);
+    }
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {          // (.) B  (columns)
+      const float4 v0 = f4sub(t[a][0], t[a][2]), v1 = f4add(t[a][1], t[a][2]);
+      const float4 v2 = f4sub(t[a][2], t[a][1]), v3 = f4sub(t[a][1], t[a][3]);
+      float* o = V + ((size_t)(a * 4) * T + tile) * C + c;
+      *reinterpret_cast<float4*>(o) = v0;
+      *reinterpret_cast<float4*>(o + T * C) = v1;
+      *reinterpret_cast<float4*>(o + 2 * T * C) = v2;
+      *reinterpret_cast<float4*>(o + 3 * T * C) = v3;
+    }
+  }
+}
+
+// U[t][k][n] = (G g G^T)[t];  mode 0: g[ky][kx] = W[(ky,kx,k=ci)][n=co]
+//                              mode 1: g[ky][kx] = W[(2-ky,2-kx,ci=n)][co=k]   (input-gradient operand)
+__global__ __launch_bounds__(256) void wino_filter_kernel(WShape w, int mode, int K, int Nn, const float* packed, float* U) {
+  const size_t total = (size_t)K * Nn;
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int k = (int)(i / Nn), n = (int)(i - (size_t)k * Nn);
+  float g[3][3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+      float v = 0.f;
+      if (mode == 0) {
+        if (k < w.Cip && n < w.Npad) v = packed[((size_t)(a * 3 + b) * w.Cip + k) * w.Npad + n];
+      } else {
+        if (n < w.Cip && k < w.Npad) v = packed[((size_t)((2 - a) * 3 + (2 - b)) * w.Cip + n) * w.Npad + k];
+      }
+      g[a][b] = v;
+    }
+  float t[4][3];
+#pragma unroll
+  for (int b = 0; b < 3; ++b) {            // G g
+    t[0][b] = g[0][b];
+    t[1][b] = 0.5f * (g[0][b] + g[1][b] + g[2][b]);
+    t[2][b] = 0.5f * (g[0][b] - g[1][b] + g[2][b]);
+    t[3][b] = g[2][b];
+  }
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {            // (.) G^T
+    const float u0 = t[a][0], u1 = 0.5f * (t[a][0] + t[a][1] + t[a][2]);
+    const float u2 = 0.5f * (t[a][0] - t[a][1] + t[a][2]), u3 = t[a][2];
+    U[(size_t)(a * 4 + 0) * total + i] = u0; U[(size_t)(a * 4 + 1) * total + i] = u1;
+    U[(size_t)(a * 4 + 2) * total + i] = u2; U[(size_t)(a * 4 + 3) * total + i] = u3;
+  }
+}
+
+// y[2ty+a'][2tx+b'] (+)= act( (A^T m A)[a'][b'] + bias ),  m = M[.][tile][c]
+__global__ __launch_bounds__(256) void wino_output_kernel(const float* M, int Cm, int N, int Th, int Tw, const float* bias,
+                                                          int act, float* y, int ycs, int yH, int yW, int Cout,
+                                                          int accumulate) {
+  const int C4 = (Cout + 3) >> 2;
+  const size_t T = (size_t)N * Th * Tw;
+  const size_t total = T * C4;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const size_t tile = i / C4;
+    const int c = (int)(i - tile * C4) * 4;
+    const int tx = (int)(tile % Tw); size_t q = tile / Tw;
+    const int ty = (int)(q % Th); const int n = (int)(q / Th);
+    float4 m[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) m[a][b] = *reinterpret_cast<const float4*>(M + ((size_t)(a * 4 + b) * T + tile) * Cm + c);
+    float4 s[2][4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {          // A^T m
+      s[0][b] = f4add(f4add(m[0][b], m[1][b]), m[2][b]);
+      s[1][b] = f4sub(f4sub(m[1][b], m[2][b]), m[3][b]);
+    }
+    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (bias) bv = make_float4(c < Cout ? bias[c] : 0.f, c + 1 < Cout ? bias[c + 1] : 0.f,
+                               c + 2 < Cout ? bias[c + 2] : 0.f, c + 3 < Cout ? bias[c + 3] : 0.f);
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      float4 o[2];
+      o[0] = f4add(f4add(s[a][0], s[a][1]), s[a][2]);
+      o[1] = f4sub(f4sub(s[a][1], s[a][2]), s[a][3]);
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        const int oy = 2 * ty + a, ox = 2 * tx + b;
+        if (oy >= yH || ox >= yW) continue;
+        float4 v = f4add(o[b], bv);
+        v.x = act_apply(v.x, act); v.y = act_apply(v.y, act); v.z = act_apply(v.z, act); v.w = act_apply(v.w, act);
+        float* dst = y + ((size_t)(n * yH + oy) * yW + ox) * ycs + c;
+        if (accumulate) v = f4add(v, *reinterpret_cast<const float4*>(dst));
+        if (c + 3 < Cout) {
+          *reinterpret_cast<float4*>(dst) = v;
+        } else {                              // ragged channel tail (Cout not a multiple of 4)
+          const float vv[4] = {v.x, v.y, v.z, v.w};
+          for (int j = 0; j < 4 && c + j < Cout; ++j) dst[j] = vv[j];
+        }
+      }
+    }
+  }
+}
+
+// dM = A dY A^T : 2x2 -> 4x4   (A = [[1,0],[1,1],[1,-1],[0,-1]])
+__global__ __launch_bounds__(256) void wino_dy_kernel(const float* dy, int dcs, int N, int H, int W, int C, int Th, int Tw,
+                                                      float* dM) {
+  const int C4 = C >> 2;
+  const size_t T = (size_t)N * Th * Tw;
+  const size_t total = T * C4;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const size_t tile = i / C4;
+    const int c = (int)(i - tile * C4) * 4;
+    const int tx = (int)(tile % Tw); size_t q = tile / Tw;
+    const int ty = (int)(q % Th); const int n = (int)(q / Th);
+    float4 g[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        const int oy = 2 * ty + a, ox = 2 * tx + b;
+        g[a][b] = (oy < H && ox < W) ? *reinterpret_cast<const float4*>(dy + ((size_t)(n * H + oy) * W + ox) * dcs + c)
+                                     : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    float4 r[4][2];                         // A g
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      r[0][b] = g[0][b];
+      r[1][b] = f4add(g[0][b], g[1][b]);
+      r[2][b] = f4sub(g[0][b], g[1][b]);
+      r[3][b] = make_float4(-g[1][b].x, -g[1][b].y, -g[1][b].z, -g[1][b].w);
+    }
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {           // (.) A^T
+      const float4 v0 = r[a][0], v1 = f4add(r[a][0], r[a][1]), v2 = f4sub(r[a][0], r[a][1]);
+      const float4 v3 = make_float4(-r[a][1].x, -r[a][1].y, -r[a][1].z, -r[a][1].w);
+      float* o = dM + ((size_t)(a * 4) * T + tile) * C + c;
+      *reinterpret_cast<float4*>(o) = v0;
+      *reinterpret_cast<float4*>(o + T * C) = v1;
+      *reinterpret_cast<float4*>(o + 2 * T * C) = v2;
+      *reinterpret_cast<float4*>(o + 3 * T * C) = v3;
+    }
+  }
+}
+
+// dW[(ky,kx,ci)][co] = (G^T dU G)[ky][kx]
+__global__ __launch_bounds__(256) void wino_filter_grad_kernel(WShape w, const float* dU, float* dpacked) {
+  const size_t total = (size_t)w.Cip * w.Npad;
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  float u[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) u[a][b] = dU[(size_t)(a * 4 + b) * total + i];
+  float t[3][4];                            // G^T u
+#pragma unroll
+  for (int b = 0; b < 4; ++b) {
+    t[0][b] = u[0][b] + 0.5f * (u[1][b] + u[2][b]);
+    t[1][b] = 0.5f * (u[1][b] - u[2][b]);
+    t[2][b] = 0.5f * (u[1][b] + u[2][b]) + u[3][b];
+  }
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {             // (.) G
+    dpacked[(size_t)(a * 3 + 0) * total + i] = t[a][0] + 0.5f * (t[a][1] + t[a][2]);
+    dpacked[(size_t)(a * 3 + 1) * total + i] = 0.5f * (t[a][1] - t[a][2]);
+    dpacked[(size_t)(a * 3 + 2) * total + i] = 0.5f * (t[a][1] + t[a][2]) + t[a][3];
+  }
+}
+
+inline unsigned wgrid(size_t total) { return (unsigned)std::min<size_t>(std::max<size_t>((total + 255) / 256, 1), 256 * 32); }
+
+}  // namespace
+
+void wino_input_transform(Stream& s, const TView& x, int pad, int pad_mode, int Th, int Tw, float* V) {
+  if (x.C % 4 || x.cs % 4) throw Error(1, "wino_input_transform: C must be a multiple of 4");
+  const size_t total = (size_t)x.N * Th * Tw * (x.C / 4);
+  hipLaunchKernelGGL(wino_input_kernel, dim3(wgrid(total)), dim3(256), 0, hs(s), x.p, x.cs, x.N, x.H, x.W, x.C, pad,
+                     pad_mode, Th, Tw, V);
+  check_launch("wino_input_transform");
+}
+void wino_filter_transform(Stream& s, const WShape& w, int mode, const float* packed, float* U) {
+  const int K = mode == 0 ? w.Cip : w.Npad, Nn = mode == 0 ? w.Npad : w.Cip;
+  hipLaunchKernelGGL(wino_filter_kernel, dim3((unsigned)(((size_t)K * Nn + 255) / 256)), dim3(256), 0, hs(s), w, mode, K,
+                     Nn, packed, U);
+  check_launch("wino_filter_transform");
+}
+void wino_output_transform(Stream& s, const float* M, int Cm, int Th, int Tw, const float* bias, int act, const TView& y,
+                           int Cout, int accumulate) {
+  const size_t total = (size_t)y.N * Th * Tw * ((Cout + 3) / 4);
+  hipLaunchKernelGGL(wino_output_kernel, dim3(wgrid(total)), dim3(256), 0, hs(s), M, Cm, y.N, Th, Tw, bias, act, y.p,
+                     y.cs, y.H, y.W, Cout, accumulate);
+  check_launch("wino_output_transform");
+}
+void wino_dy_transform(Stream& s, const TView& dy, int Th, int Tw, float* dM) {
+  if (dy.C % 4 || dy.cs % 4) throw Error(1, "wino_dy_transform: C must be a multiple of 4");
+  const size_t total = (size_t)dy.N * Th * Tw * (dy.C / 4);
+  hipLaunchKernelGGL(wino_dy_kernel, dim3(wgrid(total)), dim3(256), 0, hs(s), dy.p, dy.cs, dy.N, dy.H, dy.W, dy.C, Th, Tw,
+                     dM);
+  check_launch("wino_dy_transform");
+}
+void wino_filter_grad(Stream& s, const WShape& w, const float* dU, float* dpacked) {
+  const size_t total = (size_t)w.Cip * w.Npad;
+  hipLaunchKernelGGL(wino_filter_grad_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, hs(s), w, dU, dpacked);
+  check_launch("wino_filter_grad");
+}
+
+}  // namespace swn

@@ -51,7 +51,7 @@ static inline int srcc(int e, int ext, int mode, int ups) {
 }
 static inline float* at(const TView& v, int n, int y, int x) { return v.p + ((size_t)(n * v.H + y) * v.W + x) * v.cs; }
 
-void conv_fwd(Stream&, const ConvFwdArgs& a) {
+static void conv_fwd_one(const ConvFwdArgs& a) {
   const TView& X = a.x; const Gather& g = a.g;
   const int He = X.H << g.ups, We = X.W << g.ups;
 #pragma omp parallel for collapse(2) schedule(static)
@@ -85,9 +85,16 @@ void conv_fwd(Stream&, const ConvFwdArgs& a) {
       }
     }
 }
+void conv_fwd(Stream&, const ConvFwdArgs& a) {
+  for (int b = 0; b < (a.batch > 0 ? a.batch : 1); ++b) {
+    ConvFwdArgs c = a;
+    c.x.p = a.x.p + b * a.x_bs; c.w = a.w + b * a.w_bs; c.y.p = a.y.p + b * a.y_bs;
+    conv_fwd_one(c);
+  }
+}
 void conv_fwd_naive(Stream& s, const ConvFwdArgs& a) { conv_fwd(s, a); }
 
-void conv_wgrad(Stream&, const ConvWgradArgs& a) {
+static void conv_wgrad_one(const ConvWgradArgs& a) {
   const TView& X = a.x; const Gather& g = a.g;
   const int He = X.H << g.ups, We = X.W << g.ups;
   const int K = g.KH * g.KW * X.C;
@@ -120,7 +127,95 @@ void conv_wgrad(Stream&, const ConvWgradArgs& a) {
   }
   for (size_t i = 0; i < acc.size(); ++i) a.dw[i] = (float)acc[i];
 }
+void conv_wgrad(Stream&, const ConvWgradArgs& a) {
+  for (int b = 0; b < (a.batch > 0 ? a.batch : 1); ++b) {
+    ConvWgradArgs c = a;
+    c.x.p = a.x.p + b * a.x_bs; c.dy.p = a.dy.p + b * a.dy_bs; c.dw = a.dw + b * a.dw_bs;
+    conv_wgrad_one(c);
+  }
+}
 void conv_wgrad_naive(Stream& s, const ConvWgradArgs& a) { conv_wgrad(s, a); }
+
+static const float kBT[4][4] = {{1, 0, -1, 0}, {0, 1, 1, 0}, {0, -1, 1, 0}, {0, 1, 0, -1}};
+static const float kG[4][3] = {{1, 0, 0}, {0.5f, 0.5f, 0.5f}, {0.5f, -0.5f, 0.5f}, {0, 0, 1}};
+static const float kAT[2][4] = {{1, 1, 1, 0}, {0, 1, -1, -1}};
+void wino_input_transform(Stream&, const TView& x, int pad, int pad_mode, int Th, int Tw, float* V) {
+  const size_t T = (size_t)x.N * Th * Tw;
+  for (int n = 0; n < x.N; ++n) for (int ty = 0; ty < Th; ++ty) for (int tx = 0; tx < Tw; ++tx) {
+    const size_t tile = ((size_t)n * Th + ty) * Tw + tx;
+    for (int c = 0; c < x.C; ++c) {
+      float d[4][4], t[4][4];
+      for (int a = 0; a < 4; ++a) for (int b = 0; b < 4; ++b) {
+        const int sy = srcc(2 * ty - pad + a, x.H, pad_mode, 0), sx = srcc(2 * tx - pad + b, x.W, pad_mode, 0);
+        d[a][b] = (sy >= 0 && sx >= 0) ? at(x, n, sy, sx)[c] : 0.f;
+      }
+      for (int a = 0; a < 4; ++a) for (int b = 0; b < 4; ++b) { float s = 0; for (int k = 0; k < 4; ++k) s += kBT[a][k] * d[k][b]; t[a][b] = s; }
+      for (int a = 0; a < 4; ++a) for (int b = 0; b < 4; ++b) { float s = 0; for (int k = 0; k < 4; ++k) s += t[a][k] * kBT[b][k];
+        V[((size_t)(a * 4 + b) * T + tile) * x.C + c] = s; }
+    }
+  }
+}
+void wino_filter_transform(Stream&, const WShape& w, int mode, const float* packed, float* U) {
+  const int K = mode == 0 ? w.Cip : w.Npad, Nn = mode == 0 ? w.Npad : w.Cip;
+  const size_t total = (size_t)K * Nn;
+  for (int k = 0; k < K; ++k) for (int n = 0; n < Nn; ++n) {
+    float g[3][3], t[4][3];
+    for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b)
+      g[a][b] = mode == 0 ? packed[((size_t)(a * 3 + b) * w.Cip + k) * w.Npad + n]
+                          : packed[((size_t)((2 - a) * 3 + (2 - b)) * w.Cip + n) * w.Npad + k];
+    for (int a = 0; a < 4; ++a) for (int b = 0; b < 3; ++b) { float s = 0; for (int q = 0; q < 3; ++q) s += kG[a][q] * g[q][b]; t[a][b] = s; }
+    for (int a = 0; a < 4; ++a) for (int b = 0; b < 4; ++b) { float s = 0; for (int q = 0; q < 3; ++q) s += t[a][q] * kG[b][q];
+      U[(size_t)(a * 4 + b) * total + (size_t)k * Nn + n] = s; }
+  }
+}
+void wino_output_transform(Stream&, const float* M, int Cm, int Th, int Tw, const float* bias, int act, const TView& y,
+                           int Cout, int accumulate) {
+  const size_t T = (size_t)y.N * Th * Tw;
+  for (int n = 0; n < y.N; ++n) for (int ty = 0; ty < Th; ++ty) for (int tx = 0; tx < Tw; ++tx) {
+    const size_t tile = ((size_t)n * Th + ty) * Tw + tx;
+    for (int c = 0; c < Cout; ++c) {
+      float m[4][4], s2[2][4];
+      for (int a = 0; a < 4; ++a) for (int b = 0; b < 4; ++b) m[a][b] = M[((size_t)(a * 4 + b) * T + tile) * Cm + c];
+      for (int a = 0; a < 2; ++a) for (int b = 0; b < 4; ++b) { float s = 0; for (int q = 0; q < 4; ++q) s += kAT[a][q] * m[q][b]; s2[a][b] = s; }
+      for (int a = 0; a < 2; ++a) for (int b = 0; b < 2; ++b) {
+        const int oy = 2 * ty + a, ox = 2 * tx + b;
+        if (oy >= y.H || ox >= y.W) continue;
+        float s = 0; for (int q = 0; q < 4; ++q) s += s2[a][q] * kAT[b][q];
+        if (bias) s += bias[c];
+        s = actf(s, act);
+        float* d = at(y, n, oy, ox) + c;
+        *d = accumulate ? *d + s : s;
+      }
+    }
+  }
+}
+void wino_dy_transform(Stream&, const TView& dy, int Th, int Tw, float* dM) {
+  const size_t T = (size_t)dy.N * Th * Tw;
+  for (int n = 0; n < dy.N; ++n) for (int ty = 0; ty < Th; ++ty) for (int tx = 0; tx < Tw; ++tx) {
+    const size_t tile = ((size_t)n * Th + ty) * Tw + tx;
+    for (int c = 0; c < dy.C; ++c) {
+      float g[2][2];
+      for (int a = 0; a < 2; ++a) for (int b = 0; b < 2; ++b) {
+        const int oy = 2 * ty + a, ox = 2 * tx + b;
+        g[a][b] = (oy < dy.H && ox < dy.W) ? at(dy, n, oy, ox)[c] : 0.f;
+      }
+      for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) {     // dM = A g A^T, A = kAT^T
+        float s = 0;
+        for (int a = 0; a < 2; ++a) for (int b = 0; b < 2; ++b) s += kAT[a][i] * g[a][b] * kAT[b][j];
+        dM[((size_t)(i * 4 + j) * T + tile) * dy.C + c] = s;
+      }
+    }
+  }
+}
+void wino_filter_grad(Stream&, const WShape& w, const float* dU, float* dpacked) {
+  const size_t total = (size_t)w.Cip * w.Npad;
+  for (size_t i = 0; i < total; ++i)
+    for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) {       // dg = G^T dU G
+      float s = 0;
+      for (int p = 0; p < 4; ++p) for (int q = 0; q < 4; ++q) s += kG[p][a] * dU[(size_t)(p * 4 + q) * total + i] * kG[q][b];
+      dpacked[(size_t)(a * 3 + b) * total + i] = s;
+    }
+}
 
 void bias_grad(Stream&, const TView& dy, float* db) {
   std::vector<double> acc(dy.C, 0.0);
