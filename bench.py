@@ -18,7 +18,9 @@ Prints ONE JSON line (rank 0).  Extra objects:
   roofline     -- dominant kernel family (conv_fwd 128x128 MFMA tile): algorithmic FLOPs
                   (2*M*N*K per launch) / HIP-event time of those launches vs the 157.3 TFLOP/s
                   fp32 MFMA peak; `step_frac` = whole-step algorithmic FLOPs (251.34 GFLOP/img,
-                  BASELINE.md section 3) / step time / peak.
+                  BASELINE.md section 3) / step time / peak.  (`achieved` counts the FLOPs the
+                  kernel really executes; `step_frac` charges the dense-conv definition although the
+                  Winograd / folded-tail layers execute fewer -- both are stated in DESIGN.md.)
   cpu_baseline -- the CPU oracle (a port of the reference step, oracle/swapnet_oracle.py) timed
                   on this box's host cores on a bounded sample (N=1 only).
 """
