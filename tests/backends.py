@@ -40,3 +40,31 @@ def gpu_ctx():
     if "gpu" not in _ctx:
         _ctx["gpu"] = engine.Context(workspace_mb=1024)
     return _ctx["gpu"]
+
+
+_models = {}
+
+
+def get_model(ctx, kind, B, H, is_train=True):
+    """Native models are expensive to create on the host simulator (GBs of zeroed arenas): the
+    parity tests share one per (backend, stage, shape) and reset its training state instead."""
+    from swapnet_amd import engine
+    key = (id(ctx), kind, B, H, is_train)
+    if key not in _models:
+        _models[key] = engine.NativeModel(ctx, kind, B, H, H, is_train=is_train)
+    return _models[key]
+
+
+def reset_state(m, state_dicts):
+    """Load weights, zero both Adam moments and the step counters, default hyper-parameters."""
+    import torch
+    from swapnet_amd import engine
+    for net, sd in state_dicts.items():
+        m.load_state_dict(net, sd)
+        if net != engine.NET_VGG and m.is_train:
+            zeros = {k: torch.zeros_like(v) for k, v in sd.items()}
+            m.load_state_dict(net, zeros, which=engine.W_EXP_AVG)
+            m.load_state_dict(net, zeros, which=engine.W_EXP_AVG_SQ)
+            m.optim_step_count(net, 0)
+    if m.is_train:
+        m.set_hyper()

@@ -54,36 +54,39 @@ static inline float* at(const TView& v, int n, int y, int x) { return v.p + ((si
 static void conv_fwd_one(const ConvFwdArgs& a) {
   const TView& X = a.x; const Gather& g = a.g;
   const int He = X.H << g.ups, We = X.W << g.ups;
-#pragma omp parallel for collapse(2) schedule(static)
-  for (int n = 0; n < X.N; ++n)
-    for (int oy = 0; oy < g.Ho; ++oy) {
-      std::vector<double> acc(a.Cout);
-      for (int ox = 0; ox < g.Wo; ++ox) {
-        std::fill(acc.begin(), acc.end(), 0.0);
-        for (int kh = 0; kh < g.KH; ++kh)
-          for (int kw = 0; kw < g.KW; ++kw) {
-            const int sy = srcc(oy * g.stride - g.pad_t + kh, He, g.pad_mode, g.ups);
-            const int sx = srcc(ox * g.stride - g.pad_l + kw, We, g.pad_mode, g.ups);
-            if (sy < 0 || sx < 0) continue;
-            const float* xp = at(X, n, sy, sx);
-            const float* wp = a.w + (size_t)((kh * g.KW + kw) * X.C) * a.Npad;
-            for (int ci = 0; ci < X.C; ++ci) {
-              const float xv = xp[ci];
-              if (xv == 0.f) continue;
-              const float* wr = wp + (size_t)ci * a.Npad;
-              for (int co = 0; co < a.Cout; ++co) acc[co] += (double)xv * wr[co];
-            }
+  const long total = (long)X.N * g.Ho * g.Wo;
+#pragma omp parallel
+  {
+    std::vector<double> acc(a.Cout);
+#pragma omp for schedule(static)
+    for (long m = 0; m < total; ++m) {
+      const int n = (int)(m / ((long)g.Ho * g.Wo)); const int rem = (int)(m - (long)n * g.Ho * g.Wo);
+      const int oy = rem / g.Wo, ox = rem - oy * g.Wo;
+      std::fill(acc.begin(), acc.end(), 0.0);
+      for (int kh = 0; kh < g.KH; ++kh)
+        for (int kw = 0; kw < g.KW; ++kw) {
+          const int sy = srcc(oy * g.stride - g.pad_t + kh, He, g.pad_mode, g.ups);
+          const int sx = srcc(ox * g.stride - g.pad_l + kw, We, g.pad_mode, g.ups);
+          if (sy < 0 || sx < 0) continue;
+          const float* xp = at(X, n, sy, sx);
+          const float* wp = a.w + (size_t)((kh * g.KW + kw) * X.C) * a.Npad;
+          for (int ci = 0; ci < X.C; ++ci) {
+            const float xv = xp[ci];
+            if (xv == 0.f) continue;
+            const float* wr = wp + (size_t)ci * a.Npad;
+            for (int co = 0; co < a.Cout; ++co) acc[co] += (double)xv * wr[co];
           }
-        float* yp = at(a.y, n, oy * a.om.ymul + a.om.yoff, ox * a.om.xmul + a.om.xoff);
-        for (int co = 0; co < a.Cout; ++co) {
-          float v = (float)acc[co];
-          if (a.bias) v += a.bias[co];
-          v = actf(v, a.act);
-          if (a.accumulate) v += yp[co];
-          yp[co] = v;
         }
+      float* yp = at(a.y, n, oy * a.om.ymul + a.om.yoff, ox * a.om.xmul + a.om.xoff);
+      for (int co = 0; co < a.Cout; ++co) {
+        float v = (float)acc[co];
+        if (a.bias) v += a.bias[co];
+        v = actf(v, a.act);
+        if (a.accumulate) v += yp[co];
+        yp[co] = v;
       }
     }
+  }
 }
 void conv_fwd(Stream&, const ConvFwdArgs& a) {
   for (int b = 0; b < (a.batch > 0 ? a.batch : 1); ++b) {
@@ -97,35 +100,29 @@ void conv_fwd_naive(Stream& s, const ConvFwdArgs& a) { conv_fwd(s, a); }
 static void conv_wgrad_one(const ConvWgradArgs& a) {
   const TView& X = a.x; const Gather& g = a.g;
   const int He = X.H << g.ups, We = X.W << g.ups;
-  const int K = g.KH * g.KW * X.C;
-  std::vector<double> acc((size_t)K * a.Npad, 0.0);
-#pragma omp parallel
-  {
-    std::vector<double> loc((size_t)K * a.Npad, 0.0);
-#pragma omp for collapse(2) schedule(static) nowait
-    for (int n = 0; n < X.N; ++n)
-      for (int oy = 0; oy < g.Ho; ++oy)
-        for (int ox = 0; ox < g.Wo; ++ox) {
-          const float* dp = at(a.dy, n, oy * a.om.ymul + a.om.yoff, ox * a.om.xmul + a.om.xoff);
-          for (int kh = 0; kh < g.KH; ++kh)
-            for (int kw = 0; kw < g.KW; ++kw) {
-              const int sy = srcc(oy * g.stride - g.pad_t + kh, He, g.pad_mode, g.ups);
-              const int sx = srcc(ox * g.stride - g.pad_l + kw, We, g.pad_mode, g.ups);
-              if (sy < 0 || sx < 0) continue;
-              const float* xp = at(X, n, sy, sx);
-              double* lr = loc.data() + (size_t)((kh * g.KW + kw) * X.C) * a.Npad;
-              for (int ci = 0; ci < X.C; ++ci) {
-                const float xv = xp[ci];
-                if (xv == 0.f) continue;
-                double* l2 = lr + (size_t)ci * a.Npad;
-                for (int co = 0; co < a.Cout; ++co) l2[co] += (double)xv * dp[co];
-              }
-            }
+  const int taps = g.KH * g.KW;
+  // each thread owns whole (tap, ci) rows of dW: no cross-thread reduction, fp64 accumulation
+#pragma omp parallel for collapse(2) schedule(dynamic, 8)
+  for (int tap = 0; tap < taps; ++tap)
+    for (int ci = 0; ci < X.C; ++ci) {
+      const int kh = tap / g.KW, kw = tap - kh * g.KW;
+      std::vector<double> acc(a.Npad, 0.0);
+      for (int n = 0; n < X.N; ++n)
+        for (int oy = 0; oy < g.Ho; ++oy) {
+          const int sy = srcc(oy * g.stride - g.pad_t + kh, He, g.pad_mode, g.ups);
+          if (sy < 0) continue;
+          for (int ox = 0; ox < g.Wo; ++ox) {
+            const int sx = srcc(ox * g.stride - g.pad_l + kw, We, g.pad_mode, g.ups);
+            if (sx < 0) continue;
+            const float xv = at(X, n, sy, sx)[ci];
+            if (xv == 0.f) continue;
+            const float* dp = at(a.dy, n, oy * a.om.ymul + a.om.yoff, ox * a.om.xmul + a.om.xoff);
+            for (int co = 0; co < a.Cout; ++co) acc[co] += (double)xv * dp[co];
+          }
         }
-#pragma omp critical
-    for (size_t i = 0; i < acc.size(); ++i) acc[i] += loc[i];
-  }
-  for (size_t i = 0; i < acc.size(); ++i) a.dw[i] = (float)acc[i];
+      float* o = a.dw + (size_t)(tap * X.C + ci) * a.Npad;
+      for (int co = 0; co < a.Npad; ++co) o[co] = (float)acc[co];
+    }
 }
 void conv_wgrad(Stream&, const ConvWgradArgs& a) {
   for (int b = 0; b < (a.batch > 0 ? a.batch : 1); ++b) {

@@ -70,8 +70,8 @@ def test_warp_forward_levels(backend, oracle_run, gold):
     G, D, batch, taps, _ = oracle_run
     ctx = _ctx(backend)
     B, H = batch[0].shape[0], batch[0].shape[2]
-    m = engine.NativeModel(ctx, "warp", B, H, H, is_train=False)
-    m.load_state_dict(engine.NET_G, G)
+    m = backends.get_model(ctx, "warp", B, H, is_train=False)
+    backends.reset_state(m, {engine.NET_G: G})
     m.set_input(0, batch[0]); m.set_input(1, batch[1])
     m.forward(False, 0)
     for name, ref in taps.items():
@@ -85,7 +85,6 @@ def test_warp_forward_levels(backend, oracle_run, gold):
     assert list(sd.keys()) == list(G.keys())
     for k in G:
         assert torch.equal(sd[k], G[k]), k
-    m.close()
 
 
 @pytest.mark.parametrize("backend", BACKENDS)
@@ -93,10 +92,8 @@ def test_warp_two_steps_match_oracle_and_reference(backend, oracle_run, gold):
     G, D, batch, _, steps = oracle_run
     ctx = _ctx(backend)
     B, H = batch[0].shape[0], batch[0].shape[2]
-    m = engine.NativeModel(ctx, "warp", B, H, H, is_train=True)
-    m.load_state_dict(engine.NET_G, G)
-    m.load_state_dict(engine.NET_D, D)
-    m.set_hyper()
+    m = backends.get_model(ctx, "warp", B, H)
+    backends.reset_state(m, {engine.NET_G: G, engine.NET_D: D})
     for i, t in enumerate(batch):
         m.set_input(i, t)
     for si, s in enumerate(steps):
@@ -151,7 +148,6 @@ def test_warp_two_steps_match_oracle_and_reference(backend, oracle_run, gold):
     ea = m.state_dict(engine.NET_G, which=engine.W_EXP_AVG, to_cpu=True)
     assert ea["body_down1.model.0.weight"].shape == (64, 3, 4, 4)
     assert m.optim_step_count(engine.NET_G) == len(steps)
-    m.close()
 
 
 @pytest.mark.parametrize("backend", BACKENDS)
@@ -162,8 +158,8 @@ def test_fused_step_equals_phased_step(backend, oracle_run):
     B, H = batch[0].shape[0], batch[0].shape[2]
     outs = []
     for fused in (False, True):
-        m = engine.NativeModel(ctx, "warp", B, H, H, is_train=True)
-        m.load_state_dict(0, G); m.load_state_dict(1, D); m.set_hyper()
+        m = backends.get_model(ctx, "warp", B, H)
+        backends.reset_state(m, {engine.NET_G: G, engine.NET_D: D})
         for i, t in enumerate(batch):
             m.set_input(i, t)
         lab = steps[0]["labels"]
@@ -172,7 +168,6 @@ def test_fused_step_equals_phased_step(backend, oracle_run):
         else:
             m.forward(False, 0); m.backward_D(lab[0], lab[1]); m.optimizer_step(1); m.backward_G(lab[2]); m.optimizer_step(0)
         outs.append((m.losses(), m.state_dict(0, to_cpu=True)["upsample_and_pad.2.weight"]))
-        m.close()
     assert outs[0][0] == outs[1][0]
     assert torch.equal(outs[0][1], outs[1][1])
 
@@ -232,8 +227,8 @@ def test_other_gan_objectives_and_ce_mode(backend, mode, oracle_run):
     st = O.WarpStepOracle(G, D, hyper=hyper)
     lab = steps[0]["labels"]
     st.step(*batch, labels=lab)
-    m = engine.NativeModel(ctx, "warp", B, H, H, is_train=True)
-    m.load_state_dict(0, G); m.load_state_dict(1, D)
+    m = backends.get_model(ctx, "warp", B, H)
+    backends.reset_state(m, {engine.NET_G: G, engine.NET_D: D})
     m.set_hyper(gan_mode={"lsgan": 1, "wgan": 2, "ce": 0}[mode], warp_mode_ce=int(mode == "ce"))
     for i, t in enumerate(batch):
         m.set_input(i, t)
@@ -249,4 +244,3 @@ def test_other_gan_objectives_and_ce_mode(backend, mode, oracle_run):
         pD = m.state_dict(1, to_cpu=True)
         assert all(torch.equal(pD[k], D[k]) for k in D)
         assert m.optim_step_count(1) == 0
-    m.close()
