@@ -82,11 +82,11 @@ def main():
     from swapnet_amd import _C, engine, parallel, synthetic
     from swapnet_amd.modules import init_tensor
 
-    rank, world = parallel.init_from_env()
     local_rank = int(os.environ.get("SWAPNET_FORCE_DEVICE", os.environ.get("LOCAL_RANK", "0")))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (swapnet_amd has no CPU path)")
-    torch.cuda.set_device(local_rank)
+    torch.cuda.set_device(local_rank)            # before the process group: RCCL binds to the current device
+    rank, world = parallel.init_from_env()
     assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     import torch.distributed as dist
 

@@ -77,3 +77,29 @@ def test_synthetic_generators_follow_the_survey_spec():
     ot = O.synth_texture_batch(2, 64, 64, seed=4321)
     assert torch.equal(t["rois"], ot[1]) and torch.equal(t["input_textures"], ot[0])
     assert (t["rois"][:, 0] == torch.tensor([63., 0., 63., 0.])).all()      # one degenerate box per sample
+
+
+def test_shape_and_argument_errors_are_reported_not_crashed():
+    """Error conventions at the C-ABI: bad shapes / unknown slots come back as ValueError with
+    the library's message (SURVEY.md 8(b) "Error conventions"), never as a crash."""
+    import torch
+    from swapnet_amd import engine
+    from tests import backends
+    ctx = backends.hostsim_ctx()
+    with pytest.raises(ValueError, match="multiples of 64"):
+        engine.NativeModel(ctx, "warp", 1, 48, 48, is_train=False)          # cloth_down6 needs H/64 >= 1
+    with pytest.raises(ValueError, match="power of two"):
+        engine.NativeModel(ctx, "texture", 1, 96, 96, is_train=False)       # U-Net depth = log2(size)
+    m = backends.get_model(ctx, "warp", 2, 64, is_train=False)
+    with pytest.raises(ValueError, match="shape mismatch"):
+        m.set_input(0, torch.zeros(1, 3, 64, 64))                           # batch differs from the model's
+    with pytest.raises(ValueError, match="3 channels"):
+        m.set_input(0, torch.zeros(2, 4, 64, 64))
+    with pytest.raises(ValueError, match="unknown slot"):
+        m.set_input(7, torch.zeros(2, 3, 64, 64))
+    with pytest.raises(ValueError, match="training"):
+        m.backward_D(0.9, 0.9)                                              # inference-only model
+    with pytest.raises(ValueError, match="unknown parameter"):
+        m.set_param(engine.NET_G, "no.such.weight", torch.zeros(1))
+    with pytest.raises(ValueError, match="no such network"):
+        m.param_infos(engine.NET_D)                                         # D exists only when is_train
