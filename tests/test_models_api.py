@@ -198,3 +198,27 @@ def test_integer_label_inputs_equal_onehot_inputs(backend, tmp_path):
     model.set_input(dict(bodys=bodys, input_cloths=labels, cloth_paths=[""] * 2, body_paths=[""] * 2))
     model.test()
     assert torch.equal(a, model.fakes.cpu())
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_two_stage_device_pipeline_equals_reference_two_pass_inference(backend):
+    """inference.py's warp -> .npz (argmax labels) -> texture hand-off, kept in HBM
+    (SURVEY.md 8(f) rank 2): equals the oracle's two passes with the label round trip."""
+    from swapnet_amd.pipeline import TwoStagePipeline
+    ctx = backends.gpu_ctx() if backend == "gpu" else backends.hostsim_ctx()
+    torch.manual_seed(3)
+    Gw, Gt = O.warp_module_params(), O.texture_module_params(img_size=64)
+    bodys, inputs, _ = O.synth_warp_batch(1, 64, 64, seed=9)
+    tex, rois, _, _ = O.synth_texture_batch(1, 64, 64, seed=10)
+    with torch.no_grad():
+        warped = O.warp_module_forward(Gw, bodys, inputs)
+        labels = O.onehot_to_labels(warped)                           # what compress_and_save_cloth stores
+        cloth = O.labels_to_onehot(labels, 19)                        # what decompress_cloth_segment returns
+        ref = O.texture_module_forward(Gt, tex, rois, cloth)
+    pipe = TwoStagePipeline(Gw, Gt, img_size=64, ctx=ctx)
+    out, lab = pipe(bodys, inputs, tex, rois, return_labels=True)
+    # argmax of near-tied tanh outputs may legitimately flip on a handful of pixels (fp32 round-off)
+    agree = (lab.cpu().long() == labels).float().mean().item()
+    assert agree > 0.999, agree
+    if agree == 1.0:
+        assert float((out.cpu() - ref).norm() / ref.norm()) < 1e-3
