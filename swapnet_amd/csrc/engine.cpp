@@ -178,8 +178,11 @@ void Net::conv(const std::string& name, const Var& x, const Var& y, ConvKind kin
   // 3x3 stride-1 convs with MFMA-friendly channel counts run as Winograd F(2x2,3x3): transform,
   // 16 batched GEMMs, inverse transform (wino.hip) -- 2.25x fewer multiplies than the direct form.
   static const bool wino_on = !(getenv("SWN_WINOGRAD") && atoi(getenv("SWN_WINOGRAD")) == 0);
+  // ... when the channel counts are large enough for the 16 GEMMs (K = Cin each) to run at MFMA
+  // speed and to amortise the HBM-bound transforms (measured on VGG16: a loss below 256 channels)
+  static const int wino_minc = getenv("SWN_WINO_MINC") ? atoi(getenv("SWN_WINO_MINC")) : 256;
   const bool wino = wino_on && (kind == CK_K3S1_REFLECT || kind == CK_K3S1_ZERO) && Cip % 32 == 0 && Co % 32 == 0 &&
-                    x.v.H % 2 == 0 && x.v.W % 2 == 0 && x.v.H >= 4 && x.v.W >= 4;
+                    Cip >= wino_minc && Co >= wino_minc && x.v.H % 2 == 0 && x.v.W % 2 == 0 && x.v.H >= 4 && x.v.W >= 4;
   const int wN = x.v.N, wTh = x.v.H / 2, wTw = x.v.W / 2;
   const size_t wT = (size_t)wN * wTh * wTw;
   const int wpad2 = kind == CK_K3S1_REFLECT ? 2 : 1;                       // dgrad: pad of the transposed conv
