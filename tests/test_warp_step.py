@@ -244,3 +244,24 @@ def test_other_gan_objectives_and_ce_mode(backend, mode, oracle_run):
         pD = m.state_dict(1, to_cpu=True)
         assert all(torch.equal(pD[k], D[k]) for k in D)
         assert m.optim_step_count(1) == 0
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_non_square_warp_forward(backend, oracle_run):
+    """DeepFashion-shaped inputs are 4:3 (BASELINE.json config C5: 256x192): the warp generator
+    only needs H and W to be multiples of 64.  64x128 against the oracle."""
+    G = oracle_run[0]
+    ctx = _ctx(backend)
+    g = torch.Generator().manual_seed(11)
+    body = torch.randn(1, 3, 64, 128, generator=g)
+    lab = torch.randint(0, 19, (1, 8, 16), generator=g).repeat_interleave(8, 1).repeat_interleave(8, 2)
+    cloth = O.labels_to_onehot(lab, 19)
+    with torch.no_grad():
+        ref = O.warp_module_forward(G, body, cloth)
+    m = engine.NativeModel(ctx, "warp", 1, 64, 128, is_train=False)
+    m.load_state_dict(engine.NET_G, G)
+    m.set_input(0, body); m.set_input(1, cloth)
+    m.forward(False, 0)
+    assert m.output().shape == (1, 19, 64, 128)
+    assert rel(m.output(), ref) < 1e-3
+    m.close()
