@@ -175,25 +175,30 @@ void Net::conv(const std::string& name, const Var& x, const Var& y, ConvKind kin
     g.KH = 2 + a; g.KW = 2 + b; g.stride = 1; g.pad_t = 1; g.pad_l = 1; g.Ho = xv.H; g.Wo = xv.W;
     om.ymul = 2; om.yoff = a; om.xmul = 2; om.xoff = b;
   };
-  // 3x3 stride-1 convs with MFMA-friendly channel counts run as Winograd F(2x2,3x3): transform,
-  // 16 batched GEMMs, inverse transform (wino.hip) -- 2.25x fewer multiplies than the direct form.
-  static const bool wino_on = !(getenv("SWN_WINOGRAD") && atoi(getenv("SWN_WINOGRAD")) == 0);
-  // ... when the channel counts are large enough for the 16 GEMMs (K = Cin each) to run at MFMA
+  // 3x3 stride-1 convs with MFMA-friendly channel counts run as Winograd F(m x m,3x3): transform,
+  // (m+2)^2 batched GEMMs, inverse transform (wino.hip) -- 4x (m = 4, H and W multiples of 4) or
+  // 2.25x (m = 2) fewer multiplies than the direct form.
+  const bool wino_on = !(getenv("SWN_WINOGRAD") && atoi(getenv("SWN_WINOGRAD")) == 0);
+  // ... when the channel counts are large enough for the GEMMs (K = Cin each) to run at MFMA
   // speed and to amortise the HBM-bound transforms (measured on VGG16: a loss below 256 channels)
-  static const int wino_minc = getenv("SWN_WINO_MINC") ? atoi(getenv("SWN_WINO_MINC")) : 256;
+  const int wino_minc = getenv("SWN_WINO_MINC") ? atoi(getenv("SWN_WINO_MINC")) : 256;
+  const int wino_force_m = getenv("SWN_WINO_M") ? atoi(getenv("SWN_WINO_M")) : 0;
   const bool wino = wino_on && (kind == CK_K3S1_REFLECT || kind == CK_K3S1_ZERO) && Cip % 32 == 0 && Co % 32 == 0 &&
                     Cip >= wino_minc && Co >= wino_minc && x.v.H % 2 == 0 && x.v.W % 2 == 0 && x.v.H >= 4 && x.v.W >= 4;
-  const int wN = x.v.N, wTh = x.v.H / 2, wTw = x.v.W / 2;
+  const int wm = (wino_force_m != 2 && x.v.H % 4 == 0 && x.v.W % 4 == 0) ? 4 : 2;
+  const int wP = (wm + 2) * (wm + 2);
+  const int wN = x.v.N, wTh = x.v.H / wm, wTw = x.v.W / wm;
   const size_t wT = (size_t)wN * wTh * wTw;
   const int wpad2 = kind == CK_K3S1_REFLECT ? 2 : 1;                       // dgrad: pad of the transposed conv
-  const int wTh2 = kind == CK_K3S1_REFLECT ? (x.v.H + 2) / 2 : wTh, wTw2 = kind == CK_K3S1_REFLECT ? (x.v.W + 2) / 2 : wTw;
+  const int wTh2 = kind == CK_K3S1_REFLECT ? (x.v.H + 2 + wm - 1) / wm : wTh;
+  const int wTw2 = kind == CK_K3S1_REFLECT ? (x.v.W + 2 + wm - 1) / wm : wTw;
   const size_t wT2 = (size_t)wN * wTh2 * wTw2;
   size_t uf_off = 0, ub_off = 0;
   if (wino) {
-    uf_off = reserve_dg(self, (size_t)16 * Cip * Cop);
-    wsV_need = std::max(wsV_need, std::max((size_t)16 * wT * Cip, (size_t)16 * wT2 * Cop));
-    wsM_need = std::max(wsM_need, std::max((size_t)16 * wT * Cop, (size_t)16 * wT2 * Cip));
-    wsU_need = std::max(wsU_need, (size_t)16 * Cip * Cop);
+    uf_off = reserve_dg(self, (size_t)wP * Cip * Cop);
+    wsV_need = std::max(wsV_need, std::max((size_t)wP * wT * Cip, (size_t)wP * wT2 * Cop));
+    wsM_need = std::max(wsM_need, std::max((size_t)wP * wT * Cop, (size_t)wP * wT2 * Cip));
+    wsU_need = std::max(wsU_need, (size_t)wP * Cip * Cop);
   }
   auto plane_view = [](float* p, size_t T, int C) {
     TView v; v.p = p; v.N = 1; v.H = 1; v.W = (int)T; v.C = C; v.cs = C; return v;   // T x C matrix
@@ -206,14 +211,14 @@ void Net::conv(const std::string& name, const Var& x, const Var& y, ConvKind kin
     a.act = actf; a.y = yv; a.Cout = Co;
     if (wino) {
       n.refresh_dgrad();
-      wino_input_transform(n.ctx.s, xv, 1, gf.pad_mode, wTh, wTw, n.wsV);
+      wino_input_transform(n.ctx.s, wm, xv, 1, gf.pad_mode, wTh, wTw, n.wsV);
       ConvFwdArgs g;
       g.x = plane_view(n.wsV, wT, Cip); g.g.Ho = 1; g.g.Wo = (int)wT;
       g.w = n.dg + uf_off; g.Npad = Cop; g.Cout = Co;
       g.y = plane_view(n.wsM, wT, Cop);
-      g.batch = 16; g.x_bs = wT * Cip; g.w_bs = (size_t)Cip * Cop; g.y_bs = wT * Cop;
+      g.batch = wP; g.x_bs = wT * Cip; g.w_bs = (size_t)Cip * Cop; g.y_bs = wT * Cop;
       conv_fwd(n.ctx.s, g);
-      wino_output_transform(n.ctx.s, n.wsM, Cop, wTh, wTw, a.bias, actf, yv, Co, 0);
+      wino_output_transform(n.ctx.s, wm, n.wsM, Cop, wTh, wTw, a.bias, actf, yv, Co, 0);
       return;
     }
     if (!folded) { conv_fwd(n.ctx.s, a); return; }
@@ -245,7 +250,7 @@ void Net::conv(const std::string& name, const Var& x, const Var& y, ConvKind kin
   size_t dg_off = 0;
   const int Ndg = Cip;   // dgrad output channels = input buffer channels
   if (want_dx) {
-    if (wino) ub_off = reserve_dg(self, (size_t)16 * Cop * Cip);
+    if (wino) ub_off = reserve_dg(self, (size_t)wP * Cop * Cip);
     else dg_off = reserve_dg(self, dgrad_elems(arena.params[wi].ws, dg_mode, Cop, Ndg));
     if (kind == CK_K3S1_REFLECT) dxpad = alloc_var(x.v.N, dHo, dWo, Cip, false);
     op->grad_targets.push_back(x);
@@ -259,8 +264,8 @@ void Net::conv(const std::string& name, const Var& x, const Var& y, ConvKind kin
     const bool wdx = want_dx;
     op->repack = [=](Net& n) {
       const ParamDesc& wd = A->params[wi];
-      wino_filter_transform(n.ctx.s, wd.ws, 0, A->w + wd.off, n.dg + uf_off);
-      if (wdx) wino_filter_transform(n.ctx.s, wd.ws, 1, A->w + wd.off, n.dg + ub_off);
+      wino_filter_transform(n.ctx.s, wm, wd.ws, 0, A->w + wd.off, n.dg + uf_off);
+      if (wdx) wino_filter_transform(n.ctx.s, wm, wd.ws, 1, A->w + wd.off, n.dg + ub_off);
     };
   }
   if (folded) {
@@ -282,16 +287,16 @@ void Net::conv(const std::string& name, const Var& x, const Var& y, ConvKind kin
       ConvWgradArgs wa;
       wa.x = xv; wa.g = gf; wa.dy = dY; wa.dw = A->g + wd.off; wa.Npad = wd.ws.Npad; wa.Cout = Co;
       if (wino) {
-        // dU[t] = V[t]^T dM[t] (16 batched reductions over the tiles), then dW = G^T dU G
-        wino_input_transform(n.ctx.s, xv, 1, gf.pad_mode, wTh, wTw, n.wsV);
-        wino_dy_transform(n.ctx.s, dY, wTh, wTw, n.wsM);
+        // dU[t] = V[t]^T dM[t] (wP batched reductions over the tiles), then dW = G^T dU G
+        wino_input_transform(n.ctx.s, wm, xv, 1, gf.pad_mode, wTh, wTw, n.wsV);
+        wino_dy_transform(n.ctx.s, wm, dY, wTh, wTw, n.wsM);
         ConvWgradArgs g;
         g.x = plane_view(n.wsV, wT, Cip); g.g.Ho = 1; g.g.Wo = (int)wT;
         g.dy = plane_view(n.wsM, wT, Cop);
         g.dw = n.wsU; g.Npad = Cop; g.Cout = Co;
-        g.batch = 16; g.x_bs = wT * Cip; g.dy_bs = wT * Cop; g.dw_bs = (size_t)Cip * Cop;
+        g.batch = wP; g.x_bs = wT * Cip; g.dy_bs = wT * Cop; g.dw_bs = (size_t)Cip * Cop;
         conv_wgrad(n.ctx.s, g);
-        wino_filter_grad(n.ctx.s, wd.ws, n.wsU, A->g + wd.off);
+        wino_filter_grad(n.ctx.s, wm, wd.ws, n.wsU, A->g + wd.off);
       } else if (!folded) {
         conv_wgrad(n.ctx.s, wa);
       } else {
@@ -308,18 +313,18 @@ void Net::conv(const std::string& name, const Var& x, const Var& y, ConvKind kin
     const int accf = me.acc.empty() ? 0 : me.acc[0];
     if (wino) {
       // input gradient = the transposed 3x3 conv over dY (flipped, channel-transposed filter)
-      wino_input_transform(n.ctx.s, dY, wpad2, PAD_ZERO, wTh2, wTw2, n.wsV);
+      wino_input_transform(n.ctx.s, wm, dY, wpad2, PAD_ZERO, wTh2, wTw2, n.wsV);
       ConvFwdArgs g;
       g.x = plane_view(n.wsV, wT2, Cop); g.g.Ho = 1; g.g.Wo = (int)wT2;
       g.w = n.dg + ub_off; g.Npad = Cip; g.Cout = Cip;
       g.y = plane_view(n.wsM, wT2, Cip);
-      g.batch = 16; g.x_bs = wT2 * Cop; g.w_bs = (size_t)Cop * Cip; g.y_bs = wT2 * Cip;
+      g.batch = wP; g.x_bs = wT2 * Cop; g.w_bs = (size_t)Cop * Cip; g.y_bs = wT2 * Cip;
       conv_fwd(n.ctx.s, g);
       if (kind == CK_K3S1_REFLECT) {
-        wino_output_transform(n.ctx.s, n.wsM, Cip, wTh2, wTw2, nullptr, ACT_NONE, dxp, Cip, 0);
+        wino_output_transform(n.ctx.s, wm, n.wsM, Cip, wTh2, wTw2, nullptr, ACT_NONE, dxp, Cip, 0);
         reflect_fold(n.ctx.s, dxp, xgv, accf);
       } else {
-        wino_output_transform(n.ctx.s, n.wsM, Cip, wTh2, wTw2, nullptr, ACT_NONE, xgv, Cip, accf);
+        wino_output_transform(n.ctx.s, wm, n.wsM, Cip, wTh2, wTw2, nullptr, ACT_NONE, xgv, Cip, accf);
       }
       return;
     }

@@ -82,15 +82,16 @@ void bias_grad(Stream& s, const TView& dy, float* db);
 // ReflectionPad2d(1) back onto the HxW tensor.
 void reflect_fold(Stream& s, const TView& dxpad, const TView& dx, int accumulate);
 
-// ---- Winograd F(2x2,3x3) transforms (3x3 stride-1 convolutions; see wino.hip) -------------------
-// tile (n,ty,tx) covers outputs (2ty..2ty+1, 2tx..2tx+1) and input rows 2ty-pad .. 2ty-pad+3
-void wino_input_transform(Stream& s, const TView& x, int pad, int pad_mode, int Th, int Tw, float* V);   // V[16][T][x.C]
-// mode 0: U[16][Cip][Npad] for the forward conv; mode 1: U[16][Npad][Cip] (flipped, transposed) for dgrad
-void wino_filter_transform(Stream& s, const WShape& w, int mode, const float* packed, float* U);
-void wino_output_transform(Stream& s, const float* M, int Cm, int Th, int Tw, const float* bias, int act,
-                           const TView& y, int Cout, int accumulate);                                      // M[16][T][Cm]
-void wino_dy_transform(Stream& s, const TView& dy, int Th, int Tw, float* dM);                             // dM[16][T][dy.C]
-void wino_filter_grad(Stream& s, const WShape& w, const float* dU, float* dpacked);                        // dU[16][Cip][Npad]
+// ---- Winograd F(m x m, 3x3) transforms, m = 2 or 4 (3x3 stride-1 convolutions; see wino.hip) ----
+// tile (n,ty,tx) covers outputs (m*ty..m*ty+m-1, m*tx..) and input rows m*ty-pad .. m*ty-pad+m+1;
+// P = (m+2)^2 transform planes (16 for F(2,3): 2.25x fewer multiplies; 36 for F(4,3): 4x fewer)
+void wino_input_transform(Stream& s, int m, const TView& x, int pad, int pad_mode, int Th, int Tw, float* V);   // V[P][T][x.C]
+// mode 0: U[P][Cip][Npad] for the forward conv; mode 1: U[P][Npad][Cip] (flipped, transposed) for dgrad
+void wino_filter_transform(Stream& s, int m, const WShape& w, int mode, const float* packed, float* U);
+void wino_output_transform(Stream& s, int m, const float* M, int Cm, int Th, int Tw, const float* bias, int act,
+                           const TView& y, int Cout, int accumulate);                                      // M[P][T][Cm]
+void wino_dy_transform(Stream& s, int m, const TView& dy, int Th, int Tw, float* dM);                      // dM[P][T][dy.C]
+void wino_filter_grad(Stream& s, int m, const WShape& w, const float* dU, float* dpacked);                 // dU[P][Cip][Npad]
 
 // ---- InstanceNorm / activation / dropout -------------------------------------------
 struct NormActArgs {

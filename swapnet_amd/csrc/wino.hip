@@ -1,4 +1,4 @@
-// swapnet_amd -- Winograd F(2x2, 3x3) transforms for the 3x3 stride-1 convolutions
+// swapnet_amd -- Winograd F(2x2, 3x3) and F(4x4, 3x3) transforms for the 3x3 stride-1 convolutions
 // (ResidualBlock convs, modules/layers.py:131-138 = 59 % of WarpModule's FLOPs; VGG16 convs of
 // PerceptualLoss, modules/losses/perceptual.py:26-42).
 //
@@ -13,6 +13,10 @@
 //   wino_dy_transform      dY (2x2 per tile) -> dM[16][T][Co] = A dY A^T        (weight gradient)
 //   wino_filter_grad       dU[16][K][N] -> dW packed = G^T dU G
 // All 16-byte vectorised along the channel axis; fp32 throughout.
+//
+// F(4x4,3x3) (interpolation points 0, +-1, +-2, inf; 36 GEMMs per 4x4 outputs = 4x fewer multiplies)
+// uses the same five steps through the generic kernels at the end of the file; the engine picks
+// it when H and W are multiples of 4.
 #include "hip_util.h"
 
 namespace swn {
@@ -227,40 +231,302 @@ __global__ __launch_bounds__(256) void wino_filter_grad_kernel(WShape w, const f
   }
 }
 
+
+// ---------------------------------------------------------------------------------------
+// generic F(m x m, 3x3) transforms driven by constant matrices (instantiated for m = 4)
+// ---------------------------------------------------------------------------------------
+struct F43 {
+  static constexpr int M = 4, A = 6;
+  static constexpr float BT[6][6] = {{4, 0, -5, 0, 1, 0},  {0, -4, -4, 1, 1, 0}, {0, 4, -4, -1, 1, 0},
+                                     {0, -2, -1, 2, 1, 0}, {0, 2, -1, -2, 1, 0}, {0, 4, 0, -5, 0, 1}};
+  static constexpr float G[6][3] = {{1.f / 4, 0, 0},
+                                    {-1.f / 6, -1.f / 6, -1.f / 6},
+                                    {-1.f / 6, 1.f / 6, -1.f / 6},
+                                    {1.f / 24, 1.f / 12, 1.f / 6},
+                                    {1.f / 24, -1.f / 12, 1.f / 6},
+                                    {0, 0, 1}};
+  static constexpr float AT[4][6] = {{1, 1, 1, 1, 1, 0}, {0, 1, -1, 2, -2, 0}, {0, 1, 1, 4, 4, 0}, {0, 1, -1, 8, -8, 1}};
+};
+
+__device__ __forceinline__ void f4mac(float4& s, float c, const float4& x) {
+  if (c == 0.f) return;                     // folded at compile time (c is a literal after unrolling)
+  s.x += c * x.x; s.y += c * x.y; s.z += c * x.z; s.w += c * x.w;
+}
+__device__ __forceinline__ void f1mac(float& s, float c, float x) {
+  if (c == 0.f) return;
+  s += c * x;
+}
+#define F4ZERO make_float4(0.f, 0.f, 0.f, 0.f)
+
+template <class F>
+__global__ __launch_bounds__(256) void winog_input_kernel(const float* x, int xcs, int N, int H, int W, int C, int pad,
+                                                          int pad_mode, int Th, int Tw, float* V) {
+  constexpr int A = F::A, M = F::M;
+  const int C4 = C >> 2;
+  const size_t T = (size_t)N * Th * Tw;
+  const size_t total = T * C4;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const size_t tile = i / C4;
+    const int c = (int)(i - tile * C4) * 4;
+    const int tx = (int)(tile % Tw); size_t q = tile / Tw;
+    const int ty = (int)(q % Th); const int n = (int)(q / Th);
+    int sy[A];
+#pragma unroll
+    for (int a = 0; a < A; ++a) sy[a] = wsrc(M * ty - pad + a, H, pad_mode);
+    float4 t[A][A];
+#pragma unroll
+    for (int b = 0; b < A; ++b) {            // B^T d, one input column at a time
+      const int sx = wsrc(M * tx - pad + b, W, pad_mode);
+      float4 d[A];
+#pragma unroll
+      for (int a = 0; a < A; ++a)
+        d[a] = (sy[a] >= 0 && sx >= 0) ? *reinterpret_cast<const float4*>(x + ((size_t)(n * H + sy[a]) * W + sx) * xcs + c)
+                                       : F4ZERO;
+#pragma unroll
+      for (int r = 0; r < A; ++r) {
+        float4 s = F4ZERO;
+#pragma unroll
+        for (int k = 0; k < A; ++k) f4mac(s, F::BT[r][k], d[k]);
+        t[r][b] = s;
+      }
+    }
+#pragma unroll
+    for (int a = 0; a < A; ++a)              // (.) B
+#pragma unroll
+      for (int j = 0; j < A; ++j) {
+        float4 s = F4ZERO;
+#pragma unroll
+        for (int k = 0; k < A; ++k) f4mac(s, F::BT[j][k], t[a][k]);
+        *reinterpret_cast<float4*>(V + ((size_t)(a * A + j) * T + tile) * C + c) = s;
+      }
+  }
+}
+
+template <class F>
+__global__ __launch_bounds__(256) void winog_filter_kernel(WShape w, int mode, int K, int Nn, const float* packed, float* U) {
+  constexpr int A = F::A;
+  const size_t total = (size_t)K * Nn;
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int k = (int)(i / Nn), n = (int)(i - (size_t)k * Nn);
+  float g[3][3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+      float v = 0.f;
+      if (mode == 0) {
+        if (k < w.Cip && n < w.Npad) v = packed[((size_t)(a * 3 + b) * w.Cip + k) * w.Npad + n];
+      } else {
+        if (n < w.Cip && k < w.Npad) v = packed[((size_t)((2 - a) * 3 + (2 - b)) * w.Cip + n) * w.Npad + k];
+      }
+      g[a][b] = v;
+    }
+  float t[A][3];
+#pragma unroll
+  for (int r = 0; r < A; ++r)
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+      float s = 0.f;
+#pragma unroll
+      for (int q = 0; q < 3; ++q) f1mac(s, F::G[r][q], g[q][b]);
+      t[r][b] = s;
+    }
+#pragma unroll
+  for (int a = 0; a < A; ++a)
+#pragma unroll
+    for (int j = 0; j < A; ++j) {
+      float s = 0.f;
+#pragma unroll
+      for (int q = 0; q < 3; ++q) f1mac(s, F::G[j][q], t[a][q]);
+      U[(size_t)(a * A + j) * total + i] = s;
+    }
+}
+
+template <class F>
+__global__ __launch_bounds__(256) void winog_output_kernel(const float* Mx, int Cm, int N, int Th, int Tw, const float* bias,
+                                                           int act, float* y, int ycs, int yH, int yW, int Cout,
+                                                           int accumulate) {
+  constexpr int A = F::A, M = F::M;
+  const int C4 = (Cout + 3) >> 2;
+  const size_t T = (size_t)N * Th * Tw;
+  const size_t total = T * C4;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const size_t tile = i / C4;
+    const int c = (int)(i - tile * C4) * 4;
+    const int tx = (int)(tile % Tw); size_t q = tile / Tw;
+    const int ty = (int)(q % Th); const int n = (int)(q / Th);
+    float4 s1[M][A];
+#pragma unroll
+    for (int b = 0; b < A; ++b) {            // A^T m, one column of planes at a time
+      float4 m[A];
+#pragma unroll
+      for (int a = 0; a < A; ++a) m[a] = *reinterpret_cast<const float4*>(Mx + ((size_t)(a * A + b) * T + tile) * Cm + c);
+#pragma unroll
+      for (int r = 0; r < M; ++r) {
+        float4 s = F4ZERO;
+#pragma unroll
+        for (int k = 0; k < A; ++k) f4mac(s, F::AT[r][k], m[k]);
+        s1[r][b] = s;
+      }
+    }
+    float4 bv = F4ZERO;
+    if (bias) bv = make_float4(c < Cout ? bias[c] : 0.f, c + 1 < Cout ? bias[c + 1] : 0.f,
+                               c + 2 < Cout ? bias[c + 2] : 0.f, c + 3 < Cout ? bias[c + 3] : 0.f);
+#pragma unroll
+    for (int a = 0; a < M; ++a)
+#pragma unroll
+      for (int b = 0; b < M; ++b) {
+        const int oy = M * ty + a, ox = M * tx + b;
+        if (oy >= yH || ox >= yW) continue;
+        float4 v = F4ZERO;
+#pragma unroll
+        for (int k = 0; k < A; ++k) f4mac(v, F::AT[b][k], s1[a][k]);
+        v = f4add(v, bv);
+        v.x = act_apply(v.x, act); v.y = act_apply(v.y, act); v.z = act_apply(v.z, act); v.w = act_apply(v.w, act);
+        float* dst = y + ((size_t)(n * yH + oy) * yW + ox) * ycs + c;
+        if (accumulate) v = f4add(v, *reinterpret_cast<const float4*>(dst));
+        if (c + 3 < Cout) {
+          *reinterpret_cast<float4*>(dst) = v;
+        } else {
+          const float vv[4] = {v.x, v.y, v.z, v.w};
+          for (int j = 0; j < 4 && c + j < Cout; ++j) dst[j] = vv[j];
+        }
+      }
+  }
+}
+
+// dM = A dY A^T : m x m -> (m+2) x (m+2)   (A = AT^T)
+template <class F>
+__global__ __launch_bounds__(256) void winog_dy_kernel(const float* dy, int dcs, int N, int H, int W, int C, int Th, int Tw,
+                                                       float* dM) {
+  constexpr int A = F::A, M = F::M;
+  const int C4 = C >> 2;
+  const size_t T = (size_t)N * Th * Tw;
+  const size_t total = T * C4;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const size_t tile = i / C4;
+    const int c = (int)(i - tile * C4) * 4;
+    const int tx = (int)(tile % Tw); size_t q = tile / Tw;
+    const int ty = (int)(q % Th); const int n = (int)(q / Th);
+    float4 r[A][M];
+#pragma unroll
+    for (int b = 0; b < M; ++b) {
+      float4 g[M];
+#pragma unroll
+      for (int a = 0; a < M; ++a) {
+        const int oy = M * ty + a, ox = M * tx + b;
+        g[a] = (oy < H && ox < W) ? *reinterpret_cast<const float4*>(dy + ((size_t)(n * H + oy) * W + ox) * dcs + c) : F4ZERO;
+      }
+#pragma unroll
+      for (int p = 0; p < A; ++p) {
+        float4 s = F4ZERO;
+#pragma unroll
+        for (int a = 0; a < M; ++a) f4mac(s, F::AT[a][p], g[a]);
+        r[p][b] = s;
+      }
+    }
+#pragma unroll
+    for (int p = 0; p < A; ++p)
+#pragma unroll
+      for (int j = 0; j < A; ++j) {
+        float4 s = F4ZERO;
+#pragma unroll
+        for (int b = 0; b < M; ++b) f4mac(s, F::AT[b][j], r[p][b]);
+        *reinterpret_cast<float4*>(dM + ((size_t)(p * A + j) * T + tile) * C + c) = s;
+      }
+  }
+}
+
+// dW[(ky,kx,ci)][co] = (G^T dU G)[ky][kx]
+template <class F>
+__global__ __launch_bounds__(256) void winog_filter_grad_kernel(WShape w, const float* dU, float* dpacked) {
+  constexpr int A = F::A;
+  const size_t total = (size_t)w.Cip * w.Npad;
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  float t[3][A];
+#pragma unroll
+  for (int b = 0; b < A; ++b) {
+    float u[A];
+#pragma unroll
+    for (int a = 0; a < A; ++a) u[a] = dU[(size_t)(a * A + b) * total + i];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      float s = 0.f;
+#pragma unroll
+      for (int a = 0; a < A; ++a) f1mac(s, F::G[a][r], u[a]);
+      t[r][b] = s;
+    }
+  }
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      float s = 0.f;
+#pragma unroll
+      for (int b = 0; b < A; ++b) f1mac(s, F::G[b][j], t[a][b]);
+      dpacked[(size_t)(a * 3 + j) * total + i] = s;
+    }
+}
+
 inline unsigned wgrid(size_t total) { return (unsigned)std::min<size_t>(std::max<size_t>((total + 255) / 256, 1), 256 * 32); }
 
 }  // namespace
 
-void wino_input_transform(Stream& s, const TView& x, int pad, int pad_mode, int Th, int Tw, float* V) {
+static void check_m(int m) {
+  if (m != 2 && m != 4) throw Error(1, "winograd: output tile size must be 2 or 4");
+}
+void wino_input_transform(Stream& s, int m, const TView& x, int pad, int pad_mode, int Th, int Tw, float* V) {
+  check_m(m);
   if (x.C % 4 || x.cs % 4) throw Error(1, "wino_input_transform: C must be a multiple of 4");
   const size_t total = (size_t)x.N * Th * Tw * (x.C / 4);
-  hipLaunchKernelGGL(wino_input_kernel, dim3(wgrid(total)), dim3(256), 0, hs(s), x.p, x.cs, x.N, x.H, x.W, x.C, pad,
-                     pad_mode, Th, Tw, V);
+  if (m == 2)
+    hipLaunchKernelGGL(wino_input_kernel, dim3(wgrid(total)), dim3(256), 0, hs(s), x.p, x.cs, x.N, x.H, x.W, x.C, pad,
+                       pad_mode, Th, Tw, V);
+  else
+    hipLaunchKernelGGL(winog_input_kernel<F43>, dim3(wgrid(total)), dim3(256), 0, hs(s), x.p, x.cs, x.N, x.H, x.W, x.C,
+                       pad, pad_mode, Th, Tw, V);
   check_launch("wino_input_transform");
 }
-void wino_filter_transform(Stream& s, const WShape& w, int mode, const float* packed, float* U) {
+void wino_filter_transform(Stream& s, int m, const WShape& w, int mode, const float* packed, float* U) {
+  check_m(m);
   const int K = mode == 0 ? w.Cip : w.Npad, Nn = mode == 0 ? w.Npad : w.Cip;
-  hipLaunchKernelGGL(wino_filter_kernel, dim3((unsigned)(((size_t)K * Nn + 255) / 256)), dim3(256), 0, hs(s), w, mode, K,
-                     Nn, packed, U);
+  const dim3 grid((unsigned)(((size_t)K * Nn + 255) / 256));
+  if (m == 2) hipLaunchKernelGGL(wino_filter_kernel, grid, dim3(256), 0, hs(s), w, mode, K, Nn, packed, U);
+  else hipLaunchKernelGGL(winog_filter_kernel<F43>, grid, dim3(256), 0, hs(s), w, mode, K, Nn, packed, U);
   check_launch("wino_filter_transform");
 }
-void wino_output_transform(Stream& s, const float* M, int Cm, int Th, int Tw, const float* bias, int act, const TView& y,
-                           int Cout, int accumulate) {
+void wino_output_transform(Stream& s, int m, const float* M, int Cm, int Th, int Tw, const float* bias, int act,
+                           const TView& y, int Cout, int accumulate) {
+  check_m(m);
   const size_t total = (size_t)y.N * Th * Tw * ((Cout + 3) / 4);
-  hipLaunchKernelGGL(wino_output_kernel, dim3(wgrid(total)), dim3(256), 0, hs(s), M, Cm, y.N, Th, Tw, bias, act, y.p,
-                     y.cs, y.H, y.W, Cout, accumulate);
+  if (m == 2)
+    hipLaunchKernelGGL(wino_output_kernel, dim3(wgrid(total)), dim3(256), 0, hs(s), M, Cm, y.N, Th, Tw, bias, act, y.p,
+                       y.cs, y.H, y.W, Cout, accumulate);
+  else
+    hipLaunchKernelGGL(winog_output_kernel<F43>, dim3(wgrid(total)), dim3(256), 0, hs(s), M, Cm, y.N, Th, Tw, bias, act,
+                       y.p, y.cs, y.H, y.W, Cout, accumulate);
   check_launch("wino_output_transform");
 }
-void wino_dy_transform(Stream& s, const TView& dy, int Th, int Tw, float* dM) {
+void wino_dy_transform(Stream& s, int m, const TView& dy, int Th, int Tw, float* dM) {
+  check_m(m);
   if (dy.C % 4 || dy.cs % 4) throw Error(1, "wino_dy_transform: C must be a multiple of 4");
   const size_t total = (size_t)dy.N * Th * Tw * (dy.C / 4);
-  hipLaunchKernelGGL(wino_dy_kernel, dim3(wgrid(total)), dim3(256), 0, hs(s), dy.p, dy.cs, dy.N, dy.H, dy.W, dy.C, Th, Tw,
-                     dM);
+  if (m == 2)
+    hipLaunchKernelGGL(wino_dy_kernel, dim3(wgrid(total)), dim3(256), 0, hs(s), dy.p, dy.cs, dy.N, dy.H, dy.W, dy.C, Th,
+                       Tw, dM);
+  else
+    hipLaunchKernelGGL(winog_dy_kernel<F43>, dim3(wgrid(total)), dim3(256), 0, hs(s), dy.p, dy.cs, dy.N, dy.H, dy.W, dy.C,
+                       Th, Tw, dM);
   check_launch("wino_dy_transform");
 }
-void wino_filter_grad(Stream& s, const WShape& w, const float* dU, float* dpacked) {
+void wino_filter_grad(Stream& s, int m, const WShape& w, const float* dU, float* dpacked) {
+  check_m(m);
   const size_t total = (size_t)w.Cip * w.Npad;
-  hipLaunchKernelGGL(wino_filter_grad_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, hs(s), w, dU, dpacked);
+  const dim3 grid((unsigned)((total + 255) / 256));
+  if (m == 2) hipLaunchKernelGGL(wino_filter_grad_kernel, grid, dim3(256), 0, hs(s), w, dU, dpacked);
+  else hipLaunchKernelGGL(winog_filter_grad_kernel<F43>, grid, dim3(256), 0, hs(s), w, dU, dpacked);
   check_launch("wino_filter_grad");
 }
 

@@ -133,51 +133,69 @@ void conv_wgrad(Stream&, const ConvWgradArgs& a) {
 }
 void conv_wgrad_naive(Stream& s, const ConvWgradArgs& a) { conv_wgrad(s, a); }
 
-static const float kBT[4][4] = {{1, 0, -1, 0}, {0, 1, 1, 0}, {0, -1, 1, 0}, {0, 1, 0, -1}};
-static const float kG[4][3] = {{1, 0, 0}, {0.5f, 0.5f, 0.5f}, {0.5f, -0.5f, 0.5f}, {0, 0, 1}};
-static const float kAT[2][4] = {{1, 1, 1, 0}, {0, 1, -1, -1}};
-void wino_input_transform(Stream&, const TView& x, int pad, int pad_mode, int Th, int Tw, float* V) {
+// Winograd F(m x m, 3x3), m = 2 or 4, straight from the transform matrices
+struct WinoMats { int m, A; const float* BT; const float* G; const float* AT; };
+static const float kBT2[16] = {1, 0, -1, 0, 0, 1, 1, 0, 0, -1, 1, 0, 0, 1, 0, -1};
+static const float kG2[12] = {1, 0, 0, 0.5f, 0.5f, 0.5f, 0.5f, -0.5f, 0.5f, 0, 0, 1};
+static const float kAT2[8] = {1, 1, 1, 0, 0, 1, -1, -1};
+static const float kBT4[36] = {4, 0, -5, 0, 1, 0, 0, -4, -4, 1, 1, 0, 0, 4, -4, -1, 1, 0,
+                               0, -2, -1, 2, 1, 0, 0, 2, -1, -2, 1, 0, 0, 4, 0, -5, 0, 1};
+static const float kG4[18] = {1.f / 4, 0, 0, -1.f / 6, -1.f / 6, -1.f / 6, -1.f / 6, 1.f / 6, -1.f / 6,
+                              1.f / 24, 1.f / 12, 1.f / 6, 1.f / 24, -1.f / 12, 1.f / 6, 0, 0, 1};
+static const float kAT4[24] = {1, 1, 1, 1, 1, 0, 0, 1, -1, 2, -2, 0, 0, 1, 1, 4, 4, 0, 0, 1, -1, 8, -8, 1};
+static WinoMats wino_mats(int m) {
+  if (m == 2) return {2, 4, kBT2, kG2, kAT2};
+  if (m == 4) return {4, 6, kBT4, kG4, kAT4};
+  throw Error(1, "winograd: output tile size must be 2 or 4");
+}
+void wino_input_transform(Stream&, int m, const TView& x, int pad, int pad_mode, int Th, int Tw, float* V) {
+  const WinoMats wm = wino_mats(m);
+  const int A = wm.A;
   const size_t T = (size_t)x.N * Th * Tw;
   for (int n = 0; n < x.N; ++n) for (int ty = 0; ty < Th; ++ty) for (int tx = 0; tx < Tw; ++tx) {
     const size_t tile = ((size_t)n * Th + ty) * Tw + tx;
     for (int c = 0; c < x.C; ++c) {
-      float d[4][4], t[4][4];
-      for (int a = 0; a < 4; ++a) for (int b = 0; b < 4; ++b) {
-        const int sy = srcc(2 * ty - pad + a, x.H, pad_mode, 0), sx = srcc(2 * tx - pad + b, x.W, pad_mode, 0);
+      float d[6][6], t[6][6];
+      for (int a = 0; a < A; ++a) for (int b = 0; b < A; ++b) {
+        const int sy = srcc(m * ty - pad + a, x.H, pad_mode, 0), sx = srcc(m * tx - pad + b, x.W, pad_mode, 0);
         d[a][b] = (sy >= 0 && sx >= 0) ? at(x, n, sy, sx)[c] : 0.f;
       }
-      for (int a = 0; a < 4; ++a) for (int b = 0; b < 4; ++b) { float s = 0; for (int k = 0; k < 4; ++k) s += kBT[a][k] * d[k][b]; t[a][b] = s; }
-      for (int a = 0; a < 4; ++a) for (int b = 0; b < 4; ++b) { float s = 0; for (int k = 0; k < 4; ++k) s += t[a][k] * kBT[b][k];
-        V[((size_t)(a * 4 + b) * T + tile) * x.C + c] = s; }
+      for (int a = 0; a < A; ++a) for (int b = 0; b < A; ++b) { float s = 0; for (int k = 0; k < A; ++k) s += wm.BT[a * A + k] * d[k][b]; t[a][b] = s; }
+      for (int a = 0; a < A; ++a) for (int b = 0; b < A; ++b) { float s = 0; for (int k = 0; k < A; ++k) s += t[a][k] * wm.BT[b * A + k];
+        V[((size_t)(a * A + b) * T + tile) * x.C + c] = s; }
     }
   }
 }
-void wino_filter_transform(Stream&, const WShape& w, int mode, const float* packed, float* U) {
+void wino_filter_transform(Stream&, int m, const WShape& w, int mode, const float* packed, float* U) {
+  const WinoMats wm = wino_mats(m);
+  const int A = wm.A;
   const int K = mode == 0 ? w.Cip : w.Npad, Nn = mode == 0 ? w.Npad : w.Cip;
   const size_t total = (size_t)K * Nn;
   for (int k = 0; k < K; ++k) for (int n = 0; n < Nn; ++n) {
-    float g[3][3], t[4][3];
+    float g[3][3], t[6][3];
     for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b)
       g[a][b] = mode == 0 ? packed[((size_t)(a * 3 + b) * w.Cip + k) * w.Npad + n]
                           : packed[((size_t)((2 - a) * 3 + (2 - b)) * w.Cip + n) * w.Npad + k];
-    for (int a = 0; a < 4; ++a) for (int b = 0; b < 3; ++b) { float s = 0; for (int q = 0; q < 3; ++q) s += kG[a][q] * g[q][b]; t[a][b] = s; }
-    for (int a = 0; a < 4; ++a) for (int b = 0; b < 4; ++b) { float s = 0; for (int q = 0; q < 3; ++q) s += t[a][q] * kG[b][q];
-      U[(size_t)(a * 4 + b) * total + (size_t)k * Nn + n] = s; }
+    for (int a = 0; a < A; ++a) for (int b = 0; b < 3; ++b) { float s = 0; for (int q = 0; q < 3; ++q) s += wm.G[a * 3 + q] * g[q][b]; t[a][b] = s; }
+    for (int a = 0; a < A; ++a) for (int b = 0; b < A; ++b) { float s = 0; for (int q = 0; q < 3; ++q) s += t[a][q] * wm.G[b * 3 + q];
+      U[(size_t)(a * A + b) * total + (size_t)k * Nn + n] = s; }
   }
 }
-void wino_output_transform(Stream&, const float* M, int Cm, int Th, int Tw, const float* bias, int act, const TView& y,
-                           int Cout, int accumulate) {
+void wino_output_transform(Stream&, int m, const float* M, int Cm, int Th, int Tw, const float* bias, int act,
+                           const TView& y, int Cout, int accumulate) {
+  const WinoMats wm = wino_mats(m);
+  const int A = wm.A;
   const size_t T = (size_t)y.N * Th * Tw;
   for (int n = 0; n < y.N; ++n) for (int ty = 0; ty < Th; ++ty) for (int tx = 0; tx < Tw; ++tx) {
     const size_t tile = ((size_t)n * Th + ty) * Tw + tx;
     for (int c = 0; c < Cout; ++c) {
-      float m[4][4], s2[2][4];
-      for (int a = 0; a < 4; ++a) for (int b = 0; b < 4; ++b) m[a][b] = M[((size_t)(a * 4 + b) * T + tile) * Cm + c];
-      for (int a = 0; a < 2; ++a) for (int b = 0; b < 4; ++b) { float s = 0; for (int q = 0; q < 4; ++q) s += kAT[a][q] * m[q][b]; s2[a][b] = s; }
-      for (int a = 0; a < 2; ++a) for (int b = 0; b < 2; ++b) {
-        const int oy = 2 * ty + a, ox = 2 * tx + b;
+      float mm[6][6], s2[4][6];
+      for (int a = 0; a < A; ++a) for (int b = 0; b < A; ++b) mm[a][b] = M[((size_t)(a * A + b) * T + tile) * Cm + c];
+      for (int a = 0; a < m; ++a) for (int b = 0; b < A; ++b) { float s = 0; for (int q = 0; q < A; ++q) s += wm.AT[a * A + q] * mm[q][b]; s2[a][b] = s; }
+      for (int a = 0; a < m; ++a) for (int b = 0; b < m; ++b) {
+        const int oy = m * ty + a, ox = m * tx + b;
         if (oy >= y.H || ox >= y.W) continue;
-        float s = 0; for (int q = 0; q < 4; ++q) s += s2[a][q] * kAT[b][q];
+        float s = 0; for (int q = 0; q < A; ++q) s += s2[a][q] * wm.AT[b * A + q];
         if (bias) s += bias[c];
         s = actf(s, act);
         float* d = at(y, n, oy, ox) + c;
@@ -186,30 +204,34 @@ void wino_output_transform(Stream&, const float* M, int Cm, int Th, int Tw, cons
     }
   }
 }
-void wino_dy_transform(Stream&, const TView& dy, int Th, int Tw, float* dM) {
+void wino_dy_transform(Stream&, int m, const TView& dy, int Th, int Tw, float* dM) {
+  const WinoMats wm = wino_mats(m);
+  const int A = wm.A;
   const size_t T = (size_t)dy.N * Th * Tw;
   for (int n = 0; n < dy.N; ++n) for (int ty = 0; ty < Th; ++ty) for (int tx = 0; tx < Tw; ++tx) {
     const size_t tile = ((size_t)n * Th + ty) * Tw + tx;
     for (int c = 0; c < dy.C; ++c) {
-      float g[2][2];
-      for (int a = 0; a < 2; ++a) for (int b = 0; b < 2; ++b) {
-        const int oy = 2 * ty + a, ox = 2 * tx + b;
+      float g[4][4];
+      for (int a = 0; a < m; ++a) for (int b = 0; b < m; ++b) {
+        const int oy = m * ty + a, ox = m * tx + b;
         g[a][b] = (oy < dy.H && ox < dy.W) ? at(dy, n, oy, ox)[c] : 0.f;
       }
-      for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) {     // dM = A g A^T, A = kAT^T
+      for (int i = 0; i < A; ++i) for (int j = 0; j < A; ++j) {     // dM = A g A^T, A = AT^T
         float s = 0;
-        for (int a = 0; a < 2; ++a) for (int b = 0; b < 2; ++b) s += kAT[a][i] * g[a][b] * kAT[b][j];
-        dM[((size_t)(i * 4 + j) * T + tile) * dy.C + c] = s;
+        for (int a = 0; a < m; ++a) for (int b = 0; b < m; ++b) s += wm.AT[a * A + i] * g[a][b] * wm.AT[b * A + j];
+        dM[((size_t)(i * A + j) * T + tile) * dy.C + c] = s;
       }
     }
   }
 }
-void wino_filter_grad(Stream&, const WShape& w, const float* dU, float* dpacked) {
+void wino_filter_grad(Stream&, int m, const WShape& w, const float* dU, float* dpacked) {
+  const WinoMats wm = wino_mats(m);
+  const int A = wm.A;
   const size_t total = (size_t)w.Cip * w.Npad;
   for (size_t i = 0; i < total; ++i)
     for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) {       // dg = G^T dU G
       float s = 0;
-      for (int p = 0; p < 4; ++p) for (int q = 0; q < 4; ++q) s += kG[p][a] * dU[(size_t)(p * 4 + q) * total + i] * kG[q][b];
+      for (int p = 0; p < A; ++p) for (int q = 0; q < A; ++q) s += wm.G[p * 3 + a] * dU[(size_t)(p * A + q) * total + i] * wm.G[q * 3 + b];
       dpacked[(size_t)(a * 3 + b) * total + i] = s;
     }
 }

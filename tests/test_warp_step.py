@@ -265,3 +265,35 @@ def test_non_square_warp_forward(backend, oracle_run):
     assert m.output().shape == (1, 19, 64, 128)
     assert rel(m.output(), ref) < 1e-3
     m.close()
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("variant", ["winograd_f2x2", "direct"])
+def test_resblock_conv_variants_match_oracle(backend, variant, oracle_run, monkeypatch):
+    """The 3x3 ResidualBlock convs run as Winograd F(4x4,3x3) by default (the shared models of the
+    tests above).  The F(2x2,3x3) path (H or W not a multiple of 4) and the direct implicit-GEMM path
+    (small channel counts) must give the same step: forward, D and G gradients vs the oracle."""
+    if variant == "direct":
+        monkeypatch.setenv("SWN_WINOGRAD", "0")
+    else:
+        monkeypatch.setenv("SWN_WINO_M", "2")
+    G, D, batch, _, steps = oracle_run
+    ctx = _ctx(backend)
+    B, H = batch[0].shape[0], batch[0].shape[2]
+    m = engine.NativeModel(ctx, "warp", B, H, H)
+    try:
+        backends.reset_state(m, {engine.NET_G: G, engine.NET_D: D})
+        for i, t in enumerate(batch):
+            m.set_input(i, t)
+        s = steps[0]
+        m.forward(False, 0)
+        assert rel(m.output(), s["fakes"]) < 1e-3
+        m.backward_D(s["labels"][0], s["labels"][1])
+        m.optimizer_step(engine.NET_D)
+        m.backward_G(s["labels"][2])
+        gG = m.state_dict(engine.NET_G, which=engine.W_GRAD, to_cpu=True)
+        for k, v in s["gG"].items():
+            if not noise_bias(k):
+                assert rel(gG[k], v) < 1e-2, (variant, k, rel(gG[k], v))
+    finally:
+        m.close()
