@@ -43,7 +43,15 @@ struct GemmP {
   int splits; int per_split; float* slab;
   int tiles_n; int ntiles;
   size_t x_bs, w_bs, y_bs, slab_bs;   // batched mode (blockIdx.z)
+  int phases;                         // sub-pixel phase mode: blockIdx.z = 2a + b shifts pads / output offsets
 };
+
+__device__ __forceinline__ void apply_phase(GemmP& p) {
+  if (p.phases) {
+    const int a = blockIdx.z >> 1, b = blockIdx.z & 1;
+    p.pad_t -= a; p.pad_l -= b; p.yoff = a; p.xoff = b;
+  }
+}
 
 __device__ __forceinline__ int src_coord(int e, int ext, int pad_mode, int ups) {
   if (pad_mode == PAD_REFLECT) {
@@ -101,6 +109,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_fwd_kernel(GemmP p) {
   const int split = blockIdx.y;
   p.x += (size_t)blockIdx.z * p.x_bs; p.w += (size_t)blockIdx.z * p.w_bs;
   p.y += (size_t)blockIdx.z * p.y_bs; p.slab += (size_t)blockIdx.z * p.slab_bs;
+  apply_phase(p);
 
   const int q = t & 7, p0 = t >> 3;
   int a_iy0[RA], a_ix0[RA], a_base[RA];
@@ -266,6 +275,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_fwd_kernel(GemmP p) {
 // sums the K-split slabs in fixed order and applies the epilogue
 __global__ void conv_fwd_reduce_kernel(GemmP p) {
   p.y += (size_t)blockIdx.z * p.y_bs; p.slab += (size_t)blockIdx.z * p.slab_bs;
+  apply_phase(p);
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t total = (size_t)p.M * p.Cout;
   if (i >= total) return;
@@ -304,6 +314,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(GemmP p) {
   const int split = blockIdx.y;
   p.x += (size_t)blockIdx.z * p.x_bs; p.y += (size_t)blockIdx.z * p.y_bs;
   p.w += (size_t)blockIdx.z * p.w_bs; p.slab += (size_t)blockIdx.z * p.slab_bs;
+  apply_phase(p);
 
   // this thread's k (fixed for the whole kernel)
   const int acol = (t % (BM / 4)) * 4, arow0 = t / (BM / 4);
@@ -545,7 +556,11 @@ int prof_report(char* buf, int len) {
 // ---------------------------------------------------------------------------------------
 // host launchers
 // ---------------------------------------------------------------------------------------
-static GemmP make_params(const TView& x, const Gather& g, const TView& y, const OutMap& om) {
+static GemmP make_params(const TView& x, const Gather& g, const TView& y, OutMap om, int phases = 0, int batch = 1) {
+  if (phases) {
+    if (phases != 4 || batch > 1 || om.ymul != 2 || om.xmul != 2) throw Error(1, "conv: bad sub-pixel phase launch");
+    om.yoff = om.xoff = 1;               // bounds check below against the farthest phase
+  }
   if (x.C % 4 || x.cs % 4 || y.cs % 4) throw Error(1, "conv: channel counts/strides must be multiples of 4");
   if (((uintptr_t)x.p & 15) || ((uintptr_t)y.p & 15)) throw Error(1, "conv: views must be 16-byte aligned");
   GemmP p{};
@@ -557,6 +572,8 @@ static GemmP make_params(const TView& x, const Gather& g, const TView& y, const 
   p.y = y.p; p.yH = y.H; p.yW = y.W; p.ycs = y.cs; p.yC = y.C;
   p.ymul = om.ymul; p.yoff = om.yoff; p.xmul = om.xmul; p.xoff = om.xoff;
   p.splits = 1; p.per_split = 1 << 30;
+  p.phases = phases;
+  if (phases) p.yoff = p.xoff = 0;
   if ((g.Ho - 1) * om.ymul + om.yoff >= y.H || (g.Wo - 1) * om.xmul + om.xoff >= y.W || y.N != x.N)
     throw Error(1, "conv: output map exceeds the output view");
   return p;
@@ -640,14 +657,14 @@ void conv_force_naive(int on) { g_force_naive = on; }
 
 void conv_fwd(Stream& s, const ConvFwdArgs& a) {
   if (g_force_naive) { conv_fwd_naive(s, a); return; }
-  GemmP p = make_params(a.x, a.g, a.y, a.om);
+  GemmP p = make_params(a.x, a.g, a.y, a.om, a.phases, a.batch);
   p.w = a.w; p.Npad = a.Npad; p.bias = a.bias; p.act = a.act; p.accumulate = a.accumulate; p.Cout = a.Cout;
   if (a.Npad % 4 || a.Cout > a.Npad) throw Error(1, "conv_fwd: bad Npad/Cout");
   if (a.accumulate && a.act != ACT_NONE) throw Error(1, "conv_fwd: accumulate with activation");
   const bool fast = (a.x.C % 32) == 0;
   static const int big = getenv("SWN_TILE256") ? atoi(getenv("SWN_TILE256")) : 1;
   p.x_bs = a.x_bs; p.w_bs = a.w_bs; p.y_bs = a.y_bs;
-  const int nb = std::max(a.batch, 1);
+  const int nb = a.phases ? a.phases : std::max(a.batch, 1);
   if (a.Npad > 64 && big && fast && p.M >= 2048) launch_fwd<2, 2, 4, 2>(s, p, fast, nb);
   else if (a.Npad > 64) launch_fwd<2, 2, 2, 2>(s, p, fast, nb);
   else if (a.Npad > 32) launch_fwd<2, 1, 2, 2>(s, p, fast, nb);
@@ -688,22 +705,29 @@ static void launch_wgrad(Stream& s, GemmP& p, int batch) {
 
 void conv_wgrad(Stream& s, const ConvWgradArgs& a) {
   if (g_force_naive) { conv_wgrad_naive(s, a); return; }
-  GemmP p = make_params(a.x, a.g, a.dy, a.om);
+  GemmP p = make_params(a.x, a.g, a.dy, a.om, a.phases, a.batch);
   p.w = a.dw; p.Npad = a.Npad; p.Cout = a.Cout;
   if (a.Npad % 4 || a.Cout > a.Npad || a.dy.C % 4) throw Error(1, "conv_wgrad: bad Npad/Cout");
   p.x_bs = a.x_bs; p.y_bs = a.dy_bs; p.w_bs = a.dw_bs;
-  const int nb = std::max(a.batch, 1);
+  const int nb = a.phases ? a.phases : std::max(a.batch, 1);
   if (a.Npad > 64) launch_wgrad<2, 2, 2, 2>(s, p, nb);
   else if (a.Npad > 32) launch_wgrad<2, 1, 2, 2>(s, p, nb);
   else launch_wgrad<1, 1, 4, 1>(s, p, nb);
 }
 
+static void host_phase(GemmP& q, int ph) {
+  if (!q.phases) return;
+  q.pad_t -= ph >> 1; q.pad_l -= ph & 1; q.yoff = ph >> 1; q.xoff = ph & 1;
+  q.phases = 0;
+}
+
 void conv_fwd_naive(Stream& s, const ConvFwdArgs& a) {
-  GemmP p = make_params(a.x, a.g, a.y, a.om);
+  GemmP p = make_params(a.x, a.g, a.y, a.om, a.phases, a.batch);
   p.w = a.w; p.Npad = a.Npad; p.bias = a.bias; p.act = a.act; p.accumulate = a.accumulate; p.Cout = a.Cout;
   const size_t total = (size_t)p.M * p.Cout;
-  for (int b = 0; b < std::max(a.batch, 1); ++b) {
+  for (int b = 0; b < (a.phases ? a.phases : std::max(a.batch, 1)); ++b) {
     GemmP q = p;
+    host_phase(q, b);
     q.x += (size_t)b * a.x_bs; q.w += (size_t)b * a.w_bs; q.y += (size_t)b * a.y_bs;
     hipLaunchKernelGGL(conv_fwd_naive_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, hs(s), q);
   }
@@ -711,11 +735,12 @@ void conv_fwd_naive(Stream& s, const ConvFwdArgs& a) {
 }
 
 void conv_wgrad_naive(Stream& s, const ConvWgradArgs& a) {
-  GemmP p = make_params(a.x, a.g, a.dy, a.om);
+  GemmP p = make_params(a.x, a.g, a.dy, a.om, a.phases, a.batch);
   p.w = a.dw; p.Npad = a.Npad; p.Cout = a.Cout;
   const size_t total = (size_t)p.K * p.Npad;
-  for (int b = 0; b < std::max(a.batch, 1); ++b) {
+  for (int b = 0; b < (a.phases ? a.phases : std::max(a.batch, 1)); ++b) {
     GemmP q = p;
+    host_phase(q, b);
     q.x += (size_t)b * a.x_bs; q.y += (size_t)b * a.dy_bs; q.w += (size_t)b * a.dw_bs;
     hipLaunchKernelGGL(conv_wgrad_naive_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, hs(s), q);
   }

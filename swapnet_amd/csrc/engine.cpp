@@ -329,15 +329,13 @@ void Net::conv(const std::string& name, const Var& x, const Var& y, ConvKind kin
       return;
     }
     if (kind == CK_K4S2) {
-      for (int ph = 0; ph < 4; ++ph) {
-        const int a = ph >> 1, b = ph & 1;
-        ConvFwdArgs d;
-        d.x = dY; d.g.KH = d.g.KW = 2; d.g.stride = 1; d.g.pad_t = 1 - a; d.g.pad_l = 1 - b;
-        d.g.Ho = dY.H; d.g.Wo = dY.W;
-        d.w = n.dg + dg_off + (size_t)ph * 4 * Cop * Ndg; d.Npad = Ndg;
-        d.y = xgv; d.om.ymul = 2; d.om.yoff = a; d.om.xmul = 2; d.om.xoff = b; d.Cout = Ndg; d.accumulate = accf;
-        conv_fwd(n.ctx.s, d);
-      }
+      // four sub-pixel phases of the transposed conv (2x2 taps each) in one launch
+      ConvFwdArgs d;
+      d.x = dY; d.g.KH = d.g.KW = 2; d.g.stride = 1; d.g.pad_t = 1; d.g.pad_l = 1;
+      d.g.Ho = dY.H; d.g.Wo = dY.W;
+      d.w = n.dg + dg_off; d.w_bs = (size_t)4 * Cop * Ndg; d.Npad = Ndg;
+      d.y = xgv; d.om.ymul = 2; d.om.xmul = 2; d.phases = 4; d.Cout = Ndg; d.accumulate = accf;
+      conv_fwd(n.ctx.s, d);
     } else {
       ConvFwdArgs d;
       d.x = dY; d.g = gd; d.w = n.dg + dg_off; d.Npad = Ndg; d.Cout = Ndg;
@@ -370,15 +368,12 @@ void Net::convT(const std::string& name, const Var& x, const Var& y, int Co, boo
   const size_t phase_elems = (size_t)4 * Cip * round_up(Co, 4);
   op->fwd = [=](Net& n) {
     const ParamDesc& wd = A->params[wi];
-    for (int ph = 0; ph < 4; ++ph) {
-      const int a = ph >> 1, b = ph & 1;
-      ConvFwdArgs f;
-      f.x = xv; f.g.KH = f.g.KW = 2; f.g.stride = 1; f.g.pad_t = 1 - a; f.g.pad_l = 1 - b; f.g.Ho = xv.H; f.g.Wo = xv.W;
-      f.w = A->w + wd.off + ph * phase_elems; f.Npad = wd.ws.Npad;
-      f.bias = bi >= 0 ? A->w + A->params[bi].off : nullptr;
-      f.y = yv; f.om.ymul = 2; f.om.yoff = a; f.om.xmul = 2; f.om.xoff = b; f.Cout = Co;
-      conv_fwd(n.ctx.s, f);
-    }
+    ConvFwdArgs f;                          // 4 sub-pixel phases (2x2 taps each), one launch
+    f.x = xv; f.g.KH = f.g.KW = 2; f.g.stride = 1; f.g.pad_t = 1; f.g.pad_l = 1; f.g.Ho = xv.H; f.g.Wo = xv.W;
+    f.w = A->w + wd.off; f.w_bs = phase_elems; f.Npad = wd.ws.Npad;
+    f.bias = bi >= 0 ? A->w + A->params[bi].off : nullptr;
+    f.y = yv; f.om.ymul = 2; f.om.xmul = 2; f.phases = 4; f.Cout = Co;
+    conv_fwd(n.ctx.s, f);
   };
   const bool want_dx = x.has_grad && y.has_grad;
   size_t dg_off = 0;
@@ -395,15 +390,12 @@ void Net::convT(const std::string& name, const Var& x, const Var& y, int Co, boo
     if (!has_ygrad) return;
     const ParamDesc& wd = A->params[wi];
     if (wgrad) {
-      for (int ph = 0; ph < 4; ++ph) {
-        const int a = ph >> 1, b = ph & 1;
-        ConvWgradArgs wa;
-        wa.x = xv; wa.g.KH = wa.g.KW = 2; wa.g.stride = 1; wa.g.pad_t = 1 - a; wa.g.pad_l = 1 - b;
-        wa.g.Ho = xv.H; wa.g.Wo = xv.W;
-        wa.dy = ygv; wa.om.ymul = 2; wa.om.yoff = a; wa.om.xmul = 2; wa.om.xoff = b;
-        wa.dw = A->g + wd.off + ph * phase_elems; wa.Npad = wd.ws.Npad; wa.Cout = Co;
-        conv_wgrad(n.ctx.s, wa);
-      }
+      ConvWgradArgs wa;
+      wa.x = xv; wa.g.KH = wa.g.KW = 2; wa.g.stride = 1; wa.g.pad_t = 1; wa.g.pad_l = 1;
+      wa.g.Ho = xv.H; wa.g.Wo = xv.W;
+      wa.dy = ygv; wa.om.ymul = 2; wa.om.xmul = 2; wa.phases = 4;
+      wa.dw = A->g + wd.off; wa.dw_bs = phase_elems; wa.Npad = wd.ws.Npad; wa.Cout = Co;
+      conv_wgrad(n.ctx.s, wa);
       if (bi >= 0) bias_grad(n.ctx.s, ygv, A->g + A->params[bi].off);
     }
     if (!want_dx || (me.reads_net_input && !igrad)) return;

@@ -53,6 +53,11 @@ struct ConvFwdArgs {
   // batched mode (Winograd: 16 independent GEMMs in one launch): element strides between batches
   int batch = 1;
   size_t x_bs = 0, w_bs = 0, y_bs = 0;
+  // sub-pixel phase mode (k4s2 transposed convs and the dgrad of k4s2 convs): with phases = 4 one
+  // launch covers the four phases ph = 2a + b of a stride-2 scatter: phase ph gathers with
+  // pad_t = g.pad_t - a, pad_l = g.pad_l - b, writes outputs (2oy + a, 2ox + b) (om.ymul = om.xmul = 2)
+  // and uses the weight panel w + ph * w_bs.  Excludes batch > 1.
+  int phases = 0;
 };
 void conv_fwd(Stream& s, const ConvFwdArgs& a);
 
@@ -67,6 +72,7 @@ struct ConvWgradArgs {
   int Cout = 0;
   int batch = 1;
   size_t x_bs = 0, dy_bs = 0, dw_bs = 0;
+  int phases = 0;             // as in ConvFwdArgs; phase ph reads dy at (2oy + a, 2ox + b), writes dw + ph * dw_bs
 };
 void conv_wgrad(Stream& s, const ConvWgradArgs& a);
 

@@ -88,9 +88,17 @@ static void conv_fwd_one(const ConvFwdArgs& a) {
     }
   }
 }
+template <class Args>
+static void take_phase(Args& c, int ph) {      // sub-pixel phase mode (ops.h)
+  if (!c.phases) return;
+  if (c.phases != 4 || c.batch > 1 || c.om.ymul != 2 || c.om.xmul != 2) throw Error(1, "conv: bad sub-pixel phase launch");
+  c.g.pad_t -= ph >> 1; c.g.pad_l -= ph & 1; c.om.yoff = ph >> 1; c.om.xoff = ph & 1;
+  c.phases = 0;
+}
 void conv_fwd(Stream&, const ConvFwdArgs& a) {
-  for (int b = 0; b < (a.batch > 0 ? a.batch : 1); ++b) {
+  for (int b = 0; b < (a.phases ? a.phases : (a.batch > 0 ? a.batch : 1)); ++b) {
     ConvFwdArgs c = a;
+    take_phase(c, b);
     c.x.p = a.x.p + b * a.x_bs; c.w = a.w + b * a.w_bs; c.y.p = a.y.p + b * a.y_bs;
     conv_fwd_one(c);
   }
@@ -125,8 +133,9 @@ static void conv_wgrad_one(const ConvWgradArgs& a) {
     }
 }
 void conv_wgrad(Stream&, const ConvWgradArgs& a) {
-  for (int b = 0; b < (a.batch > 0 ? a.batch : 1); ++b) {
+  for (int b = 0; b < (a.phases ? a.phases : (a.batch > 0 ? a.batch : 1)); ++b) {
     ConvWgradArgs c = a;
+    take_phase(c, b);
     c.x.p = a.x.p + b * a.x_bs; c.dy.p = a.dy.p + b * a.dy_bs; c.dw = a.dw + b * a.dw_bs;
     conv_wgrad_one(c);
   }
