@@ -272,6 +272,186 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_fwd_kernel(GemmP p) {
   }
 }
 
+
+// ---------------------------------------------------------------------------------------
+// narrow-N forward-type kernel (Cout <= 32: the 19-channel tail conv, PatchGAN's 1-channel
+// prediction conv, dgrads into few-channel inputs).  The 32-wide MFMA tile wastes 13/32 of
+// the matrix pipe at N = 19; v_mfma_f32_4x4x1 (16 independent 4x4 blocks per wave, same
+// FLOP rate) has a 4-column granularity instead: each LANE owns one output pixel (B operand
+// = its im2col value), the weights W[k][4g..4g+3] sit in lanes 4g..4g+3 of one VGPR and are
+// broadcast to all 16 blocks (cbsz = 4, abid = g), and the result is, per lane, a float4 of
+// 4 consecutive output channels of its pixel -- a 16-byte NHWC store.  Layout verified by
+// tools/mfma_probe.hip.
+// ---------------------------------------------------------------------------------------
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <int G, int NG>
+struct NarrowMac {
+  static __device__ __forceinline__ void run(f32x4* acc, float w, float x) {
+    acc[G] = __builtin_amdgcn_mfma_f32_4x4x1f32(w, x, acc[G], 4, G, 0);
+    NarrowMac<G + 1, NG>::run(acc, w, x);
+  }
+};
+template <int NG>
+struct NarrowMac<NG, NG> {
+  static __device__ __forceinline__ void run(f32x4*, float, float) {}
+};
+
+struct NarrowTile {
+  static constexpr int BM = 256, BK = 16, AS = BK + 4;      // 20*l mod 64 distinct for 16 lanes (b128)
+  static constexpr int A_FLOATS = BM * AS, B_FLOATS = 32 * AS;
+  static constexpr int SMEM = (2 * A_FLOATS + 2 * B_FLOATS) * 4;
+};
+
+template <int NG, bool FAST>
+__global__ __launch_bounds__(256) void conv_fwd_narrow_kernel(GemmP p) {
+  using T = NarrowTile;
+  constexpr int AS = T::AS, RA = 4;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* As = smem;                       // [2][256 pixels][16 k]
+  float* Bt = smem + 2 * T::A_FLOATS;     // [2][32 n][16 k]   (weights, transposed)
+
+  const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
+  const int tile = xcd_swizzle(blockIdx.x, p.ntiles);
+  const int m0 = tile * T::BM;
+  const int split = blockIdx.y;
+  p.x += (size_t)blockIdx.z * p.x_bs; p.w += (size_t)blockIdx.z * p.w_bs;
+  p.y += (size_t)blockIdx.z * p.y_bs; p.slab += (size_t)blockIdx.z * p.slab_bs;
+  apply_phase(p);
+
+  const int q = t & 3, p0 = t >> 2;       // 4 lanes x 16 B per tile row, 64 rows per pass
+  int a_iy0[RA], a_ix0[RA], a_base[RA];
+  const int HoWo = p.Ho * p.Wo;
+#pragma unroll
+  for (int r = 0; r < RA; ++r) {
+    const int m = m0 + p0 + 64 * r;
+    if (m < p.M) {
+      const int n = m / HoWo, rem = m - n * HoWo;
+      const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+      a_iy0[r] = oy * p.stride - p.pad_t;
+      a_ix0[r] = ox * p.stride - p.pad_l;
+      a_base[r] = n * p.xH * p.xW * p.xcs;
+    } else {
+      a_iy0[r] = 0; a_ix0[r] = 0; a_base[r] = -1;
+    }
+  }
+  const int bcol = (t & 7) * 4, brow = t >> 3;      // threads 0..127 move the 16 x 32 weight tile
+  const int He = p.xH << p.ups, We = p.xW << p.ups;
+
+  float4 ra[RA], rb;
+  auto load_tiles = [&](int kb) {
+    const int k0 = kb * 16;
+    int kh, kw, ci;
+    bool kvalid = true;
+    if (FAST) {
+      const int tap = k0 / p.xC;           // xC % 32 == 0: a 16-wide k block never straddles a tap
+      ci = k0 - tap * p.xC + 4 * q;
+      kh = tap / p.KW; kw = tap - kh * p.KW;
+    } else {
+      const int k = k0 + 4 * q;
+      kvalid = k < p.K;
+      const int tap = k / p.xC;
+      ci = k - tap * p.xC;
+      kh = tap / p.KW; kw = tap - kh * p.KW;
+    }
+#pragma unroll
+    for (int r = 0; r < RA; ++r) {
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (a_base[r] >= 0 && kvalid) {
+        const int sy = src_coord(a_iy0[r] + kh, He, p.pad_mode, p.ups);
+        const int sx = src_coord(a_ix0[r] + kw, We, p.pad_mode, p.ups);
+        if (sy >= 0 && sx >= 0)
+          v = *reinterpret_cast<const float4*>(p.x + (size_t)a_base[r] + (size_t)(sy * p.xW + sx) * p.xcs + ci);
+      }
+      ra[r] = v;
+    }
+    rb = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (t < 128 && k0 + brow < p.K && bcol < p.Npad)
+      rb = *reinterpret_cast<const float4*>(p.w + (size_t)(k0 + brow) * p.Npad + bcol);
+  };
+  auto store_tiles = [&](int buf) {
+    float* A = As + buf * T::A_FLOATS;
+#pragma unroll
+    for (int r = 0; r < RA; ++r) *reinterpret_cast<float4*>(A + (p0 + 64 * r) * AS + 4 * q) = ra[r];
+    if (t < 128) {
+      float* B = Bt + buf * T::B_FLOATS + bcol * AS + brow;
+      B[0] = rb.x; B[AS] = rb.y; B[2 * AS] = rb.z; B[3 * AS] = rb.w;
+    }
+  };
+
+  f32x4 acc[NG];
+#pragma unroll
+  for (int g = 0; g < NG; ++g) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  auto compute = [&](int buf) {
+    const float* A = As + buf * T::A_FLOATS + (wid * 64 + lane) * AS;      // this lane's pixel
+    const float* B = Bt + buf * T::B_FLOATS + (lane & 31) * AS;            // W[.][lane]
+    float xv[16], wv[16];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const float4 a = *reinterpret_cast<const float4*>(A + 4 * g);
+      const float4 b = *reinterpret_cast<const float4*>(B + 4 * g);
+      xv[4 * g] = a.x; xv[4 * g + 1] = a.y; xv[4 * g + 2] = a.z; xv[4 * g + 3] = a.w;
+      wv[4 * g] = b.x; wv[4 * g + 1] = b.y; wv[4 * g + 2] = b.z; wv[4 * g + 3] = b.w;
+    }
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) NarrowMac<0, NG>::run(acc, wv[kk], xv[kk]);
+  };
+
+  const int nkb = (p.K + 15) / 16;
+  const int kb_begin = split * p.per_split;
+  const int kb_end = min(nkb, kb_begin + p.per_split);
+  if (kb_begin < kb_end) {
+    load_tiles(kb_begin);
+    store_tiles(0);
+    __syncthreads();
+    int cur = 0;
+    for (int kb = kb_begin; kb < kb_end; ++kb) {
+      const bool more = kb + 1 < kb_end;
+      if (more) load_tiles(kb + 1);
+      compute(cur);
+      if (more) store_tiles(cur ^ 1);
+      __syncthreads();
+      cur ^= 1;
+    }
+  }
+
+  // ---- epilogue: one output pixel per lane
+  const int m = m0 + wid * 64 + lane;
+  if (m >= p.M) return;
+  if (p.splits > 1) {
+    float* dst = p.slab + ((size_t)split * p.M + m) * p.Npad;
+#pragma unroll
+    for (int g = 0; g < NG; ++g)
+      if (4 * g < p.Npad) *reinterpret_cast<float4*>(dst + 4 * g) = make_float4(acc[g][0], acc[g][1], acc[g][2], acc[g][3]);
+    return;
+  }
+  const int n = m / HoWo, rem = m - n * HoWo;
+  const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+  float* dst = p.y + (size_t)((n * p.yH + oy * p.ymul + p.yoff) * p.yW + ox * p.xmul + p.xoff) * p.ycs;
+#pragma unroll
+  for (int g = 0; g < NG; ++g) {
+    const int col = 4 * g;
+    if (col >= p.Cout) break;
+    float v[4] = {acc[g][0], acc[g][1], acc[g][2], acc[g][3]};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (p.bias && col + j < p.Cout) v[j] += p.bias[col + j];
+      v[j] = act_apply(v[j], p.act);
+    }
+    if (col + 3 < p.Cout) {
+      float4 o = make_float4(v[0], v[1], v[2], v[3]);
+      if (p.accumulate) {
+        const float4 old = *reinterpret_cast<const float4*>(dst + col);
+        o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w;
+      }
+      *reinterpret_cast<float4*>(dst + col) = o;
+    } else {
+      for (int j = 0; j < 4 && col + j < p.Cout; ++j) dst[col + j] = p.accumulate ? dst[col + j] + v[j] : v[j];
+    }
+  }
+}
+
 // sums the K-split slabs in fixed order and applies the epilogue
 __global__ void conv_fwd_reduce_kernel(GemmP p) {
   p.y += (size_t)blockIdx.z * p.y_bs; p.slab += (size_t)blockIdx.z * p.slab_bs;
@@ -295,7 +475,9 @@ __global__ void conv_fwd_reduce_kernel(GemmP p) {
 // ---------------------------------------------------------------------------------------
 // wgrad-type kernel: rows = k (BM of them), cols = co, reduction over pixels
 // ---------------------------------------------------------------------------------------
-template <int MT, int NT, int WGM, int WGN>
+// NG > 0: narrow-N variant (Tile<2,1,4,1>: 256 k-rows x <= 32 channels): one k-row per lane,
+// dY[m][4g..4g+3] broadcast from lanes 4g..4g+3, v_mfma_f32_4x4x1 as in conv_fwd_narrow_kernel.
+template <int MT, int NT, int WGM, int WGN, int NG = 0>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(GemmP p) {
   using T = Tile<MT, NT, WGM, WGN>;
   constexpr int BM = T::BM, BN = T::BN;
@@ -395,7 +577,21 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(GemmP p) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
+  f32x4 nacc[NG > 0 ? NG : 1];
+#pragma unroll
+  for (int g = 0; g < (NG > 0 ? NG : 1); ++g) nacc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+
   auto compute = [&](int buf) {
+    if constexpr (NG > 0) {
+      const float* A = As + buf * 32 * BM + wid * 64 + lane;     // im2col column k of this lane
+      const float* B = Bs + buf * 32 * BN + (lane & 31);         // dY[.][lane]
+      float xv[32], dv[32];
+#pragma unroll
+      for (int st = 0; st < 32; ++st) { xv[st] = A[st * BM]; dv[st] = B[st * BN]; }
+#pragma unroll
+      for (int st = 0; st < 32; ++st) NarrowMac<0, (NG > 0 ? NG : 1)>::run(nacc, dv[st], xv[st]);
+      return;
+    }
     const float* A = As + buf * 32 * BM + (lane >> 5) * BM + wm * MT * 32 + (lane & 31);
     const float* B = Bs + buf * 32 * BN + (lane >> 5) * BN + wn * NT * 32 + (lane & 31);
     float af[MT][16], bf[NT][16];
@@ -431,6 +627,16 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(GemmP p) {
     }
   }
   float* out = p.splits > 1 ? p.slab + (size_t)split * p.K * p.Npad : const_cast<float*>(p.w);
+  if constexpr (NG > 0) {
+    const int row = kt0 + wid * 64 + lane;
+    if (row < p.K) {
+#pragma unroll
+      for (int g = 0; g < NG; ++g)
+        if (4 * g < p.Npad)
+          *reinterpret_cast<float4*>(out + (size_t)row * p.Npad + 4 * g) = make_float4(nacc[g][0], nacc[g][1], nacc[g][2], nacc[g][3]);
+    }
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -652,6 +858,41 @@ static void launch_fwd(Stream& s, GemmP& p, bool fast, int batch) {
   }
 }
 
+template <int NG>
+static void launch_fwd_narrow(Stream& s, GemmP& p, bool fast, int batch) {
+  using T = NarrowTile;
+  p.tiles_n = 1;
+  p.ntiles = ceil_div(p.M, T::BM);
+  const int nkb = ceil_div(p.K, T::BK);
+  const int slots = 256 * 3;
+  const int splits = choose_splits(p.ntiles * batch, nkb, slots, 16, (size_t)p.M * p.Npad * 4 * batch, s.ws_bytes);
+  p.per_split = ceil_div(nkb, splits);
+  p.splits = ceil_div(nkb, p.per_split);
+  p.slab = reinterpret_cast<float*>(s.ws);
+  p.slab_bs = (size_t)p.M * p.Npad * p.splits;
+  dim3 grid(p.ntiles, p.splits, batch);
+  char pname[96];
+  if (prof_detail())
+    snprintf(pname, sizeof pname, "conv_fwd_narrow%d_%s[M%d,N%d,K%d,s%d]", 4 * NG, fast ? "fast" : "generic", p.M, p.Cout, p.K,
+             p.splits);
+  else
+    snprintf(pname, sizeof pname, "conv_fwd_narrow%d_%s", 4 * NG, fast ? "fast" : "generic");
+  ProfScope prof(s, pname, 2.0 * p.M * p.Cout * p.K * batch);
+  if (fast) hipLaunchKernelGGL((conv_fwd_narrow_kernel<NG, true>), grid, dim3(256), T::SMEM, hs(s), p);
+  else hipLaunchKernelGGL((conv_fwd_narrow_kernel<NG, false>), grid, dim3(256), T::SMEM, hs(s), p);
+  check_launch("conv_fwd_narrow");
+  if (p.splits > 1) {
+    const size_t total = (size_t)p.M * p.Cout;
+    hipLaunchKernelGGL(conv_fwd_reduce_kernel, dim3((unsigned)((total + 255) / 256), 1, batch), dim3(256), 0, hs(s), p);
+    check_launch("conv_fwd_reduce");
+  }
+}
+
+static bool narrow_on() {
+  static const bool on = !(getenv("SWN_NARROW") && atoi(getenv("SWN_NARROW")) == 0);
+  return on;
+}
+
 static int g_force_naive = 0;
 void conv_force_naive(int on) { g_force_naive = on; }
 
@@ -668,10 +909,16 @@ void conv_fwd(Stream& s, const ConvFwdArgs& a) {
   if (a.Npad > 64 && big && fast && p.M >= 2048) launch_fwd<2, 2, 4, 2>(s, p, fast, nb);
   else if (a.Npad > 64) launch_fwd<2, 2, 2, 2>(s, p, fast, nb);
   else if (a.Npad > 32) launch_fwd<2, 1, 2, 2>(s, p, fast, nb);
-  else launch_fwd<1, 1, 4, 1>(s, p, fast, nb);
+  else if (!narrow_on()) launch_fwd<1, 1, 4, 1>(s, p, fast, nb);
+  else if (a.Npad <= 4) launch_fwd_narrow<1>(s, p, fast, nb);
+  else if (a.Npad <= 8) launch_fwd_narrow<2>(s, p, fast, nb);
+  else if (a.Npad <= 16) launch_fwd_narrow<4>(s, p, fast, nb);
+  else if (a.Npad <= 20) launch_fwd_narrow<5>(s, p, fast, nb);
+  else if (a.Npad <= 24) launch_fwd_narrow<6>(s, p, fast, nb);
+  else launch_fwd_narrow<8>(s, p, fast, nb);
 }
 
-template <int MT, int NT, int WGM, int WGN>
+template <int MT, int NT, int WGM, int WGN, int NG = 0>
 static void launch_wgrad(Stream& s, GemmP& p, int batch) {
   using T = Tile<MT, NT, WGM, WGN>;
   const int tiles_k = ceil_div(p.K, T::BM);
@@ -684,15 +931,16 @@ static void launch_wgrad(Stream& s, GemmP& p, int batch) {
   p.splits = ceil_div(nmb, p.per_split);
   p.slab = reinterpret_cast<float*>(s.ws);
   p.slab_bs = (size_t)p.K * p.Npad * p.splits;
-  static bool once = (set_smem(conv_wgrad_kernel<MT, NT, WGM, WGN>, T::SMEM_WG), true);
+  static bool once = (set_smem(conv_wgrad_kernel<MT, NT, WGM, WGN, NG>, T::SMEM_WG), true);
   (void)once;
   char pname[96];
+  const int bn = NG > 0 ? 4 * NG : T::BN;
   if (prof_detail())
-    snprintf(pname, sizeof pname, "conv_wgrad_%dx%d[M%d,N%d,K%d,s%d]", T::BM, T::BN, p.M, p.Cout, p.K, p.splits);
+    snprintf(pname, sizeof pname, "conv_wgrad_%dx%d[M%d,N%d,K%d,s%d]", T::BM, bn, p.M, p.Cout, p.K, p.splits);
   else
-    snprintf(pname, sizeof pname, "conv_wgrad_%dx%d", T::BM, T::BN);
+    snprintf(pname, sizeof pname, "conv_wgrad_%dx%d", T::BM, bn);
   ProfScope prof(s, pname, 2.0 * p.M * p.Cout * p.K * batch);
-  hipLaunchKernelGGL((conv_wgrad_kernel<MT, NT, WGM, WGN>), dim3(p.ntiles, p.splits, batch), dim3(256), T::SMEM_WG, hs(s), p);
+  hipLaunchKernelGGL((conv_wgrad_kernel<MT, NT, WGM, WGN, NG>), dim3(p.ntiles, p.splits, batch), dim3(256), T::SMEM_WG, hs(s), p);
   check_launch("conv_wgrad");
   if (p.splits > 1) {
     const size_t n = (size_t)p.K * p.Npad;
@@ -712,6 +960,10 @@ void conv_wgrad(Stream& s, const ConvWgradArgs& a) {
   const int nb = a.phases ? a.phases : std::max(a.batch, 1);
   if (a.Npad > 64) launch_wgrad<2, 2, 2, 2>(s, p, nb);
   else if (a.Npad > 32) launch_wgrad<2, 1, 2, 2>(s, p, nb);
+  // narrow variant only where it measured faster (N <= 8: PatchGAN's 1-channel head); at N = 19 both
+  // forms are bound by the im2col load path (2 N FLOP per loaded float), not by the matrix pipe
+  else if (narrow_on() && a.Npad <= 4) launch_wgrad<2, 1, 4, 1, 1>(s, p, nb);
+  else if (narrow_on() && a.Npad <= 8) launch_wgrad<2, 1, 4, 1, 2>(s, p, nb);
   else launch_wgrad<1, 1, 4, 1>(s, p, nb);
 }
 
