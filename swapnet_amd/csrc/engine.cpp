@@ -175,23 +175,28 @@ void Net::conv(const std::string& name, const Var& x, const Var& y, ConvKind kin
     g.KH = 2 + a; g.KW = 2 + b; g.stride = 1; g.pad_t = 1; g.pad_l = 1; g.Ho = xv.H; g.Wo = xv.W;
     om.ymul = 2; om.yoff = a; om.xmul = 2; om.xoff = b;
   };
-  // 3x3 stride-1 convs with MFMA-friendly channel counts run as Winograd F(m x m,3x3): transform,
-  // (m+2)^2 batched GEMMs, inverse transform (wino.hip) -- 4x (m = 4, H and W multiples of 4) or
-  // 2.25x (m = 2) fewer multiplies than the direct form.
+  // Stride-1 convs with MFMA-friendly channel counts run as Winograd F(m x m, r x r): transform,
+  // (m+r-1)^2 batched GEMMs, inverse transform (wino.hip).  3x3: F(4x4,3x3) when H and W are
+  // multiples of 4 (4x fewer multiplies), else F(2x2,3x3) (2.25x); PatchGAN's k4 s1: F(3x3,4x4) (4x).
   const bool wino_on = !(getenv("SWN_WINOGRAD") && atoi(getenv("SWN_WINOGRAD")) == 0);
   // ... when the channel counts are large enough for the GEMMs (K = Cin each) to run at MFMA
   // speed and to amortise the HBM-bound transforms (measured on VGG16: a loss below 256 channels)
   const int wino_minc = getenv("SWN_WINO_MINC") ? atoi(getenv("SWN_WINO_MINC")) : 256;
   const int wino_force_m = getenv("SWN_WINO_M") ? atoi(getenv("SWN_WINO_M")) : 0;
-  const bool wino = wino_on && (kind == CK_K3S1_REFLECT || kind == CK_K3S1_ZERO) && Cip % 32 == 0 && Co % 32 == 0 &&
-                    Cip >= wino_minc && Co >= wino_minc && x.v.H % 2 == 0 && x.v.W % 2 == 0 && x.v.H >= 4 && x.v.W >= 4;
-  const int wm = (wino_force_m != 2 && x.v.H % 4 == 0 && x.v.W % 4 == 0) ? 4 : 2;
-  const int wP = (wm + 2) * (wm + 2);
-  const int wN = x.v.N, wTh = x.v.H / wm, wTw = x.v.W / wm;
+  const bool wino_k4 = !(getenv("SWN_WINO_K4") && atoi(getenv("SWN_WINO_K4")) == 0);
+  const bool is_k3 = kind == CK_K3S1_REFLECT || kind == CK_K3S1_ZERO;
+  const bool is_k4 = kind == CK_K4S1 && wino_k4;
+  const bool wino = wino_on && Cip % 32 == 0 && Co % 32 == 0 && Cip >= wino_minc && Co >= wino_minc && x.v.H >= 4 &&
+                    x.v.W >= 4 && ((is_k3 && x.v.H % 2 == 0 && x.v.W % 2 == 0) || is_k4);
+  const int wr = is_k4 ? 4 : 3;
+  const int wm = is_k4 ? 3 : ((wino_force_m != 2 && x.v.H % 4 == 0 && x.v.W % 4 == 0) ? 4 : 2);
+  const int wP = (wm + wr - 1) * (wm + wr - 1);
+  const int wN = x.v.N, wTh = ceil_div(y.v.H, wm), wTw = ceil_div(y.v.W, wm);
   const size_t wT = (size_t)wN * wTh * wTw;
-  const int wpad2 = kind == CK_K3S1_REFLECT ? 2 : 1;                       // dgrad: pad of the transposed conv
-  const int wTh2 = kind == CK_K3S1_REFLECT ? (x.v.H + 2 + wm - 1) / wm : wTh;
-  const int wTw2 = kind == CK_K3S1_REFLECT ? (x.v.W + 2 + wm - 1) / wm : wTw;
+  // dgrad = the transposed stride-1 conv over dY (pad r-1-p), producing the (reflect: padded) input grid
+  const int wpad2 = kind == CK_K3S1_ZERO ? 1 : 2;
+  const int wTh2 = ceil_div(x.v.H + (kind == CK_K3S1_REFLECT ? 2 : 0), wm);
+  const int wTw2 = ceil_div(x.v.W + (kind == CK_K3S1_REFLECT ? 2 : 0), wm);
   const size_t wT2 = (size_t)wN * wTh2 * wTw2;
   size_t uf_off = 0, ub_off = 0;
   if (wino) {
@@ -211,14 +216,14 @@ void Net::conv(const std::string& name, const Var& x, const Var& y, ConvKind kin
     a.act = actf; a.y = yv; a.Cout = Co;
     if (wino) {
       n.refresh_dgrad();
-      wino_input_transform(n.ctx.s, wm, xv, 1, gf.pad_mode, wTh, wTw, n.wsV);
+      wino_input_transform(n.ctx.s, wm, wr, xv, 1, gf.pad_mode, wTh, wTw, n.wsV);
       ConvFwdArgs g;
       g.x = plane_view(n.wsV, wT, Cip); g.g.Ho = 1; g.g.Wo = (int)wT;
       g.w = n.dg + uf_off; g.Npad = Cop; g.Cout = Co;
       g.y = plane_view(n.wsM, wT, Cop);
       g.batch = wP; g.x_bs = wT * Cip; g.w_bs = (size_t)Cip * Cop; g.y_bs = wT * Cop;
       conv_fwd(n.ctx.s, g);
-      wino_output_transform(n.ctx.s, wm, n.wsM, Cop, wTh, wTw, a.bias, actf, yv, Co, 0);
+      wino_output_transform(n.ctx.s, wm, wr, n.wsM, Cop, wTh, wTw, a.bias, actf, yv, Co, 0);
       return;
     }
     if (!folded) { conv_fwd(n.ctx.s, a); return; }
@@ -264,8 +269,8 @@ void Net::conv(const std::string& name, const Var& x, const Var& y, ConvKind kin
     const bool wdx = want_dx;
     op->repack = [=](Net& n) {
       const ParamDesc& wd = A->params[wi];
-      wino_filter_transform(n.ctx.s, wm, wd.ws, 0, A->w + wd.off, n.dg + uf_off);
-      if (wdx) wino_filter_transform(n.ctx.s, wm, wd.ws, 1, A->w + wd.off, n.dg + ub_off);
+      wino_filter_transform(n.ctx.s, wm, wr, wd.ws, 0, A->w + wd.off, n.dg + uf_off);
+      if (wdx) wino_filter_transform(n.ctx.s, wm, wr, wd.ws, 1, A->w + wd.off, n.dg + ub_off);
     };
   }
   if (folded) {
@@ -288,15 +293,15 @@ void Net::conv(const std::string& name, const Var& x, const Var& y, ConvKind kin
       wa.x = xv; wa.g = gf; wa.dy = dY; wa.dw = A->g + wd.off; wa.Npad = wd.ws.Npad; wa.Cout = Co;
       if (wino) {
         // dU[t] = V[t]^T dM[t] (wP batched reductions over the tiles), then dW = G^T dU G
-        wino_input_transform(n.ctx.s, wm, xv, 1, gf.pad_mode, wTh, wTw, n.wsV);
-        wino_dy_transform(n.ctx.s, wm, dY, wTh, wTw, n.wsM);
+        wino_input_transform(n.ctx.s, wm, wr, xv, 1, gf.pad_mode, wTh, wTw, n.wsV);
+        wino_dy_transform(n.ctx.s, wm, wr, dY, wTh, wTw, n.wsM);
         ConvWgradArgs g;
         g.x = plane_view(n.wsV, wT, Cip); g.g.Ho = 1; g.g.Wo = (int)wT;
         g.dy = plane_view(n.wsM, wT, Cop);
         g.dw = n.wsU; g.Npad = Cop; g.Cout = Co;
         g.batch = wP; g.x_bs = wT * Cip; g.dy_bs = wT * Cop; g.dw_bs = (size_t)Cip * Cop;
         conv_wgrad(n.ctx.s, g);
-        wino_filter_grad(n.ctx.s, wm, wd.ws, n.wsU, A->g + wd.off);
+        wino_filter_grad(n.ctx.s, wm, wr, wd.ws, n.wsU, A->g + wd.off);
       } else if (!folded) {
         conv_wgrad(n.ctx.s, wa);
       } else {
@@ -313,7 +318,7 @@ void Net::conv(const std::string& name, const Var& x, const Var& y, ConvKind kin
     const int accf = me.acc.empty() ? 0 : me.acc[0];
     if (wino) {
       // input gradient = the transposed 3x3 conv over dY (flipped, channel-transposed filter)
-      wino_input_transform(n.ctx.s, wm, dY, wpad2, PAD_ZERO, wTh2, wTw2, n.wsV);
+      wino_input_transform(n.ctx.s, wm, wr, dY, wpad2, PAD_ZERO, wTh2, wTw2, n.wsV);
       ConvFwdArgs g;
       g.x = plane_view(n.wsV, wT2, Cop); g.g.Ho = 1; g.g.Wo = (int)wT2;
       g.w = n.dg + ub_off; g.Npad = Cip; g.Cout = Cip;
@@ -321,10 +326,10 @@ void Net::conv(const std::string& name, const Var& x, const Var& y, ConvKind kin
       g.batch = wP; g.x_bs = wT2 * Cop; g.w_bs = (size_t)Cop * Cip; g.y_bs = wT2 * Cip;
       conv_fwd(n.ctx.s, g);
       if (kind == CK_K3S1_REFLECT) {
-        wino_output_transform(n.ctx.s, wm, n.wsM, Cip, wTh2, wTw2, nullptr, ACT_NONE, dxp, Cip, 0);
+        wino_output_transform(n.ctx.s, wm, wr, n.wsM, Cip, wTh2, wTw2, nullptr, ACT_NONE, dxp, Cip, 0);
         reflect_fold(n.ctx.s, dxp, xgv, accf);
       } else {
-        wino_output_transform(n.ctx.s, wm, n.wsM, Cip, wTh2, wTw2, nullptr, ACT_NONE, xgv, Cip, accf);
+        wino_output_transform(n.ctx.s, wm, wr, n.wsM, Cip, wTh2, wTw2, nullptr, ACT_NONE, xgv, Cip, accf);
       }
       return;
     }

@@ -88,16 +88,17 @@ void bias_grad(Stream& s, const TView& dy, float* db);
 // ReflectionPad2d(1) back onto the HxW tensor.
 void reflect_fold(Stream& s, const TView& dxpad, const TView& dx, int accumulate);
 
-// ---- Winograd F(m x m, 3x3) transforms, m = 2 or 4 (3x3 stride-1 convolutions; see wino.hip) ----
-// tile (n,ty,tx) covers outputs (m*ty..m*ty+m-1, m*tx..) and input rows m*ty-pad .. m*ty-pad+m+1;
-// P = (m+2)^2 transform planes (16 for F(2,3): 2.25x fewer multiplies; 36 for F(4,3): 4x fewer)
-void wino_input_transform(Stream& s, int m, const TView& x, int pad, int pad_mode, int Th, int Tw, float* V);   // V[P][T][x.C]
+// ---- Winograd F(m x m, r x r) transforms (stride-1 convolutions; see wino.hip) -------------------
+// supported (m, r): (2,3), (4,3) for the 3x3 convs, (3,4) for PatchGAN's k4 s1 conv.
+// tile (n,ty,tx) covers outputs (m*ty..m*ty+m-1, m*tx..) and input rows m*ty-pad .. m*ty-pad+m+r-2;
+// P = (m+r-1)^2 transform planes (16 for F(2,3): 2.25x fewer multiplies; 36 for F(4,3) / F(3,4): 4x fewer)
+void wino_input_transform(Stream& s, int m, int r, const TView& x, int pad, int pad_mode, int Th, int Tw, float* V);  // V[P][T][x.C]
 // mode 0: U[P][Cip][Npad] for the forward conv; mode 1: U[P][Npad][Cip] (flipped, transposed) for dgrad
-void wino_filter_transform(Stream& s, int m, const WShape& w, int mode, const float* packed, float* U);
-void wino_output_transform(Stream& s, int m, const float* M, int Cm, int Th, int Tw, const float* bias, int act,
+void wino_filter_transform(Stream& s, int m, int r, const WShape& w, int mode, const float* packed, float* U);
+void wino_output_transform(Stream& s, int m, int r, const float* M, int Cm, int Th, int Tw, const float* bias, int act,
                            const TView& y, int Cout, int accumulate);                                      // M[P][T][Cm]
-void wino_dy_transform(Stream& s, int m, const TView& dy, int Th, int Tw, float* dM);                      // dM[P][T][dy.C]
-void wino_filter_grad(Stream& s, int m, const WShape& w, const float* dU, float* dpacked);                 // dU[P][Cip][Npad]
+void wino_dy_transform(Stream& s, int m, int r, const TView& dy, int Th, int Tw, float* dM);               // dM[P][T][dy.C]
+void wino_filter_grad(Stream& s, int m, int r, const WShape& w, const float* dU, float* dpacked);          // dU[P][Cip][Npad]
 
 // ---- InstanceNorm / activation / dropout -------------------------------------------
 struct NormActArgs {

@@ -1,4 +1,4 @@
-// swapnet_amd -- Winograd F(2x2, 3x3) and F(4x4, 3x3) transforms for the 3x3 stride-1 convolutions
+// swapnet_amd -- Winograd F(2x2,3x3), F(4x4,3x3) and F(3x3,4x4) transforms for the stride-1 convolutions
 // (ResidualBlock convs, modules/layers.py:131-138 = 59 % of WarpModule's FLOPs; VGG16 convs of
 // PerceptualLoss, modules/losses/perceptual.py:26-42).
 //
@@ -236,7 +236,7 @@ __global__ __launch_bounds__(256) void wino_filter_grad_kernel(WShape w, const f
 // generic F(m x m, 3x3) transforms driven by constant matrices (instantiated for m = 4)
 // ---------------------------------------------------------------------------------------
 struct F43 {
-  static constexpr int M = 4, A = 6;
+  static constexpr int M = 4, R = 3, A = 6;
   static constexpr float BT[6][6] = {{4, 0, -5, 0, 1, 0},  {0, -4, -4, 1, 1, 0}, {0, 4, -4, -1, 1, 0},
                                      {0, -2, -1, 2, 1, 0}, {0, 2, -1, -2, 1, 0}, {0, 4, 0, -5, 0, 1}};
   static constexpr float G[6][3] = {{1.f / 4, 0, 0},
@@ -246,6 +246,21 @@ struct F43 {
                                     {1.f / 24, -1.f / 12, 1.f / 6},
                                     {0, 0, 1}};
   static constexpr float AT[4][6] = {{1, 1, 1, 1, 1, 0}, {0, 1, -1, 2, -2, 0}, {0, 1, 1, 4, 4, 0}, {0, 1, -1, 8, -8, 1}};
+};
+
+// F(3x3, 4x4): same interpolation points (same B^T), 36 multiplies per 3x3 outputs of a 4x4 filter
+// (4x fewer than direct) -- PatchGAN's k4 s1 conv (modules/discriminators.py:124-128)
+struct F34 {
+  static constexpr int M = 3, R = 4, A = 6;
+  static constexpr float BT[6][6] = {{4, 0, -5, 0, 1, 0},  {0, -4, -4, 1, 1, 0}, {0, 4, -4, -1, 1, 0},
+                                     {0, -2, -1, 2, 1, 0}, {0, 2, -1, -2, 1, 0}, {0, 4, 0, -5, 0, 1}};
+  static constexpr float G[6][4] = {{1.f / 4, 0, 0, 0},
+                                    {-1.f / 6, -1.f / 6, -1.f / 6, -1.f / 6},
+                                    {-1.f / 6, 1.f / 6, -1.f / 6, 1.f / 6},
+                                    {1.f / 24, 1.f / 12, 1.f / 6, 1.f / 3},
+                                    {1.f / 24, -1.f / 12, 1.f / 6, -1.f / 3},
+                                    {0, 0, 0, 1}};
+  static constexpr float AT[3][6] = {{1, 1, 1, 1, 1, 0}, {0, 1, -1, 2, -2, 0}, {0, 1, 1, 4, 4, 1}};
 };
 
 __device__ __forceinline__ void f4mac(float4& s, float c, const float4& x) {
@@ -304,32 +319,32 @@ __global__ __launch_bounds__(256) void winog_input_kernel(const float* x, int xc
 
 template <class F>
 __global__ __launch_bounds__(256) void winog_filter_kernel(WShape w, int mode, int K, int Nn, const float* packed, float* U) {
-  constexpr int A = F::A;
+  constexpr int A = F::A, R = F::R;
   const size_t total = (size_t)K * Nn;
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= total) return;
   const int k = (int)(i / Nn), n = (int)(i - (size_t)k * Nn);
-  float g[3][3];
+  float g[R][R];
 #pragma unroll
-  for (int a = 0; a < 3; ++a)
+  for (int a = 0; a < R; ++a)
 #pragma unroll
-    for (int b = 0; b < 3; ++b) {
+    for (int b = 0; b < R; ++b) {
       float v = 0.f;
       if (mode == 0) {
-        if (k < w.Cip && n < w.Npad) v = packed[((size_t)(a * 3 + b) * w.Cip + k) * w.Npad + n];
+        if (k < w.Cip && n < w.Npad) v = packed[((size_t)(a * R + b) * w.Cip + k) * w.Npad + n];
       } else {
-        if (n < w.Cip && k < w.Npad) v = packed[((size_t)((2 - a) * 3 + (2 - b)) * w.Cip + n) * w.Npad + k];
+        if (n < w.Cip && k < w.Npad) v = packed[((size_t)((R - 1 - a) * R + (R - 1 - b)) * w.Cip + n) * w.Npad + k];
       }
       g[a][b] = v;
     }
-  float t[A][3];
+  float t[A][R];
 #pragma unroll
   for (int r = 0; r < A; ++r)
 #pragma unroll
-    for (int b = 0; b < 3; ++b) {
+    for (int b = 0; b < R; ++b) {
       float s = 0.f;
 #pragma unroll
-      for (int q = 0; q < 3; ++q) f1mac(s, F::G[r][q], g[q][b]);
+      for (int q = 0; q < R; ++q) f1mac(s, F::G[r][q], g[q][b]);
       t[r][b] = s;
     }
 #pragma unroll
@@ -338,7 +353,7 @@ __global__ __launch_bounds__(256) void winog_filter_kernel(WShape w, int mode, i
     for (int j = 0; j < A; ++j) {
       float s = 0.f;
 #pragma unroll
-      for (int q = 0; q < 3; ++q) f1mac(s, F::G[j][q], t[a][q]);
+      for (int q = 0; q < R; ++q) f1mac(s, F::G[j][q], t[a][q]);
       U[(size_t)(a * A + j) * total + i] = s;
     }
 }
@@ -441,18 +456,18 @@ __global__ __launch_bounds__(256) void winog_dy_kernel(const float* dy, int dcs,
 // dW[(ky,kx,ci)][co] = (G^T dU G)[ky][kx]
 template <class F>
 __global__ __launch_bounds__(256) void winog_filter_grad_kernel(WShape w, const float* dU, float* dpacked) {
-  constexpr int A = F::A;
+  constexpr int A = F::A, R = F::R;
   const size_t total = (size_t)w.Cip * w.Npad;
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= total) return;
-  float t[3][A];
+  float t[R][A];
 #pragma unroll
   for (int b = 0; b < A; ++b) {
     float u[A];
 #pragma unroll
     for (int a = 0; a < A; ++a) u[a] = dU[(size_t)(a * A + b) * total + i];
 #pragma unroll
-    for (int r = 0; r < 3; ++r) {
+    for (int r = 0; r < R; ++r) {
       float s = 0.f;
 #pragma unroll
       for (int a = 0; a < A; ++a) f1mac(s, F::G[a][r], u[a]);
@@ -460,13 +475,13 @@ __global__ __launch_bounds__(256) void winog_filter_grad_kernel(WShape w, const 
     }
   }
 #pragma unroll
-  for (int a = 0; a < 3; ++a)
+  for (int a = 0; a < R; ++a)
 #pragma unroll
-    for (int j = 0; j < 3; ++j) {
+    for (int j = 0; j < R; ++j) {
       float s = 0.f;
 #pragma unroll
       for (int b = 0; b < A; ++b) f1mac(s, F::G[b][j], t[a][b]);
-      dpacked[(size_t)(a * 3 + j) * total + i] = s;
+      dpacked[(size_t)(a * R + j) * total + i] = s;
     }
 }
 
@@ -474,59 +489,73 @@ inline unsigned wgrid(size_t total) { return (unsigned)std::min<size_t>(std::max
 
 }  // namespace
 
-static void check_m(int m) {
-  if (m != 2 && m != 4) throw Error(1, "winograd: output tile size must be 2 or 4");
+// variant id: 0 = F(2,3) hand-written, 1 = F(4,3), 2 = F(3,4)
+static int variant(int m, int r) {
+  if (m == 2 && r == 3) return 0;
+  if (m == 4 && r == 3) return 1;
+  if (m == 3 && r == 4) return 2;
+  throw Error(1, "winograd: supported forms are F(2,3), F(4,3) and F(3,4)");
 }
-void wino_input_transform(Stream& s, int m, const TView& x, int pad, int pad_mode, int Th, int Tw, float* V) {
-  check_m(m);
+void wino_input_transform(Stream& s, int m, int r, const TView& x, int pad, int pad_mode, int Th, int Tw, float* V) {
+  const int v = variant(m, r);
   if (x.C % 4 || x.cs % 4) throw Error(1, "wino_input_transform: C must be a multiple of 4");
   const size_t total = (size_t)x.N * Th * Tw * (x.C / 4);
-  if (m == 2)
-    hipLaunchKernelGGL(wino_input_kernel, dim3(wgrid(total)), dim3(256), 0, hs(s), x.p, x.cs, x.N, x.H, x.W, x.C, pad,
-                       pad_mode, Th, Tw, V);
+  const dim3 grid(wgrid(total));
+  if (v == 0)
+    hipLaunchKernelGGL(wino_input_kernel, grid, dim3(256), 0, hs(s), x.p, x.cs, x.N, x.H, x.W, x.C, pad, pad_mode, Th, Tw, V);
+  else if (v == 1)
+    hipLaunchKernelGGL(winog_input_kernel<F43>, grid, dim3(256), 0, hs(s), x.p, x.cs, x.N, x.H, x.W, x.C, pad, pad_mode, Th,
+                       Tw, V);
   else
-    hipLaunchKernelGGL(winog_input_kernel<F43>, dim3(wgrid(total)), dim3(256), 0, hs(s), x.p, x.cs, x.N, x.H, x.W, x.C,
-                       pad, pad_mode, Th, Tw, V);
+    hipLaunchKernelGGL(winog_input_kernel<F34>, grid, dim3(256), 0, hs(s), x.p, x.cs, x.N, x.H, x.W, x.C, pad, pad_mode, Th,
+                       Tw, V);
   check_launch("wino_input_transform");
 }
-void wino_filter_transform(Stream& s, int m, const WShape& w, int mode, const float* packed, float* U) {
-  check_m(m);
+void wino_filter_transform(Stream& s, int m, int r, const WShape& w, int mode, const float* packed, float* U) {
+  const int v = variant(m, r);
   const int K = mode == 0 ? w.Cip : w.Npad, Nn = mode == 0 ? w.Npad : w.Cip;
   const dim3 grid((unsigned)(((size_t)K * Nn + 255) / 256));
-  if (m == 2) hipLaunchKernelGGL(wino_filter_kernel, grid, dim3(256), 0, hs(s), w, mode, K, Nn, packed, U);
-  else hipLaunchKernelGGL(winog_filter_kernel<F43>, grid, dim3(256), 0, hs(s), w, mode, K, Nn, packed, U);
+  if (v == 0) hipLaunchKernelGGL(wino_filter_kernel, grid, dim3(256), 0, hs(s), w, mode, K, Nn, packed, U);
+  else if (v == 1) hipLaunchKernelGGL(winog_filter_kernel<F43>, grid, dim3(256), 0, hs(s), w, mode, K, Nn, packed, U);
+  else hipLaunchKernelGGL(winog_filter_kernel<F34>, grid, dim3(256), 0, hs(s), w, mode, K, Nn, packed, U);
   check_launch("wino_filter_transform");
 }
-void wino_output_transform(Stream& s, int m, const float* M, int Cm, int Th, int Tw, const float* bias, int act,
+void wino_output_transform(Stream& s, int m, int r, const float* M, int Cm, int Th, int Tw, const float* bias, int act,
                            const TView& y, int Cout, int accumulate) {
-  check_m(m);
+  const int v = variant(m, r);
   const size_t total = (size_t)y.N * Th * Tw * ((Cout + 3) / 4);
-  if (m == 2)
-    hipLaunchKernelGGL(wino_output_kernel, dim3(wgrid(total)), dim3(256), 0, hs(s), M, Cm, y.N, Th, Tw, bias, act, y.p,
-                       y.cs, y.H, y.W, Cout, accumulate);
+  const dim3 grid(wgrid(total));
+  if (v == 0)
+    hipLaunchKernelGGL(wino_output_kernel, grid, dim3(256), 0, hs(s), M, Cm, y.N, Th, Tw, bias, act, y.p, y.cs, y.H, y.W,
+                       Cout, accumulate);
+  else if (v == 1)
+    hipLaunchKernelGGL(winog_output_kernel<F43>, grid, dim3(256), 0, hs(s), M, Cm, y.N, Th, Tw, bias, act, y.p, y.cs, y.H,
+                       y.W, Cout, accumulate);
   else
-    hipLaunchKernelGGL(winog_output_kernel<F43>, dim3(wgrid(total)), dim3(256), 0, hs(s), M, Cm, y.N, Th, Tw, bias, act,
-                       y.p, y.cs, y.H, y.W, Cout, accumulate);
+    hipLaunchKernelGGL(winog_output_kernel<F34>, grid, dim3(256), 0, hs(s), M, Cm, y.N, Th, Tw, bias, act, y.p, y.cs, y.H,
+                       y.W, Cout, accumulate);
   check_launch("wino_output_transform");
 }
-void wino_dy_transform(Stream& s, int m, const TView& dy, int Th, int Tw, float* dM) {
-  check_m(m);
+void wino_dy_transform(Stream& s, int m, int r, const TView& dy, int Th, int Tw, float* dM) {
+  const int v = variant(m, r);
   if (dy.C % 4 || dy.cs % 4) throw Error(1, "wino_dy_transform: C must be a multiple of 4");
   const size_t total = (size_t)dy.N * Th * Tw * (dy.C / 4);
-  if (m == 2)
-    hipLaunchKernelGGL(wino_dy_kernel, dim3(wgrid(total)), dim3(256), 0, hs(s), dy.p, dy.cs, dy.N, dy.H, dy.W, dy.C, Th,
-                       Tw, dM);
+  const dim3 grid(wgrid(total));
+  if (v == 0)
+    hipLaunchKernelGGL(wino_dy_kernel, grid, dim3(256), 0, hs(s), dy.p, dy.cs, dy.N, dy.H, dy.W, dy.C, Th, Tw, dM);
+  else if (v == 1)
+    hipLaunchKernelGGL(winog_dy_kernel<F43>, grid, dim3(256), 0, hs(s), dy.p, dy.cs, dy.N, dy.H, dy.W, dy.C, Th, Tw, dM);
   else
-    hipLaunchKernelGGL(winog_dy_kernel<F43>, dim3(wgrid(total)), dim3(256), 0, hs(s), dy.p, dy.cs, dy.N, dy.H, dy.W, dy.C,
-                       Th, Tw, dM);
+    hipLaunchKernelGGL(winog_dy_kernel<F34>, grid, dim3(256), 0, hs(s), dy.p, dy.cs, dy.N, dy.H, dy.W, dy.C, Th, Tw, dM);
   check_launch("wino_dy_transform");
 }
-void wino_filter_grad(Stream& s, int m, const WShape& w, const float* dU, float* dpacked) {
-  check_m(m);
+void wino_filter_grad(Stream& s, int m, int r, const WShape& w, const float* dU, float* dpacked) {
+  const int v = variant(m, r);
   const size_t total = (size_t)w.Cip * w.Npad;
   const dim3 grid((unsigned)((total + 255) / 256));
-  if (m == 2) hipLaunchKernelGGL(wino_filter_grad_kernel, grid, dim3(256), 0, hs(s), w, dU, dpacked);
-  else hipLaunchKernelGGL(winog_filter_grad_kernel<F43>, grid, dim3(256), 0, hs(s), w, dU, dpacked);
+  if (v == 0) hipLaunchKernelGGL(wino_filter_grad_kernel, grid, dim3(256), 0, hs(s), w, dU, dpacked);
+  else if (v == 1) hipLaunchKernelGGL(winog_filter_grad_kernel<F43>, grid, dim3(256), 0, hs(s), w, dU, dpacked);
+  else hipLaunchKernelGGL(winog_filter_grad_kernel<F34>, grid, dim3(256), 0, hs(s), w, dU, dpacked);
   check_launch("wino_filter_grad");
 }
 

@@ -142,23 +142,27 @@ void conv_wgrad(Stream&, const ConvWgradArgs& a) {
 }
 void conv_wgrad_naive(Stream& s, const ConvWgradArgs& a) { conv_wgrad(s, a); }
 
-// Winograd F(m x m, 3x3), m = 2 or 4, straight from the transform matrices
-struct WinoMats { int m, A; const float* BT; const float* G; const float* AT; };
+// Winograd F(m x m, r x r) straight from the transform matrices: (2,3), (4,3), (3,4)
+struct WinoMats { int m, r, A; const float* BT; const float* G; const float* AT; };
 static const float kBT2[16] = {1, 0, -1, 0, 0, 1, 1, 0, 0, -1, 1, 0, 0, 1, 0, -1};
 static const float kG2[12] = {1, 0, 0, 0.5f, 0.5f, 0.5f, 0.5f, -0.5f, 0.5f, 0, 0, 1};
 static const float kAT2[8] = {1, 1, 1, 0, 0, 1, -1, -1};
-static const float kBT4[36] = {4, 0, -5, 0, 1, 0, 0, -4, -4, 1, 1, 0, 0, 4, -4, -1, 1, 0,
+static const float kBT6[36] = {4, 0, -5, 0, 1, 0, 0, -4, -4, 1, 1, 0, 0, 4, -4, -1, 1, 0,
                                0, -2, -1, 2, 1, 0, 0, 2, -1, -2, 1, 0, 0, 4, 0, -5, 0, 1};
-static const float kG4[18] = {1.f / 4, 0, 0, -1.f / 6, -1.f / 6, -1.f / 6, -1.f / 6, 1.f / 6, -1.f / 6,
-                              1.f / 24, 1.f / 12, 1.f / 6, 1.f / 24, -1.f / 12, 1.f / 6, 0, 0, 1};
-static const float kAT4[24] = {1, 1, 1, 1, 1, 0, 0, 1, -1, 2, -2, 0, 0, 1, 1, 4, 4, 0, 0, 1, -1, 8, -8, 1};
-static WinoMats wino_mats(int m) {
-  if (m == 2) return {2, 4, kBT2, kG2, kAT2};
-  if (m == 4) return {4, 6, kBT4, kG4, kAT4};
-  throw Error(1, "winograd: output tile size must be 2 or 4");
+static const float kG43[18] = {1.f / 4, 0, 0, -1.f / 6, -1.f / 6, -1.f / 6, -1.f / 6, 1.f / 6, -1.f / 6,
+                               1.f / 24, 1.f / 12, 1.f / 6, 1.f / 24, -1.f / 12, 1.f / 6, 0, 0, 1};
+static const float kAT43[24] = {1, 1, 1, 1, 1, 0, 0, 1, -1, 2, -2, 0, 0, 1, 1, 4, 4, 0, 0, 1, -1, 8, -8, 1};
+static const float kG34[24] = {1.f / 4, 0, 0, 0, -1.f / 6, -1.f / 6, -1.f / 6, -1.f / 6, -1.f / 6, 1.f / 6, -1.f / 6, 1.f / 6,
+                               1.f / 24, 1.f / 12, 1.f / 6, 1.f / 3, 1.f / 24, -1.f / 12, 1.f / 6, -1.f / 3, 0, 0, 0, 1};
+static const float kAT34[18] = {1, 1, 1, 1, 1, 0, 0, 1, -1, 2, -2, 0, 0, 1, 1, 4, 4, 1};
+static WinoMats wino_mats(int m, int r) {
+  if (m == 2 && r == 3) return {2, 3, 4, kBT2, kG2, kAT2};
+  if (m == 4 && r == 3) return {4, 3, 6, kBT6, kG43, kAT43};
+  if (m == 3 && r == 4) return {3, 4, 6, kBT6, kG34, kAT34};
+  throw Error(1, "winograd: supported forms are F(2,3), F(4,3) and F(3,4)");
 }
-void wino_input_transform(Stream&, int m, const TView& x, int pad, int pad_mode, int Th, int Tw, float* V) {
-  const WinoMats wm = wino_mats(m);
+void wino_input_transform(Stream&, int m, int r, const TView& x, int pad, int pad_mode, int Th, int Tw, float* V) {
+  const WinoMats wm = wino_mats(m, r);
   const int A = wm.A;
   const size_t T = (size_t)x.N * Th * Tw;
   for (int n = 0; n < x.N; ++n) for (int ty = 0; ty < Th; ++ty) for (int tx = 0; tx < Tw; ++tx) {
@@ -175,24 +179,24 @@ void wino_input_transform(Stream&, int m, const TView& x, int pad, int pad_mode,
     }
   }
 }
-void wino_filter_transform(Stream&, int m, const WShape& w, int mode, const float* packed, float* U) {
-  const WinoMats wm = wino_mats(m);
-  const int A = wm.A;
+void wino_filter_transform(Stream&, int m, int r, const WShape& w, int mode, const float* packed, float* U) {
+  const WinoMats wm = wino_mats(m, r);
+  const int A = wm.A, R = wm.r;
   const int K = mode == 0 ? w.Cip : w.Npad, Nn = mode == 0 ? w.Npad : w.Cip;
   const size_t total = (size_t)K * Nn;
   for (int k = 0; k < K; ++k) for (int n = 0; n < Nn; ++n) {
-    float g[3][3], t[6][3];
-    for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b)
-      g[a][b] = mode == 0 ? packed[((size_t)(a * 3 + b) * w.Cip + k) * w.Npad + n]
-                          : packed[((size_t)((2 - a) * 3 + (2 - b)) * w.Cip + n) * w.Npad + k];
-    for (int a = 0; a < A; ++a) for (int b = 0; b < 3; ++b) { float s = 0; for (int q = 0; q < 3; ++q) s += wm.G[a * 3 + q] * g[q][b]; t[a][b] = s; }
-    for (int a = 0; a < A; ++a) for (int b = 0; b < A; ++b) { float s = 0; for (int q = 0; q < 3; ++q) s += t[a][q] * wm.G[b * 3 + q];
+    float g[4][4], t[6][4];
+    for (int a = 0; a < R; ++a) for (int b = 0; b < R; ++b)
+      g[a][b] = mode == 0 ? packed[((size_t)(a * R + b) * w.Cip + k) * w.Npad + n]
+                          : packed[((size_t)((R - 1 - a) * R + (R - 1 - b)) * w.Cip + n) * w.Npad + k];
+    for (int a = 0; a < A; ++a) for (int b = 0; b < R; ++b) { float s = 0; for (int q = 0; q < R; ++q) s += wm.G[a * R + q] * g[q][b]; t[a][b] = s; }
+    for (int a = 0; a < A; ++a) for (int b = 0; b < A; ++b) { float s = 0; for (int q = 0; q < R; ++q) s += t[a][q] * wm.G[b * R + q];
       U[(size_t)(a * A + b) * total + (size_t)k * Nn + n] = s; }
   }
 }
-void wino_output_transform(Stream&, int m, const float* M, int Cm, int Th, int Tw, const float* bias, int act,
+void wino_output_transform(Stream&, int m, int r, const float* M, int Cm, int Th, int Tw, const float* bias, int act,
                            const TView& y, int Cout, int accumulate) {
-  const WinoMats wm = wino_mats(m);
+  const WinoMats wm = wino_mats(m, r);
   const int A = wm.A;
   const size_t T = (size_t)y.N * Th * Tw;
   for (int n = 0; n < y.N; ++n) for (int ty = 0; ty < Th; ++ty) for (int tx = 0; tx < Tw; ++tx) {
@@ -213,8 +217,8 @@ void wino_output_transform(Stream&, int m, const float* M, int Cm, int Th, int T
     }
   }
 }
-void wino_dy_transform(Stream&, int m, const TView& dy, int Th, int Tw, float* dM) {
-  const WinoMats wm = wino_mats(m);
+void wino_dy_transform(Stream&, int m, int r, const TView& dy, int Th, int Tw, float* dM) {
+  const WinoMats wm = wino_mats(m, r);
   const int A = wm.A;
   const size_t T = (size_t)dy.N * Th * Tw;
   for (int n = 0; n < dy.N; ++n) for (int ty = 0; ty < Th; ++ty) for (int tx = 0; tx < Tw; ++tx) {
@@ -233,15 +237,15 @@ void wino_dy_transform(Stream&, int m, const TView& dy, int Th, int Tw, float* d
     }
   }
 }
-void wino_filter_grad(Stream&, int m, const WShape& w, const float* dU, float* dpacked) {
-  const WinoMats wm = wino_mats(m);
-  const int A = wm.A;
+void wino_filter_grad(Stream&, int m, int r, const WShape& w, const float* dU, float* dpacked) {
+  const WinoMats wm = wino_mats(m, r);
+  const int A = wm.A, R = wm.r;
   const size_t total = (size_t)w.Cip * w.Npad;
   for (size_t i = 0; i < total; ++i)
-    for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) {       // dg = G^T dU G
+    for (int a = 0; a < R; ++a) for (int b = 0; b < R; ++b) {       // dg = G^T dU G
       float s = 0;
-      for (int p = 0; p < A; ++p) for (int q = 0; q < A; ++q) s += wm.G[p * 3 + a] * dU[(size_t)(p * A + q) * total + i] * wm.G[q * 3 + b];
-      dpacked[(size_t)(a * 3 + b) * total + i] = s;
+      for (int p = 0; p < A; ++p) for (int q = 0; q < A; ++q) s += wm.G[p * R + a] * dU[(size_t)(p * A + q) * total + i] * wm.G[q * R + b];
+      dpacked[(size_t)(a * R + b) * total + i] = s;
     }
 }
 
