@@ -452,24 +452,40 @@ __global__ __launch_bounds__(256) void conv_fwd_narrow_kernel(GemmP p) {
   }
 }
 
-// sums the K-split slabs in fixed order and applies the epilogue
+// sums the K-split slabs in fixed order and applies the epilogue (4 output channels per thread)
 __global__ void conv_fwd_reduce_kernel(GemmP p) {
   p.y += (size_t)blockIdx.z * p.y_bs; p.slab += (size_t)blockIdx.z * p.slab_bs;
   apply_phase(p);
+  const int C4 = (p.Cout + 3) >> 2;
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const size_t total = (size_t)p.M * p.Cout;
+  const size_t total = (size_t)p.M * C4;
   if (i >= total) return;
-  const int m = (int)(i / p.Cout), col = (int)(i - (size_t)m * p.Cout);
-  float v = 0.f;
-  for (int s = 0; s < p.splits; ++s) v += p.slab[((size_t)s * p.M + m) * p.Npad + col];
-  if (p.bias) v += p.bias[col];
-  v = act_apply(v, p.act);
+  const int m = (int)(i / C4), col = (int)(i - (size_t)m * C4) * 4;
+  float4 a = *reinterpret_cast<const float4*>(p.slab + (size_t)m * p.Npad + col);   // Npad % 4 == 0
+  for (int s = 1; s < p.splits; ++s) {
+    const float4 b = *reinterpret_cast<const float4*>(p.slab + ((size_t)s * p.M + m) * p.Npad + col);
+    a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+  }
+  float v[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    if (p.bias && col + j < p.Cout) v[j] += p.bias[col + j];
+    v[j] = act_apply(v[j], p.act);
+  }
   const int HoWo = p.Ho * p.Wo;
   const int n = m / HoWo, rem = m - n * HoWo;
   const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
   float* dst = p.y + (size_t)((n * p.yH + oy * p.ymul + p.yoff) * p.yW + ox * p.xmul + p.xoff) * p.ycs + col;
-  if (p.accumulate) v += *dst;
-  *dst = v;
+  if (col + 3 < p.Cout) {
+    float4 o = make_float4(v[0], v[1], v[2], v[3]);
+    if (p.accumulate) {
+      const float4 old = *reinterpret_cast<const float4*>(dst);
+      o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w;
+    }
+    *reinterpret_cast<float4*>(dst) = o;
+  } else {
+    for (int j = 0; j < 4 && col + j < p.Cout; ++j) dst[j] = p.accumulate ? dst[j] + v[j] : v[j];
+  }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -478,12 +494,13 @@ __global__ void conv_fwd_reduce_kernel(GemmP p) {
 // NG > 0: narrow-N variant (Tile<2,1,4,1>: 256 k-rows x <= 32 channels): one k-row per lane,
 // dY[m][4g..4g+3] broadcast from lanes 4g..4g+3, v_mfma_f32_4x4x1 as in conv_fwd_narrow_kernel.
 template <int MT, int NT, int WGM, int WGN, int NG = 0>
-__global__ __launch_bounds__(256) void conv_wgrad_kernel(GemmP p) {
+__global__ __launch_bounds__(64 * WGM * WGN) void conv_wgrad_kernel(GemmP p) {
   using T = Tile<MT, NT, WGM, WGN>;
   constexpr int BM = T::BM, BN = T::BN;
-  constexpr int RA = BM / 32;          // float4 per thread for the [32][BM] tile
-  constexpr int RB = BN / 32;
-  constexpr int AROWS = 1024 / BM, BROWS = 1024 / BN;
+  constexpr int NTHR = 64 * WGM * WGN;
+  constexpr int AROWS = NTHR / (BM / 4), BROWS = NTHR / (BN / 4);   // pixel rows of the [32][BM] / [32][BN] tiles per pass
+  constexpr int RA = 32 / AROWS;       // float4 per thread
+  constexpr int RB = 32 / BROWS;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* As = smem;                    // [2][32*BM]
   float* Bs = smem + 2 * 32 * BM;      // [2][32*BN]
@@ -650,7 +667,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(GemmP p) {
     }
 }
 
-__global__ void slab_sum_kernel(const float* slab, float* out, size_t n, int splits) {
+__global__ void slab_sum_kernel(const float* slab, float* out, size_t n, int splits, size_t slab_bs, size_t out_bs) {
+  slab += (size_t)blockIdx.y * slab_bs; out += (size_t)blockIdx.y * out_bs;
   const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
   if (i >= n) return;
   float4 a = *reinterpret_cast<const float4*>(slab + i);
@@ -852,7 +870,7 @@ static void launch_fwd(Stream& s, GemmP& p, bool fast, int batch) {
   }
   check_launch("conv_fwd");
   if (p.splits > 1) {
-    const size_t total = (size_t)p.M * p.Cout;
+    const size_t total = (size_t)p.M * ((p.Cout + 3) / 4);
     hipLaunchKernelGGL(conv_fwd_reduce_kernel, dim3((unsigned)((total + 255) / 256), 1, batch), dim3(256), 0, hs(s), p);
     check_launch("conv_fwd_reduce");
   }
@@ -882,7 +900,7 @@ static void launch_fwd_narrow(Stream& s, GemmP& p, bool fast, int batch) {
   else hipLaunchKernelGGL((conv_fwd_narrow_kernel<NG, false>), grid, dim3(256), T::SMEM, hs(s), p);
   check_launch("conv_fwd_narrow");
   if (p.splits > 1) {
-    const size_t total = (size_t)p.M * p.Cout;
+    const size_t total = (size_t)p.M * ((p.Cout + 3) / 4);
     hipLaunchKernelGGL(conv_fwd_reduce_kernel, dim3((unsigned)((total + 255) / 256), 1, batch), dim3(256), 0, hs(s), p);
     check_launch("conv_fwd_reduce");
   }
@@ -925,7 +943,7 @@ static void launch_wgrad(Stream& s, GemmP& p, int batch) {
   p.tiles_n = ceil_div(p.Npad, T::BN);
   p.ntiles = tiles_k * p.tiles_n;
   const int nmb = ceil_div(p.M, 32);
-  const int slots = 256 * (T::SMEM_WG >= 64 * 1024 ? 2 : (T::SMEM_WG >= 48 * 1024 ? 3 : 4));
+  const int slots = 256 * (T::SMEM_WG > 80 * 1024 ? 1 : (T::SMEM_WG >= 64 * 1024 ? 2 : (T::SMEM_WG >= 48 * 1024 ? 3 : 4)));
   const int splits = choose_splits(p.ntiles * batch, nmb, slots, 8, (size_t)p.K * p.Npad * 4 * batch, s.ws_bytes);
   p.per_split = ceil_div(nmb, splits);
   p.splits = ceil_div(nmb, p.per_split);
@@ -940,13 +958,13 @@ static void launch_wgrad(Stream& s, GemmP& p, int batch) {
   else
     snprintf(pname, sizeof pname, "conv_wgrad_%dx%d", T::BM, bn);
   ProfScope prof(s, pname, 2.0 * p.M * p.Cout * p.K * batch);
-  hipLaunchKernelGGL((conv_wgrad_kernel<MT, NT, WGM, WGN, NG>), dim3(p.ntiles, p.splits, batch), dim3(256), T::SMEM_WG, hs(s), p);
+  hipLaunchKernelGGL((conv_wgrad_kernel<MT, NT, WGM, WGN, NG>), dim3(p.ntiles, p.splits, batch), dim3(64 * WGM * WGN),
+                     T::SMEM_WG, hs(s), p);
   check_launch("conv_wgrad");
   if (p.splits > 1) {
     const size_t n = (size_t)p.K * p.Npad;
-    for (int b = 0; b < batch; ++b)
-      hipLaunchKernelGGL(slab_sum_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, hs(s),
-                         p.slab + (size_t)b * p.slab_bs, const_cast<float*>(p.w) + (size_t)b * p.w_bs, n, p.splits);
+    hipLaunchKernelGGL(slab_sum_kernel, dim3((unsigned)((n / 4 + 255) / 256), batch), dim3(256), 0, hs(s), p.slab,
+                       const_cast<float*>(p.w), n, p.splits, p.slab_bs, p.w_bs);
     check_launch("slab_sum");
   }
 }
@@ -958,7 +976,10 @@ void conv_wgrad(Stream& s, const ConvWgradArgs& a) {
   if (a.Npad % 4 || a.Cout > a.Npad || a.dy.C % 4) throw Error(1, "conv_wgrad: bad Npad/Cout");
   p.x_bs = a.x_bs; p.y_bs = a.dy_bs; p.w_bs = a.dw_bs;
   const int nb = a.phases ? a.phases : std::max(a.batch, 1);
-  if (a.Npad > 64) launch_wgrad<2, 2, 2, 2>(s, p, nb);
+  static const int big = getenv("SWN_WGRAD256") ? atoi(getenv("SWN_WGRAD256")) : 1;
+  // 8-wave 256x128 tile: +3 % on the single-GEMM layers, -7 % on the batched Winograd planes (measured)
+  if (a.Npad > 64 && big && p.K >= 512 && nb == 1) launch_wgrad<2, 2, 4, 2>(s, p, nb);
+  else if (a.Npad > 64) launch_wgrad<2, 2, 2, 2>(s, p, nb);
   else if (a.Npad > 32) launch_wgrad<2, 1, 2, 2>(s, p, nb);
   // narrow variant only where it measured faster (N <= 8: PatchGAN's 1-channel head); at N = 19 both
   // forms are bound by the im2col load path (2 N FLOP per loaded float), not by the matrix pipe

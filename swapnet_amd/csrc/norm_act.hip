@@ -229,17 +229,23 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* dy, in
     for (int j = 0; j < 4; ++j) partial[(size_t)blockIdx.x * C + tx * 4 + j] = red[t * 4 + j];
   }
 }
-// 64 channels x 4 lanes per block: each lane sums a quarter of the chunk partials (fixed order)
+// 16 channels x 16 lanes per block: each lane sums every 16th chunk partial, then a fixed-order
+// LDS sum over the 16 lanes (deterministic)
 __global__ __launch_bounds__(256) void colsum_final_kernel(const double* partial, int nchunk, int C, float* out) {
   __shared__ double red[256];
-  const int cl = threadIdx.x & 63, lane4 = threadIdx.x >> 6;
-  const int c = blockIdx.x * 64 + cl;
+  const int cl = threadIdx.x & 15, ln = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + cl;
   double a = 0;
   if (c < C)
-    for (int i = lane4; i < nchunk; i += 4) a += partial[(size_t)i * C + c];
+    for (int i = ln; i < nchunk; i += 16) a += partial[(size_t)i * C + c];
   red[threadIdx.x] = a;
   __syncthreads();
-  if (lane4 == 0 && c < C) out[c] = (float)(red[cl] + red[64 + cl] + red[128 + cl] + red[192 + cl]);
+  if (ln == 0 && c < C) {
+    double t = 0;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) t += red[j * 16 + cl];
+    out[c] = (float)t;
+  }
 }
 
 __global__ __launch_bounds__(256) void reflect_fold_kernel(const float* src, int scs, float* dst, int dcs, int N,
@@ -371,7 +377,7 @@ void bias_grad(Stream& s, const TView& dy, float* db) {
   double* partial = reinterpret_cast<double*>(s.ws);
   if ((size_t)nchunk * dy.C * 8 > s.ws_bytes) throw Error(1, "bias_grad: workspace too small");
   hipLaunchKernelGGL(colsum_partial_kernel, dim3(nchunk), dim3(256), 0, hs(s), dy.p, dy.cs, pixels, dy.C, chunk, partial);
-  hipLaunchKernelGGL(colsum_final_kernel, dim3(ceil_div(dy.C, 64)), dim3(256), 0, hs(s), partial, nchunk, dy.C, db);
+  hipLaunchKernelGGL(colsum_final_kernel, dim3(ceil_div(dy.C, 16)), dim3(256), 0, hs(s), partial, nchunk, dy.C, db);
   check_launch("bias_grad");
 }
 
