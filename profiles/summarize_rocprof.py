@@ -48,5 +48,23 @@ def main(src, tag):
         print("wrote counters for", len(out), "kernels")
 
 
+def traffic(fetch_tag, write_tag, out_tag):
+    """HBM bytes per launch from two separate PMC passes (MI355X_MICROARCH.md: FETCH_SIZE / WRITE_SIZE
+    count KiB; on gfx950 FETCH_SIZE tallies 128-B requests as 64 B -> x2)."""
+    f = json.load(open(os.path.join(HERE, f"pmc_{fetch_tag}.json")))
+    w = json.load(open(os.path.join(HERE, f"pmc_{write_tag}.json")))
+    out = {}
+    for k in sorted(set(f) | set(w)):
+        n = int((f.get(k) or w.get(k))["dispatches"])
+        out[k] = {"launches": n,
+                  "fetch_bytes_per_launch": int(f.get(k, {}).get("FETCH_SIZE", 0) * 1024 * 2 / max(n, 1)),
+                  "write_bytes_per_launch": int(w.get(k, {}).get("WRITE_SIZE", 0) * 1024 / max(n, 1))}
+    json.dump({"kernels": out}, open(os.path.join(HERE, f"traffic_{out_tag}.json"), "w"), indent=1, sort_keys=True)
+    print("wrote traffic for", len(out), "kernels")
+
+
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2])
+    if sys.argv[1] == "traffic":
+        traffic(sys.argv[2], sys.argv[3], sys.argv[4])
+    else:
+        main(sys.argv[1], sys.argv[2])
