@@ -179,17 +179,19 @@ void Net::conv(const std::string& name, const Var& x, const Var& y, ConvKind kin
   // (m+r-1)^2 batched GEMMs, inverse transform (wino.hip).  3x3: F(4x4,3x3) when H and W are
   // multiples of 4 (4x fewer multiplies), else F(2x2,3x3) (2.25x); PatchGAN's k4 s1: F(3x3,4x4) (4x).
   const bool wino_on = !(getenv("SWN_WINOGRAD") && atoi(getenv("SWN_WINOGRAD")) == 0);
-  // ... when the channel counts are large enough for the GEMMs (K = Cin each) to run at MFMA
-  // speed and to amortise the HBM-bound transforms (measured on VGG16: a loss below 256 channels)
-  const int wino_minc = getenv("SWN_WINO_MINC") ? atoi(getenv("SWN_WINO_MINC")) : 256;
+  // ... when the channel counts are large enough for the GEMMs (K = Cin each) to run at MFMA speed
+  // and to amortise the HBM-bound transforms: measured on VGG16 (texture C3), the 6-point forms win
+  // from 64 channels up, F(2x2,3x3) (4x instead of 2.25x transform data per input) only from 256
+  const int wino_minc_env = getenv("SWN_WINO_MINC") ? atoi(getenv("SWN_WINO_MINC")) : 0;
   const int wino_force_m = getenv("SWN_WINO_M") ? atoi(getenv("SWN_WINO_M")) : 0;
   const bool wino_k4 = !(getenv("SWN_WINO_K4") && atoi(getenv("SWN_WINO_K4")) == 0);
   const bool is_k3 = kind == CK_K3S1_REFLECT || kind == CK_K3S1_ZERO;
   const bool is_k4 = kind == CK_K4S1 && wino_k4;
-  const bool wino = wino_on && Cip % 32 == 0 && Co % 32 == 0 && Cip >= wino_minc && Co >= wino_minc && x.v.H >= 4 &&
-                    x.v.W >= 4 && ((is_k3 && x.v.H % 2 == 0 && x.v.W % 2 == 0) || is_k4);
   const int wr = is_k4 ? 4 : 3;
   const int wm = is_k4 ? 3 : ((wino_force_m != 2 && x.v.H % 4 == 0 && x.v.W % 4 == 0) ? 4 : 2);
+  const int wino_minc = wino_minc_env > 0 ? wino_minc_env : (wm == 2 ? 256 : 64);
+  const bool wino = wino_on && Cip % 32 == 0 && Co % 32 == 0 && Cip >= wino_minc && Co >= wino_minc && x.v.H >= 4 &&
+                    x.v.W >= 4 && ((is_k3 && x.v.H % 2 == 0 && x.v.W % 2 == 0) || is_k4);
   const int wP = (wm + wr - 1) * (wm + wr - 1);
   const int wN = x.v.N, wTh = ceil_div(y.v.H, wm), wTw = ceil_div(y.v.W, wm);
   const size_t wT = (size_t)wN * wTh * wTw;

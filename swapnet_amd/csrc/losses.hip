@@ -30,11 +30,18 @@ __device__ __forceinline__ double block_sum(double v, double* sh) {
   return r;
 }
 
-__global__ void finalize_kernel(const double* partial, int n, double mul, float* out) {
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
-    double a = 0;
-    for (int i = 0; i < n; ++i) a += partial[i];
-    out[0] = (float)(a * mul);
+// one 64-lane block: lane l sums partial[l], partial[l+64], ...; lane 0 then adds the 64 lane sums in
+// index order (fixed order -> deterministic)
+__global__ __launch_bounds__(64) void finalize_kernel(const double* partial, int n, double mul, float* out) {
+  __shared__ double sh[64];
+  double a = 0;
+  for (int i = threadIdx.x; i < n; i += 64) a += partial[i];
+  sh[threadIdx.x] = a;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = 0;
+    for (int i = 0; i < 64; ++i) t += sh[i];
+    out[0] = (float)(t * mul);
   }
 }
 
@@ -213,8 +220,8 @@ __global__ __launch_bounds__(256) void normed_mse_kernel(const float* f, int fcs
 // stage 1: per pixel-chunk partial Gram of both images (R = N*C rows, R <= 128)
 __global__ __launch_bounds__(256) void gram_partial_kernel(const float* a, int acs, const float* b, int bcs, int N,
                                                            int HW, int C, int chunk, float* partial) {
-  extern __shared__ float xs[];        // [2][R][chunk]
-  const int R = N * C;
+  extern __shared__ float xs[];        // [2][R][chunk + 1]  (+1: rows of different r2 land in different banks)
+  const int R = N * C, cst = chunk + 1;
   const int p0 = blockIdx.x * chunk;
   const int np = min(chunk, HW - p0);
   for (int i = threadIdx.x; i < R * chunk; i += 256) {
@@ -225,7 +232,7 @@ __global__ __launch_bounds__(256) void gram_partial_kernel(const float* a, int a
       va = a[((size_t)n * HW + p0 + pp) * acs + c];
       vb = b[((size_t)n * HW + p0 + pp) * bcs + c];
     }
-    xs[i] = va; xs[R * chunk + i] = vb;
+    xs[r * cst + pp] = va; xs[R * cst + r * cst + pp] = vb;
   }
   __syncthreads();
   float* out = partial + (size_t)blockIdx.x * 2 * R * R;
@@ -233,29 +240,40 @@ __global__ __launch_bounds__(256) void gram_partial_kernel(const float* a, int a
     const int r1 = i / R, r2 = i - r1 * R;
     float s1 = 0.f, s2 = 0.f;
     for (int pp = 0; pp < chunk; ++pp) {
-      s1 = fmaf(xs[r1 * chunk + pp], xs[r2 * chunk + pp], s1);
-      s2 = fmaf(xs[R * chunk + r1 * chunk + pp], xs[R * chunk + r2 * chunk + pp], s2);
+      s1 = fmaf(xs[r1 * cst + pp], xs[r2 * cst + pp], s1);
+      s2 = fmaf(xs[R * cst + r1 * cst + pp], xs[R * cst + r2 * cst + pp], s2);
     }
     out[i] = s1; out[R * R + i] = s2;
   }
 }
-// stage 2: G = sum of partials (fp64), dG = gscale * 2 * (Ga - Gb); loss partial
+// stage 2: G = sum of partials (fp64), dG = gscale * 2 * (Ga - Gb); loss partial.
+// 16 Gram entries x 16 lanes per block: lane l sums chunks l, l+16, ...; fixed-order LDS sum.
 __global__ __launch_bounds__(256) void gram_final_kernel(const float* partial, int nchunk, int R, float gscale,
                                                          float* dG, double* losspartial) {
-  __shared__ double sh[4];
-  double acc = 0;
-  for (int i = blockIdx.x * 256 + threadIdx.x; i < R * R; i += gridDim.x * 256) {
-    double ga = 0, gb = 0;
-    for (int ch = 0; ch < nchunk; ++ch) {
+  __shared__ double sa[256], sb[256];
+  const int el = threadIdx.x & 15, ln = threadIdx.x >> 4;
+  const int i = blockIdx.x * 16 + el;
+  double ga = 0, gb = 0;
+  if (i < R * R)
+    for (int ch = ln; ch < nchunk; ch += 16) {
       ga += partial[(size_t)ch * 2 * R * R + i];
       gb += partial[(size_t)ch * 2 * R * R + R * R + i];
     }
-    const double d = ga - gb;
-    acc += d * d;
-    dG[i] = (float)(2.0 * d) * gscale;
+  sa[threadIdx.x] = ga; sb[threadIdx.x] = gb;
+  __syncthreads();
+  if (threadIdx.x < 16) {
+    double ta = 0, tb = 0;
+    for (int j = 0; j < 16; ++j) { ta += sa[j * 16 + el]; tb += sb[j * 16 + el]; }
+    const double d = ta - tb;
+    sa[el] = (i < R * R) ? d * d : 0.0;
+    if (i < R * R) dG[i] = (float)(2.0 * d) * gscale;
   }
-  const double r = block_sum(acc, sh);
-  if (threadIdx.x == 0) losspartial[blockIdx.x] = r;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = 0;
+    for (int j = 0; j < 16; ++j) t += sa[j];
+    losspartial[blockIdx.x] = t;
+  }
 }
 // stage 3: dA[r][p] (+)= sum_r' (dG[r][r'] + dG[r'][r]) * A[r'][p]
 __global__ __launch_bounds__(256) void gram_bwd_kernel(const float* a, int acs, const float* dG, int N, int HW, int C,
@@ -358,14 +376,14 @@ void gram_style_loss(Stream& s, const TView& a, const TView& b, int C, float sca
   const size_t pbytes = (size_t)nchunk * 2 * R * R * 4;
   const size_t off_dG = (pbytes + 255) / 256 * 256;
   const size_t off_lp = off_dG + (size_t)R * R * 4 + 256;
-  if (off_lp + 64 * 8 > s.ws_bytes) throw Error(1, "gram_style_loss: workspace too small");
+  const int fgrid = ceil_div(R * R, 16);
+  if (off_lp + 256 + (size_t)fgrid * 8 > s.ws_bytes) throw Error(1, "gram_style_loss: workspace too small");
   float* partial = reinterpret_cast<float*>(s.ws);
   float* dG = reinterpret_cast<float*>(s.ws + off_dG);
   double* lp = reinterpret_cast<double*>(s.ws + (off_lp + 255) / 256 * 256);
   const double numel = (double)R * R;
-  hipLaunchKernelGGL(gram_partial_kernel, dim3(nchunk), dim3(256), 2 * R * chunk * 4, hs(s), a.p, a.cs, b.p, b.cs, a.N,
-                     HW, C, chunk, partial);
-  const int fgrid = std::min(ceil_div(R * R, 256), 64);
+  hipLaunchKernelGGL(gram_partial_kernel, dim3(nchunk), dim3(256), 2 * R * (chunk + 1) * 4, hs(s), a.p, a.cs, b.p, b.cs,
+                     a.N, HW, C, chunk, partial);
   hipLaunchKernelGGL(gram_final_kernel, dim3(fgrid), dim3(256), 0, hs(s), partial, nchunk, R, (float)(scale / numel),
                      dG, lp);
   hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(64), 0, hs(s), lp, fgrid, 1.0 / numel, loss_out);
