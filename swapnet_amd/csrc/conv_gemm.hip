@@ -44,6 +44,7 @@ struct GemmP {
   int tiles_n; int ntiles;
   size_t x_bs, w_bs, y_bs, slab_bs;   // batched mode (blockIdx.z)
   int phases;                         // sub-pixel phase mode: blockIdx.z = 2a + b shifts pads / output offsets
+  int tail4;                          // fused folded-tail kernels
 };
 
 __device__ __forceinline__ void apply_phase(GemmP& p) {
@@ -449,6 +450,283 @@ __global__ __launch_bounds__(256) void conv_fwd_narrow_kernel(GemmP p) {
     } else {
       for (int j = 0; j < 4 && col + j < p.Cout; ++j) dst[col + j] = p.accumulate ? dst[col + j] + v[j] : v[j];
     }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// Folded tail conv, all four sub-pixel phases in one kernel (ops.h `tail4`).
+// Phase (a,b) of the folded tail conv uses taps u < 2+a, v < 2+b of the 3x3 neighbourhood of the
+// un-upsampled input: run as separate narrow-N GEMMs the four phases load 4+6+6+9 = 25 im2col taps per
+// pixel, and at N = 19 that load path (not the matrix pipe) is the bound.  Here one block walks the
+// 9 union taps once and feeds every phase that uses the tap from the same LDS stage: 2.8x fewer A
+// loads, same MFMA work (v_mfma_f32_4x4x1, one pixel / one k-row per lane as in the narrow kernels).
+// Folded weight layout: tail_fold_weights (optim.hip): phase panels at tap offsets {0,4,10,16},
+// panel row = (u*(2+b)+v)*Cin + ci.
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ bool tail_active(int ph, int u, int v) { return u < 2 + (ph >> 1) && v < 2 + (ph & 1); }
+__device__ __forceinline__ int tail_row0(int ph, int u, int v, int xC) {      // first panel row of (ph, tap)
+  const int pre = ph == 0 ? 0 : (ph == 1 ? 4 : (ph == 2 ? 10 : 16));
+  return (pre + u * (2 + (ph & 1)) + v) * xC;
+}
+
+struct TailTile {
+  static constexpr int BM = 256, BK = 16, AS = BK + 4;
+  static constexpr int A_FLOATS = BM * AS, B_FLOATS = 32 * AS;       // B: one [32 n][16 k] tile per phase
+  static constexpr int SMEM = (2 * A_FLOATS + 2 * 4 * B_FLOATS) * 4;
+};
+
+template <int NG>
+__global__ __launch_bounds__(256) void tail_fwd4_kernel(GemmP p) {
+  using T = TailTile;
+  constexpr int AS = T::AS, RA = 4;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* As = smem;                       // [2][256 pixels][16 k]
+  float* Bt = smem + 2 * T::A_FLOATS;     // [2][4 phases][32 n][16 k]
+
+  const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
+  const int tile = xcd_swizzle(blockIdx.x, p.ntiles);
+  const int m0 = tile * T::BM;
+  const int q = t & 3, p0 = t >> 2;
+  int a_iy0[RA], a_ix0[RA], a_base[RA];
+  const int HoWo = p.Ho * p.Wo;
+#pragma unroll
+  for (int r = 0; r < RA; ++r) {
+    const int m = m0 + p0 + 64 * r;
+    if (m < p.M) {
+      const int n = m / HoWo, rem = m - n * HoWo;
+      const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+      a_iy0[r] = oy - 1; a_ix0[r] = ox - 1;
+      a_base[r] = n * p.xH * p.xW * p.xcs;
+    } else {
+      a_iy0[r] = 0; a_ix0[r] = 0; a_base[r] = -1;
+    }
+  }
+  const int bcol = (t & 7) * 4, brow = t >> 3;      // threads 0..127: one float4 of each phase's 16 x 32 weight tile
+
+  float4 ra[RA], rb[4];
+  auto load_tiles = [&](int kb) {
+    const int k0 = kb * 16;
+    const int tap = k0 / p.xC;             // xC % 32 == 0
+    const int c0 = k0 - tap * p.xC;
+    const int u = tap / 3, v = tap - u * 3;
+#pragma unroll
+    for (int r = 0; r < RA; ++r) {
+      float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (a_base[r] >= 0) {
+        const int sy = a_iy0[r] + u, sx = a_ix0[r] + v;
+        if (sy >= 0 && sy < p.xH && sx >= 0 && sx < p.xW)
+          val = *reinterpret_cast<const float4*>(p.x + (size_t)a_base[r] + (size_t)(sy * p.xW + sx) * p.xcs + c0 + 4 * q);
+      }
+      ra[r] = val;
+    }
+#pragma unroll
+    for (int ph = 0; ph < 4; ++ph) {
+      rb[ph] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (t < 128 && tail_active(ph, u, v) && bcol < p.Npad)
+        rb[ph] = *reinterpret_cast<const float4*>(p.w + (size_t)(tail_row0(ph, u, v, p.xC) + c0 + brow) * p.Npad + bcol);
+    }
+  };
+  auto store_tiles = [&](int buf) {
+    float* A = As + buf * T::A_FLOATS;
+#pragma unroll
+    for (int r = 0; r < RA; ++r) *reinterpret_cast<float4*>(A + (p0 + 64 * r) * AS + 4 * q) = ra[r];
+    if (t < 128) {
+#pragma unroll
+      for (int ph = 0; ph < 4; ++ph) {
+        float* B = Bt + (buf * 4 + ph) * T::B_FLOATS + bcol * AS + brow;
+        B[0] = rb[ph].x; B[AS] = rb[ph].y; B[2 * AS] = rb[ph].z; B[3 * AS] = rb[ph].w;
+      }
+    }
+  };
+
+  f32x4 acc[4][NG];
+#pragma unroll
+  for (int ph = 0; ph < 4; ++ph)
+#pragma unroll
+    for (int g = 0; g < NG; ++g) acc[ph][g] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  auto compute = [&](int buf, int kb) {
+    const int tap = (kb * 16) / p.xC;
+    const int u = tap / 3, v = tap - u * 3;
+    const float* A = As + buf * T::A_FLOATS + (wid * 64 + lane) * AS;
+    float xv[16];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const float4 a = *reinterpret_cast<const float4*>(A + 4 * g);
+      xv[4 * g] = a.x; xv[4 * g + 1] = a.y; xv[4 * g + 2] = a.z; xv[4 * g + 3] = a.w;
+    }
+#pragma unroll
+    for (int ph = 0; ph < 4; ++ph) {
+      if (!tail_active(ph, u, v)) continue;        // block-uniform
+      const float* B = Bt + (buf * 4 + ph) * T::B_FLOATS + (lane & 31) * AS;
+      float wv[16];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const float4 b = *reinterpret_cast<const float4*>(B + 4 * g);
+        wv[4 * g] = b.x; wv[4 * g + 1] = b.y; wv[4 * g + 2] = b.z; wv[4 * g + 3] = b.w;
+      }
+#pragma unroll
+      for (int kk = 0; kk < 16; ++kk) NarrowMac<0, NG>::run(acc[ph], wv[kk], xv[kk]);
+    }
+  };
+
+  const int nkb = (9 * p.xC) / 16;
+  load_tiles(0);
+  store_tiles(0);
+  __syncthreads();
+  int cur = 0;
+  for (int kb = 0; kb < nkb; ++kb) {
+    const bool more = kb + 1 < nkb;
+    if (more) load_tiles(kb + 1);
+    compute(cur, kb);
+    if (more) store_tiles(cur ^ 1);
+    __syncthreads();
+    cur ^= 1;
+  }
+
+  const int m = m0 + wid * 64 + lane;
+  if (m >= p.M) return;
+  const int n = m / HoWo, rem = m - n * HoWo;
+  const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+#pragma unroll
+  for (int ph = 0; ph < 4; ++ph) {
+    float* dst = p.y + (size_t)((n * p.yH + 2 * oy + (ph >> 1)) * p.yW + 2 * ox + (ph & 1)) * p.ycs;
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      const int col = 4 * g;
+      if (col >= p.Cout) break;
+      float val[4] = {acc[ph][g][0], acc[ph][g][1], acc[ph][g][2], acc[ph][g][3]};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (p.bias && col + j < p.Cout) val[j] += p.bias[col + j];
+        val[j] = act_apply(val[j], p.act);
+      }
+      if (col + 3 < p.Cout) {
+        *reinterpret_cast<float4*>(dst + col) = make_float4(val[0], val[1], val[2], val[3]);
+      } else {
+        for (int j = 0; j < 4 && col + j < p.Cout; ++j) dst[col + j] = val[j];
+      }
+    }
+  }
+}
+
+// weight gradient of the folded tail conv, four phases fused: block = (union tap, pixel split), NW
+// waves of 64 k-rows (one input channel per lane), reduction over PX-pixel stages (Wo % PX == 0: a
+// stage lies inside one image row).  PX = 16 keeps the block at 35 KB of LDS and <= 168 VGPRs so 4
+// blocks (3 waves per SIMD) share a CU -- with 32-pixel stages (1 wave per SIMD, one SIMD idle) the
+// kernel ran at 27 % MFMA utilisation.  Writes the folded-gradient layout (or its slabs).
+template <int NG, int NW, int PX>
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(3, 3))) void tail_wgrad4_kernel(GemmP p) {
+  constexpr int NTHR = 64 * NW, KC = 64 * NW;       // KC = Cin
+  constexpr int BST = 20;                            // dY tile row stride (Npad <= 20)
+  constexpr int A_FLOATS = PX * KC, B_FLOATS = PX * BST;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* As = smem;                                   // [2][PX px][KC]
+  float* Bs = smem + 2 * A_FLOATS;                    // [2][4 phases][PX px][20]  (+ tail padding)
+
+  const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
+  const int tap = blockIdx.x, u = tap / 3, v = tap - u * 3;
+  const int split = blockIdx.y;
+  bool act[4];
+#pragma unroll
+  for (int ph = 0; ph < 4; ++ph) act[ph] = tail_active(ph, u, v);
+
+  constexpr int A4 = KC / 4;                          // float4 per pixel row
+  constexpr int RA = PX * A4 / NTHR;
+  constexpr int AROWS = NTHR / A4;
+  const int acol = (t % A4) * 4, arow0 = t / A4;      // rows arow0 + AROWS * r
+  constexpr int NB4 = 4 * PX * 5;                     // dY: 4 phases x PX px x 5 float4
+  constexpr int RB = (NB4 + NTHR - 1) / NTHR;
+
+  const int nmb = p.M / PX;
+  const int mb_begin = split * p.per_split;
+  const int mb_end = min(nmb, mb_begin + p.per_split);
+
+  float4 ra[RA], rb[RB];
+  auto load_tiles = [&](int mb) {
+    const int m = mb * PX;                            // first pixel of the stage; the PX share (n, oy)
+    const int n = m / (p.Ho * p.Wo), rem = m - n * p.Ho * p.Wo;
+    const int oy = rem / p.Wo, ox0 = rem - oy * p.Wo;
+    const int sy = oy - 1 + u;
+    const bool yok = sy >= 0 && sy < p.xH;
+    const float* xrow = p.x + ((size_t)n * p.xH + (yok ? sy : 0)) * p.xW * p.xcs;
+#pragma unroll
+    for (int r = 0; r < RA; ++r) {
+      const int sx = ox0 + arow0 + AROWS * r - 1 + v;
+      float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (yok && sx >= 0 && sx < p.xW) val = *reinterpret_cast<const float4*>(xrow + (size_t)sx * p.xcs + acol);
+      ra[r] = val;
+    }
+#pragma unroll
+    for (int r = 0; r < RB; ++r) {
+      const int i = t + NTHR * r;
+      float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (i < NB4) {
+        const int ph = i / (PX * 5), j = i - ph * (PX * 5), px = j / 5, c4 = (j - px * 5) * 4;
+        if (act[ph] && c4 < p.Npad)
+          val = *reinterpret_cast<const float4*>(
+              p.y + ((size_t)(n * p.yH + 2 * oy + (ph >> 1)) * p.yW + 2 * (ox0 + px) + (ph & 1)) * p.ycs + c4);
+      }
+      rb[r] = val;
+    }
+  };
+  auto store_tiles = [&](int buf) {
+    float* A = As + buf * A_FLOATS;
+#pragma unroll
+    for (int r = 0; r < RA; ++r) *reinterpret_cast<float4*>(A + (arow0 + AROWS * r) * KC + acol) = ra[r];
+    float* B = Bs + buf * 4 * B_FLOATS;
+#pragma unroll
+    for (int r = 0; r < RB; ++r) {
+      const int i = t + NTHR * r;
+      if (i < NB4) *reinterpret_cast<float4*>(B + i * 4) = rb[r];       // [ph][px][20] is contiguous in i
+    }
+  };
+
+  f32x4 acc[4][NG];
+#pragma unroll
+  for (int ph = 0; ph < 4; ++ph)
+#pragma unroll
+    for (int g = 0; g < NG; ++g) acc[ph][g] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  auto compute = [&](int buf) {
+    const float* A = As + buf * A_FLOATS + wid * 64 + lane;
+    float xv[PX];
+#pragma unroll
+    for (int st = 0; st < PX; ++st) xv[st] = A[st * KC];
+#pragma unroll
+    for (int ph = 0; ph < 4; ++ph) {
+      if (!act[ph]) continue;                          // block-uniform
+      const float* B = Bs + (buf * 4 + ph) * B_FLOATS + (lane & 31);   // lanes >= 20 read past the row: unused blocks
+      float dv[PX];
+#pragma unroll
+      for (int st = 0; st < PX; ++st) dv[st] = B[st * BST];
+#pragma unroll
+      for (int st = 0; st < PX; ++st) NarrowMac<0, NG>::run(acc[ph], dv[st], xv[st]);
+    }
+  };
+
+  if (mb_begin < mb_end) {
+    load_tiles(mb_begin);
+    store_tiles(0);
+    __syncthreads();
+    int cur = 0;
+    for (int mb = mb_begin; mb < mb_end; ++mb) {
+      const bool more = mb + 1 < mb_end;
+      if (more) load_tiles(mb + 1);
+      compute(cur);
+      if (more) store_tiles(cur ^ 1);
+      __syncthreads();
+      cur ^= 1;
+    }
+  }
+  float* out = p.splits > 1 ? p.slab + (size_t)split * 25 * KC * p.Npad : const_cast<float*>(p.w);
+#pragma unroll
+  for (int ph = 0; ph < 4; ++ph) {
+    if (!act[ph]) continue;
+    float* row = out + (size_t)(tail_row0(ph, u, v, KC) + wid * 64 + lane) * p.Npad;
+#pragma unroll
+    for (int g = 0; g < NG; ++g)
+      if (4 * g < p.Npad) *reinterpret_cast<float4*>(row + 4 * g) = make_float4(acc[ph][g][0], acc[ph][g][1], acc[ph][g][2], acc[ph][g][3]);
   }
 }
 
@@ -914,7 +1192,49 @@ static bool narrow_on() {
 static int g_force_naive = 0;
 void conv_force_naive(int on) { g_force_naive = on; }
 
+// per-phase form of a tail4 launch (ops.h): the reference path and the fallback of the fused kernels
+template <class Args>
+static Args tail_phase_args(const Args& a, int ph, size_t woff) {
+  Args c = a;
+  c.tail4 = 0;
+  c.g.KH = 2 + (ph >> 1); c.g.KW = 2 + (ph & 1); c.g.stride = 1; c.g.pad_t = 1; c.g.pad_l = 1;
+  c.om.ymul = 2; c.om.xmul = 2; c.om.yoff = ph >> 1; c.om.xoff = ph & 1;
+  (void)woff;
+  return c;
+}
+static size_t tail_panel_off(int ph, int xC, int Npad) {
+  const int pre = ph == 0 ? 0 : (ph == 1 ? 4 : (ph == 2 ? 10 : 16));
+  return (size_t)pre * xC * Npad;
+}
+static void check_tail4(const Gather& g, const OutMap& om, int batch, int phases) {
+  if (g.KH != 3 || g.KW != 3 || g.stride != 1 || g.pad_t != 1 || g.pad_l != 1 || g.ups || g.pad_mode != PAD_ZERO ||
+      om.ymul != 2 || om.xmul != 2 || batch > 1 || phases)
+    throw Error(1, "conv: bad tail4 launch");
+}
+
 void conv_fwd(Stream& s, const ConvFwdArgs& a) {
+  if (a.tail4) {
+    check_tail4(a.g, a.om, a.batch, a.phases);
+    static const bool fused = !(getenv("SWN_TAIL4") && atoi(getenv("SWN_TAIL4")) == 0);
+    if (g_force_naive || !fused || a.x.C % 32 || a.Npad > 20 || a.accumulate) {
+      for (int ph = 0; ph < 4; ++ph) {
+        ConvFwdArgs c = tail_phase_args(a, ph, 0);
+        c.w = a.w + tail_panel_off(ph, a.x.C, a.Npad);
+        conv_fwd(s, c);
+      }
+      return;
+    }
+    OutMap om = a.om; om.yoff = om.xoff = 1;          // bounds check against the farthest phase
+    GemmP p = make_params(a.x, a.g, a.y, om);
+    p.w = a.w; p.Npad = a.Npad; p.bias = a.bias; p.act = a.act; p.Cout = a.Cout; p.tail4 = 1;
+    p.tiles_n = 1; p.ntiles = ceil_div(p.M, TailTile::BM);
+    static bool once = (set_smem(tail_fwd4_kernel<5>, TailTile::SMEM), true);
+    (void)once;
+    ProfScope prof(s, "tail_fwd4", 2.0 * p.M * p.Cout * 25 * a.x.C);
+    hipLaunchKernelGGL(tail_fwd4_kernel<5>, dim3(p.ntiles), dim3(256), TailTile::SMEM, hs(s), p);
+    check_launch("tail_fwd4");
+    return;
+  }
   if (g_force_naive) { conv_fwd_naive(s, a); return; }
   GemmP p = make_params(a.x, a.g, a.y, a.om, a.phases, a.batch);
   p.w = a.w; p.Npad = a.Npad; p.bias = a.bias; p.act = a.act; p.accumulate = a.accumulate; p.Cout = a.Cout;
@@ -970,6 +1290,41 @@ static void launch_wgrad(Stream& s, GemmP& p, int batch) {
 }
 
 void conv_wgrad(Stream& s, const ConvWgradArgs& a) {
+  if (a.tail4) {
+    check_tail4(a.g, a.om, a.batch, a.phases);
+    static const bool fused = !(getenv("SWN_TAIL4") && atoi(getenv("SWN_TAIL4")) == 0);
+    if (g_force_naive || !fused || a.x.C != 192 || a.Npad > 20 || a.g.Wo % 16 || a.g.Wo != a.x.W || a.g.Ho != a.x.H) {
+      for (int ph = 0; ph < 4; ++ph) {
+        ConvWgradArgs c = tail_phase_args(a, ph, 0);
+        c.dw = a.dw + tail_panel_off(ph, a.x.C, a.Npad);
+        conv_wgrad(s, c);
+      }
+      return;
+    }
+    OutMap om = a.om; om.yoff = om.xoff = 1;
+    GemmP p = make_params(a.x, a.g, a.dy, om);
+    p.w = a.dw; p.Npad = a.Npad; p.Cout = a.Cout; p.tail4 = 1;
+    constexpr int NW = 3, KC = 64 * NW, PX = 16;
+    constexpr int smem = (2 * PX * KC + 2 * 4 * PX * 20 + 32) * 4;
+    const int nmb = p.M / PX;
+    // 9 tap blocks of unequal length (1-4 active phases): many short splits keep the chip balanced
+    const size_t slab_bytes = (size_t)25 * KC * p.Npad * 4;
+    int splits = std::max(1, std::min(nmb / 32, 456));
+    while (splits > 1 && slab_bytes * splits > s.ws_bytes) --splits;
+    p.per_split = ceil_div(nmb, splits);
+    p.splits = ceil_div(nmb, p.per_split);
+    p.slab = reinterpret_cast<float*>(s.ws);
+    ProfScope prof(s, "tail_wgrad4", 2.0 * p.M * p.Cout * 25 * a.x.C);
+    hipLaunchKernelGGL((tail_wgrad4_kernel<5, NW, PX>), dim3(9, p.splits), dim3(64 * NW), smem, hs(s), p);
+    check_launch("tail_wgrad4");
+    if (p.splits > 1) {
+      const size_t n = (size_t)25 * KC * p.Npad;
+      hipLaunchKernelGGL(slab_sum_kernel, dim3((unsigned)((n / 4 + 255) / 256), 1), dim3(256), 0, hs(s), p.slab,
+                         const_cast<float*>(p.w), n, p.splits, (size_t)0, (size_t)0);
+      check_launch("slab_sum");
+    }
+    return;
+  }
   if (g_force_naive) { conv_wgrad_naive(s, a); return; }
   GemmP p = make_params(a.x, a.g, a.dy, a.om, a.phases, a.batch);
   p.w = a.dw; p.Npad = a.Npad; p.Cout = a.Cout;

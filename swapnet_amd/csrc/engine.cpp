@@ -169,12 +169,6 @@ void Net::conv(const std::string& name, const Var& x, const Var& y, ConvKind kin
     fold_off = reserve_dg(self, fe);
     dfold_off = reserve_dg(self, fe);
   }
-  auto phase_geom = [=](int ph, Gather& g, OutMap& om) {
-    const int a = ph >> 1, b = ph & 1;
-    g = Gather();
-    g.KH = 2 + a; g.KW = 2 + b; g.stride = 1; g.pad_t = 1; g.pad_l = 1; g.Ho = xv.H; g.Wo = xv.W;
-    om.ymul = 2; om.yoff = a; om.xmul = 2; om.xoff = b;
-  };
   // Stride-1 convs with MFMA-friendly channel counts run as Winograd F(m x m, r x r): transform,
   // (m+r-1)^2 batched GEMMs, inverse transform (wino.hip).  3x3: F(4x4,3x3) when H and W are
   // multiples of 4 (4x fewer multiplies), else F(2x2,3x3) (2.25x); PatchGAN's k4 s1: F(3x3,4x4) (4x).
@@ -230,11 +224,10 @@ void Net::conv(const std::string& name, const Var& x, const Var& y, ConvKind kin
     }
     if (!folded) { conv_fwd(n.ctx.s, a); return; }
     n.refresh_dgrad();                       // folded weights are derived operands too
-    for (int ph = 0; ph < 4; ++ph) {
-      phase_geom(ph, a.g, a.om);
-      a.w = n.dg + fold_off + tail_fold_offset(wd.ws, ph);
-      conv_fwd(n.ctx.s, a);
-    }
+    a.g = Gather(); a.g.KH = a.g.KW = 3; a.g.stride = 1; a.g.pad_t = a.g.pad_l = 1; a.g.Ho = xv.H; a.g.Wo = xv.W;
+    a.om.ymul = a.om.xmul = 2; a.tail4 = 1;
+    a.w = n.dg + fold_off;
+    conv_fwd(n.ctx.s, a);
   };
 
   // ---- backward plan
@@ -307,11 +300,10 @@ void Net::conv(const std::string& name, const Var& x, const Var& y, ConvKind kin
       } else if (!folded) {
         conv_wgrad(n.ctx.s, wa);
       } else {
-        for (int ph = 0; ph < 4; ++ph) {
-          phase_geom(ph, wa.g, wa.om);
-          wa.dw = n.dg + dfold_off + tail_fold_offset(wd.ws, ph);
-          conv_wgrad(n.ctx.s, wa);
-        }
+        wa.g = Gather(); wa.g.KH = wa.g.KW = 3; wa.g.stride = 1; wa.g.pad_t = wa.g.pad_l = 1; wa.g.Ho = xv.H; wa.g.Wo = xv.W;
+        wa.om.ymul = wa.om.xmul = 2; wa.tail4 = 1;
+        wa.dw = n.dg + dfold_off;
+        conv_wgrad(n.ctx.s, wa);
         tail_unfold_wgrad(n.ctx.s, wd.ws, n.dg + dfold_off, A->g + wd.off);
       }
       if (bi >= 0) bias_grad(n.ctx.s, dY, A->g + A->params[bi].off);

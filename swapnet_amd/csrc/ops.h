@@ -58,6 +58,10 @@ struct ConvFwdArgs {
   // pad_t = g.pad_t - a, pad_l = g.pad_l - b, writes outputs (2oy + a, 2ox + b) (om.ymul = om.xmul = 2)
   // and uses the weight panel w + ph * w_bs.  Excludes batch > 1.
   int phases = 0;
+  // folded tail conv (tail_fold_weights below), four phases fused: w = the folded block, g = the 3x3
+  // union gather (KH = KW = 3, stride 1, pad 1 on the un-upsampled input), om.ymul = om.xmul = 2; phase
+  // (a,b) uses taps u < 2+a, v < 2+b and writes outputs (2oy + a, 2ox + b).
+  int tail4 = 0;
 };
 void conv_fwd(Stream& s, const ConvFwdArgs& a);
 
@@ -73,6 +77,7 @@ struct ConvWgradArgs {
   int batch = 1;
   size_t x_bs = 0, dy_bs = 0, dw_bs = 0;
   int phases = 0;             // as in ConvFwdArgs; phase ph reads dy at (2oy + a, 2ox + b), writes dw + ph * dw_bs
+  int tail4 = 0;              // as in ConvFwdArgs; dw = the folded-gradient block (layout of tail_fold_weights)
 };
 void conv_wgrad(Stream& s, const ConvWgradArgs& a);
 

@@ -95,7 +95,30 @@ static void take_phase(Args& c, int ph) {      // sub-pixel phase mode (ops.h)
   c.g.pad_t -= ph >> 1; c.g.pad_l -= ph & 1; c.om.yoff = ph >> 1; c.om.xoff = ph & 1;
   c.phases = 0;
 }
-void conv_fwd(Stream&, const ConvFwdArgs& a) {
+// fused folded-tail launch (ops.h tail4) evaluated phase by phase
+template <class Args>
+static Args tail_phase(const Args& a, int ph) {
+  if (a.g.KH != 3 || a.g.KW != 3 || a.g.stride != 1 || a.g.pad_t != 1 || a.g.pad_l != 1 || a.om.ymul != 2 || a.om.xmul != 2)
+    throw Error(1, "conv: bad tail4 launch");
+  Args c = a;
+  c.tail4 = 0;
+  c.g.KH = 2 + (ph >> 1); c.g.KW = 2 + (ph & 1);
+  c.om.yoff = ph >> 1; c.om.xoff = ph & 1;
+  return c;
+}
+static size_t tail_panel(int ph, int xC, int Npad) {
+  static const int pre[4] = {0, 4, 10, 16};
+  return (size_t)pre[ph] * xC * Npad;
+}
+void conv_fwd(Stream& s, const ConvFwdArgs& a) {
+  if (a.tail4) {
+    for (int ph = 0; ph < 4; ++ph) {
+      ConvFwdArgs c = tail_phase(a, ph);
+      c.w = a.w + tail_panel(ph, a.x.C, a.Npad);
+      conv_fwd(s, c);
+    }
+    return;
+  }
   for (int b = 0; b < (a.phases ? a.phases : (a.batch > 0 ? a.batch : 1)); ++b) {
     ConvFwdArgs c = a;
     take_phase(c, b);
@@ -132,7 +155,15 @@ static void conv_wgrad_one(const ConvWgradArgs& a) {
       for (int co = 0; co < a.Npad; ++co) o[co] = (float)acc[co];
     }
 }
-void conv_wgrad(Stream&, const ConvWgradArgs& a) {
+void conv_wgrad(Stream& s, const ConvWgradArgs& a) {
+  if (a.tail4) {
+    for (int ph = 0; ph < 4; ++ph) {
+      ConvWgradArgs c = tail_phase(a, ph);
+      c.dw = a.dw + tail_panel(ph, a.x.C, a.Npad);
+      conv_wgrad(s, c);
+    }
+    return;
+  }
   for (int b = 0; b < (a.phases ? a.phases : (a.batch > 0 ? a.batch : 1)); ++b) {
     ConvWgradArgs c = a;
     take_phase(c, b);
