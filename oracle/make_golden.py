@@ -51,6 +51,43 @@ def hook_taps(net, names):
     return taps, handles
 
 
+def golden_cloth_format(path_npz, path_expected, H=24, W=16, n_labels=19, seed=7):
+    """A cloth segmentation written by the reference's compress_and_save_cloth and what its
+    decompress_cloth_segment reads back (datasets/data_utils.py:298-343)."""
+    from datasets import data_utils as R
+    g = torch.Generator().manual_seed(seed)
+    lab = torch.randint(0, n_labels, (H, W), generator=g)
+    lab[:, :3] = 0                                       # background columns (not stored)
+    scores = torch.rand((n_labels, H, W), generator=g) * 0.5
+    scores.scatter_(0, lab[None], 1.0)                   # argmax == lab
+    R.compress_and_save_cloth(scores, path_npz)
+    onehot = R.decompress_cloth_segment(path_npz, n_labels)
+    np.savez(path_expected, labels=lab.numpy().astype(np.int32), scores=scores.numpy(),
+             onehot=onehot.numpy(), n_labels=np.int64(n_labels))
+    print("wrote", path_npz, path_expected)
+
+
+def golden_roi_ops(path, seed=11):
+    """crop_rois / flip_rois_ of the reference (datasets/data_utils.py:197-295) on seeded ROI tables."""
+    from datasets import data_utils as R
+    g = torch.Generator().manual_seed(seed)
+    xy = torch.randint(0, 200, (12, 2), generator=g)
+    wh = torch.randint(0, 90, (12, 2), generator=g)
+    rois = torch.cat([xy, xy + wh], 1).float()
+    rois[3] = rois[3, [0, 1, 0, 1]]                       # degenerate box
+    bounds = ((40, 32), (168, 224))
+    out = {"rois": rois.numpy(), "bounds": np.array(bounds),
+           "crop_torch": R.crop_rois(rois, bounds).numpy(),
+           "crop_numpy": R.crop_rois(rois.numpy().astype(np.int64), bounds)}
+    for axis, center in ((0, 128), (1, 96)):
+        r = rois.clone()
+        R.flip_rois_(r, axis, center)
+        out["flip%d" % axis] = r.numpy()
+        out["center%d" % axis] = np.int64(center)
+    np.savez(path, **out)
+    print("wrote", path)
+
+
 def golden_warp(path, H=64, B=2, init_seed=0, step_seeds=(100, 101)):
     from oracle.swapnet_oracle import synth_warp_batch
     from models.warp_model import WarpModel
@@ -206,10 +243,15 @@ if __name__ == "__main__":
     torch.set_num_threads(8)
     gold = os.path.join(REPO, "tests", "golden")
     os.makedirs(gold, exist_ok=True)
-    which = sys.argv[1:] or ["warp", "texture", "roi"]
+    which = sys.argv[1:] or ["warp", "texture", "roi", "cloth", "roiops"]
     if "warp" in which:
         golden_warp(os.path.join(gold, "warp_step_64.npz"))
     if "texture" in which:
         golden_texture(os.path.join(gold, "texture_step_64.npz"))
     if "roi" in which:
         golden_roi(os.path.join(gold, "notebook_rois.npz"))
+    if "roiops" in which:
+        golden_roi_ops(os.path.join(gold, "roi_ops_reference.npz"))
+    if "cloth" in which:
+        golden_cloth_format(os.path.join(gold, "cloth_segment_reference.npz"),
+                            os.path.join(gold, "cloth_segment_expected.npz"))
