@@ -119,7 +119,10 @@ void conv_fwd(Stream& s, const ConvFwdArgs& a) {
     }
     return;
   }
-  for (int b = 0; b < (a.phases ? a.phases : (a.batch > 0 ? a.batch : 1)); ++b) {
+  const int nb = a.phases ? a.phases : (a.batch > 0 ? a.batch : 1);
+  // batched Winograd planes have few rows each: spread the planes over the threads instead
+#pragma omp parallel for schedule(dynamic, 1) if (nb >= 8)
+  for (int b = 0; b < nb; ++b) {
     ConvFwdArgs c = a;
     take_phase(c, b);
     c.x.p = a.x.p + b * a.x_bs; c.w = a.w + b * a.w_bs; c.y.p = a.y.p + b * a.y_bs;
@@ -164,7 +167,9 @@ void conv_wgrad(Stream& s, const ConvWgradArgs& a) {
     }
     return;
   }
-  for (int b = 0; b < (a.phases ? a.phases : (a.batch > 0 ? a.batch : 1)); ++b) {
+  const int nb = a.phases ? a.phases : (a.batch > 0 ? a.batch : 1);
+#pragma omp parallel for schedule(dynamic, 1) if (nb >= 8)
+  for (int b = 0; b < nb; ++b) {
     ConvWgradArgs c = a;
     take_phase(c, b);
     c.x.p = a.x.p + b * a.x_bs; c.dy.p = a.dy.p + b * a.dy_bs; c.dw = a.dw + b * a.dw_bs;
@@ -196,6 +201,7 @@ void wino_input_transform(Stream&, int m, int r, const TView& x, int pad, int pa
   const WinoMats wm = wino_mats(m, r);
   const int A = wm.A;
   const size_t T = (size_t)x.N * Th * Tw;
+#pragma omp parallel for collapse(3)
   for (int n = 0; n < x.N; ++n) for (int ty = 0; ty < Th; ++ty) for (int tx = 0; tx < Tw; ++tx) {
     const size_t tile = ((size_t)n * Th + ty) * Tw + tx;
     for (int c = 0; c < x.C; ++c) {
@@ -215,6 +221,7 @@ void wino_filter_transform(Stream&, int m, int r, const WShape& w, int mode, con
   const int A = wm.A, R = wm.r;
   const int K = mode == 0 ? w.Cip : w.Npad, Nn = mode == 0 ? w.Npad : w.Cip;
   const size_t total = (size_t)K * Nn;
+#pragma omp parallel for
   for (int k = 0; k < K; ++k) for (int n = 0; n < Nn; ++n) {
     float g[4][4], t[6][4];
     for (int a = 0; a < R; ++a) for (int b = 0; b < R; ++b)
@@ -230,6 +237,7 @@ void wino_output_transform(Stream&, int m, int r, const float* M, int Cm, int Th
   const WinoMats wm = wino_mats(m, r);
   const int A = wm.A;
   const size_t T = (size_t)y.N * Th * Tw;
+#pragma omp parallel for collapse(3)
   for (int n = 0; n < y.N; ++n) for (int ty = 0; ty < Th; ++ty) for (int tx = 0; tx < Tw; ++tx) {
     const size_t tile = ((size_t)n * Th + ty) * Tw + tx;
     for (int c = 0; c < Cout; ++c) {
@@ -252,6 +260,7 @@ void wino_dy_transform(Stream&, int m, int r, const TView& dy, int Th, int Tw, f
   const WinoMats wm = wino_mats(m, r);
   const int A = wm.A;
   const size_t T = (size_t)dy.N * Th * Tw;
+#pragma omp parallel for collapse(3)
   for (int n = 0; n < dy.N; ++n) for (int ty = 0; ty < Th; ++ty) for (int tx = 0; tx < Tw; ++tx) {
     const size_t tile = ((size_t)n * Th + ty) * Tw + tx;
     for (int c = 0; c < dy.C; ++c) {
@@ -272,7 +281,8 @@ void wino_filter_grad(Stream&, int m, int r, const WShape& w, const float* dU, f
   const WinoMats wm = wino_mats(m, r);
   const int A = wm.A, R = wm.r;
   const size_t total = (size_t)w.Cip * w.Npad;
-  for (size_t i = 0; i < total; ++i)
+#pragma omp parallel for
+  for (long i = 0; i < (long)total; ++i)
     for (int a = 0; a < R; ++a) for (int b = 0; b < R; ++b) {       // dg = G^T dU G
       float s = 0;
       for (int p = 0; p < A; ++p) for (int q = 0; q < A; ++q) s += wm.G[p * R + a] * dU[(size_t)(p * A + q) * total + i] * wm.G[q * R + b];
@@ -552,10 +562,11 @@ void scalar_axpby(Stream&, const float* a, float ca, const float* b, float cb, f
 }
 
 // ---- optimizer / layouts -----------------------------------------------------------------
-void adamw_step(Stream&, const AdamWArgs& a) {
+void adamw_step(Stream&, const AdamWArgs& a) {  // (elementwise: threads split the arena)
   const double bc1 = 1.0 - std::pow((double)a.beta1, a.step), bc2 = 1.0 - std::pow((double)a.beta2, a.step);
   const float decay = 1.f - a.lr * a.weight_decay, ss = (float)(a.lr / bc1), isb = (float)(1.0 / std::sqrt(bc2));
-  for (size_t i = 0; i < a.n; ++i) {
+#pragma omp parallel for
+  for (long i = 0; i < (long)a.n; ++i) {
     float p = a.p[i] * decay;
     const float m = a.m[i] * a.beta1 + (1.f - a.beta1) * a.g[i];
     const float v = a.v[i] * a.beta2 + (1.f - a.beta2) * a.g[i] * a.g[i];
@@ -569,6 +580,7 @@ size_t packed_elems(const WShape& w) {
 static int refch(const WShape& w, int cb) { return w.cimap ? w.cimap[cb] : (cb < w.Ci ? cb : -1); }
 void pack_weight(Stream&, const WShape& w, const float* src, float* dst) {
   std::memset(dst, 0, packed_elems(w) * sizeof(float));
+#pragma omp parallel for
   for (int cb = 0; cb < w.Cip; ++cb) {
     const int ci = refch(w, cb);
     if (ci < 0) continue;
@@ -584,6 +596,7 @@ void pack_weight(Stream&, const WShape& w, const float* src, float* dst) {
   }
 }
 void unpack_weight(Stream&, const WShape& w, const float* src, float* dst) {
+#pragma omp parallel for
   for (int cb = 0; cb < w.Cip; ++cb) {
     const int ci = refch(w, cb);
     if (ci < 0) continue;
