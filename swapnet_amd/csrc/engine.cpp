@@ -159,6 +159,49 @@ void Net::conv(const std::string& name, const Var& x, const Var& y, ConvKind kin
   ParamArena* A = &arena;
   const Gather gf = geo.fwd;
   const TView xv = x.v, yv = y.v;
+  // PatchGAN's 1-channel head conv (discriminators.py:131): taps on the N axis (ops.h head_*): the input
+  // is read once by a 1x1 conv with N = 16 instead of 16 times by an N = 1 implicit GEMM.
+  const bool head_on = !(getenv("SWN_HEAD_TAPN") && atoi(getenv("SWN_HEAD_TAPN")) == 0);
+  if (head_on && kind == CK_K4S1 && Co == 1 && Cip % 32 == 0 && actf == ACT_NONE && x.has_grad == y.has_grad) {
+    const size_t wt_off = reserve_dg(self, (size_t)Cip * 16), wt2_off = reserve_dg(self, (size_t)16 * Cip);
+    const size_t dwt_off = reserve_dg(self, (size_t)Cip * 16);
+    Var Z = alloc_var(xv.N, xv.H, xv.W, 16, false);          // Z forward, dZ backward (same scratch)
+    const TView zv = Z.v, ygv = y.g, xgv = x.g;
+    const bool has_grad = y.has_grad;
+    op->repack = [=](Net& n) {
+      const ParamDesc& wd = A->params[wi];
+      head_pack(n.ctx.s, wd.ws, A->w + wd.off, n.dg + wt_off, n.dg + wt2_off);
+    };
+    op->fwd = [=](Net& n) {
+      n.refresh_dgrad();
+      ConvFwdArgs a;
+      a.x = xv; a.g.Ho = xv.H; a.g.Wo = xv.W;               // 1x1, stride 1
+      a.w = n.dg + wt_off; a.Npad = 16; a.Cout = 16; a.y = zv;
+      conv_fwd(n.ctx.s, a);
+      head_gather(n.ctx.s, zv, bi >= 0 ? A->w + A->params[bi].off : nullptr, yv);
+    };
+    if (has_grad) op->grad_targets.push_back(x);
+    op->bwd = [=](Net& n, Op& me, bool wgrad, bool igrad) {
+      if (!has_grad) return;
+      const ParamDesc& wd = A->params[wi];
+      head_scatter(n.ctx.s, ygv, zv);
+      if (wgrad) {
+        ConvWgradArgs wa;
+        wa.x = xv; wa.g.Ho = xv.H; wa.g.Wo = xv.W; wa.dy = zv;
+        wa.dw = n.dg + dwt_off; wa.Npad = 16; wa.Cout = 16;
+        conv_wgrad(n.ctx.s, wa);
+        head_unpack_grad(n.ctx.s, wd.ws, n.dg + dwt_off, A->g + wd.off);
+        if (bi >= 0) bias_grad(n.ctx.s, ygv, A->g + A->params[bi].off);
+      }
+      if (me.reads_net_input && !igrad) return;
+      ConvFwdArgs d;
+      d.x = zv; d.g.Ho = xv.H; d.g.Wo = xv.W;
+      d.w = n.dg + wt2_off; d.Npad = Cip; d.Cout = Cip; d.y = xgv; d.accumulate = me.acc.empty() ? 0 : me.acc[0];
+      conv_fwd(n.ctx.s, d);
+    };
+    ops.push_back(std::move(op));
+    return;
+  }
   // tail conv: run as 4 folded sub-pixel phases on the un-upsampled input (25 instead of 64
   // taps per 2x2 outputs; see ops.h tail_fold_weights).  The folded weights and the folded
   // weight-gradient scratch live next to the dgrad operands and follow arena.version.

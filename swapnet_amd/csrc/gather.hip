@@ -263,9 +263,96 @@ void argmax_labels(Stream& s, const TView& x, int C, int32_t* labels) {
                      (uint8_t*)nullptr, labels);
   check_launch("argmax_labels");
 }
+// ---- 1-channel k4 s1 p1 head conv as taps-on-N (ops.h) ----------------------------------
+__global__ void head_pack_kernel(int Cip, int Npad, const float* packed, float* wt, float* wt2) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 16 * Cip) return;
+  const int t = i / Cip, c = i - t * Cip;
+  const float v = packed[(size_t)i * Npad];            // row (t*Cip + c), column 0
+  wt[c * 16 + t] = v;
+  wt2[(size_t)t * Cip + c] = v;
+}
+__global__ void head_unpack_kernel(int Cip, int Npad, const float* dwt, float* dpacked) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 16 * Cip) return;
+  const int t = i / Cip, c = i - t * Cip;
+  float* d = dpacked + (size_t)i * Npad;
+  d[0] = dwt[c * 16 + t];
+  for (int j = 1; j < Npad; ++j) d[j] = 0.f;
+}
+// one thread per output pixel: 16 shifted reads of one float each
+__global__ void head_gather_kernel(const float* z, int zcs, int N, int H, int W, const float* bias, float* y, int ycs) {
+  const int Ho = H - 1, Wo = W - 1;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N * Ho * Wo) return;
+  const int n = i / (Ho * Wo), rem = i - n * Ho * Wo, oy = rem / Wo, ox = rem - oy * Wo;
+  float acc = 0.f;
+#pragma unroll
+  for (int kh = 0; kh < 4; ++kh) {
+    const int sy = oy - 1 + kh;
+    if (sy < 0 || sy >= H) continue;
+#pragma unroll
+    for (int kw = 0; kw < 4; ++kw) {
+      const int sx = ox - 1 + kw;
+      if (sx < 0 || sx >= W) continue;
+      acc += z[((size_t)(n * H + sy) * W + sx) * zcs + kh * 4 + kw];
+    }
+  }
+  if (bias) acc += bias[0];
+  *reinterpret_cast<float4*>(y + (size_t)i * ycs) = make_float4(acc, 0.f, 0.f, 0.f);
+}
+// one thread per (input pixel, 4 taps): dZ[q][4 kh + kw] = dY[iy+1-kh][ix+1-kw]
+__global__ void head_scatter_kernel(const float* dy, int dcs, int N, int H, int W, float* dz, int zcs) {
+  const int Ho = H - 1, Wo = W - 1;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N * H * W * 4) return;
+  const int kh = i & 3, q = i >> 2;
+  const int n = q / (H * W), rem = q - n * H * W, iy = rem / W, ix = rem - iy * W;
+  const int oy = iy + 1 - kh;
+  float v[4] = {0.f, 0.f, 0.f, 0.f};
+  if (oy >= 0 && oy < Ho) {
+#pragma unroll
+    for (int kw = 0; kw < 4; ++kw) {
+      const int ox = ix + 1 - kw;
+      if (ox >= 0 && ox < Wo) v[kw] = dy[((size_t)(n * Ho + oy) * Wo + ox) * dcs];
+    }
+  }
+  *reinterpret_cast<float4*>(dz + (size_t)q * zcs + kh * 4) = make_float4(v[0], v[1], v[2], v[3]);
+}
+
 void labels_to_onehot(Stream& s, const int32_t* labels, const TView& y, int C) {
   hipLaunchKernelGGL(onehot_kernel, dim3(egrid(y.pixels())), dim3(256), 0, hs(s), labels, y.pixels(), C, y.p, y.cs);
   check_launch("labels_to_onehot");
+}
+
+static void check_head(const WShape& w) {
+  if (w.KH != 4 || w.KW != 4 || w.Co != 1) throw Error(1, "head conv: needs a 4x4 kernel with one output channel");
+}
+void head_pack(Stream& s, const WShape& w, const float* packed, float* wt, float* wt2) {
+  check_head(w);
+  hipLaunchKernelGGL(head_pack_kernel, dim3((16 * w.Cip + 255) / 256), dim3(256), 0, hs(s), w.Cip, w.Npad, packed, wt, wt2);
+  check_launch("head_pack");
+}
+void head_unpack_grad(Stream& s, const WShape& w, const float* dwt, float* dpacked) {
+  check_head(w);
+  hipLaunchKernelGGL(head_unpack_kernel, dim3((16 * w.Cip + 255) / 256), dim3(256), 0, hs(s), w.Cip, w.Npad, dwt, dpacked);
+  check_launch("head_unpack_grad");
+}
+void head_gather(Stream& s, const TView& z, const float* bias, const TView& y) {
+  if (z.C != 16 || y.H != z.H - 1 || y.W != z.W - 1 || y.N != z.N || y.cs % 4 || z.cs % 4)
+    throw Error(1, "head_gather: shape mismatch");
+  const int total = y.N * y.H * y.W;
+  hipLaunchKernelGGL(head_gather_kernel, dim3((total + 255) / 256), dim3(256), 0, hs(s), z.p, z.cs, z.N, z.H, z.W, bias, y.p,
+                     y.cs);
+  check_launch("head_gather");
+}
+void head_scatter(Stream& s, const TView& dy, const TView& dz) {
+  if (dz.C != 16 || dy.H != dz.H - 1 || dy.W != dz.W - 1 || dy.N != dz.N || dz.cs % 4)
+    throw Error(1, "head_scatter: shape mismatch");
+  const int total = dz.N * dz.H * dz.W * 4;
+  hipLaunchKernelGGL(head_scatter_kernel, dim3((total + 255) / 256), dim3(256), 0, hs(s), dy.p, dy.cs, dz.N, dz.H, dz.W, dz.p,
+                     dz.cs);
+  check_launch("head_scatter");
 }
 
 }  // namespace swn

@@ -218,4 +218,15 @@ void tail_fold_weights(Stream& s, const WShape& w, const float* packed, float* f
 // inverse for the weight gradient: dW[ky][kx] = sum over the 4 phases of dWfold[p][r(a,ky)][c(b,kx)]
 void tail_unfold_wgrad(Stream& s, const WShape& w, const float* dfolded, float* dpacked);
 
+// ---- PatchGAN's 1-channel k4 s1 p1 head conv (modules/discriminators.py:131) as "taps on the N axis" ----
+// An implicit GEMM with N = 1 reads every input element 16 times (once per tap) for one MAC each: it is
+// bound by the load path.  Instead Z[q][t] = sum_c x[q][c] w[t][c] (a 1x1 conv, N = 16 taps, x read
+// once), then y[n,oy,ox] = b + sum_{kh,kw} Z[n, oy-1+kh, ox-1+kw][4 kh + kw].  Backward uses the adjoint
+// gather dZ[n,iy,ix][4 kh + kw] = dY[n, iy+1-kh, ix+1-kw], dW = X^T dZ, dX = dZ W.
+// wt: [Cip][16], wt2: [16][Cip] (both derived from the packed [(t*Cip + c)][Npad] weight, column 0)
+void head_pack(Stream& s, const WShape& w, const float* packed, float* wt, float* wt2);
+void head_unpack_grad(Stream& s, const WShape& w, const float* dwt, float* dpacked);     // dpacked column 0; pads zeroed
+void head_gather(Stream& s, const TView& z, const float* bias, const TView& y);          // z.C = 16, y = (N, H-1, W-1, 4)
+void head_scatter(Stream& s, const TView& dy, const TView& dz);
+
 }  // namespace swn

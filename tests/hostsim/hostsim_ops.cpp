@@ -490,6 +490,40 @@ void labels_to_onehot(Stream&, const int32_t* labels, const TView& y, int C) {
     for (int c = 0; c < C; ++c) y.p[e * y.cs + c] = (c == labels[e] && labels[e] != 0) ? 1.f : 0.f;
 }
 
+// ---- 1-channel head conv as taps-on-N (ops.h) ---------------------------------------------
+void head_pack(Stream&, const WShape& w, const float* packed, float* wt, float* wt2) {
+  for (int t = 0; t < 16; ++t) for (int c = 0; c < w.Cip; ++c) {
+    const float v = packed[(size_t)(t * w.Cip + c) * w.Npad];
+    wt[c * 16 + t] = v; wt2[(size_t)t * w.Cip + c] = v;
+  }
+}
+void head_unpack_grad(Stream&, const WShape& w, const float* dwt, float* dpacked) {
+  for (int t = 0; t < 16; ++t) for (int c = 0; c < w.Cip; ++c) {
+    float* d = dpacked + (size_t)(t * w.Cip + c) * w.Npad;
+    d[0] = dwt[c * 16 + t];
+    for (int j = 1; j < w.Npad; ++j) d[j] = 0.f;
+  }
+}
+void head_gather(Stream&, const TView& z, const float* bias, const TView& y) {
+  for (int n = 0; n < y.N; ++n) for (int oy = 0; oy < y.H; ++oy) for (int ox = 0; ox < y.W; ++ox) {
+    float acc = 0.f;
+    for (int kh = 0; kh < 4; ++kh) for (int kw = 0; kw < 4; ++kw) {
+      const int sy = oy - 1 + kh, sx = ox - 1 + kw;
+      if (sy < 0 || sy >= z.H || sx < 0 || sx >= z.W) continue;
+      acc += at(z, n, sy, sx)[kh * 4 + kw];
+    }
+    float* d = at(y, n, oy, ox);
+    d[0] = acc + (bias ? bias[0] : 0.f); d[1] = d[2] = d[3] = 0.f;
+  }
+}
+void head_scatter(Stream&, const TView& dy, const TView& dz) {
+  for (int n = 0; n < dz.N; ++n) for (int iy = 0; iy < dz.H; ++iy) for (int ix = 0; ix < dz.W; ++ix)
+    for (int kh = 0; kh < 4; ++kh) for (int kw = 0; kw < 4; ++kw) {
+      const int oy = iy + 1 - kh, ox = ix + 1 - kw;
+      at(dz, n, iy, ix)[kh * 4 + kw] = (oy >= 0 && oy < dy.H && ox >= 0 && ox < dy.W) ? at(dy, n, oy, ox)[0] : 0.f;
+    }
+}
+
 // ---- losses ----------------------------------------------------------------------------
 static void gan(const TView& pred, float label, float scale, float* out, const TView* dp, int mode) {
   const size_t n = pred.pixels(); double acc = 0;

@@ -67,7 +67,10 @@ CONV_CASES_SIM = [
     (K4S2, 0, 2, 3, 16, 8, False), (K4S2, 0, 1, 32, 8, 36, True), (K3REFL, 0, 2, 8, 6, 8, True),
     (K4S1, 0, 2, 8, 9, 5, True), (K3ZERO, 0, 1, 3, 8, 8, True), (TAIL, 0, 1, 12, 6, 19, True),
     (K4S2, 1, 2, 8, 5, 12, False), (K4S2, 1, 1, 4, 3, 3, True),
-    (K3REFL, 0, 2, 32, 6, 32, True), (K3ZERO, 0, 1, 32, 8, 64, True),      # Winograd F(2x2,3x3) path
+    (K3REFL, 0, 2, 32, 6, 32, True), (K3ZERO, 0, 1, 32, 8, 64, True),      # Winograd F(2x2,3x3) / F(4x4,3x3)
+    (K3REFL, 0, 1, 32, 8, 32, True),                                       # F(4x4,3x3) + reflect fold (10x10 -> 3x3 tiles)
+    (K4S1, 0, 1, 32, 8, 32, True),                                         # F(3x3,4x4): 7x7 outputs, ragged tiles
+    (K4S1, 0, 2, 32, 6, 1, True),                                          # 1-channel head: taps on the N axis
 ]
 CONV_CASES_GPU = CONV_CASES_SIM + [
     (K4S2, 0, 3, 64, 40, 128, False),        # fast path, M = 3*400 (ragged tile), N = 128
