@@ -128,6 +128,53 @@ def test_texture_step_matches_oracle_and_reference(backend, oracle_run, gold):
 
 
 @pytest.mark.gpu
+def test_texture_step_at_full_resolution_matches_oracle():
+    """One texture G+D step at the C3 resolution (256x256, 12 ROIs; bs 1 so the CPU oracle finishes in
+    seconds): 8-level U-Net, 128x128 RoIAlign, VGG16 at 256x256 (6-point Winograd from 64 channels up),
+    PatchGAN at 31x31 -- losses / fakes 1e-3, gradients 5e-3 (D) / 1e-2 (G), RoIAlign bit-exact."""
+    ctx = backends.gpu_ctx()
+    B, H = 1, 256
+    torch.manual_seed(5)
+    G, D = O.texture_module_params(img_size=H), O.patchgan_params(22)
+    vgg = O.vgg16_feature_params()
+    batch = O.synth_texture_batch(B, H, H, seed=77)
+    taps = {}
+    with torch.no_grad():
+        O.texture_module_forward(G, batch[0], batch[1], batch[2], taps=taps)
+    st = O.TextureStepOracle({k: v.clone() for k, v in G.items()}, {k: v.clone() for k, v in D.items()}, vgg)
+    torch.manual_seed(23)
+    st.step(*batch)
+    m = engine.NativeModel(ctx, "texture", B, H, H, is_train=True)
+    try:
+        m.load_state_dict(engine.NET_G, G)
+        m.load_state_dict(engine.NET_D, D)
+        m.load_state_dict(engine.NET_VGG, vgg_state_dict(m, vgg))
+        m.set_hyper()
+        for i, t in enumerate(batch):
+            m.set_input(i, t)
+        m.forward(False, 0)
+        assert torch.equal(m.tap(engine.NET_G, "pooled").cpu(), taps["pooled"])
+        m.backward_D(st.labels[0], st.labels[1])
+        gD = m.state_dict(engine.NET_D, which=engine.W_GRAD, to_cpu=True)
+        m.optimizer_step(engine.NET_D)
+        m.backward_G(st.labels[2])
+        gG = m.state_dict(engine.NET_G, which=engine.W_GRAD, to_cpu=True)
+        L = m.losses()
+        for k, v in st.losses.items():
+            assert abs(L[k] - v) <= 1e-3 * abs(v) + 1e-6, (k, L[k], v)
+        assert rel(m.output(), st.fakes) < 1e-3
+        keys = list(G.keys())
+        for k, v in st.grads_D.items():
+            if not noise_bias(k, keys):
+                assert rel(gD[k], v) < 5e-3, ("gradD", k, rel(gD[k], v))
+        for k, v in st.grads_G.items():
+            if not noise_bias(k, keys):
+                assert rel(gG[k], v) < 1e-2, ("gradG", k, rel(gG[k], v))
+    finally:
+        m.close()
+
+
+@pytest.mark.gpu
 def test_texture_full_size_properties():
     """Config C3 shape (256x256, bs 16, ROIs, perceptual + style on): determinism of a full
     step, finite losses, RoIAlign output bit-exact vs the CPU restatement at full size."""

@@ -215,6 +215,45 @@ def test_warp_full_size_properties():
     m.close()
 
 
+@pytest.mark.gpu
+def test_warp_step_at_full_resolution_matches_oracle():
+    """One full G+D step at the C2 resolution (256x256; bs 2 so the CPU oracle finishes in seconds): the
+    shapes every full-size kernel path sees -- F(4x4,3x3) on 16x16 maps with the 18x18 reflect-padded
+    gradient, F(3x3,4x4) on PatchGAN's 31x31 map, the fused 4-phase tail conv at 128x128, the head conv --
+    against the oracle: losses / fakes 1e-3, gradients 5e-3 (D) / 1e-2 (G)."""
+    ctx = backends.gpu_ctx()
+    B, H = 2, 256
+    torch.manual_seed(3)
+    G, D = O.warp_module_params(), O.patchgan_params(22)
+    batch = O.synth_warp_batch(B, H, H, seed=99)
+    st = O.WarpStepOracle({k: v.clone() for k, v in G.items()}, {k: v.clone() for k, v in D.items()})
+    torch.manual_seed(17)
+    st.step(*batch)
+    m = engine.NativeModel(ctx, "warp", B, H, H)
+    try:
+        backends.reset_state(m, {engine.NET_G: G, engine.NET_D: D})
+        for i, t in enumerate(batch):
+            m.set_input(i, t)
+        m.forward(False, 0)
+        m.backward_D(st.labels[0], st.labels[1])
+        gD = m.state_dict(engine.NET_D, which=engine.W_GRAD, to_cpu=True)
+        m.optimizer_step(engine.NET_D)
+        m.backward_G(st.labels[2])
+        gG = m.state_dict(engine.NET_G, which=engine.W_GRAD, to_cpu=True)
+        L = m.losses()
+        for k, v in st.losses.items():
+            assert abs(L[k] - v) <= 1e-3 * abs(v) + 1e-6, (k, L[k], v)
+        assert rel(m.output(), st.fakes) < 1e-3
+        for k, v in st.grads_D.items():
+            if not noise_bias(k):
+                assert rel(gD[k], v) < 5e-3, ("gradD", k, rel(gD[k], v))
+        for k, v in st.grads_G.items():
+            if not noise_bias(k):
+                assert rel(gG[k], v) < 1e-2, ("gradG", k, rel(gG[k], v))
+    finally:
+        m.close()
+
+
 @pytest.mark.parametrize("backend", BACKENDS)
 @pytest.mark.parametrize("mode", ["lsgan", "wgan", "ce"])
 def test_other_gan_objectives_and_ce_mode(backend, mode, oracle_run):
