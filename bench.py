@@ -11,11 +11,11 @@ already resident in HBM (config C2 of BASELINE.json: "Warp stage, 256x256 synthe
 1xMI355X, fp32").  Train mode (dropout on), random-init weights of the reference architecture
 (kaiming, the reference's default), smooth GAN labels redrawn every step like the reference.
 N > 1: pure data parallel, weak scaling (bs 32 per GPU), RCCL all-reduce of the two flat
-gradient arenas; the D exchange overlaps with D1-forward/G-side work, the G exchange is
-issued right after backward_G.
+gradient arenas; the generator's backward runs in buckets (swn_model_backward_G_part) and each
+bucket's all-reduce overlaps the back-propagation of the earlier layers.
 
 Prints ONE JSON line (rank 0).  Extra objects:
-  roofline     -- dominant kernel family (conv_fwd 128x128 MFMA tile): algorithmic FLOPs
+  roofline     -- dominant kernel family (conv_fwd 256x128 MFMA tile): algorithmic FLOPs
                   (2*M*N*K per launch) / HIP-event time of those launches vs the 157.3 TFLOP/s
                   fp32 MFMA peak; `step_frac` = whole-step algorithmic FLOPs (251.34 GFLOP/img,
                   BASELINE.md section 3) / step time / peak.  (`achieved` counts the FLOPs the
@@ -129,12 +129,11 @@ def main():
         model.backward_D(lab[0], lab[1])
         xchg.allreduce_mean(gD)
         model.optimizer_step(engine.NET_D)
-        # generator backward in two parts: the decoder + residual-block gradients (59 % of the arena)
-        # travel over xGMI while the encoders are still being back-propagated
-        off, cnt = model.backward_G_part(lab[2], 0)
-        xchg.begin(gG[off:off + cnt])
-        _, cnt2 = model.backward_G_part(lab[2], 1)
-        xchg.begin(gG[:cnt2])
+        # generator backward in buckets (decoder + late resblocks first, encoders last): each bucket's
+        # gradients travel over xGMI while the earlier layers are still being back-propagated
+        for part in range(model.backward_G_parts()):
+            off, cnt = model.backward_G_part(lab[2], part)
+            xchg.begin(gG[off:off + cnt])
         xchg.finish()
         model.optimizer_step(engine.NET_G)
 

@@ -111,10 +111,12 @@ int swn_model_forward(swn_model* m, int training, uint64_t dropout_seed);
 int swn_model_backward_D(swn_model* m, float label_fake, float label_real);
 /* backward_G (warp_model.py:141-167, texture_model.py:157-180) */
 int swn_model_backward_G(swn_model* m, float label_real);
-/* backward_G in two parts so the data-parallel exchange of the generator gradients overlaps the
- * rest of the backward pass: part 0 runs the loss head and the generator backward down to a
- * split layer (decoder + residual blocks; their arena range [off, off+count) is final on return),
- * part 1 the remaining encoder layers ([0, off)). */
+/* backward_G in `nparts` buckets (part = 0 .. nparts-1, in this order) so the data-parallel exchange of
+ * the generator gradients overlaps the rest of the backward pass: part 0 runs the loss head and the
+ * last layers (decoder + late residual blocks), each further part the next group of earlier layers;
+ * on return the arena range [ready_off, ready_off+ready_count) holds final gradients and can be handed to
+ * the all-reduce while the next part runs.  The ranges tile the arena from its end to its start. */
+int swn_model_backward_G_parts(swn_model* m, int* nparts);
 int swn_model_backward_G_part(swn_model* m, float label_real, int part, size_t* ready_off, size_t* ready_count);
 /* optimizer_{G,D}.step() (models/base_gan.py:199,203): fused AdamW over the net's arena */
 int swn_model_optimizer_step(swn_model* m, int net);

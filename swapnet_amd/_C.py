@@ -54,6 +54,7 @@ _PROTOS = {
     "swn_model_forward": ([_vp, _i, C.c_uint64], _i),
     "swn_model_backward_D": ([_vp, _f, _f], _i),
     "swn_model_backward_G": ([_vp, _f], _i),
+    "swn_model_backward_G_parts": ([_vp, C.POINTER(C.c_int)], _i),
     "swn_model_backward_G_part": ([_vp, _f, _i, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)], _i),
     "swn_model_optimizer_step": ([_vp, _i], _i),
     "swn_model_step": ([_vp, C.POINTER(_f * 3), _i, C.c_uint64], _i),

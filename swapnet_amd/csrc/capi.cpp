@@ -203,9 +203,12 @@ int swn_model_backward_D(swn_model* m, float lf, float lr) {
 int swn_model_backward_G(swn_model* m, float lr) {
   return guard([&] { REQUIRE(m && m->m->is_train, "model was not created for training"); m->m->backward_G(lr); });
 }
+int swn_model_backward_G_parts(swn_model* m, int* nparts) {
+  return guard([&] { REQUIRE(m && nparts, "NULL argument"); *nparts = m->m->backward_G_parts(); });
+}
 int swn_model_backward_G_part(swn_model* m, float lr, int part, size_t* off, size_t* count) {
   return guard([&] {
-    REQUIRE(m && m->m->is_train && (part == 0 || part == 1), "bad argument");
+    REQUIRE(m && m->m->is_train && part >= 0 && part < m->m->backward_G_parts(), "bad argument");
     m->m->backward_G_part(lr, part, off, count);
   });
 }

@@ -607,20 +607,27 @@ int Net::split_point(double frac, size_t* arena_off) const {
   return (int)ops.size();
 }
 
+// Bucket boundaries (fractions of the generator's gradient arena, high to low = backward order).
+// WarpModule: [.70,1] = decoder + resblock convs 5-7, [.41,.70) = resblock convs 1-4, [.10,.41) =
+// cloth_down6, cloth_up1/2, resblock conv 0, [0,.10) = the encoders -- the last (exposed) exchange is
+// 10 % of the bytes, the others overlap the rest of the backward pass.
+static const double kGradCuts[] = {0.70, 0.41, 0.10};
+int Model::backward_G_parts() const { return (int)(sizeof(kGradCuts) / sizeof(kGradCuts[0])) + 1; }
+
 void Model::backward_G_part(float label_real, int part, size_t* ready_off, size_t* ready_count) {
-  size_t off = 0;
-  const int sp = G->split_point(0.35, &off);
+  const int np = backward_G_parts();
+  if (part < 0 || part >= np) throw Error(1, "backward_G_part: part out of range");
+  size_t hi_off = arenaG.n, lo_off = 0;
+  int hi_op = (int)G->ops.size(), lo_op = 0;
+  if (part > 0) hi_op = G->split_point(kGradCuts[part - 1], &hi_off);
+  if (part < np - 1) lo_op = G->split_point(kGradCuts[part], &lo_off);
   if (part == 0) {
     backward_G_head(label_real);
     G->refresh_dgrad();
-    G->backward_range(true, false, sp, (int)G->ops.size());
-    if (ready_off) *ready_off = off;
-    if (ready_count) *ready_count = arenaG.n - off;
-  } else {
-    G->backward_range(true, false, 0, sp);
-    if (ready_off) *ready_off = 0;
-    if (ready_count) *ready_count = off;
   }
+  G->backward_range(true, false, lo_op, hi_op);
+  if (ready_off) *ready_off = lo_off;
+  if (ready_count) *ready_count = hi_off - lo_off;
 }
 
 // ---------------------------------------------------------------------------------------

@@ -160,6 +160,7 @@ class Model {
   // backward_G in two parts for gradient-exchange overlap: part 0 = everything down to the split
   // op (its arena range [off, n) is final on return), part 1 = the rest ([0, off)).
   virtual void backward_G_head(float label_real) = 0;
+  int backward_G_parts() const;
   void backward_G_part(float label_real, int part, size_t* ready_off, size_t* ready_count);
   void optimizer_step(int net);
   void step(const float labels[3], bool training, uint64_t seed);

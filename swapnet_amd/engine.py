@@ -196,6 +196,12 @@ class NativeModel:
     def backward_G(self, label_real):
         self.lib.call("swn_model_backward_G", self.handle, C.c_float(label_real))
 
+    def backward_G_parts(self):
+        """Number of buckets backward_G_part splits the generator backward into."""
+        n = C.c_int()
+        self.lib.call("swn_model_backward_G_parts", self.handle, C.byref(n))
+        return n.value
+
     def backward_G_part(self, label_real, part):
         """Returns (offset, count) of the generator gradient-arena range that is final after this part."""
         off, cnt = C.c_size_t(), C.c_size_t()

@@ -133,10 +133,9 @@ class BaseGAN(BaseModel, ABC):
             self._xchg.allreduce_mean(m.grad_arena(engine.NET_D))
             m.optimizer_step(engine.NET_D)
             gG = m.grad_arena(engine.NET_G)
-            off, cnt = m.backward_G_part(labels[2], 0)       # decoder + resblocks: exchange overlaps part 1
-            self._xchg.begin(gG[off:off + cnt])
-            _, cnt2 = m.backward_G_part(labels[2], 1)
-            self._xchg.begin(gG[:cnt2])
+            for part in range(m.backward_G_parts()):         # each bucket's exchange overlaps the next part
+                off, cnt = m.backward_G_part(labels[2], part)
+                self._xchg.begin(gG[off:off + cnt])
             self._xchg.finish()
             m.optimizer_step(engine.NET_G)
         self._losses_stale = True

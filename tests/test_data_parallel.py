@@ -38,12 +38,15 @@ def _worker(rank, world, port, out_dir):
     x.allreduce_mean(m.grad_arena(engine.NET_D))
     m.optimizer_step(engine.NET_D)
     gG = m.grad_arena(engine.NET_G)
-    off, cnt = m.backward_G_part(lab[2], 0)            # split backward: exchange part 0 while part 1 runs
-    assert 0 < off and off + cnt == gG.numel()
-    x.begin(gG[off:off + cnt])
-    off2, cnt2 = m.backward_G_part(lab[2], 1)
-    assert off2 == 0 and cnt2 == off
-    x.begin(gG[:cnt2])
+    end = gG.numel()                                   # bucketed backward: exchange part p while part p+1 runs
+    nparts = m.backward_G_parts()
+    assert nparts >= 2
+    for part in range(nparts):
+        off, cnt = m.backward_G_part(lab[2], part)
+        assert cnt > 0 and off + cnt == end, (part, off, cnt, end)      # buckets tile the arena end -> start
+        x.begin(gG[off:off + cnt])
+        end = off
+    assert end == 0
     x.finish()
     m.optimizer_step(engine.NET_G)
     if rank == 0:
