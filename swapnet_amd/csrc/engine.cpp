@@ -238,6 +238,8 @@ void Net::conv(const std::string& name, const Var& x, const Var& y, ConvKind kin
   const int wTw2 = ceil_div(x.v.W + (kind == CK_K3S1_REFLECT ? 2 : 0), wm);
   const size_t wT2 = (size_t)wN * wTh2 * wTw2;
   size_t uf_off = 0, ub_off = 0;
+  float* keepV = nullptr;         // V = B^T d B of the forward input, reused by the weight gradient
+  if (wino && keep_wino_inputs && y.has_grad) keepV = static_cast<float*>(ctx.alloc((size_t)wP * wT * Cip * sizeof(float)));
   if (wino) {
     uf_off = reserve_dg(self, (size_t)wP * Cip * Cop);
     wsV_need = std::max(wsV_need, std::max((size_t)wP * wT * Cip, (size_t)wP * wT2 * Cop));
@@ -255,9 +257,10 @@ void Net::conv(const std::string& name, const Var& x, const Var& y, ConvKind kin
     a.act = actf; a.y = yv; a.Cout = Co;
     if (wino) {
       n.refresh_dgrad();
-      wino_input_transform(n.ctx.s, wm, wr, xv, 1, gf.pad_mode, wTh, wTw, n.wsV);
+      float* V = keepV ? keepV : n.wsV;
+      wino_input_transform(n.ctx.s, wm, wr, xv, 1, gf.pad_mode, wTh, wTw, V);
       ConvFwdArgs g;
-      g.x = plane_view(n.wsV, wT, Cip); g.g.Ho = 1; g.g.Wo = (int)wT;
+      g.x = plane_view(V, wT, Cip); g.g.Ho = 1; g.g.Wo = (int)wT;
       g.w = n.dg + uf_off; g.Npad = Cop; g.Cout = Co;
       g.y = plane_view(n.wsM, wT, Cop);
       g.batch = wP; g.x_bs = wT * Cip; g.w_bs = (size_t)Cip * Cop; g.y_bs = wT * Cop;
@@ -331,10 +334,11 @@ void Net::conv(const std::string& name, const Var& x, const Var& y, ConvKind kin
       wa.x = xv; wa.g = gf; wa.dy = dY; wa.dw = A->g + wd.off; wa.Npad = wd.ws.Npad; wa.Cout = Co;
       if (wino) {
         // dU[t] = V[t]^T dM[t] (wP batched reductions over the tiles), then dW = G^T dU G
-        wino_input_transform(n.ctx.s, wm, wr, xv, 1, gf.pad_mode, wTh, wTw, n.wsV);
+        float* V = keepV ? keepV : n.wsV;
+        if (!keepV) wino_input_transform(n.ctx.s, wm, wr, xv, 1, gf.pad_mode, wTh, wTw, V);
         wino_dy_transform(n.ctx.s, wm, wr, dY, wTh, wTw, n.wsM);
         ConvWgradArgs g;
-        g.x = plane_view(n.wsV, wT, Cip); g.g.Ho = 1; g.g.Wo = (int)wT;
+        g.x = plane_view(V, wT, Cip); g.g.Ho = 1; g.g.Wo = (int)wT;
         g.dy = plane_view(n.wsM, wT, Cop);
         g.dw = n.wsU; g.Npad = Cop; g.Cout = Co;
         g.batch = wP; g.x_bs = wT * Cip; g.dy_bs = wT * Cop; g.dw_bs = (size_t)Cip * Cop;

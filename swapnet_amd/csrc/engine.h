@@ -87,6 +87,9 @@ class Net {
   float* dg = nullptr;      // dgrad operands of this net's convs
   size_t dg_n = 0;
   int dg_version = 0;       // arena.version the operands were derived from
+  // set by the model for nets whose weight gradients are taken (G, the 2B discriminator instance): the
+  // Winograd-transformed input of every such conv is kept from forward for its weight gradient
+  bool keep_wino_inputs = false;
   // Winograd scratch shared by all 3x3 layers of the net (V/M planes, dU): sized in finalize()
   size_t wsV_need = 0, wsM_need = 0, wsU_need = 0;
   float *wsV = nullptr, *wsM = nullptr, *wsU = nullptr;

@@ -156,6 +156,7 @@ class WarpModel final : public Model {
   WarpModel(Ctx& c, int B_, int H_, int W_, bool train, float drop) {
     ctx = &c; B = B_; H = H_; W = W_; is_train = train; dropout = drop;
     G = std::make_unique<Net>(c, arenaG);
+    G->keep_wino_inputs = train;
     body = G->alloc_var(B, H, W, 4, false);
     cloth = G->alloc_var(B, H, W, 20, false);
     Dx = G->alloc_var(train ? 2 * B : B, H, W, 24, train);
@@ -169,6 +170,7 @@ class WarpModel final : public Model {
       for (int i = 0; i < 19; ++i) cimap[i] = 3 + i;     // cloth channels follow the 3 body channels
       for (int i = 0; i < 3; ++i) cimap[20 + i] = i;
       D2 = std::make_unique<Net>(c, arenaD);
+      D2->keep_wino_inputs = true;
       pred2 = build_patchgan(*D2, Dx, 3, cimap);
       arenaD.allocate(c);
       D2->finalize({pred2});

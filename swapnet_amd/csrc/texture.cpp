@@ -140,6 +140,7 @@ class TextureModel final : public Model {
   TextureModel(Ctx& c, int B_, int H_, int W_, bool train, int nroi) {
     ctx = &c; B = B_; H = H_; W = W_; is_train = train; num_roi = nroi;
     G = std::make_unique<Net>(c, arenaG);
+    G->keep_wino_inputs = train;
     tex = G->alloc_var(B, H, W, 4, false);
     unet_in = G->alloc_var(B, H, W, 56, true);     // d(unet_in)[0:36) feeds the encode branch
     Dx = G->alloc_var(train ? 2 * B : B, H, W, 24, train);
@@ -154,6 +155,7 @@ class TextureModel final : public Model {
     for (int i = 0; i < 3; ++i) cimap[i] = 19 + i;       // textures follow the 19 cloth channels
     for (int i = 0; i < 19; ++i) cimap[4 + i] = i;
     D2 = std::make_unique<Net>(c, arenaD);
+    D2->keep_wino_inputs = true;
     pred2 = build_patchgan(*D2, Dx, 3, cimap);
     arenaD.allocate(c);
     D2->finalize({pred2});
