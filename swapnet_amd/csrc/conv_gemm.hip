@@ -95,8 +95,9 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_fwd_kernel(GemmP p) {
   constexpr int NTHR = 64 * WGM * WGN;
   constexpr int AROWS = NTHR / 8;        // A-tile rows covered by one pass (8 lanes x 16 B per row)
   constexpr int RA = BM / AROWS;
-  constexpr int BROWS = NTHR / (BN / 4);  // B-tile rows covered by one pass
-  constexpr int RB = 32 / BROWS;
+  constexpr int B4 = BN / 4;             // float4 per B-tile row
+  constexpr int RB = 32 * B4 / NTHR;     // float4 of the 32 x BN weight tile per thread (element i = t + r * NTHR)
+  static_assert(32 * B4 % NTHR == 0, "B tile must divide evenly over the workgroup");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* As = smem;
   float* Bs = smem + 2 * T::A_FLOATS;
@@ -128,7 +129,6 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_fwd_kernel(GemmP p) {
       a_iy0[r] = 0; a_ix0[r] = 0; a_base[r] = -1;
     }
   }
-  const int bcol = (t % (BN / 4)) * 4, brow0 = t / (BN / 4);
   const int He = p.xH << p.ups, We = p.xW << p.ups;
 
   float4 ra[RA], rb[RB];
@@ -160,8 +160,9 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_fwd_kernel(GemmP p) {
     }
 #pragma unroll
     for (int r = 0; r < RB; ++r) {
-      const int krow = k0 + brow0 + r * BROWS;
-      const int n = n0 + bcol;
+      const int bi = t + r * NTHR;
+      const int krow = k0 + bi / B4;
+      const int n = n0 + (bi % B4) * 4;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       if (krow < p.K && n < p.Npad) v = *reinterpret_cast<const float4*>(p.w + (size_t)krow * p.Npad + n);
       rb[r] = v;
@@ -173,8 +174,10 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_fwd_kernel(GemmP p) {
     for (int r = 0; r < RA; ++r) *reinterpret_cast<float4*>(A + (p0 + AROWS * r) * AS + 4 * q) = ra[r];
     float* B = Bs + buf * T::B_FLOATS;
 #pragma unroll
-    for (int r = 0; r < RB; ++r)
-      *reinterpret_cast<float4*>(B + (brow0 + r * BROWS) * BN + bcol) = rb[r];
+    for (int r = 0; r < RB; ++r) {
+      const int bi = t + r * NTHR;
+      *reinterpret_cast<float4*>(B + (bi / B4) * BN + (bi % B4) * 4) = rb[r];
+    }
   };
 
   f32x16 acc[MT][NT];
@@ -1244,7 +1247,11 @@ void conv_fwd(Stream& s, const ConvFwdArgs& a) {
   static const int big = getenv("SWN_TILE256") ? atoi(getenv("SWN_TILE256")) : 1;
   p.x_bs = a.x_bs; p.w_bs = a.w_bs; p.y_bs = a.y_bs;
   const int nb = a.phases ? a.phases : std::max(a.batch, 1);
-  if (a.Npad > 64 && big && fast && p.M >= 2048) launch_fwd<2, 2, 4, 2>(s, p, fast, nb);
+  static const int t192 = getenv("SWN_TILE192") ? atoi(getenv("SWN_TILE192")) : 1;
+  // N in (128, 192] (the tail conv's input gradient into the 192-channel concat): a 128x192 tile instead
+  // of two 128-wide column tiles of which the second is half empty
+  if (t192 && a.Npad > 128 && a.Npad <= 192) launch_fwd<2, 3, 2, 2>(s, p, fast, nb);
+  else if (a.Npad > 64 && big && fast && p.M >= 2048) launch_fwd<2, 2, 4, 2>(s, p, fast, nb);
   else if (a.Npad > 64) launch_fwd<2, 2, 2, 2>(s, p, fast, nb);
   else if (a.Npad > 32) launch_fwd<2, 1, 2, 2>(s, p, fast, nb);   // (a 2-wave 128x64 tile with 64x64 wave tiles measured 4 % slower)
   else if (!narrow_on()) launch_fwd<1, 1, 4, 1>(s, p, fast, nb);
