@@ -4,6 +4,8 @@
 #include <string>
 
 #include "../../include/swapnet_hip.h"
+#include <cstdlib>
+
 #include "engine.h"
 
 using namespace swn;
@@ -52,6 +54,7 @@ int swn_ctx_create(int device, void* hip_stream, int create_stream, size_t works
     else device_check(device);
     if (workspace_bytes < (size_t)64 << 20) workspace_bytes = (size_t)64 << 20;
     h->c = std::make_unique<Ctx>(st, workspace_bytes);
+    if (!(getenv("SWN_OVERLAP") && atoi(getenv("SWN_OVERLAP")) == 0)) h->c->enable_side(device);
     *out = h.release();
   });
 }

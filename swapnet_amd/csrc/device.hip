@@ -46,6 +46,16 @@ void device_check(int device) {
 void stream_destroy(void* h) {
   if (h) (void)hipStreamDestroy((hipStream_t)h);
 }
+void* event_create() {
+  hipEvent_t e;
+  SWN_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  return (void*)e;
+}
+void event_destroy(void* ev) {
+  if (ev) (void)hipEventDestroy((hipEvent_t)ev);
+}
+void event_record(void* ev, Stream& s) { SWN_HIP_CHECK(hipEventRecord((hipEvent_t)ev, hs(s))); }
+void stream_wait_event(Stream& s, void* ev) { SWN_HIP_CHECK(hipStreamWaitEvent(hs(s), (hipEvent_t)ev, 0)); }
 int is_device_build() { return 1; }
 
 }  // namespace swn

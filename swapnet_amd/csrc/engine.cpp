@@ -17,6 +17,35 @@ Ctx::Ctx(const Stream& shared) : s(shared), owns_ws(false) {}
 Ctx::~Ctx() {
   for (void* p : allocs) dev_free(p);
   if (owns_ws) dev_free(s.ws);
+  if (has_side) {
+    dev_free(side.ws);
+    for (void* e : fork_events) event_destroy(e);
+    event_destroy(join_event);
+    stream_destroy(owned_side_stream);
+  }
+}
+void Ctx::enable_side(int device) {
+  if (has_side || !is_device_build()) return;
+  owned_side_stream = stream_create(device);
+  side.handle = owned_side_stream;
+  side.ws_bytes = s.ws_bytes;
+  side.ws = static_cast<char*>(dev_alloc(side.ws_bytes));
+  for (int i = 0; i < 8; ++i) fork_events.push_back(event_create());
+  join_event = event_create();
+  has_side = true;
+}
+Stream& Ctx::fork_side() {
+  void* ev = fork_events[fork_i++ % fork_events.size()];
+  event_record(ev, s);
+  stream_wait_event(side, ev);
+  side_dirty = true;
+  return side;
+}
+void Ctx::join_side() {
+  if (!has_side || !side_dirty) return;
+  event_record(join_event, side);
+  stream_wait_event(s, join_event);
+  side_dirty = false;
 }
 void* Ctx::alloc(size_t bytes) {
   void* p = dev_alloc(bytes);
@@ -186,12 +215,13 @@ void Net::conv(const std::string& name, const Var& x, const Var& y, ConvKind kin
       const ParamDesc& wd = A->params[wi];
       head_scatter(n.ctx.s, ygv, zv);
       if (wgrad) {
+        Stream& sw = n.wgrad_stream();
         ConvWgradArgs wa;
         wa.x = xv; wa.g.Ho = xv.H; wa.g.Wo = xv.W; wa.dy = zv;
         wa.dw = n.dg + dwt_off; wa.Npad = 16; wa.Cout = 16;
-        conv_wgrad(n.ctx.s, wa);
-        head_unpack_grad(n.ctx.s, wd.ws, n.dg + dwt_off, A->g + wd.off);
-        if (bi >= 0) bias_grad(n.ctx.s, ygv, A->g + A->params[bi].off);
+        conv_wgrad(sw, wa);
+        head_unpack_grad(sw, wd.ws, n.dg + dwt_off, A->g + wd.off);
+        if (bi >= 0) bias_grad(sw, ygv, A->g + A->params[bi].off);
       }
       if (me.reads_net_input && !igrad) return;
       ConvFwdArgs d;
@@ -330,30 +360,32 @@ void Net::conv(const std::string& name, const Var& x, const Var& y, ConvKind kin
     if (actf != ACT_NONE) { act_bwd(n.ctx.s, ygv, yv, scr, actf, 0); dY = scr; }
     const ParamDesc& wd = A->params[wi];
     if (wgrad) {
+      Stream& sw = n.wgrad_stream();          // dY is final: the weight-gradient work may run beside the dgrad chain
       ConvWgradArgs wa;
       wa.x = xv; wa.g = gf; wa.dy = dY; wa.dw = A->g + wd.off; wa.Npad = wd.ws.Npad; wa.Cout = Co;
       if (wino) {
         // dU[t] = V[t]^T dM[t] (wP batched reductions over the tiles), then dW = G^T dU G
         float* V = keepV ? keepV : n.wsV;
-        if (!keepV) wino_input_transform(n.ctx.s, wm, wr, xv, 1, gf.pad_mode, wTh, wTw, V);
-        wino_dy_transform(n.ctx.s, wm, wr, dY, wTh, wTw, n.wsM);
+        float* dM = n.wgrad_planes(sw);
+        if (!keepV) wino_input_transform(sw, wm, wr, xv, 1, gf.pad_mode, wTh, wTw, V);
+        wino_dy_transform(sw, wm, wr, dY, wTh, wTw, dM);
         ConvWgradArgs g;
         g.x = plane_view(V, wT, Cip); g.g.Ho = 1; g.g.Wo = (int)wT;
-        g.dy = plane_view(n.wsM, wT, Cop);
+        g.dy = plane_view(dM, wT, Cop);
         g.dw = n.wsU; g.Npad = Cop; g.Cout = Co;
         g.batch = wP; g.x_bs = wT * Cip; g.dy_bs = wT * Cop; g.dw_bs = (size_t)Cip * Cop;
-        conv_wgrad(n.ctx.s, g);
-        wino_filter_grad(n.ctx.s, wm, wr, wd.ws, n.wsU, A->g + wd.off);
+        conv_wgrad(sw, g);
+        wino_filter_grad(sw, wm, wr, wd.ws, n.wsU, A->g + wd.off);
       } else if (!folded) {
-        conv_wgrad(n.ctx.s, wa);
+        conv_wgrad(sw, wa);
       } else {
         wa.g = Gather(); wa.g.KH = wa.g.KW = 3; wa.g.stride = 1; wa.g.pad_t = wa.g.pad_l = 1; wa.g.Ho = xv.H; wa.g.Wo = xv.W;
         wa.om.ymul = wa.om.xmul = 2; wa.tail4 = 1;
         wa.dw = n.dg + dfold_off;
-        conv_wgrad(n.ctx.s, wa);
-        tail_unfold_wgrad(n.ctx.s, wd.ws, n.dg + dfold_off, A->g + wd.off);
+        conv_wgrad(sw, wa);
+        tail_unfold_wgrad(sw, wd.ws, n.dg + dfold_off, A->g + wd.off);
       }
-      if (bi >= 0) bias_grad(n.ctx.s, dY, A->g + A->params[bi].off);
+      if (bi >= 0) bias_grad(sw, dY, A->g + A->params[bi].off);
     }
     if (!want_dx || (me.reads_net_input && !igrad)) return;
     const int accf = me.acc.empty() ? 0 : me.acc[0];
@@ -441,8 +473,9 @@ void Net::convT(const std::string& name, const Var& x, const Var& y, int Co, boo
       wa.g.Ho = xv.H; wa.g.Wo = xv.W;
       wa.dy = ygv; wa.om.ymul = 2; wa.om.xmul = 2; wa.phases = 4;
       wa.dw = A->g + wd.off; wa.dw_bs = phase_elems; wa.Npad = wd.ws.Npad; wa.Cout = Co;
-      conv_wgrad(n.ctx.s, wa);
-      if (bi >= 0) bias_grad(n.ctx.s, ygv, A->g + A->params[bi].off);
+      Stream& sw = n.wgrad_stream();
+      conv_wgrad(sw, wa);
+      if (bi >= 0) bias_grad(sw, ygv, A->g + A->params[bi].off);
     }
     if (!want_dx || (me.reads_net_input && !igrad)) return;
     ConvFwdArgs d;
@@ -580,6 +613,7 @@ void Net::finalize(const std::vector<Var>& pre) {
     }
   }
   dg = dg_n ? static_cast<float*>(ctx.alloc(dg_n * sizeof(float))) : nullptr;
+  if (wsM_need && ctx.has_side && keep_wino_inputs) wsM2 = static_cast<float*>(ctx.alloc(wsM_need * sizeof(float)));
   if (wsV_need) wsV = static_cast<float*>(ctx.alloc(wsV_need * sizeof(float)));
   if (wsM_need) wsM = static_cast<float*>(ctx.alloc(wsM_need * sizeof(float)));
   if (wsU_need) wsU = static_cast<float*>(ctx.alloc(wsU_need * sizeof(float)));
@@ -588,9 +622,32 @@ void Net::finalize(const std::vector<Var>& pre) {
 
 void Net::forward() {
   if (!finalized_) throw Error(1, "Net::forward before finalize");
+  prefetch_dgrad();
   for (auto& op : ops) op->fwd(*this);
 }
+void Net::prefetch_dgrad() {
+  if (!ctx.has_side || dg_version == arena.version || refresh_pending) return;
+  bool any = false;
+  for (auto& op : ops) any = any || (bool)op->repack;
+  if (!any) return;
+  ctx.fork_side();                 // after the optimizer step that produced the weights and after every
+                                   // main-stream reader of the previous operands
+  std::swap(ctx.s, ctx.side);      // the re-pack launchers use ctx.s
+  try {
+    for (auto& op : ops)
+      if (op->repack) op->repack(*this);
+  } catch (...) { std::swap(ctx.s, ctx.side); throw; }
+  std::swap(ctx.s, ctx.side);
+  if (!refresh_event) refresh_event = event_create();
+  event_record(refresh_event, ctx.side);
+  refresh_pending = true;
+  dg_version = arena.version;
+}
 void Net::refresh_dgrad() {
+  if (refresh_pending) {
+    stream_wait_event(ctx.s, refresh_event);
+    refresh_pending = false;
+  }
   if (dg_version == arena.version) return;
   for (auto& op : ops)
     if (op->repack) op->repack(*this);
@@ -599,6 +656,7 @@ void Net::refresh_dgrad() {
 void Net::backward(bool wgrad, bool igrad) { backward_range(wgrad, igrad, 0, (int)ops.size()); }
 void Net::backward_range(bool wgrad, bool igrad, int op_begin, int op_end) {
   for (int i = op_end - 1; i >= op_begin; --i) ops[i]->bwd(*this, *ops[i], wgrad, igrad);
+  ctx.join_side();      // weight gradients of the range are final for whatever the main stream does next
 }
 int Net::split_point(double frac, size_t* arena_off) const {
   const size_t want = (size_t)(frac * (double)arena.n);

@@ -14,6 +14,20 @@ namespace swn {
 
 struct Ctx {
   Stream s;
+  // Side stream for weight-gradient work (wgrad GEMMs, their Winograd transforms, bias gradients, slab
+  // sums).  In backward only the input-gradient chain is sequential; a layer's weight gradient just has
+  // to be done before the optimizer step.  Forked per layer after dY is final (event on `s`), joined at
+  // the end of every backward range: the HBM-bound kernels of one stream overlap the MFMA-bound GEMMs
+  // of the other and kernel tails fill.  Own split / partial workspace.
+  Stream side;
+  bool has_side = false, side_dirty = false;
+  std::vector<void*> fork_events;
+  size_t fork_i = 0;
+  void* join_event = nullptr;
+  void* owned_side_stream = nullptr;
+  void enable_side(int device);
+  Stream& fork_side();        // side stream, ordered after everything enqueued on `s` so far
+  void join_side();           // `s` continues after the side stream's work (no-op if nothing was forked)
   std::vector<void*> allocs;
   size_t bytes_allocated = 0;
   explicit Ctx(void* stream, size_t ws_bytes);
@@ -78,6 +92,7 @@ struct Op {
 class Net {
  public:
   Net(Ctx& c, ParamArena& a) : ctx(c), arena(a) {}
+  ~Net() { if (refresh_event) event_destroy(refresh_event); }
   Ctx& ctx;
   ParamArena& arena;
   std::vector<std::unique_ptr<Op>> ops;
@@ -93,6 +108,11 @@ class Net {
   // Winograd scratch shared by all 3x3 layers of the net (V/M planes, dU): sized in finalize()
   size_t wsV_need = 0, wsM_need = 0, wsU_need = 0;
   float *wsV = nullptr, *wsM = nullptr, *wsU = nullptr;
+  float* wsM2 = nullptr;     // dY-transform planes of the weight gradient when it runs on the side stream
+  // stream for this layer's weight-gradient work: the side stream (forked now) when the context has
+  // one and the net keeps its Winograd inputs (so the work touches no scratch of the main stream)
+  Stream& wgrad_stream() { return (ctx.has_side && keep_wino_inputs) ? ctx.fork_side() : ctx.s; }
+  float* wgrad_planes(const Stream& sw) const { return (&sw == &ctx.side && wsM2) ? wsM2 : wsM; }
   std::vector<std::pair<Op*, size_t>> dg_layout;
 
   Var alloc_var(int N, int H, int W, int C, bool need_grad);
@@ -116,7 +136,12 @@ class Net {
   void backward_range(bool wgrad, bool igrad, int op_begin, int op_end);   // ops [begin,end) in reverse
   // first op whose parameters start at or after `frac` of the arena (ops are registered in arena order)
   int split_point(double frac, size_t* arena_off) const;
-  void refresh_dgrad();     // no-op when the operands are current
+  void refresh_dgrad();     // no-op when the operands are current (waits for a prefetch in flight)
+  // with a side stream: start the refresh there (forward() calls it, so the HBM-bound re-packs /
+  // filter transforms overlap the first layers); refresh_dgrad() is the wait point
+  void prefetch_dgrad();
+  void* refresh_event = nullptr;
+  bool refresh_pending = false;
 
  private:
   size_t reserve_dg(Op* op, size_t elems);

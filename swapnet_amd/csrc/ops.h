@@ -17,6 +17,12 @@ struct Stream {
   size_t ws_bytes = 0;
 };
 
+// ---- stream ordering (the weight-gradient side stream of engine.cpp) ------------------------------
+void* event_create();
+void event_destroy(void* ev);
+void event_record(void* ev, Stream& s);
+void stream_wait_event(Stream& s, void* ev);      // work enqueued on s afterwards starts after the recorded point
+
 // ---- memory -------------------------------------------------------------------------
 void* dev_alloc(size_t bytes);            // zero-filled
 void dev_free(void* p);

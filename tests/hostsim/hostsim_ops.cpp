@@ -26,6 +26,10 @@ void stream_sync(Stream&) {}
 void* stream_create(int) { return nullptr; }
 void stream_destroy(void*) {}
 void device_check(int) {}
+void* event_create() { return nullptr; }
+void event_destroy(void*) {}
+void event_record(void*, Stream&) {}
+void stream_wait_event(Stream&, void*) {}
 int is_device_build() { return 0; }
 void conv_force_naive(int) {}
 void prof_enable(int) {}
