@@ -43,6 +43,11 @@ int swn_is_device_build(void);
  * create_stream != 0: the library creates and owns a private non-blocking stream. */
 int swn_ctx_create(int device, void* hip_stream, int create_stream, size_t workspace_bytes, swn_ctx** out);
 int swn_ctx_destroy(swn_ctx* ctx);
+/* The context runs weight-gradient work and the derived-weight refresh on an internal second stream
+ * (DESIGN.md section 4).  on = 0 keeps everything in order on the caller's stream (used by bench.py's
+ * per-kernel roofline pass so that kernel durations are not inflated by co-running kernels); results
+ * are identical either way.  Synchronises. */
+int swn_ctx_set_overlap(swn_ctx* ctx, int on);
 int swn_ctx_sync(swn_ctx* ctx);
 int swn_ctx_bytes_allocated(swn_ctx* ctx, size_t* out);
 

@@ -66,6 +66,14 @@ int swn_ctx_destroy(swn_ctx* ctx) {
     delete ctx;
   });
 }
+int swn_ctx_set_overlap(swn_ctx* ctx, int on) {
+  return guard([&] {
+    REQUIRE(ctx, "ctx is NULL");
+    ctx->c->join_side();
+    stream_sync(ctx->c->s);
+    ctx->c->side_enabled = on != 0;
+  });
+}
 int swn_ctx_sync(swn_ctx* ctx) {
   return guard([&] { REQUIRE(ctx, "ctx is NULL"); stream_sync(ctx->c->s); });
 }

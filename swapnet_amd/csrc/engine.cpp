@@ -626,7 +626,7 @@ void Net::forward() {
   for (auto& op : ops) op->fwd(*this);
 }
 void Net::prefetch_dgrad() {
-  if (!ctx.has_side || dg_version == arena.version || refresh_pending) return;
+  if (!ctx.use_side() || dg_version == arena.version || refresh_pending) return;
   bool any = false;
   for (auto& op : ops) any = any || (bool)op->repack;
   if (!any) return;

@@ -21,6 +21,8 @@ struct Ctx {
   // of the other and kernel tails fill.  Own split / partial workspace.
   Stream side;
   bool has_side = false, side_dirty = false;
+  bool side_enabled = true;   // runtime switch (swn_ctx_set_overlap): off = everything in order on `s`
+  bool use_side() const { return has_side && side_enabled; }
   std::vector<void*> fork_events;
   size_t fork_i = 0;
   void* join_event = nullptr;
@@ -111,7 +113,7 @@ class Net {
   float* wsM2 = nullptr;     // dY-transform planes of the weight gradient when it runs on the side stream
   // stream for this layer's weight-gradient work: the side stream (forked now) when the context has
   // one and the net keeps its Winograd inputs (so the work touches no scratch of the main stream)
-  Stream& wgrad_stream() { return (ctx.has_side && keep_wino_inputs) ? ctx.fork_side() : ctx.s; }
+  Stream& wgrad_stream() { return (ctx.use_side() && keep_wino_inputs) ? ctx.fork_side() : ctx.s; }
   float* wgrad_planes(const Stream& sw) const { return (&sw == &ctx.side && wsM2) ? wsM2 : wsM; }
   std::vector<std::pair<Op*, size_t>> dg_layout;
 

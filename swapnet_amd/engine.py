@@ -37,6 +37,10 @@ class Context:
         self.lib.call("swn_ctx_create", dev_index, stream, create, C.c_size_t(workspace_mb << 20), C.byref(h))
         self.handle = h
 
+    def set_overlap(self, on):
+        """Side stream on/off (results identical; off gives un-overlapped per-kernel timings)."""
+        self.lib.call("swn_ctx_set_overlap", self.handle, int(bool(on)))
+
     def sync(self):
         self.lib.call("swn_ctx_sync", self.handle)
 
