@@ -172,6 +172,7 @@ def main():
                                 f"train mode (dropout 0.5), WarpModule 137.6M + PatchGAN 2.8M params, AdamW"),
                    "global_batch": world * B, "parallelism": f"dp{world}"},
         "losses_finite": all(v == v and abs(v) < 1e30 for v in losses.values()),
+        "hbm_allocated_gb": round(ctx.bytes_allocated() / 1e9, 2),      # arenas + activations (+ 2 x 1 GB split workspaces)
     }
 
     if rank == 0 and not args.no_roofline:
