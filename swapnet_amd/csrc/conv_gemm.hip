@@ -339,7 +339,8 @@ __global__ __launch_bounds__(256) void conv_fwd_narrow_kernel(GemmP p) {
       a_iy0[r] = 0; a_ix0[r] = 0; a_base[r] = -1;
     }
   }
-  const int bcol = (t & 7) * 4, brow = t >> 3;      // threads 0..127 move the 16 x 32 weight tile
+  const int brow = t & 15, bcol = (t >> 4) * 4;     // threads 0..127 move the 16 x 32 weight tile; this mapping
+                                                    // makes the transposed LDS stores ((bcol+i)*20 + brow) conflict-free
   const int He = p.xH << p.ups, We = p.xW << p.ups;
 
   float4 ra[RA], rb;
@@ -504,7 +505,8 @@ __global__ __launch_bounds__(256) void tail_fwd4_kernel(GemmP p) {
       a_iy0[r] = 0; a_ix0[r] = 0; a_base[r] = -1;
     }
   }
-  const int bcol = (t & 7) * 4, brow = t >> 3;      // threads 0..127: one float4 of each phase's 16 x 32 weight tile
+  const int brow = t & 15, bcol = (t >> 4) * 4;     // threads 0..127: one float4 of each phase's 16 x 32 weight tile
+                                                    // (conflict-free transposed LDS stores)
 
   float4 ra[RA], rb[4];
   auto load_tiles = [&](int kb) {
