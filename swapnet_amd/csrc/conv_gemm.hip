@@ -198,17 +198,20 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_fwd_kernel(GemmP p) {
     const float* A = As + buf * T::A_FLOATS + (wm * MT * 32 + (lane & 31)) * AS + 16 * h;
     const float* B = Bs + buf * T::B_FLOATS + (16 * h) * BN + wn * NT * 32 + (lane & 31);
     float af[MT][16], bf[NT][16];
+    // issue order = consumption order (k-steps 0-3 of every fragment first, then 4-7, ...): LDS returns
+    // in order, so the first MFMAs wait for a quarter of the reads only and the rest land under them
 #pragma unroll
-    for (int i = 0; i < MT; ++i)
+    for (int g = 0; g < 4; ++g) {
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
+      for (int i = 0; i < MT; ++i) {
         const float4 v = *reinterpret_cast<const float4*>(A + i * 32 * AS + 4 * g);
         af[i][4 * g] = v.x; af[i][4 * g + 1] = v.y; af[i][4 * g + 2] = v.z; af[i][4 * g + 3] = v.w;
       }
 #pragma unroll
-    for (int j = 0; j < NT; ++j)
+      for (int e = 0; e < 4; ++e)
 #pragma unroll
-      for (int st = 0; st < 16; ++st) bf[j][st] = B[st * BN + j * 32];
+        for (int j = 0; j < NT; ++j) bf[j][4 * g + e] = B[(4 * g + e) * BN + j * 32];
+    }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int st = 0; st < 16; ++st)
