@@ -122,9 +122,11 @@ def main():
         lab = draw_labels()
         step_no[0] += 1
         seed = step_no[0] * 1000 + rank
-        if world == 1:
+        if world == 1 and not os.environ.get("SWAPNET_BENCH_PHASED"):
             model.step(lab, training=True, seed=seed)
             return
+        # (SWAPNET_BENCH_PHASED=1 runs this multi-GPU call sequence on one GPU, exchanges being no-ops, to
+        # price the phased / bucketed form against the fused swn_model_step)
         model.forward(True, seed)
         model.backward_D(lab[0], lab[1])
         xchg.allreduce_mean(gD)

@@ -83,3 +83,81 @@ def test_two_rank_gloo_step_equals_single_process_big_batch(tmp_path):
                 continue                       # round-off-only gradients
             err = float((dp[key][k] - v).norm() / (v.norm() + 1e-30))
             assert err < 2e-4, (key, k, err)
+
+
+@pytest.mark.parametrize("backend", [pytest.param("sim", id="hostsim"),
+                                     pytest.param("gpu", id="mi355x", marks=pytest.mark.gpu)])
+@pytest.mark.parametrize("stage", ["warp", "texture"])
+def test_bucketed_generator_backward_equals_monolithic(stage, backend):
+    """swn_model_backward_G_part over all buckets == swn_model_backward_G, bit for bit, for both
+    generators; each bucket's reported arena range is already final when its part returns (checked by
+    snapshotting the range right after the part and comparing with the finished gradient)."""
+    from oracle import swapnet_oracle as O
+    from swapnet_amd import engine
+    from tests import backends
+    ctx = backends.gpu_ctx() if backend == "gpu" else backends.hostsim_ctx()
+    torch.manual_seed(0)
+    D = O.patchgan_params(22)
+    if stage == "warp":
+        G = O.warp_module_params()
+        batch = O.synth_warp_batch(1, 64, 64, seed=3)
+    else:
+        G = O.texture_module_params(img_size=64)
+        batch = O.synth_texture_batch(1, 64, 64, seed=3)
+    m = engine.NativeModel(ctx, stage, 1, 64, 64, is_train=True)
+    try:
+        m.load_state_dict(0, G); m.load_state_dict(1, D); m.set_hyper()
+        if stage == "texture":
+            vgg = O.vgg16_feature_params()
+            names = list(m.param_infos(engine.NET_VGG).keys())
+            m.load_state_dict(engine.NET_VGG, {names[2 * i + j]: t for i, wb in enumerate(vgg) for j, t in enumerate(wb)})
+        for i, t in enumerate(batch):
+            m.set_input(i, t)
+        m.forward(False, 0)
+        m.backward_G(0.9)
+        ref = m.grad_arena(engine.NET_G).clone()
+        m.grad_arena(engine.NET_G).zero_()
+        m.forward(False, 0)
+        end, snaps = ref.numel(), []
+        for part in range(m.backward_G_parts()):
+            off, cnt = m.backward_G_part(0.9, part)
+            assert cnt > 0 and off + cnt == end
+            snaps.append((off, cnt, m.grad_arena(engine.NET_G)[off:off + cnt].clone()))
+            end = off
+        assert end == 0
+        got = m.grad_arena(engine.NET_G)
+        assert torch.equal(got.cpu(), ref.cpu())
+        for off, cnt, snap in snaps:
+            assert torch.equal(snap.cpu(), ref[off:off + cnt].cpu()), (off, cnt)
+    finally:
+        m.close()
+
+
+@pytest.mark.gpu
+def test_second_stream_leaves_results_bit_identical():
+    """swn_ctx_set_overlap: the weight-gradient side stream / operand prefetch reorder work in time only.
+    Two steps from the same state, overlap on vs off, must give bitwise equal weights and losses."""
+    from oracle import swapnet_oracle as O
+    from swapnet_amd import engine
+    from tests import backends
+    ctx = backends.gpu_ctx()
+    torch.manual_seed(1)
+    G, D = O.warp_module_params(), O.patchgan_params(22)
+    batch = O.synth_warp_batch(4, 128, 128, seed=11)
+    m = engine.NativeModel(ctx, "warp", 4, 128, 128, is_train=True)
+    out = []
+    try:
+        for on in (True, False, True):
+            ctx.set_overlap(on)
+            backends.reset_state(m, {engine.NET_G: G, engine.NET_D: D})
+            for i, t in enumerate(batch):
+                m.set_input(i, t)
+            for s in range(2):
+                m.step([0.9, 0.8, 1.0], training=True, seed=5 + s)
+            out.append((m.losses(), m.weight_arena(0).clone().cpu(), m.weight_arena(1).clone().cpu()))
+    finally:
+        ctx.set_overlap(True)
+        m.close()
+    for o in out[1:]:
+        assert o[0] == out[0][0]
+        assert torch.equal(o[1], out[0][1]) and torch.equal(o[2], out[0][2])
