@@ -77,6 +77,9 @@ def main():
                          "perceptual + style losses on), reported for reference")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--with-h2d", action="store_true",
+                    help="additionally time steps that re-upload the batch from host memory every step through "
+                         "the model API (set_input + step), reported as `h2d_inclusive` (never `value`)")
     args = ap.parse_args()
 
     from swapnet_amd import _C, engine, parallel, synthetic
@@ -226,6 +229,29 @@ def main():
                 "all_gemm_kernels": {n: {"tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2),
                                          "ms_per_step": round(v["ms"] / nprof, 3)} for n, v in sorted(kernels.items())},
             }
+    if rank == 0 and world == 1 and args.with_h2d and not texture:
+        # the boundary hands over host buffers (warp_model.py:99-104): PCIe-inclusive rate, one-hot fp32
+        # cloths (the reference's format) and integer label maps (device-side one-hot)
+        host = [batch["bodys"], batch["input_cloths"], batch["target_cloths"]]
+        labels = [t.argmax(1).to(torch.int32) * (t.sum(1) > 0) for t in host[1:]]
+        pinned = [t.pin_memory() for t in host]          # DataLoader(pin_memory=True)
+        res = {}
+        for name, feed in (("onehot_fp32", lambda: [model.set_input(i, t) for i, t in enumerate(host)]),
+                           ("onehot_fp32_pinned", lambda: [model.set_input(i, t) for i, t in enumerate(pinned)]),
+                           ("label_maps", lambda: (model.set_input(0, host[0]), model.set_input_labels(1, labels[0]),
+                                                   model.set_input_labels(2, labels[1])))):
+            for _ in range(2):
+                feed(); one_step()
+            fence()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                feed(); one_step()
+            fence()
+            d1 = (time.perf_counter() - t1) / args.steps
+            res[name] = {"images_per_sec": round(B / d1, 2), "ms_per_step": round(d1 * 1e3, 3)}
+        res["h2d_bytes_per_step"] = {"onehot_fp32": sum(t.numel() * 4 for t in host),
+                                     "label_maps": host[0].numel() * 4 + sum(t.numel() * 4 for t in labels)}
+        out["h2d_inclusive"] = res
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not texture:
         out["cpu_baseline"] = cpu_baseline()
     if rank == 0:

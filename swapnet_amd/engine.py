@@ -36,6 +36,51 @@ class Context:
         h = C.c_void_p()
         self.lib.call("swn_ctx_create", dev_index, stream, create, C.c_size_t(workspace_mb << 20), C.byref(h))
         self.handle = h
+        self._copy_stream = None
+
+    def upload(self, tensor, dtype, key=None):
+        """Host batch -> device on a dedicated copy stream: `set_input` is called right after
+        `optimize_parameters` returned (train.py:62-64) while that step's kernels are still running, so the
+        H2D transfer (335 MB/step for one-hot cloths at bs 32) hides under them instead of queueing
+        behind them.  With `key` the destination is one of two persistent staging buffers per input slot
+        (no allocator traffic -- a fresh hipMalloc per step synchronises the device); the copy stream
+        waits for the kernel that last read the buffer it is about to overwrite (`consumed`), the main
+        stream for the copy.  Returns (device tensor, token for `consumed`)."""
+        t = tensor.detach()
+        if self.device.type != "cuda" or t.is_cuda:
+            return t.to(device=self.device, dtype=dtype).contiguous(), None
+        t = t.to(dtype=dtype).contiguous()
+        if self._copy_stream is None:
+            self._copy_stream = torch.cuda.Stream(device=self.device)
+            self._staging = {}
+        cs, main = self._copy_stream, torch.cuda.current_stream(self.device)
+        if key is None:
+            with torch.cuda.stream(cs):
+                d = t.to(self.device, non_blocking=True)
+            main.wait_stream(cs)
+            d.record_stream(main)
+            return d, None
+        st = self._staging.setdefault(key, {"bufs": [None, None], "events": [None, None], "i": 0})
+        i = st["i"]
+        st["i"] ^= 1
+        buf = st["bufs"][i]
+        if buf is None or buf.shape != t.shape or buf.dtype != dtype:
+            buf = torch.empty(t.shape, dtype=dtype, device=self.device)
+            st["bufs"][i], st["events"][i] = buf, None
+        if st["events"][i] is not None:
+            cs.wait_event(st["events"][i])
+        with torch.cuda.stream(cs):
+            buf.copy_(t, non_blocking=True)
+        main.wait_stream(cs)
+        return buf, (key, i)
+
+    def consumed(self, token):
+        """The kernel reading an `upload(..., key=)` buffer has been enqueued on the current stream."""
+        if token is None:
+            return
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.device))
+        self._staging[token[0]]["events"][token[1]] = ev
 
     def set_overlap(self, on):
         """Side stream on/off (results identical; off gives un-overlapped per-kernel timings)."""
@@ -162,19 +207,21 @@ class NativeModel:
 
     # ---- data / step ----------------------------------------------------------------------
     def set_input(self, slot, tensor):
-        t = self._dev(tensor)
+        t, token = self.ctx.upload(tensor, torch.float32, key=(id(self), "in", slot))
         if t.dim() == 3:                       # rois (B,R,4)
             n, c, h, w = t.shape[0], t.shape[1], t.shape[2], 1
         else:
             n, c, h, w = t.shape
         self.lib.call("swn_model_set_input", self.handle, slot, _C.ptr(t), n, c, h, w)
+        self.ctx.consumed(token)
         self._keep = [t]
 
     def set_input_labels(self, slot, labels):
         """Integer cloth label map (B,H,W) -> one-hot expansion on the device."""
-        t = labels.detach().to(device=self.ctx.device, dtype=torch.int32).contiguous()
+        t, token = self.ctx.upload(labels, torch.int32, key=(id(self), "lab", slot))
         n, h, w = t.shape
         self.lib.call("swn_model_set_input_labels", self.handle, slot, _C.ptr(t), n, h, w)
+        self.ctx.consumed(token)
         self._keep_labels = t
 
     def forward(self, training=False, seed=0):
