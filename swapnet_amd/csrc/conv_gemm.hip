@@ -1193,7 +1193,7 @@ static void launch_fwd_narrow(Stream& s, GemmP& p, bool fast, int batch) {
 }
 
 static bool narrow_on() {
-  static const bool on = !(getenv("SWN_NARROW") && atoi(getenv("SWN_NARROW")) == 0);
+  const bool on = !(getenv("SWN_NARROW") && atoi(getenv("SWN_NARROW")) == 0);     // read per launch: tests toggle it
   return on;
 }
 
@@ -1223,7 +1223,7 @@ static void check_tail4(const Gather& g, const OutMap& om, int batch, int phases
 void conv_fwd(Stream& s, const ConvFwdArgs& a) {
   if (a.tail4) {
     check_tail4(a.g, a.om, a.batch, a.phases);
-    static const bool fused = !(getenv("SWN_TAIL4") && atoi(getenv("SWN_TAIL4")) == 0);
+    const bool fused = !(getenv("SWN_TAIL4") && atoi(getenv("SWN_TAIL4")) == 0);
     if (g_force_naive || !fused || a.x.C % 32 || a.Npad > 20 || a.accumulate) {
       for (int ph = 0; ph < 4; ++ph) {
         ConvFwdArgs c = tail_phase_args(a, ph, 0);
@@ -1304,7 +1304,7 @@ static void launch_wgrad(Stream& s, GemmP& p, int batch) {
 void conv_wgrad(Stream& s, const ConvWgradArgs& a) {
   if (a.tail4) {
     check_tail4(a.g, a.om, a.batch, a.phases);
-    static const bool fused = !(getenv("SWN_TAIL4") && atoi(getenv("SWN_TAIL4")) == 0);
+    const bool fused = !(getenv("SWN_TAIL4") && atoi(getenv("SWN_TAIL4")) == 0);
     if (g_force_naive || !fused || a.x.C != 192 || a.Npad > 20 || a.g.Wo % 16 || a.g.Wo != a.x.W || a.g.Ho != a.x.H) {
       for (int ph = 0; ph < 4; ++ph) {
         ConvWgradArgs c = tail_phase_args(a, ph, 0);

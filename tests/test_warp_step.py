@@ -336,3 +336,36 @@ def test_resblock_conv_variants_match_oracle(backend, variant, oracle_run, monke
                 assert rel(gG[k], v) < 1e-2, (variant, k, rel(gG[k], v))
     finally:
         m.close()
+
+
+@pytest.mark.gpu
+def test_fast_algorithms_track_the_direct_kernels_over_training_steps(monkeypatch):
+    """Winograd (F(4x4,3x3), F(3x3,4x4)), the fused tail kernels and the taps-on-N head change the
+    summation order, not the math.  Five free-running training steps (dropout on, Adam) at 128x128 with
+    all of them against five steps with every conv on the direct implicit-GEMM kernel: the loss
+    trajectories must stay within 1 % (Adam's sign-like first steps amplify round-off, so this bounds
+    drift, the per-step parity tests bound error)."""
+    ctx = backends.gpu_ctx()
+    B, H = 4, 128
+    torch.manual_seed(2)
+    G, D = O.warp_module_params(), O.patchgan_params(22)
+    batch = O.synth_warp_batch(B, H, H, seed=21)
+    traj = []
+    for direct in (False, True):
+        for k in ("SWN_WINOGRAD", "SWN_TAIL4", "SWN_HEAD_TAPN", "SWN_NARROW"):
+            (monkeypatch.setenv(k, "0") if direct else monkeypatch.delenv(k, raising=False))
+        m = engine.NativeModel(ctx, "warp", B, H, H, is_train=True)
+        try:
+            backends.reset_state(m, {engine.NET_G: G, engine.NET_D: D})
+            for i, t in enumerate(batch):
+                m.set_input(i, t)
+            steps = []
+            for s in range(5):
+                m.step([0.9, 0.8, 1.0], training=True, seed=100 + s)
+                steps.append(m.losses())
+            traj.append(steps)
+        finally:
+            m.close()
+    for a, b in zip(*traj):
+        for k in ("D", "G", "G_ce", "G_gan"):
+            assert abs(a[k] - b[k]) <= 1e-2 * abs(b[k]) + 1e-4, (k, a[k], b[k])
