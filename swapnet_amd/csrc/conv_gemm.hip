@@ -12,13 +12,15 @@
 // A is never materialised: the im2col tile is gathered from the NHWC activation straight
 // into LDS (16-byte loads along the channel axis = full 128-B lines per 8 lanes).
 //
-// CDNA4 mapping: 256-thread workgroup = 4 wave64, one per SIMD; v_mfma_f32_32x32x2_f32
-// (exact fp32, 64 FLOP/clk/SIMD); BK = 32 per LDS stage, double-buffered LDS with the next
-// stage prefetched into VGPRs while the current one feeds the matrix pipe (one barrier per
-// stage).  A-tile rows are padded to 33 floats so the 32 lanes of a half-wave (one output
-// row each, same k) hit 32 distinct banks on ds_read_b32; the W / dY tile is read along its
-// contiguous axis.  Small-M x large-K layers (cloth_down5/6, cloth_up1) are split along K
-// (wgrad: along pixels) into deterministic slabs that a reduce kernel sums in fixed order.
+// CDNA4 mapping: v_mfma_f32_32x32x2_f32 (exact fp32, 64 FLOP/clk/SIMD); workgroups of 4 wave64
+// (128 x {192,128,64,32} tiles) or 8 wave64 (256 x 128), wave tile 64 x 64; BK = 32 per LDS stage,
+// double-buffered LDS with the next stage prefetched into VGPRs while the current one feeds the
+// matrix pipe (one barrier per stage).  A-tile rows are padded to 36 floats (16-byte aligned,
+// conflict-free ds_read_b128 of a lane's 16 k-values, k order permuted inside the stage); the
+// W / dY tile is read along its contiguous axis.  Launch modes: batched (Winograd planes), the four
+// sub-pixel phases of a stride-2 scatter in one grid, deterministic split-K / split-M slabs chosen by
+// a wave-quantisation cost model.  Narrow outputs (Cout <= 32) use v_mfma_f32_4x4x1 kernels (one
+// pixel / one k-row per lane); the folded tail conv has fused 4-phase kernels.  See DESIGN.md 4.
 #include <array>
 #include <cmath>
 #include <cstdio>
