@@ -56,7 +56,7 @@ struct ConvFwdArgs {
   TView y;                    // y.C = Cout (logical), may be a slice
   OutMap om;
   int Cout = 0;               // valid output channels (<= Npad)
-  // batched mode (Winograd: 16 independent GEMMs in one launch): element strides between batches
+  // batched mode (Winograd: the 16 / 36 plane GEMMs in one launch): element strides between batches
   int batch = 1;
   size_t x_bs = 0, w_bs = 0, y_bs = 0;
   // sub-pixel phase mode (k4s2 transposed convs and the dgrad of k4s2 convs): with phases = 4 one

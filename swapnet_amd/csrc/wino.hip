@@ -1,22 +1,23 @@
-// swapnet_amd -- Winograd F(2x2,3x3), F(4x4,3x3) and F(3x3,4x4) transforms for the stride-1 convolutions
-// (ResidualBlock convs, modules/layers.py:131-138 = 59 % of WarpModule's FLOPs; VGG16 convs of
-// PerceptualLoss, modules/losses/perceptual.py:26-42).
+// swapnet_amd -- Winograd F(m x m, r x r) transforms for the stride-1 convolutions: the ResidualBlock
+// convs (modules/layers.py:131-138 = 59 % of WarpModule's FLOPs), the VGG16 convs of PerceptualLoss
+// (modules/losses/perceptual.py:26-42) and PatchGAN's k4 s1 conv (modules/discriminators.py:124-128).
 //
-//   Y = A^T [ (G g G^T) .* (B^T d B) ] A        2.25x fewer multiplies than the direct form
+//   Y = A^T [ (G g G^T) .* (B^T d B) ] A
 //
-// The element-wise products summed over input channels are 16 independent GEMMs
-// M[t] = V[t] (T x C) * U[t] (C x Co), t = 0..15, executed by the MFMA implicit-GEMM kernel in
-// batched mode (conv_gemm.hip); this file holds the HBM-bound transforms around them:
-//   wino_input_transform   d (4x4 input patches, reflect / zero padding) -> V[16][T][C]
-//   wino_filter_transform  packed W -> U[16][K][N]      (forward, or flipped+transposed for dgrad)
-//   wino_output_transform  M[16][T][Co] -> y (2x2 per tile) + bias + activation
-//   wino_dy_transform      dY (2x2 per tile) -> dM[16][T][Co] = A dY A^T        (weight gradient)
-//   wino_filter_grad       dU[16][K][N] -> dW packed = G^T dU G
-// All 16-byte vectorised along the channel axis; fp32 throughout.
+//   F(4x4,3x3)  P = 36 planes per 4x4 outputs (4x fewer multiplies), points 0, +-1, +-2, inf   [H, W % 4 == 0]
+//   F(2x2,3x3)  P = 16 planes per 2x2 outputs (2.25x fewer)                                     [otherwise]
+//   F(3x3,4x4)  P = 36 planes per 3x3 outputs of a 4x4 filter (4x fewer), same points / same B^T
 //
-// F(4x4,3x3) (interpolation points 0, +-1, +-2, inf; 36 GEMMs per 4x4 outputs = 4x fewer multiplies)
-// uses the same five steps through the generic kernels at the end of the file; the engine picks
-// it when H and W are multiples of 4.
+// The element-wise products summed over input channels are P independent GEMMs
+// M[t] = V[t] (T x C) * U[t] (C x Co), executed by the MFMA implicit-GEMM kernel in batched mode
+// (conv_gemm.hip); this file holds the HBM-bound transforms around them:
+//   wino_input_transform   d (input patches, reflect / zero padding) -> V[P][T][C]
+//   wino_filter_transform  packed W -> U[P][K][N]       (forward, or flipped+transposed for dgrad)
+//   wino_output_transform  M[P][T][Co] -> y (m x m per tile, ragged edge) + bias + activation
+//   wino_dy_transform      dY (m x m per tile) -> dM[P][T][Co] = A dY A^T        (weight gradient)
+//   wino_filter_grad       dU[P][K][N] -> dW packed = G^T dU G
+// All 16-byte vectorised along the channel axis; fp32 throughout.  F(2x2,3x3) is hand-written, the two
+// 6-point forms instantiate the generic kernels at the end of the file from constant matrices.
 #include "hip_util.h"
 
 namespace swn {
