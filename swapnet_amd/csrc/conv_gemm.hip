@@ -134,41 +134,73 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_fwd_kernel(GemmP p) {
   const int He = p.xH << p.ups, We = p.xW << p.ups;
 
   float4 ra[RA], rb[RB];
-  auto load_tiles = [&](int kb) {
-    const int k0 = kb * 32;
-    int kh, kw, ci;
-    bool kvalid = true;
-    if (FAST) {
-      const int tap = k0 / p.xC;           // wave-uniform: a 32-wide k block never straddles a tap
-      ci = k0 - tap * p.xC + 4 * q;
-      kh = tap / p.KW; kw = tap - kh * p.KW;
-    } else {
-      const int k = k0 + 4 * q;
-      kvalid = k < p.K;
-      const int tap = k / p.xC;
-      ci = k - tap * p.xC;
-      kh = tap / p.KW; kw = tap - kh * p.KW;
-    }
+  // FAST (Cin % 32 == 0): a 32-wide k block never straddles a tap, and the tap changes only every Cin/32
+  // stages (never for the 1x1 batched Winograd GEMMs).  The per-row source offsets of the current tap are
+  // therefore cached; a stage only advances the channel offset.  This keeps ~100 VALU/SALU instructions
+  // (tap decode, padding rules, 64-bit address math per row) out of every stage -- issue slots the matrix
+  // pipe waits for when both waves of a SIMD sit behind the same workgroup barrier.
+  int b_row[RB], b_off[RB];               // this thread's rows of the 32 x BN weight tile; offset inside the panel
+#pragma unroll
+  for (int r = 0; r < RB; ++r) {
+    const int bi = t + r * NTHR;
+    const int n = n0 + (bi % B4) * 4;
+    b_row[r] = bi / B4;
+    b_off[r] = n < p.Npad ? b_row[r] * p.Npad + n : -1;
+  }
+  int a_off[RA];                          // element offset of this row's pixel for the cached tap, -1 = zero fill
+  int ld_tap = -1, ld_ci = 0;             // wave-uniform loader state
+  auto set_tap = [&](int tap) {
+    const int kh = tap / p.KW, kw = tap - kh * p.KW;
 #pragma unroll
     for (int r = 0; r < RA; ++r) {
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (a_base[r] >= 0 && kvalid) {
+      int off = -1;
+      if (a_base[r] >= 0) {
         const int sy = src_coord(a_iy0[r] + kh, He, p.pad_mode, p.ups);
         const int sx = src_coord(a_ix0[r] + kw, We, p.pad_mode, p.ups);
-        if (sy >= 0 && sx >= 0)
-          v = *reinterpret_cast<const float4*>(p.x + (size_t)a_base[r] + (size_t)(sy * p.xW + sx) * p.xcs + ci);
+        if (sy >= 0 && sx >= 0) off = a_base[r] + (sy * p.xW + sx) * p.xcs + 4 * q;
       }
-      ra[r] = v;
+      a_off[r] = off;
     }
+    ld_tap = tap;
+  };
+  auto load_tiles = [&](int kb) {
+    const int k0 = kb * 32;
+    if (FAST) {
+      if (ld_tap < 0) {                    // first stage of this block (split-K blocks start anywhere)
+        const int tap = k0 / p.xC;
+        ld_ci = k0 - tap * p.xC;
+        set_tap(tap);
+      } else {                             // stages are visited in order
+        ld_ci += 32;
+        if (ld_ci >= p.xC) { ld_ci = 0; set_tap(ld_tap + 1); }
+      }
 #pragma unroll
-    for (int r = 0; r < RB; ++r) {
-      const int bi = t + r * NTHR;
-      const int krow = k0 + bi / B4;
-      const int n = n0 + (bi % B4) * 4;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (krow < p.K && n < p.Npad) v = *reinterpret_cast<const float4*>(p.w + (size_t)krow * p.Npad + n);
-      rb[r] = v;
+      for (int r = 0; r < RA; ++r)
+        ra[r] = a_off[r] >= 0 ? *reinterpret_cast<const float4*>(p.x + (size_t)(unsigned)a_off[r] + ld_ci)
+                              : make_float4(0.f, 0.f, 0.f, 0.f);
+    } else {
+      const int k = k0 + 4 * q;
+      const bool kvalid = k < p.K;
+      const int tap = k / p.xC;
+      const int ci = k - tap * p.xC;
+      const int kh = tap / p.KW, kw = tap - kh * p.KW;
+#pragma unroll
+      for (int r = 0; r < RA; ++r) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (a_base[r] >= 0 && kvalid) {
+          const int sy = src_coord(a_iy0[r] + kh, He, p.pad_mode, p.ups);
+          const int sx = src_coord(a_ix0[r] + kw, We, p.pad_mode, p.ups);
+          if (sy >= 0 && sx >= 0)
+            v = *reinterpret_cast<const float4*>(p.x + (size_t)a_base[r] + (size_t)(sy * p.xW + sx) * p.xcs + ci);
+        }
+        ra[r] = v;
+      }
     }
+    const float* wk = p.w + (size_t)k0 * p.Npad;          // uniform part of the weight-panel address
+#pragma unroll
+    for (int r = 0; r < RB; ++r)
+      rb[r] = (b_off[r] >= 0 && k0 + b_row[r] < p.K) ? *reinterpret_cast<const float4*>(wk + b_off[r])
+                                                     : make_float4(0.f, 0.f, 0.f, 0.f);
   };
   auto store_tiles = [&](int buf) {
     float* A = As + buf * T::A_FLOATS;
