@@ -813,7 +813,8 @@ __global__ void conv_fwd_reduce_kernel(GemmP p) {
 // ---------------------------------------------------------------------------------------
 // NG > 0: narrow-N variant (Tile<2,1,4,1>: 256 k-rows x <= 32 channels): one k-row per lane,
 // dY[m][4g..4g+3] broadcast from lanes 4g..4g+3, v_mfma_f32_4x4x1 as in conv_fwd_narrow_kernel.
-template <int MT, int NT, int WGM, int WGN, int NG = 0>
+// ROWU: Wo % 32 == 0, so the 32 pixels of a stage share (n, oy) and that decode is wave-uniform.
+template <int MT, int NT, int WGM, int WGN, int NG = 0, bool ROWU = false>
 __global__ __launch_bounds__(64 * WGM * WGN) void conv_wgrad_kernel(GemmP p) {
   using T = Tile<MT, NT, WGM, WGN>;
   constexpr int BM = T::BM, BN = T::BN;
@@ -864,15 +865,39 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_wgrad_kernel(GemmP p) {
       if (oy >= p.Ho) { const int r = oy / p.Ho; oy -= r * p.Ho; n += r; }
     }
   };
+  if constexpr (!ROWU) {
 #pragma unroll
-  for (int r = 0; r < RA; ++r) decode(mb_begin * 32 + arow0 + r * AROWS, an[r], aoy[r], aox[r]);
+    for (int r = 0; r < RA; ++r) decode(mb_begin * 32 + arow0 + r * AROWS, an[r], aoy[r], aox[r]);
 #pragma unroll
-  for (int r = 0; r < RB; ++r) decode(mb_begin * 32 + brow0 + r * BROWS, bn[r], boy[r], box[r]);
+    for (int r = 0; r < RB; ++r) decode(mb_begin * 32 + brow0 + r * BROWS, bn[r], boy[r], box[r]);
+  }
   const int ximg = p.xH * p.xW * p.xcs;
 
   float4 ra[RA], rb[RB];
   auto load_tiles = [&](int mb) {
     const int mbase = mb * 32;
+    if constexpr (ROWU) {
+      // one scalar decode per stage; per row only the x coordinate (and its padding rule) is left
+      const int n = mbase / HoWo, rem = mbase - n * HoWo;
+      const int oy = rem / p.Wo, ox0 = rem - oy * p.Wo;
+      const bool live = mbase < p.M;                       // M % 32 == 0 here: a stage is all-valid or empty
+      const int sy = src_coord(oy * p.stride - p.pad_t + kh, He, p.pad_mode, p.ups);
+      const float* xrow = p.x + (size_t)n * ximg + (size_t)(sy < 0 ? 0 : sy) * p.xW * p.xcs + ci;
+      const bool arow_ok = live && kvalid && sy >= 0;
+#pragma unroll
+      for (int r = 0; r < RA; ++r) {
+        const int sx = src_coord((ox0 + arow0 + r * AROWS) * p.stride - p.pad_l + kw, We, p.pad_mode, p.ups);
+        ra[r] = (arow_ok && sx >= 0) ? *reinterpret_cast<const float4*>(xrow + (size_t)sx * p.xcs)
+                                     : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+      const float* yrow = p.y + ((size_t)(n * p.yH + oy * p.ymul + p.yoff) * p.yW + p.xoff) * p.ycs + n0 + bcol;
+      const bool brow_ok = live && nvalid;
+#pragma unroll
+      for (int r = 0; r < RB; ++r)
+        rb[r] = brow_ok ? *reinterpret_cast<const float4*>(yrow + (size_t)((ox0 + brow0 + r * BROWS) * p.xmul) * p.ycs)
+                        : make_float4(0.f, 0.f, 0.f, 0.f);
+      return;
+    }
 #pragma unroll
     for (int r = 0; r < RA; ++r) {
       const int m = mbase + arow0 + r * AROWS;
@@ -1302,8 +1327,11 @@ void conv_fwd(Stream& s, const ConvFwdArgs& a) {
   else launch_fwd_narrow<8>(s, p, fast, nb);
 }
 
-template <int MT, int NT, int WGM, int WGN, int NG = 0>
+template <int MT, int NT, int WGM, int WGN, int NG = 0, bool ROWU = false>
 static void launch_wgrad(Stream& s, GemmP& p, int batch) {
+  if constexpr (!ROWU) {
+    if (p.Wo % 32 == 0 && p.M % 32 == 0) { launch_wgrad<MT, NT, WGM, WGN, NG, true>(s, p, batch); return; }
+  }
   using T = Tile<MT, NT, WGM, WGN>;
   const int tiles_k = ceil_div(p.K, T::BM);
   p.tiles_n = ceil_div(p.Npad, T::BN);
@@ -1315,7 +1343,7 @@ static void launch_wgrad(Stream& s, GemmP& p, int batch) {
   p.splits = ceil_div(nmb, p.per_split);
   p.slab = reinterpret_cast<float*>(s.ws);
   p.slab_bs = (size_t)p.K * p.Npad * p.splits;
-  static bool once = (set_smem(conv_wgrad_kernel<MT, NT, WGM, WGN, NG>, T::SMEM_WG), true);
+  static bool once = (set_smem(conv_wgrad_kernel<MT, NT, WGM, WGN, NG, ROWU>, T::SMEM_WG), true);
   (void)once;
   char pname[96];
   const int bn = NG > 0 ? 4 * NG : T::BN;
@@ -1324,7 +1352,7 @@ static void launch_wgrad(Stream& s, GemmP& p, int batch) {
   else
     snprintf(pname, sizeof pname, "conv_wgrad_%dx%d", T::BM, bn);
   ProfScope prof(s, pname, 2.0 * p.M * p.Cout * p.K * batch);
-  hipLaunchKernelGGL((conv_wgrad_kernel<MT, NT, WGM, WGN, NG>), dim3(p.ntiles, p.splits, batch), dim3(64 * WGM * WGN),
+  hipLaunchKernelGGL((conv_wgrad_kernel<MT, NT, WGM, WGN, NG, ROWU>), dim3(p.ntiles, p.splits, batch), dim3(64 * WGM * WGN),
                      T::SMEM_WG, hs(s), p);
   check_launch("conv_wgrad");
   if (p.splits > 1) {
