@@ -546,21 +546,33 @@ __global__ __launch_bounds__(256) void tail_fwd4_kernel(GemmP p) {
                                                     // (conflict-free transposed LDS stores)
 
   float4 ra[RA], rb[4];
+  // stages run over (tap, 16-channel chunk) in order: the per-row source offsets are recomputed only when
+  // the tap changes (every Cin/16 stages), as in conv_fwd_kernel's fast loader
+  int a_off[RA];
+  int ld_tap = -1, ld_c0 = 0;
   auto load_tiles = [&](int kb) {
-    const int k0 = kb * 16;
-    const int tap = k0 / p.xC;             // xC % 32 == 0
-    const int c0 = k0 - tap * p.xC;
-    const int u = tap / 3, v = tap - u * 3;
+    if (ld_tap < 0 || ld_c0 + 16 >= p.xC) {
+      ld_tap += 1; ld_c0 = 0;               // kb == 0, or the next tap
+      const int uu = ld_tap / 3, vv = ld_tap - uu * 3;
 #pragma unroll
-    for (int r = 0; r < RA; ++r) {
-      float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (a_base[r] >= 0) {
-        const int sy = a_iy0[r] + u, sx = a_ix0[r] + v;
-        if (sy >= 0 && sy < p.xH && sx >= 0 && sx < p.xW)
-          val = *reinterpret_cast<const float4*>(p.x + (size_t)a_base[r] + (size_t)(sy * p.xW + sx) * p.xcs + c0 + 4 * q);
+      for (int r = 0; r < RA; ++r) {
+        int off = -1;
+        if (a_base[r] >= 0) {
+          const int sy = a_iy0[r] + uu, sx = a_ix0[r] + vv;
+          if (sy >= 0 && sy < p.xH && sx >= 0 && sx < p.xW) off = a_base[r] + (sy * p.xW + sx) * p.xcs + 4 * q;
+        }
+        a_off[r] = off;
       }
-      ra[r] = val;
+    } else {
+      ld_c0 += 16;
     }
+    const int tap = ld_tap, c0 = ld_c0;
+    const int u = tap / 3, v = tap - u * 3;
+    (void)kb;
+#pragma unroll
+    for (int r = 0; r < RA; ++r)
+      ra[r] = a_off[r] >= 0 ? *reinterpret_cast<const float4*>(p.x + (size_t)(unsigned)a_off[r] + c0)
+                            : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int ph = 0; ph < 4; ++ph) {
       rb[ph] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -813,7 +825,8 @@ __global__ void conv_fwd_reduce_kernel(GemmP p) {
 // ---------------------------------------------------------------------------------------
 // NG > 0: narrow-N variant (Tile<2,1,4,1>: 256 k-rows x <= 32 channels): one k-row per lane,
 // dY[m][4g..4g+3] broadcast from lanes 4g..4g+3, v_mfma_f32_4x4x1 as in conv_fwd_narrow_kernel.
-// ROWU: Wo % 32 == 0, so the 32 pixels of a stage share (n, oy) and that decode is wave-uniform.
+// ROWU: Wo % 32 == 0, or Wo | 32 with Ho*Wo % 32 == 0: the 32 pixels of a stage lie inside one image at fixed
+// offsets from its first pixel, whose decode is wave-uniform.
 template <int MT, int NT, int WGM, int WGN, int NG = 0, bool ROWU = false>
 __global__ __launch_bounds__(64 * WGM * WGN) void conv_wgrad_kernel(GemmP p) {
   using T = Tile<MT, NT, WGM, WGN>;
@@ -865,6 +878,21 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_wgrad_kernel(GemmP p) {
       if (oy >= p.Ho) { const int r = oy / p.Ho; oy -= r * p.Ho; n += r; }
     }
   };
+  // ROWU: offsets of this thread's rows inside a 32-pixel stage (the stage starts at ox = 0 unless Wo % 32 == 0)
+  int a_dy[RA], a_dx[RA], b_dy[RB], b_dx[RB];
+  if constexpr (ROWU) {
+    const bool wide = (p.Wo & 31) == 0;
+#pragma unroll
+    for (int r = 0; r < RA; ++r) {
+      const int j = arow0 + r * AROWS;
+      a_dy[r] = wide ? 0 : j / p.Wo; a_dx[r] = wide ? j : j % p.Wo;
+    }
+#pragma unroll
+    for (int r = 0; r < RB; ++r) {
+      const int j = brow0 + r * BROWS;
+      b_dy[r] = wide ? 0 : j / p.Wo; b_dx[r] = wide ? j : j % p.Wo;
+    }
+  }
   if constexpr (!ROWU) {
 #pragma unroll
     for (int r = 0; r < RA; ++r) decode(mb_begin * 32 + arow0 + r * AROWS, an[r], aoy[r], aox[r]);
@@ -877,24 +905,25 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_wgrad_kernel(GemmP p) {
   auto load_tiles = [&](int mb) {
     const int mbase = mb * 32;
     if constexpr (ROWU) {
-      // one scalar decode per stage; per row only the x coordinate (and its padding rule) is left
+      // one scalar decode per stage; a thread's rows sit at fixed (dy, dx) from the stage's first pixel
       const int n = mbase / HoWo, rem = mbase - n * HoWo;
-      const int oy = rem / p.Wo, ox0 = rem - oy * p.Wo;
+      const int oy0 = rem / p.Wo, ox0 = rem - oy0 * p.Wo;
       const bool live = mbase < p.M;                       // M % 32 == 0 here: a stage is all-valid or empty
-      const int sy = src_coord(oy * p.stride - p.pad_t + kh, He, p.pad_mode, p.ups);
-      const float* xrow = p.x + (size_t)n * ximg + (size_t)(sy < 0 ? 0 : sy) * p.xW * p.xcs + ci;
-      const bool arow_ok = live && kvalid && sy >= 0;
+      const float* ximg_p = p.x + (size_t)n * ximg + ci;
+      const bool arow_ok = live && kvalid;
 #pragma unroll
       for (int r = 0; r < RA; ++r) {
-        const int sx = src_coord((ox0 + arow0 + r * AROWS) * p.stride - p.pad_l + kw, We, p.pad_mode, p.ups);
-        ra[r] = (arow_ok && sx >= 0) ? *reinterpret_cast<const float4*>(xrow + (size_t)sx * p.xcs)
-                                     : make_float4(0.f, 0.f, 0.f, 0.f);
+        const int sy = src_coord((oy0 + a_dy[r]) * p.stride - p.pad_t + kh, He, p.pad_mode, p.ups);
+        const int sx = src_coord((ox0 + a_dx[r]) * p.stride - p.pad_l + kw, We, p.pad_mode, p.ups);
+        ra[r] = (arow_ok && sy >= 0 && sx >= 0) ? *reinterpret_cast<const float4*>(ximg_p + (size_t)(sy * p.xW + sx) * p.xcs)
+                                                : make_float4(0.f, 0.f, 0.f, 0.f);
       }
-      const float* yrow = p.y + ((size_t)(n * p.yH + oy * p.ymul + p.yoff) * p.yW + p.xoff) * p.ycs + n0 + bcol;
+      const float* yimg_p = p.y + ((size_t)(n * p.yH + p.yoff) * p.yW + p.xoff) * p.ycs + n0 + bcol;
       const bool brow_ok = live && nvalid;
 #pragma unroll
       for (int r = 0; r < RB; ++r)
-        rb[r] = brow_ok ? *reinterpret_cast<const float4*>(yrow + (size_t)((ox0 + brow0 + r * BROWS) * p.xmul) * p.ycs)
+        rb[r] = brow_ok ? *reinterpret_cast<const float4*>(
+                              yimg_p + (size_t)((oy0 + b_dy[r]) * p.ymul * p.yW + (ox0 + b_dx[r]) * p.xmul) * p.ycs)
                         : make_float4(0.f, 0.f, 0.f, 0.f);
       return;
     }
@@ -1330,7 +1359,9 @@ void conv_fwd(Stream& s, const ConvFwdArgs& a) {
 template <int MT, int NT, int WGM, int WGN, int NG = 0, bool ROWU = false>
 static void launch_wgrad(Stream& s, GemmP& p, int batch) {
   if constexpr (!ROWU) {
-    if (p.Wo % 32 == 0 && p.M % 32 == 0) { launch_wgrad<MT, NT, WGM, WGN, NG, true>(s, p, batch); return; }
+    // a 32-pixel stage lies inside one image and starts at a row start (or inside one row)
+    const bool rowu = p.M % 32 == 0 && (p.Wo % 32 == 0 || (32 % p.Wo == 0 && (p.Ho * p.Wo) % 32 == 0));
+    if (rowu) { launch_wgrad<MT, NT, WGM, WGN, NG, true>(s, p, batch); return; }
   }
   using T = Tile<MT, NT, WGM, WGN>;
   const int tiles_k = ceil_div(p.K, T::BM);
