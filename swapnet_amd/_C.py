@@ -85,6 +85,10 @@ class Lib:
             raise SwapnetHipError(
                 f"{self.path} not found: build it with `python -m swapnet_amd.build` "
                 "(hipcc --offload-arch=gfx950).  swapnet_amd has no CPU fallback.")
+        # torch first: it ships its own libamdhip64 / libhsa-runtime64, and the library's NEEDED
+        # libamdhip64.so.7 must resolve to that already-loaded copy.  Loaded the other way round the
+        # process ends up with two HSA runtimes and the second to initialise sees no device.
+        import torch  # noqa: F401
         self.dll = C.CDLL(self.path)
         self.dll.swn_last_error.restype = C.c_char_p
         self.dll.swn_last_error.argtypes = []
