@@ -149,6 +149,9 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_fwd_kernel(GemmP p) {
   }
   int a_off[RA];                          // element offset of this row's pixel for the cached tap, -1 = zero fill
   int ld_tap = -1, ld_ci = 0;             // wave-uniform loader state
+  int g_tap = -1, g_ci = 0;               // generic path: per-thread (tap, ci)
+  const int q32 = 32 / p.xC, r32 = 32 - q32 * p.xC;
+  const int rcpKW = (65536 + p.KW - 1) / p.KW;
   auto set_tap = [&](int tap) {
     const int kh = tap / p.KW, kw = tap - kh * p.KW;
 #pragma unroll
@@ -179,11 +182,20 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_fwd_kernel(GemmP p) {
         ra[r] = a_off[r] >= 0 ? *reinterpret_cast<const float4*>(p.x + (size_t)(unsigned)a_off[r] + ld_ci)
                               : make_float4(0.f, 0.f, 0.f, 0.f);
     } else {
-      const int k = k0 + 4 * q;
-      const bool kvalid = k < p.K;
-      const int tap = k / p.xC;
-      const int ci = k - tap * p.xC;
-      const int kh = tap / p.KW, kw = tap - kh * p.KW;
+      // generic path (Cin % 32 != 0): every thread tracks the (tap, ci) of its own 4-channel group and
+      // advances it by 32 channels per stage with the precomputed quotient / remainder of 32 by Cin --
+      // no per-stage integer divisions (tap -> (kh, kw) by a 16-bit reciprocal, exact for tap < 4096)
+      if (g_tap < 0) {
+        const int k = k0 + 4 * q;
+        g_tap = k / p.xC;
+        g_ci = k - g_tap * p.xC;
+      } else {
+        g_tap += q32; g_ci += r32;
+        if (g_ci >= p.xC) { g_ci -= p.xC; ++g_tap; }
+      }
+      const bool kvalid = k0 + 4 * q < p.K;
+      const int tap = g_tap, ci = g_ci;
+      const int kh = (tap * rcpKW) >> 16, kw = tap - kh * p.KW;
 #pragma unroll
       for (int r = 0; r < RA; ++r) {
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
