@@ -82,7 +82,7 @@ def main():
                          "the model API (set_input + step), reported as `h2d_inclusive` (never `value`)")
     args = ap.parse_args()
 
-    from swapnet_amd import _C, engine, parallel, synthetic
+    from swapnet_amd import engine, parallel, synthetic
     from swapnet_amd.modules import init_tensor
 
     local_rank = int(os.environ.get("SWAPNET_FORCE_DEVICE", os.environ.get("LOCAL_RANK", "0")))

@@ -3,7 +3,6 @@
 lambda_l1 * L1 + lambda_content * content + lambda_style * style."""
 from argparse import ArgumentParser
 
-from .. import engine
 from ..modules.losses import PerceptualLoss
 from ..modules.swapnet_modules import TextureModule
 from ..util.decode_labels import decode_cloth_labels, labels_to_onehot

@@ -3,7 +3,6 @@ WarpModule generator against a PatchGAN conditioned on cat(body, cloth); G loss 
 CE(fakes, argmax(targets)) + lambda_gan * GAN; `--warp_mode ce` trains G alone."""
 from argparse import ArgumentParser
 
-from .. import engine
 from ..modules.swapnet_modules import WarpModule
 from ..util.decode_labels import decode_cloth_labels, labels_to_onehot
 from ..util.util import unnormalize

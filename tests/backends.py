@@ -1,7 +1,6 @@
 """Test helpers: the product (HIP) context and the CI-only host-simulator context."""
 import os
 import subprocess
-import sys
 
 import pytest
 

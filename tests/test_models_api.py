@@ -12,7 +12,6 @@ import torch
 
 from oracle import swapnet_oracle as O
 from oracle.golden_io import compare
-from swapnet_amd import engine
 from tests import backends
 
 BACKENDS = [pytest.param("sim", id="hostsim"), pytest.param("gpu", id="mi355x", marks=pytest.mark.gpu)]
