@@ -158,6 +158,41 @@ def golden_warp(path, H=64, B=2, init_seed=0, step_seeds=(100, 101)):
     print("wrote", path, len(out), "entries")
 
 
+def golden_warp_modes(path, H=64, B=2, init_seed=0, step_seed=100):
+    """One reference step of WarpModel under --gan_mode lsgan / wgan and --warp_mode ce
+    (modules/loss.py:55-62,117-128; models/warp_model.py:169-183): losses, fakes and two post-step
+    weights.  Same init seed / batch / step seed as golden_warp, so the weights and labels coincide."""
+    from oracle.swapnet_oracle import synth_warp_batch
+    from models.warp_model import WarpModel
+    out = OrderedDict()
+    bodys, inputs, targets = synth_warp_batch(B, H, H, seed=1234)
+    for mode, opts in (("lsgan", dict(gan_mode="lsgan", warp_mode="gan")),
+                       ("wgan", dict(gan_mode="wgan", warp_mode="gan")),
+                       ("ce", dict(gan_mode="vanilla", warp_mode="ce"))):
+        with tempfile.TemporaryDirectory() as tmp:
+            opt = base_opt(tmp, lambda_ce=100.0, model="warp", **opts)
+            torch.manual_seed(init_seed)
+            model = WarpModel(opt)
+            model.eval()
+            model.set_input(dict(bodys=bodys, input_cloths=inputs, target_cloths=targets,
+                                 cloth_paths=[""] * B, body_paths=[""] * B))
+            torch.manual_seed(step_seed)
+            model.optimize_parameters()
+            pre = mode + "/"
+            for k, v in model.get_current_losses().items():
+                out[pre + "loss/" + k] = np.float64(v)
+            summarize(out, pre + "fakes", model.fakes)
+            sd = model.net_generator.state_dict()
+            for k in ("upsample_and_pad.2.weight", "resblocks.3.conv_block.6.weight", "body_down1.model.0.weight"):
+                summarize(out, pre + "postG/" + k, sd[k])
+            if hasattr(model, "net_discriminator"):
+                summarize(out, pre + "postD/model.0.weight", model.net_discriminator.state_dict()["model.0.weight"])
+    out["meta/init_seed"] = np.int64(init_seed); out["meta/step_seed"] = np.int64(step_seed)
+    out["meta/B"] = np.int64(B); out["meta/H"] = np.int64(H)
+    np.savez_compressed(path, **out)
+    print("wrote", path, len(out), "entries")
+
+
 def golden_texture(path, H=64, B=2, init_seed=1, step_seeds=(200, 201)):
     from oracle.swapnet_oracle import synth_texture_batch
     from models.texture_model import TextureModel
@@ -243,13 +278,15 @@ if __name__ == "__main__":
     torch.set_num_threads(8)
     gold = os.path.join(REPO, "tests", "golden")
     os.makedirs(gold, exist_ok=True)
-    which = sys.argv[1:] or ["warp", "texture", "roi", "cloth", "roiops"]
+    which = sys.argv[1:] or ["warp", "texture", "roi", "cloth", "roiops", "modes"]
     if "warp" in which:
         golden_warp(os.path.join(gold, "warp_step_64.npz"))
     if "texture" in which:
         golden_texture(os.path.join(gold, "texture_step_64.npz"))
     if "roi" in which:
         golden_roi(os.path.join(gold, "notebook_rois.npz"))
+    if "modes" in which:
+        golden_warp_modes(os.path.join(gold, "warp_modes_64.npz"))
     if "roiops" in which:
         golden_roi_ops(os.path.join(gold, "roi_ops_reference.npz"))
     if "cloth" in which:

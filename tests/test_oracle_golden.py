@@ -109,6 +109,34 @@ def test_warp_step(warp_gold, warp_run, si):
         assert ok, msg
 
 
+@pytest.mark.parametrize("mode", ["lsgan", "wgan", "ce"])
+def test_warp_other_objectives_match_reference(golden_dir, mode):
+    """--gan_mode lsgan / wgan and --warp_mode ce: the oracle against one step of the real reference
+    (tests/golden/warp_modes_64.npz, oracle/make_golden.py::golden_warp_modes)."""
+    g = np.load(os.path.join(golden_dir, "warp_modes_64.npz"))
+    torch.manual_seed(int(g["meta/init_seed"]))
+    G, D = O.warp_module_params(), O.patchgan_params(22)
+    B, H = int(g["meta/B"]), int(g["meta/H"])
+    batch = O.synth_warp_batch(B, H, H, seed=1234)
+    hyper = dict(gan_mode="vanilla" if mode == "ce" else mode, warp_mode="ce" if mode == "ce" else "gan")
+    st = O.WarpStepOracle(G, D, hyper=hyper)
+    torch.manual_seed(int(g["meta/step_seed"]))
+    losses = st.step(*batch)
+    pre = mode + "/"
+    ref_keys = [k[len(pre) + 5:] for k in g.files if k.startswith(pre + "loss/")]
+    assert ref_keys and set(ref_keys) <= set(losses)
+    for k in ref_keys:
+        np.testing.assert_allclose(losses[k], float(g[pre + "loss/" + k]), rtol=1e-4, atol=1e-6, err_msg=(mode, k))
+    ok, msg = compare(g, pre + "fakes", st.fakes, rtol=1e-4, atol_frac=1e-4)
+    assert ok, msg
+    for k in ("upsample_and_pad.2.weight", "resblocks.3.conv_block.6.weight", "body_down1.model.0.weight"):
+        ok, msg = compare(g, pre + "postG/" + k, st.G[k], rtol=1e-3, atol_frac=1e-3)
+        assert ok, msg
+    if mode != "ce":
+        ok, msg = compare(g, pre + "postD/model.0.weight", st.D["model.0.weight"], rtol=1e-3, atol_frac=1e-3)
+        assert ok, msg
+
+
 def test_decode_labels_bit_exact(warp_gold, warp_run):
     # util/decode_labels.py golden on the reference's own generated batch is tied to its
     # fakes; check the palette path on the recorded argmax instead (integer, exact).

@@ -275,10 +275,20 @@ def test_other_gan_objectives_and_ce_mode(backend, mode, oracle_run):
     L = m.losses()
     for k, v in st.losses.items():
         assert abs(L[k] - v) <= 1e-3 * abs(v) + 1e-6, (mode, k, L[k], v)
+    # ... and against the real reference's step under this objective (same seeds => same labels)
+    gm = np.load(os.path.join(os.path.dirname(__file__), "golden", "warp_modes_64.npz"))
+    for key in gm.files:
+        if key.startswith(mode + "/loss/"):
+            k, ref = key.split("/")[-1], float(gm[key])
+            assert abs(L[k] - ref) <= 1e-3 * abs(ref) + 1e-6, (mode, k, L[k], ref, "vs reference")
+    ok, msg = compare(gm, mode + "/fakes", m.output(), 1e-3, 1e-3)
+    assert ok, msg
     pG = m.state_dict(0, to_cpu=True)
     for k, v in st.G.items():
         if not noise_bias(k):
             assert rel(pG[k], v) < 1e-3, (mode, "postG", k, rel(pG[k], v))
+    ok, msg = compare(gm, mode + "/postG/upsample_and_pad.2.weight", pG["upsample_and_pad.2.weight"], 1e-3, 3e-3)
+    assert ok, msg
     if mode == "ce":      # the discriminator is untouched
         pD = m.state_dict(1, to_cpu=True)
         assert all(torch.equal(pD[k], D[k]) for k in D)
