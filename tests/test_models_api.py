@@ -221,3 +221,23 @@ def test_two_stage_device_pipeline_equals_reference_two_pass_inference(backend):
     assert agree > 0.999, agree
     if agree == 1.0:
         assert float((out.cpu() - ref).norm() / ref.norm()) < 1e-3
+
+
+@pytest.mark.parametrize("stage", ["warp", "texture"])
+def test_seeded_init_equals_the_reference(stage, tmp_path, golden_dir):
+    """`torch.manual_seed(s); create_model(opt)` gives the weights the reference
+    gives -- the native init consumes the CPU RNG like the reference's constructors + init_weights do
+    (construction order, incl. the pix2pix U-Net's inside-out recursion; module-tree order for the
+    re-draw).  Against the init weights recorded from the real reference in tests/golden/*_step_64.npz."""
+    from swapnet_amd.models import create_model
+    gold = np.load(os.path.join(golden_dir, "%s_step_64.npz" % stage))
+    opt = make_opt(tmp_path, "sim", model=stage)
+    torch.manual_seed(int(gold["meta/init_seed"]))
+    model = create_model(opt)
+    for net, tag in ((model.net_generator, "G"), (model.net_discriminator, "D")):
+        sd = net.state_dict()
+        keys = [k[len("init/%s/" % tag):-len("/norm")] for k in gold.files if k.startswith("init/%s/" % tag) and k.endswith("/norm")]
+        assert keys and set(keys) == set(sd.keys()), (tag, sorted(set(keys) ^ set(sd.keys()))[:4])
+        for k in keys:
+            ok, msg = compare(gold, "init/%s/%s" % (tag, k), sd[k], rtol=1e-6, atol_frac=1e-6)
+            assert ok, msg
