@@ -241,3 +241,13 @@ def test_seeded_init_equals_the_reference(stage, tmp_path, golden_dir):
         for k in keys:
             ok, msg = compare(gold, "init/%s/%s" % (tag, k), sd[k], rtol=1e-6, atol_frac=1e-6)
             assert ok, msg
+    if stage == "warp":
+        # ... and from there one seeded step is the reference's step: nothing was loaded from outside
+        model.eval()
+        bodys, inputs, targets = O.synth_warp_batch(2, 64, 64, seed=1234)
+        model.set_input(dict(bodys=bodys, input_cloths=inputs, target_cloths=targets, cloth_paths=["", ""], body_paths=["", ""]))
+        torch.manual_seed(int(gold["meta/step_seeds"][0]))
+        model.optimize_parameters()
+        for k, v in model.get_current_losses().items():
+            ref = float(gold["step0/loss/" + k])
+            assert abs(v - ref) <= 1e-3 * abs(ref) + 1e-6, (k, v, ref)
