@@ -251,3 +251,18 @@ def test_seeded_init_equals_the_reference(stage, tmp_path, golden_dir):
         for k, v in model.get_current_losses().items():
             ref = float(gold["step0/loss/" + k])
             assert abs(v - ref) <= 1e-3 * abs(ref) + 1e-6, (k, v, ref)
+
+
+def test_seeded_init_matches_oracle_for_the_8_level_unet(tmp_path):
+    """Same property at the C3 size (crop 256: 8 U-Net levels, inside-out construction order) against the
+    oracle's RNG-faithful builder (itself pinned to the reference at 64x64): exact equality."""
+    from swapnet_amd.models import create_model
+    opt = make_opt(tmp_path, "sim", model="texture", crop_size=256, batch_size=1)
+    torch.manual_seed(11)
+    model = create_model(opt)
+    torch.manual_seed(11)
+    G, D = O.texture_module_params(img_size=256), O.patchgan_params(22)
+    sg, sd = model.net_generator.state_dict(), model.net_discriminator.state_dict()
+    assert list(sg.keys()) == list(G.keys()) and list(sd.keys()) == list(D.keys())
+    assert all(torch.equal(sg[k].cpu(), G[k]) for k in G)
+    assert all(torch.equal(sd[k].cpu(), D[k]) for k in D)
