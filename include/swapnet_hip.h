@@ -109,6 +109,16 @@ int swn_model_get_output(swn_model* m, int slot, float* dev_nchw);
 /* named intermediate activation (debug / per-level parity tests), copied out as NCHW */
 int swn_model_get_tap(swn_model* m, int net, const char* name, float* dev_nchw, int shape[4]);
 
+/* nn.Dropout sites of the generator in forward order (WarpModule: body_down4, cloth_down5, cloth_down6 and the
+ * four ResidualBlocks, modules/swapnet_modules.py:37,46-47,58 / modules/layers.py:22-23,136; pix2pix U-Net:
+ * the three inner ngf*8 blocks, modules/pix2pix_modules.py:251-252).  swn_model_dropout_mask writes the factor
+ * (0 or 1/(1-p)) that a training-mode forward AND backward with `dropout_seed` apply at `site`, as an NCHW
+ * tensor of `shape` (channel count = the padded channel count of the layer).  dst may be NULL to query the
+ * shape.  Diagnostic: lets a parity test replay the exact masks in the CPU oracle. */
+int swn_model_dropout_sites(swn_model* m, int net, int* count);
+int swn_model_dropout_mask(swn_model* m, int net, int site, uint64_t dropout_seed, float* dev_nchw, int shape[4],
+                           float* p);
+
 /* BaseModel.forward (models/warp_model.py:106-107, models/texture_model.py:121-125) */
 int swn_model_forward(swn_model* m, int training, uint64_t dropout_seed);
 /* WarpModel.backward_D / TextureModel.backward_D (warp_model.py:109-139, texture_model.py:
@@ -162,6 +172,11 @@ int swn_op_conv(swn_ctx* ctx, int kind, int transposed, int what, int naive, flo
 int swn_op_instance_norm_act(swn_ctx* ctx, const float* x, int n, int c, int h, int w, int act, float* y);
 int swn_op_instance_norm_act_bwd(swn_ctx* ctx, const float* x, const float* dy, int n, int c, int h, int w, int act,
                                  float* dx);
+/* [InstanceNorm] -> act -> nn.Dropout(p) in TRAINING mode as ONE op (UNetDown / ResidualBlock, modules/layers.py:
+ * 18-23,133-136): y, the keep/scale mask it used (0 or 1/(1-p); may be NULL) and, when dy and dx are given, the
+ * input gradient computed with the same mask.  NCHW fp32, C % 4 == 0. */
+int swn_op_norm_act_dropout(swn_ctx* ctx, const float* x, const float* dy, int n, int c, int h, int w, int norm, int act,
+                            float p, uint64_t seed, float* y, float* mask, float* dx);
 /* torch.optim.AdamW single step on flat arrays (optimizers/__init__.py:52-59) */
 int swn_op_adamw(swn_ctx* ctx, float* p, const float* g, float* m, float* v, size_t n, float lr, float b1, float b2,
                  float eps, float wd, int step);

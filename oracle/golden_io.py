@@ -1,10 +1,21 @@
 """TEST INFRASTRUCTURE ONLY.  Summary format of tests/golden/*.npz: each tensor is
 stored as key/norm (L2, float64), key/sum and key/samples (24 elements at fixed
-flat indices derived from an FNV hash of the key)."""
+flat indices derived from an FNV hash of the key).  A few tensors are ALSO stored
+whole as key/full (float32; FULL_TENSORS below) so that a localized error -- one tile,
+one channel block -- that leaves the norm and 24 samples of a large tensor intact
+cannot hide: the generator output, the gradients at both ends of the backward chain
+(tail conv, first encoder convs) and the discriminator head."""
 import numpy as np
 import torch
 
 NSAMP = 24
+FULL_TENSORS = {
+    "warp": ("step0/fakes", "step1/fakes", "step0/gradG/upsample_and_pad.2.weight", "step0/postG/upsample_and_pad.2.weight",
+             "step0/gradG/body_down1.model.0.weight", "step0/gradG/cloth_down1.model.0.weight",
+             "step0/gradD/model.11.weight", "step0/gradD/model.0.weight"),
+    "texture": ("step0/fakes", "step0/gradG/encode.model.0.weight", "step0/gradG/unet.model.model.3.weight",
+                "step0/postG/unet.model.model.3.weight", "step0/gradD/model.11.weight", "step0/gradD/model.0.weight"),
+}
 
 
 def _fnv(s):
@@ -25,6 +36,28 @@ def summarize(out, key, t):
     out[key + "/norm"] = np.float64(t.norm().item())
     out[key + "/sum"] = np.float64(t.sum().item())
     out[key + "/samples"] = t[torch.from_numpy(idx)].numpy()
+
+
+def store_full(out, key, t):
+    out[key + "/full"] = t.detach().float().cpu().numpy()
+
+
+def compare_full(gold, key, t, rtol=1e-3):
+    """Whole-tensor check against key/full: rel-L2 <= rtol AND every element within
+    rtol*|ref| + 4*rtol*rms(ref) (round-off outliers of a few sigma pass, a wrong tile / channel -- an error
+    of order rms -- cannot).  Returns (ok, message)."""
+    ref = torch.from_numpy(np.asarray(gold[key + "/full"])).double()
+    t = t.detach().double().cpu()
+    if tuple(t.shape) != tuple(ref.shape):
+        return False, "%s: shape %s vs reference %s" % (key, tuple(t.shape), tuple(ref.shape))
+    rms = float(ref.norm()) / max(np.sqrt(ref.numel()), 1.0)
+    err = (t - ref).abs()
+    tol = rtol * ref.abs() + 4 * rtol * rms
+    rl2 = float((t - ref).norm() / (ref.norm() + 1e-30))
+    bad = int((err > tol).sum())
+    ok = rl2 <= rtol and bad == 0
+    return ok, "%s: rel-L2 %.2e (tol %.0e), %d / %d elements outside tol, worst |d| %.3e" % (
+        key, rl2, rtol, bad, ref.numel(), float(err.max()))
 
 
 def compare(gold, key, t, rtol=1e-3, atol_frac=1e-3):

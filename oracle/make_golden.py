@@ -23,7 +23,15 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
 from oracle import ref_stubs  # noqa: E402
 
-from oracle.golden_io import summarize  # noqa: E402
+from oracle.golden_io import summarize as _summarize, store_full, FULL_TENSORS  # noqa: E402
+
+_FULL = set()
+
+
+def summarize(out, key, t):
+    _summarize(out, key, t)
+    if key in _FULL:
+        store_full(out, key, t)
 
 
 def base_opt(tmp, **kw):
@@ -92,6 +100,7 @@ def golden_warp(path, H=64, B=2, init_seed=0, step_seeds=(100, 101)):
     from oracle.swapnet_oracle import synth_warp_batch
     from models.warp_model import WarpModel
     out = OrderedDict()
+    _FULL.clear(); _FULL.update(FULL_TENSORS["warp"])
     with tempfile.TemporaryDirectory() as tmp:
         opt = base_opt(tmp, warp_mode="gan", lambda_ce=100.0, model="warp")
         torch.manual_seed(init_seed)
@@ -197,6 +206,7 @@ def golden_texture(path, H=64, B=2, init_seed=1, step_seeds=(200, 201)):
     from oracle.swapnet_oracle import synth_texture_batch
     from models.texture_model import TextureModel
     out = OrderedDict()
+    _FULL.clear(); _FULL.update(FULL_TENSORS["texture"])
     with tempfile.TemporaryDirectory() as tmp:
         opt = base_opt(tmp, model="texture", netG="swapnet", crop_size=H, lambda_l1=10.0,
                        lambda_content=20.0, lambda_style=1e-8)

@@ -192,6 +192,34 @@ def vgg16_feature_params(seed=VGG_SEED):
 # Layers (modules/layers.py)
 # ----------------------------------------------------------------------------
 
+class MaskReplay:
+    """Stands in for `training` at the nn.Dropout call sites below: instead of drawing from torch's RNG,
+    the keep/scale masks exported from a HIP run (swn_model_dropout_mask, NCHW, values 0 or 1/(1-p),
+    channel count possibly padded) are applied in call order, so a TRAINING-mode step can be compared
+    value for value.  autograd multiplies the gradient by the same tensor, which is exactly what
+    nn.Dropout does with its own mask."""
+
+    def __init__(self, masks):
+        self.masks = [m if torch.is_tensor(m) else m[0] for m in masks]
+        self.i = 0
+
+    def __call__(self, x, p):
+        m = self.masks[self.i]
+        self.i += 1
+        assert m.shape[0] == x.shape[0] and m.shape[2:] == x.shape[2:] and m.shape[1] >= x.shape[1], (m.shape, x.shape)
+        return x * m[:, :x.shape[1]].to(device=x.device, dtype=x.dtype)
+
+    def done(self):
+        return self.i == len(self.masks)
+
+
+def _dropout(x, p, training):
+    """nn.Dropout(p)(x) (modules/layers.py:22-23,136; pix2pix_modules.py:251-252)."""
+    if isinstance(training, MaskReplay):
+        return training(x, p)
+    return F.dropout(x, p, bool(training))
+
+
 def _inorm(x):
     # nn.InstanceNorm2d(affine=False, track_running_stats=False), eps 1e-5, biased var
     # (modules/__init__.py:66-69)
@@ -205,7 +233,7 @@ def unet_down(x, w, normalize=True, dropout=0.0, training=False):
         x = _inorm(x)
     x = F.leaky_relu(x, 0.2)
     if dropout:
-        x = F.dropout(x, dropout, training)
+        x = _dropout(x, dropout, training)
     return x
 
 
@@ -214,7 +242,7 @@ def unet_up(x, w, skips=(), dropout=0.0, training=False):
     x = F.conv_transpose2d(x, w, None, stride=2, padding=1)
     x = F.relu(_inorm(x))
     if dropout:
-        x = F.dropout(x, dropout, training)
+        x = _dropout(x, dropout, training)
     if skips:
         x = torch.cat((x,) + tuple(skips), 1)
     return x
@@ -224,7 +252,7 @@ def residual_block(x, w1, b1, w2, b2, dropout=0.0, training=False):
     """ResidualBlock.forward (modules/layers.py:126-144)."""
     h = F.conv2d(F.pad(x, (1, 1, 1, 1), mode="reflect"), w1, b1)
     h = F.relu(_inorm(h))
-    h = F.dropout(h, dropout, training)
+    h = _dropout(h, dropout, training)
     h = F.conv2d(F.pad(h, (1, 1, 1, 1), mode="reflect"), w2, b2)
     return x + _inorm(h)
 
@@ -396,7 +424,7 @@ def unet_generator_forward(P, x, num_downs, prefix="unet.model", dropout=True, t
             h = _inorm(h)
             # Dropout(0.5) on the num_downs-5 inner ngf*8 blocks (:144-152,251-252)
             if dropout and 4 <= d < depth - 1:
-                h = F.dropout(h, 0.5, training)
+                h = _dropout(h, 0.5, training)
         return torch.cat([xl, h], 1)
 
     return block(0, x)
@@ -406,7 +434,7 @@ def texture_module_forward(P, input_tex, rois, cloth, num_roi=12, training=False
     """TextureModule.forward (modules/swapnet_modules.py:231-260)."""
     t = taps if taps is not None else {}
     r = reshape_rois(rois)
-    pooled = roi_align(input_tex, r, (128, 128), 1.0, 1)                      # :234
+    pooled = roi_align(input_tex, r, (128, 128), 1.0, 1).to(input_tex.dtype)  # :234 (fp32 arithmetic; see fp64 note)
     B = pooled.shape[0] // num_roi
     pooled = t["pooled"] = pooled.view(B, -1, pooled.shape[2], pooled.shape[3])   # :237-240
     enc = t["encoded"] = unet_down(pooled, P["encode.model.0.weight"])        # :242
@@ -538,28 +566,53 @@ def _leaf(P):
     return OrderedDict((k, v.detach().clone().requires_grad_(True)) for k, v in P.items())
 
 
+def _clone_step_oracle(src, dtype):
+    """Deep copy of a step oracle (weights, both AdamW states, step counters) evaluated in `dtype`: lets a test
+    run the SAME step from the SAME state in float64 as the yardstick for fp32 tolerances."""
+    import copy
+    dst = copy.copy(src)
+    dst.dtype = dtype
+    dst.G = OrderedDict((k, v.clone().to(dtype)) for k, v in src.G.items())
+    dst.D = OrderedDict((k, v.clone().to(dtype)) for k, v in src.D.items())
+    for name in ("optG", "optD"):
+        o = copy.copy(getattr(src, name))
+        o.m = OrderedDict((k, v.clone().to(dtype)) for k, v in o.m.items())
+        o.v = OrderedDict((k, v.clone().to(dtype)) for k, v in o.v.items())
+        setattr(dst, name, o)
+    if hasattr(src, "vgg"):
+        dst.vgg = [(w.to(dtype), b.to(dtype)) for w, b in src.vgg]
+    return dst
+
+
 class WarpStepOracle:
     """WarpModel (models/warp_model.py) + BaseGAN.optimize_parameters restated
     functionally.  Holds G/D params and both AdamW states."""
 
-    def __init__(self, G, D, hyper=None, training=False):
+    def __init__(self, G, D, hyper=None, training=False, dtype=torch.float32):
+        """training: False (eval), True (torch RNG dropout) or a MaskReplay.  dtype=torch.float64 evaluates the
+        same step in double precision (the yardstick the fp32 tolerances of tests/ are measured against)."""
         self.h = dict(DEFAULT_HYPER, **(hyper or {}))
-        self.G = OrderedDict((k, v.clone()) for k, v in G.items())
-        self.D = OrderedDict((k, v.clone()) for k, v in D.items())
+        self.dtype = dtype
+        self.G = OrderedDict((k, v.clone().to(dtype)) for k, v in G.items())
+        self.D = OrderedDict((k, v.clone().to(dtype)) for k, v in D.items())
         self.optG = AdamWState(self.G, self.h["lr"], self.h["weight_decay"], (self.h["b1"], self.h["b2"]))
         self.optD = AdamWState(self.D, self.h["d_lr"], self.h["d_weight_decay"], (self.h["b1"], self.h["b2"]))
         self.training = training
         self.losses = OrderedDict()
         self.labels = []
 
+    def astype(self, dtype):
+        return _clone_step_oracle(self, dtype)
+
     def step(self, bodys, inputs, targets, labels=None):
         """optimize_parameters (base_gan.py:194-203; warp_model.py:106-167).
         `labels` = the three smooth-label scalars (fake_D, real_D, real_G); drawn
         from the global CPU RNG in the reference's order when None."""
         h = self.h
+        bodys, inputs, targets = bodys.to(self.dtype), inputs.to(self.dtype), targets.to(self.dtype)
         G, D = _leaf(self.G), _leaf(self.D)
         fakes = warp_module_forward(G, bodys, inputs, training=self.training)         # :106-107
-        draw = (lambda i: smooth_label()) if labels is None else (lambda i: torch.tensor([labels[i]], dtype=torch.float32))
+        draw = (lambda i: smooth_label().to(self.dtype)) if labels is None else (lambda i: torch.tensor([labels[i]], dtype=self.dtype))
         if h.get("warp_mode", "gan") == "ce":
             # --warp_mode ce (warp_model.py:169-183): generator only, loss = lambda_ce * CE
             loss_G = F.cross_entropy(fakes, torch.argmax(targets, dim=1)) * h["lambda_ce"]
@@ -602,20 +655,27 @@ class WarpStepOracle:
 class TextureStepOracle:
     """TextureModel (models/texture_model.py:121-180) restated functionally."""
 
-    def __init__(self, G, D, vgg=None, hyper=None, training=False):
+    def __init__(self, G, D, vgg=None, hyper=None, training=False, dtype=torch.float32):
+        """training / dtype as in WarpStepOracle (RoIAlign stays the fp32 restatement in every dtype: its
+        index arithmetic is defined in float32 by torchvision)."""
         self.h = dict(DEFAULT_HYPER, **(hyper or {}))
-        self.G = OrderedDict((k, v.clone()) for k, v in G.items())
-        self.D = OrderedDict((k, v.clone()) for k, v in D.items())
-        self.vgg = vgg if vgg is not None else vgg16_feature_params()
+        self.dtype = dtype
+        self.G = OrderedDict((k, v.clone().to(dtype)) for k, v in G.items())
+        self.D = OrderedDict((k, v.clone().to(dtype)) for k, v in D.items())
+        self.vgg = [(w.to(dtype), b.to(dtype)) for w, b in (vgg if vgg is not None else vgg16_feature_params())]
         self.optG = AdamWState(self.G, self.h["lr"], self.h["weight_decay"], (self.h["b1"], self.h["b2"]))
         self.optD = AdamWState(self.D, self.h["d_lr"], self.h["d_weight_decay"], (self.h["b1"], self.h["b2"]))
         self.training = training
 
+    def astype(self, dtype):
+        return _clone_step_oracle(self, dtype)
+
     def step(self, textures, rois, cloths, targets, labels=None):
         h = self.h
+        textures, cloths, targets = textures.to(self.dtype), cloths.to(self.dtype), targets.to(self.dtype)
         G, D = _leaf(self.G), _leaf(self.D)
         fakes = texture_module_forward(G, textures, rois, cloths, training=self.training)   # :121-125
-        draw = (lambda i: smooth_label()) if labels is None else (lambda i: torch.tensor([labels[i]], dtype=torch.float32))
+        draw = (lambda i: smooth_label().to(self.dtype)) if labels is None else (lambda i: torch.tensor([labels[i]], dtype=self.dtype))
         # ---- backward_D (:127-155)
         pred_fake = patchgan_forward(D, torch.cat((cloths, fakes), 1).detach())
         l_fake = draw(0)

@@ -52,6 +52,8 @@ _PROTOS = {
     "swn_model_set_input_labels": ([_vp, _i, _vp, _i, _i, _i], _i),
     "swn_model_get_output": ([_vp, _i, _fp], _i),
     "swn_model_get_tap": ([_vp, _i, C.c_char_p, _fp, C.POINTER(_i * 4)], _i),
+    "swn_model_dropout_sites": ([_vp, _i, C.POINTER(_i)], _i),
+    "swn_model_dropout_mask": ([_vp, _i, _i, C.c_uint64, _fp, C.POINTER(_i * 4), C.POINTER(_f)], _i),
     "swn_model_forward": ([_vp, _i, C.c_uint64], _i),
     "swn_model_backward_D": ([_vp, _f, _f], _i),
     "swn_model_backward_G": ([_vp, _f], _i),
@@ -71,6 +73,7 @@ _PROTOS = {
     "swn_op_conv": ([_vp, _i, _i, _i, _i, _fp, _i, _i, _i, _i, _fp, _i, _fp, _i, _fp], _i),
     "swn_op_instance_norm_act": ([_vp, _fp, _i, _i, _i, _i, _i, _fp], _i),
     "swn_op_instance_norm_act_bwd": ([_vp, _fp, _fp, _i, _i, _i, _i, _i, _fp], _i),
+    "swn_op_norm_act_dropout": ([_vp, _fp, _fp, _i, _i, _i, _i, _i, _i, _f, C.c_uint64, _fp, _fp, _fp], _i),
     "swn_op_adamw": ([_vp, _fp, _fp, _fp, _fp, C.c_size_t, _f, _f, _f, _f, _f, _i], _i),
 }
 

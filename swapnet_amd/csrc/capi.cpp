@@ -205,6 +205,26 @@ int swn_model_get_tap(swn_model* m, int net, const char* name, float* dst, int s
     if (dst) nhwc_to_nchw(m->m->ctx->s, v, dst, v.C);
   });
 }
+int swn_model_dropout_sites(swn_model* m, int net, int* count) {
+  return guard([&] {
+    REQUIRE(m && count, "NULL argument");
+    Net* n = m->m->net_for_taps(net);
+    REQUIRE(n, "no such network");
+    *count = (int)n->drop_sites.size();
+  });
+}
+int swn_model_dropout_mask(swn_model* m, int net, int site, uint64_t seed, float* dst, int shape[4], float* p) {
+  return guard([&] {
+    REQUIRE(m, "NULL argument");
+    Net* n = m->m->net_for_taps(net);
+    REQUIRE(n, "no such network");
+    REQUIRE(site >= 0 && site < (int)n->drop_sites.size(), "dropout site out of range");
+    const Net::DropSite& d = n->drop_sites[site];
+    if (shape) { shape[0] = d.N; shape[1] = d.C; shape[2] = d.H; shape[3] = d.W; }
+    if (p) *p = d.p;
+    if (dst) dropout_mask(m->m->ctx->s, d.N, d.H, d.W, d.C, d.p, Net::drop_seed(seed, d.salt), dst);
+  });
+}
 int swn_model_forward(swn_model* m, int training, uint64_t seed) {
   return guard([&] { REQUIRE(m, "NULL"); m->m->forward(training != 0, seed); });
 }
@@ -391,6 +411,36 @@ int swn_op_instance_norm_act_bwd(swn_ctx* ctx, const float* x, const float* dy, 
     nchw_to_nhwc(tmp.s, dy, n, c, h, w, yv.g);
     net.backward(false, true);
     nhwc_to_nchw(tmp.s, xv.g, dx, c);
+    stream_sync(tmp.s);
+  });
+}
+int swn_op_norm_act_dropout(swn_ctx* ctx, const float* x, const float* dy, int n, int c, int h, int w, int norm, int act,
+                            float p, uint64_t seed, float* y, float* mask, float* dx) {
+  return guard([&] {
+    REQUIRE(ctx && x && y && c % 4 == 0, "bad argument (C must be a multiple of 4)");
+    REQUIRE(p >= 0.f && p < 1.f, "dropout probability must be in [0, 1)");
+    Ctx tmp(ctx->c->s);
+    ParamArena A; Net net(tmp, A);
+    Var xv = net.alloc_var(n, h, w, c, true), yv = net.alloc_var(n, h, w, c, true);
+    net.norm_act(xv, yv, norm != 0, act, p);
+    net.finalize({});
+    net.training = true; net.seed = seed;
+    nchw_to_nhwc(tmp.s, x, n, c, h, w, xv.v);
+    net.forward();
+    nhwc_to_nchw(tmp.s, yv.v, y, c);
+    if (mask) {
+      if (p > 0.f) {
+        const Net::DropSite& d = net.drop_sites.at(0);
+        dropout_mask(tmp.s, d.N, d.H, d.W, d.C, d.p, Net::drop_seed(seed, d.salt), mask);
+      } else {
+        REQUIRE(false, "mask requested with p == 0");
+      }
+    }
+    if (dy && dx) {
+      nchw_to_nhwc(tmp.s, dy, n, c, h, w, yv.g);
+      net.backward(false, true);
+      nhwc_to_nchw(tmp.s, xv.g, dx, c);
+    }
     stream_sync(tmp.s);
   });
 }

@@ -492,13 +492,14 @@ void Net::norm_act(const Var& raw, const Var& y, bool norm, int actf, float drop
   op->label = "norm_act";
   float* stats = norm ? static_cast<float*>(ctx.alloc((size_t)raw.v.N * raw.v.C * 2 * sizeof(float))) : nullptr;
   const uint64_t salt = ops.size() + 1;
+  if (drop_p > 0.f) drop_sites.push_back({salt, raw.v.N, raw.v.H, raw.v.W, raw.v.C, drop_p});
   const TView rv = raw.v, rg = raw.g, yv = y.v, yg = y.g;
   const bool has_res = residual != nullptr;
   const Var res = has_res ? *residual : Var();
   op->fwd = [=](Net& n) {
     NormActArgs a;
     a.x = rv; a.y = yv; a.stats = stats; a.norm = norm; a.act = actf;
-    a.drop_p = n.training ? drop_p : 0.f; a.seed = n.seed * 0x9E3779B1ull + salt;
+    a.drop_p = n.training ? drop_p : 0.f; a.seed = Net::drop_seed(n.seed, salt);
     a.residual = has_res ? &res.v : nullptr;
     norm_act_fwd(n.ctx.s, a);
   };
@@ -509,7 +510,7 @@ void Net::norm_act(const Var& raw, const Var& y, bool norm, int actf, float drop
     if (has_res && res.has_grad) axpy(n.ctx.s, yg, res.g, 1.f, me.acc.empty() ? 0 : me.acc[0]);
     NormActBwdArgs b;
     b.dy = yg; b.x = rv; b.stats = stats; b.dx = rg; b.norm = norm; b.act = actf;
-    b.drop_p = n.training ? drop_p : 0.f; b.seed = n.seed * 0x9E3779B1ull + salt;
+    b.drop_p = n.training ? drop_p : 0.f; b.seed = Net::drop_seed(n.seed, salt);
     norm_act_bwd(n.ctx.s, b);
   };
   ops.push_back(std::move(op));

@@ -116,6 +116,10 @@ class Net {
   Stream& wgrad_stream() { return (ctx.use_side() && keep_wino_inputs) ? ctx.fork_side() : ctx.s; }
   float* wgrad_planes(const Stream& sw) const { return (&sw == &ctx.side && wsM2) ? wsM2 : wsM; }
   std::vector<std::pair<Op*, size_t>> dg_layout;
+  // dropout sites in forward order (one per norm_act with drop_p > 0): what swn_model_dropout_mask exports
+  struct DropSite { uint64_t salt; int N, H, W, C; float p; };
+  std::vector<DropSite> drop_sites;
+  static uint64_t drop_seed(uint64_t seed, uint64_t salt) { return seed * 0x9E3779B1ull + salt; }
 
   Var alloc_var(int N, int H, int W, int C, bool need_grad);
   // layers

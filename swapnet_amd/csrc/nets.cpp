@@ -73,6 +73,7 @@ void build_warp_generator(Net& n, const Var& body, const Var& cloth, const Var& 
     n.conv(p + "6", h, raw2, CK_K3S1_REFLECT, 1024, 1024, true, ACT_NONE);
     n.norm_act(raw2, rn, true, ACT_NONE, 0.f, &r);
     n.taps["res" + std::to_string(i)] = rn;
+    n.taps["res" + std::to_string(i) + "_h"] = h;
     r = rn;
   }
   // dual decoder (:72-76)

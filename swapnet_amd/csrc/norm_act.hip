@@ -282,6 +282,15 @@ __global__ __launch_bounds__(256) void reflect_fold_kernel(const float* src, int
   }
 }
 
+__global__ __launch_bounds__(256) void dropout_mask_kernel(int N, int HW, int C, float p, uint64_t seed, float* out) {
+  const size_t total = (size_t)N * C * HW;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int pix = (int)(i % HW); const size_t q = i / HW;
+    const int c = (int)(q % C); const size_t n = q / C;
+    out[i] = drop_scale(seed, (n * HW + pix) * C + c, p);
+  }
+}
+
 inline unsigned ew_grid(size_t total) {
   size_t b = (total + 255) / 256;
   return (unsigned)std::min<size_t>(std::max<size_t>(b, 1), 256 * 16);
@@ -339,6 +348,12 @@ void norm_act_bwd(Stream& s, const NormActBwdArgs& a) {
   }
   hipLaunchKernelGGL(norm_act_bwd_apply_kernel, dim3(ew_grid((size_t)p.N * p.HW * (p.C / 4))), dim3(256), 0, hs(s), p);
   check_launch("norm_act_bwd");
+}
+
+void dropout_mask(Stream& s, int N, int H, int W, int C, float p, uint64_t seed, float* out_nchw) {
+  hipLaunchKernelGGL(dropout_mask_kernel, dim3(ew_grid((size_t)N * H * W * C)), dim3(256), 0, hs(s), N, H * W, C, p, seed,
+                     out_nchw);
+  check_launch("dropout_mask");
 }
 
 static EWp ew_params(const TView& a, const TView* b, const TView& o) {

@@ -136,6 +136,12 @@ struct NormActBwdArgs {
 };
 void norm_act_bwd(Stream& s, const NormActBwdArgs& a);
 
+// The keep/scale factor norm_act_fwd / norm_act_bwd apply at a dropout site, written out as an NCHW tensor
+// (N,C,H,W): element (n,c,h,w) = drop_scale(seed, ((n*H*W + h*W + w)*C + c), p) -- 0 or 1/(1-p).
+// Diagnostic export (swn_model_dropout_mask): parity tests hand it to the oracle so that a train-mode
+// step is compared value for value.
+void dropout_mask(Stream& s, int N, int H, int W, int C, float p, uint64_t seed, float* out_nchw);
+
 // y = act(x) elementwise on views; bwd: dx (+)= dy * act'  (derivative expressed through the
 // activation OUTPUT y: lrelu y>0?1:.2, relu y>0, tanh 1-y^2)
 void act_fwd(Stream& s, const TView& x, const TView& y, int act);

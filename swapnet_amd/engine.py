@@ -227,6 +227,21 @@ class NativeModel:
     def forward(self, training=False, seed=0):
         self.lib.call("swn_model_forward", self.handle, int(training), C.c_uint64(seed))
 
+    def dropout_masks(self, net=NET_G, seed=0):
+        """The keep/scale factors (0 or 1/(1-p)) a training-mode pass with `seed` applies at every dropout
+        site of `net`, in forward order, as NCHW tensors (diagnostic export for the parity tests)."""
+        n = C.c_int()
+        self.lib.call("swn_model_dropout_sites", self.handle, net, C.byref(n))
+        out = []
+        for i in range(n.value):
+            shape, p = (C.c_int * 4)(), C.c_float()
+            self.lib.call("swn_model_dropout_mask", self.handle, net, i, C.c_uint64(seed), None, C.byref(shape), C.byref(p))
+            t = torch.empty(tuple(shape), dtype=torch.float32, device=self.ctx.device)
+            self.lib.call("swn_model_dropout_mask", self.handle, net, i, C.c_uint64(seed), _C.ptr(t), C.byref(shape), C.byref(p))
+            out.append((t, p.value))
+        self.ctx.sync()
+        return out
+
     def output(self, slot=0):
         t = torch.empty((self.B, self.out_channels, self.H, self.W), dtype=torch.float32, device=self.ctx.device)
         self.lib.call("swn_model_get_output", self.handle, slot, _C.ptr(t))
@@ -297,6 +312,19 @@ class NativeModel:
             self.close()
         except Exception:
             pass
+
+
+def op_norm_act_dropout(ctx, x, dy=None, norm=True, act=2, p=0.5, seed=0):
+    """[InstanceNorm] -> activation -> Dropout(p), training mode, forward (+ backward when dy is given) through
+    swn_op_norm_act_dropout.  Returns (y, mask, dx): mask holds the factor (0 or 1/(1-p)) both passes applied."""
+    xd = x.to(device=ctx.device, dtype=torch.float32).contiguous()
+    dyd = None if dy is None else dy.to(device=ctx.device, dtype=torch.float32).contiguous()
+    y, mask = torch.empty_like(xd), torch.empty_like(xd)
+    dx = None if dy is None else torch.empty_like(xd)
+    n, c, h, w = xd.shape
+    ctx.lib.call("swn_op_norm_act_dropout", ctx.handle, _C.ptr(xd), _C.ptr(dyd), n, c, h, w, int(norm), int(act),
+                 C.c_float(p), C.c_uint64(seed), _C.ptr(y), _C.ptr(mask), _C.ptr(dx))
+    return y, mask, dx
 
 
 class _ArrayIface:

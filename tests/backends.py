@@ -41,6 +41,25 @@ def gpu_ctx():
     return _ctx["gpu"]
 
 
+def rel_l2(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def assert_grads_vs_fp64(got, ref32, ref64, skip, what):
+    """The gradient bar of the parity tests: per tensor, rel-L2(native, fp64 oracle) <= max(1e-3, 1.5 x
+    rel-L2(torch fp32 oracle, fp64 oracle)) -- north_star's 1e-3 wherever the reference's own fp32 backward meets
+    it, never worse than 1.5x the reference's round-off elsewhere.  Returns (worst native, worst torch-fp32)."""
+    w_hip = w_t32 = 0.0
+    for k, v in ref64.items():
+        if skip(k):
+            continue
+        e_hip, e_t32 = rel_l2(got[k], v), rel_l2(ref32[k], v)
+        w_hip, w_t32 = max(w_hip, e_hip), max(w_t32, e_t32)
+        assert e_hip <= max(1e-3, 1.5 * e_t32), (what, k, "native %.2e" % e_hip, "torch fp32 %.2e" % e_t32)
+    return w_hip, w_t32
+
+
 _models = {}
 
 

@@ -324,6 +324,13 @@ static inline float hdrop(uint64_t seed, uint64_t idx, float p) {
   return u >= p ? 1.0f / (1.0f - p) : 0.0f;
 }
 
+void dropout_mask(Stream&, int N, int H, int W, int C, float p, uint64_t seed, float* out) {
+  const size_t HW = (size_t)H * W;
+  for (size_t n = 0; n < (size_t)N; ++n)
+    for (int c = 0; c < C; ++c)
+      for (size_t pix = 0; pix < HW; ++pix) out[(n * C + c) * HW + pix] = hdrop(seed, (n * HW + pix) * C + c, p);
+}
+
 void norm_act_fwd(Stream&, const NormActArgs& a) {
   const int N = a.x.N, HW = a.x.H * a.x.W, C = a.x.C;
   for (int n = 0; n < N; ++n)

@@ -7,7 +7,7 @@ import pytest
 import torch
 
 from oracle import swapnet_oracle as O
-from oracle.golden_io import compare
+from oracle.golden_io import compare, compare_full, FULL_TENSORS
 
 # biases that feed an InstanceNorm carry round-off-only gradients (|g| ~ 1e-9); Adam
 # normalises them, so their post-step values are noise in the reference too.
@@ -107,6 +107,22 @@ def test_warp_step(warp_gold, warp_run, si):
             continue
         ok, msg = compare(g, pre + "postD/" + k, v, rtol=1e-3, atol_frac=1e-3)
         assert ok, msg
+    _check_full(g, s, pre, "warp")
+
+
+def _check_full(g, s, pre, stage):
+    """the tensors stored whole (golden_io.FULL_TENSORS): every element, not 24 samples"""
+    groups = {"gradG": "gG", "gradD": "gD", "postG": "pG", "postD": "pD"}
+    n = 0
+    for key in FULL_TENSORS[stage]:
+        if not key.startswith(pre):
+            continue
+        parts = key[len(pre):].split("/", 1)
+        t = s["fakes"] if parts[0] == "fakes" else s[groups[parts[0]]][parts[1]]
+        ok, msg = compare_full(g, key, t, rtol=1e-4 if parts[0] == "fakes" else (2e-3 if parts[0].startswith("grad") else 1e-2))
+        assert ok, msg
+        n += 1
+    assert n or pre != "step0/"
 
 
 @pytest.mark.parametrize("mode", ["lsgan", "wgan", "ce"])
@@ -224,6 +240,7 @@ def test_texture_step(tex_gold, tex_run, si):
                 continue
             ok, msg = compare(g, pre + gk + k, v, rtol=tol, atol_frac=tol)
             assert ok, msg
+    _check_full(g, s, pre, "texture")
 
 
 # ----------------------------------------------------------------------------- RoIAlign KATs

@@ -4,7 +4,7 @@ step against the CPU oracle and the golden vectors of the real reference
 (tests/golden/texture_step_64.npz; 64x64 so the U-Net has 6 levels, VGG16 with the shared
 seeded-random weights because pretrained weights are not obtainable offline: parity unpinned
 for the pretrained values, pinned for the arithmetic).
-Tolerances as in test_warp_step.py."""
+Tolerances as in test_warp_step.py (gradients: fp64 yardstick)."""
 import os
 
 import numpy as np
@@ -12,7 +12,7 @@ import pytest
 import torch
 
 from oracle import swapnet_oracle as O
-from oracle.golden_io import compare
+from oracle.golden_io import compare, compare_full, FULL_TENSORS
 from swapnet_amd import engine
 from tests import backends
 
@@ -68,9 +68,11 @@ def oracle_run(gold):
     with torch.no_grad():
         O.texture_module_forward(G, batch[0], batch[1], batch[2], taps=taps)
     st = O.TextureStepOracle(G, D, vgg)
+    s64 = st.astype(torch.float64)
     torch.manual_seed(int(gold["meta/step_seeds"][0]))
     st.step(*batch)
-    s = dict(losses=dict(st.losses), labels=list(st.labels), fakes=st.fakes.clone(),
+    s64.step(*batch, labels=st.labels)
+    s = dict(losses=dict(st.losses), labels=list(st.labels), fakes=st.fakes.clone(), g64G=s64.grads_G, g64D=s64.grads_D,
              gG={k: v.clone() for k, v in st.grads_G.items()}, gD={k: v.clone() for k, v in st.grads_D.items()},
              pG={k: v.clone() for k, v in st.G.items()}, pD={k: v.clone() for k, v in st.D.items()})
     return G, D, vgg, batch, taps, s
@@ -108,12 +110,9 @@ def test_texture_step_matches_oracle_and_reference(backend, oracle_run, gold):
     ok, msg = compare(gold, "step0/fakes", out, 1e-3, 1e-3)
     assert ok, msg
     keys = list(G.keys())
-    for k, v in s["gD"].items():
-        if not noise_bias(k, keys):
-            assert rel(gD[k], v) < 5e-3, ("gradD", k, rel(gD[k], v))
-    for k, v in s["gG"].items():
-        if not noise_bias(k, keys):
-            assert rel(gG[k], v) < 1e-2, ("gradG", k, rel(gG[k], v))
+    skip = lambda k: noise_bias(k, keys)
+    backends.assert_grads_vs_fp64(gD, s["gD"], s["g64D"], skip, "gradD")
+    backends.assert_grads_vs_fp64(gG, s["gG"], s["g64G"], skip, "gradG")
     pG = m.state_dict(engine.NET_G, to_cpu=True)
     pD = m.state_dict(engine.NET_D, to_cpu=True)
     for k, v in s["pG"].items():
@@ -124,6 +123,12 @@ def test_texture_step_matches_oracle_and_reference(backend, oracle_run, gold):
     for k, v in s["pD"].items():
         if not noise_bias(k, keys):
             assert rel(pD[k], v) < 1e-3, ("postD", k, rel(pD[k], v))
+    got = {"fakes": out, "gradG": gG, "gradD": gD, "postG": pG, "postD": pD}
+    for key in FULL_TENSORS["texture"]:          # stored whole in the golden file: every element is checked
+        grp, _, name = key[len("step0/"):].partition("/")
+        t = got[grp] if grp == "fakes" else got[grp][name]
+        ok, msg = compare_full(gold, key, t, rtol=1e-3 if grp == "fakes" else (3e-3 if grp.startswith("grad") else 1e-2))
+        assert ok, msg
     m.close()
 
 
@@ -131,7 +136,8 @@ def test_texture_step_matches_oracle_and_reference(backend, oracle_run, gold):
 def test_texture_step_at_full_resolution_matches_oracle():
     """One texture G+D step at the C3 resolution (256x256, 12 ROIs; bs 1 so the CPU oracle finishes in
     seconds): 8-level U-Net, 128x128 RoIAlign, VGG16 at 256x256 (6-point Winograd from 64 channels up),
-    PatchGAN at 31x31 -- losses / fakes 1e-3, gradients 5e-3 (D) / 1e-2 (G), RoIAlign bit-exact."""
+    PatchGAN at 31x31 -- losses / fakes 1e-3, gradients by the fp64 yardstick (backends.assert_grads_vs_fp64),
+    RoIAlign bit-exact."""
     ctx = backends.gpu_ctx()
     B, H = 1, 256
     torch.manual_seed(5)
@@ -142,8 +148,10 @@ def test_texture_step_at_full_resolution_matches_oracle():
     with torch.no_grad():
         O.texture_module_forward(G, batch[0], batch[1], batch[2], taps=taps)
     st = O.TextureStepOracle({k: v.clone() for k, v in G.items()}, {k: v.clone() for k, v in D.items()}, vgg)
+    s64 = st.astype(torch.float64)
     torch.manual_seed(23)
     st.step(*batch)
+    s64.step(*batch, labels=st.labels)
     m = engine.NativeModel(ctx, "texture", B, H, H, is_train=True)
     try:
         m.load_state_dict(engine.NET_G, G)
@@ -164,12 +172,9 @@ def test_texture_step_at_full_resolution_matches_oracle():
             assert abs(L[k] - v) <= 1e-3 * abs(v) + 1e-6, (k, L[k], v)
         assert rel(m.output(), st.fakes) < 1e-3
         keys = list(G.keys())
-        for k, v in st.grads_D.items():
-            if not noise_bias(k, keys):
-                assert rel(gD[k], v) < 5e-3, ("gradD", k, rel(gD[k], v))
-        for k, v in st.grads_G.items():
-            if not noise_bias(k, keys):
-                assert rel(gG[k], v) < 1e-2, ("gradG", k, rel(gG[k], v))
+        skip = lambda k: noise_bias(k, keys)
+        backends.assert_grads_vs_fp64(gD, st.grads_D, s64.grads_D, skip, "gradD 256")
+        backends.assert_grads_vs_fp64(gG, st.grads_G, s64.grads_G, skip, "gradG 256")
     finally:
         m.close()
 

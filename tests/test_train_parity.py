@@ -1,0 +1,332 @@
+"""Parity in the configuration bench.py times: TRAINING mode (dropout 0.5 at the
+reference's 7 warp / 3 texture sites, modules/layers.py:22-23,136 and pix2pix_modules.py:251-252), the full
+batch sizes of BASELINE.json C2 / C3, and gradient tolerances measured against an fp64 evaluation.
+
+How a training-mode step can be compared value for value: the library exports, per dropout site, the keep/scale
+factor its forward AND backward kernels apply for a given seed (swn_model_dropout_mask).  The oracle replays those
+tensors at its nn.Dropout call sites (oracle.MaskReplay) -- autograd then multiplies the gradient by the same
+tensor, which is nn.Dropout's definition -- so a wrong scale, a forward/backward mask mismatch or a misplaced
+site shows up as a plain numerical difference.  The masks themselves are checked separately: values exactly
+{0, 1/(1-p)}, keep rate 1-p within 4 sigma, distinct per site / seed / rank, and (taps) y_train == y_eval * mask
+bit for bit at the sites whose input does not depend on another dropout.
+
+Gradient tolerance: rel-L2(HIP, fp64 oracle) <= max(1e-3, 1.5 x rel-L2(torch fp32 oracle, fp64 oracle)) per tensor,
+i.e. north_star's 1e-3 wherever torch's own fp32 backward meets it, and never worse than 1.5x torch elsewhere.
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import swapnet_oracle as O
+from swapnet_amd import engine
+from tests import backends
+from tests.test_texture_step import noise_bias as tex_noise_bias, vgg_state_dict
+from tests.test_warp_step import noise_bias as warp_noise_bias
+
+BACKENDS = [pytest.param("sim", id="hostsim"), pytest.param("gpu", id="mi355x", marks=pytest.mark.gpu)]
+
+
+def _ctx(kind):
+    return backends.gpu_ctx() if kind == "gpu" else backends.hostsim_ctx()
+
+
+def rel(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def noise_bias(name, keys=()):
+    # biases feeding an InstanceNorm: true gradient 0, the reference's value is round-off
+    if name.startswith("unet."):
+        return tex_noise_bias(name, keys)
+    return warp_noise_bias(name)
+
+
+def _phased_step(m, labels, training, seed):
+    m.forward(training, seed)
+    m.backward_D(labels[0], labels[1])
+    gD = m.state_dict(engine.NET_D, which=engine.W_GRAD, to_cpu=True)
+    m.optimizer_step(engine.NET_D)
+    m.backward_G(labels[2])
+    gG = m.state_dict(engine.NET_G, which=engine.W_GRAD, to_cpu=True)
+    m.optimizer_step(engine.NET_G)
+    return gD, gG
+
+
+def _check_step(m, st, gD, gG, tol_loss=1e-3, tol_out=1e-3, tol_gD=5e-3, tol_gG=1e-2, tol_post=1e-3, what=""):
+    L = m.losses()
+    for k, v in st.losses.items():
+        assert abs(L[k] - v) <= tol_loss * abs(v) + 1e-6, (what, "loss", k, L[k], v)
+    assert rel(m.output(), st.fakes) < tol_out, (what, "fakes", rel(m.output(), st.fakes))
+    worst = {}
+    for name, got, ref, tol in (("gradD", gD, st.grads_D, tol_gD), ("gradG", gG, st.grads_G, tol_gG)):
+        for k, v in ref.items():
+            if noise_bias(k, list(ref)):
+                continue
+            e = rel(got[k], v)
+            worst[name] = max(worst.get(name, 0.0), e)
+            assert e < tol, (what, name, k, e)
+    pG, pD = m.state_dict(engine.NET_G, to_cpu=True), m.state_dict(engine.NET_D, to_cpu=True)
+    for name, got, ref in (("postG", pG, st.G), ("postD", pD, st.D)):
+        for k, v in ref.items():
+            if not noise_bias(k, list(ref)):
+                e = rel(got[k], v)
+                worst[name] = max(worst.get(name, 0.0), e)
+                assert e < tol_post, (what, name, k, e)
+    return worst
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# dropout semantics through the C-ABI
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_dropout_mask_semantics(backend):
+    ctx = _ctx(backend)
+    B, H = 2, 64
+    torch.manual_seed(0)
+    G = O.warp_module_params()
+    batch = O.synth_warp_batch(B, H, H, seed=1234)
+    m = backends.get_model(ctx, "warp", B, H)
+    backends.reset_state(m, {engine.NET_G: G, engine.NET_D: O.patchgan_params(22)})
+    for i, t in enumerate(batch):
+        m.set_input(i, t)
+    masks = m.dropout_masks(engine.NET_G, seed=7)
+    # the reference's 7 sites, in forward order, with the shapes of the layers they follow
+    assert [tuple(t.shape) for t, _ in masks] == [(B, 512, H // 16, H // 16), (B, 1024, H // 32, H // 32),
+                                                    (B, 1024, H // 64, H // 64)] + [(B, 1024, H // 16, H // 16)] * 4
+    for t, p in masks:
+        assert p == 0.5
+        vals = torch.unique(t.cpu())
+        assert vals.tolist() == [0.0, 2.0], vals                      # exactly {0, 1/(1-p)}
+        n = t.numel()
+        keep = float((t > 0).double().mean())
+        assert abs(keep - 0.5) < 4 * 0.5 / math.sqrt(n) + 1e-9, (keep, n)
+    cpu = [t.cpu() for t, _ in masks]
+    # independent streams: per site (the four resblock sites share a shape), per seed, per rank (base_gan seeds
+    # rank r with seed + r, swapnet_amd/models/base_gan.py)
+    for i in range(3, 7):
+        for j in range(i + 1, 7):
+            assert 0.4 < float((cpu[i] == cpu[j]).double().mean()) < 0.6
+    other = [t.cpu() for t, _ in m.dropout_masks(engine.NET_G, seed=8)]
+    for a, b in zip(cpu, other):
+        if a.numel() >= 4096:
+            assert 0.4 < float((a == b).double().mean()) < 0.6
+    again = [t.cpu() for t, _ in m.dropout_masks(engine.NET_G, seed=7)]
+    assert all(torch.equal(a, b) for a, b in zip(cpu, again))
+    # forward applies exactly this factor: at the sites fed by dropout-free layers y_train == y_eval * mask
+    m.forward(False, 0)
+    ev = {k: m.tap(engine.NET_G, k).cpu() for k in ("body_d4", "cloth_d5")}
+    m.forward(True, 7)
+    tr = {k: m.tap(engine.NET_G, k).cpu() for k in ("body_d4", "cloth_d5", "cloth_d6", "res0_h")}
+    assert torch.equal(tr["body_d4"], ev["body_d4"] * cpu[0])
+    assert torch.equal(tr["cloth_d5"], ev["cloth_d5"] * cpu[1])
+    # downstream sites: zero exactly where the mask is zero
+    assert float(tr["cloth_d6"][cpu[2] == 0].abs().max()) == 0.0
+    assert float(tr["res0_h"][cpu[3] == 0].abs().max()) == 0.0
+    # eval mode never drops
+    m.forward(False, 7)
+    assert torch.equal(m.tap(engine.NET_G, "body_d4").cpu(), ev["body_d4"])
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_op_level_dropout_forward_backward_share_one_mask(backend):
+    """InstanceNorm -> ReLU -> Dropout as one op (ResidualBlock's first half, modules/layers.py:133-136) through
+    swn_op_norm_act_dropout: y in {0, 2*relu(IN(x))}, and the input gradient equals autograd's with that mask."""
+    ctx = _ctx(backend)
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 8, 12, 12, generator=g)
+    dy = torch.randn(2, 8, 12, 12, generator=g)
+    y, mask, dx = engine.op_norm_act_dropout(ctx, x, dy, act=2, p=0.5, seed=11)
+    y, mask, dx = y.cpu(), mask.cpu(), dx.cpu()
+    assert torch.unique(mask).tolist() == [0.0, 2.0]
+    xr = x.clone().requires_grad_(True)
+    ref = torch.relu(torch.nn.functional.instance_norm(xr, eps=1e-5)) * mask
+    ref.backward(dy)
+    assert rel(y, ref.detach()) < 1e-5
+    assert rel(dx, xr.grad) < 1e-4
+    assert float(y[mask == 0].abs().max()) == 0.0
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# training-mode step == oracle with the replayed masks
+# ---------------------------------------------------------------------------------------------------------------
+def _warp_train_case(ctx, B, H, seed_w, seed_b, drop_seed, model=None):
+    torch.manual_seed(seed_w)
+    G, D = O.warp_module_params(), O.patchgan_params(22)
+    batch = O.synth_warp_batch(B, H, H, seed=seed_b)
+    m = model or engine.NativeModel(ctx, "warp", B, H, H)
+    backends.reset_state(m, {engine.NET_G: G, engine.NET_D: D})
+    for i, t in enumerate(batch):
+        m.set_input(i, t)
+    masks = [t.cpu() for t, _ in m.dropout_masks(engine.NET_G, seed=drop_seed)]
+    return m, G, D, batch, masks
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_warp_training_mode_step_matches_oracle(backend):
+    ctx = _ctx(backend)
+    labels = [0.9, 0.8, 1.0]
+    m, G, D, batch, masks = _warp_train_case(ctx, 2, 64, 0, 1234, 41, model=backends.get_model(ctx, "warp", 2, 64))
+    replay = O.MaskReplay(masks)
+    st = O.WarpStepOracle(G, D, training=replay)
+    st.step(*batch, labels=labels)
+    assert replay.done()
+    gD, gG = _phased_step(m, labels, True, 41)
+    _check_step(m, st, gD, gG, what="warp train 64")
+    # and the step really was stochastic: the eval-mode loss differs
+    ev = O.WarpStepOracle(G, D)
+    ev.step(*batch, labels=labels)
+    assert rel(ev.fakes, st.fakes) > 1e-2
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["eval", "train"])
+def test_warp_c2_full_batch_step_matches_oracle(mode):
+    """BASELINE.json config C2 exactly: warp 256x256, bs 32, fp32 -- the shapes bench.py times (256x128 MFMA tiles
+    with M >= 2048, the bs-32 split-K plans, Winograd planes of 512 tiles).  One phased G+D step against the CPU
+    oracle; mode 'train' is bench.py's mode (dropout on), with the library's masks replayed in the oracle."""
+    ctx = backends.gpu_ctx()
+    labels = [0.85, 0.95, 0.75]
+    m, G, D, batch, masks = _warp_train_case(ctx, 32, 256, 5, 77, 1234)
+    try:
+        training = mode == "train"
+        st = O.WarpStepOracle(G, D, training=O.MaskReplay(masks) if training else False)
+        st.step(*batch, labels=labels)
+        gD, gG = _phased_step(m, labels, training, 1234)
+        worst = _check_step(m, st, gD, gG, what="warp C2 bs32 " + mode)
+        print("warp C2 bs32", mode, "worst rel-L2:", {k: "%.2e" % v for k, v in worst.items()})
+    finally:
+        m.close()
+
+
+def _texture_case(ctx, B, H, drop_seed):
+    torch.manual_seed(9)
+    G, D = O.texture_module_params(img_size=H), O.patchgan_params(22)
+    vgg = O.vgg16_feature_params()
+    batch = O.synth_texture_batch(B, H, H, seed=31)
+    m = engine.NativeModel(ctx, "texture", B, H, H)
+    backends.reset_state(m, {engine.NET_G: G, engine.NET_D: D})
+    m.load_state_dict(engine.NET_VGG, vgg_state_dict(m, vgg))
+    for i, t in enumerate(batch):
+        m.set_input(i, t)
+    masks = [t.cpu() for t, _ in m.dropout_masks(engine.NET_G, seed=drop_seed)]
+    return m, G, D, vgg, batch, masks
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["eval", "train"])
+def test_texture_c3_full_batch_step_matches_oracle(mode):
+    """BASELINE.json config C3 exactly: texture 256x256, bs 16, 12 ROIs, L1 + VGG16 content + style on."""
+    ctx = backends.gpu_ctx()
+    labels = [0.85, 0.95, 0.75]
+    m, G, D, vgg, batch, masks = _texture_case(ctx, 16, 256, 99)
+    try:
+        assert len(masks) == 3 and all(tuple(t.shape[1:]) == (512, s, s) for t, s in zip(masks, (4, 8, 16)))
+        training = mode == "train"
+        st = O.TextureStepOracle(G, D, vgg, training=O.MaskReplay(masks) if training else False)
+        st.step(*batch, labels=labels)
+        gD, gG = _phased_step(m, labels, training, 99)
+        worst = _check_step(m, st, gD, gG, what="texture C3 bs16 " + mode)
+        print("texture C3 bs16", mode, "worst rel-L2:", {k: "%.2e" % v for k, v in worst.items()})
+    finally:
+        m.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# the gradient tolerance, earned: HIP vs an fp64 evaluation, next to torch's own fp32 backward
+# ---------------------------------------------------------------------------------------------------------------
+def _fp64_yardstick(G, D, batch, labels, training32, training64):
+    s32 = O.WarpStepOracle(G, D, training=training32)
+    s32.step(*batch, labels=labels)
+    s64 = O.WarpStepOracle(G, D, training=training64, dtype=torch.float64)
+    s64.step(*batch, labels=labels)
+    return s32, s64
+
+
+def _assert_vs_fp64(got, s32, s64, which, what):
+    ref64 = getattr(s64, which)
+    w = backends.assert_grads_vs_fp64(got, getattr(s32, which), ref64, lambda k: noise_bias(k, list(ref64)), (what, which))
+    return [("worst", w[0], w[1])]
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("winograd", ["on", "off"])
+def test_gradients_against_fp64_oracle(backend, winograd, monkeypatch):
+    """Per-tensor gradient error of the native step measured against the SAME step in float64, beside the error of
+    torch's fp32 CPU backward (the reference's arithmetic): HIP <= max(1e-3, 1.5 x torch-fp32).  Winograd
+    F(4x4,3x3) / F(3x3,4x4) on and off (fp32 Winograd is where a looser bound could hide a real defect)."""
+    if winograd == "off":
+        monkeypatch.setenv("SWN_WINOGRAD", "0")
+    ctx = _ctx(backend)
+    labels = [0.9, 0.8, 1.0]
+    B, H = 2, 64
+    torch.manual_seed(0)
+    G, D = O.warp_module_params(), O.patchgan_params(22)
+    batch = O.synth_warp_batch(B, H, H, seed=1234)
+    s32, s64 = _fp64_yardstick(G, D, batch, labels, False, False)
+    m = engine.NativeModel(ctx, "warp", B, H, H)
+    try:
+        backends.reset_state(m, {engine.NET_G: G, engine.NET_D: D})
+        for i, t in enumerate(batch):
+            m.set_input(i, t)
+        gD, gG = _phased_step(m, labels, False, 0)
+        rows = _assert_vs_fp64(gD, s32, s64, "grads_D", "64x64") + _assert_vs_fp64(gG, s32, s64, "grads_G", "64x64")
+        print("max HIP err vs fp64 %.2e ; max torch-fp32 err vs fp64 %.2e" % (max(r[1] for r in rows), max(r[2] for r in rows)))
+        assert rel(m.output(), s64.fakes) < 1e-4
+    finally:
+        m.close()
+
+
+@pytest.mark.gpu
+def test_gradients_against_fp64_oracle_at_full_resolution():
+    """The same yardstick at 256x256 (bs 2): F(4x4,3x3) on the 16x16 maps with 1024-channel reductions, the fused
+    tail kernels, F(3x3,4x4) on PatchGAN's 31x31 map."""
+    ctx = backends.gpu_ctx()
+    labels = [0.9, 0.8, 1.0]
+    B, H = 2, 256
+    torch.manual_seed(3)
+    G, D = O.warp_module_params(), O.patchgan_params(22)
+    batch = O.synth_warp_batch(B, H, H, seed=99)
+    s32, s64 = _fp64_yardstick(G, D, batch, labels, False, False)
+    m = engine.NativeModel(ctx, "warp", B, H, H)
+    try:
+        backends.reset_state(m, {engine.NET_G: G, engine.NET_D: D})
+        for i, t in enumerate(batch):
+            m.set_input(i, t)
+        gD, gG = _phased_step(m, labels, False, 0)
+        rows = _assert_vs_fp64(gD, s32, s64, "grads_D", "256x256") + _assert_vs_fp64(gG, s32, s64, "grads_G", "256x256")
+        print("max HIP err vs fp64 %.2e ; max torch-fp32 err vs fp64 %.2e" % (max(r[1] for r in rows), max(r[2] for r in rows)))
+    finally:
+        m.close()
+
+
+@pytest.mark.gpu
+def test_training_mode_loss_statistics_match_oracle():
+    """Train-mode statistics without replaying masks: the mean generator loss over K independent dropout draws
+    (library RNG) against the oracle's mean over K draws of torch's RNG -- same distribution, different streams."""
+    ctx = backends.gpu_ctx()
+    B, H, K = 4, 64, 24
+    torch.manual_seed(0)
+    G, D = O.warp_module_params(), O.patchgan_params(22)
+    batch = O.synth_warp_batch(B, H, H, seed=5)
+    m = engine.NativeModel(ctx, "warp", B, H, H)
+    try:
+        got, ref = [], []
+        for k in range(K):
+            backends.reset_state(m, {engine.NET_G: G, engine.NET_D: D})
+            for i, t in enumerate(batch):
+                m.set_input(i, t)
+            m.step([0.9, 0.8, 1.0], training=True, seed=1000 + k)
+            got.append(m.losses()["G_ce"])
+            torch.manual_seed(2000 + k)
+            st = O.WarpStepOracle(G, D, training=True)
+            st.step(*batch, labels=[0.9, 0.8, 1.0])
+            ref.append(st.losses["G_ce"])
+        got, ref = np.array(got), np.array(ref)
+        se = math.sqrt(got.var(ddof=1) / K + ref.var(ddof=1) / K)
+        assert abs(got.mean() - ref.mean()) < 4 * se + 1e-3 * abs(ref.mean()), (got.mean(), ref.mean(), se)
+        assert 0.5 < got.std(ddof=1) / ref.std(ddof=1) < 2.0
+    finally:
+        m.close()

@@ -5,9 +5,11 @@ from the real reference (tests/golden/warp_step_64.npz, config C1 shape 64x64).
 fp32 tolerances (north_star: 1e-3 relative):
   forward activations / fakes / losses : 1e-3 (observed ~1e-6 .. 1e-5)
   post-step weights                    : 1e-3 rel-L2 per tensor
-  gradients                            : 5e-3 (D) / 1e-2 (G) rel-L2 per tensor -- the reference's own fp32 CPU
-    backward differs from an fp64-accumulated evaluation by ~1e-3 on the deep layers, so a
-    tighter bound would test the oracle's round-off, not our kernels.
+  gradients                            : measured against the SAME step evaluated in float64 (oracle dtype=float64):
+    rel-L2(native, fp64) <= max(1e-3, 1.5 x rel-L2(torch fp32, fp64)) per tensor (backends.assert_grads_vs_fp64).
+    The reference's own fp32 CPU backward is ~1.3e-3 away from the fp64 evaluation on the deep layers
+    (printed by tests/test_train_parity.py::test_gradients_against_fp64_oracle), so a fixed 1e-3 against the
+    fp32 oracle would test the oracle's round-off, not our kernels.
 Biases that feed an InstanceNorm are excluded from grad / post-step checks: their true
 gradient is 0, the reference's is round-off noise that Adam normalises to +-lr.
 """
@@ -18,7 +20,7 @@ import pytest
 import torch
 
 from oracle import swapnet_oracle as O
-from oracle.golden_io import compare
+from oracle.golden_io import compare, compare_full, FULL_TENSORS
 from swapnet_amd import engine
 from tests import backends
 
@@ -54,9 +56,12 @@ def oracle_run(gold):
     st = O.WarpStepOracle(G, D)
     steps = []
     for seed in gold["meta/step_seeds"]:
+        s64 = st.astype(torch.float64)          # same pre-step state, evaluated in double
         torch.manual_seed(int(seed))
         st.step(*batch)
+        s64.step(*batch, labels=st.labels)
         steps.append(dict(losses=dict(st.losses), labels=list(st.labels), fakes=st.fakes.clone(),
+                          g64G=s64.grads_G, g64D=s64.grads_D,
                           gG={k: v.clone() for k, v in st.grads_G.items()},
                           gD={k: v.clone() for k, v in st.grads_D.items()},
                           pG={k: v.clone() for k, v in st.G.items()}, pD={k: v.clone() for k, v in st.D.items()},
@@ -126,14 +131,8 @@ def test_warp_two_steps_match_oracle_and_reference(backend, oracle_run, gold):
         assert rel(out, s["fakes"]) < 1e-3
         ok, msg = compare(gold, pre + "fakes", out, 1e-3, 1e-3)
         assert ok, msg
-        for k, v in s["gD"].items():
-            if not noise_bias(k):
-                assert rel(gD[k], v) < 5e-3, (si, "gradD", k, rel(gD[k], v))
-        for k, v in s["gG"].items():
-            if not noise_bias(k):
-                # G's gradient flows through the D that was Adam-updated inside this very step
-                # (base_gan.py:199 precedes backward_G), which amplifies gradD round-off once more
-                assert rel(gG[k], v) < 1e-2, (si, "gradG", k, rel(gG[k], v))
+        backends.assert_grads_vs_fp64(gD, s["gD"], s["g64D"], noise_bias, (si, "gradD"))
+        backends.assert_grads_vs_fp64(gG, s["gG"], s["g64G"], noise_bias, (si, "gradG"))
         pG = m.state_dict(engine.NET_G, to_cpu=True)
         pD = m.state_dict(engine.NET_D, to_cpu=True)
         for k, v in s["pG"].items():
@@ -144,6 +143,15 @@ def test_warp_two_steps_match_oracle_and_reference(backend, oracle_run, gold):
         for k, v in s["pD"].items():
             if not noise_bias(k):
                 assert rel(pD[k], v) < 1e-3, (si, "postD", k, rel(pD[k], v))
+        # the tensors the golden file stores WHOLE (recorded from the real reference): every element of the
+        # generator output and of the gradients at both ends of the backward chain, not 24 samples
+        got = {"fakes": out, "gradG": gG, "gradD": gD, "postG": pG, "postD": pD}
+        for key in FULL_TENSORS["warp"]:
+            if key.startswith(pre):
+                grp, _, name = key[len(pre):].partition("/")
+                t = got[grp] if grp == "fakes" else got[grp][name]
+                ok, msg = compare_full(gold, key, t, rtol=1e-3 if grp == "fakes" else (3e-3 if grp.startswith("grad") else 1e-2))
+                assert ok, msg
     # Adam moments come back in the reference's state-dict layout
     ea = m.state_dict(engine.NET_G, which=engine.W_EXP_AVG, to_cpu=True)
     assert ea["body_down1.model.0.weight"].shape == (64, 3, 4, 4)
@@ -220,15 +228,17 @@ def test_warp_step_at_full_resolution_matches_oracle():
     """One full G+D step at the C2 resolution (256x256; bs 2 so the CPU oracle finishes in seconds): the
     shapes every full-size kernel path sees -- F(4x4,3x3) on 16x16 maps with the 18x18 reflect-padded
     gradient, F(3x3,4x4) on PatchGAN's 31x31 map, the fused 4-phase tail conv at 128x128, the head conv --
-    against the oracle: losses / fakes 1e-3, gradients 5e-3 (D) / 1e-2 (G)."""
+    against the oracle: losses / fakes 1e-3, gradients by the fp64 yardstick (module docstring)."""
     ctx = backends.gpu_ctx()
     B, H = 2, 256
     torch.manual_seed(3)
     G, D = O.warp_module_params(), O.patchgan_params(22)
     batch = O.synth_warp_batch(B, H, H, seed=99)
     st = O.WarpStepOracle({k: v.clone() for k, v in G.items()}, {k: v.clone() for k, v in D.items()})
+    s64 = st.astype(torch.float64)
     torch.manual_seed(17)
     st.step(*batch)
+    s64.step(*batch, labels=st.labels)
     m = engine.NativeModel(ctx, "warp", B, H, H)
     try:
         backends.reset_state(m, {engine.NET_G: G, engine.NET_D: D})
@@ -244,12 +254,8 @@ def test_warp_step_at_full_resolution_matches_oracle():
         for k, v in st.losses.items():
             assert abs(L[k] - v) <= 1e-3 * abs(v) + 1e-6, (k, L[k], v)
         assert rel(m.output(), st.fakes) < 1e-3
-        for k, v in st.grads_D.items():
-            if not noise_bias(k):
-                assert rel(gD[k], v) < 5e-3, ("gradD", k, rel(gD[k], v))
-        for k, v in st.grads_G.items():
-            if not noise_bias(k):
-                assert rel(gG[k], v) < 1e-2, ("gradG", k, rel(gG[k], v))
+        backends.assert_grads_vs_fp64(gD, st.grads_D, s64.grads_D, noise_bias, "gradD 256")
+        backends.assert_grads_vs_fp64(gG, st.grads_G, s64.grads_G, noise_bias, "gradG 256")
     finally:
         m.close()
 
@@ -341,9 +347,7 @@ def test_resblock_conv_variants_match_oracle(backend, variant, oracle_run, monke
         m.optimizer_step(engine.NET_D)
         m.backward_G(s["labels"][2])
         gG = m.state_dict(engine.NET_G, which=engine.W_GRAD, to_cpu=True)
-        for k, v in s["gG"].items():
-            if not noise_bias(k):
-                assert rel(gG[k], v) < 1e-2, (variant, k, rel(gG[k], v))
+        backends.assert_grads_vs_fp64(gG, s["gG"], s["g64G"], noise_bias, variant)
     finally:
         m.close()
 
