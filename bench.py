@@ -15,12 +15,16 @@ gradient arenas; the generator's backward runs in buckets (swn_model_backward_G_
 bucket's all-reduce overlaps the back-propagation of the earlier layers.
 
 Prints ONE JSON line (rank 0).  Extra objects:
-  roofline     -- dominant kernel family (conv_fwd 256x128 MFMA tile): algorithmic FLOPs
-                  (2*M*N*K per launch) / HIP-event time of those launches vs the 157.3 TFLOP/s
-                  fp32 MFMA peak; `step_frac` = whole-step algorithmic FLOPs (251.34 GFLOP/img,
-                  BASELINE.md section 3) / step time / peak.  (`achieved` counts the FLOPs the
-                  kernel really executes; `step_frac` charges the dense-conv definition although the
-                  Winograd / folded-tail layers execute fewer -- both are stated in DESIGN.md.)
+  roofline     -- dominant kernel family: FLOPs the kernel EXECUTES (2*M*N*K per launch) / HIP-event time of
+                  those launches vs the 157.3 TFLOP/s fp32 MFMA peak (`frac`).  Whole step, two readings:
+                  `step_frac_executed` = executed FLOPs of all implicit-GEMM launches of one step / step time /
+                  peak -- the fraction of the matrix pipe the step really uses, the number to quote;
+                  `algorithmic_speedup` = dense-conv FLOPs of the step (251.34 GFLOP/img)
+                  / executed FLOPs (Winograd F(4x4,3x3) / F(3x3,4x4) and the folded tail conv execute fewer);
+                  `dense_equivalent_frac` = their product (dense-count FLOPs / step time / peak), which exceeds
+                  step_frac_executed by exactly that factor and is NOT a utilisation figure.
+                  `traffic` = HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC
+                  passes of this same command (`traffic_source`), not collected inside this run.
   cpu_baseline -- the CPU oracle (a port of the reference step, oracle/swapnet_oracle.py) timed
                   on this box's host cores on a bounded sample (N=1 only).
 """
@@ -39,7 +43,7 @@ GFLOP_PER_IMG_256 = 251.34          # BASELINE.md section 3 (dense-conv definiti
 PEAK_FP32_MFMA_TFLOPS = 157.3       # MI355X_MICROARCH.md "Peak FP32 (matrix)"
 
 
-def cpu_baseline(sample_bs=4, size=256, warm=1, timed=2):
+def cpu_baseline(sample_bs=4, size=256, warm=2, timed=5):
     """Oracle = functional port of the reference's WarpModel step on torch CPU ("kind": "port")."""
     from oracle import swapnet_oracle as O
     # threads actually usable by this process (cgroup / affinity aware), capped: beyond ~32 threads
@@ -210,21 +214,29 @@ def main():
             k = kernels[dom]
             ach = k["flops"] / (k["ms"] * 1e-3) / 1e12
             gemm_ms = sum(v["ms"] for v in kernels.values()) / nprof
-            traffic = None
-            tpath = os.path.join(REPO, "profiles", "traffic_r01.json")
+            traffic, traffic_src = None, None
             rp_name = {"conv_fwd_128x128_fast": "conv_fwd_kernel<2, 2, 2, 2, true>",
-                       "conv_fwd_256x128_fast": "conv_fwd_kernel<2, 2, 4, 2, true>"}.get(dom)
-            if os.path.exists(tpath) and rp_name:
-                # HBM bytes per launch from the committed rocprofv3 PMC passes of this same command
-                # (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE; see profiles/README.md)
-                t = json.load(open(tpath))["kernels"].get(rp_name)
-                if t:
-                    traffic = t["fetch_bytes_per_launch"] + t["write_bytes_per_launch"]
+                       "conv_fwd_256x128_fast": "conv_fwd_kernel<2, 2, 4, 2, true>"}.get(dom, dom)
+            for tname in ("traffic_r02.json", "traffic_r01.json"):
+                tpath = os.path.join(REPO, "profiles", tname)
+                if os.path.exists(tpath):
+                    # HBM bytes per launch from the committed rocprofv3 PMC passes of this same command
+                    # (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE; see profiles/README.md)
+                    t = json.load(open(tpath))["kernels"].get(rp_name)
+                    if t:
+                        traffic = t["fetch_bytes_per_launch"] + t["write_bytes_per_launch"]
+                        traffic_src = "profiles/" + tname + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command; not collected in this run)"
+                        break
+            exec_flops_step = sum(v["flops"] for v in kernels.values()) / nprof
+            dense_flops_step = flop_per_img * B
             out["roofline"] = {
                 "bound": "mfma", "kernel": dom, "measured": "HIP events, in-order pass (second stream off)", "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS,
-                "unit": "TFLOP/s", "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic,
+                "unit": "TFLOP/s", "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
                 "avg_launch_ms": round(k["ms"] / k["launches"], 4), "launches_per_step": k["launches"] // nprof,
-                "step_frac": round(flop_per_img * B / (ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
+                "step_frac_executed": round(exec_flops_step / (ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
+                "executed_tflop_per_step": round(exec_flops_step / 1e12, 3),
+                "algorithmic_speedup": round(dense_flops_step / exec_flops_step, 3),
+                "dense_equivalent_frac": round(dense_flops_step / (ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
                 "gemm_ms_per_step": round(gemm_ms, 2),
                 "all_gemm_kernels": {n: {"tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2),
                                          "ms_per_step": round(v["ms"] / nprof, 3)} for n, v in sorted(kernels.items())},
