@@ -30,7 +30,7 @@ extern "C" {
 typedef struct swn_ctx swn_ctx;
 typedef struct swn_model swn_model;
 
-int swn_abi_version(void);
+int swn_abi_version(void);   /* 2: swn_hyper gained d_b1, d_b2 */
 const char* swn_last_error(void);
 /* 1 when this library executes on a HIP device (libswapnet_hip.so), 0 for the CI simulator */
 int swn_is_device_build(void);
@@ -81,6 +81,8 @@ typedef struct swn_hyper {
   int warp_mode_ce;  /* 1 = --warp_mode ce (generator only) */
   float grad_scale;  /* multiplies every loss gradient: 1/world_size under data parallelism so the
                         RCCL all-reduce(SUM) of the arenas yields the mean without an extra pass */
+  float d_b1, d_b2;  /* AdamW betas of optimizer_D (0 = same as b1 / b2): the two torch optimizers of the
+                        reference are independent objects (models/base_gan.py:87-120) */
 } swn_hyper;
 int swn_model_set_hyper(swn_model* m, const swn_hyper* h);
 
@@ -118,6 +120,17 @@ int swn_model_get_tap(swn_model* m, int net, const char* name, float* dev_nchw, 
 int swn_model_dropout_sites(swn_model* m, int net, int* count);
 int swn_model_dropout_mask(swn_model* m, int net, int site, uint64_t dropout_seed, float* dev_nchw, int shape[4],
                            float* p);
+
+/* NLayerDiscriminator.forward(input) (modules/discriminators.py:134-136) as a standalone call on the model's
+ * discriminator weights: x = conditioned input in the reference's channel order, (B, 22, H, W); pred receives
+ * (B, 1, H/8-2, W/8-2).  Uses a private activation set: self.fakes and the staged batch stay untouched. */
+int swn_model_discriminate(swn_model* m, const float* x_nchw, float* pred_nchw);
+/* PerceptualLoss(use_style)(output, target) -> (content, style) (modules/losses/perceptual.py:49-66), texture model:
+ * output / target (B, 3, H, W); out2 = device float[2] = { sum over the 5 VGG16 slices of MSE(normalised features),
+ * 5 x MSE(Gram(output), Gram(target)) }.  d_output (optional, (B,3,H,W)) receives content_w * d(content)/d(output)
+ * + style_w * d(style)/d(output) -- what autograd would return for content_w*content + style_w*style. */
+int swn_model_perceptual(swn_model* m, const float* output_nchw, const float* target_nchw, int use_style, float* out2,
+                         float content_w, float style_w, float* d_output_nchw);
 
 /* BaseModel.forward (models/warp_model.py:106-107, models/texture_model.py:121-125) */
 int swn_model_forward(swn_model* m, int training, uint64_t dropout_seed);
@@ -172,6 +185,12 @@ int swn_op_conv(swn_ctx* ctx, int kind, int transposed, int what, int naive, flo
 int swn_op_instance_norm_act(swn_ctx* ctx, const float* x, int n, int c, int h, int w, int act, float* y);
 int swn_op_instance_norm_act_bwd(swn_ctx* ctx, const float* x, const float* dy, int n, int c, int h, int w, int act,
                                  float* dx);
+/* GANLoss(gan_mode)(prediction, target_is_real) (modules/loss.py:110-130) with the target scalar already drawn
+ * (`label`; the smooth-label draw stays host-side like in the reference, loss.py:65-108): mean BCE-with-logits /
+ * MSE / +-mean over ALL elements of pred (N,C,H,W).  loss_out = device float; dpred (optional, same shape) receives
+ * grad_scale * d(loss)/d(pred). */
+int swn_op_gan_loss(swn_ctx* ctx, int gan_mode, const float* pred, int n, int c, int h, int w, float label,
+                    int target_is_real, float grad_scale, float* loss_out, float* dpred);
 /* [InstanceNorm] -> act -> nn.Dropout(p) in TRAINING mode as ONE op (UNetDown / ResidualBlock, modules/layers.py:
  * 18-23,133-136): y, the keep/scale mask it used (0 or 1/(1-p); may be NULL) and, when dy and dx are given, the
  * input gradient computed with the same mask.  NCHW fp32, C % 4 == 0. */

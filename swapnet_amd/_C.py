@@ -18,7 +18,8 @@ LOSS_NAMES = ("D", "D_real", "D_fake", "G", "G_gan", "G_ce", "G_l1", "G_content"
 class SwnHyper(C.Structure):
     _fields_ = [(n, C.c_float) for n in ("lr", "d_lr", "weight_decay", "d_weight_decay", "b1", "b2",
                                          "lambda_gan", "lambda_ce", "lambda_l1", "lambda_content",
-                                         "lambda_style")] + [("gan_mode", C.c_int), ("warp_mode_ce", C.c_int), ("grad_scale", C.c_float)]
+                                         "lambda_style")] + [("gan_mode", C.c_int), ("warp_mode_ce", C.c_int), ("grad_scale", C.c_float),
+                                                                           ("d_b1", C.c_float), ("d_b2", C.c_float)]
 
 
 class SwapnetHipError(RuntimeError):
@@ -54,6 +55,8 @@ _PROTOS = {
     "swn_model_get_tap": ([_vp, _i, C.c_char_p, _fp, C.POINTER(_i * 4)], _i),
     "swn_model_dropout_sites": ([_vp, _i, C.POINTER(_i)], _i),
     "swn_model_dropout_mask": ([_vp, _i, _i, C.c_uint64, _fp, C.POINTER(_i * 4), C.POINTER(_f)], _i),
+    "swn_model_discriminate": ([_vp, _fp, _fp], _i),
+    "swn_model_perceptual": ([_vp, _fp, _fp, _i, _fp, _f, _f, _fp], _i),
     "swn_model_forward": ([_vp, _i, C.c_uint64], _i),
     "swn_model_backward_D": ([_vp, _f, _f], _i),
     "swn_model_backward_G": ([_vp, _f], _i),
@@ -73,6 +76,7 @@ _PROTOS = {
     "swn_op_conv": ([_vp, _i, _i, _i, _i, _fp, _i, _i, _i, _i, _fp, _i, _fp, _i, _fp], _i),
     "swn_op_instance_norm_act": ([_vp, _fp, _i, _i, _i, _i, _i, _fp], _i),
     "swn_op_instance_norm_act_bwd": ([_vp, _fp, _fp, _i, _i, _i, _i, _i, _fp], _i),
+    "swn_op_gan_loss": ([_vp, _i, _fp, _i, _i, _i, _i, _f, _i, _f, _fp, _fp], _i),
     "swn_op_norm_act_dropout": ([_vp, _fp, _fp, _i, _i, _i, _i, _i, _i, _f, C.c_uint64, _fp, _fp, _fp], _i),
     "swn_op_adamw": ([_vp, _fp, _fp, _fp, _fp, C.c_size_t, _f, _f, _f, _f, _f, _i], _i),
 }

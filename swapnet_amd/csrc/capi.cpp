@@ -41,7 +41,7 @@ static int guard(F f) {
 
 extern "C" {
 
-int swn_abi_version(void) { return 1; }
+int swn_abi_version(void) { return 2; }
 const char* swn_last_error(void) { return g_err.c_str(); }
 int swn_is_device_build(void) { return is_device_build(); }
 
@@ -118,6 +118,7 @@ int swn_model_set_hyper(swn_model* m, const swn_hyper* h) {
     REQUIRE(h->gan_mode >= 0 && h->gan_mode <= 2, "gan mode not implemented");
     y.gan_mode = h->gan_mode; y.warp_mode_ce_only = h->warp_mode_ce;
     y.grad_scale = h->grad_scale > 0.f ? h->grad_scale : 1.f;
+    y.d_b1 = h->d_b1 > 0.f ? h->d_b1 : h->b1; y.d_b2 = h->d_b2 > 0.f ? h->d_b2 : h->b2;
   });
 }
 
@@ -223,6 +224,16 @@ int swn_model_dropout_mask(swn_model* m, int net, int site, uint64_t seed, float
     if (shape) { shape[0] = d.N; shape[1] = d.C; shape[2] = d.H; shape[3] = d.W; }
     if (p) *p = d.p;
     if (dst) dropout_mask(m->m->ctx->s, d.N, d.H, d.W, d.C, d.p, Net::drop_seed(seed, d.salt), dst);
+  });
+}
+int swn_model_discriminate(swn_model* m, const float* x, float* pred) {
+  return guard([&] { REQUIRE(m && x && pred, "NULL argument"); m->m->discriminate(x, pred); });
+}
+int swn_model_perceptual(swn_model* m, const float* output, const float* target, int use_style, float* out2,
+                         float content_w, float style_w, float* d_output) {
+  return guard([&] {
+    REQUIRE(m && output && target && out2, "NULL argument");
+    m->m->perceptual(output, target, use_style, out2, content_w, style_w, d_output);
   });
 }
 int swn_model_forward(swn_model* m, int training, uint64_t seed) {
@@ -411,6 +422,26 @@ int swn_op_instance_norm_act_bwd(swn_ctx* ctx, const float* x, const float* dy, 
     nchw_to_nhwc(tmp.s, dy, n, c, h, w, yv.g);
     net.backward(false, true);
     nhwc_to_nchw(tmp.s, xv.g, dx, c);
+    stream_sync(tmp.s);
+  });
+}
+int swn_op_gan_loss(swn_ctx* ctx, int gan_mode, const float* pred, int n, int c, int h, int w, float label,
+                    int target_is_real, float grad_scale, float* loss_out, float* dpred) {
+  return guard([&] {
+    REQUIRE(ctx && pred && loss_out, "NULL argument");
+    REQUIRE(gan_mode >= 0 && gan_mode <= 2, "gan mode not implemented");
+    Ctx tmp(ctx->c->s);
+    ParamArena A; Net net(tmp, A);
+    // the prediction map (N,C,H,W) is reduced over all of its elements: view it as N*C single-channel images
+    Var pv = net.alloc_var(n * c, h, w, 4, true);
+    nchw_to_nhwc(tmp.s, pred, n * c, 1, h, w, pv.v);
+    float* lo = static_cast<float*>(tmp.alloc(sizeof(float)));
+    const TView* dp = dpred ? &pv.g : nullptr;
+    if (gan_mode == 0) bce_logits_loss(tmp.s, pv.v, label, grad_scale, lo, dp);
+    else if (gan_mode == 1) lsgan_loss(tmp.s, pv.v, label, grad_scale, lo, dp);
+    else wgan_loss(tmp.s, pv.v, target_is_real ? -1.f : 1.f, grad_scale, lo, dp);
+    dev_copy(tmp.s, loss_out, lo, sizeof(float));
+    if (dpred) nhwc_to_nchw(tmp.s, pv.g, dpred, 1);
     stream_sync(tmp.s);
   });
 }

@@ -626,6 +626,11 @@ void Net::forward() {
   prefetch_dgrad();
   for (auto& op : ops) op->fwd(*this);
 }
+void Net::forward_from(int op_begin) {
+  if (!finalized_) throw Error(1, "Net::forward before finalize");
+  prefetch_dgrad();
+  for (size_t i = (size_t)op_begin; i < ops.size(); ++i) ops[i]->fwd(*this);
+}
 void Net::prefetch_dgrad() {
   if (!ctx.use_side() || dg_version == arena.version || refresh_pending) return;
   bool any = false;
@@ -701,9 +706,43 @@ void Model::optimizer_step(int net) {
   a.p = A.w; a.g = A.g; a.m = A.m; a.v = A.v; a.n = A.n;
   a.lr = net == 0 ? hyper.lr : hyper.d_lr;
   a.weight_decay = net == 0 ? hyper.weight_decay : hyper.d_weight_decay;
-  a.beta1 = hyper.b1; a.beta2 = hyper.b2; a.eps = 1e-8f; a.step = A.step;
+  a.beta1 = net == 0 ? hyper.b1 : hyper.d_b1; a.beta2 = net == 0 ? hyper.b2 : hyper.d_b2; a.eps = 1e-8f; a.step = A.step;
   adamw_step(ctx->s, a);
   A.version += 1;
+}
+
+void Model::discriminate(const float* x_nchw, float* pred_nchw) {
+  if (!is_train || !D2) throw Error(1, "discriminate: the model has no discriminator (created with is_train = 0)");
+  if (d_cimap_.empty()) throw Error(1, "discriminate: model did not publish its conditional-input channel map");
+  if (!D3_) {
+    D3_ = std::make_unique<Net>(*ctx, arenaD);
+    d3_in_ = D3_->alloc_var(B, H, W, (int)d_cimap_.size(), false);
+    d3_pred_ = build_patchgan(*D3_, d3_in_, 3, d_cimap_);
+    D3_->finalize({});
+  }
+  // scatter the reference-ordered channels into the buffer order: maximal runs of consecutive channels
+  const int nb = (int)d_cimap_.size();
+  const size_t plane = (size_t)H * W;
+  int nref = 0;
+  for (int v : d_cimap_) nref += v >= 0;
+  for (int b0 = 0; b0 < nb;) {
+    if (d_cimap_[b0] < 0) { ++b0; continue; }
+    int len = 1;
+    while (b0 + len < nb && d_cimap_[b0 + len] == d_cimap_[b0] + len) ++len;
+    // NCHW source with nref channels: a channel sub-range is strided per image -> copy image by image
+    for (int n = 0; n < B; ++n) {
+      // (pad channels of the buffer stay zero: dev_alloc zero-fills and nothing else writes them)
+      nchw_to_nhwc(ctx->s, x_nchw + ((size_t)n * nref + d_cimap_[b0]) * plane, 1, len, H, W, d3_in_.batch(n, 1).v.slice(b0, len));
+    }
+    b0 += len;
+  }
+  D3_->training = false;
+  D3_->refresh_dgrad();
+  D3_->forward();
+  nhwc_to_nchw(ctx->s, d3_pred_.v, pred_nchw, 1);
+}
+void Model::perceptual(const float*, const float*, int, float*, float, float, float*) {
+  throw Error(1, "perceptual: only the texture model carries the VGG16 network (not implemented for this model)");
 }
 
 // BaseGAN.optimize_parameters (models/base_gan.py:194-203): forward, D step, G step.

@@ -138,6 +138,7 @@ class Net {
   // bookkeeping
   void finalize(const std::vector<Var>& pre_initialised_grads);
   void forward();
+  void forward_from(int op_begin);           // ops [op_begin, end): the caller has filled the inputs of op_begin itself
   void backward(bool wgrad, bool igrad);
   void backward_range(bool wgrad, bool igrad, int op_begin, int op_end);   // ops [begin,end) in reverse
   // first op whose parameters start at or after `frac` of the arena (ops are registered in arena order)
@@ -168,6 +169,7 @@ struct Hyper {
   int gan_mode = 0;          // 0 vanilla (BCE), 1 lsgan, 2 wgan
   int warp_mode_ce_only = 0; // --warp_mode ce
   float grad_scale = 1.f;    // multiplies every loss gradient (1/world_size under data parallelism)
+  float d_b1 = 0.9f, d_b2 = 0.999f;   // optimizer_D's betas
 };
 
 enum LossSlot {
@@ -198,6 +200,21 @@ class Model {
   void backward_G_part(float label_real, int part, size_t* ready_off, size_t* ready_count);
   void optimizer_step(int net);
   void step(const float labels[3], bool training, uint64_t seed);
+  // NLayerDiscriminator.forward (modules/discriminators.py:134-136) as a standalone call: x = the conditioned input
+  // in the REFERENCE's channel order (B, 22, H, W) NCHW on the device, pred = (B, 1, H/8-2, W/8-2).  Runs on a
+  // private PatchGAN instance bound to the same weights (created on first use), so the model's own buffers
+  // (self.fakes, the conditioned batch) are left untouched.
+  void discriminate(const float* x_nchw, float* pred_nchw);
+  // PerceptualLoss.forward (modules/losses/perceptual.py:49-66) as a standalone call (texture model): writes
+  // (content, style) = (sum_k MSE of the normalised VGG slice features, 5 x MSE of the image Grams) to the two
+  // device floats at `out2`; d_output (optional, NCHW) receives content_w * d(content) + style_w * d(style).
+  virtual void perceptual(const float* output_nchw, const float* target_nchw, int use_style, float* out2,
+                          float content_w, float style_w, float* d_output_nchw);
+ protected:
+  std::unique_ptr<Net> D3_;       // discriminate(): own input buffer + activations, shared (frozen) arenaD
+  Var d3_in_, d3_pred_;
+  std::vector<int32_t> d_cimap_;  // buffer channel -> reference channel of the conditional D input (set by the model)
+ public:
   ParamArena& arena(int net) { return net == 0 ? arenaG : arenaD; }
   virtual ParamArena* arena_ptr(int net) {
     if (net == 0) return &arenaG;

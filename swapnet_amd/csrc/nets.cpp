@@ -170,6 +170,7 @@ class WarpModel final : public Model {
       std::vector<int32_t> cimap(24, -1);
       for (int i = 0; i < 19; ++i) cimap[i] = 3 + i;     // cloth channels follow the 3 body channels
       for (int i = 0; i < 3; ++i) cimap[20 + i] = i;
+      d_cimap_ = cimap;
       D2 = std::make_unique<Net>(c, arenaD);
       D2->keep_wino_inputs = true;
       pred2 = build_patchgan(*D2, Dx, 3, cimap);

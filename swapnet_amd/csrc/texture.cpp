@@ -154,6 +154,7 @@ class TextureModel final : public Model {
     std::vector<int32_t> cimap(24, -1);
     for (int i = 0; i < 3; ++i) cimap[i] = 19 + i;       // textures follow the 19 cloth channels
     for (int i = 0; i < 19; ++i) cimap[4 + i] = i;
+    d_cimap_ = cimap;
     D2 = std::make_unique<Net>(c, arenaD);
     D2->keep_wino_inputs = true;
     pred2 = build_patchgan(*D2, Dx, 3, cimap);
@@ -179,6 +180,43 @@ class TextureModel final : public Model {
     std::vector<Var> pre(feat_f.begin(), feat_f.end());
     pre.push_back(fake_slot);
     VF->finalize(pre);
+  }
+
+  // PerceptualLoss.forward (modules/losses/perceptual.py:49-66) on caller-supplied images.  The VGG instances of
+  // the training step are reused from their second op on (op 0 is the 2x-1 affine reading the model's own fake /
+  // target slots, which stay untouched); raw images and the image gradient live in lazily allocated scratch.
+  Var p_out_, p_tgt_;
+  void perceptual(const float* output_nchw, const float* target_nchw, int use_style, float* out2, float content_w,
+                  float style_w, float* d_output_nchw) override {
+    if (!is_train) throw Error(1, "perceptual: the model was created without its loss networks (is_train = 0)");
+    Stream& s = ctx->s;
+    if (!p_out_.v.p) {
+      p_out_ = G->alloc_var(B, H, W, 4, true);
+      p_tgt_ = G->alloc_var(B, H, W, 4, false);
+    }
+    nchw_to_nhwc(s, output_nchw, B, 3, H, W, p_out_.v);
+    nchw_to_nhwc(s, target_nchw, B, 3, H, W, p_tgt_.v);
+    axpy(s, p_out_.v, vin_f.v, 2.f, 0, -1.f);            // x <- 2x - 1 (perceptual.py:70)
+    axpy(s, p_tgt_.v, vin_t.v, 2.f, 0, -1.f);
+    VF->refresh_dgrad();
+    VT->forward_from(1);
+    VF->forward_from(1);
+    const bool want_grad = d_output_nchw != nullptr;
+    dev_memset(s, losses + L_TMP4, 0, 2 * sizeof(float));
+    for (int k = 0; k < 5; ++k) {
+      normed_mse_loss(s, feat_f[k].v, feat_t[k].v, content_w, losses + L_TMP2, want_grad ? &feat_f[k].g : nullptr, 0);
+      scalar_axpby(s, losses + L_TMP4, 1.f, losses + L_TMP2, 1.f, losses + L_TMP4);
+    }
+    if (want_grad) {
+      VF->backward_range(false, true, 1, (int)VF->ops.size());      // d(content)/d(2x-1) -> vin_f.g
+      axpy(s, vin_f.g, p_out_.g, 2.f, 0, 0.f);
+    }
+    if (use_style) {                                       // 5 identical image-Gram terms (perceptual.py:58-63)
+      gram_style_loss(s, p_out_.v, p_tgt_.v, 3, 5.f * style_w, losses + L_TMP3, want_grad ? &p_out_.g : nullptr, 1);
+      scalar_axpby(s, losses + L_TMP3, 5.f, nullptr, 0.f, losses + L_TMP5);
+    }
+    dev_copy(s, out2, losses + L_TMP4, 2 * sizeof(float));
+    if (want_grad) nhwc_to_nchw(s, p_out_.g, d_output_nchw, 3);
   }
 
   void set_input(int slot, const float* src, int N, int C, int Hh, int Ww) override {

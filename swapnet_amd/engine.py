@@ -200,7 +200,7 @@ class NativeModel:
     def set_hyper(self, **kw):
         h = _C.SwnHyper(lr=1e-4, d_lr=4e-4, weight_decay=0.0, d_weight_decay=0.01, b1=0.9, b2=0.999,
                         lambda_gan=1.0, lambda_ce=100.0, lambda_l1=10.0, lambda_content=20.0,
-                        lambda_style=1e-8, gan_mode=0, warp_mode_ce=0, grad_scale=1.0)
+                        lambda_style=1e-8, gan_mode=0, warp_mode_ce=0, grad_scale=1.0, d_b1=0.0, d_b2=0.0)
         for k, v in kw.items():
             setattr(h, k, v)
         self.lib.call("swn_model_set_hyper", self.handle, C.byref(h))
@@ -241,6 +241,29 @@ class NativeModel:
             out.append((t, p.value))
         self.ctx.sync()
         return out
+
+    def discriminate(self, x):
+        """NLayerDiscriminator.forward on a conditioned input in the reference's channel order (B,22,H,W)."""
+        xd = x.detach().to(device=self.ctx.device, dtype=torch.float32).contiguous()
+        if tuple(xd.shape) != (self.B, 22, self.H, self.W):
+            raise ValueError("discriminator input must be (%d, 22, %d, %d), got %s" % (self.B, self.H, self.W, tuple(xd.shape)))
+        pred = torch.empty((self.B, 1, self.H // 8 - 2, self.W // 8 - 2), dtype=torch.float32, device=self.ctx.device)
+        self.lib.call("swn_model_discriminate", self.handle, _C.ptr(xd), _C.ptr(pred))
+        self.ctx.sync()
+        return pred
+
+    def perceptual(self, output, target, use_style=True, content_w=1.0, style_w=1.0, want_grad=False):
+        """PerceptualLoss.forward: returns (losses[2] device tensor = content, style ; d_output or None)."""
+        o = output.detach().to(device=self.ctx.device, dtype=torch.float32).contiguous()
+        t = target.detach().to(device=self.ctx.device, dtype=torch.float32).contiguous()
+        if tuple(o.shape) != (self.B, 3, self.H, self.W) or o.shape != t.shape:
+            raise ValueError("perceptual loss inputs must both be (%d, 3, %d, %d)" % (self.B, self.H, self.W))
+        out2 = torch.empty(2, dtype=torch.float32, device=self.ctx.device)
+        d = torch.empty_like(o) if want_grad else None
+        self.lib.call("swn_model_perceptual", self.handle, _C.ptr(o), _C.ptr(t), int(bool(use_style)), _C.ptr(out2),
+                      C.c_float(content_w), C.c_float(style_w), _C.ptr(d))
+        self.ctx.sync()
+        return out2, d
 
     def output(self, slot=0):
         t = torch.empty((self.B, self.out_channels, self.H, self.W), dtype=torch.float32, device=self.ctx.device)
@@ -312,6 +335,19 @@ class NativeModel:
             self.close()
         except Exception:
             pass
+
+
+def op_gan_loss(ctx, pred, gan_mode, label, target_is_real, grad_scale=1.0, want_grad=True):
+    """GANLoss value (+ gradient w.r.t. the prediction map) through swn_op_gan_loss.  Returns (loss[1], dpred)."""
+    p = pred.detach().to(device=ctx.device, dtype=torch.float32).contiguous()
+    shape = tuple(p.shape)
+    p4 = p.reshape((shape + (1, 1, 1, 1))[:4]) if p.dim() < 4 else p
+    n, c, h, w = p4.shape
+    loss = torch.empty(1, dtype=torch.float32, device=ctx.device)
+    d = torch.empty_like(p4) if want_grad else None
+    ctx.lib.call("swn_op_gan_loss", ctx.handle, int(gan_mode), _C.ptr(p4), n, c, h, w, C.c_float(label),
+                 int(bool(target_is_real)), C.c_float(grad_scale), _C.ptr(loss), _C.ptr(d))
+    return loss, (d.reshape(shape) if d is not None else None)
 
 
 def op_norm_act_dropout(ctx, x, dy=None, norm=True, act=2, p=0.5, seed=0):

@@ -65,6 +65,7 @@ class BaseGAN(BaseModel, ABC):
             self.model_names.append("discriminator")
             use_smooth = opt.gan_label_mode == "smooth"
             self.criterion_GAN = GANLoss(opt.gan_mode, smooth_labels=use_smooth)
+            self.criterion_GAN.ctx = self.backend.ctx
             if opt.lambda_discriminator:
                 self.loss_names = ["D", "D_real", "D_fake"]
             self.loss_names += ["G"]
@@ -111,9 +112,15 @@ class BaseGAN(BaseModel, ABC):
         else:
             m.set_input(slot, t)
 
+    def _ce_only(self):
+        return getattr(self.opt, "warp_mode", "gan") == "ce" and self.KIND == "warp"
+
     def _draw_labels(self):
         """The three smooth-label scalars in the reference's draw order: backward_D fake, real
-        (warp_model.py:116,120), backward_G real (:158)."""
+        (warp_model.py:116,120), backward_G real (:158).  --warp_mode ce never calls GANLoss
+        (warp_model.py:169-183): no draws, so a seeded run consumes the RNG like the reference."""
+        if self._ce_only():
+            return [0.0, 0.0, 0.0]
         c = self.criterion_GAN
         return [c.sample_label(False), c.sample_label(True), c.sample_label(True)]
 
@@ -124,14 +131,16 @@ class BaseGAN(BaseModel, ABC):
         training = bool(self.net_generator.training)
         seed = (self._step * 1000003 + torch.initial_seed()) % (2 ** 62)
         labels = self._draw_labels()
+        self.optimizer_G.sync(); self.optimizer_D.sync()          # live param_groups (lr schedulers)
         if self.world == 1:
             m.step(labels, training=training, seed=seed)
         else:
             rank = torch.distributed.get_rank()
             m.forward(training, seed + rank)
-            m.backward_D(labels[0], labels[1])
-            self._xchg.allreduce_mean(m.grad_arena(engine.NET_D))
-            m.optimizer_step(engine.NET_D)
+            if not self._ce_only():                             # --warp_mode ce: generator only (warp_model.py:178-183)
+                m.backward_D(labels[0], labels[1])
+                self._xchg.allreduce_mean(m.grad_arena(engine.NET_D))
+                m.optimizer_step(engine.NET_D)
             gG = m.grad_arena(engine.NET_G)
             for part in range(m.backward_G_parts()):         # each bucket's exchange overlaps the next part
                 off, cnt = m.backward_G_part(labels[2], part)

@@ -21,6 +21,8 @@ class TextureModel(BaseGAN):
             parser.add_argument("--lambda_l1", type=float, default=10, help="weight for L1 loss in final term")
             parser.add_argument("--lambda_content", type=float, default=20, help="weight for content loss in final term")
             parser.add_argument("--lambda_style", type=float, default=1e-8, help="weight for content loss in final term")
+            parser.add_argument("--vgg_weights", default=None, help="(swapnet_amd) file with torchvision vgg16 weights "
+                                "(vgg16().state_dict() or .features.state_dict()) for the perceptual loss")
             parser.set_defaults(display_ncols=5)
         return parser
 
@@ -38,21 +40,56 @@ class TextureModel(BaseGAN):
                     self.loss_names.append(f"G_{loss}")
 
     def _init_vgg(self):
-        """The reference downloads torchvision's pretrained VGG16 (perceptual.py:26).  There is no
-        network here: start from seeded random weights (private generator, global RNG untouched)
-        and let the user load real ones with
-        `model.criterion_perceptual.load_vgg16_features(vgg16(pretrained=True).features.state_dict())`."""
+        """The reference's PerceptualLoss builds torchvision's vgg16(pretrained=True) (perceptual.py:26).  Sources
+        tried in order: (1) a file named by --vgg_weights / $SWAPNET_VGG16_WEIGHTS holding vgg16().state_dict() or
+        vgg16().features.state_dict(); (2) torchvision's pretrained model when torchvision is importable and its
+        checkpoint is cached or downloadable.  If neither is available the network starts from seeded random
+        weights (private generator, global RNG untouched) and -- because lambda_content would then optimise
+        against random features, a DIFFERENT objective than the reference's -- a RuntimeWarning says so loudly;
+        $SWAPNET_REQUIRE_PRETRAINED_VGG=1 turns that into an error."""
+        import os
+        import warnings
         import torch
+        crit = self.criterion_perceptual
+        path = getattr(self.opt, "vgg_weights", None) or os.environ.get("SWAPNET_VGG16_WEIGHTS")
+        feats = None
+        if path:
+            sd = torch.load(path, map_location="cpu")
+            sd = sd.get("state_dict", sd)
+            feats = {k[len("features."):] if k.startswith("features.") else k: v for k, v in sd.items()
+                     if k.startswith("features.") or k.split(".")[0].isdigit()}
+            source = path
+        else:
+            try:
+                from torchvision.models import vgg16
+                feats = vgg16(pretrained=True).features.state_dict()
+                source = "torchvision vgg16(pretrained=True)"
+            except Exception:            # torchvision absent, or no cached checkpoint and no network
+                feats = None
+        if feats is not None:
+            crit.load_vgg16_features(feats)
+            self.vgg_source = source
+            print("PerceptualLoss: VGG16 features loaded from %s" % source)
+            return
         g = torch.Generator().manual_seed(4242)
         sd = {}
-        for name, shape in self.criterion_perceptual.native_param_shapes().items():
+        for name, shape in crit.native_param_shapes().items():
             if name.endswith(".bias"):
                 sd[name] = torch.randn(shape, generator=g) * 0.05
             else:
                 sd[name] = torch.randn(shape, generator=g) * (2.0 / (shape[0] * 9)) ** 0.5
-        self.criterion_perceptual.load_state_dict(sd)
-        print("PerceptualLoss: VGG16 initialised with seeded random weights; load pretrained "
-              "features with criterion_perceptual.load_vgg16_features(...)")
+        crit.load_state_dict(sd)
+        self.vgg_source = "seeded-random"
+        if self.opt.lambda_content != 0:
+            msg = ("PerceptualLoss: pretrained VGG16 weights are NOT available (no --vgg_weights / "
+                   "$SWAPNET_VGG16_WEIGHTS file, torchvision checkpoint not obtainable): the content loss "
+                   "(lambda_content=%g) will be computed on SEEDED RANDOM VGG16 features, which is not the "
+                   "reference's objective.  Load real weights with "
+                   "model.criterion_perceptual.load_vgg16_features(vgg16(pretrained=True).features.state_dict())."
+                   % self.opt.lambda_content)
+            if os.environ.get("SWAPNET_REQUIRE_PRETRAINED_VGG") == "1":
+                raise RuntimeError(msg)
+            warnings.warn(msg, RuntimeWarning, stacklevel=2)
 
     def compute_visuals(self):
         self.textures_unnormalized = unnormalize(self.textures.cpu(), *self.opt.texture_norm_stats)

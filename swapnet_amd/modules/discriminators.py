@@ -1,7 +1,7 @@
 """PatchGAN discriminator factory with the reference's signature
-(/root/reference/modules/discriminators.py:45-136).  The native PatchGAN always runs
-conditioned inside a model step (its input buffer is the zero-copy cat of condition and
-generator output), so the module object is the parameter / checkpoint view of it."""
+(/root/reference/modules/discriminators.py:45-136).  Inside a model step the native PatchGAN runs
+fused on the zero-copy cat of condition and generator output; the module object is the parameter /
+checkpoint view of it and `net(x)` evaluates it standalone through swn_model_discriminate."""
 from .. import engine
 from .native import NativeNet
 
@@ -15,9 +15,14 @@ class NLayerDiscriminator(NativeNet):
         super().__init__(backend, engine.NET_D)
 
     def forward(self, input):
-        raise NotImplementedError(
-            "the native PatchGAN runs inside model.backward_D / backward_G on the conditioned buffer; "
-            "its prediction map is available as model.backend.cur.tap(NET_D, 'pred')")
+        """NLayerDiscriminator.forward (:134-136): `input` = the conditioned batch in the reference's channel
+        order, (B, 22, H, W) -> prediction map (B, 1, H/8-2, W/8-2).  Inference-only call on the current
+        weights (inside a training step the discriminator runs fused in model.backward_D / backward_G)."""
+        b, c, h, w = input.shape
+        m = self._backend.ensure(b, h, w)
+        return m.discriminate(input)
+
+    __call__ = forward
 
 
 def define_D(input_nc, ndf, netD, n_layers_D=3, norm="batch", init_type="normal", init_gain=0.02, gpu_ids=[],

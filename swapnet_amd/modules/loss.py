@@ -1,8 +1,28 @@
-"""GANLoss label logic of the reference (/root/reference/modules/loss.py:12-130).  The loss
-value and its gradient are computed by the library (losses.hip); this class reproduces what
+"""GANLoss of the reference (/root/reference/modules/loss.py:12-130).  The loss value and its
+gradient are computed by the library (losses.hip, swn_op_gan_loss); this class reproduces what
 is host-side in the reference: WHICH scalar target each call uses, drawn from the global torch
-CPU RNG in the reference's order so seeded runs see identical labels."""
+CPU RNG in the reference's order so seeded runs see identical labels.  `criterion(pred, is_real)`
+is usable standalone like the reference's module: it returns a scalar tensor whose backward()
+delivers the library's gradient (torch.autograd is glue only; no arithmetic of the loss runs in
+torch)."""
 import torch
+
+from .. import engine
+
+
+class _GanLossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(fctx, pred, mode, label, is_real, lib_ctx):
+        loss, dpred = engine.op_gan_loss(lib_ctx, pred, mode, label, is_real, 1.0, want_grad=pred.requires_grad)
+        fctx.dpred, fctx.src = dpred, (pred.device, pred.dtype)
+        return loss.reshape(()).to(pred.device)
+
+    @staticmethod
+    def backward(fctx, g):
+        d = fctx.dpred
+        if d is None:
+            return None, None, None, None, None
+        return (d * g.to(d.device)).to(device=fctx.src[0], dtype=fctx.src[1]), None, None, None, None
 
 
 class GANLoss:
@@ -28,6 +48,15 @@ class GANLoss:
 
     def to(self, device):
         return self
+
+    def __call__(self, prediction, target_is_real):
+        """GANLoss.__call__ (loss.py:110-130): draws the target scalar exactly like get_target_tensor, then
+        BCE-with-logits / MSE / +-mean of `prediction` on the device.  Returns a scalar tensor."""
+        label = self.sample_label(target_is_real)
+        ctx = getattr(self, "ctx", None) or engine.default_context()
+        return _GanLossFn.apply(prediction, self.native_mode, label, bool(target_is_real), ctx)
+
+    forward = __call__
 
     @staticmethod
     def rand_between(low, high):

@@ -36,8 +36,20 @@ class NativeAdamW:
     def __init__(self, backend, net, lr, weight_decay, betas):
         self.backend, self.net = backend, net
         self.param_groups = [dict(lr=lr, weight_decay=weight_decay, betas=tuple(betas), eps=1e-8, amsgrad=False)]
-        key = "d_" if net == engine.NET_D else ""
-        backend.set_hyper(**{key + "lr": lr, key + "weight_decay": weight_decay, "b1": betas[0], "b2": betas[1]})
+        self._pushed = None
+        self.sync()
+
+    def sync(self):
+        """param_groups is live like torch's: a scheduler (or the user) editing param_groups[0]["lr"] /
+        ["weight_decay"] / ["betas"] takes effect at the next step.  Each optimizer owns its own hyper-parameters
+        (G: lr, weight_decay, b1, b2; D: d_lr, d_weight_decay, d_b1, d_b2), so loading optimizer_D's state never
+        touches G's betas."""
+        g = self.param_groups[0]
+        cur = (float(g["lr"]), float(g["weight_decay"]), float(g["betas"][0]), float(g["betas"][1]))
+        if cur != self._pushed:
+            key = "d_" if self.net == engine.NET_D else ""
+            self.backend.set_hyper(**{key + "lr": cur[0], key + "weight_decay": cur[1], key + "b1": cur[2], key + "b2": cur[3]})
+            self._pushed = cur
 
     def zero_grad(self, set_to_none=False):
         # every backward pass overwrites the whole gradient arena (each parameter has exactly one
@@ -45,6 +57,7 @@ class NativeAdamW:
         pass
 
     def step(self, closure=None):
+        self.sync()
         self.backend.cur.optimizer_step(self.net)
 
     def state_dict(self):
@@ -74,9 +87,7 @@ class NativeAdamW:
             m.optim_step_count(self.net, int(float(state[0]["step"])))
         g = sd["param_groups"][0]
         self.param_groups[0].update(lr=g["lr"], weight_decay=g["weight_decay"], betas=tuple(g["betas"]))
-        key = "d_" if self.net == engine.NET_D else ""
-        self.backend.set_hyper(**{key + "lr": g["lr"], key + "weight_decay": g["weight_decay"],
-                                  "b1": g["betas"][0], "b2": g["betas"][1]})
+        self.sync()
 
 
 def define_optimizer(parameters, opt, net: str):

@@ -271,3 +271,51 @@ def test_seeded_init_matches_oracle_for_the_8_level_unet(tmp_path):
     assert list(sg.keys()) == list(G.keys()) and list(sd.keys()) == list(D.keys())
     assert all(torch.equal(sg[k].cpu(), G[k]) for k in G)
     assert all(torch.equal(sd[k].cpu(), D[k]) for k in D)
+
+
+def test_optimizer_param_groups_are_live_and_per_network(tmp_path):
+    """editing optimizer.param_groups (what an lr scheduler does) must reach the native step, and
+    the two optimizers keep separate betas (loading optimizer_D's state must not overwrite G's)."""
+    from swapnet_amd.models import create_model
+    opt = make_opt(tmp_path, "sim")
+    model = create_model(opt)
+    model.eval()
+    bodys, inputs, targets = O.synth_warp_batch(2, 64, 64, seed=1234)
+    data = dict(bodys=bodys, input_cloths=inputs, target_cloths=targets, cloth_paths=["", ""], body_paths=["", ""])
+    model.set_input(data)
+    g0 = model.net_generator.state_dict()["upsample_and_pad.2.weight"].clone()
+    d0 = model.net_discriminator.state_dict()["model.0.weight"].clone()
+    model.optimizer_G.param_groups[0]["lr"] = 0.0                 # scheduler-style edit
+    torch.manual_seed(1)
+    model.optimize_parameters()
+    assert torch.equal(model.net_generator.state_dict()["upsample_and_pad.2.weight"], g0)      # lr 0: G frozen
+    assert not torch.equal(model.net_discriminator.state_dict()["model.0.weight"], d0)         # D still trains
+    model.optimizer_G.param_groups[0]["lr"] = 1e-4
+    torch.manual_seed(2)
+    model.optimize_parameters()
+    assert not torch.equal(model.net_generator.state_dict()["upsample_and_pad.2.weight"], g0)
+    # separate betas: D's state dict with other betas leaves G's hyper-parameters alone
+    sd = model.optimizer_D.state_dict()
+    sd["param_groups"][0]["betas"] = (0.5, 0.9)
+    model.optimizer_D.load_state_dict(sd)
+    h = model.backend.hyper
+    assert (h["d_b1"], h["d_b2"]) == (0.5, 0.9) and (h["b1"], h["b2"]) == (0.9, 0.999)
+    assert model.optimizer_G.state_dict()["param_groups"][0]["betas"] == (0.9, 0.999)
+
+
+def test_ce_mode_draws_no_labels_and_skips_D(tmp_path):
+    """--warp_mode ce (warp_model.py:169-183): generator only; GANLoss is never called, so the global RNG is not
+    consumed (a seeded run stays aligned with the reference) and the discriminator is untouched."""
+    from swapnet_amd.models import create_model
+    opt = make_opt(tmp_path, "sim", warp_mode="ce")
+    model = create_model(opt)
+    model.eval()
+    bodys, inputs, targets = O.synth_warp_batch(2, 64, 64, seed=1234)
+    model.set_input(dict(bodys=bodys, input_cloths=inputs, target_cloths=targets, cloth_paths=["", ""], body_paths=["", ""]))
+    d0 = {k: v.clone() for k, v in model.net_discriminator.state_dict().items()}
+    torch.manual_seed(5)
+    model.optimize_parameters()
+    nxt = torch.rand(1)
+    torch.manual_seed(5)
+    assert torch.equal(nxt, torch.rand(1))                        # no draws happened
+    assert all(torch.equal(v, d0[k]) for k, v in model.net_discriminator.state_dict().items())
