@@ -327,6 +327,292 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_fwd_kernel(GemmP p) {
 
 
 // ---------------------------------------------------------------------------------------
+// forward-type kernel, LDS-DMA ring (round 2).  Same contraction as conv_fwd_kernel<FAST>, different machine:
+//   * global -> LDS by `buffer_load_dwordx4 ... lds` (no staging VGPRs, no ds_write pass); padding taps and rows past M
+//     are fetched OUT OF RANGE of the buffer descriptor, which the hardware returns as zeros;
+//   * BK = 16, three LDS stages, two of them in flight across every barrier (counted s_waitcnt vmcnt, raw s_barrier);
+//   * 64-byte A rows XOR-swizzled on the SOURCE side (lane l of a row fetches chunk (l & 3) ^ ((row >> 2) & 3)) so that
+//     the 16-lane groups of ds_read_b128 touch 16 distinct 4-bank groups: conflict-free without padding;
+//   * B fragments are ds_read_b64 of two ADJACENT columns, i.e. a lane's two 32x32 MFMA blocks hold columns
+//     (2c, 2c+1) of its wave's 64 -> the epilogue stores float2 (256 contiguous bytes per row and wave);
+//   * ~95 VGPRs: three 4-wave workgroups (128x128 tile, 48 KB) per CU = three independent waves per SIMD, so one
+//     workgroup's barrier / epilogue / prologue is covered by the MFMAs of the other two.  (The register-staged
+//     256x128 kernel above runs ONE 8-wave workgroup per CU -- 194 VGPRs, 105 KB -- and idles the matrix pipe a third
+//     of the time; measured on the Winograd-plane and k4s2 shapes of this model: 87-105 -> 104-144 TFLOP/s.)
+// The LDS-DMA is issued from an asm statement on purpose: hipcc's waitcnt pass puts `s_waitcnt vmcnt(0)` in front of every
+// ds_read that follows an LDS-DMA *builtin* (one pending LDS write = "may alias"), which drains the ring each stage.
+// Scheduling: tiles beyond a whole number of chip-fills ("the tail round") are split along K so that the last round is
+// as full as the others (hybrid data-parallel / split-K); their partial tiles go to a compact slab that
+// conv_dma_reduce_kernel sums in fixed order (deterministic) and finishes with the usual epilogue.
+// ---------------------------------------------------------------------------------------
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+// raw buffer descriptor: stride 0, num_records = bytes, gfx9 raw-buffer flags; offsets >= bytes read 0
+__device__ __forceinline__ i32x4 make_rsrc(const void* ptr, unsigned bytes) {
+  const unsigned long long a = (unsigned long long)ptr;
+  i32x4 r;
+  r[0] = (int)(unsigned)(a & 0xffffffffull); r[1] = (int)(unsigned)((a >> 32) & 0xffffull); r[2] = (int)bytes; r[3] = 0x00020000;
+  return r;
+}
+// one LDS-DMA instruction: lane i fetches 16 bytes at base + voff + soff, the wave's 1 KiB lands at LDS byte lds_dst + 16 i
+__device__ __forceinline__ void lds_dma16(unsigned voff, i32x4 rsrc, unsigned soff, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 4\n\tbuffer_load_dwordx4 %1, %2, %4 offen lds\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(voff), "s"(rsrc), "s"(lds_dst), "s"(soff) : "memory");
+}
+constexpr unsigned DMA_OOB = 0x80000000u;      // > any buffer this library addresses (checked by the launcher)
+
+struct DmaSched {            // hybrid schedule, computed by the launcher
+  int full;                  // work units [0, full): one whole tile each
+  int tail_tiles, tail_s;    // then tail_tiles tiles split tail_s ways along K
+  int per_split;             // stages per split of a tail tile
+  int tiles_per_z;           // tiles of one batch element / phase
+};
+
+template <int WGM, int WGN>
+struct DmaTile {
+  static constexpr int NW = WGM * WGN, BM = 64 * WGM, BN = 64 * WGN, BK = 16, NST = 3;
+  static constexpr int A_FL = BM * BK, B_FL = BK * BN, ST_FL = A_FL + B_FL;
+  static constexpr int AI = 4 / WGN, BI = 4 / WGM;       // LDS-DMA instructions per wave per stage
+  static constexpr int LPR = BN / 4, RPI = 64 / LPR;     // lanes per B row, B rows per instruction
+  static constexpr int SMEM = NST * ST_FL * 4;
+  static_assert(4 % WGN == 0 && 4 % WGM == 0, "tile shape");
+};
+
+template <int WGM, int WGN>
+__global__ __launch_bounds__(64 * WGM * WGN) void conv_fwd_dma_kernel(GemmP p, DmaSched sc) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  using T = DmaTile<WGM, WGN>;
+  constexpr int BM = T::BM, BN = T::BN, BK = T::BK, NST = T::NST, AI = T::AI, BI = T::BI;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int t = threadIdx.x, lane = t & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wm = wid / WGN, wn = wid % WGN;
+
+  // ---- work unit -> (tile, K range)
+  int u = blockIdx.x, gtile, split = 0, nsplit = 1, tt = 0;
+  if (u < sc.full) {
+    gtile = xcd_swizzle(u, sc.full);
+  } else {
+    u -= sc.full;
+    tt = u / sc.tail_s; split = u - tt * sc.tail_s; nsplit = sc.tail_s;
+    gtile = sc.full + tt;
+  }
+  const int z = gtile / sc.tiles_per_z, tile = gtile - z * sc.tiles_per_z;
+  const int tile_n = tile % p.tiles_n, tile_m = tile / p.tiles_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  p.x += (size_t)z * p.x_bs; p.w += (size_t)z * p.w_bs; p.y += (size_t)z * p.y_bs;
+  if (p.phases) { const int a = z >> 1, b = z & 1; p.pad_t -= a; p.pad_l -= b; p.yoff = a; p.xoff = b; }
+  const int nkb_all = p.K / BK;
+  const int kb_begin = nsplit > 1 ? split * sc.per_split : 0;
+  const int kb_end = nsplit > 1 ? min(nkb_all, kb_begin + sc.per_split) : nkb_all;
+
+  const unsigned x_bytes = (unsigned)((((size_t)p.xH * p.xW * (size_t)(p.M / (p.Ho * p.Wo)) - 1) * p.xcs + p.xC) * 4);
+  const i32x4 rsA = make_rsrc(p.x, x_bytes), rsB = make_rsrc(p.w, (unsigned)((size_t)p.K * p.Npad * 4));
+  const unsigned lds0 = (unsigned)(size_t)(lds_ptr_t)smem;
+
+  // ---- loader state.  A: this lane owns AI rows (row = 16 q + lane / 4, q = wid * AI + r) and one swizzled chunk of each.
+  int a_iy0[AI], a_ix0[AI], a_base[AI];
+  unsigned a_voff[AI], b_voff[BI];
+  const int HoWo = p.Ho * p.Wo;
+  const int He = p.xH << p.ups, We = p.xW << p.ups;
+#pragma unroll
+  for (int r = 0; r < AI; ++r) {
+    const int row = 16 * (wid * AI + r) + (lane >> 2);
+    const int m = m0 + row;
+    if (m < p.M) {
+      const int n = m / HoWo, rem = m - n * HoWo;
+      const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+      a_iy0[r] = oy * p.stride - p.pad_t;
+      a_ix0[r] = ox * p.stride - p.pad_l;
+      a_base[r] = n * p.xH * p.xW * p.xcs + 4 * ((lane & 3) ^ ((row >> 2) & 3));     // + inverse-swizzled chunk
+    } else {
+      a_iy0[r] = 0; a_ix0[r] = 0; a_base[r] = -1;
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < BI; ++r) {
+    const int krow = T::RPI * (wid * BI + r) + lane / T::LPR;
+    const int nn = n0 + 4 * (lane % T::LPR);
+    b_voff[r] = nn < p.Npad ? (unsigned)(krow * p.Npad + nn) * 4u : DMA_OOB;
+  }
+  auto set_tap = [&](int tap) {
+    const int kh = tap / p.KW, kw = tap - kh * p.KW;
+#pragma unroll
+    for (int r = 0; r < AI; ++r) {
+      unsigned off = DMA_OOB;
+      if (a_base[r] >= 0) {
+        const int sy = src_coord(a_iy0[r] + kh, He, p.pad_mode, p.ups);
+        const int sx = src_coord(a_ix0[r] + kw, We, p.pad_mode, p.ups);
+        if (sy >= 0 && sx >= 0) off = (unsigned)(a_base[r] + (sy * p.xW + sx) * p.xcs) * 4u;
+      }
+      a_voff[r] = off;
+    }
+  };
+  // stages are issued strictly in order kb_begin, kb_begin + 1, ...: (tap, ci) of the next stage to issue
+  int ld_tap = (kb_begin * BK) / p.xC, ld_ci = kb_begin * BK - ld_tap * p.xC;
+  set_tap(ld_tap);
+  auto issue = [&](int st, int kb) {
+    const unsigned As = lds0 + (unsigned)(st * T::ST_FL) * 4u, Bs = As + T::A_FL * 4u;
+#pragma unroll
+    for (int r = 0; r < AI; ++r) lds_dma16(a_voff[r], rsA, (unsigned)ld_ci * 4u, As + (unsigned)(wid * AI + r) * 1024u);
+#pragma unroll
+    for (int r = 0; r < BI; ++r)
+      lds_dma16(b_voff[r], rsB, (unsigned)kb * (unsigned)(BK * 4) * (unsigned)p.Npad, Bs + (unsigned)(wid * BI + r) * 1024u);
+    ld_ci += BK;
+    if (ld_ci >= p.xC) { ld_ci = 0; ld_tap += 1; if (ld_tap < p.KH * p.KW) set_tap(ld_tap); }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  const int h = lane >> 5, l31 = lane & 31;
+  const int f = (l31 >> 2) & 3;
+  const int a_rd = (wm * 64 + l31) * BK;
+  const int a_c0 = ((2 * h) ^ f) * 4, a_c1 = ((2 * h + 1) ^ f) * 4;
+  const int b_rd = T::A_FL + (8 * h) * BN + wn * 64 + 2 * l31;
+  // k order inside a stage: step s multiplies k = s (lanes 0-31) and k = 8 + s (lanes 32-63)
+  auto compute = [&](int st) {
+    const float* S = smem + st * T::ST_FL;
+    float af[2][8], bf[2][8];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const float4 v0 = *reinterpret_cast<const float4*>(S + a_rd + i * 32 * BK + a_c0);
+      const float4 v1 = *reinterpret_cast<const float4*>(S + a_rd + i * 32 * BK + a_c1);
+      af[i][0] = v0.x; af[i][1] = v0.y; af[i][2] = v0.z; af[i][3] = v0.w;
+      af[i][4] = v1.x; af[i][5] = v1.y; af[i][6] = v1.z; af[i][7] = v1.w;
+    }
+#pragma unroll
+    for (int s8 = 0; s8 < 8; ++s8) {
+      const float2 b = *reinterpret_cast<const float2*>(S + b_rd + s8 * BN);
+      bf[0][s8] = b.x; bf[1][s8] = b.y;
+    }
+#pragma unroll
+    for (int s8 = 0; s8 < 8; ++s8)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s8], bf[j][s8], acc[i][j], 0, 0, 0);
+  };
+
+  if (kb_begin < kb_end) {
+    issue(0, kb_begin);
+    if (kb_begin + 1 < kb_end) issue(1, kb_begin + 1);
+    int st = 0;
+    for (int kb = kb_begin; kb < kb_end; ++kb) {
+      // this wave's share of stage kb has landed: only the next stage's AI + BI loads may still be in flight
+      if (kb + 1 < kb_end) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(AI + BI) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();          // everybody's share landed; everybody finished reading stage kb - 1
+      asm volatile("" ::: "memory");
+      int st2 = st + 2; if (st2 >= NST) st2 -= NST;
+      if (kb + 2 < kb_end) issue(st2, kb + 2);         // overwrites the stage read in iteration kb - 1
+      compute(st);
+      st = st + 1 == NST ? 0 : st + 1;
+    }
+  }
+
+  // ---- epilogue.  lane: columns (c, c+1) = n0 + wn*64 + 2*l31 + {0,1}; rows wm*64 + i*32 + (e&3) + 8*(e>>2) + 4*h
+  const int colr = wn * 64 + 2 * l31;                   // column inside the tile
+  if (nsplit > 1) {
+    float* slab = p.slab + ((size_t)(tt * nsplit + split) * BM) * BN;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+        *reinterpret_cast<float2*>(slab + (size_t)row * BN + colr) = make_float2(acc[i][0][e], acc[i][1][e]);
+      }
+    return;
+  }
+  __syncthreads();                                      // the ring is dead: reuse it for the per-row output offsets
+  int* rowoff = reinterpret_cast<int*>(smem);
+  if (t < BM) {
+    const int m = m0 + t;
+    int off = -1;
+    if (m < p.M) {
+      const int n = m / HoWo, rem = m - n * HoWo;
+      const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+      off = ((n * p.yH + oy * p.ymul + p.yoff) * p.yW + ox * p.xmul + p.xoff) * p.ycs;
+    }
+    rowoff[t] = off;
+  }
+  __syncthreads();
+  const int col = n0 + colr;
+  const bool c0ok = col < p.Cout, c1ok = col + 1 < p.Cout;
+  float b0 = 0.f, b1 = 0.f;
+  if (p.bias) { if (c0ok) b0 = p.bias[col]; if (c1ok) b1 = p.bias[col + 1]; }
+  if (c0ok) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int off = rowoff[wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h];
+        if (off < 0) continue;
+        float v0 = act_apply(acc[i][0][e] + b0, p.act), v1 = act_apply(acc[i][1][e] + b1, p.act);
+        float* dst = p.y + (size_t)off + col;
+        if (c1ok) {
+          if (p.accumulate) { const float2 o = *reinterpret_cast<const float2*>(dst); v0 += o.x; v1 += o.y; }
+          *reinterpret_cast<float2*>(dst) = make_float2(v0, v1);
+        } else {
+          if (p.accumulate) v0 += *dst;
+          *dst = v0;
+        }
+      }
+  }
+#endif
+}
+
+// sums the partial tiles of the split tail in fixed order and applies the epilogue; one float4 of a tile row per thread
+template <int BM, int BN>
+__global__ __launch_bounds__(256) void conv_dma_reduce_kernel(GemmP p, DmaSched sc) {
+  const int tt = blockIdx.y;
+  const int e4 = blockIdx.x * 256 + threadIdx.x;
+  if (e4 >= BM * BN / 4) return;
+  const int r = e4 / (BN / 4), c4 = (e4 - r * (BN / 4)) * 4;
+  const int gtile = sc.full + tt;
+  const int z = gtile / sc.tiles_per_z, tile = gtile - z * sc.tiles_per_z;
+  const int tile_n = tile % p.tiles_n, tile_m = tile / p.tiles_n;
+  const int m = tile_m * BM + r, col = tile_n * BN + c4;
+  if (m >= p.M || col >= p.Cout) return;
+  p.y += (size_t)z * p.y_bs;
+  if (p.phases) { p.yoff = z >> 1; p.xoff = z & 1; }
+  const float* sl = p.slab + ((size_t)tt * sc.tail_s * BM + r) * BN + c4;
+  float4 a = *reinterpret_cast<const float4*>(sl);
+  for (int s = 1; s < sc.tail_s; ++s) {
+    const float4 b = *reinterpret_cast<const float4*>(sl + (size_t)s * BM * BN);
+    a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+  }
+  float v[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    if (p.bias && col + j < p.Cout) v[j] += p.bias[col + j];
+    v[j] = act_apply(v[j], p.act);
+  }
+  const int HoWo = p.Ho * p.Wo;
+  const int n = m / HoWo, rem = m - n * HoWo;
+  const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+  float* dst = p.y + (size_t)((n * p.yH + oy * p.ymul + p.yoff) * p.yW + ox * p.xmul + p.xoff) * p.ycs + col;
+  if (col + 3 < p.Cout) {
+    float4 o = make_float4(v[0], v[1], v[2], v[3]);
+    if (p.accumulate) {
+      const float4 old = *reinterpret_cast<const float4*>(dst);
+      o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w;
+    }
+    *reinterpret_cast<float4*>(dst) = o;
+  } else {
+    for (int j = 0; j < 4 && col + j < p.Cout; ++j) dst[j] = p.accumulate ? dst[j] + v[j] : v[j];
+  }
+}
+
+// ---------------------------------------------------------------------------------------
 // narrow-N forward-type kernel (Cout <= 32: the 19-channel tail conv, PatchGAN's 1-channel
 // prediction conv, dgrads into few-channel inputs).  The 32-wide MFMA tile wastes 13/32 of
 // the matrix pipe at N = 19; v_mfma_f32_4x4x1 (16 independent 4x4 blocks per wave, same
@@ -1292,6 +1578,76 @@ static void launch_fwd_narrow(Stream& s, GemmP& p, bool fast, int batch) {
   }
 }
 
+
+// ---- LDS-DMA forward kernel: schedule + launch ------------------------------------------------------------------
+// T tiles of `work` stages on `slots` resident workgroups.  Whole rounds run one tile per unit; the remainder tiles
+// (all tiles when T < slots) are split s ways along K so that the last round is as full as the others.
+static DmaSched plan_dma(int tiles_total, int tiles_per_z, int work, int slots, size_t tile_bytes, size_t ws_bytes) {
+  DmaSched sc{};
+  sc.tiles_per_z = tiles_per_z;
+  const int rounds = tiles_total / slots;
+  int rem = tiles_total - rounds * slots;
+  sc.full = rounds * slots; sc.tail_tiles = rem; sc.tail_s = 1; sc.per_split = work;
+  if (rem == 0) return sc;
+  // the first full round absorbs a small remainder better than a split does (fixed cost per tile ~ 4 stages)
+  int best = 1;
+  double best_cost = 1e300;
+  const int max_s = std::max(1, std::min(64, work / 8));
+  for (int sp = 1; sp <= max_s; ++sp) {
+    if (sp > 1 && (size_t)rem * sp * tile_bytes > ws_bytes) break;
+    const int per = ceil_div(work, sp), eff = ceil_div(work, per);
+    const double tail_rounds = std::ceil((double)rem * eff / slots);
+    double cost = tail_rounds * (per + 4.0);
+    if (eff > 1) cost += 0.03 * eff * work * ((double)rem / slots) / std::max(work / 16, 1) + 1.5;   // slab write + reduce
+    if (cost < best_cost * 0.97) { best_cost = cost; best = eff; }
+  }
+  sc.tail_s = best;
+  sc.per_split = ceil_div(work, best);
+  sc.tail_s = ceil_div(work, sc.per_split);
+  if (sc.tail_s == 1) { sc.full = tiles_total; sc.tail_tiles = 0; }
+  return sc;
+}
+
+template <int WGM, int WGN>
+static void launch_fwd_dma(Stream& s, GemmP& p, int nb) {
+  using T = DmaTile<WGM, WGN>;
+  const int tiles_m = ceil_div(p.M, T::BM);
+  p.tiles_n = ceil_div(p.Npad, T::BN);
+  p.ntiles = tiles_m * p.tiles_n;
+  const int nkb = p.K / T::BK;
+  const int wg_per_cu = std::min(160 * 1024 / T::SMEM, 12 / T::NW);        // LDS and 3 waves/SIMD (<= 168 VGPRs)
+  const DmaSched sc = plan_dma(p.ntiles * nb, p.ntiles, nkb, 256 * wg_per_cu, (size_t)T::BM * T::BN * 4, s.ws_bytes);
+  p.slab = reinterpret_cast<float*>(s.ws);
+  p.splits = sc.tail_s;
+  static bool once = (set_smem(conv_fwd_dma_kernel<WGM, WGN>, T::SMEM), true);
+  (void)once;
+  char pname[112];
+  if (prof_detail())
+    snprintf(pname, sizeof pname, "conv_fwd_dma_%dx%d[M%d,N%d,K%d,b%d,full%d,tail%dx%d]", T::BM, T::BN, p.M, p.Cout, p.K, nb,
+             sc.full, sc.tail_tiles, sc.tail_s);
+  else
+    snprintf(pname, sizeof pname, "conv_fwd_dma_%dx%d", T::BM, T::BN);
+  ProfScope prof(s, pname, 2.0 * p.M * p.Cout * p.K * nb);
+  const int units = sc.full + sc.tail_tiles * sc.tail_s;
+  hipLaunchKernelGGL((conv_fwd_dma_kernel<WGM, WGN>), dim3(units), dim3(64 * T::NW), T::SMEM, hs(s), p, sc);
+  check_launch("conv_fwd_dma");
+  if (sc.tail_tiles > 0 && sc.tail_s > 1) {
+    hipLaunchKernelGGL((conv_dma_reduce_kernel<T::BM, T::BN>), dim3(T::BM * T::BN / 4 / 256, sc.tail_tiles), dim3(256), 0, hs(s), p, sc);
+    check_launch("conv_dma_reduce");
+  }
+}
+
+static bool dma_on() {
+  static const bool on = !(getenv("SWN_DMA") && atoi(getenv("SWN_DMA")) == 0);
+  return on;
+}
+// the LDS-DMA kernel addresses activations through 32-bit buffer offsets and marks padding with offsets >= 2^31
+static bool dma_ok(const ConvFwdArgs& a, const GemmP& p) {
+  if (!dma_on() || a.x.C % 16 || a.Npad <= 32) return false;
+  const size_t xbytes = (size_t)a.x.N * a.x.H * a.x.W * a.x.cs * 4, wbytes = (size_t)p.K * a.Npad * 4;
+  return xbytes < ((size_t)1 << 31) && wbytes < ((size_t)1 << 31);
+}
+
 static bool narrow_on() {
   const bool on = !(getenv("SWN_NARROW") && atoi(getenv("SWN_NARROW")) == 0);     // read per launch: tests toggle it
   return on;
@@ -1355,6 +1711,11 @@ void conv_fwd(Stream& s, const ConvFwdArgs& a) {
   static const int t192 = getenv("SWN_TILE192") ? atoi(getenv("SWN_TILE192")) : 1;
   // N in (128, 192] (the tail conv's input gradient into the 192-channel concat): a 128x192 tile instead
   // of two 128-wide column tiles of which the second is half empty
+  if (dma_ok(a, p)) {
+    if (a.Npad > 64) launch_fwd_dma<2, 2>(s, p, nb);     // 128 x 128, 4 waves, 3 workgroups / CU
+    else launch_fwd_dma<4, 1>(s, p, nb);                 // 256 x 64
+    return;
+  }
   if (t192 && a.Npad > 128 && a.Npad <= 192) launch_fwd<2, 3, 2, 2>(s, p, fast, nb);
   else if (a.Npad > 64 && big && fast && p.M >= 2048) launch_fwd<2, 2, 4, 2>(s, p, fast, nb);
   else if (a.Npad > 64) launch_fwd<2, 2, 2, 2>(s, p, fast, nb);

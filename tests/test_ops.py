@@ -85,6 +85,10 @@ CONV_CASES_GPU = CONV_CASES_SIM + [
     (K4S2, 1, 2, 1024, 4, 512, False),       # convT, split-K per phase
     (K4S2, 1, 2, 384, 32, 64, False),        # dual_up3
     (K4S2, 1, 1, 128, 64, 3, True),          # texture outermost up conv
+    # LDS-DMA ring kernel corner cases: Ci % 16 == 0 but not % 32, N = 64 (256x64 tile), N = 96 / 80 / 48 (columns of
+    # the 128-wide tile past Npad are fetched out of range), ragged M, zero / reflect padding rows out of range
+    (K4S2, 0, 2, 48, 24, 96, True), (K4S2, 0, 1, 16, 32, 64, True), (K3ZERO, 0, 2, 48, 12, 80, True),
+    (K3REFL, 0, 1, 16, 10, 48, True), (K4S1, 0, 3, 48, 9, 40, True), (K4S2, 1, 1, 48, 6, 72, True),
 ]
 
 

@@ -68,13 +68,23 @@ def _check_step(m, st, gD, gG, tol_loss=1e-3, tol_out=1e-3, tol_gD=5e-3, tol_gG=
             e = rel(got[k], v)
             worst[name] = max(worst.get(name, 0.0), e)
             assert e < tol, (what, name, k, e)
+    # post-step weights.  The first AdamW step moves every element by lr * g / (|g| + eps): an element whose gradient
+    # is round-off-sized relative to its tensor (|g| < 1e-2 rms(g)) gets a sign-like update of arbitrary sign in the
+    # reference too, so those elements are compared on the un-amplified quantity only (their gradient, above) and
+    # the weight check covers the rest -- at the full-size shapes a few such elements exist in otherwise clean
+    # tensors (e.g. one unit of the innermost U-Net conv bias), unlike the "noise biases" which are noise throughout.
     pG, pD = m.state_dict(engine.NET_G, to_cpu=True), m.state_dict(engine.NET_D, to_cpu=True)
-    for name, got, ref in (("postG", pG, st.G), ("postD", pD, st.D)):
+    for name, got, ref, gref in (("postG", pG, st.G, st.grads_G), ("postD", pD, st.D, st.grads_D)):
         for k, v in ref.items():
-            if not noise_bias(k, list(ref)):
-                e = rel(got[k], v)
-                worst[name] = max(worst.get(name, 0.0), e)
-                assert e < tol_post, (what, name, k, e)
+            if noise_bias(k, list(ref)):
+                continue
+            g = gref[k].double()
+            solid = g.abs() >= 1e-2 * g.pow(2).mean().sqrt()
+            assert float(solid.double().mean()) > 0.9, (what, name, k, "fraction of well-conditioned elements")
+            a, b = got[k].double().cpu()[solid], v.double()[solid]
+            e = float((a - b).norm() / (b.norm() + 1e-30))
+            worst[name] = max(worst.get(name, 0.0), e)
+            assert e < tol_post, (what, name, k, e)
     return worst
 
 
