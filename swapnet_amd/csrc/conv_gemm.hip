@@ -1339,6 +1339,210 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_wgrad_kernel(GemmP p) {
     }
 }
 
+
+// ---------------------------------------------------------------------------------------
+// wgrad-type kernel on the LDS-DMA ring: dW[k][n] = sum_m A[m][k] dY[m][n], tile = BMK k-rows x BN columns, reduction
+// over 16-pixel stages.  Both LDS tiles are pixel-major ([16 px][BMK] and [16 px][BN]), i.e. plain images of what the
+// lanes fetch: a lane owns one 16-byte chunk of k (fixed tap and channels for the whole kernel, so it works for any
+// Cin % 4 == 0, also across taps) or of n, and one or more pixels of the stage.  A stage's 16 pixels lie in one image
+// (Wo % 16 == 0, or Wo | 16 with Ho*Wo % 16 == 0): its first pixel is tracked by a scalar cursor and every lane adds a
+// fixed (dy, dx).  Fragments are ds_read_b64 of two adjacent k-rows / columns (conflict-free, no transposes):
+// a lane's MFMA blocks i = 0, 1 hold k-rows (2r, 2r+1), blocks j = 0, 1 columns (2c, 2c+1).
+// ---------------------------------------------------------------------------------------
+template <int WGM, int WGN>
+struct DmaWgTile {
+  static constexpr int NW = WGM * WGN, BMK = 64 * WGM, BN = 64 * WGN, PX = 16, NST = 3;
+  static constexpr int A_FL = PX * BMK, B_FL = PX * BN, ST_FL = A_FL + B_FL;
+  static constexpr int LPRA = BMK / 4, LPRB = BN / 4;              // lanes per pixel row
+  static constexpr int PPIA = 64 / LPRA > 0 ? 64 / LPRA : 1, PPIB = 64 / LPRB;   // pixels per instruction
+  static constexpr int AI = (PX * LPRA / 64) / NW, BI = (PX * LPRB / 64) / NW;   // instructions per wave per stage
+  static constexpr int SMEM = NST * ST_FL * 4;
+  static_assert(LPRA <= 64 && AI >= 1 && BI >= 1, "tile shape");
+};
+
+template <int WGM, int WGN>
+__global__ __launch_bounds__(64 * WGM * WGN) void conv_wgrad_dma_kernel(GemmP p, DmaSched sc) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  using T = DmaWgTile<WGM, WGN>;
+  constexpr int BMK = T::BMK, BN = T::BN, PX = T::PX, NST = T::NST, AI = T::AI, BI = T::BI;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int t = threadIdx.x, lane = t & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wm = wid / WGN, wn = wid % WGN;
+
+  int u = blockIdx.x, gtile, split = 0, nsplit = 1, tt = 0;
+  if (u < sc.full) {
+    gtile = xcd_swizzle(u, sc.full);
+  } else {
+    u -= sc.full;
+    tt = u / sc.tail_s; split = u - tt * sc.tail_s; nsplit = sc.tail_s;
+    gtile = sc.full + tt;
+  }
+  const int z = gtile / sc.tiles_per_z, tile = gtile - z * sc.tiles_per_z;
+  const int tile_n = tile % p.tiles_n, tile_k = tile / p.tiles_n;
+  const int kt0 = tile_k * BMK, n0 = tile_n * BN;
+  p.x += (size_t)z * p.x_bs; p.y += (size_t)z * p.y_bs; p.w += (size_t)z * p.w_bs;
+  if (p.phases) { const int a = z >> 1, b = z & 1; p.pad_t -= a; p.pad_l -= b; p.yoff = a; p.xoff = b; }
+  const int HoWo = p.Ho * p.Wo;
+  const int nimg = p.M / HoWo;
+  const int nmb_all = p.M / PX;
+  const int mb_begin = nsplit > 1 ? split * sc.per_split : 0;
+  const int mb_end = nsplit > 1 ? min(nmb_all, mb_begin + sc.per_split) : nmb_all;
+
+  const unsigned x_bytes = (unsigned)((((size_t)p.xH * p.xW * nimg - 1) * p.xcs + p.xC) * 4);
+  const unsigned y_bytes = (unsigned)((((size_t)p.yH * p.yW * nimg - 1) * p.ycs + p.yC) * 4);
+  const i32x4 rsA = make_rsrc(p.x, x_bytes), rsB = make_rsrc(p.y, y_bytes);
+  const unsigned lds0 = (unsigned)(size_t)(lds_ptr_t)smem;
+  const int He = p.xH << p.ups, We = p.xW << p.ups;
+  const bool wide = (p.Wo % PX) == 0;
+
+  // ---- per-lane constants: A chunk -> (tap, ci); pixel offsets (dy, dx) of the lane's pixels inside a stage
+  const int ak = kt0 + 4 * (lane % T::LPRA);
+  const bool kvalid = ak < p.K;
+  const int atap = ak / p.xC, aci = ak - atap * p.xC;
+  const int akh = atap / p.KW, akw = atap - akh * p.KW;
+  int a_dy[AI], a_dx[AI], b_dy[BI], b_dx[BI];
+#pragma unroll
+  for (int r = 0; r < AI; ++r) {
+    const int j = (wid * AI + r) * T::PPIA + lane / T::LPRA;
+    a_dy[r] = wide ? 0 : j / p.Wo; a_dx[r] = wide ? j : j % p.Wo;
+  }
+  const int bn = n0 + 4 * (lane % T::LPRB);
+  const bool nvalid = bn < p.yC;
+#pragma unroll
+  for (int r = 0; r < BI; ++r) {
+    const int j = (wid * BI + r) * T::PPIB + lane / T::LPRB;
+    b_dy[r] = wide ? 0 : j / p.Wo; b_dx[r] = wide ? j : j % p.Wo;
+  }
+  // scalar cursor of the next stage to issue
+  int c_n, c_oy, c_ox;
+  {
+    const int mbase = mb_begin * PX;
+    c_n = mbase / HoWo; const int rem = mbase - c_n * HoWo;
+    c_oy = rem / p.Wo; c_ox = rem - c_oy * p.Wo;
+  }
+  const int rows_per_stage = wide ? 0 : PX / p.Wo;
+  auto issue = [&](int st) {
+    const unsigned As = lds0 + (unsigned)(st * T::ST_FL) * 4u, Bs = As + T::A_FL * 4u;
+    const int xin = c_n * p.xH * p.xW, yin = c_n * p.yH;
+#pragma unroll
+    for (int r = 0; r < AI; ++r) {
+      unsigned off = DMA_OOB;
+      const int sy = src_coord((c_oy + a_dy[r]) * p.stride - p.pad_t + akh, He, p.pad_mode, p.ups);
+      const int sx = src_coord((c_ox + a_dx[r]) * p.stride - p.pad_l + akw, We, p.pad_mode, p.ups);
+      if (kvalid && sy >= 0 && sx >= 0) off = (unsigned)((xin + sy * p.xW + sx) * p.xcs + aci) * 4u;
+      lds_dma16(off, rsA, 0u, As + (unsigned)(wid * AI + r) * 1024u);
+    }
+#pragma unroll
+    for (int r = 0; r < BI; ++r) {
+      unsigned off = DMA_OOB;
+      if (nvalid)
+        off = (unsigned)(((yin + (c_oy + b_dy[r]) * p.ymul + p.yoff) * p.yW + (c_ox + b_dx[r]) * p.xmul + p.xoff) * p.ycs + bn) * 4u;
+      lds_dma16(off, rsB, 0u, Bs + (unsigned)(wid * BI + r) * 1024u);
+    }
+    if (wide) {
+      c_ox += PX;
+      if (c_ox >= p.Wo) { c_ox = 0; c_oy += 1; if (c_oy >= p.Ho) { c_oy = 0; c_n += 1; } }
+    } else {
+      c_oy += rows_per_stage;
+      if (c_oy >= p.Ho) { c_oy = 0; c_n += 1; }
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  const int h = lane >> 5, l31 = lane & 31;
+  const int a_rd = (8 * h) * BMK + wm * 64 + 2 * l31;
+  const int b_rd = T::A_FL + (8 * h) * BN + wn * 64 + 2 * l31;
+  // pixel order inside a stage: step s multiplies pixel s (lanes 0-31) and pixel 8 + s (lanes 32-63)
+  auto compute = [&](int st) {
+    const float* S = smem + st * T::ST_FL;
+    float af[2][8], bf[2][8];
+#pragma unroll
+    for (int s8 = 0; s8 < 8; ++s8) {
+      const float2 a = *reinterpret_cast<const float2*>(S + a_rd + s8 * BMK);
+      const float2 b = *reinterpret_cast<const float2*>(S + b_rd + s8 * BN);
+      af[0][s8] = a.x; af[1][s8] = a.y; bf[0][s8] = b.x; bf[1][s8] = b.y;
+    }
+#pragma unroll
+    for (int s8 = 0; s8 < 8; ++s8)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s8], bf[j][s8], acc[i][j], 0, 0, 0);
+  };
+
+  if (mb_begin < mb_end) {
+    issue(0);
+    if (mb_begin + 1 < mb_end) issue(1);
+    int st = 0;
+    for (int mb = mb_begin; mb < mb_end; ++mb) {
+      if (mb + 1 < mb_end) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(AI + BI) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      int st2 = st + 2; if (st2 >= NST) st2 -= NST;
+      if (mb + 2 < mb_end) issue(st2);
+      compute(st);
+      st = st + 1 == NST ? 0 : st + 1;
+    }
+  }
+
+  // ---- epilogue: lane holds k-rows kt0 + wm*64 + 2*rr + i (rr = (e&3) + 8*(e>>2) + 4*h), columns n0 + wn*64 + 2*l31 + j
+  const int colr = wn * 64 + 2 * l31;
+  if (nsplit > 1) {
+    float* slab = p.slab + ((size_t)(tt * nsplit + split) * BMK) * BN;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = wm * 64 + 2 * ((e & 3) + 8 * (e >> 2) + 4 * h) + i;
+        *reinterpret_cast<float2*>(slab + (size_t)row * BN + colr) = make_float2(acc[i][0][e], acc[i][1][e]);
+      }
+    return;
+  }
+  float* out = const_cast<float*>(p.w);
+  const int col = n0 + colr;
+  if (col < p.Npad) {                           // Npad % 4 == 0 and col even: col + 1 < Npad too
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = kt0 + wm * 64 + 2 * ((e & 3) + 8 * (e >> 2) + 4 * h) + i;
+        if (row < p.K) *reinterpret_cast<float2*>(out + (size_t)row * p.Npad + col) = make_float2(acc[i][0][e], acc[i][1][e]);
+      }
+  }
+#endif
+}
+
+template <int BMK, int BN>
+__global__ __launch_bounds__(256) void wgrad_dma_reduce_kernel(GemmP p, DmaSched sc) {
+  const int tt = blockIdx.y;
+  const int e4 = blockIdx.x * 256 + threadIdx.x;
+  if (e4 >= BMK * BN / 4) return;
+  const int r = e4 / (BN / 4), c4 = (e4 - r * (BN / 4)) * 4;
+  const int gtile = sc.full + tt;
+  const int z = gtile / sc.tiles_per_z, tile = gtile - z * sc.tiles_per_z;
+  const int tile_n = tile % p.tiles_n, tile_k = tile / p.tiles_n;
+  const int row = tile_k * BMK + r, col = tile_n * BN + c4;
+  if (row >= p.K || col >= p.Npad) return;
+  const float* sl = p.slab + ((size_t)tt * sc.tail_s * BMK + r) * BN + c4;
+  float4 a = *reinterpret_cast<const float4*>(sl);
+  for (int s = 1; s < sc.tail_s; ++s) {
+    const float4 b = *reinterpret_cast<const float4*>(sl + (size_t)s * BMK * BN);
+    a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+  }
+  float* out = const_cast<float*>(p.w) + (size_t)z * p.w_bs;
+  *reinterpret_cast<float4*>(out + (size_t)row * p.Npad + col) = a;
+}
+
 __global__ void slab_sum_kernel(const float* slab, float* out, size_t n, int splits, size_t slab_bs, size_t out_bs) {
   slab += (size_t)blockIdx.y * slab_bs; out += (size_t)blockIdx.y * out_bs;
   const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
@@ -1767,6 +1971,43 @@ static void launch_wgrad(Stream& s, GemmP& p, int batch) {
   }
 }
 
+
+template <int WGM, int WGN>
+static void launch_wgrad_dma(Stream& s, GemmP& p, int nb) {
+  using T = DmaWgTile<WGM, WGN>;
+  const int tiles_k = ceil_div(p.K, T::BMK);
+  p.tiles_n = ceil_div(p.Npad, T::BN);
+  p.ntiles = tiles_k * p.tiles_n;
+  const int nmb = p.M / T::PX;
+  const int wg_per_cu = std::min(160 * 1024 / T::SMEM, 12 / T::NW);
+  const DmaSched sc = plan_dma(p.ntiles * nb, p.ntiles, nmb, 256 * wg_per_cu, (size_t)T::BMK * T::BN * 4, s.ws_bytes);
+  p.slab = reinterpret_cast<float*>(s.ws);
+  p.splits = sc.tail_s;
+  static bool once = (set_smem(conv_wgrad_dma_kernel<WGM, WGN>, T::SMEM), true);
+  (void)once;
+  char pname[112];
+  if (prof_detail())
+    snprintf(pname, sizeof pname, "conv_wgrad_dma_%dx%d[M%d,N%d,K%d,b%d,full%d,tail%dx%d]", T::BMK, T::BN, p.M, p.Cout, p.K, nb,
+             sc.full, sc.tail_tiles, sc.tail_s);
+  else
+    snprintf(pname, sizeof pname, "conv_wgrad_dma_%dx%d", T::BMK, T::BN);
+  ProfScope prof(s, pname, 2.0 * p.M * p.Cout * p.K * nb);
+  const int units = sc.full + sc.tail_tiles * sc.tail_s;
+  hipLaunchKernelGGL((conv_wgrad_dma_kernel<WGM, WGN>), dim3(units), dim3(64 * T::NW), T::SMEM, hs(s), p, sc);
+  check_launch("conv_wgrad_dma");
+  if (sc.tail_tiles > 0 && sc.tail_s > 1) {
+    hipLaunchKernelGGL((wgrad_dma_reduce_kernel<T::BMK, T::BN>), dim3(T::BMK * T::BN / 4 / 256, sc.tail_tiles), dim3(256), 0, hs(s), p, sc);
+    check_launch("wgrad_dma_reduce");
+  }
+}
+// stage geometry the LDS-DMA wgrad kernel needs: 16 consecutive pixels inside one image at fixed offsets from the first
+static bool wgrad_dma_ok(const ConvWgradArgs& a, const GemmP& p) {
+  if (!dma_on() || a.Npad <= 32 || a.dy.C % 4 || a.x.C % 4) return false;
+  const bool geom = (p.Wo % 16 == 0) || (16 % p.Wo == 0 && (p.Ho * p.Wo) % 16 == 0);
+  const size_t xbytes = (size_t)a.x.N * a.x.H * a.x.W * a.x.cs * 4, ybytes = (size_t)a.dy.N * a.dy.H * a.dy.W * a.dy.cs * 4;
+  return geom && p.M % 16 == 0 && xbytes < ((size_t)1 << 31) && ybytes < ((size_t)1 << 31);
+}
+
 void conv_wgrad(Stream& s, const ConvWgradArgs& a) {
   if (a.tail4) {
     check_tail4(a.g, a.om, a.batch, a.phases);
@@ -1810,6 +2051,11 @@ void conv_wgrad(Stream& s, const ConvWgradArgs& a) {
   p.x_bs = a.x_bs; p.y_bs = a.dy_bs; p.w_bs = a.dw_bs;
   const int nb = a.phases ? a.phases : std::max(a.batch, 1);
   static const int big = getenv("SWN_WGRAD256") ? atoi(getenv("SWN_WGRAD256")) : 1;
+  if (wgrad_dma_ok(a, p)) {
+    if (a.Npad > 64) launch_wgrad_dma<2, 2>(s, p, nb);    // 128 k-rows x 128 columns
+    else launch_wgrad_dma<4, 1>(s, p, nb);                // 256 x 64
+    return;
+  }
   // 8-wave 256x128 tile: +3 % on the single-GEMM layers, -7 % on the batched Winograd planes (measured)
   if (a.Npad > 64 && big && p.K >= 512 && nb == 1) launch_wgrad<2, 2, 4, 2>(s, p, nb);
   else if (a.Npad > 64) launch_wgrad<2, 2, 2, 2>(s, p, nb);

@@ -29,7 +29,7 @@ struct NAp {
   const float* res; int rescs;  // fwd residual
   float* stats;                 // [N][C][2]
   double* partial;              // [N][nchunk][C][2]
-  float* sums;                  // bwd: [N][C][2] = mean(dxh), mean(dxh*xh)
+  double* sums;                 // bwd: [N][C][2] = mean(dxh), mean(dxh*xh)
   int N, HW, C, nchunk, chunk;
   int norm, act;
   float drop_p; uint64_t seed;
@@ -66,10 +66,10 @@ __global__ __launch_bounds__(256) void in_partial_kernel(NAp p) {
         const float ga[4] = {gv.x, gv.y, gv.z, gv.w};
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          const float xh = (xa[j] - mean[j]) * rstd[j];
+          const float xh = (xa[j] - mean[j]) * rstd[j];                 // the forward's value (selects the activation branch)
           float g = ga[j] * act_grad_from_in(xh, p.act);
           if (p.drop_p > 0.f) g *= drop_scale(p.seed, e * p.C + tx * 4 + j, p.drop_p);
-          s[j] += g; ss[j] += (double)g * xh;
+          s[j] += g; ss[j] += (double)g * (((double)xa[j] - (double)mean[j]) * (double)rstd[j]);
         }
       }
     }
@@ -104,8 +104,8 @@ __global__ void in_finalize_kernel(NAp p) {
     p.stats[(size_t)i * 2] = (float)mean;
     p.stats[(size_t)i * 2 + 1] = (float)(1.0 / sqrt(var + (double)IN_EPS));
   } else {
-    p.sums[(size_t)i * 2] = (float)(a / p.HW);
-    p.sums[(size_t)i * 2 + 1] = (float)(b / p.HW);
+    p.sums[(size_t)i * 2] = a / p.HW;
+    p.sums[(size_t)i * 2 + 1] = b / p.HW;
   }
 }
 
@@ -151,7 +151,8 @@ __global__ __launch_bounds__(256) void norm_act_bwd_apply_kernel(NAp p) {
     float o[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      float mean = 0.f, rstd = 1.f, m1 = 0.f, m2 = 0.f;
+      float mean = 0.f, rstd = 1.f;
+      double m1 = 0.0, m2 = 0.0;
       if (p.norm) {
         mean = p.stats[((size_t)n * p.C + c + j) * 2];
         rstd = p.stats[((size_t)n * p.C + c + j) * 2 + 1];
@@ -161,7 +162,9 @@ __global__ __launch_bounds__(256) void norm_act_bwd_apply_kernel(NAp p) {
       const float xh = (xa[j] - mean) * rstd;
       float g = ga[j] * act_grad_from_in(xh, p.act);
       if (p.drop_p > 0.f) g *= drop_scale(p.seed, e * p.C + c + j, p.drop_p);
-      o[j] = p.norm ? rstd * (g - m1 - xh * m2) : g;
+      // g - mean(g) - xh * mean(g xh) cancels heavily (the deep layers lose 3 digits here): the combination is done in
+      // double -- the kernel is HBM-bound (20 B per element), the handful of fp64 operations is free
+      o[j] = p.norm ? (float)((double)rstd * ((double)g - m1 - (((double)xa[j] - (double)mean) * (double)rstd) * m2)) : g;
     }
     *reinterpret_cast<float4*>(p.y + e * p.ycs + c) = make_float4(o[0], o[1], o[2], o[3]);
   }
@@ -341,8 +344,8 @@ void norm_act_bwd(Stream& s, const NormActBwdArgs& a) {
     plan_chunks(p.HW, p.N, p.C, p.nchunk, p.chunk);
     p.partial = reinterpret_cast<double*>(s.ws);
     const size_t pbytes = (size_t)p.N * p.nchunk * p.C * 16;
-    p.sums = reinterpret_cast<float*>(s.ws + round_up((int)pbytes, 256));
-    if (pbytes + 256 + (size_t)p.N * p.C * 8 > s.ws_bytes) throw Error(1, "norm_act: workspace too small");
+    p.sums = reinterpret_cast<double*>(s.ws + round_up((int)pbytes, 256));
+    if (pbytes + 256 + (size_t)p.N * p.C * 16 > s.ws_bytes) throw Error(1, "norm_act: workspace too small");
     hipLaunchKernelGGL(in_partial_kernel<1>, dim3(p.nchunk, p.N), dim3(256), 0, hs(s), p);
     hipLaunchKernelGGL(in_finalize_kernel<1>, dim3(ceil_div(p.N * p.C, 256)), dim3(256), 0, hs(s), p);
   }

@@ -184,7 +184,7 @@ def test_fused_step_equals_phased_step(backend, oracle_run):
 def test_warp_full_size_properties():
     """Config C2 shape (256x256, bs 32): size-independent properties the oracle cannot reach.
     (1) run-to-run bitwise determinism of a full training step (fixed-order reductions);
-    (2) batch-permutation equivariance of the generator (every layer is per-sample);
+    (2) batch-permutation equivariance of the generator (every layer is per-sample), to summation-order round-off;
     (3) dropout: train-mode forward differs from eval, and is reproducible for a fixed seed."""
     ctx = backends.gpu_ctx()
     B, H = 32, 256
@@ -213,7 +213,9 @@ def test_warp_full_size_properties():
     m.set_input(0, batch[0][perm]); m.set_input(1, batch[1][perm])
     m.forward(False, 0)
     b = m.output().cpu()
-    assert torch.equal(a[perm], b)
+    # (not bitwise: the tile a sample falls into decides whether its K reduction runs whole or as the split tail
+    # of the launch -- a different, still fixed, summation order)
+    assert float((a[perm] - b).abs().max()) < 2e-5 and rel(b, a[perm]) < 1e-6
     # (3) dropout
     m.forward(True, 5); d1 = m.output().cpu()
     m.forward(True, 5); d2 = m.output().cpu()
