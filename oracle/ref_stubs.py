@@ -100,8 +100,34 @@ class _Inert:
         return _Inert()
 
 
-def install():
-    """Install the stand-ins and put the reference first on sys.path."""
+class _ToTensor:
+    """transforms.ToTensor: PIL / HxWxC uint8 -> float CxHxW in [0,1]"""
+
+    def __call__(self, pic):
+        import numpy as np
+        a = np.asarray(pic)
+        if a.ndim == 2:
+            a = a[:, :, None]
+        t = torch.from_numpy(a.copy()).permute(2, 0, 1)
+        return t.float().div(255) if t.dtype == torch.uint8 else t.float()
+
+
+class _Normalize:
+    """transforms.Normalize(mean, std)"""
+
+    def __init__(self, mean, std, inplace=False):
+        self.mean, self.std = torch.tensor(list(mean), dtype=torch.float32), torch.tensor(list(std), dtype=torch.float32)
+
+    def __call__(self, t):
+        return (t - self.mean[:, None, None]) / self.std[:, None, None]
+
+
+def install(functional_transforms=False):
+    """Install the stand-ins and put the reference first on sys.path.  functional_transforms=True makes ToTensor /
+    Normalize real (needed when the reference's own dataloader is run, tests/test_reference_scripts.py)."""
+    if functional_transforms and "torchvision.transforms" in sys.modules:
+        sys.modules["torchvision.transforms"].ToTensor = _ToTensor
+        sys.modules["torchvision.transforms"].Normalize = _Normalize
     if "torchvision" not in sys.modules:
         tv = _mod("torchvision")
         tv.ops = _mod("torchvision.ops", RoIAlign=_RoIAlignStub)
@@ -111,6 +137,8 @@ def install():
                   "RandomHorizontalFlip", "Resize", "CenterCrop", "RandomCrop", "Lambda",
                   "ToPILImage", "ColorJitter", "Pad"):
             setattr(tf, n, _Inert)
+        if functional_transforms:
+            tf.ToTensor, tf.Normalize = _ToTensor, _Normalize
         tf.functional = _mod("torchvision.transforms.functional")
         tf.transforms = tf                      # `from torchvision.transforms import transforms`
         sys.modules["torchvision.transforms.transforms"] = tf
