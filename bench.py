@@ -69,6 +69,49 @@ def cpu_baseline(sample_bs=4, size=256, warm=2, timed=5):
                       f"torch {torch.__version__} CPU fp32, {cores} threads"}
 
 
+def bench_infer(args):
+    """inference.py's two stages (warp -> label hand-off -> texture) at batch size 1, the
+    reference's inference batch size (inference.py:67), kept on the device and replayed as a hipGraph.  Reports the
+    per-image latency (host launch -> results complete, inputs resident) eager and as a graph replay."""
+    from swapnet_amd import engine, synthetic
+    from swapnet_amd.modules import init_tensor
+    torch.cuda.set_device(0)
+    ctx = engine.Context(device=0, workspace_mb=256)
+    B, S = 1, args.size
+    warp = engine.NativeModel(ctx, "warp", B, S, S, is_train=False)
+    tex = engine.NativeModel(ctx, "texture", B, S, S, is_train=False)
+    torch.manual_seed(0)
+    for m in (warp, tex):
+        m.load_state_dict(engine.NET_G, {n: (torch.zeros(sh) if n.endswith(".bias") else init_tensor(torch.empty(sh), "kaiming"))
+                                         for n, sh in m.param_infos(engine.NET_G).items()})
+    wb, tb = synthetic.warp_batch(B, S, S, seed=1), synthetic.texture_batch(B, S, S, seed=2)
+    warp.set_input(0, wb["bodys"]); warp.set_input(1, wb["input_cloths"])
+    tex.set_input(0, tb["input_textures"]); tex.set_input(1, tb["rois"])
+    pipe = engine.NativePipeline(warp, tex)
+    res = {}
+    for mode, use_graph in (("eager", False), ("hipgraph", True)):
+        for _ in range(max(args.warmup, 2)):
+            pipe.run(use_graph)
+        torch.cuda.synchronize()
+        lat = []
+        for _ in range(max(args.steps, 50)):
+            t0 = time.perf_counter()
+            pipe.run(use_graph)
+            torch.cuda.synchronize()
+            lat.append((time.perf_counter() - t0) * 1e3)
+        lat.sort()
+        res[mode] = {"p50_ms": round(lat[len(lat) // 2], 4), "p90_ms": round(lat[int(len(lat) * 0.9)], 4),
+                     "min_ms": round(lat[0], 4)}
+    out = {"metric": "two-stage inference latency (warp -> texture), 256x256, batch 1", "value": res["hipgraph"]["p50_ms"],
+           "unit": "ms/image (p50)", "n_gpus": 1, "steps": max(args.steps, 50), "warmup": max(args.warmup, 2),
+           "ms_per_step": res["hipgraph"]["p50_ms"], "higher_is_better": False, "scaling": "n/a", "vs_baseline": None,
+           "dtype": "f32", "data": "synthetic",
+           "config": {"workload": f"inference.py pipeline: WarpModule forward -> argmax labels -> one-hot -> TextureModule "
+                                  f"forward (12 ROIs), {S}x{S}, batch 1, eval mode, inputs resident in HBM"},
+           "latency": res, "images_per_sec": round(1e3 / res["hipgraph"]["p50_ms"], 2)}
+    print(json.dumps(out), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -76,7 +119,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=32, help="per-GPU batch (config C2: 32)")
     ap.add_argument("--size", type=int, default=256)
-    ap.add_argument("--stage", choices=("warp", "texture"), default="warp",
+    ap.add_argument("--stage", choices=("warp", "texture", "infer"), default="warp",
                     help="warp = config C2 (the headline metric); texture = config C3 (256x256, bs 16, ROIs, "
                          "perceptual + style losses on), reported for reference")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -85,6 +128,8 @@ def main():
                     help="additionally time steps that re-upload the batch from host memory every step through "
                          "the model API (set_input + step), reported as `h2d_inclusive` (never `value`)")
     args = ap.parse_args()
+    if args.stage == "infer":
+        return bench_infer(args)
 
     from swapnet_amd import engine, parallel, synthetic
     from swapnet_amd.modules import init_tensor

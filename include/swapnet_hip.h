@@ -121,6 +121,18 @@ int swn_model_dropout_sites(swn_model* m, int net, int* count);
 int swn_model_dropout_mask(swn_model* m, int net, int site, uint64_t dropout_seed, float* dev_nchw, int shape[4],
                            float* p);
 
+/* inference.py's warp -> texture hand-off (inference.py:94-126; .npz round trip of :140-149,169-180 /
+ * datasets/data_utils.py:311-343) kept in HBM: warp forward -> argmax label map -> one-hot into the texture model's
+ * cloth inputs -> texture forward.  Inputs are staged with swn_model_set_input on the two models beforehand (warp
+ * slots 0,1; texture slots 0,1 -- texture slot 2 is produced here); the result is the texture model's output.
+ * use_graph != 0: the first call runs eagerly and captures the sequence into a hipGraph, later calls replay it
+ * (*graph_replayed = 1).  Both models must be inference models (is_train = 0) of one context and one (B,H,W). */
+typedef struct swn_pipeline swn_pipeline;
+int swn_pipeline_create(swn_model* warp, swn_model* texture, swn_pipeline** out);
+int swn_pipeline_destroy(swn_pipeline* p);
+int swn_pipeline_run(swn_pipeline* p, int use_graph, int* graph_replayed);
+int swn_pipeline_labels(swn_pipeline* p, int32_t** dev_labels);   /* (B,H,W) int32 of the last run, library-owned */
+
 /* NLayerDiscriminator.forward(input) (modules/discriminators.py:134-136) as a standalone call on the model's
  * discriminator weights: x = conditioned input in the reference's channel order, (B, 22, H, W); pred receives
  * (B, 1, H/8-2, W/8-2).  Uses a private activation set: self.fakes and the staged batch stay untouched. */
@@ -185,6 +197,14 @@ int swn_op_conv(swn_ctx* ctx, int kind, int transposed, int what, int naive, flo
 int swn_op_instance_norm_act(swn_ctx* ctx, const float* x, int n, int c, int h, int w, int act, float* y);
 int swn_op_instance_norm_act_bwd(swn_ctx* ctx, const float* x, const float* dy, int n, int c, int h, int w, int act,
                                  float* dx);
+/* WarpDataset's per-channel augmentation (datasets/warp_dataset.py:131-137, datasets/data_utils.py:346-361
+ * per_channel_transform: an independent random flip / affine / perspective chain for each of the 19 cloth channels
+ * of each sample) as ONE device gather over the batch instead of B*19*ntransforms PIL calls.  src, dst (B,C,H,W)
+ * fp32; maps = device doubles [B*C][nmaps][9] = {kind, c0..c7} applied in index order: kind 0 identity, 1 affine in
+ * Pillow's 16.16 fixed point (bit-identical to Image.transform(AFFINE, NEAREST) and to the flips), 2 perspective with
+ * NEAREST sampling.  swapnet_amd/datasets/gpu_augment.py draws the parameters like torchvision's transforms do. */
+int swn_op_affine_gather(swn_ctx* ctx, const float* src, float* dst, int b, int c, int h, int w, const double* maps,
+                         int nmaps);
 /* GANLoss(gan_mode)(prediction, target_is_real) (modules/loss.py:110-130) with the target scalar already drawn
  * (`label`; the smooth-label draw stays host-side like in the reference, loss.py:65-108): mean BCE-with-logits /
  * MSE / +-mean over ALL elements of pred (N,C,H,W).  loss_out = device float; dpred (optional, same shape) receives

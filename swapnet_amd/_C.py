@@ -55,6 +55,10 @@ _PROTOS = {
     "swn_model_get_tap": ([_vp, _i, C.c_char_p, _fp, C.POINTER(_i * 4)], _i),
     "swn_model_dropout_sites": ([_vp, _i, C.POINTER(_i)], _i),
     "swn_model_dropout_mask": ([_vp, _i, _i, C.c_uint64, _fp, C.POINTER(_i * 4), C.POINTER(_f)], _i),
+    "swn_pipeline_create": ([_vp, _vp, C.POINTER(_vp)], _i),
+    "swn_pipeline_destroy": ([_vp], _i),
+    "swn_pipeline_run": ([_vp, _i, C.POINTER(_i)], _i),
+    "swn_pipeline_labels": ([_vp, C.POINTER(_vp)], _i),
     "swn_model_discriminate": ([_vp, _fp, _fp], _i),
     "swn_model_perceptual": ([_vp, _fp, _fp, _i, _fp, _f, _f, _fp], _i),
     "swn_model_forward": ([_vp, _i, C.c_uint64], _i),
@@ -76,6 +80,7 @@ _PROTOS = {
     "swn_op_conv": ([_vp, _i, _i, _i, _i, _fp, _i, _i, _i, _i, _fp, _i, _fp, _i, _fp], _i),
     "swn_op_instance_norm_act": ([_vp, _fp, _i, _i, _i, _i, _i, _fp], _i),
     "swn_op_instance_norm_act_bwd": ([_vp, _fp, _fp, _i, _i, _i, _i, _i, _fp], _i),
+    "swn_op_affine_gather": ([_vp, _fp, _fp, _i, _i, _i, _i, _vp, _i], _i),
     "swn_op_gan_loss": ([_vp, _i, _fp, _i, _i, _i, _i, _f, _i, _f, _fp, _fp], _i),
     "swn_op_norm_act_dropout": ([_vp, _fp, _fp, _i, _i, _i, _i, _i, _i, _f, C.c_uint64, _fp, _fp, _fp], _i),
     "swn_op_adamw": ([_vp, _fp, _fp, _fp, _fp, C.c_size_t, _f, _f, _f, _f, _f, _i], _i),

@@ -17,6 +17,9 @@ struct swn_ctx {
 struct swn_model {
   std::unique_ptr<Model> m;
 };
+struct swn_pipeline {
+  std::unique_ptr<Pipeline> p;
+};
 
 static thread_local std::string g_err;
 
@@ -236,6 +239,28 @@ int swn_model_perceptual(swn_model* m, const float* output, const float* target,
     m->m->perceptual(output, target, use_style, out2, content_w, style_w, d_output);
   });
 }
+int swn_pipeline_create(swn_model* warp, swn_model* texture, swn_pipeline** out) {
+  return guard([&] {
+    REQUIRE(warp && texture && out, "NULL argument");
+    auto h = std::make_unique<swn_pipeline>();
+    h->p = std::make_unique<Pipeline>(*warp->m, *texture->m);
+    *out = h.release();
+  });
+}
+int swn_pipeline_destroy(swn_pipeline* p) {
+  return guard([&] { delete p; });
+}
+int swn_pipeline_run(swn_pipeline* p, int use_graph, int* graph_replayed) {
+  return guard([&] {
+    REQUIRE(p, "NULL argument");
+    const bool had = p->p->graph_captured();
+    p->p->run(use_graph != 0);
+    if (graph_replayed) *graph_replayed = (use_graph && had) ? 1 : 0;
+  });
+}
+int swn_pipeline_labels(swn_pipeline* p, int32_t** dev_labels) {
+  return guard([&] { REQUIRE(p && dev_labels, "NULL argument"); *dev_labels = p->p->labels(); });
+}
 int swn_model_forward(swn_model* m, int training, uint64_t seed) {
   return guard([&] { REQUIRE(m, "NULL"); m->m->forward(training != 0, seed); });
 }
@@ -423,6 +448,14 @@ int swn_op_instance_norm_act_bwd(swn_ctx* ctx, const float* x, const float* dy, 
     net.backward(false, true);
     nhwc_to_nchw(tmp.s, xv.g, dx, c);
     stream_sync(tmp.s);
+  });
+}
+int swn_op_affine_gather(swn_ctx* ctx, const float* src, float* dst, int b, int c, int h, int w, const double* maps,
+                         int nmaps) {
+  return guard([&] {
+    REQUIRE(ctx && src && dst && maps, "NULL argument");
+    REQUIRE(src != dst, "affine_gather is out of place");
+    affine_gather(ctx->c->s, src, dst, b, c, h, w, maps, nmaps);
   });
 }
 int swn_op_gan_loss(swn_ctx* ctx, int gan_mode, const float* pred, int n, int c, int h, int w, float label,

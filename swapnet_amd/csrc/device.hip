@@ -58,4 +58,19 @@ void event_record(void* ev, Stream& s) { SWN_HIP_CHECK(hipEventRecord((hipEvent_
 void stream_wait_event(Stream& s, void* ev) { SWN_HIP_CHECK(hipStreamWaitEvent(hs(s), (hipEvent_t)ev, 0)); }
 int is_device_build() { return 1; }
 
+void graph_begin(Stream& s) { SWN_HIP_CHECK(hipStreamBeginCapture(hs(s), hipStreamCaptureModeThreadLocal)); }
+void* graph_end(Stream& s) {
+  hipGraph_t g = nullptr;
+  SWN_HIP_CHECK(hipStreamEndCapture(hs(s), &g));
+  hipGraphExec_t exec = nullptr;
+  const hipError_t e = hipGraphInstantiate(&exec, g, nullptr, nullptr, 0);
+  (void)hipGraphDestroy(g);
+  if (e != hipSuccess) throw Error(2, std::string("hipGraphInstantiate failed: ") + hipGetErrorString(e));
+  return (void*)exec;
+}
+void graph_launch(void* exec, Stream& s) { SWN_HIP_CHECK(hipGraphLaunch((hipGraphExec_t)exec, hs(s))); }
+void graph_destroy(void* exec) {
+  if (exec) (void)hipGraphExecDestroy((hipGraphExec_t)exec);
+}
+
 }  // namespace swn

@@ -190,6 +190,7 @@ class Model {
   virtual void set_input(int slot, const float* dev_nchw, int N, int C, int Hh, int Ww) = 0;
   virtual void set_input_labels(int slot, const int32_t* dev_labels, int N, int Hh, int Ww) = 0;
   virtual void get_output(int slot, float* dev_nchw) = 0;
+  virtual TView output_view() = 0;              // NHWC view of self.fakes (logical channels: 19 warp / 3 texture)
   virtual void forward(bool training, uint64_t seed) = 0;
   virtual void backward_D(float label_fake, float label_real) = 0;
   virtual void backward_G(float label_real) = 0;
@@ -222,6 +223,30 @@ class Model {
     return nullptr;
   }
   Net* net_for_taps(int net) { return net == 0 ? G.get() : D2.get(); }
+};
+
+// ---------------------------------------------------------------------------------------------------------------
+// inference.py's two stages (inference.py:94-126,140-149,169-180) as one device-resident sequence:
+//   warp forward -> argmax over the 19 cloth channels (what compress_and_save_cloth stores, data_utils.py:322) ->
+//   one-hot expansion straight into the texture model's cloth inputs (to_onehot_tensor, data_utils.py:330-343) ->
+//   texture forward.
+// The sequence has no host decisions in it, so it is captured once into a hipGraph and replayed: at batch size 1
+// the ~150 launches are otherwise launch-latency bound.
+// ---------------------------------------------------------------------------------------------------------------
+class Pipeline {
+ public:
+  Pipeline(Model& warp, Model& texture);
+  ~Pipeline();
+  void run(bool use_graph);
+  int32_t* labels() const { return labels_; }      // device (B, H, W): the hand-off label map of the last run
+  bool graph_captured() const { return exec_ != nullptr; }
+ private:
+  void enqueue();
+  Model& warp_;
+  Model& tex_;
+  int32_t* labels_ = nullptr;
+  void* exec_ = nullptr;
+  bool warmed_ = false;
 };
 
 Model* create_warp_model(Ctx& ctx, int B, int H, int W, bool is_train, float dropout);

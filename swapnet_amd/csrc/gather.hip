@@ -243,6 +243,41 @@ void maxpool2_bwd(Stream& s, const TView& dy, const TView& x, const TView& y, co
   check_launch("maxpool2_bwd");
 }
 
+__global__ __launch_bounds__(256) void affine_gather_kernel(const float* src, float* dst, int BC, int H, int W,
+                                                            const double* maps, int nmaps) {
+  const size_t total = (size_t)BC * H * W;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int x0 = (int)(i % W); const size_t q = i / W;
+    const int y0 = (int)(q % H); const int bc = (int)(q / H);
+    long long x = x0, y = y0;
+    bool inside = true;
+    // out = T_n(...T_1(in)): the value at p comes from in[m_1(m_2(...m_n(p)))] -- walk the chain backwards
+    for (int k = nmaps - 1; k >= 0 && inside; --k) {
+      const double* m = maps + ((size_t)bc * nmaps + k) * 9;
+      const int kind = (int)m[0];
+      long long xin = x, yin = y;
+      if (kind == 1) {
+        xin = ((long long)m[3] + (long long)m[2] * y + (long long)m[1] * x) >> 16;
+        yin = ((long long)m[6] + (long long)m[5] * y + (long long)m[4] * x) >> 16;
+      } else if (kind == 2) {
+        const double xc = (double)x + 0.5, yc = (double)y + 0.5;
+        const double den = m[7] * xc + m[8] * yc + 1.0;
+        const double fx = (m[1] * xc + m[2] * yc + m[3]) / den, fy = (m[4] * xc + m[5] * yc + m[6]) / den;
+        xin = fx < 0.0 ? -1 : (long long)(int)fx;
+        yin = fy < 0.0 ? -1 : (long long)(int)fy;
+      }
+      inside = xin >= 0 && xin < W && yin >= 0 && yin < H;
+      x = xin; y = yin;
+    }
+    dst[i] = inside ? src[((size_t)bc * H + y) * W + x] : 0.f;
+  }
+}
+void affine_gather(Stream& s, const float* src, float* dst, int B, int C, int H, int W, const double* maps, int nmaps) {
+  if (nmaps < 1) throw Error(1, "affine_gather: need at least one map per channel");
+  hipLaunchKernelGGL(affine_gather_kernel, dim3(egrid((size_t)B * C * H * W)), dim3(256), 0, hs(s), src, dst, B * C, H, W, maps, nmaps);
+  check_launch("affine_gather");
+}
+
 void nchw_to_nhwc(Stream& s, const float* src, int N, int C, int H, int W, const TView& dst) {
   if (dst.N != N || dst.H != H || dst.W != W || dst.C < C) throw Error(1, "nchw_to_nhwc: shape mismatch");
   hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(egrid((size_t)N * C * H * W)), dim3(256), 0, hs(s), src, N, C, H * W, dst.p, dst.cs);

@@ -211,6 +211,7 @@ class WarpModel final : public Model {
     if (slot != 0) throw Error(1, "get_output: unknown slot");
     nhwc_to_nchw(ctx->s, Dx.batch(0, B).v.slice(0, 20), dst, 19);
   }
+  TView output_view() override { return Dx.batch(0, B).v.slice(0, 20); }
   void forward(bool training, uint64_t seed) override {       // warp_model.py:106-107
     G->training = training; G->seed = seed;
     G->forward();

@@ -23,6 +23,15 @@ void event_destroy(void* ev);
 void event_record(void* ev, Stream& s);
 void stream_wait_event(Stream& s, void* ev);      // work enqueued on s afterwards starts after the recorded point
 
+// ---- hipGraph capture of a launch sequence (two-stage inference, pipeline.cpp) ---------------------------------
+// graph_begin puts the stream into capture mode: everything enqueued until graph_end is recorded instead of executed
+// (no allocation, synchronisation or host read-back in between).  graph_end returns an executable graph handle (NULL on
+// the host simulator, which has no graphs: callers then simply run the sequence eagerly).
+void graph_begin(Stream& s);
+void* graph_end(Stream& s);
+void graph_launch(void* exec, Stream& s);
+void graph_destroy(void* exec);
+
 // ---- memory -------------------------------------------------------------------------
 void* dev_alloc(size_t bytes);            // zero-filled
 void dev_free(void* p);
@@ -161,6 +170,19 @@ void roi_align_fwd(Stream& s, const TView& tex, int C, const float* rois, int R,
 // bit-exact debug dump of the integer part: idx[k][ph][pw][4] = yl,yh,xl,xh ; valid[k][ph][pw]
 void roi_align_indices(Stream& s, const float* rois, int K, int H, int W, int PH, int PW,
                        int32_t* idx, uint8_t* valid);
+
+// Per-channel geometric augmentation of the warp dataloader (datasets/warp_dataset.py:131-137 ->
+// datasets/data_utils.py:346-361: every one of the 19 cloth channels of every sample goes through its own random
+// PIL transform chain) as one device gather.  src / dst: (B, C, H, W) fp32 NCHW.  maps: device doubles
+// [B*C][nmaps][9] = { kind, c0..c7 }, applied to a channel in index order (map 0 first), each with PIL's NEAREST rule:
+//   kind 0 -- identity;
+//   kind 1 -- affine in Pillow's 16.16 fixed point (Geometry.c affine_fixed): c0..c5 = the six FIXed integers
+//             a0,a1,a2',a3,a4,a5' (a2', a5' already include the half-pixel terms): xin = (a2' + a1 y + a0 x) >> 16,
+//             yin = (a5' + a4 y + a3 x) >> 16 -- flips and RandomAffine, bit-identical to Image.transform(AFFINE, NEAREST);
+//   kind 2 -- perspective (Geometry.c perspective_transform): xin = floor((c0 xc + c1 yc + c2) / (c6 xc + c7 yc + 1)),
+//             xc = x + .5 (same for y with c3..c5); -1 when negative.
+// A source coordinate outside the image at ANY step yields 0 (PIL's fill), like the sequential PIL calls.
+void affine_gather(Stream& s, const float* src, float* dst, int B, int C, int H, int W, const double* maps, int nmaps);
 
 // layout conversion at the Python boundary (NCHW fp32 <-> NHWC view)
 void nchw_to_nhwc(Stream& s, const float* src, int N, int C, int H, int W, const TView& dst);

@@ -1,0 +1,44 @@
+// swapnet_amd -- two-stage inference kept on the device and replayed as a hipGraph (SURVEY.md 8(f) rank 2;
+// reference: inference.py:94-126 with the .npz hand-off of :140-149 / :169-180 replaced by an HBM label map).
+#include "engine.h"
+
+namespace swn {
+
+Pipeline::Pipeline(Model& warp, Model& texture) : warp_(warp), tex_(texture) {
+  if (warp.ctx != texture.ctx) throw Error(1, "pipeline: both models must live in the same context");
+  if (warp.B != texture.B || warp.H != texture.H || warp.W != texture.W)
+    throw Error(1, "pipeline: warp and texture models must share (B, H, W)");
+  labels_ = static_cast<int32_t*>(warp.ctx->alloc((size_t)warp.B * warp.H * warp.W * sizeof(int32_t)));
+}
+Pipeline::~Pipeline() { graph_destroy(exec_); }
+
+void Pipeline::enqueue() {
+  Stream& s = warp_.ctx->s;
+  warp_.forward(false, 0);
+  argmax_labels(s, warp_.output_view(), 19, labels_);
+  tex_.set_input_labels(2, labels_, tex_.B, tex_.H, tex_.W);
+  tex_.forward(false, 0);
+}
+
+void Pipeline::run(bool use_graph) {
+  Stream& s = warp_.ctx->s;
+  if (!use_graph) { enqueue(); return; }
+  if (!exec_) {
+    if (!warmed_) {             // first call: eager (kernel attributes, derived weight operands) -- results are this run's
+      enqueue();
+      warmed_ = true;
+      if (!is_device_build()) return;
+      stream_sync(s);
+      // capture the identical sequence; nothing in it allocates, synchronises or depends on host state
+      graph_begin(s);
+      try { enqueue(); } catch (...) { graph_end(s); throw; }
+      exec_ = graph_end(s);
+      return;
+    }
+    enqueue();                  // host simulator: no graphs
+    return;
+  }
+  graph_launch(exec_, s);
+}
+
+}  // namespace swn

@@ -254,6 +254,7 @@ class TextureModel final : public Model {
     if (slot != 0) throw Error(1, "get_output: unknown slot");
     nhwc_to_nchw(ctx->s, Dx.batch(0, B).v.slice(0, 4), dst, 3);
   }
+  TView output_view() override { return Dx.batch(0, B).v.slice(0, 4); }
   void forward(bool training, uint64_t seed) override {        // texture_model.py:121-125
     G->training = training; G->seed = seed;
     G->forward();

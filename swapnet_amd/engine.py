@@ -364,16 +364,52 @@ def op_norm_act_dropout(ctx, x, dy=None, norm=True, act=2, p=0.5, seed=0):
 
 
 class _ArrayIface:
-    def __init__(self, ptr, n, cuda):
-        d = dict(shape=(n,), typestr="<f4", data=(ptr, False), version=2 if cuda else 3)
+    def __init__(self, ptr, n, cuda, typestr="<f4"):
+        d = dict(shape=(n,), typestr=typestr, data=(ptr, False), version=2 if cuda else 3)
         if cuda:
             self.__cuda_array_interface__ = d
         else:
             self.__array_interface__ = d
 
 
-def _wrap_pointer(ptr, n, device):
+def _wrap_pointer(ptr, n, device, typestr="<f4"):
     if device.type == "cuda":
-        return torch.as_tensor(_ArrayIface(ptr, n, True), device=device)
+        return torch.as_tensor(_ArrayIface(ptr, n, True, typestr), device=device)
     import numpy as np
-    return torch.from_numpy(np.asarray(_ArrayIface(ptr, n, False)))
+    return torch.from_numpy(np.asarray(_ArrayIface(ptr, n, False, typestr)))
+
+
+class NativePipeline:
+    """swn_pipeline handle: warp forward -> argmax labels -> one-hot -> texture forward on the device, optionally
+    replayed as a hipGraph (see include/swapnet_hip.h)."""
+
+    def __init__(self, warp_model, texture_model):
+        self.warp, self.texture = warp_model, texture_model
+        self.lib, self.ctx = warp_model.lib, warp_model.ctx
+        h = C.c_void_p()
+        self.lib.call("swn_pipeline_create", warp_model.handle, texture_model.handle, C.byref(h))
+        self.handle = h
+
+    def run(self, use_graph=True):
+        """Returns True when the call was a graph replay (False: eager run, incl. the capturing first call)."""
+        replayed = C.c_int()
+        self.lib.call("swn_pipeline_run", self.handle, int(bool(use_graph)), C.byref(replayed))
+        return bool(replayed.value)
+
+    def labels(self):
+        p = C.c_void_p()
+        self.lib.call("swn_pipeline_labels", self.handle, C.byref(p))
+        n = self.warp.B * self.warp.H * self.warp.W
+        self.ctx.sync()
+        return _wrap_pointer(p.value, n, self.ctx.device, "<i4").reshape(self.warp.B, self.warp.H, self.warp.W).clone()
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.call("swn_pipeline_destroy", self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

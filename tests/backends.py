@@ -8,7 +8,7 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HOSTSIM_DIR = os.path.join(REPO, "tests", "hostsim")
 HOSTSIM_SO = os.path.join(HOSTSIM_DIR, "build", "libswapnet_hostsim.so")
 _CSRC = os.path.join(REPO, "swapnet_amd", "csrc")
-_HOST_SOURCES = [os.path.join(_CSRC, f) for f in ("engine.cpp", "nets.cpp", "texture.cpp", "capi.cpp")] + \
+_HOST_SOURCES = [os.path.join(_CSRC, f) for f in ("engine.cpp", "nets.cpp", "texture.cpp", "pipeline.cpp", "capi.cpp")] + \
     [os.path.join(HOSTSIM_DIR, "hostsim_ops.cpp")]
 
 

@@ -31,6 +31,10 @@ void event_destroy(void*) {}
 void event_record(void*, Stream&) {}
 void stream_wait_event(Stream&, void*) {}
 int is_device_build() { return 0; }
+void graph_begin(Stream&) {}
+void* graph_end(Stream&) { return nullptr; }
+void graph_launch(void*, Stream&) {}
+void graph_destroy(void*) {}
 void conv_force_naive(int) {}
 void prof_enable(int) {}
 void prof_reset() {}
@@ -471,6 +475,33 @@ void roi_align_indices(Stream&, const float* rois, int K, int H, int W, int PH, 
     const size_t i = ((size_t)k * PH + ph) * PW + pw;
     idx[i * 4] = s.yl; idx[i * 4 + 1] = s.yh; idx[i * 4 + 2] = s.xl; idx[i * 4 + 3] = s.xh; valid[i] = s.valid;
   }
+}
+
+void affine_gather(Stream&, const float* src, float* dst, int B, int C, int H, int W, const double* maps, int nmaps) {
+  for (int bc = 0; bc < B * C; ++bc)
+    for (int y0 = 0; y0 < H; ++y0)
+      for (int x0 = 0; x0 < W; ++x0) {
+        long long x = x0, y = y0;
+        bool inside = true;
+        for (int k = nmaps - 1; k >= 0 && inside; --k) {
+          const double* m = maps + ((size_t)bc * nmaps + k) * 9;
+          const int kind = (int)m[0];
+          long long xin = x, yin = y;
+          if (kind == 1) {
+            xin = ((long long)m[3] + (long long)m[2] * y + (long long)m[1] * x) >> 16;
+            yin = ((long long)m[6] + (long long)m[5] * y + (long long)m[4] * x) >> 16;
+          } else if (kind == 2) {
+            const double xc = (double)x + 0.5, yc = (double)y + 0.5;
+            const double den = m[7] * xc + m[8] * yc + 1.0;
+            const double fx = (m[1] * xc + m[2] * yc + m[3]) / den, fy = (m[4] * xc + m[5] * yc + m[6]) / den;
+            xin = fx < 0.0 ? -1 : (long long)(int)fx;
+            yin = fy < 0.0 ? -1 : (long long)(int)fy;
+          }
+          inside = xin >= 0 && xin < W && yin >= 0 && yin < H;
+          x = xin; y = yin;
+        }
+        dst[((size_t)bc * H + y0) * W + x0] = inside ? src[((size_t)bc * H + y) * W + x] : 0.f;
+      }
 }
 
 void nchw_to_nhwc(Stream&, const float* src, int N, int C, int H, int W, const TView& dst) {

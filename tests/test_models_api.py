@@ -226,6 +226,18 @@ def test_two_stage_device_pipeline_equals_reference_two_pass_inference(backend):
     assert float((out.cpu() - ref_dev).norm() / ref_dev.norm()) < 1e-3
     if agree == 1.0:
         assert torch.equal(ref_dev, ref)
+    # second and third call with OTHER inputs: on the GPU these replay the hipGraph captured by the first call --
+    # the replay must read the newly staged inputs and reproduce the eager result bit for bit
+    bodys2, inputs2, _ = O.synth_warp_batch(1, 64, 64, seed=19)
+    tex2, rois2, _, _ = O.synth_texture_batch(1, 64, 64, seed=20)
+    out2, lab2 = pipe(bodys2, inputs2, tex2, rois2, return_labels=True)
+    assert pipe.last_call_was_graph_replay == (backend == "gpu")
+    eager = TwoStagePipeline(Gw, Gt, img_size=64, ctx=ctx, use_graph=False)
+    out2e, lab2e = eager(bodys2, inputs2, tex2, rois2, return_labels=True)
+    assert not eager.last_call_was_graph_replay
+    assert torch.equal(lab2.cpu(), lab2e.cpu()) and torch.equal(out2.cpu(), out2e.cpu())
+    out3 = pipe(bodys, inputs, tex, rois)
+    assert torch.equal(out3.cpu(), out.cpu())
 
 
 @pytest.mark.parametrize("stage", ["warp", "texture"])
