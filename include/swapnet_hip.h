@@ -111,6 +111,9 @@ int swn_model_get_output(swn_model* m, int slot, float* dev_nchw);
 /* named intermediate activation (debug / per-level parity tests), copied out as NCHW */
 int swn_model_get_tap(swn_model* m, int net, const char* name, float* dev_nchw, int shape[4]);
 
+/* gradient w.r.t. a named activation as left by the last backward pass through `net` (diagnostics) */
+int swn_model_get_tap_grad(swn_model* m, int net, const char* name, float* dev_nchw, int shape[4]);
+
 /* nn.Dropout sites of the generator in forward order (WarpModule: body_down4, cloth_down5, cloth_down6 and the
  * four ResidualBlocks, modules/swapnet_modules.py:37,46-47,58 / modules/layers.py:22-23,136; pix2pix U-Net:
  * the three inner ngf*8 blocks, modules/pix2pix_modules.py:251-252).  swn_model_dropout_mask writes the factor

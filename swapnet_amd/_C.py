@@ -53,6 +53,7 @@ _PROTOS = {
     "swn_model_set_input_labels": ([_vp, _i, _vp, _i, _i, _i], _i),
     "swn_model_get_output": ([_vp, _i, _fp], _i),
     "swn_model_get_tap": ([_vp, _i, C.c_char_p, _fp, C.POINTER(_i * 4)], _i),
+    "swn_model_get_tap_grad": ([_vp, _i, C.c_char_p, _fp, C.POINTER(_i * 4)], _i),
     "swn_model_dropout_sites": ([_vp, _i, C.POINTER(_i)], _i),
     "swn_model_dropout_mask": ([_vp, _i, _i, C.c_uint64, _fp, C.POINTER(_i * 4), C.POINTER(_f)], _i),
     "swn_pipeline_create": ([_vp, _vp, C.POINTER(_vp)], _i),

@@ -197,6 +197,19 @@ int swn_model_set_input_labels(swn_model* m, int slot, const int32_t* lab, int n
 int swn_model_get_output(swn_model* m, int slot, float* dst) {
   return guard([&] { REQUIRE(m && dst, "NULL argument"); m->m->get_output(slot, dst); });
 }
+int swn_model_get_tap_grad(swn_model* m, int net, const char* name, float* dst, int shape[4]) {
+  return guard([&] {
+    REQUIRE(m && name, "NULL argument");
+    Net* n = m->m->net_for_taps(net);
+    REQUIRE(n, "no such network");
+    auto it = n->taps.find(name);
+    if (it == n->taps.end()) throw Error(1, std::string("unknown tap ") + name);
+    REQUIRE(it->second.has_grad, "tap carries no gradient");
+    const TView& v = it->second.g;
+    if (shape) { shape[0] = v.N; shape[1] = v.C; shape[2] = v.H; shape[3] = v.W; }
+    if (dst) nhwc_to_nchw(m->m->ctx->s, v, dst, v.C);
+  });
+}
 int swn_model_get_tap(swn_model* m, int net, const char* name, float* dst, int shape[4]) {
   return guard([&] {
     REQUIRE(m && name, "NULL argument");

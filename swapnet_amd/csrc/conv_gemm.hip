@@ -1793,16 +1793,17 @@ static DmaSched plan_dma(int tiles_total, int tiles_per_z, int work, int slots, 
   int rem = tiles_total - rounds * slots;
   sc.full = rounds * slots; sc.tail_tiles = rem; sc.tail_s = 1; sc.per_split = work;
   if (rem == 0) return sc;
-  // the first full round absorbs a small remainder better than a split does (fixed cost per tile ~ 4 stages)
+  // cost in units of one stage-time of a resident workgroup (32 MFMAs per wave ~ 0.9 us): tail rounds x (stages per
+  // unit + ~4 of prologue / epilogue) + the slab round trip of the split tiles at ~5 TB/s + the reduce launch
   int best = 1;
   double best_cost = 1e300;
-  const int max_s = std::max(1, std::min(64, work / 8));
+  const int max_s = std::max(1, std::min(1024, work / 8));
   for (int sp = 1; sp <= max_s; ++sp) {
     if (sp > 1 && (size_t)rem * sp * tile_bytes > ws_bytes) break;
     const int per = ceil_div(work, sp), eff = ceil_div(work, per);
     const double tail_rounds = std::ceil((double)rem * eff / slots);
     double cost = tail_rounds * (per + 4.0);
-    if (eff > 1) cost += 0.03 * eff * work * ((double)rem / slots) / std::max(work / 16, 1) + 1.5;   // slab write + reduce
+    if (eff > 1) cost += (double)rem * eff * (double)tile_bytes * 2.0 / 4.5e6 + 2.0;
     if (cost < best_cost * 0.97) { best_cost = cost; best = eff; }
   }
   sc.tail_s = best;
@@ -2005,7 +2006,11 @@ static bool wgrad_dma_ok(const ConvWgradArgs& a, const GemmP& p) {
   if (!dma_on() || a.Npad <= 32 || a.dy.C % 4 || a.x.C % 4) return false;
   const bool geom = (p.Wo % 16 == 0) || (16 % p.Wo == 0 && (p.Ho * p.Wo) % 16 == 0);
   const size_t xbytes = (size_t)a.x.N * a.x.H * a.x.W * a.x.cs * 4, ybytes = (size_t)a.dy.N * a.dy.H * a.dy.W * a.dy.cs * 4;
-  return geom && p.M % 16 == 0 && xbytes < ((size_t)1 << 31) && ybytes < ((size_t)1 << 31);
+  // the k-tile is 128 rows (N > 64) or 256 rows (N <= 64): shapes that would leave a quarter or more of the tile rows
+  // empty (the K = 64 / 320 / 384 first-layer weight gradients) stay on the 128-row register-staged kernel
+  const int bmk = a.Npad > 64 ? 128 : 256;
+  const bool fill = (double)p.K / (double)(ceil_div(p.K, bmk) * bmk) > 0.8;
+  return geom && fill && p.M % 16 == 0 && xbytes < ((size_t)1 << 31) && ybytes < ((size_t)1 << 31);
 }
 
 void conv_wgrad(Stream& s, const ConvWgradArgs& a) {

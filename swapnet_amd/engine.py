@@ -279,6 +279,15 @@ class NativeModel:
         self.ctx.sync()
         return t
 
+    def tap_grad(self, net, name):
+        """Gradient w.r.t. a named activation after the last backward pass (diagnostics)."""
+        shape = (C.c_int * 4)()
+        self.lib.call("swn_model_get_tap_grad", self.handle, net, name.encode(), None, C.byref(shape))
+        t = torch.empty(tuple(shape), dtype=torch.float32, device=self.ctx.device)
+        self.lib.call("swn_model_get_tap_grad", self.handle, net, name.encode(), _C.ptr(t), C.byref(shape))
+        self.ctx.sync()
+        return t
+
     def backward_D(self, label_fake, label_real):
         self.lib.call("swn_model_backward_D", self.handle, C.c_float(label_fake), C.c_float(label_real))
 

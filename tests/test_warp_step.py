@@ -215,7 +215,7 @@ def test_warp_full_size_properties():
     b = m.output().cpu()
     # (not bitwise: the tile a sample falls into decides whether its K reduction runs whole or as the split tail
     # of the launch -- a different, still fixed, summation order)
-    assert float((a[perm] - b).abs().max()) < 2e-5 and rel(b, a[perm]) < 1e-6
+    assert float((a[perm] - b).abs().max()) < 1e-4 and rel(b, a[perm]) < 2e-6
     # (3) dropout
     m.forward(True, 5); d1 = m.output().cpu()
     m.forward(True, 5); d2 = m.output().cpu()
