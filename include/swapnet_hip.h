@@ -30,7 +30,7 @@ extern "C" {
 typedef struct swn_ctx swn_ctx;
 typedef struct swn_model swn_model;
 
-int swn_abi_version(void);   /* 2: swn_hyper gained d_b1, d_b2 */
+int swn_abi_version(void);   /* 2: swn_hyper gained d_b1, d_b2; 3: gp_mode, lambda_gp */
 const char* swn_last_error(void);
 /* 1 when this library executes on a HIP device (libswapnet_hip.so), 0 for the CI simulator */
 int swn_is_device_build(void);
@@ -83,6 +83,9 @@ typedef struct swn_hyper {
                         RCCL all-reduce(SUM) of the arenas yields the mean without an extra pass */
   float d_b1, d_b2;  /* AdamW betas of optimizer_D (0 = same as b1 / b2): the two torch optimizers of the
                         reference are independent objects (models/base_gan.py:87-120) */
+  int gp_mode;       /* gradient penalty of --gan_mode (modules/loss.py:133-184): 0 none, 1 wgan-gp (with gan_mode 2),
+                        2 dragan-gp, 3 dragan-lp (with gan_mode 0); warp model only */
+  float lambda_gp;   /* --lambda_gp (models/base_gan.py:54-58) */
 } swn_hyper;
 int swn_model_set_hyper(swn_model* m, const swn_hyper* h);
 
@@ -136,6 +139,10 @@ int swn_pipeline_destroy(swn_pipeline* p);
 int swn_pipeline_run(swn_pipeline* p, int use_graph, int* graph_replayed);
 int swn_pipeline_labels(swn_pipeline* p, int32_t** dev_labels);   /* (B,H,W) int32 of the last run, library-owned */
 
+/* The random draws of the next gradient-penalty pass (modules/loss.py:141-147): alpha = torch.rand(B,1,1,1) as B
+ * device floats; beta = torch.rand_like(conditioned_real) as (B, 22, H, W) in the reference's channel order (dragan
+ * modes only).  Either may be NULL (the library then draws it from its own counter RNG).  One-shot. */
+int swn_model_set_gp_random(swn_model* m, const float* alpha_dev, const float* beta_nchw_dev);
 /* NLayerDiscriminator.forward(input) (modules/discriminators.py:134-136) as a standalone call on the model's
  * discriminator weights: x = conditioned input in the reference's channel order, (B, 22, H, W); pred receives
  * (B, 1, H/8-2, W/8-2).  Uses a private activation set: self.fakes and the staged batch stay untouched. */
@@ -166,7 +173,7 @@ int swn_model_optimizer_step(swn_model* m, int net);
 /* BaseGAN.optimize_parameters (models/base_gan.py:194-203; warp_model.py:169-183) in one call */
 int swn_model_step(swn_model* m, const float labels[3], int training, uint64_t dropout_seed);
 /* BaseModel.get_current_losses (models/base_model.py:139-147): host array of 9 floats
- * D, D_real, D_fake, G, G_gan, G_ce, G_l1, G_content, G_style  (one small D2H + sync) */
+ * D, D_real, D_fake, G, G_gan, G_ce, G_l1, G_content, G_style, D_gp  (one small D2H + sync; n <= 10) */
 int swn_model_get_losses(swn_model* m, float* host_out, int n);
 
 /* data-parallel hook: flat gradient arena of a net (device pointer, float count) so the host
@@ -219,6 +226,10 @@ int swn_op_gan_loss(swn_ctx* ctx, int gan_mode, const float* pred, int n, int c,
  * input gradient computed with the same mask.  NCHW fp32, C % 4 == 0. */
 int swn_op_norm_act_dropout(swn_ctx* ctx, const float* x, const float* dy, int n, int c, int h, int w, int norm, int act,
                             float p, uint64_t seed, float* y, float* mask, float* dx);
+/* second-order step through y = act(InstanceNorm(x)) (gradient-penalty pass, csrc/gp.cpp): with gx = d<y,gy>/dx the first
+ * backward, returns uy = d<gx,u>/d gy and ax = d<gx,u>/d x.  NCHW fp32, C % 4 == 0. */
+int swn_op_norm_act_bwd2(swn_ctx* ctx, const float* x, const float* gy, const float* u, int n, int c, int h, int w, int act,
+                         float* uy, float* ax);
 /* torch.optim.AdamW single step on flat arrays (optimizers/__init__.py:52-59) */
 int swn_op_adamw(swn_ctx* ctx, float* p, const float* g, float* m, float* v, size_t n, float lr, float b1, float b2,
                  float eps, float wd, int step);

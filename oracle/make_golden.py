@@ -177,7 +177,11 @@ def golden_warp_modes(path, H=64, B=2, init_seed=0, step_seed=100):
     bodys, inputs, targets = synth_warp_batch(B, H, H, seed=1234)
     for mode, opts in (("lsgan", dict(gan_mode="lsgan", warp_mode="gan")),
                        ("wgan", dict(gan_mode="wgan", warp_mode="gan")),
-                       ("ce", dict(gan_mode="vanilla", warp_mode="ce"))):
+                       ("ce", dict(gan_mode="vanilla", warp_mode="ce")),
+                       # gradient-penalty objectives (modules/loss.py:133-184: double backward through D)
+                       ("wgan-gp", dict(gan_mode="wgan-gp", warp_mode="gan")),
+                       ("dragan-gp", dict(gan_mode="dragan-gp", warp_mode="gan")),
+                       ("dragan-lp", dict(gan_mode="dragan-lp", warp_mode="gan"))):
         with tempfile.TemporaryDirectory() as tmp:
             opt = base_opt(tmp, lambda_ce=100.0, model="warp", **opts)
             torch.manual_seed(init_seed)
@@ -195,7 +199,11 @@ def golden_warp_modes(path, H=64, B=2, init_seed=0, step_seed=100):
             for k in ("upsample_and_pad.2.weight", "resblocks.3.conv_block.6.weight", "body_down1.model.0.weight"):
                 summarize(out, pre + "postG/" + k, sd[k])
             if hasattr(model, "net_discriminator"):
-                summarize(out, pre + "postD/model.0.weight", model.net_discriminator.state_dict()["model.0.weight"])
+                dsd = model.net_discriminator.state_dict()
+                summarize(out, pre + "postD/model.0.weight", dsd["model.0.weight"])
+                if "p" in mode[-2:]:
+                    for k in ("model.5.weight", "model.8.weight", "model.11.weight"):
+                        summarize(out, pre + "postD/" + k, dsd[k])
     out["meta/init_seed"] = np.int64(init_seed); out["meta/step_seed"] = np.int64(step_seed)
     out["meta/B"] = np.int64(B); out["meta/H"] = np.int64(H)
     np.savez_compressed(path, **out)

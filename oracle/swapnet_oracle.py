@@ -472,6 +472,29 @@ def gan_loss(pred, label, gan_mode="vanilla", target_is_real=True):
     raise ValueError(f"{gan_mode} not recognized")
 
 
+def gradient_penalty(f, real, fake, mode, p_norm=2, alpha=None, beta=None):
+    """modules/loss.py:133-184.  wgan-gp / wgan-lp: penalty on the interpolate between real and fake; dragan[-gp|-lp]:
+    on real perturbed by 0.5*std(real)*U[0,1).  Random draws in the reference's order (beta = rand_like(real) first,
+    only for dragan; then alpha = rand(B,1,1,1)) from the global RNG unless given explicitly.  Returns (gp, alpha, beta)."""
+    if mode in ("dragan", "dragan-gp", "dragan-lp"):
+        penalty = "gp" if mode == "dragan" else mode[-2:]
+        if beta is None:
+            beta = torch.rand_like(real)
+        b = real + 0.5 * real.std() * beta.to(real.dtype)
+    elif mode in ("wgan-gp", "wgan-lp"):
+        penalty, b = mode[-2:], fake
+    else:
+        raise ValueError("Don't know how to handle gan mode", mode)
+    if alpha is None:
+        alpha = torch.rand([real.size(0)] + [1] * (real.dim() - 1))
+    x = (real + alpha.to(real.dtype) * (b - real)).detach().requires_grad_(True)
+    pred = f(x)
+    grad = torch.autograd.grad(pred, x, grad_outputs=torch.ones_like(pred), create_graph=True)[0]
+    norm = grad.view(grad.size(0), -1).norm(p=p_norm, dim=1)
+    gp = ((norm - 1) ** 2).mean() if penalty == "gp" else (torch.max(torch.zeros_like(norm), norm - 1) ** 2).mean()
+    return gp, alpha, beta
+
+
 def gram_matrix(t):
     """modules/losses/perceptual.py:6-10."""
     b, c, h, w = t.size()
@@ -558,7 +581,7 @@ class AdamWState:
 DEFAULT_HYPER = dict(
     lr=1e-4, d_lr=4e-4, weight_decay=0.0, d_weight_decay=0.01, b1=0.9, b2=0.999,
     lambda_gan=1.0, lambda_ce=100.0, lambda_l1=10.0, lambda_content=20.0,
-    lambda_style=1e-8, gan_mode="vanilla",
+    lambda_style=1e-8, gan_mode="vanilla", lambda_gp=10.0,
 )
 
 
@@ -613,6 +636,8 @@ class WarpStepOracle:
         G, D = _leaf(self.G), _leaf(self.D)
         fakes = warp_module_forward(G, bodys, inputs, training=self.training)         # :106-107
         draw = (lambda i: smooth_label().to(self.dtype)) if labels is None else (lambda i: torch.tensor([labels[i]], dtype=self.dtype))
+        if "wgan" in h["gan_mode"] and labels is None:      # GANLoss.__call__ draws no target in the wgan modes (loss.py:124-128)
+            draw = lambda i: torch.zeros(1, dtype=self.dtype)
         if h.get("warp_mode", "gan") == "ce":
             # --warp_mode ce (warp_model.py:169-183): generator only, loss = lambda_ce * CE
             loss_G = F.cross_entropy(fakes, torch.argmax(targets, dim=1)) * h["lambda_ce"]
@@ -632,6 +657,13 @@ class WarpStepOracle:
         l_real = draw(1)
         loss_D_real = gan_loss(pred_real, l_real, h["gan_mode"], True)
         loss_D = 0.5 * (loss_D_fake + loss_D_real)          # lambda_discriminator ignored (:123)
+        loss_D_gp = None
+        if any(m in h["gan_mode"] for m in ("gp", "lp")):      # warp_model.py:126-136
+            gp, self.gp_alpha, self.gp_beta = gradient_penalty(
+                lambda x: patchgan_forward(D, x), torch.cat((bodys, targets), 1), cond_fake, h["gan_mode"],
+                alpha=getattr(self, "gp_alpha_in", None), beta=getattr(self, "gp_beta_in", None))
+            loss_D_gp = gp * h["lambda_gp"]
+            loss_D = loss_D + loss_D_gp
         gD = torch.autograd.grad(loss_D, list(D.values()))
         self.grads_D = OrderedDict(zip(D.keys(), gD))
         self.optD.apply(self.D, self.grads_D)                                          # base_gan.py:199
@@ -649,6 +681,8 @@ class WarpStepOracle:
         self.labels = [float(l_fake), float(l_real), float(l_g)]
         self.losses = OrderedDict(D=float(loss_D.detach()), D_real=float(loss_D_real.detach()), D_fake=float(loss_D_fake.detach()),
                                   G=float(loss_G.detach()), G_gan=float(loss_G_gan.detach()), G_ce=float(loss_ce.detach()))
+        if loss_D_gp is not None:
+            self.losses["D_gp"] = float(loss_D_gp.detach())
         return self.losses
 
 

@@ -12,14 +12,15 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libswapnet_hip.so")
 
-LOSS_NAMES = ("D", "D_real", "D_fake", "G", "G_gan", "G_ce", "G_l1", "G_content", "G_style")
+LOSS_NAMES = ("D", "D_real", "D_fake", "G", "G_gan", "G_ce", "G_l1", "G_content", "G_style", "D_gp")
 
 
 class SwnHyper(C.Structure):
     _fields_ = [(n, C.c_float) for n in ("lr", "d_lr", "weight_decay", "d_weight_decay", "b1", "b2",
                                          "lambda_gan", "lambda_ce", "lambda_l1", "lambda_content",
                                          "lambda_style")] + [("gan_mode", C.c_int), ("warp_mode_ce", C.c_int), ("grad_scale", C.c_float),
-                                                                           ("d_b1", C.c_float), ("d_b2", C.c_float)]
+                                                                           ("d_b1", C.c_float), ("d_b2", C.c_float),
+                                                                           ("gp_mode", C.c_int), ("lambda_gp", C.c_float)]
 
 
 class SwapnetHipError(RuntimeError):
@@ -60,6 +61,7 @@ _PROTOS = {
     "swn_pipeline_destroy": ([_vp], _i),
     "swn_pipeline_run": ([_vp, _i, C.POINTER(_i)], _i),
     "swn_pipeline_labels": ([_vp, C.POINTER(_vp)], _i),
+    "swn_model_set_gp_random": ([_vp, _fp, _fp], _i),
     "swn_model_discriminate": ([_vp, _fp, _fp], _i),
     "swn_model_perceptual": ([_vp, _fp, _fp, _i, _fp, _f, _f, _fp], _i),
     "swn_model_forward": ([_vp, _i, C.c_uint64], _i),
@@ -83,6 +85,7 @@ _PROTOS = {
     "swn_op_instance_norm_act_bwd": ([_vp, _fp, _fp, _i, _i, _i, _i, _i, _fp], _i),
     "swn_op_affine_gather": ([_vp, _fp, _fp, _i, _i, _i, _i, _vp, _i], _i),
     "swn_op_gan_loss": ([_vp, _i, _fp, _i, _i, _i, _i, _f, _i, _f, _fp, _fp], _i),
+    "swn_op_norm_act_bwd2": ([_vp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _fp, _fp], _i),
     "swn_op_norm_act_dropout": ([_vp, _fp, _fp, _i, _i, _i, _i, _i, _i, _f, C.c_uint64, _fp, _fp, _fp], _i),
     "swn_op_adamw": ([_vp, _fp, _fp, _fp, _fp, C.c_size_t, _f, _f, _f, _f, _f, _i], _i),
 }

@@ -8,7 +8,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(CSRC, "libswapnet_hip.so")
 HIP_SOURCES = ["device.hip", "conv_gemm.hip", "wino.hip", "norm_act.hip", "losses.hip", "optim.hip", "gather.hip"]
-CPP_SOURCES = ["engine.cpp", "nets.cpp", "texture.cpp", "pipeline.cpp", "capi.cpp"]
+CPP_SOURCES = ["engine.cpp", "nets.cpp", "texture.cpp", "pipeline.cpp", "gp.cpp", "capi.cpp"]
 HEADERS = ["common.h", "ops.h", "hip_util.h", "engine.h", os.path.join("..", "..", "include", "swapnet_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off"]
 

@@ -44,7 +44,7 @@ static int guard(F f) {
 
 extern "C" {
 
-int swn_abi_version(void) { return 2; }
+int swn_abi_version(void) { return 3; }
 const char* swn_last_error(void) { return g_err.c_str(); }
 int swn_is_device_build(void) { return is_device_build(); }
 
@@ -122,6 +122,10 @@ int swn_model_set_hyper(swn_model* m, const swn_hyper* h) {
     y.gan_mode = h->gan_mode; y.warp_mode_ce_only = h->warp_mode_ce;
     y.grad_scale = h->grad_scale > 0.f ? h->grad_scale : 1.f;
     y.d_b1 = h->d_b1 > 0.f ? h->d_b1 : h->b1; y.d_b2 = h->d_b2 > 0.f ? h->d_b2 : h->b2;
+    REQUIRE(h->gp_mode >= 0 && h->gp_mode <= 3, "gradient penalty mode not implemented");
+    REQUIRE(h->gp_mode == 0 || m->m->supports_gradient_penalty(),
+            "gradient penalty modes are not implemented for the texture model (the reference's call fails there too)");
+    y.gp_mode = h->gp_mode; y.lambda_gp = h->lambda_gp;
   });
 }
 
@@ -241,6 +245,9 @@ int swn_model_dropout_mask(swn_model* m, int net, int site, uint64_t seed, float
     if (p) *p = d.p;
     if (dst) dropout_mask(m->m->ctx->s, d.N, d.H, d.W, d.C, d.p, Net::drop_seed(seed, d.salt), dst);
   });
+}
+int swn_model_set_gp_random(swn_model* m, const float* alpha, const float* beta) {
+  return guard([&] { REQUIRE(m, "NULL argument"); m->m->set_gp_random(alpha, beta); });
 }
 int swn_model_discriminate(swn_model* m, const float* x, float* pred) {
   return guard([&] { REQUIRE(m && x && pred, "NULL argument"); m->m->discriminate(x, pred); });
@@ -488,6 +495,28 @@ int swn_op_gan_loss(swn_ctx* ctx, int gan_mode, const float* pred, int n, int c,
     else wgan_loss(tmp.s, pv.v, target_is_real ? -1.f : 1.f, grad_scale, lo, dp);
     dev_copy(tmp.s, loss_out, lo, sizeof(float));
     if (dpred) nhwc_to_nchw(tmp.s, pv.g, dpred, 1);
+    stream_sync(tmp.s);
+  });
+}
+int swn_op_norm_act_bwd2(swn_ctx* ctx, const float* x, const float* gy, const float* u, int n, int c, int h, int w, int act,
+                         float* uy, float* ax) {
+  return guard([&] {
+    REQUIRE(ctx && x && gy && u && uy && ax && c % 4 == 0, "bad argument (C must be a multiple of 4)");
+    Ctx tmp(ctx->c->s);
+    ParamArena A; Net net(tmp, A);
+    Var xv = net.alloc_var(n, h, w, c, true), yv = net.alloc_var(n, h, w, c, true), uv = net.alloc_var(n, h, w, c, true);
+    net.norm_act(xv, yv, true, act, 0.f);
+    net.finalize({});
+    nchw_to_nhwc(tmp.s, x, n, c, h, w, xv.v);
+    nchw_to_nhwc(tmp.s, gy, n, c, h, w, yv.g);
+    nchw_to_nhwc(tmp.s, u, n, c, h, w, uv.v);
+    net.forward();                                  // InstanceNorm statistics of x
+    // the statistics live with the op: fetch them through a second-order call on the same buffers
+    NormActBwd2Args b2;
+    b2.u = uv.v; b2.gy = yv.g; b2.x = xv.v; b2.stats = net.last_stats; b2.uy = uv.g; b2.ax = xv.g; b2.act = act;
+    norm_act_bwd2(tmp.s, b2);
+    nhwc_to_nchw(tmp.s, uv.g, uy, c);
+    nhwc_to_nchw(tmp.s, xv.g, ax, c);
     stream_sync(tmp.s);
   });
 }

@@ -58,6 +58,11 @@ void event_record(void* ev, Stream& s) { SWN_HIP_CHECK(hipEventRecord((hipEvent_
 void stream_wait_event(Stream& s, void* ev) { SWN_HIP_CHECK(hipStreamWaitEvent(hs(s), (hipEvent_t)ev, 0)); }
 int is_device_build() { return 1; }
 
+void* stream_create_current() {
+  hipStream_t st;
+  SWN_HIP_CHECK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+  return (void*)st;
+}
 void graph_begin(Stream& s) { SWN_HIP_CHECK(hipStreamBeginCapture(hs(s), hipStreamCaptureModeThreadLocal)); }
 void* graph_end(Stream& s) {
   hipGraph_t g = nullptr;

@@ -491,6 +491,7 @@ void Net::norm_act(const Var& raw, const Var& y, bool norm, int actf, float drop
   auto op = std::make_unique<Op>();
   op->label = "norm_act";
   float* stats = norm ? static_cast<float*>(ctx.alloc((size_t)raw.v.N * raw.v.C * 2 * sizeof(float))) : nullptr;
+  last_stats = stats;
   const uint64_t salt = ops.size() + 1;
   if (drop_p > 0.f) drop_sites.push_back({salt, raw.v.N, raw.v.H, raw.v.W, raw.v.C, drop_p});
   const TView rv = raw.v, rg = raw.g, yv = y.v, yg = y.g;
@@ -740,6 +741,37 @@ void Model::discriminate(const float* x_nchw, float* pred_nchw) {
   D3_->refresh_dgrad();
   D3_->forward();
   nhwc_to_nchw(ctx->s, d3_pred_.v, pred_nchw, 1);
+}
+void Model::set_gp_random(const float* alpha_dev, const float* beta_nchw_dev) {
+  if (!is_train || d_cimap_.empty()) throw Error(1, "set_gp_random: the model has no discriminator");
+  if (!gp_) gp_ = std::make_unique<GradPenalty>(*ctx, arenaD, B, H, W);
+  if (alpha_dev) { dev_copy(ctx->s, gp_->alpha_buffer(), alpha_dev, (size_t)B * sizeof(float)); gp_alpha_set_ = true; }
+  if (beta_nchw_dev) {                       // reference channel order (B, 22, H, W) -> buffer order, pads stay 0
+    const int nb = (int)d_cimap_.size();
+    const size_t plane = (size_t)H * W;
+    int nref = 0;
+    for (int v : d_cimap_) nref += v >= 0;
+    const TView bv = gp_->beta_buffer();
+    for (int b0 = 0; b0 < nb;) {
+      if (d_cimap_[b0] < 0) { ++b0; continue; }
+      int len = 1;
+      while (b0 + len < nb && d_cimap_[b0 + len] == d_cimap_[b0] + len) ++len;
+      for (int n = 0; n < B; ++n) {
+        TView dst = bv; dst.p = bv.p + (size_t)n * plane * bv.cs; dst.N = 1;
+        nchw_to_nhwc(ctx->s, beta_nchw_dev + ((size_t)n * nref + d_cimap_[b0]) * plane, 1, len, H, W, dst.slice(b0, len));
+      }
+      b0 += len;
+    }
+    gp_beta_set_ = true;
+  }
+}
+void Model::run_gradient_penalty(const TView& real, const TView& fake) {
+  if (!gp_) gp_ = std::make_unique<GradPenalty>(*ctx, arenaD, B, H, W);
+  const TView beta = gp_->beta_buffer();
+  gp_->run(real, fake, hyper.gp_mode, hyper.grad_scale, hyper.lambda_gp, gp_alpha_set_ ? gp_->alpha_buffer() : nullptr,
+           gp_beta_set_ ? &beta : nullptr, (uint64_t)arenaD.step * 7919ull + 13ull, losses + L_D_GP);
+  gp_alpha_set_ = gp_beta_set_ = false;
+  scalar_axpby(ctx->s, losses + L_D, 1.f, losses + L_D_GP, 1.f, losses + L_D);     // loss_D += loss_D_gp (warp_model.py:136)
 }
 void Model::perceptual(const float*, const float*, int, float*, float, float, float*) {
   throw Error(1, "perceptual: only the texture model carries the VGG16 network (not implemented for this model)");

@@ -117,6 +117,7 @@ class Net {
   float* wgrad_planes(const Stream& sw) const { return (&sw == &ctx.side && wsM2) ? wsM2 : wsM; }
   std::vector<std::pair<Op*, size_t>> dg_layout;
   // dropout sites in forward order (one per norm_act with drop_p > 0): what swn_model_dropout_mask exports
+  float* last_stats = nullptr;        // (mean, rstd) buffer of the most recently built norm_act op (op-level entry points)
   struct DropSite { uint64_t salt; int N, H, W, C; float p; };
   std::vector<DropSite> drop_sites;
   static uint64_t drop_seed(uint64_t seed, uint64_t salt) { return seed * 0x9E3779B1ull + salt; }
@@ -162,6 +163,43 @@ void build_texture_generator(Net& net, const Var& tex, const float* rois_dev, in
                              const Var& unet_in, const Var& out, int img_size);
 std::vector<Var> build_vgg16_slices(Net& net, const Var& img);
 
+// ---- gradient penalty (gp.cpp): second-order pass through PatchGAN for --gan_mode wgan-gp / dragan-gp / dragan-lp ----
+class GradPenalty {
+ public:
+  GradPenalty(Ctx& c, ParamArena& arenaD, int B, int H, int W);
+  ~GradPenalty();
+  // real / fake: the conditioned (B, H, W, 24) halves of the discriminator's input buffer.  gp_mode 1 wgan-gp,
+  // 2 dragan-gp, 3 dragan-lp.  Adds grad_scale * lambda_gp * d gp / d theta to the discriminator's gradient arena and
+  // writes lambda_gp * gp to loss_gp_out (device).  alpha (B floats) / beta ((B,H,W,24) view) NULL = library RNG.
+  void run(const TView& real, const TView& fake, int gp_mode, float grad_scale, float lambda_gp, const float* alpha,
+           const TView* beta, uint64_t seed, float* loss_gp_out);
+  TView beta_buffer() const { return beta_; }
+  float* alpha_buffer() const { return alpha_; }
+ private:
+  struct Layer {
+    WShape ws{};
+    size_t woff = 0, boff = (size_t)-1;
+    int kind = 0;                  // 0: k4 s2 p1, 1: k4 s1 p1
+    int Cin = 0, Co = 0, Cop = 0;  // input buffer channels, logical / padded output channels
+    bool norm = false;
+    float* stats = nullptr;
+    float* dg = nullptr;           // input-gradient operand (repack_dgrad), refreshed every run
+    Var raw, h;                    // conv output (l = 1..3) and activation; .g = first-backward gradients
+    TView u_raw, u_h, a_raw, a_h, tmp, gr0;
+  };
+  void conv(int l, const TView& x, const TView& y, bool bias, int act);
+  void dgrad(int l, const TView& dy, const TView& dx);
+  void wgrad(int l, const TView& x, const TView& dy, float* arena);
+  Ctx& ctx_;
+  ParamArena& A_;
+  int B_;
+  std::unique_ptr<Net> net_;
+  std::vector<Layer> L_;
+  Var xh_;
+  TView u0_, beta_;
+  float *gA_ = nullptr, *gB_ = nullptr, *alpha_ = nullptr, *half_std_ = nullptr, *tmp_loss_ = nullptr;
+};
+
 // ---- trainers: the fused optimize_parameters() of models/{warp,texture}_model.py -----
 struct Hyper {
   float lr = 1e-4f, d_lr = 4e-4f, weight_decay = 0.f, d_weight_decay = 0.01f, b1 = 0.9f, b2 = 0.999f;
@@ -170,10 +208,12 @@ struct Hyper {
   int warp_mode_ce_only = 0; // --warp_mode ce
   float grad_scale = 1.f;    // multiplies every loss gradient (1/world_size under data parallelism)
   float d_b1 = 0.9f, d_b2 = 0.999f;   // optimizer_D's betas
+  int gp_mode = 0;           // 0 none, 1 wgan-gp, 2 dragan-gp, 3 dragan-lp (modules/loss.py:133-184)
+  float lambda_gp = 10.f;
 };
 
 enum LossSlot {
-  L_D = 0, L_D_REAL, L_D_FAKE, L_G, L_G_GAN, L_G_CE, L_G_L1, L_G_CONTENT, L_G_STYLE, L_TMP0, L_TMP1, L_TMP2, L_TMP3,
+  L_D = 0, L_D_REAL, L_D_FAKE, L_G, L_G_GAN, L_G_CE, L_G_L1, L_G_CONTENT, L_G_STYLE, L_D_GP, L_TMP0, L_TMP1, L_TMP2, L_TMP3,
   L_TMP4, L_TMP5, L_COUNT = 32
 };
 
@@ -211,7 +251,14 @@ class Model {
   // device floats at `out2`; d_output (optional, NCHW) receives content_w * d(content) + style_w * d(style).
   virtual void perceptual(const float* output_nchw, const float* target_nchw, int use_style, float* out2,
                           float content_w, float style_w, float* d_output_nchw);
+ public:
+  // one-shot random inputs of the next gradient-penalty pass (host-provided for seeded parity; see capi)
+  void set_gp_random(const float* alpha_dev, const float* beta_nchw_dev);
+  virtual bool supports_gradient_penalty() const { return false; }
  protected:
+  std::unique_ptr<GradPenalty> gp_;
+  bool gp_alpha_set_ = false, gp_beta_set_ = false;
+  void run_gradient_penalty(const TView& real, const TView& fake);   // called by backward_D after D2's backward
   std::unique_ptr<Net> D3_;       // discriminate(): own input buffer + activations, shared (frozen) arenaD
   Var d3_in_, d3_pred_;
   std::vector<int32_t> d_cimap_;  // buffer channel -> reference channel of the conditional D input (set by the model)
@@ -246,6 +293,8 @@ class Pipeline {
   Model& tex_;
   int32_t* labels_ = nullptr;
   void* exec_ = nullptr;
+  void* cap_stream_ = nullptr;     // capture happens on a private stream: the caller's may be the legacy default stream,
+                                   // which cannot be captured; the instantiated graph is launched on the caller's stream
   bool warmed_ = false;
 };
 

@@ -300,6 +300,80 @@ __global__ __launch_bounds__(256) void gram_bwd_kernel(const float* a, int acs, 
   }
 }
 
+// ---- gradient penalty helpers (ops.h) ----------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gp_interp_kernel(const float* a, int acs, const float* b, int bcs, const float* alpha,
+                                                        const float* beta, int becs, const float* half_std, float* out,
+                                                        int ocs, int N, size_t HW, int C) {
+  const size_t total = (size_t)N * HW * C;
+  const float hs = half_std ? half_std[0] : 0.f;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const size_t e = i / C;
+    const int c = (int)(i - e * C);
+    const int n = (int)(e / HW);
+    const float av = a[e * acs + c];
+    const float bv = b ? b[e * bcs + c] : av + hs * beta[e * becs + c];
+    out[e * ocs + c] = av + alpha[n] * (bv - av);
+  }
+}
+__global__ __launch_bounds__(256) void gp_sumsq_kernel(const float* g, int gcs, size_t per_sample, int C, int nchunk,
+                                                       double* partial, int with_sum) {
+  // grid (nchunk, N): partial[(n*nchunk + ch)*2] = sum x^2 (and sum x) over a strided share of sample n
+  __shared__ double sh[4];
+  const int n = blockIdx.y;
+  double s2 = 0, s1 = 0;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < per_sample; i += (size_t)gridDim.x * 256) {
+    const size_t e = i / C;
+    const int c = (int)(i - e * C);
+    const double v = g[((size_t)n * (per_sample / C) + e) * gcs + c];
+    s2 += v * v; s1 += v;
+  }
+  const double r2 = block_sum(s2, sh);
+  const double r1 = with_sum ? block_sum(s1, sh) : 0.0;
+  if (threadIdx.x == 0) { partial[((size_t)n * nchunk + blockIdx.x) * 2] = r2; partial[((size_t)n * nchunk + blockIdx.x) * 2 + 1] = r1; }
+}
+// one block: per-sample norms -> penalty value and the per-sample gradient coefficients
+__global__ __launch_bounds__(64) void gp_finalize_kernel(const double* partial, int N, int nchunk, int lp, float scale,
+                                                         float* loss_out, float* coef) {
+  if (threadIdx.x != 0) return;
+  double loss = 0;
+  for (int n = 0; n < N; ++n) {
+    double s2 = 0;
+    for (int ch = 0; ch < nchunk; ++ch) s2 += partial[((size_t)n * nchunk + ch) * 2];
+    const double norm = sqrt(s2);
+    double d = norm - 1.0;
+    if (lp && d < 0) d = 0;
+    loss += d * d;
+    coef[n] = norm > 0 ? (float)((double)scale * 2.0 * d / ((double)N * norm)) : 0.f;
+  }
+  loss_out[0] = (float)(loss / N);
+}
+__global__ __launch_bounds__(256) void gp_scale_kernel(const float* g, int gcs, const float* coef, float* u, int ucs, int N,
+                                                       size_t HW, int C) {
+  const size_t total = (size_t)N * HW * C;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const size_t e = i / C;
+    const int c = (int)(i - e * C);
+    u[e * ucs + c] = coef[e / HW] * g[e * gcs + c];
+  }
+}
+__global__ __launch_bounds__(64) void gp_std_finalize_kernel(const double* partial, int nblocks, double numel, float* out) {
+  if (threadIdx.x != 0) return;
+  double s2 = 0, s1 = 0;
+  for (int i = 0; i < nblocks; ++i) { s2 += partial[(size_t)i * 2]; s1 += partial[(size_t)i * 2 + 1]; }
+  const double mean = s1 / numel;
+  double var = (s2 - numel * mean * mean) / (numel - 1.0);
+  if (var < 0) var = 0;
+  out[0] = (float)(0.5 * sqrt(var));
+}
+__global__ __launch_bounds__(256) void gp_uniform_kernel(float* v, int cs, size_t pixels, int C, int Clog, uint64_t seed) {
+  const size_t total = pixels * C;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const size_t e = i / C;
+    const int c = (int)(i - e * C);
+    v[e * cs + c] = c < Clog ? (float)(mix64(seed * 0xD1342543DE82EF95ull + i) & 0xFFFFFFu) * (1.0f / 16777216.0f) : 0.f;
+  }
+}
+
 __global__ void scalar_axpby_kernel(const float* a, float ca, const float* b, float cb, float* out) {
   if (threadIdx.x == 0 && blockIdx.x == 0) out[0] = (a ? a[0] * ca : 0.f) + (b ? b[0] * cb : 0.f);
 }
@@ -393,6 +467,37 @@ void gram_style_loss(Stream& s, const TView& a, const TView& b, int C, float sca
                        da->p, da->cs, accumulate);
   }
   check_launch("gram_style_loss");
+}
+
+void gp_interpolate(Stream& s, const TView& a, const TView* b, const float* alpha, const TView* beta, const float* half_std,
+                    const TView& out) {
+  if (!b && !(beta && half_std)) throw Error(1, "gp_interpolate: dragan form needs beta and half_std");
+  const size_t HW = (size_t)a.H * a.W;
+  hipLaunchKernelGGL(gp_interp_kernel, dim3(loss_grid((size_t)a.N * HW * a.C)), dim3(256), 0, hs(s), a.p, a.cs, b ? b->p : nullptr,
+                     b ? b->cs : 0, alpha, beta ? beta->p : nullptr, beta ? beta->cs : 0, half_std, out.p, out.cs, a.N, HW, a.C);
+  check_launch("gp_interpolate");
+}
+void gp_half_std(Stream& s, const TView& a, size_t numel, float* out) {
+  const size_t per = (size_t)a.H * a.W * a.C;
+  const int nchunk = 64;
+  double* partial = reinterpret_cast<double*>(s.ws);
+  hipLaunchKernelGGL(gp_sumsq_kernel, dim3(nchunk, a.N), dim3(256), 0, hs(s), a.p, a.cs, per, a.C, nchunk, partial, 1);
+  hipLaunchKernelGGL(gp_std_finalize_kernel, dim3(1), dim3(64), 0, hs(s), partial, nchunk * a.N, (double)numel, out);
+  check_launch("gp_half_std");
+}
+void gp_penalty(Stream& s, const TView& g, int lp, float scale, float* loss_out, const TView& u) {
+  const size_t HW = (size_t)g.H * g.W, per = HW * g.C;
+  const int nchunk = 64;
+  double* partial = reinterpret_cast<double*>(s.ws);
+  float* coef = reinterpret_cast<float*>(s.ws + (size_t)nchunk * g.N * 16 + 256);
+  hipLaunchKernelGGL(gp_sumsq_kernel, dim3(nchunk, g.N), dim3(256), 0, hs(s), g.p, g.cs, per, g.C, nchunk, partial, 0);
+  hipLaunchKernelGGL(gp_finalize_kernel, dim3(1), dim3(64), 0, hs(s), partial, g.N, nchunk, lp, scale, loss_out, coef);
+  hipLaunchKernelGGL(gp_scale_kernel, dim3(loss_grid((size_t)g.N * per)), dim3(256), 0, hs(s), g.p, g.cs, coef, u.p, u.cs, g.N, HW, g.C);
+  check_launch("gp_penalty");
+}
+void gp_uniform(Stream& s, const TView& v, int Clog, uint64_t seed) {
+  hipLaunchKernelGGL(gp_uniform_kernel, dim3(loss_grid(v.pixels() * v.C)), dim3(256), 0, hs(s), v.p, v.cs, v.pixels(), v.C, Clog, seed);
+  check_launch("gp_uniform");
 }
 
 void scalar_axpby(Stream& s, const float* a, float ca, const float* b, float cb, float* out) {

@@ -212,6 +212,7 @@ class WarpModel final : public Model {
     nhwc_to_nchw(ctx->s, Dx.batch(0, B).v.slice(0, 20), dst, 19);
   }
   TView output_view() override { return Dx.batch(0, B).v.slice(0, 20); }
+  bool supports_gradient_penalty() const override { return true; }
   void forward(bool training, uint64_t seed) override {       // warp_model.py:106-107
     G->training = training; G->seed = seed;
     G->forward();
@@ -228,6 +229,8 @@ class WarpModel final : public Model {
     gan_loss_op(s, hyper.gan_mode, pr, label_real, true, 0.5f * hyper.grad_scale, losses + L_D_REAL, &gr);
     scalar_axpby(s, losses + L_D_FAKE, 0.5f, losses + L_D_REAL, 0.5f, losses + L_D);
     D2->backward(true, false);
+    if (hyper.gp_mode) run_gradient_penalty(Dx.batch(B, B).v, Dx.batch(0, B).v);     // warp_model.py:126-136
+    else dev_memset(s, losses + L_D_GP, 0, sizeof(float));
   }
   void backward_G(float label_real) override {                        // warp_model.py:141-167
     backward_G_head(label_real);

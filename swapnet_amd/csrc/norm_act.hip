@@ -170,6 +170,78 @@ __global__ __launch_bounds__(256) void norm_act_bwd_apply_kernel(NAp p) {
   }
 }
 
+// ---- second-order step through act(IN(x)) -- ops.h norm_act_bwd2 ------------------------------------------------
+struct NA2p {
+  const float *u, *gy, *x; int ucs, gycs, xcs;
+  float *uy, *ax; int uycs, axcs;
+  const float* stats;
+  double* partial;      // [N][nchunk][C][5]
+  double* sums;         // [N][C][5] = <u>, <gm>, <u xh>, <gm xh>, <u gm>
+  int N, HW, C, nchunk, chunk, act;
+};
+__global__ __launch_bounds__(256) void in2_partial_kernel(NA2p p) {
+  __shared__ double red[256 * 5];
+  const int n = blockIdx.y, ch = blockIdx.x;
+  const int c0 = ch * p.chunk, c1 = min(p.HW, c0 + p.chunk);
+  // thread = one channel of one pixel row: consecutive threads walk consecutive channels (coalesced scalar loads)
+  const int cpb = min(p.C, 256), rows = 256 / cpb;
+  const int tx = threadIdx.x % cpb, ty = threadIdx.x / cpb;
+  for (int cb = 0; cb < p.C; cb += cpb) {
+    const int c = cb + tx;
+    double s[5] = {0, 0, 0, 0, 0};
+    if (ty < rows && c < p.C) {
+      const float mean = p.stats[((size_t)n * p.C + c) * 2], rstd = p.stats[((size_t)n * p.C + c) * 2 + 1];
+      for (int pix = c0 + ty; pix < c1; pix += rows) {
+        const size_t e = (size_t)n * p.HW + pix;
+        const float xv = p.x[e * p.xcs + c];
+        const float xhf = (xv - mean) * rstd;
+        const double xh = ((double)xv - (double)mean) * (double)rstd;
+        const double uu = p.u[e * p.ucs + c];
+        const double gm = (double)(p.gy[e * p.gycs + c] * act_grad_from_in(xhf, p.act));
+        s[0] += uu; s[1] += gm; s[2] += uu * xh; s[3] += gm * xh; s[4] += uu * gm;
+      }
+    }
+    for (int j = 0; j < 5; ++j) red[threadIdx.x * 5 + j] = s[j];
+    __syncthreads();
+    if (ty == 0 && c < p.C) {
+      for (int r = 1; r < rows; ++r)
+        for (int j = 0; j < 5; ++j) red[threadIdx.x * 5 + j] += red[(r * cpb + tx) * 5 + j];
+      double* o = p.partial + (((size_t)n * p.nchunk + ch) * p.C + c) * 5;
+      for (int j = 0; j < 5; ++j) o[j] = red[threadIdx.x * 5 + j];
+    }
+    __syncthreads();
+  }
+}
+__global__ void in2_finalize_kernel(NA2p p) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= p.N * p.C) return;
+  const int n = i / p.C, c = i - n * p.C;
+  double a[5] = {0, 0, 0, 0, 0};
+  for (int ch = 0; ch < p.nchunk; ++ch) {
+    const double* o = p.partial + (((size_t)n * p.nchunk + ch) * p.C + c) * 5;
+    for (int j = 0; j < 5; ++j) a[j] += o[j];
+  }
+  for (int j = 0; j < 5; ++j) p.sums[(size_t)i * 5 + j] = a[j] / p.HW;
+}
+__global__ __launch_bounds__(256) void in2_apply_kernel(NA2p p) {
+  const size_t total = (size_t)p.N * p.HW * p.C;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t e = i / p.C;
+    const int c = (int)(i - e * p.C);
+    const int n = (int)(e / p.HW);
+    const float mean = p.stats[((size_t)n * p.C + c) * 2], rstdf = p.stats[((size_t)n * p.C + c) * 2 + 1];
+    const double* m = p.sums + ((size_t)n * p.C + c) * 5;
+    const double mu = m[0], mg = m[1], muh = m[2], mgh = m[3], mug = m[4];
+    const float xv = p.x[e * p.xcs + c];
+    const float ad = act_grad_from_in((xv - mean) * rstdf, p.act);
+    const double rstd = rstdf, xh = ((double)xv - (double)mean) * rstd;
+    const double uu = p.u[e * p.ucs + c], gm = (double)(p.gy[e * p.gycs + c] * ad);
+    const double ju = uu - mu - xh * muh;
+    p.uy[e * p.uycs + c] = (float)((double)ad * rstd * ju);
+    p.ax[e * p.axcs + c] = (float)(-rstd * rstd * (xh * (mug - mu * mg - muh * mgh) + mgh * ju + muh * (gm - mg - xh * mgh)));
+  }
+}
+
 struct EWp {
   const float* a; int acs;
   const float* b; int bcs;
@@ -357,6 +429,23 @@ void dropout_mask(Stream& s, int N, int H, int W, int C, float p, uint64_t seed,
   hipLaunchKernelGGL(dropout_mask_kernel, dim3(ew_grid((size_t)N * H * W * C)), dim3(256), 0, hs(s), N, H * W, C, p, seed,
                      out_nchw);
   check_launch("dropout_mask");
+}
+
+void norm_act_bwd2(Stream& s, const NormActBwd2Args& a) {
+  NA2p p{};
+  p.u = a.u.p; p.ucs = a.u.cs; p.gy = a.gy.p; p.gycs = a.gy.cs; p.x = a.x.p; p.xcs = a.x.cs;
+  p.uy = a.uy.p; p.uycs = a.uy.cs; p.ax = a.ax.p; p.axcs = a.ax.cs; p.stats = a.stats;
+  p.N = a.x.N; p.HW = a.x.H * a.x.W; p.C = a.x.C; p.act = a.act;
+  if (!a.stats) throw Error(1, "norm_act_bwd2: stats required");
+  plan_chunks(p.HW, p.N, std::max(p.C, 4), p.nchunk, p.chunk);
+  p.partial = reinterpret_cast<double*>(s.ws);
+  const size_t pbytes = (size_t)p.N * p.nchunk * p.C * 5 * 8;
+  p.sums = reinterpret_cast<double*>(s.ws + (pbytes + 255) / 256 * 256);
+  if ((pbytes + 255) / 256 * 256 + (size_t)p.N * p.C * 5 * 8 > s.ws_bytes) throw Error(1, "norm_act_bwd2: workspace too small");
+  hipLaunchKernelGGL(in2_partial_kernel, dim3(p.nchunk, p.N), dim3(256), 0, hs(s), p);
+  hipLaunchKernelGGL(in2_finalize_kernel, dim3(ceil_div(p.N * p.C, 256)), dim3(256), 0, hs(s), p);
+  hipLaunchKernelGGL(in2_apply_kernel, dim3(ew_grid((size_t)p.N * p.HW * p.C)), dim3(256), 0, hs(s), p);
+  check_launch("norm_act_bwd2");
 }
 
 static EWp ew_params(const TView& a, const TView* b, const TView& o) {

@@ -27,6 +27,7 @@ void stream_wait_event(Stream& s, void* ev);      // work enqueued on s afterwar
 // graph_begin puts the stream into capture mode: everything enqueued until graph_end is recorded instead of executed
 // (no allocation, synchronisation or host read-back in between).  graph_end returns an executable graph handle (NULL on
 // the host simulator, which has no graphs: callers then simply run the sequence eagerly).
+void* stream_create_current();        // a new non-blocking stream on the calling thread's current device (NULL on the simulator)
 void graph_begin(Stream& s);
 void* graph_end(Stream& s);
 void graph_launch(void* exec, Stream& s);
@@ -210,6 +211,31 @@ void normed_mse_loss(Stream& s, const TView& f, const TView& t, float scale, flo
 // style term: scale * MSE(Gram(a), Gram(b)), Gram over (N*C) x (H*W) of the raw images
 void gram_style_loss(Stream& s, const TView& a, const TView& b, int C, float scale, float* loss_out,
                      const TView* da, int accumulate);
+// ---- gradient penalty (modules/loss.py:133-184; wgan-gp / dragan-gp / dragan-lp), see gp.cpp ---------------------
+// x_hat = a + alpha[n] * (b - a) per sample n.  b = the second view (wgan: the conditioned fakes) or, when b is NULL
+// (dragan), a + half_std[0] * beta with beta ~ U[0,1) the same shape as a (NHWC view; pad channels 0).
+void gp_interpolate(Stream& s, const TView& a, const TView* b, const float* alpha, const TView* beta, const float* half_std,
+                    const TView& out);
+// out[0] = 0.5 * unbiased std of the `numel` logical elements of view a (pad channels hold zeros and add nothing)
+void gp_half_std(Stream& s, const TView& a, size_t numel, float* out);
+// per-sample L2 norm of g over all its elements; penalty = mean_n (norm_n - 1)^2 (lp != 0: max(0, norm_n - 1)^2);
+// loss_out[0] = penalty, u = scale * d(penalty)/dg   (same geometry as g)
+void gp_penalty(Stream& s, const TView& g, int lp, float scale, float* loss_out, const TView& u);
+// fills a view with U[0,1) from the library's counter RNG (logical channels only, pads 0): beta of dragan
+void gp_uniform(Stream& s, const TView& v, int Clog, uint64_t seed);
+// Second-order step through y = act(InstanceNorm(x)) (reverse over reverse).  The first backward computed
+// gx = IN'(x)^T (act'(xh) * gy).  Given u = adjoint of gx:  uy = act'(xh) * IN'(x) u   (adjoint of gy; IN' is symmetric)
+// and ax = (d gx / d x)^T u (adjoint of the raw activation x):
+//   ax = -rstd^2 [ xh (<u gm> - <u><gm> - <u xh><gm xh>) + <gm xh> (u - <u> - xh <u xh>) + <u xh> (gm - <gm> - xh <gm xh>) ],
+//   gm = act'(xh) * gy, <.> = mean over the pixels of one (n, c) plane.  All reductions in fp64.
+struct NormActBwd2Args {
+  TView u, gy, x;             // adjoint of gx; gradient w.r.t. y from the first backward; raw activation
+  const float* stats = nullptr;
+  TView uy, ax;               // outputs (overwritten)
+  int act = ACT_NONE;
+};
+void norm_act_bwd2(Stream& s, const NormActBwd2Args& a);
+
 // out[0] = a[0]*ca + b[0]*cb (device scalars; used to combine loss terms without a sync)
 void scalar_axpby(Stream& s, const float* a, float ca, const float* b, float cb, float* out);
 

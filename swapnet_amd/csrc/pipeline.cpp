@@ -10,7 +10,10 @@ Pipeline::Pipeline(Model& warp, Model& texture) : warp_(warp), tex_(texture) {
     throw Error(1, "pipeline: warp and texture models must share (B, H, W)");
   labels_ = static_cast<int32_t*>(warp.ctx->alloc((size_t)warp.B * warp.H * warp.W * sizeof(int32_t)));
 }
-Pipeline::~Pipeline() { graph_destroy(exec_); }
+Pipeline::~Pipeline() {
+  graph_destroy(exec_);
+  stream_destroy(cap_stream_);
+}
 
 void Pipeline::enqueue() {
   Stream& s = warp_.ctx->s;
@@ -30,9 +33,15 @@ void Pipeline::run(bool use_graph) {
       if (!is_device_build()) return;
       stream_sync(s);
       // capture the identical sequence; nothing in it allocates, synchronises or depends on host state
-      graph_begin(s);
-      try { enqueue(); } catch (...) { graph_end(s); throw; }
-      exec_ = graph_end(s);
+      void* caller = s.handle;
+      if (!cap_stream_) cap_stream_ = stream_create_current();
+      s.handle = cap_stream_;
+      try {
+        graph_begin(s);
+        try { enqueue(); } catch (...) { graph_end(s); throw; }
+        exec_ = graph_end(s);
+      } catch (...) { s.handle = caller; throw; }
+      s.handle = caller;
       return;
     }
     enqueue();                  // host simulator: no graphs

@@ -271,6 +271,9 @@ class TextureModel final : public Model {
     else { wgan_loss(s, pf, 1.f, gs, losses + L_D_FAKE, &gf); wgan_loss(s, pr, -1.f, gs, losses + L_D_REAL, &gr); }
     scalar_axpby(s, losses + L_D_FAKE, 0.5f, losses + L_D_REAL, 0.5f, losses + L_D);
     D2->backward(true, false);
+    // (texture_model.py:148-153 hands the UNconditioned 3-channel targets / fakes to the 22-channel discriminator in the
+    // gradient-penalty modes, which raises in the reference; set_hyper rejects gp_mode for this model)
+    dev_memset(s, losses + L_D_GP, 0, sizeof(float));
   }
   void backward_G(float label_real) override {                          // texture_model.py:157-180
     backward_G_head(label_real);

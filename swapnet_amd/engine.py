@@ -200,7 +200,8 @@ class NativeModel:
     def set_hyper(self, **kw):
         h = _C.SwnHyper(lr=1e-4, d_lr=4e-4, weight_decay=0.0, d_weight_decay=0.01, b1=0.9, b2=0.999,
                         lambda_gan=1.0, lambda_ce=100.0, lambda_l1=10.0, lambda_content=20.0,
-                        lambda_style=1e-8, gan_mode=0, warp_mode_ce=0, grad_scale=1.0, d_b1=0.0, d_b2=0.0)
+                        lambda_style=1e-8, gan_mode=0, warp_mode_ce=0, grad_scale=1.0, d_b1=0.0, d_b2=0.0,
+                        gp_mode=0, lambda_gp=10.0)
         for k, v in kw.items():
             setattr(h, k, v)
         self.lib.call("swn_model_set_hyper", self.handle, C.byref(h))
@@ -241,6 +242,13 @@ class NativeModel:
             out.append((t, p.value))
         self.ctx.sync()
         return out
+
+    def set_gp_random(self, alpha=None, beta=None):
+        """alpha (B,) / (B,1,1,1) and beta (B,22,H,W): the gradient-penalty draws of the next backward_D (one-shot)."""
+        a = None if alpha is None else alpha.detach().reshape(-1).to(device=self.ctx.device, dtype=torch.float32).contiguous()
+        b = None if beta is None else beta.detach().to(device=self.ctx.device, dtype=torch.float32).contiguous()
+        self.lib.call("swn_model_set_gp_random", self.handle, _C.ptr(a), _C.ptr(b))
+        self._gp_keep = (a, b)
 
     def discriminate(self, x):
         """NLayerDiscriminator.forward on a conditioned input in the reference's channel order (B,22,H,W)."""
@@ -357,6 +365,16 @@ def op_gan_loss(ctx, pred, gan_mode, label, target_is_real, grad_scale=1.0, want
     ctx.lib.call("swn_op_gan_loss", ctx.handle, int(gan_mode), _C.ptr(p4), n, c, h, w, C.c_float(label),
                  int(bool(target_is_real)), C.c_float(grad_scale), _C.ptr(loss), _C.ptr(d))
     return loss, (d.reshape(shape) if d is not None else None)
+
+
+def op_norm_act_bwd2(ctx, x, gy, u, act=1):
+    """(uy, ax) of swn_op_norm_act_bwd2: the second-order step through act(InstanceNorm(x))."""
+    d = [t.to(device=ctx.device, dtype=torch.float32).contiguous() for t in (x, gy, u)]
+    uy, ax = torch.empty_like(d[0]), torch.empty_like(d[0])
+    n, c, h, w = d[0].shape
+    ctx.lib.call("swn_op_norm_act_bwd2", ctx.handle, _C.ptr(d[0]), _C.ptr(d[1]), _C.ptr(d[2]), n, c, h, w, int(act),
+                 _C.ptr(uy), _C.ptr(ax))
+    return uy, ax
 
 
 def op_norm_act_dropout(ctx, x, dy=None, norm=True, act=2, p=0.5, seed=0):

@@ -68,14 +68,21 @@ class BaseGAN(BaseModel, ABC):
             self.criterion_GAN.ctx = self.backend.ctx
             if opt.lambda_discriminator:
                 self.loss_names = ["D", "D_real", "D_fake"]
+                if self.criterion_GAN.gp_mode:                 # base_gan.py:163-164
+                    self.loss_names += ["D_gp"]
             self.loss_names += ["G"]
             if opt.lambda_gan:
                 self.loss_names += ["G_gan"]
             self.optimizer_G = optimizers.define_optimizer(self.net_generator, opt, "G")
             self.optimizer_D = optimizers.define_optimizer(self.net_discriminator, opt, "D")
             self.optimizer_names = ("G", "D")
-            self.backend.set_hyper(gan_mode=self.criterion_GAN.native_mode, lambda_gan=opt.lambda_gan)
-            for n in ("D", "D_real", "D_fake", "G", "G_gan", "G_ce", "G_l1", "G_content", "G_style"):
+            if self.criterion_GAN.gp_mode and self.KIND != "warp":
+                raise NotImplementedError("gan mode %s: the gradient-penalty objectives are implemented for the warp "
+                                          "stage (the reference's texture-stage call passes unconditioned tensors to "
+                                          "the conditional discriminator and fails)" % opt.gan_mode)
+            self.backend.set_hyper(gan_mode=self.criterion_GAN.native_mode, lambda_gan=opt.lambda_gan,
+                                   gp_mode=self.criterion_GAN.gp_mode, lambda_gp=getattr(opt, "lambda_gp", 10.0))
+            for n in ("D", "D_real", "D_fake", "G", "G_gan", "G_ce", "G_l1", "G_content", "G_style", "D_gp"):
                 setattr(self, "loss_" + n, 0.0)
 
     # ---- data parallel (new design; the reference is single-device: SURVEY.md 2a) ---------
@@ -122,7 +129,17 @@ class BaseGAN(BaseModel, ABC):
         if self._ce_only():
             return [0.0, 0.0, 0.0]
         c = self.criterion_GAN
-        return [c.sample_label(False), c.sample_label(True), c.sample_label(True)]
+        labels = [c.sample_label(False), c.sample_label(True)]
+        if c.gp_mode and getattr(self.opt, "gp_host_random", False):
+            # gradient_penalty's draws sit between backward_D's labels and backward_G's (loss.py:141-147): drawn here
+            # from the global torch RNG in the reference's order so that a seeded run reproduces the reference's CPU path;
+            # by default the library draws them on the device (no host round trip of a (B,22,H,W) tensor)
+            m = self._native()
+            beta = torch.rand(m.B, 22, m.H, m.W) if c.gp_mode >= 2 else None
+            alpha = torch.rand([m.B, 1, 1, 1])
+            m.set_gp_random(alpha, beta)
+        labels.append(c.sample_label(True))
+        return labels
 
     def optimize_parameters(self):
         """base_gan.py:194-203: forward, D step, G step."""

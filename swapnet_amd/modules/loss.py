@@ -30,16 +30,15 @@ class GANLoss:
     default_fake = 0.0
     default_smooth_real = (0.7, 1.1)
     default_smooth_fake = (0.0, 0.3)
-    MODES = {"vanilla": 0, "dragan": 0, "lsgan": 1, "wgan": 2}
+    MODES = {"vanilla": 0, "dragan": 0, "lsgan": 1, "wgan": 2, "wgan-gp": 2, "dragan-gp": 0, "dragan-lp": 0}
+    GP_MODES = {"wgan-gp": 1, "dragan-gp": 2, "dragan-lp": 3}        # swn_hyper.gp_mode (modules/loss.py:133-184)
 
     def __init__(self, gan_mode, smooth_labels=True, target_real_label=None, target_fake_label=None):
         if gan_mode not in self.MODES:
-            if any(k in gan_mode for k in ("gp", "lp")):
-                raise NotImplementedError("gan mode %s not implemented (gradient-penalty modes need a "
-                                          "double backward through D: SURVEY.md 8(f) rank 4)" % gan_mode)
-            raise NotImplementedError("gan mode %s not implemented" % gan_mode)
+            raise NotImplementedError("gan mode %s not implemented" % gan_mode)      # e.g. mescheder-r1-gp, like loss.py:62
         self.gan_mode = gan_mode
         self.native_mode = self.MODES[gan_mode]
+        self.gp_mode = self.GP_MODES.get(gan_mode, 0)
         self.smooth = smooth_labels
         self.real_label = target_real_label if target_real_label is not None else (
             self.default_smooth_real if smooth_labels else self.default_real)

@@ -31,6 +31,7 @@ void event_destroy(void*) {}
 void event_record(void*, Stream&) {}
 void stream_wait_event(Stream&, void*) {}
 int is_device_build() { return 0; }
+void* stream_create_current() { return nullptr; }
 void graph_begin(Stream&) {}
 void* graph_end(Stream&) { return nullptr; }
 void graph_launch(void*, Stream&) {}
@@ -632,6 +633,78 @@ void gram_style_loss(Stream&, const TView& a, const TView& b, int C, float scale
   if (da) for (int p = 0; p < HW; ++p) for (int r = 0; r < R; ++r) { float s = 0;
     for (int r2 = 0; r2 < R; ++r2) s += (dG[(size_t)r * R + r2] + dG[(size_t)r2 * R + r]) * val(a, r2, p);
     float* dp = da->p + ((size_t)(r / C) * HW + p) * da->cs + (r % C); *dp = accumulate ? *dp + s : s; }
+}
+void gp_interpolate(Stream&, const TView& a, const TView* b, const float* alpha, const TView* beta, const float* half_std,
+                    const TView& out) {
+  const size_t HW = (size_t)a.H * a.W;
+  for (size_t e = 0; e < a.pixels(); ++e)
+    for (int c = 0; c < a.C; ++c) {
+      const float av = a.p[e * a.cs + c];
+      const float bv = b ? b->p[e * b->cs + c] : av + half_std[0] * beta->p[e * beta->cs + c];
+      out.p[e * out.cs + c] = av + alpha[e / HW] * (bv - av);
+    }
+}
+void gp_half_std(Stream&, const TView& a, size_t numel, float* out) {
+  double s1 = 0, s2 = 0;
+  for (size_t e = 0; e < a.pixels(); ++e)
+    for (int c = 0; c < a.C; ++c) { const double v = a.p[e * a.cs + c]; s1 += v; s2 += v * v; }
+  const double mean = s1 / (double)numel;
+  double var = (s2 - (double)numel * mean * mean) / ((double)numel - 1.0);
+  if (var < 0) var = 0;
+  out[0] = (float)(0.5 * std::sqrt(var));
+}
+void gp_penalty(Stream&, const TView& g, int lp, float scale, float* loss_out, const TView& u) {
+  const size_t HW = (size_t)g.H * g.W;
+  double loss = 0;
+  for (int n = 0; n < g.N; ++n) {
+    double s2 = 0;
+    for (size_t e = n * HW; e < (n + 1) * HW; ++e)
+      for (int c = 0; c < g.C; ++c) { const double v = g.p[e * g.cs + c]; s2 += v * v; }
+    const double norm = std::sqrt(s2);
+    double d = norm - 1.0;
+    if (lp && d < 0) d = 0;
+    loss += d * d;
+    const float coef = norm > 0 ? (float)((double)scale * 2.0 * d / ((double)g.N * norm)) : 0.f;
+    for (size_t e = n * HW; e < (n + 1) * HW; ++e)
+      for (int c = 0; c < g.C; ++c) u.p[e * u.cs + c] = coef * g.p[e * g.cs + c];
+  }
+  loss_out[0] = (float)(loss / g.N);
+}
+void gp_uniform(Stream&, const TView& v, int Clog, uint64_t seed) {
+  for (size_t e = 0; e < v.pixels(); ++e)
+    for (int c = 0; c < v.C; ++c) {
+      uint64_t z = seed * 0xD1342543DE82EF95ull + (e * v.C + c) + 0x9E3779B97F4A7C15ull;
+      z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; z ^= z >> 31;
+      v.p[e * v.cs + c] = c < Clog ? (float)((uint32_t)(z >> 11) & 0xFFFFFFu) * (1.0f / 16777216.0f) : 0.f;
+    }
+}
+void norm_act_bwd2(Stream&, const NormActBwd2Args& a) {
+  const int N = a.x.N, HW = a.x.H * a.x.W, C = a.x.C;
+  for (int n = 0; n < N; ++n)
+    for (int c = 0; c < C; ++c) {
+      const float mean = a.stats[((size_t)n * C + c) * 2], rstdf = a.stats[((size_t)n * C + c) * 2 + 1];
+      const double rstd = rstdf;
+      double m[5] = {0, 0, 0, 0, 0};
+      for (int p = 0; p < HW; ++p) {
+        const size_t e = (size_t)n * HW + p;
+        const float xv = a.x.p[e * a.x.cs + c];
+        const double xh = ((double)xv - mean) * rstd;
+        const double uu = a.u.p[e * a.u.cs + c];
+        const double gm = (double)(a.gy.p[e * a.gy.cs + c] * actg_in((xv - mean) * rstdf, a.act));
+        m[0] += uu; m[1] += gm; m[2] += uu * xh; m[3] += gm * xh; m[4] += uu * gm;
+      }
+      for (double& v : m) v /= HW;
+      for (int p = 0; p < HW; ++p) {
+        const size_t e = (size_t)n * HW + p;
+        const float xv = a.x.p[e * a.x.cs + c];
+        const float ad = actg_in((xv - mean) * rstdf, a.act);
+        const double xh = ((double)xv - mean) * rstd;
+        const double uu = a.u.p[e * a.u.cs + c], gm = (double)(a.gy.p[e * a.gy.cs + c] * ad);
+        const double ju = uu - m[0] - xh * m[2];
+        a.uy.p[e * a.uy.cs + c] = (float)((double)ad * rstd * ju);
+        a.ax.p[e * a.ax.cs + c] = (float)(-rstd * rstd * (xh * (m[4] - m[0] * m[1] - m[2] * m[3]) + m[3] * ju + m[2] * (gm - m[1] - xh * m[3])));
+      }
+    }
 }
 void scalar_axpby(Stream&, const float* a, float ca, const float* b, float cb, float* out) {
   out[0] = (a ? a[0] * ca : 0.f) + (b ? b[0] * cb : 0.f);

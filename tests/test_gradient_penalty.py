@@ -1,0 +1,118 @@
+"""--gan_mode wgan-gp / dragan-gp / dragan-lp (modules/loss.py:133-184, warp_model.py:126-136).
+The discriminator step needs d/d(theta_D) of a function of D's INPUT gradient, i.e. a derivative through D's backward
+pass (torch: create_graph=True).  The native path does it as an explicit reverse-over-reverse pass (csrc/gp.cpp).
+Checked (i) op by op against torch double-backward, (ii) as a full warp step against the oracle -- which is itself
+pinned to one step of the REAL reference under each of the three objectives (tests/golden/warp_modes_64.npz) -- and
+(iii) through the drop-in model API against those golden losses."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import swapnet_oracle as O
+from oracle.golden_io import compare
+from swapnet_amd import _C, engine
+from tests import backends
+from tests.test_models_api import make_opt
+from tests.test_warp_step import noise_bias
+
+BACKENDS = [pytest.param("sim", id="hostsim"), pytest.param("gpu", id="mi355x", marks=pytest.mark.gpu)]
+MODES = {"wgan-gp": (2, 1), "dragan-gp": (0, 2), "dragan-lp": (0, 3)}        # name -> (gan_mode, gp_mode) of swn_hyper
+
+
+def _ctx(kind):
+    return backends.gpu_ctx() if kind == "gpu" else backends.hostsim_ctx()
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("mode", list(MODES))
+def test_warp_step_with_gradient_penalty_matches_oracle(backend, mode):
+    ctx = _ctx(backend)
+    B, H = 2, 64
+    torch.manual_seed(0)
+    G, D = O.warp_module_params(), O.patchgan_params(22)
+    batch = O.synth_warp_batch(B, H, H, seed=1234)
+    labels = [0.9, 0.8, 1.0]
+    g = torch.Generator().manual_seed(77)
+    alpha = torch.rand([B, 1, 1, 1], generator=g)
+    beta = torch.rand([B, 22, H, H], generator=g) if mode.startswith("dragan") else None
+    st = O.WarpStepOracle(G, D, hyper=dict(gan_mode=mode))
+    s64 = st.astype(torch.float64)
+    for o in (st, s64):
+        o.gp_alpha_in, o.gp_beta_in = alpha, beta
+        o.step(*batch, labels=labels)
+    m = backends.get_model(ctx, "warp", B, H)
+    backends.reset_state(m, {engine.NET_G: G, engine.NET_D: D})
+    m.set_hyper(gan_mode=MODES[mode][0], gp_mode=MODES[mode][1], lambda_gp=10.0)
+    for i, t in enumerate(batch):
+        m.set_input(i, t)
+    m.forward(False, 0)
+    m.set_gp_random(alpha, beta)
+    m.backward_D(labels[0], labels[1])
+    gD = m.state_dict(engine.NET_D, which=engine.W_GRAD, to_cpu=True)
+    m.optimizer_step(engine.NET_D)
+    m.backward_G(labels[2])
+    m.optimizer_step(engine.NET_G)
+    L = m.losses()
+    for k, v in st.losses.items():
+        assert abs(L[k] - v) <= 1e-3 * abs(v) + 1e-6, (mode, k, L[k], v)
+    assert L["D_gp"] > 1.0                                          # the penalty dominates the discriminator loss here
+    # the second-order gradient: every discriminator tensor against the float64 evaluation
+    w = backends.assert_grads_vs_fp64(gD, st.grads_D, s64.grads_D, noise_bias, (mode, "gradD"))
+    print(mode, "worst gradD error vs fp64: native %.2e, torch fp32 %.2e" % w)
+    pD = m.state_dict(engine.NET_D, to_cpu=True)
+    for k, v in st.D.items():
+        if not noise_bias(k):
+            assert backends.rel_l2(pD[k], v) < 2e-3, (mode, "postD", k, backends.rel_l2(pD[k], v))
+    m.set_hyper()                                                   # leave the shared model in its default objective
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_instance_norm_second_order_op(backend):
+    """ops.h norm_act_bwd2 against torch's double backward of y = leaky_relu(instance_norm(x)), through the model-free
+    entry point swn_op_norm_act_bwd2."""
+    ctx = _ctx(backend)
+    g = torch.Generator().manual_seed(4)
+    x = (torch.randn(2, 8, 9, 7, generator=g) * 2 + 0.5).double().requires_grad_(True)
+    gy = torch.randn(2, 8, 9, 7, generator=g).double().requires_grad_(True)
+    u = torch.randn(2, 8, 9, 7, generator=g).double()
+    y = F.leaky_relu(F.instance_norm(x, eps=1e-5), 0.2)
+    gx, = torch.autograd.grad(y, x, gy, create_graph=True)
+    ax_ref, uy_ref = torch.autograd.grad((gx * u).sum(), (x, gy))
+    uy, ax = engine.op_norm_act_bwd2(ctx, x.detach().float(), gy.detach().float(), u.float(), act=1)
+    assert backends.rel_l2(uy, uy_ref) < 1e-5 and backends.rel_l2(ax, ax_ref) < 1e-4
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_model_api_reproduces_reference_losses_under_wgan_gp(backend, tmp_path, golden_dir):
+    """create_model(opt) with --gan_mode wgan-gp, seeded like the golden run of the real reference, with the
+    penalty's random draws taken from the global torch RNG in the reference's order (opt.gp_host_random)."""
+    from swapnet_amd.models import create_model
+    gm = np.load(os.path.join(golden_dir, "warp_modes_64.npz"))
+    for mode in ("wgan-gp", "dragan-gp"):
+        opt = make_opt(tmp_path, backend, gan_mode=mode, gp_host_random=True)
+        model = create_model(opt)
+        assert model.loss_names == ["D", "D_real", "D_fake", "D_gp", "G", "G_gan", "G_ce"]       # base_gan.py:161-167
+        torch.manual_seed(int(gm["meta/init_seed"]))
+        model.net_generator.load_state_dict(O.warp_module_params())
+        model.net_discriminator.load_state_dict(O.patchgan_params(22))
+        model.eval()
+        bodys, inputs, targets = O.synth_warp_batch(2, 64, 64, seed=1234)
+        model.set_input(dict(bodys=bodys, input_cloths=inputs, target_cloths=targets, cloth_paths=["", ""], body_paths=["", ""]))
+        torch.manual_seed(int(gm["meta/step_seed"]))
+        model.optimize_parameters()
+        for k, v in model.get_current_losses().items():
+            ref = float(gm[mode + "/loss/" + k])
+            assert abs(v - ref) <= 1e-3 * abs(ref) + 1e-6, (mode, k, v, ref)
+        ok, msg = compare(gm, mode + "/postD/model.8.weight", model.net_discriminator.state_dict()["model.8.weight"], 2e-3, 5e-3)
+        assert ok, msg
+
+
+def test_texture_stage_rejects_gradient_penalty_modes(tmp_path):
+    from swapnet_amd.models import create_model
+    with pytest.raises(NotImplementedError):
+        create_model(make_opt(tmp_path, "sim", model="texture", gan_mode="wgan-gp"))
+    with pytest.raises(NotImplementedError):
+        create_model(make_opt(tmp_path, "sim", gan_mode="mescheder-r1-gp"))                     # like modules/loss.py:62

@@ -125,9 +125,9 @@ def _check_full(g, s, pre, stage):
     assert n or pre != "step0/"
 
 
-@pytest.mark.parametrize("mode", ["lsgan", "wgan", "ce"])
+@pytest.mark.parametrize("mode", ["lsgan", "wgan", "ce", "wgan-gp", "dragan-gp", "dragan-lp"])
 def test_warp_other_objectives_match_reference(golden_dir, mode):
-    """--gan_mode lsgan / wgan and --warp_mode ce: the oracle against one step of the real reference
+    """--gan_mode lsgan / wgan / wgan-gp / dragan-gp / dragan-lp and --warp_mode ce: the oracle against one step of the real reference
     (tests/golden/warp_modes_64.npz, oracle/make_golden.py::golden_warp_modes)."""
     g = np.load(os.path.join(golden_dir, "warp_modes_64.npz"))
     torch.manual_seed(int(g["meta/init_seed"]))

@@ -6,7 +6,7 @@ fp32 tolerances (north_star: 1e-3 relative):
   forward activations / fakes / losses : 1e-3 (observed ~1e-6 .. 1e-5)
   post-step weights                    : 1e-3 rel-L2 per tensor
   gradients                            : measured against the SAME step evaluated in float64 (oracle dtype=float64):
-    rel-L2(native, fp64) <= max(1e-3, 1.5 x rel-L2(torch fp32, fp64)) per tensor (backends.assert_grads_vs_fp64).
+    rel-L2(native, fp64) <= max(1e-3, 2 x rel-L2(torch fp32, fp64)) per tensor (backends.assert_grads_vs_fp64).
     The reference's own fp32 CPU backward is ~1.3e-3 away from the fp64 evaluation on the deep layers
     (printed by tests/test_train_parity.py::test_gradients_against_fp64_oracle), so a fixed 1e-3 against the
     fp32 oracle would test the oracle's round-off, not our kernels.
