@@ -161,7 +161,13 @@ def main():
         batch = synthetic.warp_batch(B, S, S, seed=1234 + rank)
         model.set_input(0, batch["bodys"]); model.set_input(1, batch["input_cloths"]); model.set_input(2, batch["target_cloths"])
     gG, gD = model.grad_arena(engine.NET_G), model.grad_arena(engine.NET_D)
-    xchg = parallel.GradExchange(world)
+    # SWAPNET_BENCH_RCCL1=1: 1-rank "nccl" process group and the full multi-GPU call sequence with real (identity)
+    # RCCL all-reduces on the arena slices -- the N > 1 code path on a single-GPU box
+    rccl1 = world == 1 and os.environ.get("SWAPNET_BENCH_RCCL1") == "1"
+    if rccl1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group(backend="nccl", rank=0, world_size=1)
+    xchg = parallel.GradExchange(world, force=rccl1)
     label_rng = torch.Generator().manual_seed(4321)        # same on every rank (SURVEY.md 8(e) caveat 2)
 
     def draw_labels():
@@ -174,7 +180,7 @@ def main():
         lab = draw_labels()
         step_no[0] += 1
         seed = step_no[0] * 1000 + rank
-        if world == 1 and not os.environ.get("SWAPNET_BENCH_PHASED"):
+        if world == 1 and not os.environ.get("SWAPNET_BENCH_PHASED") and not rccl1:
             model.step(lab, training=True, seed=seed)
             return
         # (SWAPNET_BENCH_PHASED=1 runs this multi-GPU call sequence on one GPU, exchanges being no-ops, to
@@ -183,13 +189,10 @@ def main():
         model.backward_D(lab[0], lab[1])
         xchg.allreduce_mean(gD)
         model.optimizer_step(engine.NET_D)
-        # generator backward in buckets (decoder + late resblocks first, encoders last): each bucket's
-        # gradients travel over xGMI while the earlier layers are still being back-propagated
-        for part in range(model.backward_G_parts()):
-            off, cnt = model.backward_G_part(lab[2], part)
-            xchg.begin(gG[off:off + cnt])
-        xchg.finish()
-        model.optimizer_step(engine.NET_G)
+        # generator backward in buckets (decoder + late resblocks first, encoders last): each bucket's gradients
+        # travel over xGMI while the earlier layers are still being back-propagated, and each bucket's AdamW runs
+        # under the next bucket's transfer
+        parallel.generator_backward_with_exchange(model, lab[2], xchg)
 
     def fence():
         if world > 1:
@@ -224,7 +227,7 @@ def main():
                                 if texture else
                                 f"warp-stage G+D optimize_parameters step, {S}x{S}, bs {B}/GPU, fp32, "
                                 f"train mode (dropout 0.5), WarpModule 137.6M + PatchGAN 2.8M params, AdamW"),
-                   "global_batch": world * B, "parallelism": f"dp{world}"},
+                   "global_batch": world * B, "parallelism": f"dp{world}" + (" (1-rank RCCL exchange exercised)" if rccl1 else "")},
         "losses_finite": all(v == v and abs(v) < 1e30 for v in losses.values()),
         "hbm_allocated_gb": round(ctx.bytes_allocated() / 1e9, 2),      # arenas + activations (+ 2 x 1 GB split workspaces)
     }
@@ -313,7 +316,7 @@ def main():
         out["cpu_baseline"] = cpu_baseline()
     if rank == 0:
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if world > 1 or rccl1:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -139,6 +139,12 @@ int swn_pipeline_destroy(swn_pipeline* p);
 int swn_pipeline_run(swn_pipeline* p, int use_graph, int* graph_replayed);
 int swn_pipeline_labels(swn_pipeline* p, int32_t** dev_labels);   /* (B,H,W) int32 of the last run, library-owned */
 
+/* Data-parallel texture stage: the style term is MSE(Gram(output), Gram(target)) with the Gram over the WHOLE batch viewed
+ * as (B*C, H*W) (modules/losses/perceptual.py:6-10,58-63), so it couples the samples of all ranks.  The host all-gathers the
+ * generated and target images ((n_total, 3, H, W) each; this rank's samples start at n0) after swn_model_forward; the next
+ * backward_G evaluates the Gram over that global batch and back-propagates into the local samples -- the step then equals
+ * the one-process big-batch step.  One-shot. */
+int swn_model_set_style_context(swn_model* m, const float* all_out_nchw, const float* all_tgt_nchw, int n_total, int n0);
 /* The random draws of the next gradient-penalty pass (modules/loss.py:141-147): alpha = torch.rand(B,1,1,1) as B
  * device floats; beta = torch.rand_like(conditioned_real) as (B, 22, H, W) in the reference's channel order (dragan
  * modes only).  Either may be NULL (the library then draws it from its own counter RNG).  One-shot. */
@@ -170,6 +176,10 @@ int swn_model_backward_G_parts(swn_model* m, int* nparts);
 int swn_model_backward_G_part(swn_model* m, float label_real, int part, size_t* ready_off, size_t* ready_count);
 /* optimizer_{G,D}.step() (models/base_gan.py:199,203): fused AdamW over the net's arena */
 int swn_model_optimizer_step(swn_model* m, int net);
+/* the same AdamW step restricted to the arena range [off, off+count) (the ranges swn_model_backward_G_part reports):
+ * under data parallelism a bucket is stepped as soon as its all-reduce has landed, while the next bucket is still
+ * being back-propagated.  first != 0 on the first range of an optimizer step (advances AdamW's step counter). */
+int swn_model_optimizer_step_range(swn_model* m, int net, size_t off, size_t count, int first);
 /* BaseGAN.optimize_parameters (models/base_gan.py:194-203; warp_model.py:169-183) in one call */
 int swn_model_step(swn_model* m, const float labels[3], int training, uint64_t dropout_seed);
 /* BaseModel.get_current_losses (models/base_model.py:139-147): host array of 9 floats

@@ -61,6 +61,7 @@ _PROTOS = {
     "swn_pipeline_destroy": ([_vp], _i),
     "swn_pipeline_run": ([_vp, _i, C.POINTER(_i)], _i),
     "swn_pipeline_labels": ([_vp, C.POINTER(_vp)], _i),
+    "swn_model_set_style_context": ([_vp, _fp, _fp, _i, _i], _i),
     "swn_model_set_gp_random": ([_vp, _fp, _fp], _i),
     "swn_model_discriminate": ([_vp, _fp, _fp], _i),
     "swn_model_perceptual": ([_vp, _fp, _fp, _i, _fp, _f, _f, _fp], _i),
@@ -70,6 +71,7 @@ _PROTOS = {
     "swn_model_backward_G_parts": ([_vp, C.POINTER(C.c_int)], _i),
     "swn_model_backward_G_part": ([_vp, _f, _i, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)], _i),
     "swn_model_optimizer_step": ([_vp, _i], _i),
+    "swn_model_optimizer_step_range": ([_vp, _i, C.c_size_t, C.c_size_t, _i], _i),
     "swn_model_step": ([_vp, C.POINTER(_f * 3), _i, C.c_uint64], _i),
     "swn_model_get_losses": ([_vp, C.POINTER(_f), _i], _i),
     "swn_model_grad_arena": ([_vp, _i, C.POINTER(_vp), C.POINTER(C.c_size_t)], _i),

@@ -246,6 +246,9 @@ int swn_model_dropout_mask(swn_model* m, int net, int site, uint64_t seed, float
     if (dst) dropout_mask(m->m->ctx->s, d.N, d.H, d.W, d.C, d.p, Net::drop_seed(seed, d.salt), dst);
   });
 }
+int swn_model_set_style_context(swn_model* m, const float* all_out, const float* all_tgt, int n_total, int n0) {
+  return guard([&] { REQUIRE(m && all_out && all_tgt, "NULL argument"); m->m->set_style_context(all_out, all_tgt, n_total, n0); });
+}
 int swn_model_set_gp_random(swn_model* m, const float* alpha, const float* beta) {
   return guard([&] { REQUIRE(m, "NULL argument"); m->m->set_gp_random(alpha, beta); });
 }
@@ -304,6 +307,13 @@ int swn_model_optimizer_step(swn_model* m, int net) {
     REQUIRE(m && m->m->is_train, "model was not created for training");
     REQUIRE(net == 0 || net == 1, "net must be 0 (G) or 1 (D)");
     m->m->optimizer_step(net);
+  });
+}
+int swn_model_optimizer_step_range(swn_model* m, int net, size_t off, size_t count, int first) {
+  return guard([&] {
+    REQUIRE(m && m->m->is_train, "model was not created for training");
+    REQUIRE(net == 0 || net == 1, "net must be 0 (G) or 1 (D)");
+    m->m->optimizer_step_range(net, off, count, first);
   });
 }
 int swn_model_step(swn_model* m, const float labels[3], int training, uint64_t seed) {

@@ -1543,16 +1543,28 @@ __global__ __launch_bounds__(256) void wgrad_dma_reduce_kernel(GemmP p, DmaSched
   *reinterpret_cast<float4*>(out + (size_t)row * p.Npad + col) = a;
 }
 
-__global__ void slab_sum_kernel(const float* slab, float* out, size_t n, int splits, size_t slab_bs, size_t out_bs) {
+// sums the `splits` slabs of n floats: 16 outputs (float4) x 16 slab groups per block -- group g adds slabs g, g+16, ...
+// in index order, then the 16 group sums are added in index order (fixed order: deterministic).  With hundreds of slabs
+// of a small weight tensor (first-layer weight gradients: 250-500 slabs of 24 K floats) one thread per output walking
+// all slabs is latency-bound (98 us); spreading the slab axis over the block makes it a 10 us kernel.
+__global__ __launch_bounds__(256) void slab_sum_kernel(const float* slab, float* out, size_t n, int splits, size_t slab_bs, size_t out_bs) {
+  __shared__ float4 red[256];
   slab += (size_t)blockIdx.y * slab_bs; out += (size_t)blockIdx.y * out_bs;
-  const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
-  if (i >= n) return;
-  float4 a = *reinterpret_cast<const float4*>(slab + i);
-  for (int s = 1; s < splits; ++s) {
-    const float4 b = *reinterpret_cast<const float4*>(slab + (size_t)s * n + i);
-    a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+  const int o = threadIdx.x & 15, g = threadIdx.x >> 4;
+  const size_t i = ((size_t)blockIdx.x * 16 + o) * 4;
+  float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (i < n)
+    for (int sp = g; sp < splits; sp += 16) {
+      const float4 b = *reinterpret_cast<const float4*>(slab + (size_t)sp * n + i);
+      a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    }
+  red[threadIdx.x] = a;
+  __syncthreads();
+  if (g == 0 && i < n) {
+    float4 t = red[o];
+    for (int k = 1; k < 16; ++k) { const float4 b = red[k * 16 + o]; t.x += b.x; t.y += b.y; t.z += b.z; t.w += b.w; }
+    *reinterpret_cast<float4*>(out + i) = t;
   }
-  *reinterpret_cast<float4*>(out + i) = a;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1793,8 +1805,10 @@ static DmaSched plan_dma(int tiles_total, int tiles_per_z, int work, int slots, 
   int rem = tiles_total - rounds * slots;
   sc.full = rounds * slots; sc.tail_tiles = rem; sc.tail_s = 1; sc.per_split = work;
   if (rem == 0) return sc;
-  // cost in units of one stage-time of a resident workgroup (32 MFMAs per wave ~ 0.9 us): tail rounds x (stages per
-  // unit + ~4 of prologue / epilogue) + the slab round trip of the split tiles at ~5 TB/s + the reduce launch
+  // cost in units of one stage-time of a resident workgroup (32 MFMAs per wave, three waves sharing a SIMD: ~2.7 us):
+  // tail rounds x (stages per unit + ~4 of prologue / epilogue) + the slab round trip of the split tiles at ~5 TB/s
+  // (13.5 MB per unit) + the reduce launch.  Calibrated on the Winograd-plane launches of the warp step (M 800 x 36
+  // planes: 3 whole rounds 0.559 ms, 2 + a 3-way split tail 0.535 ms).
   int best = 1;
   double best_cost = 1e300;
   const int max_s = std::max(1, std::min(1024, work / 8));
@@ -1803,8 +1817,8 @@ static DmaSched plan_dma(int tiles_total, int tiles_per_z, int work, int slots, 
     const int per = ceil_div(work, sp), eff = ceil_div(work, per);
     const double tail_rounds = std::ceil((double)rem * eff / slots);
     double cost = tail_rounds * (per + 4.0);
-    if (eff > 1) cost += (double)rem * eff * (double)tile_bytes * 2.0 / 4.5e6 + 2.0;
-    if (cost < best_cost * 0.97) { best_cost = cost; best = eff; }
+    if (eff > 1) cost += (double)rem * eff * (double)tile_bytes * 2.0 / 13.5e6 + 2.0;
+    if (cost < best_cost * 0.985) { best_cost = cost; best = eff; }
   }
   sc.tail_s = best;
   sc.per_split = ceil_div(work, best);
@@ -1966,7 +1980,7 @@ static void launch_wgrad(Stream& s, GemmP& p, int batch) {
   check_launch("conv_wgrad");
   if (p.splits > 1) {
     const size_t n = (size_t)p.K * p.Npad;
-    hipLaunchKernelGGL(slab_sum_kernel, dim3((unsigned)((n / 4 + 255) / 256), batch), dim3(256), 0, hs(s), p.slab,
+    hipLaunchKernelGGL(slab_sum_kernel, dim3((unsigned)((n / 4 + 15) / 16), batch), dim3(256), 0, hs(s), p.slab,
                        const_cast<float*>(p.w), n, p.splits, p.slab_bs, p.w_bs);
     check_launch("slab_sum");
   }
@@ -2043,7 +2057,7 @@ void conv_wgrad(Stream& s, const ConvWgradArgs& a) {
     check_launch("tail_wgrad4");
     if (p.splits > 1) {
       const size_t n = (size_t)25 * KC * p.Npad;
-      hipLaunchKernelGGL(slab_sum_kernel, dim3((unsigned)((n / 4 + 255) / 256), 1), dim3(256), 0, hs(s), p.slab,
+      hipLaunchKernelGGL(slab_sum_kernel, dim3((unsigned)((n / 4 + 15) / 16), 1), dim3(256), 0, hs(s), p.slab,
                          const_cast<float*>(p.w), n, p.splits, (size_t)0, (size_t)0);
       check_launch("slab_sum");
     }

@@ -773,8 +773,25 @@ void Model::run_gradient_penalty(const TView& real, const TView& fake) {
   gp_alpha_set_ = gp_beta_set_ = false;
   scalar_axpby(ctx->s, losses + L_D, 1.f, losses + L_D_GP, 1.f, losses + L_D);     // loss_D += loss_D_gp (warp_model.py:136)
 }
+void Model::set_style_context(const float*, const float*, int, int) {
+  throw Error(1, "set_style_context: only the texture model has a style term");
+}
 void Model::perceptual(const float*, const float*, int, float*, float, float, float*) {
   throw Error(1, "perceptual: only the texture model carries the VGG16 network (not implemented for this model)");
+}
+
+void Model::optimizer_step_range(int net, size_t off, size_t count, int first) {
+  ParamArena& A = arena(net);
+  if (off % 4 || off + count > A.n) throw Error(1, "optimizer_step_range: range outside the arena / not 16-byte aligned");
+  if (first) A.step += 1;
+  if (count == 0) return;
+  AdamWArgs a;
+  a.p = A.w + off; a.g = A.g + off; a.m = A.m + off; a.v = A.v + off; a.n = (count + 3) / 4 * 4 <= A.n - off ? (count + 3) / 4 * 4 : count;
+  a.lr = net == 0 ? hyper.lr : hyper.d_lr;
+  a.weight_decay = net == 0 ? hyper.weight_decay : hyper.d_weight_decay;
+  a.beta1 = net == 0 ? hyper.b1 : hyper.d_b1; a.beta2 = net == 0 ? hyper.b2 : hyper.d_b2; a.eps = 1e-8f; a.step = A.step;
+  adamw_step(ctx->s, a);
+  A.version += 1;
 }
 
 // BaseGAN.optimize_parameters (models/base_gan.py:194-203): forward, D step, G step.

@@ -240,6 +240,10 @@ class Model {
   int backward_G_parts() const;
   void backward_G_part(float label_real, int part, size_t* ready_off, size_t* ready_count);
   void optimizer_step(int net);
+  // AdamW on the arena range [off, off + count) only (data parallel: a bucket is stepped as soon as its all-reduce
+  // has landed, under the back-propagation of the next bucket).  first != 0 opens a new optimizer step (advances
+  // the bias-correction counter); the ranges of one step must tile the arena.
+  void optimizer_step_range(int net, size_t off, size_t count, int first);
   void step(const float labels[3], bool training, uint64_t seed);
   // NLayerDiscriminator.forward (modules/discriminators.py:134-136) as a standalone call: x = the conditioned input
   // in the REFERENCE's channel order (B, 22, H, W) NCHW on the device, pred = (B, 1, H/8-2, W/8-2).  Runs on a
@@ -255,6 +259,12 @@ class Model {
   // one-shot random inputs of the next gradient-penalty pass (host-provided for seeded parity; see capi)
   void set_gp_random(const float* alpha_dev, const float* beta_nchw_dev);
   virtual bool supports_gradient_penalty() const { return false; }
+  // Data parallelism, texture stage: the style term's image Gram couples ALL samples of the global batch
+  // (modules/losses/perceptual.py:6-10,58-63).  The host all-gathers the generated and target images of every rank
+  // and hands them over ((n_total, 3, H, W) NCHW, this rank's samples start at n0); the next backward_G then evaluates
+  // the Gram over the global batch and back-propagates into the local samples -- identical to the one-process
+  // big-batch step.  One-shot (consumed by the next backward_G).
+  virtual void set_style_context(const float* all_out_nchw, const float* all_tgt_nchw, int n_total, int n0);
  protected:
   std::unique_ptr<GradPenalty> gp_;
   bool gp_alpha_set_ = false, gp_beta_set_ = false;

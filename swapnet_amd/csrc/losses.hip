@@ -300,6 +300,74 @@ __global__ __launch_bounds__(256) void gram_bwd_kernel(const float* a, int acs, 
   }
 }
 
+// ---- generic image-Gram kernels: any R = N*C (large batches, data-parallel global batches) -------------------------
+// G = X X^T for both images as 32 x 32 output tiles, the pixel axis split over blockIdx.y (deterministic partials, same
+// layout as gram_partial_kernel: partial[split][2][R][R])
+__global__ __launch_bounds__(256) void gram_tile_kernel(const float* a, int acs, const float* b, int bcs, int N, int HW, int C,
+                                                        int per_split, float* partial) {
+  __shared__ float xa[2][32][65], xb[2][32][65];     // [row panel | column panel][32 rows][64 px (+1)]
+  const int R = N * C, tr = (R + 31) / 32;
+  const int t0 = blockIdx.x / tr, t1 = blockIdx.x % tr;
+  const int r0 = t0 * 32, c0 = t1 * 32;
+  const int p_begin = blockIdx.y * per_split, p_end = min(HW, p_begin + per_split);
+  const int ty = threadIdx.x >> 5, tx = threadIdx.x & 31;          // thread owns entries (ty + 8 k, tx), k = 0..3
+  float sa[4] = {0, 0, 0, 0}, sb[4] = {0, 0, 0, 0};
+  for (int p0 = p_begin; p0 < p_end; p0 += 64) {
+    for (int i = threadIdx.x; i < 2 * 32 * 64; i += 256) {
+      const int panel = i >> 11, rr = (i >> 6) & 31, pp = i & 63;
+      const int r = (panel ? c0 : r0) + rr, pix = p0 + pp;
+      float va = 0.f, vb = 0.f;
+      if (r < R && pix < p_end) {
+        const int n = r / C, c = r - n * C;
+        va = a[((size_t)n * HW + pix) * acs + c];
+        vb = b[((size_t)n * HW + pix) * bcs + c];
+      }
+      xa[panel][rr][pp] = va; xb[panel][rr][pp] = vb;
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int pp = 0; pp < 64; ++pp) {
+      const float ca = xa[1][tx][pp], cb = xb[1][tx][pp];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        sa[k] = fmaf(xa[0][ty + 8 * k][pp], ca, sa[k]);
+        sb[k] = fmaf(xb[0][ty + 8 * k][pp], cb, sb[k]);
+      }
+    }
+    __syncthreads();
+  }
+  float* out = partial + (size_t)blockIdx.y * 2 * R * R;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int r = r0 + ty + 8 * k, c = c0 + tx;
+    if (r < R && c < R) { out[(size_t)r * R + c] = sa[k]; out[(size_t)R * R + (size_t)r * R + c] = sb[k]; }
+  }
+}
+// dA[r][p] (+)= sum_r' (dG[r][r'] + dG[r'][r]) A[r'][p] for the local rows r in [row0, row0 + Rloc): block = 32 pixels
+__global__ __launch_bounds__(256) void gram_bwd_generic_kernel(const float* a, int acs, const float* dG, int N, int HW, int C,
+                                                               int row0, int Rloc, float* da, int dcs, int accumulate) {
+  extern __shared__ float xs[];       // [R][33]
+  const int R = N * C;
+  const int p0 = blockIdx.x * 32;
+  for (int i = threadIdx.x; i < R * 32; i += 256) {
+    const int r = i >> 5, pp = i & 31;
+    const int n = r / C, c = r - n * C;
+    xs[r * 33 + pp] = p0 + pp < HW ? a[((size_t)n * HW + p0 + pp) * acs + c] : 0.f;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < Rloc * 32; i += 256) {
+    const int rl = i >> 5, pp = i & 31;
+    if (p0 + pp >= HW) continue;
+    const int r = row0 + rl;
+    float s = 0.f;
+    for (int r2 = 0; r2 < R; ++r2) s = fmaf(dG[(size_t)r * R + r2] + dG[(size_t)r2 * R + r], xs[r2 * 33 + pp], s);
+    const int nl = rl / C, c = rl - nl * C;
+    float* dp = da + ((size_t)nl * HW + p0 + pp) * dcs + c;
+    if (accumulate) s += *dp;
+    *dp = s;
+  }
+}
+
 // ---- gradient penalty helpers (ops.h) ----------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void gp_interp_kernel(const float* a, int acs, const float* b, int bcs, const float* alpha,
                                                         const float* beta, int becs, const float* half_std, float* out,
@@ -442,29 +510,57 @@ void normed_mse_loss(Stream& s, const TView& f, const TView& t, float scale, flo
 }
 
 void gram_style_loss(Stream& s, const TView& a, const TView& b, int C, float scale, float* loss_out, const TView* da,
-                     int accumulate) {
+                     int accumulate, int n0, int nloc) {
   const int R = a.N * C, HW = a.H * a.W;
-  if (R > 128) throw Error(1, "gram_style_loss: N*C > 128 unsupported");
-  const int chunk = 64;
-  const int nchunk = ceil_div(HW, chunk);
-  const size_t pbytes = (size_t)nchunk * 2 * R * R * 4;
-  const size_t off_dG = (pbytes + 255) / 256 * 256;
-  const size_t off_lp = off_dG + (size_t)R * R * 4 + 256;
+  if (nloc < 0) { n0 = 0; nloc = a.N; }
+  const double numel = (double)R * R;
   const int fgrid = ceil_div(R * R, 16);
+  if (R <= 128 && n0 == 0 && nloc == a.N) {        // whole Gram in LDS (the single-GPU default: 16 x 3 = 48 rows)
+    const int chunk = 64;
+    const int nchunk = ceil_div(HW, chunk);
+    const size_t pbytes = (size_t)nchunk * 2 * R * R * 4;
+    const size_t off_dG = (pbytes + 255) / 256 * 256;
+    const size_t off_lp = off_dG + (size_t)R * R * 4 + 256;
+    if (off_lp + 256 + (size_t)fgrid * 8 > s.ws_bytes) throw Error(1, "gram_style_loss: workspace too small");
+    float* partial = reinterpret_cast<float*>(s.ws);
+    float* dG = reinterpret_cast<float*>(s.ws + off_dG);
+    double* lp = reinterpret_cast<double*>(s.ws + (off_lp + 255) / 256 * 256);
+    hipLaunchKernelGGL(gram_partial_kernel, dim3(nchunk), dim3(256), 2 * R * (chunk + 1) * 4, hs(s), a.p, a.cs, b.p, b.cs,
+                       a.N, HW, C, chunk, partial);
+    hipLaunchKernelGGL(gram_final_kernel, dim3(fgrid), dim3(256), 0, hs(s), partial, nchunk, R, (float)(scale / numel),
+                       dG, lp);
+    hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(64), 0, hs(s), lp, fgrid, 1.0 / numel, loss_out);
+    if (da) {
+      const size_t total = (size_t)HW * R;
+      hipLaunchKernelGGL(gram_bwd_kernel, dim3(loss_grid(total)), dim3(256), R * R * 4, hs(s), a.p, a.cs, dG, a.N, HW, C,
+                         da->p, da->cs, accumulate);
+    }
+    check_launch("gram_style_loss");
+    return;
+  }
+  // generic path: large batches (R > 128) and the data-parallel form (global Gram, gradient for the local samples)
+  if (R > 1024) throw Error(1, "gram_style_loss: N*C > 1024 unsupported");
+  const int nsplit = std::max(1, std::min(64, HW / 256));
+  const int per_split = ceil_div(ceil_div(HW, nsplit), 64) * 64;
+  const int ns = ceil_div(HW, per_split);
+  const size_t pbytes = (size_t)ns * 2 * R * R * 4;
+  const size_t off_dG = (pbytes + 255) / 256 * 256;
+  const size_t off_lp = off_dG + ((size_t)R * R * 4 + 255) / 256 * 256;
   if (off_lp + 256 + (size_t)fgrid * 8 > s.ws_bytes) throw Error(1, "gram_style_loss: workspace too small");
   float* partial = reinterpret_cast<float*>(s.ws);
   float* dG = reinterpret_cast<float*>(s.ws + off_dG);
-  double* lp = reinterpret_cast<double*>(s.ws + (off_lp + 255) / 256 * 256);
-  const double numel = (double)R * R;
-  hipLaunchKernelGGL(gram_partial_kernel, dim3(nchunk), dim3(256), 2 * R * (chunk + 1) * 4, hs(s), a.p, a.cs, b.p, b.cs,
-                     a.N, HW, C, chunk, partial);
-  hipLaunchKernelGGL(gram_final_kernel, dim3(fgrid), dim3(256), 0, hs(s), partial, nchunk, R, (float)(scale / numel),
-                     dG, lp);
+  double* lp = reinterpret_cast<double*>(s.ws + off_lp);
+  const int tr = ceil_div(R, 32);
+  hipLaunchKernelGGL(gram_tile_kernel, dim3(tr * tr, ns), dim3(256), 0, hs(s), a.p, a.cs, b.p, b.cs, a.N, HW, C, per_split, partial);
+  hipLaunchKernelGGL(gram_final_kernel, dim3(fgrid), dim3(256), 0, hs(s), partial, ns, R, (float)(scale / numel), dG, lp);
   hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(64), 0, hs(s), lp, fgrid, 1.0 / numel, loss_out);
   if (da) {
-    const size_t total = (size_t)HW * R;
-    hipLaunchKernelGGL(gram_bwd_kernel, dim3(loss_grid(total)), dim3(256), R * R * 4, hs(s), a.p, a.cs, dG, a.N, HW, C,
-                       da->p, da->cs, accumulate);
+    const size_t smem = (size_t)R * 33 * 4;
+    static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(gram_bwd_generic_kernel),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, 1024 * 33 * 4), true);
+    (void)once;
+    hipLaunchKernelGGL(gram_bwd_generic_kernel, dim3(ceil_div(HW, 32)), dim3(256), smem, hs(s), a.p, a.cs, dG, a.N, HW, C,
+                       n0 * C, nloc * C, da->p, da->cs, accumulate);
   }
   check_launch("gram_style_loss");
 }

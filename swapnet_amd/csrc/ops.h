@@ -209,8 +209,10 @@ void l1_loss(Stream& s, const TView& a, const TView& b, int C, float scale, floa
 void normed_mse_loss(Stream& s, const TView& f, const TView& t, float scale, float* loss_out,
                      const TView* df, int accumulate);
 // style term: scale * MSE(Gram(a), Gram(b)), Gram over (N*C) x (H*W) of the raw images
+// Under data parallelism a, b are the GLOBAL batches (all ranks' images, gathered by the host) and the gradient is
+// produced for the nloc samples starting at n0 only (da: a view of those samples); n0 = 0, nloc < 0: whole batch.
 void gram_style_loss(Stream& s, const TView& a, const TView& b, int C, float scale, float* loss_out,
-                     const TView* da, int accumulate);
+                     const TView* da, int accumulate, int n0 = 0, int nloc = -1);
 // ---- gradient penalty (modules/loss.py:133-184; wgan-gp / dragan-gp / dragan-lp), see gp.cpp ---------------------
 // x_hat = a + alpha[n] * (b - a) per sample n.  b = the second view (wgan: the conditioned fakes) or, when b is NULL
 // (dragan), a + half_std[0] * beta with beta ~ U[0,1) the same shape as a (NHWC view; pad channels 0).

@@ -219,6 +219,21 @@ class TextureModel final : public Model {
     if (want_grad) nhwc_to_nchw(s, p_out_.g, d_output_nchw, 3);
   }
 
+  Var g_out_, g_tgt_;            // global batches of the data-parallel style term (lazily sized)
+  int style_total_ = 0, style_n0_ = 0;
+  bool style_ctx_ = false;
+  void set_style_context(const float* all_out, const float* all_tgt, int n_total, int n0) override {
+    if (!is_train) throw Error(1, "set_style_context: training model required");
+    if (n_total < B || n0 < 0 || n0 + B > n_total) throw Error(1, "set_style_context: local range outside the global batch");
+    if (!g_out_.v.p || g_out_.v.N != n_total) {
+      g_out_ = G->alloc_var(n_total, H, W, 4, false);
+      g_tgt_ = G->alloc_var(n_total, H, W, 4, false);
+    }
+    nchw_to_nhwc(ctx->s, all_out, n_total, 3, H, W, g_out_.v);
+    nchw_to_nhwc(ctx->s, all_tgt, n_total, 3, H, W, g_tgt_.v);
+    style_total_ = n_total; style_n0_ = n0; style_ctx_ = true;
+  }
+
   void set_input(int slot, const float* src, int N, int C, int Hh, int Ww) override {
     Stream& s = ctx->s;
     if (slot == 1) {                                   // rois (B,R,4)
@@ -308,7 +323,16 @@ class TextureModel final : public Model {
       VF->backward(false, true);                         // accumulates 2 * d/d(2x-1) into d(fakes)
       if (hyper.lambda_style != 0.f) {
         // 5 identical image-Gram terms (perceptual.py:58-63)
-        gram_style_loss(s, fakes, targets, 3, 5.f * hyper.lambda_style * gsc, losses + L_TMP3, &dfakes, 1);
+        if (style_ctx_) {
+          // data parallel: Gram over the gathered global batch, gradient for this rank's samples; the factor
+          // n_total / B undoes grad_scale = 1 / world (the term is the same global value on every rank, and each rank
+          // contributes exactly the rows it owns)
+          gram_style_loss(s, g_out_.v, g_tgt_.v, 3, 5.f * hyper.lambda_style * gsc * (float)style_total_ / (float)B, losses + L_TMP3,
+                          &dfakes, 1, style_n0_, B);
+          style_ctx_ = false;
+        } else {
+          gram_style_loss(s, fakes, targets, 3, 5.f * hyper.lambda_style * gsc, losses + L_TMP3, &dfakes, 1);
+        }
         scalar_axpby(s, losses + L_TMP3, 5.f * hyper.lambda_style, nullptr, 0.f, losses + L_G_STYLE);
       }
     }

@@ -243,6 +243,13 @@ class NativeModel:
         self.ctx.sync()
         return out
 
+    def set_style_context(self, all_out, all_tgt, n0):
+        """Global (all ranks') generated / target images for the style term of the next backward_G (data parallel)."""
+        o = all_out.detach().to(device=self.ctx.device, dtype=torch.float32).contiguous()
+        t = all_tgt.detach().to(device=self.ctx.device, dtype=torch.float32).contiguous()
+        self.lib.call("swn_model_set_style_context", self.handle, _C.ptr(o), _C.ptr(t), int(o.shape[0]), int(n0))
+        self._style_keep = (o, t)
+
     def set_gp_random(self, alpha=None, beta=None):
         """alpha (B,) / (B,1,1,1) and beta (B,22,H,W): the gradient-penalty draws of the next backward_D (one-shot)."""
         a = None if alpha is None else alpha.detach().reshape(-1).to(device=self.ctx.device, dtype=torch.float32).contiguous()
@@ -316,6 +323,9 @@ class NativeModel:
 
     def optimizer_step(self, net):
         self.lib.call("swn_model_optimizer_step", self.handle, net)
+
+    def optimizer_step_range(self, net, off, count, first):
+        self.lib.call("swn_model_optimizer_step_range", self.handle, net, C.c_size_t(off), C.c_size_t(count), int(bool(first)))
 
     def step(self, labels, training=True, seed=0):
         arr = (C.c_float * 3)(*[float(x) for x in labels])

@@ -158,12 +158,10 @@ class BaseGAN(BaseModel, ABC):
                 m.backward_D(labels[0], labels[1])
                 self._xchg.allreduce_mean(m.grad_arena(engine.NET_D))
                 m.optimizer_step(engine.NET_D)
-            gG = m.grad_arena(engine.NET_G)
-            for part in range(m.backward_G_parts()):         # each bucket's exchange overlaps the next part
-                off, cnt = m.backward_G_part(labels[2], part)
-                self._xchg.begin(gG[off:off + cnt])
-            self._xchg.finish()
-            m.optimizer_step(engine.NET_G)
+            if self.KIND == "texture" and getattr(self.opt, "lambda_style", 0) != 0:
+                parallel.gather_style_context(m, self.targets)      # the style Gram spans the global batch
+            # buckets: exchange of bucket k under the back-propagation of bucket k+1, its AdamW under the next exchange
+            parallel.generator_backward_with_exchange(m, labels[2], self._xchg)
         self._losses_stale = True
         self._fakes = None
 

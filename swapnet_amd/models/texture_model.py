@@ -31,6 +31,10 @@ class TextureModel(BaseGAN):
         self.visual_names = ["textures_unnormalized", "cloths_decoded", "fakes", "fakes_scaled"]
         if self.is_train:
             self.visual_names.append("targets_unnormalized")
+            if opt.lambda_style != 0 and getattr(opt, "batch_size", 1) * opt.texture_channels > 1024:
+                raise ValueError("texture stage with the style term on (lambda_style=%g): batch_size * texture_channels "
+                                 "must be <= 1024 (rows of the image Gram); got %d x %d"
+                                 % (opt.lambda_style, opt.batch_size, opt.texture_channels))
             self.criterion_perceptual = PerceptualLoss(use_style=opt.lambda_style != 0, backend=self.backend)
             self._init_vgg()
             self.backend.set_hyper(lambda_l1=opt.lambda_l1, lambda_content=opt.lambda_content,

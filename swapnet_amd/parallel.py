@@ -1,8 +1,17 @@
 """Data parallelism: one process per GPU, torch.distributed (backend "nccl" == RCCL on ROCm)
-over xGMI.  The hot path shards over the batch axis (InstanceNorm, RoIAlign and every loss are
-per-sample: SURVEY.md 8(e)); the only exchange is the gradient of each optimizer's arena,
-which is ONE flat fp32 buffer per network (G 550 MB, D 11 MB) -> one all-reduce each, no
-per-tensor launches.  The reference has no multi-GPU code at all; this is new design."""
+over xGMI.  The hot path shards over the batch axis: InstanceNorm and RoIAlign are per-sample and
+every loss is a batch mean, so summing per-rank gradients pre-scaled by 1/world
+reproduces the single-process big-batch step -- with ONE exception that needs data, not just gradients:
+the texture stage's style term.  `gram_matrix` views the batch as (B*C, H*W)
+(modules/losses/perceptual.py:6-10), so the Gram and its MSE couple the samples of ALL ranks
+(SURVEY.md 8(e) caveat 1; not negligible: with the default lambda_style = 1e-8 a per-rank Gram moves
+generator gradient tensors by >10 %).  `gather_style_context` therefore all-gathers the 3-channel
+generated / target images (12.6 MB per rank) and the library evaluates the Gram over the global
+batch, back-propagating into the local samples: tests/test_data_parallel.py checks that the
+two-rank step equals the big-batch step with the term on and off.  The only other exchange is the
+gradient of each optimizer's arena, which is ONE flat fp32 buffer per network (G 550 MB, D 11 MB) ->
+bucketed all-reduces, no per-tensor launches.  The reference has no multi-GPU code at all; this is
+new design."""
 import os
 
 import torch
@@ -28,14 +37,25 @@ class GradExchange:
     `finish()` makes the compute stream wait for it -- work enqueued between the two calls
     (the other network's forward/backward) overlaps with the transfer."""
 
-    def __init__(self, world=None):
+    def __init__(self, world=None, force=False):
+        """force=True issues the collectives even at world size 1 (a 1-rank RCCL all-reduce is an identity that still
+        exercises pointer wrapping of the arena slices and the stream ordering with the library's side stream)."""
         self.world = world if world is not None else (dist.get_world_size() if dist.is_initialized() else 1)
+        self.force = force and dist.is_initialized()
         self._pending = []
 
     def begin(self, flat):
-        if self.world <= 1:
+        if self.world <= 1 and not self.force:
             return
         self._pending.append((dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True), flat))
+
+    def wait_oldest(self):
+        """Make the compute stream wait for the oldest outstanding collective only; returns its buffer (or None)."""
+        if not self._pending:
+            return None
+        work, flat = self._pending.pop(0)
+        work.wait()
+        return flat
 
     def finish(self):
         # the mean needs no extra pass: every loss gradient is pre-scaled by 1/world
@@ -47,6 +67,42 @@ class GradExchange:
     def allreduce_mean(self, flat):
         self.begin(flat)
         self.finish()
+
+
+def gather_style_context(model, targets_local):
+    """Texture stage under data parallelism: all-gather the generated and the target images of every rank and hand them
+    to the library so that the style term's Gram spans the global batch (swn_model_set_style_context).  Call after
+    forward, before backward_G.  B x 3 x H x W floats per rank (12.6 MB at bs 16, 256 x 256): negligible next to the
+    gradient exchange."""
+    world, rank = dist.get_world_size(), dist.get_rank()
+    out = model.output()
+    tgt = targets_local.to(device=out.device, dtype=torch.float32).contiguous()
+    allo = torch.empty((world * out.shape[0],) + tuple(out.shape[1:]), dtype=torch.float32, device=out.device)
+    allt = torch.empty_like(allo)
+    dist.all_gather_into_tensor(allo, out.contiguous())
+    dist.all_gather_into_tensor(allt, tgt)
+    model.set_style_context(allo, allt, rank * out.shape[0])
+
+
+def generator_backward_with_exchange(model, label_real, xchg, net_g=0):
+    """backward_G in buckets with the exchange AND the optimizer pipelined behind it:
+        bwd part k ; begin all-reduce(bucket k) ; [wait bucket k-1 ; AdamW(bucket k-1)]
+    so a bucket's transfer runs under the next bucket's back-propagation and its AdamW under the transfer of the one
+    after.  Equivalent to backward_G + one all-reduce + optimizer_step (AdamW is elementwise on the arena)."""
+    gG = model.grad_arena(net_g)
+    ranges = []
+    for part in range(model.backward_G_parts()):
+        off, cnt = model.backward_G_part(label_real, part)
+        xchg.begin(gG[off:off + cnt])
+        if ranges:                                  # the previous bucket has had a whole part's time to arrive
+            xchg.wait_oldest()
+            o, c = ranges[-1]
+            model.optimizer_step_range(net_g, o, c, first=len(ranges) == 1)
+        ranges.append((off, cnt))
+    xchg.wait_oldest()
+    o, c = ranges[-1]
+    model.optimizer_step_range(net_g, o, c, first=len(ranges) == 1)
+    xchg.finish()
 
 
 def broadcast_arena(flat, src=0):

@@ -620,8 +620,10 @@ void normed_mse_loss(Stream&, const TView& f, const TView& t, float scale, float
   }
   *out = (float)(acc / numel);
 }
-void gram_style_loss(Stream&, const TView& a, const TView& b, int C, float scale, float* out, const TView* da, int accumulate) {
+void gram_style_loss(Stream&, const TView& a, const TView& b, int C, float scale, float* out, const TView* da, int accumulate,
+                     int n0, int nloc) {
   const int R = a.N * C, HW = a.H * a.W;
+  if (nloc < 0) { n0 = 0; nloc = a.N; }
   std::vector<double> Ga((size_t)R * R, 0.0), Gb((size_t)R * R, 0.0);
   auto val = [&](const TView& v, int r, int p) { return v.p[((size_t)(r / C) * HW + p) * v.cs + (r % C)]; };
   for (int r1 = 0; r1 < R; ++r1) for (int r2 = 0; r2 < R; ++r2) { double s1 = 0, s2 = 0;
@@ -630,9 +632,10 @@ void gram_style_loss(Stream&, const TView& a, const TView& b, int C, float scale
   double acc = 0; std::vector<float> dG((size_t)R * R);
   for (size_t i = 0; i < Ga.size(); ++i) { const double d = Ga[i] - Gb[i]; acc += d * d; dG[i] = (float)(2.0 * d) * scale / (float)(R * R); }
   *out = (float)(acc / ((double)R * R));
-  if (da) for (int p = 0; p < HW; ++p) for (int r = 0; r < R; ++r) { float s = 0;
+  if (da) for (int p = 0; p < HW; ++p) for (int rl = 0; rl < nloc * C; ++rl) { float s = 0;
+    const int r = n0 * C + rl;
     for (int r2 = 0; r2 < R; ++r2) s += (dG[(size_t)r * R + r2] + dG[(size_t)r2 * R + r]) * val(a, r2, p);
-    float* dp = da->p + ((size_t)(r / C) * HW + p) * da->cs + (r % C); *dp = accumulate ? *dp + s : s; }
+    float* dp = da->p + ((size_t)(rl / C) * HW + p) * da->cs + (rl % C); *dp = accumulate ? *dp + s : s; }
 }
 void gp_interpolate(Stream&, const TView& a, const TView* b, const float* alpha, const TView* beta, const float* half_std,
                     const TView& out) {

@@ -37,18 +37,11 @@ def _worker(rank, world, port, out_dir):
     m.backward_D(lab[0], lab[1])
     x.allreduce_mean(m.grad_arena(engine.NET_D))
     m.optimizer_step(engine.NET_D)
-    gG = m.grad_arena(engine.NET_G)
-    end = gG.numel()                                   # bucketed backward: exchange part p while part p+1 runs
-    nparts = m.backward_G_parts()
-    assert nparts >= 2
-    for part in range(nparts):
-        off, cnt = m.backward_G_part(lab[2], part)
-        assert cnt > 0 and off + cnt == end, (part, off, cnt, end)      # buckets tile the arena end -> start
-        x.begin(gG[off:off + cnt])
-        end = off
-    assert end == 0
-    x.finish()
-    m.optimizer_step(engine.NET_G)
+    # bucketed backward: exchange of bucket k under the back-propagation of bucket k+1, AdamW of a bucket as soon as its
+    # all-reduce landed (swn_model_optimizer_step_range) -- the production schedule of bench.py / base_gan
+    assert m.backward_G_parts() >= 2
+    parallel.generator_backward_with_exchange(m, lab[2], x)
+    assert m.optim_step_count(engine.NET_G) == 1
     if rank == 0:
         torch.save({"G": m.state_dict(0, to_cpu=True), "D": m.state_dict(1, to_cpu=True)}, os.path.join(out_dir, "dp.pt"))
     # replicas stay identical
@@ -83,6 +76,71 @@ def test_two_rank_gloo_step_equals_single_process_big_batch(tmp_path):
                 continue                       # round-off-only gradients
             err = float((dp[key][k] - v).norm() / (v.norm() + 1e-30))
             assert err < 2e-4, (key, k, err)
+
+
+def _texture_worker(rank, world, port, out_dir, lambda_style):
+    sys.path.insert(0, REPO)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(2)
+    from oracle import swapnet_oracle as O
+    from swapnet_amd import engine, parallel
+    from tests import backends
+    from tests.test_texture_step import vgg_state_dict
+    parallel.init_from_env(backend="gloo")
+    ctx = backends.hostsim_ctx()
+    torch.manual_seed(0)
+    G, D, vgg = O.texture_module_params(img_size=64), O.patchgan_params(22), O.vgg16_feature_params()
+    full = O.synth_texture_batch(world, 64, 64, seed=77)
+    m = engine.NativeModel(ctx, "texture", 1, 64, 64, is_train=True)
+    m.load_state_dict(0, G); m.load_state_dict(1, D); m.load_state_dict(2, vgg_state_dict(m, vgg))
+    m.set_hyper(grad_scale=1.0 / world, lambda_style=lambda_style)
+    for i, t in enumerate(full):
+        m.set_input(i, t[rank:rank + 1])
+    x = parallel.GradExchange(world)
+    lab = [0.9, 0.8, 1.0]
+    m.forward(False, 0)
+    m.backward_D(lab[0], lab[1])
+    x.allreduce_mean(m.grad_arena(engine.NET_D))
+    m.optimizer_step(engine.NET_D)
+    if lambda_style != 0:
+        parallel.gather_style_context(m, full[3][rank:rank + 1])
+    parallel.generator_backward_with_exchange(m, lab[2], x)
+    if rank == 0:
+        torch.save({"G": m.state_dict(0, to_cpu=True), "gG": m.state_dict(0, which=engine.W_GRAD, to_cpu=True)},
+                   os.path.join(out_dir, "dp_tex_%g.pt" % lambda_style))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("lambda_style", [0.0, 1e-8])
+def test_two_rank_texture_step_vs_big_batch(tmp_path, lambda_style):
+    """the texture stage under data parallelism equals the one-process big-batch step (to summation order)
+    with the style term off AND on: the style term's Gram spans the whole batch, so the ranks all-gather their 3-channel
+    images and the library evaluates it globally (parallel.gather_style_context).  (Without that, a per-rank Gram moved
+    generator gradient tensors by 12 % in this very test.)"""
+    from oracle import swapnet_oracle as O
+    from swapnet_amd import engine
+    from tests import backends
+    from tests.test_texture_step import noise_bias, vgg_state_dict
+    backends.build_hostsim()
+    port = 31500 + os.getpid() % 2000 + int(lambda_style > 0)
+    mp.spawn(_texture_worker, args=(2, port, str(tmp_path), lambda_style), nprocs=2, join=True)
+    dp = torch.load(os.path.join(tmp_path, "dp_tex_%g.pt" % lambda_style))
+    ctx = backends.hostsim_ctx()
+    torch.manual_seed(0)
+    G, D, vgg = O.texture_module_params(img_size=64), O.patchgan_params(22), O.vgg16_feature_params()
+    full = O.synth_texture_batch(2, 64, 64, seed=77)
+    m = engine.NativeModel(ctx, "texture", 2, 64, 64, is_train=True)
+    m.load_state_dict(0, G); m.load_state_dict(1, D); m.load_state_dict(2, vgg_state_dict(m, vgg))
+    m.set_hyper(lambda_style=lambda_style)
+    for i, t in enumerate(full):
+        m.set_input(i, t)
+    m.forward(False, 0); m.backward_D(0.9, 0.8); m.optimizer_step(1); m.backward_G(1.0)
+    gG = m.state_dict(0, which=engine.W_GRAD, to_cpu=True)
+    keys = list(G.keys())
+    worst = max(float((dp["gG"][k] - v).norm() / (v.norm() + 1e-30)) for k, v in gG.items() if not noise_bias(k, keys))
+    assert worst < 2e-4, worst
+    m.close()
 
 
 @pytest.mark.parametrize("backend", [pytest.param("sim", id="hostsim"),
@@ -161,3 +219,44 @@ def test_second_stream_leaves_results_bit_identical():
     for o in out[1:]:
         assert o[0] == out[0][0]
         assert torch.equal(o[1], out[0][1]) and torch.equal(o[2], out[0][2])
+
+
+@pytest.mark.gpu
+def test_one_rank_rccl_exchange_equals_the_fused_step():
+    """The N > 1 call sequence with REAL RCCL collectives (backend "nccl", world size 1: every all-reduce is an identity)
+    on the zero-copy arena slices: pointer wrapping, the ordering between torch's collective stream, the library's compute
+    stream and its weight-gradient side stream, and the ranged AdamW steps must reproduce swn_model_step bit for bit."""
+    from oracle import swapnet_oracle as O
+    from swapnet_amd import engine, parallel
+    from tests import backends
+    ctx = backends.gpu_ctx()
+    if not dist.is_initialized():
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29700 + os.getpid() % 200))
+        dist.init_process_group(backend="nccl", rank=0, world_size=1)
+    try:
+        torch.manual_seed(1)
+        G, D = O.warp_module_params(), O.patchgan_params(22)
+        batch = O.synth_warp_batch(4, 128, 128, seed=11)
+        m = engine.NativeModel(ctx, "warp", 4, 128, 128, is_train=True)
+        out = []
+        for mode in ("fused", "rccl"):
+            backends.reset_state(m, {engine.NET_G: G, engine.NET_D: D})
+            for i, t in enumerate(batch):
+                m.set_input(i, t)
+            for step in range(2):
+                lab = [0.9, 0.8, 1.0]
+                if mode == "fused":
+                    m.step(lab, training=True, seed=5 + step)
+                else:
+                    x = parallel.GradExchange(1, force=True)
+                    m.forward(True, 5 + step)
+                    m.backward_D(lab[0], lab[1])
+                    x.allreduce_mean(m.grad_arena(engine.NET_D))
+                    m.optimizer_step(engine.NET_D)
+                    parallel.generator_backward_with_exchange(m, lab[2], x)
+            out.append((m.losses(), m.weight_arena(0).clone().cpu(), m.weight_arena(1).clone().cpu(), m.optim_step_count(0)))
+        m.close()
+        assert out[0][0] == out[1][0] and out[0][3] == out[1][3] == 2
+        assert torch.equal(out[0][1], out[1][1]) and torch.equal(out[0][2], out[1][2])
+    finally:
+        dist.destroy_process_group()

@@ -123,7 +123,7 @@ def test_inference_only_generator_and_error_conventions(backend, tmp_path):
         find_model_using_name("pix2pix")
     from swapnet_amd.modules.loss import GANLoss
     with pytest.raises(NotImplementedError):
-        GANLoss("wgan-gp")
+        GANLoss("mescheder-r1-gp")          # in --gan_mode choices but not implemented, like the reference (loss.py:62)
     with pytest.raises(NotImplementedError):
         GANLoss("nonsense")
     from swapnet_amd import optimizers

@@ -137,3 +137,27 @@ def test_vgg_weights_file_is_loaded(tmp_path):
     assert model.vgg_source == path
     got = model.criterion_perceptual.state_dict()
     assert torch.equal(got["net.0.0.weight"].cpu(), vgg[0][0]) and torch.equal(got["net.4.28.bias"].cpu(), vgg[12][1])
+
+
+@pytest.mark.gpu
+def test_style_term_with_a_large_batch_uses_the_generic_gram_kernels(tmp_path):
+    """batch_size * 3 > 128 rows of the image Gram (bs >= 43) used to raise; the tiled Gram kernels have no
+    such limit.  PerceptualLoss(use_style=True) at bs 44 against the oracle, value and gradient."""
+    from swapnet_amd.models import create_model
+    opt = make_opt(tmp_path, "gpu", model="texture", batch_size=44)
+    with pytest.warns(RuntimeWarning):
+        model = create_model(opt)
+    crit = model.criterion_perceptual
+    vgg = O.vgg16_feature_params()
+    names = list(crit.native_param_shapes().keys())
+    crit.load_state_dict({names[2 * i + j]: t for i, wb in enumerate(vgg) for j, t in enumerate(wb)})
+    g = torch.Generator().manual_seed(6)
+    out = (torch.rand(44, 3, 64, 64, generator=g) * 2 - 1).requires_grad_(True)
+    tgt = torch.rand(44, 3, 64, 64, generator=g) * 2 - 1
+    content, style = crit(out, tgt)
+    o2 = out.detach().clone().requires_grad_(True)
+    rc, rs = O.perceptual_loss(vgg, o2, tgt, use_style=True)
+    assert abs(float(style) - float(rs)) <= 1e-3 * abs(float(rs)) and abs(float(content) - float(rc)) <= 1e-3 * abs(float(rc))
+    (1e-8 * style).backward()
+    (1e-8 * rs).backward()
+    assert rel(out.grad, o2.grad) < 2e-3
