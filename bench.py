@@ -309,6 +309,19 @@ def main():
             fence()
             d1 = (time.perf_counter() - t1) / args.steps
             res[name] = {"images_per_sec": round(B / d1, 2), "ms_per_step": round(d1 * 1e3, 3)}
+        # what the box's host->device link itself delivers (plain torch copies of one 256 MB buffer, best of 5): the
+        # PCIe-inclusive rates above are bounded by this, not by the library
+        raw = {}
+        probe = torch.empty(64 << 20, dtype=torch.float32)
+        dst = torch.empty_like(probe, device="cuda")
+        for name, src in (("pageable", probe), ("pinned", probe.pin_memory())):
+            best = 0.0
+            for _ in range(5):
+                torch.cuda.synchronize(); t1 = time.perf_counter()
+                dst.copy_(src, non_blocking=True); torch.cuda.synchronize()
+                best = max(best, probe.numel() * 4 / (time.perf_counter() - t1) / 1e9)
+            raw[name] = round(best, 2)
+        res["raw_h2d_GBps"] = raw
         res["h2d_bytes_per_step"] = {"onehot_fp32": sum(t.numel() * 4 for t in host),
                                      "label_maps": host[0].numel() * 4 + sum(t.numel() * 4 for t in labels)}
         out["h2d_inclusive"] = res

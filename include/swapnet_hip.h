@@ -124,6 +124,17 @@ int swn_model_get_tap_grad(swn_model* m, int net, const char* name, float* dev_n
  * tensor of `shape` (channel count = the padded channel count of the layer).  dst may be NULL to query the
  * shape.  Diagnostic: lets a parity test replay the exact masks in the CPU oracle. */
 int swn_model_dropout_sites(swn_model* m, int net, int* count);
+/* Diagnostic export for parity tests: the branch every piecewise-linear op of the last pass took.  LeakyReLU / ReLU
+ * (kind 1): byte 1 where the activation output is > 0, i.e. the side the backward pass differentiates on; MaxPool2d
+ * (kind 2): the window position 2*kh + kw that receives the gradient.  NCHW bytes on the device, `shape` = (N,C,H,W)
+ * with C the buffer's (possibly padded) channel count; dev_nchw = NULL only queries shape / kind.  Sites are numbered
+ * in forward order per network: net 0 = generator, 1 = discriminator of the D step (samples [0,B) generated, [B,2B)
+ * real), 2 = discriminator as re-evaluated inside the G step, 3 = VGG16 on the generated image (texture model).
+ * Why: an fp32 pass in a different summation order leaves a handful of pre-activations on the other side of zero and
+ * each flip moves the gradient by O(1) of that element (rel-L2 ~1e-3 on PatchGAN at 256x256, for torch's own fp32
+ * backward as much as for this library); with the pattern replayed in the float64 oracle the comparison is ~1e-5. */
+int swn_model_act_sites(swn_model* m, int net, int* count);
+int swn_model_act_pattern(swn_model* m, int net, int site, uint8_t* dev_nchw, int shape[4], int* kind);
 int swn_model_dropout_mask(swn_model* m, int net, int site, uint64_t dropout_seed, float* dev_nchw, int shape[4],
                            float* p);
 

@@ -220,6 +220,143 @@ def _dropout(x, p, training):
     return F.dropout(x, p, bool(training))
 
 
+class _ActReplayFn(torch.autograd.Function):
+    """LeakyReLU / ReLU whose BACKWARD differentiates on a given side (mask) instead of on sign(x)."""
+
+    @staticmethod
+    def forward(ctx, x, mask, slope):
+        ctx.save_for_backward(mask)
+        ctx.slope = slope
+        return F.leaky_relu(x, slope) if slope else F.relu(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        (mask,) = ctx.saved_tensors
+        return g * torch.where(mask, 1.0, ctx.slope).to(g.dtype), None, None
+
+
+class _PoolReplayFn(torch.autograd.Function):
+    """MaxPool2d(2,2) that takes a given window element (idx = 2*kh + kw) and routes the gradient to it."""
+
+    @staticmethod
+    def forward(ctx, x, idx):
+        N, C, H, W = x.shape
+        win = x.reshape(N, C, H // 2, 2, W // 2, 2).permute(0, 1, 2, 4, 3, 5).reshape(N, C, H // 2, W // 2, 4)
+        ctx.save_for_backward(idx)
+        ctx.shape = x.shape
+        return win.gather(4, idx.unsqueeze(-1)).squeeze(-1)
+
+    @staticmethod
+    def backward(ctx, g):
+        (idx,) = ctx.saved_tensors
+        N, C, H, W = ctx.shape
+        win = torch.zeros(N, C, H // 2, W // 2, 4, dtype=g.dtype)
+        win.scatter_(4, idx.unsqueeze(-1), g.unsqueeze(-1))
+        return win.reshape(N, C, H // 2, W // 2, 2, 2).permute(0, 1, 2, 4, 3, 5).reshape(N, C, H, W), None
+
+
+class PatternReplay:
+    """The piecewise-linear ops of a network (LeakyReLU, ReLU, MaxPool) take, in the BACKWARD pass, the branches a HIP
+    run exported (swn_model_act_pattern) instead of the ones this evaluation's own values select.  Why: two evaluations
+    of the same network in different summation orders leave a handful of pre-activations (|x| within round-off of 0)
+    on opposite sides; each such flip changes d(loss)/dx of that element by O(1), and on PatchGAN at 256x256 two to six
+    flips out of 2M elements ARE the whole ~1e-3 rel-L2 distance between any two fp32 gradients (torch's own fp32 CPU
+    backward against float64 included).  With the pattern pinned, what is left is the arithmetic error of the kernels.
+    groups: {name: [(kind, uint8 NCHW tensor), ...]} in forward order; kind 1 = output > 0, 2 = pool arg-max.
+    Use: `with replay.scope("D", slice(0, B)):` around the forward of the network the group belongs to."""
+
+    current = None          # (replay, group name, [next site], batch slice)
+
+    def __init__(self, groups):
+        self.groups = groups
+        self.flips = {}             # group -> elements whose own branch differs from the replayed one
+        self.elements = {}
+        self.used = {}
+
+    class _Scope:
+        def __init__(self, replay, name, sl):
+            self.state = (replay, name, [0], sl)
+
+        def __enter__(self):
+            self.prev, PatternReplay.current = PatternReplay.current, self.state
+            return self
+
+        def __exit__(self, *exc):
+            r, name, i, _ = self.state
+            if exc[0] is None:
+                assert i[0] == len(r.groups[name]), ("pattern replay", name, "sites used", i[0], "of", len(r.groups[name]))
+            r.used[name] = i[0]
+            PatternReplay.current = self.prev
+
+    def scope(self, name, batch=None):
+        return PatternReplay._Scope(self, name, batch)
+
+    @staticmethod
+    def _next(kind, x):
+        r, name, i, sl = PatternReplay.current
+        k, pat = r.groups[name][i[0]]
+        i[0] += 1
+        assert k == kind, ("pattern replay", name, i[0] - 1, "kind", k, "expected", kind)
+        if sl is not None:
+            pat = pat[sl]
+        return r, name, pat
+
+    @staticmethod
+    def act(x, slope):
+        r, name, pat = PatternReplay._next(1, x)
+        assert pat.shape[0] == x.shape[0] and pat.shape[2:] == x.shape[2:] and pat.shape[1] >= x.shape[1], (name, pat.shape, x.shape)
+        mask = pat[:, :x.shape[1]] != 0
+        own = x.detach() > 0
+        n_pos, n_neg = int((mask & ~own).sum()), int((own & ~mask).sum())
+        # in front of a dropout the export reads 0 for every dropped element (its gradient is 0 on either side):
+        # there only the exported-positive direction is informative; genuine flips are symmetric
+        n = 2 * n_pos if n_neg > 0.05 * mask.numel() else n_pos + n_neg
+        r.flips[name] = r.flips.get(name, 0) + n
+        r.elements[name] = r.elements.get(name, 0) + mask.numel()
+        return _ActReplayFn.apply(x, mask, slope)
+
+    @staticmethod
+    def pool(x):
+        r, name, pat = PatternReplay._next(2, x)
+        assert pat.shape[0] == x.shape[0] and pat.shape[2] * 2 == x.shape[2] and pat.shape[1] >= x.shape[1], (name, pat.shape, x.shape)
+        idx = pat[:, :x.shape[1]].long()
+        own = F.max_pool2d(x.detach(), 2, 2)
+        y = _PoolReplayFn.apply(x, idx)
+        r.flips[name] = r.flips.get(name, 0) + int((y.detach() != own).sum())
+        r.elements[name] = r.elements.get(name, 0) + idx.numel()
+        return y
+
+    def check(self, max_fraction=1e-3):
+        """A mis-ordered replay disagrees on ~half the elements; a correct one on a few per million."""
+        for name, n in self.flips.items():
+            assert n <= max_fraction * self.elements[name], ("pattern replay: wrong site order?", name, n, self.elements[name])
+        return dict(self.flips)
+
+
+def _lrelu(x):
+    return PatternReplay.act(x, 0.2) if PatternReplay.current else F.leaky_relu(x, 0.2)
+
+
+def _relu(x):
+    return PatternReplay.act(x, 0.0) if PatternReplay.current else F.relu(x)
+
+
+def _maxpool(x):
+    return PatternReplay.pool(x) if PatternReplay.current else F.max_pool2d(x, 2, 2)
+
+
+class _NoScope:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        return False
+
+
+def _pscope(replay, name, batch=None):
+    return replay.scope(name, batch) if replay is not None else _NoScope()
+
+
 def _inorm(x):
     # nn.InstanceNorm2d(affine=False, track_running_stats=False), eps 1e-5, biased var
     # (modules/__init__.py:66-69)
@@ -231,7 +368,7 @@ def unet_down(x, w, normalize=True, dropout=0.0, training=False):
     x = F.conv2d(x, w, None, stride=2, padding=1)
     if normalize:
         x = _inorm(x)
-    x = F.leaky_relu(x, 0.2)
+    x = _lrelu(x)
     if dropout:
         x = _dropout(x, dropout, training)
     return x
@@ -240,7 +377,7 @@ def unet_down(x, w, normalize=True, dropout=0.0, training=False):
 def unet_up(x, w, skips=(), dropout=0.0, training=False):
     """UNetUp / DualUNetUp.forward (modules/layers.py:27-63)."""
     x = F.conv_transpose2d(x, w, None, stride=2, padding=1)
-    x = F.relu(_inorm(x))
+    x = _relu(_inorm(x))
     if dropout:
         x = _dropout(x, dropout, training)
     if skips:
@@ -251,7 +388,7 @@ def unet_up(x, w, skips=(), dropout=0.0, training=False):
 def residual_block(x, w1, b1, w2, b2, dropout=0.0, training=False):
     """ResidualBlock.forward (modules/layers.py:126-144)."""
     h = F.conv2d(F.pad(x, (1, 1, 1, 1), mode="reflect"), w1, b1)
-    h = F.relu(_inorm(h))
+    h = _relu(_inorm(h))
     h = _dropout(h, dropout, training)
     h = F.conv2d(F.pad(h, (1, 1, 1, 1), mode="reflect"), w2, b2)
     return x + _inorm(h)
@@ -294,14 +431,14 @@ def warp_module_forward(P, body, cloth, dropout=0.5, training=False, taps=None):
 def patchgan_forward(P, x, n_layers=3, taps=None):
     """NLayerDiscriminator.forward (modules/discriminators.py:110-136)."""
     t = taps if taps is not None else {}
-    x = t["d0"] = F.leaky_relu(F.conv2d(x, P["model.0.weight"], P["model.0.bias"], stride=2, padding=1), 0.2)
+    x = t["d0"] = _lrelu(F.conv2d(x, P["model.0.weight"], P["model.0.bias"], stride=2, padding=1))
     idx = 2
     for n in range(1, n_layers):
         x = F.conv2d(x, P["model.%d.weight" % idx], P["model.%d.bias" % idx], stride=2, padding=1)
-        x = t["d%d" % n] = F.leaky_relu(_inorm(x), 0.2)
+        x = t["d%d" % n] = _lrelu(_inorm(x))
         idx += 3
     x = F.conv2d(x, P["model.%d.weight" % idx], P["model.%d.bias" % idx], stride=1, padding=1)
-    x = t["d%d" % n_layers] = F.leaky_relu(_inorm(x), 0.2)
+    x = t["d%d" % n_layers] = _lrelu(_inorm(x))
     idx += 3
     return F.conv2d(x, P["model.%d.weight" % idx], P["model.%d.bias" % idx], stride=1, padding=1)
 
@@ -407,19 +544,19 @@ def unet_generator_forward(P, x, num_downs, prefix="unet.model", dropout=True, t
         if outermost:
             h = F.conv2d(x, P[p + ".model.0.weight"], P[p + ".model.0.bias"], stride=2, padding=1)
             h = block(d + 1, h)
-            h = F.relu(h)
+            h = _relu(h)
             h = F.conv_transpose2d(h, P[p + ".model.3.weight"], P[p + ".model.3.bias"], stride=2, padding=1)
             return torch.tanh(h)
-        xl = F.leaky_relu(x, 0.2)                 # in-place in the reference: x itself becomes xl
+        xl = _lrelu(x)                 # in-place in the reference: x itself becomes xl
         h = F.conv2d(xl, P[p + ".model.1.weight"], P[p + ".model.1.bias"], stride=2, padding=1)
         if innermost:
-            h = F.relu(h)
+            h = _relu(h)
             h = F.conv_transpose2d(h, P[p + ".model.3.weight"], P[p + ".model.3.bias"], stride=2, padding=1)
             h = _inorm(h)
         else:
             h = _inorm(h)
             h = block(d + 1, h)
-            h = F.relu(h)
+            h = _relu(h)
             h = F.conv_transpose2d(h, P[p + ".model.5.weight"], P[p + ".model.5.bias"], stride=2, padding=1)
             h = _inorm(h)
             # Dropout(0.5) on the num_downs-5 inner ngf*8 blocks (:144-152,251-252)
@@ -524,17 +661,18 @@ def vgg_slice_features(vgg, x):
             if kind == "conv":
                 x = F.conv2d(x, vgg[i][0], vgg[i][1], padding=1)
             elif kind == "relu":
-                x = F.relu(x)
+                x = _relu(x)
             else:
-                x = F.max_pool2d(x, 2, 2)
+                x = _maxpool(x)
         feats.append(x / (torch.sqrt(torch.pow(x, 2).sum(1, keepdim=True)) + 1e-8))
     return feats
 
 
-def perceptual_loss(vgg, output, target, use_style=True):
+def perceptual_loss(vgg, output, target, use_style=True, patterns=None):
     """PerceptualLoss.forward (modules/losses/perceptual.py:49-66).  Style term is
     the Gram of the raw IMAGES added once per VGG slice (5x), :58-63."""
-    out_f = vgg_slice_features(vgg, output)
+    with _pscope(patterns, "VGG"):
+        out_f = vgg_slice_features(vgg, output)
     with torch.no_grad():
         tgt_f = vgg_slice_features(vgg, target)
     content = sum(F.mse_loss(o, t) for o, t in zip(out_f, tgt_f))
@@ -621,6 +759,7 @@ class WarpStepOracle:
         self.optG = AdamWState(self.G, self.h["lr"], self.h["weight_decay"], (self.h["b1"], self.h["b2"]))
         self.optD = AdamWState(self.D, self.h["d_lr"], self.h["d_weight_decay"], (self.h["b1"], self.h["b2"]))
         self.training = training
+        self.patterns = None        # a PatternReplay: groups "G", "D" (batch [fake | real]), "D_G"
         self.losses = OrderedDict()
         self.labels = []
 
@@ -634,7 +773,9 @@ class WarpStepOracle:
         h = self.h
         bodys, inputs, targets = bodys.to(self.dtype), inputs.to(self.dtype), targets.to(self.dtype)
         G, D = _leaf(self.G), _leaf(self.D)
-        fakes = warp_module_forward(G, bodys, inputs, training=self.training)         # :106-107
+        rp, B = self.patterns, bodys.shape[0]
+        with _pscope(rp, "G"):
+            fakes = warp_module_forward(G, bodys, inputs, training=self.training)     # :106-107
         draw = (lambda i: smooth_label().to(self.dtype)) if labels is None else (lambda i: torch.tensor([labels[i]], dtype=self.dtype))
         if "wgan" in h["gan_mode"] and labels is None:      # GANLoss.__call__ draws no target in the wgan modes (loss.py:124-128)
             draw = lambda i: torch.zeros(1, dtype=self.dtype)
@@ -650,10 +791,12 @@ class WarpStepOracle:
             return self.losses
         # ---- backward_D (warp_model.py:109-139)
         cond_fake = torch.cat((bodys, fakes), 1)
-        pred_fake = patchgan_forward(D, cond_fake.detach())
+        with _pscope(rp, "D", slice(0, B)):
+            pred_fake = patchgan_forward(D, cond_fake.detach())
         l_fake = draw(0)
         loss_D_fake = gan_loss(pred_fake, l_fake, h["gan_mode"], False)
-        pred_real = patchgan_forward(D, torch.cat((bodys, targets), 1))
+        with _pscope(rp, "D", slice(B, 2 * B)):
+            pred_real = patchgan_forward(D, torch.cat((bodys, targets), 1))
         l_real = draw(1)
         loss_D_real = gan_loss(pred_real, l_real, h["gan_mode"], True)
         loss_D = 0.5 * (loss_D_fake + loss_D_real)          # lambda_discriminator ignored (:123)
@@ -670,7 +813,8 @@ class WarpStepOracle:
         # ---- backward_G (warp_model.py:141-167) with the UPDATED D
         D2 = OrderedDict((k, v.detach()) for k, v in self.D.items())
         loss_ce = F.cross_entropy(fakes, torch.argmax(targets, dim=1)) * h["lambda_ce"]
-        pred = patchgan_forward(D2, torch.cat((bodys, fakes), 1))
+        with _pscope(rp, "D_G"):
+            pred = patchgan_forward(D2, torch.cat((bodys, fakes), 1))
         l_g = draw(2)
         loss_G_gan = gan_loss(pred, l_g, h["gan_mode"], True) * h["lambda_gan"]
         loss_G = loss_G_gan + loss_ce
@@ -700,6 +844,7 @@ class TextureStepOracle:
         self.optG = AdamWState(self.G, self.h["lr"], self.h["weight_decay"], (self.h["b1"], self.h["b2"]))
         self.optD = AdamWState(self.D, self.h["d_lr"], self.h["d_weight_decay"], (self.h["b1"], self.h["b2"]))
         self.training = training
+        self.patterns = None        # a PatternReplay: groups "G", "D" (batch [fake | real]), "D_G", "VGG"
 
     def astype(self, dtype):
         return _clone_step_oracle(self, dtype)
@@ -708,13 +853,17 @@ class TextureStepOracle:
         h = self.h
         textures, cloths, targets = textures.to(self.dtype), cloths.to(self.dtype), targets.to(self.dtype)
         G, D = _leaf(self.G), _leaf(self.D)
-        fakes = texture_module_forward(G, textures, rois, cloths, training=self.training)   # :121-125
+        rp, B = self.patterns, textures.shape[0]
+        with _pscope(rp, "G"):
+            fakes = texture_module_forward(G, textures, rois, cloths, training=self.training)   # :121-125
         draw = (lambda i: smooth_label().to(self.dtype)) if labels is None else (lambda i: torch.tensor([labels[i]], dtype=self.dtype))
         # ---- backward_D (:127-155)
-        pred_fake = patchgan_forward(D, torch.cat((cloths, fakes), 1).detach())
+        with _pscope(rp, "D", slice(0, B)):
+            pred_fake = patchgan_forward(D, torch.cat((cloths, fakes), 1).detach())
         l_fake = draw(0)
         loss_D_fake = gan_loss(pred_fake, l_fake, h["gan_mode"], False)
-        pred_real = patchgan_forward(D, torch.cat((cloths, targets), 1))
+        with _pscope(rp, "D", slice(B, 2 * B)):
+            pred_real = patchgan_forward(D, torch.cat((cloths, targets), 1))
         l_real = draw(1)
         loss_D_real = gan_loss(pred_real, l_real, h["gan_mode"], True)
         loss_D = 0.5 * (loss_D_fake + loss_D_real)
@@ -723,11 +872,12 @@ class TextureStepOracle:
         self.optD.apply(self.D, self.grads_D)
         # ---- backward_G (:157-180)
         D2 = OrderedDict((k, v.detach()) for k, v in self.D.items())
-        pred = patchgan_forward(D2, torch.cat((cloths, fakes), 1))
+        with _pscope(rp, "D_G"):
+            pred = patchgan_forward(D2, torch.cat((cloths, fakes), 1))
         l_g = draw(2)
         loss_G_gan = gan_loss(pred, l_g, h["gan_mode"], True) * h["lambda_gan"]
         loss_G_l1 = F.l1_loss(fakes, targets) * h["lambda_l1"]
-        content, style = perceptual_loss(self.vgg, fakes, targets, use_style=h["lambda_style"] != 0)
+        content, style = perceptual_loss(self.vgg, fakes, targets, use_style=h["lambda_style"] != 0, patterns=rp)
         loss_G_content = content * h["lambda_content"]
         loss_G_style = style * h["lambda_style"]
         loss_G = loss_G_gan + loss_G_l1 + loss_G_content + loss_G_style

@@ -56,6 +56,8 @@ _PROTOS = {
     "swn_model_get_tap": ([_vp, _i, C.c_char_p, _fp, C.POINTER(_i * 4)], _i),
     "swn_model_get_tap_grad": ([_vp, _i, C.c_char_p, _fp, C.POINTER(_i * 4)], _i),
     "swn_model_dropout_sites": ([_vp, _i, C.POINTER(_i)], _i),
+    "swn_model_act_sites": ([_vp, _i, C.POINTER(_i)], _i),
+    "swn_model_act_pattern": ([_vp, _i, _i, _vp, C.POINTER(_i * 4), C.POINTER(_i)], _i),
     "swn_model_dropout_mask": ([_vp, _i, _i, C.c_uint64, _fp, C.POINTER(_i * 4), C.POINTER(_f)], _i),
     "swn_pipeline_create": ([_vp, _vp, C.POINTER(_vp)], _i),
     "swn_pipeline_destroy": ([_vp], _i),

@@ -246,6 +246,29 @@ int swn_model_dropout_mask(swn_model* m, int net, int site, uint64_t seed, float
     if (dst) dropout_mask(m->m->ctx->s, d.N, d.H, d.W, d.C, d.p, Net::drop_seed(seed, d.salt), dst);
   });
 }
+int swn_model_act_sites(swn_model* m, int net, int* count) {
+  return guard([&] {
+    REQUIRE(m && count, "NULL argument");
+    Net* n = m->m->net_for_patterns(net);
+    REQUIRE(n, "no such network");
+    *count = (int)n->act_sites.size();
+  });
+}
+int swn_model_act_pattern(swn_model* m, int net, int site, uint8_t* dst, int shape[4], int* kind) {
+  return guard([&] {
+    REQUIRE(m, "NULL argument");
+    Net* n = m->m->net_for_patterns(net);
+    REQUIRE(n, "no such network");
+    REQUIRE(site >= 0 && site < (int)n->act_sites.size(), "activation site out of range");
+    const Net::ActSite& a = n->act_sites[site];
+    if (shape) { shape[0] = a.y.N; shape[1] = a.y.C; shape[2] = a.y.H; shape[3] = a.y.W; }
+    if (kind) *kind = a.kind;
+    if (dst) {
+      if (a.kind == 2) pool_pattern(m->m->ctx->s, a.x, a.y, dst);
+      else act_pattern(m->m->ctx->s, a.y, dst);
+    }
+  });
+}
 int swn_model_set_style_context(swn_model* m, const float* all_out, const float* all_tgt, int n_total, int n0) {
   return guard([&] { REQUIRE(m && all_out && all_tgt, "NULL argument"); m->m->set_style_context(all_out, all_tgt, n_total, n0); });
 }

@@ -179,6 +179,7 @@ void Net::conv(const std::string& name, const Var& x, const Var& y, ConvKind kin
   const int bi = bias ? arena.add_bias(name + ".bias", Co) : -1;
   const int Cop = round_up(Co, 4);
   if (y.v.C != Cop) throw Error(1, "conv " + name + ": output view must have round_up(Co,4) channels");
+  note_act(actf, y.v);
 
   auto op = std::make_unique<Op>();
   Op* self = op.get();
@@ -494,6 +495,8 @@ void Net::norm_act(const Var& raw, const Var& y, bool norm, int actf, float drop
   last_stats = stats;
   const uint64_t salt = ops.size() + 1;
   if (drop_p > 0.f) drop_sites.push_back({salt, raw.v.N, raw.v.H, raw.v.W, raw.v.C, drop_p});
+  if (residual && actf != ACT_NONE) throw Error(1, "norm_act: an activation in front of a residual add is not supported");
+  note_act(actf, y.v);        // a dropped element reads 0: its gradient is 0 whichever side the pattern records
   const TView rv = raw.v, rg = raw.g, yv = y.v, yg = y.g;
   const bool has_res = residual != nullptr;
   const Var res = has_res ? *residual : Var();
@@ -520,6 +523,7 @@ void Net::norm_act(const Var& raw, const Var& y, bool norm, int actf, float drop
 void Net::act(const Var& x, const Var& y, int actf) {
   auto op = std::make_unique<Op>();
   op->label = "act";
+  note_act(actf, y.v);
   const TView xv = x.v, yv = y.v, xg = x.g, yg = y.g;
   op->fwd = [=](Net& n) { act_fwd(n.ctx.s, xv, yv, actf); };
   const bool do_bwd = x.has_grad && y.has_grad;
@@ -559,6 +563,7 @@ void Net::upsample(const Var& x, const Var& y, int f) {
 void Net::maxpool(const Var& x, const Var& y) {
   auto op = std::make_unique<Op>();
   op->label = "maxpool";
+  act_sites.push_back({2, y.v, x.v});
   const TView xv = x.v, yv = y.v, xg = x.g, yg = y.g;
   op->fwd = [=](Net& n) { maxpool2_fwd(n.ctx.s, xv, yv); };
   const bool do_bwd = x.has_grad && y.has_grad;

@@ -121,6 +121,11 @@ class Net {
   struct DropSite { uint64_t salt; int N, H, W, C; float p; };
   std::vector<DropSite> drop_sites;
   static uint64_t drop_seed(uint64_t seed, uint64_t salt) { return seed * 0x9E3779B1ull + salt; }
+  // piecewise-linear ops in forward order: what swn_model_act_pattern exports (ops.h act_pattern / pool_pattern).
+  // kind 1 = LeakyReLU / ReLU (fused into a conv, a norm_act or standalone): sign of the output y; kind 2 = MaxPool2d(2,2)
+  struct ActSite { int kind; TView y, x; };
+  std::vector<ActSite> act_sites;
+  void note_act(int actf, const TView& y) { if (actf == ACT_LRELU || actf == ACT_RELU) act_sites.push_back({1, y, TView()}); }
 
   Var alloc_var(int N, int H, int W, int C, bool need_grad);
   // layers
@@ -280,6 +285,9 @@ class Model {
     return nullptr;
   }
   Net* net_for_taps(int net) { return net == 0 ? G.get() : D2.get(); }
+  // swn_model_act_pattern: 0 = generator, 1 = discriminator of the D step (batch [fake | real]), 2 = discriminator as
+  // re-evaluated in the G step (fake only, updated weights), 3 = VGG16 on the generated image (texture model)
+  virtual Net* net_for_patterns(int net) { return net == 0 ? G.get() : net == 1 ? D2.get() : net == 2 ? D1.get() : nullptr; }
 };
 
 // ---------------------------------------------------------------------------------------------------------------

@@ -153,6 +153,31 @@ __global__ __launch_bounds__(256) void maxpool_kernel(const float* x, int xcs, f
   }
 }
 
+__global__ __launch_bounds__(256) void act_pattern_kernel(const float* y, int ycs, int N, int HW, int C, uint8_t* out) {
+  const size_t total = (size_t)N * C * HW;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int pix = (int)(i % HW); size_t q = i / HW;
+    const int c = (int)(q % C); const int n = (int)(q / C);
+    out[i] = y[((size_t)n * HW + pix) * ycs + c] > 0.f ? 1 : 0;
+  }
+}
+// same scan as maxpool_kernel: (kh, kw) order, strict '>' (NaN wins)
+__global__ __launch_bounds__(256) void pool_pattern_kernel(const float* x, int xcs, int N, int Ho, int Wo, int C, uint8_t* out) {
+  const int Hi = Ho * 2, Wi = Wo * 2;
+  const size_t total = (size_t)N * C * Ho * Wo;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int ox = (int)(i % Wo); size_t q = i / Wo;
+    const int oy = (int)(q % Ho); q /= Ho;
+    const int c = (int)(q % C); const int n = (int)(q / C);
+    float m = 0.f; int am = 0;
+    for (int t = 0; t < 4; ++t) {
+      const float v = x[(((size_t)n * Hi + oy * 2 + (t >> 1)) * Wi + ox * 2 + (t & 1)) * xcs + c];
+      if (t == 0 || v > m || v != v) { m = v; am = t; }
+    }
+    out[i] = (uint8_t)am;
+  }
+}
+
 __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* src, int N, int C, int HW, float* dst, int dcs) {
   const size_t total = (size_t)N * C * HW;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
@@ -236,6 +261,15 @@ void maxpool2_fwd(Stream& s, const TView& x, const TView& y) {
   hipLaunchKernelGGL(maxpool_kernel, dim3(egrid(y.pixels() * (y.C / 4))), dim3(256), 0, hs(s), x.p, x.cs, y.p, y.cs,
                      (const float*)nullptr, 0, (float*)nullptr, 0, y.N, y.H, y.W, y.C, 0, 0);
   check_launch("maxpool2_fwd");
+}
+void act_pattern(Stream& s, const TView& y, uint8_t* out_nchw) {
+  hipLaunchKernelGGL(act_pattern_kernel, dim3(egrid(y.pixels() * y.C)), dim3(256), 0, hs(s), y.p, y.cs, y.N, y.H * y.W, y.C, out_nchw);
+  check_launch("act_pattern");
+}
+void pool_pattern(Stream& s, const TView& x, const TView& y, uint8_t* out_nchw) {
+  if (x.H != y.H * 2 || x.W != y.W * 2 || x.C != y.C) throw Error(1, "pool_pattern: shape mismatch");
+  hipLaunchKernelGGL(pool_pattern_kernel, dim3(egrid(y.pixels() * y.C)), dim3(256), 0, hs(s), x.p, x.cs, y.N, y.H, y.W, y.C, out_nchw);
+  check_launch("pool_pattern");
 }
 void maxpool2_bwd(Stream& s, const TView& dy, const TView& x, const TView& y, const TView& dx, int accumulate) {
   hipLaunchKernelGGL(maxpool_kernel, dim3(egrid(y.pixels() * (y.C / 4))), dim3(256), 0, hs(s), x.p, x.cs, y.p, y.cs, dy.p,

@@ -152,6 +152,15 @@ void norm_act_bwd(Stream& s, const NormActBwdArgs& a);
 // step is compared value for value.
 void dropout_mask(Stream& s, int N, int H, int W, int C, float p, uint64_t seed, float* out_nchw);
 
+// The branch every piecewise-linear op took, written out as NCHW bytes (diagnostic export, swn_model_act_pattern).
+// LeakyReLU / ReLU: 1 where the activation OUTPUT y is > 0 -- the side act_bwd / norm_act_bwd differentiate on.
+// MaxPool2d(2,2): the window position (2*kh + kw) the backward pass routes the gradient to (first maximum in scan
+// order).  An fp32 evaluation in another summation order puts pre-activations within round-off of zero on the other
+// side; each such flip changes the gradient by O(1) of that element, which is what bounds any fp32-vs-fp64 gradient
+// comparison at ~1e-3.  Parity tests replay these patterns in the float64 oracle and compare at ~1e-5 instead.
+void act_pattern(Stream& s, const TView& y, uint8_t* out_nchw);
+void pool_pattern(Stream& s, const TView& x, const TView& y, uint8_t* out_nchw);
+
 // y = act(x) elementwise on views; bwd: dx (+)= dy * act'  (derivative expressed through the
 // activation OUTPUT y: lrelu y>0?1:.2, relu y>0, tanh 1-y^2)
 void act_fwd(Stream& s, const TView& x, const TView& y, int act);

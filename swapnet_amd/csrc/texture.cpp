@@ -130,6 +130,7 @@ class TextureModel final : public Model {
   int num_roi = 12;
   ParamArena arenaV;
   std::unique_ptr<Net> VF, VT;
+  Net* net_for_patterns(int net) override { return net == 3 ? VF.get() : Model::net_for_patterns(net); }
   std::vector<Var> feat_f, feat_t;
 
   ParamArena* arena_ptr(int net) override {

@@ -243,6 +243,23 @@ class NativeModel:
         self.ctx.sync()
         return out
 
+    def act_patterns(self, net=NET_G):
+        """The branch every LeakyReLU / ReLU / MaxPool of `net` took in the last pass, in forward order: a list of
+        (kind, uint8 NCHW tensor on the CPU), kind 1 = output > 0, kind 2 = arg-max window position (diagnostic export:
+        the parity tests replay the pattern in the float64 oracle).  net: 0 G, 1 D of the D step ([fake | real]),
+        2 D inside the G step, 3 VGG16 on the generated image (texture)."""
+        n = C.c_int()
+        self.lib.call("swn_model_act_sites", self.handle, net, C.byref(n))
+        out = []
+        for i in range(n.value):
+            shape, kind = (C.c_int * 4)(), C.c_int()
+            self.lib.call("swn_model_act_pattern", self.handle, net, i, None, C.byref(shape), C.byref(kind))
+            t = torch.empty(tuple(shape), dtype=torch.uint8, device=self.ctx.device)
+            self.lib.call("swn_model_act_pattern", self.handle, net, i, _C.ptr(t), C.byref(shape), C.byref(kind))
+            self.ctx.sync()
+            out.append((kind.value, t.cpu()))
+        return out
+
     def set_style_context(self, all_out, all_tgt, n0):
         """Global (all ranks') generated / target images for the style term of the next backward_G (data parallel)."""
         o = all_out.detach().to(device=self.ctx.device, dtype=torch.float32).contiguous()

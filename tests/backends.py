@@ -46,20 +46,21 @@ def rel_l2(a, b):
     return float((a - b).norm() / (b.norm() + 1e-30))
 
 
-def assert_grads_vs_fp64(got, ref32, ref64, skip, what):
-    """The gradient bar of the parity tests: per tensor, rel-L2(native, fp64 oracle) <= max(1e-3, 2 x
-    rel-L2(torch fp32 oracle, fp64 oracle)) -- north_star's 1e-3 wherever the reference's own fp32 backward meets
-    it, never worse than 2x the reference's own round-off elsewhere (two fp32 evaluations in different summation
-    orders of a backward pass that amplifies round-off ~1000x through the InstanceNorm gradients; measured on
-    MI355X at 256x256: generator tensors 0.8-1.0x torch's error, discriminator tensors 1.3-1.5x; DESIGN.md
-    section 2).  Returns (worst native, worst torch-fp32)."""
+def assert_grads_vs_fp64(got, ref32, ref64, skip, what, floor=1e-3):
+    """The UN-PINNED gradient bar: per tensor, rel-L2(native, fp64 oracle) <= max(floor, 2 x rel-L2(torch fp32 oracle,
+    fp64 oracle)).  floor = 1e-3 (north_star) at the small sizes, where no pre-activation lands within round-off of
+    zero.  At 256x256 a handful of LeakyReLU / ReLU sign flips between ANY two fp32 evaluations (2-6 elements out of
+    2M on PatchGAN's 31x31 map) are the whole distance to the fp64 gradient -- a Poisson count proportional to the
+    forward round-off, 0.4e-3 .. 4e-3 for torch's own fp32 backward, 1.5e-3 .. 4e-3 here -- so those call sites pass
+    floor = 5e-3 and the rigorous comparison is the pinned one (tests/test_pattern_replay.py: activation pattern
+    replayed in the oracle, tolerance 5e-5).  Returns (worst native, worst torch-fp32)."""
     w_hip = w_t32 = 0.0
     for k, v in ref64.items():
         if skip(k):
             continue
         e_hip, e_t32 = rel_l2(got[k], v), rel_l2(ref32[k], v)
         w_hip, w_t32 = max(w_hip, e_hip), max(w_t32, e_t32)
-        assert e_hip <= max(1e-3, 2.0 * e_t32), (what, k, "native %.2e" % e_hip, "torch fp32 %.2e" % e_t32)
+        assert e_hip <= max(floor, 2.0 * e_t32), (what, k, "native %.2e" % e_hip, "torch fp32 %.2e" % e_t32)
     return w_hip, w_t32
 
 
@@ -89,3 +90,25 @@ def reset_state(m, state_dicts):
             m.optim_step_count(net, 0)
     if m.is_train:
         m.set_hyper()
+
+
+def collect_patterns(m, vgg=False):
+    """The activation / pooling branches of the pass the model just ran, grouped the way the step oracles replay them
+    (oracle.swapnet_oracle.PatternReplay): G, D (D step, batch [fake | real]), D_G (D inside the G step), VGG."""
+    groups = {"G": m.act_patterns(0), "D": m.act_patterns(1), "D_G": m.act_patterns(2)}
+    if vgg:
+        groups["VGG"] = m.act_patterns(3)
+    return groups
+
+
+def assert_grads_replayed(got, ref64, skip, tol, what):
+    """With the native pass's activation pattern replayed in the float64 oracle, every gradient tensor agrees to `tol`
+    rel-L2 (what is left is the fp32 arithmetic of the kernels).  Returns the worst error."""
+    worst = 0.0
+    for k, v in ref64.items():
+        if skip(k):
+            continue
+        e = rel_l2(got[k], v)
+        worst = max(worst, e)
+        assert e <= tol, (what, k, "rel-L2 %.2e > %.1e" % (e, tol))
+    return worst

@@ -336,6 +336,27 @@ void dropout_mask(Stream&, int N, int H, int W, int C, float p, uint64_t seed, f
       for (size_t pix = 0; pix < HW; ++pix) out[(n * C + c) * HW + pix] = hdrop(seed, (n * HW + pix) * C + c, p);
 }
 
+void act_pattern(Stream&, const TView& y, uint8_t* out) {
+  const size_t HW = (size_t)y.H * y.W;
+  for (size_t n = 0; n < (size_t)y.N; ++n)
+    for (int c = 0; c < y.C; ++c)
+      for (size_t pix = 0; pix < HW; ++pix) out[(n * y.C + c) * HW + pix] = y.p[(n * HW + pix) * y.cs + c] > 0.f ? 1 : 0;
+}
+void pool_pattern(Stream&, const TView& x, const TView& y, uint8_t* out) {
+  if (x.H != y.H * 2 || x.W != y.W * 2 || x.C != y.C) throw Error(1, "pool_pattern: shape mismatch");
+  for (int n = 0; n < y.N; ++n)
+    for (int c = 0; c < y.C; ++c)
+      for (int oy = 0; oy < y.H; ++oy)
+        for (int ox = 0; ox < y.W; ++ox) {
+          float m = 0.f; int am = 0;
+          for (int t = 0; t < 4; ++t) {
+            const float v = x.p[(((size_t)n * x.H + oy * 2 + (t >> 1)) * x.W + ox * 2 + (t & 1)) * x.cs + c];
+            if (t == 0 || v > m || v != v) { m = v; am = t; }
+          }
+          out[(((size_t)n * y.C + c) * y.H + oy) * y.W + ox] = (uint8_t)am;
+        }
+}
+
 void norm_act_fwd(Stream&, const NormActArgs& a) {
   const int N = a.x.N, HW = a.x.H * a.x.W, C = a.x.C;
   for (int n = 0; n < N; ++n)

@@ -1,0 +1,108 @@
+"""Gradient parity with the activation pattern pinned.
+
+Two fp32 evaluations of these networks in different summation orders (this library's MFMA tiles vs torch's CPU
+kernels) leave a handful of LeakyReLU / ReLU pre-activations -- and max-pool windows -- within round-off of a tie on
+opposite sides.  Each flip changes d(loss)/dx of that element by O(1); on PatchGAN at 256x256, 2-6 flips out of 2M
+elements are the ENTIRE ~1e-3 rel-L2 distance of any fp32 gradient (torch's own fp32 backward included) from the
+float64 one (tools/d_grad_trace.py).  These tests take the branch pattern the native pass
+actually used (swn_model_act_pattern), replay it in the float64 oracle's backward, and compare every gradient tensor
+at a tolerance two orders tighter than the 1e-3 of the un-pinned comparison -- in eval and (with the dropout masks
+replayed as well) in training mode."""
+import pytest
+import torch
+
+from oracle import swapnet_oracle as O
+from swapnet_amd import engine
+from tests import backends
+from tests.test_train_parity import BACKENDS, _ctx, _phased_step, _texture_case, noise_bias, rel
+
+TOL = 5e-5
+
+
+def _warp_replay(ctx, B, H, seed, training, labels=(0.9, 0.8, 1.0), drop_seed=77):
+    torch.manual_seed(seed)
+    G, D = O.warp_module_params(), O.patchgan_params(22)
+    batch = O.synth_warp_batch(B, H, H, seed=99)
+    m = engine.NativeModel(ctx, "warp", B, H, H)
+    try:
+        backends.reset_state(m, {engine.NET_G: G, engine.NET_D: D})
+        for i, t in enumerate(batch):
+            m.set_input(i, t)
+        masks = [t.cpu() for t, _ in m.dropout_masks(engine.NET_G, seed=drop_seed)] if training else None
+        gD, gG = _phased_step(m, list(labels), training, drop_seed)
+        replay = O.PatternReplay(backends.collect_patterns(m))
+        s64 = O.WarpStepOracle(G, D, training=O.MaskReplay(masks) if training else False, dtype=torch.float64)
+        s64.patterns = replay
+        s64.step(*batch, labels=list(labels))
+        flips = replay.check()
+        wD = backends.assert_grads_replayed(gD, s64.grads_D, lambda k: noise_bias(k, list(s64.grads_D)), TOL, ("warp", H, "D"))
+        wG = backends.assert_grads_replayed(gG, s64.grads_G, lambda k: noise_bias(k, list(s64.grads_G)), TOL, ("warp", H, "G"))
+        assert rel(m.output(), s64.fakes) < 2e-5
+        L = m.losses()
+        for k, v in s64.losses.items():
+            assert abs(L[k] - v) <= 2e-5 * abs(v) + 1e-7, (k, L[k], v)
+        return flips, wD, wG
+    finally:
+        m.close()
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("mode", ["eval", "train"])
+def test_warp_gradients_with_pinned_pattern(backend, mode):
+    flips, wD, wG = _warp_replay(_ctx(backend), 2, 64, 0, mode == "train")
+    print("warp 64x64", mode, "flips", flips, "worst D %.2e G %.2e" % (wD, wG))
+
+
+def _texture_replay(ctx, B, H, training, labels=(0.85, 0.95, 0.75), drop_seed=99):
+    m, G, D, vgg, batch, masks = _texture_case(ctx, B, H, drop_seed)
+    try:
+        gD, gG = _phased_step(m, list(labels), training, drop_seed)
+        replay = O.PatternReplay(backends.collect_patterns(m, vgg=True))
+        s64 = O.TextureStepOracle(G, D, vgg, training=O.MaskReplay(masks) if training else False, dtype=torch.float64)
+        s64.patterns = replay
+        s64.step(*batch, labels=list(labels))
+        flips = replay.check()
+        wD = backends.assert_grads_replayed(gD, s64.grads_D, lambda k: noise_bias(k, list(s64.grads_D)), TOL, ("texture", H, "D"))
+        wG = backends.assert_grads_replayed(gG, s64.grads_G, lambda k: noise_bias(k, list(s64.grads_G)), TOL, ("texture", H, "G"))
+        assert rel(m.output(), s64.fakes) < 2e-5
+        return flips, wD, wG
+    finally:
+        m.close()
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("mode", ["eval", "train"])
+def test_texture_gradients_with_pinned_pattern(backend, mode):
+    flips, wD, wG = _texture_replay(_ctx(backend), 2, 64, mode == "train")
+    print("texture 64x64", mode, "flips", flips, "worst D %.2e G %.2e" % (wD, wG))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["eval", "train"])
+def test_warp_gradients_with_pinned_pattern_at_full_resolution(mode):
+    """256x256: every kernel family of the benchmarked configuration (LDS-DMA ring tiles, Winograd F(4x4,3x3) /
+    F(3x3,4x4), the fused tail kernels, hybrid split-K) with the comparison no longer dominated by sign flips."""
+    flips, wD, wG = _warp_replay(backends.gpu_ctx(), 2, 256, 3, mode == "train")
+    print("warp 256x256", mode, "flips", flips, "worst D %.2e G %.2e" % (wD, wG))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["eval", "train"])
+def test_texture_gradients_with_pinned_pattern_at_full_resolution(mode):
+    flips, wD, wG = _texture_replay(backends.gpu_ctx(), 2, 256, mode == "train")
+    print("texture 256x256", mode, "flips", flips, "worst D %.2e G %.2e" % (wD, wG))
+
+
+@pytest.mark.gpu
+def test_warp_c2_full_batch_training_step_with_pinned_pattern():
+    """BASELINE.json C2 exactly as bench.py times it (256x256, bs 32, TRAINING mode): dropout masks and activation
+    pattern replayed in the float64 oracle, every gradient tensor within 5e-5."""
+    flips, wD, wG = _warp_replay(backends.gpu_ctx(), 32, 256, 3, True)
+    print("warp C2 bs32 train", "flips", flips, "worst D %.2e G %.2e" % (wD, wG))
+
+
+@pytest.mark.gpu
+def test_texture_c3_full_batch_training_step_with_pinned_pattern():
+    """BASELINE.json C3 (256x256, bs 16, 12 ROIs, L1 + VGG16 content + style, TRAINING mode), same comparison."""
+    flips, wD, wG = _texture_replay(backends.gpu_ctx(), 16, 256, True)
+    print("texture C3 bs16 train", "flips", flips, "worst D %.2e G %.2e" % (wD, wG))

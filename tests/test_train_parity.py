@@ -256,9 +256,9 @@ def _fp64_yardstick(G, D, batch, labels, training32, training64):
     return s32, s64
 
 
-def _assert_vs_fp64(got, s32, s64, which, what):
+def _assert_vs_fp64(got, s32, s64, which, what, floor=1e-3):
     ref64 = getattr(s64, which)
-    w = backends.assert_grads_vs_fp64(got, getattr(s32, which), ref64, lambda k: noise_bias(k, list(ref64)), (what, which))
+    w = backends.assert_grads_vs_fp64(got, getattr(s32, which), ref64, lambda k: noise_bias(k, list(ref64)), (what, which), floor)
     return [("worst", w[0], w[1])]
 
 
@@ -293,7 +293,9 @@ def test_gradients_against_fp64_oracle(backend, winograd, monkeypatch):
 @pytest.mark.gpu
 def test_gradients_against_fp64_oracle_at_full_resolution():
     """The same yardstick at 256x256 (bs 2): F(4x4,3x3) on the 16x16 maps with 1024-channel reductions, the fused
-    tail kernels, F(3x3,4x4) on PatchGAN's 31x31 map."""
+    tail kernels, F(3x3,4x4) on PatchGAN's 31x31 map.  Un-pinned, so bounded by the sign-flip floor (5e-3, see
+    backends.assert_grads_vs_fp64); the same case with the activation pattern pinned is held to 5e-5 in
+    tests/test_pattern_replay.py."""
     ctx = backends.gpu_ctx()
     labels = [0.9, 0.8, 1.0]
     B, H = 2, 256
@@ -307,7 +309,7 @@ def test_gradients_against_fp64_oracle_at_full_resolution():
         for i, t in enumerate(batch):
             m.set_input(i, t)
         gD, gG = _phased_step(m, labels, False, 0)
-        rows = _assert_vs_fp64(gD, s32, s64, "grads_D", "256x256") + _assert_vs_fp64(gG, s32, s64, "grads_G", "256x256")
+        rows = _assert_vs_fp64(gD, s32, s64, "grads_D", "256x256", 5e-3) + _assert_vs_fp64(gG, s32, s64, "grads_G", "256x256", 5e-3)
         print("max HIP err vs fp64 %.2e ; max torch-fp32 err vs fp64 %.2e" % (max(r[1] for r in rows), max(r[2] for r in rows)))
     finally:
         m.close()
