@@ -264,7 +264,10 @@ def main():
             gemm_ms = sum(v["ms"] for v in kernels.values()) / nprof
             traffic, traffic_src = None, None
             rp_name = {"conv_fwd_128x128_fast": "conv_fwd_kernel<2, 2, 2, 2, true>",
-                       "conv_fwd_256x128_fast": "conv_fwd_kernel<2, 2, 4, 2, true>"}.get(dom, dom)
+                       "conv_fwd_256x128_fast": "conv_fwd_kernel<2, 2, 4, 2, true>",
+                       "conv_fwd_dma_128x128": "conv_fwd_dma_kernel<2, 2>", "conv_fwd_dma_256x64": "conv_fwd_dma_kernel<4, 1>",
+                       "conv_wgrad_dma_128x128": "conv_wgrad_dma_kernel<2, 2>",
+                       "conv_wgrad_dma_256x64": "conv_wgrad_dma_kernel<4, 1>"}.get(dom.split("[")[0], dom)
             for tname in ("traffic_r02.json", "traffic_r01.json"):
                 tpath = os.path.join(REPO, "profiles", tname)
                 if os.path.exists(tpath):
@@ -312,8 +315,8 @@ def main():
         # what the box's host->device link itself delivers (plain torch copies of one 256 MB buffer, best of 5): the
         # PCIe-inclusive rates above are bounded by this, not by the library
         raw = {}
-        probe = torch.empty(64 << 20, dtype=torch.float32)
-        dst = torch.empty_like(probe, device="cuda")
+        probe = torch.rand(64 << 20, dtype=torch.float32)          # touched pages with real data (an untouched
+        dst = torch.empty_like(probe, device="cuda")               # torch.empty maps the zero page and copies "fast")
         for name, src in (("pageable", probe), ("pinned", probe.pin_memory())):
             best = 0.0
             for _ in range(5):

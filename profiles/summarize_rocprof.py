@@ -12,6 +12,10 @@ import sys
 from collections import defaultdict
 
 HERE = os.path.dirname(os.path.abspath(__file__))
+if "--out" in sys.argv:                 # write the summaries somewhere else (on the GPU box: under gpurun_out/)
+    i = sys.argv.index("--out")
+    HERE = sys.argv[i + 1]
+    del sys.argv[i:i + 2]
 
 
 def short(name):

@@ -10,14 +10,23 @@
 
 using namespace swn;
 
-struct swn_ctx {
+// The context is shared-owned by its handle and by every model / pipeline created in it: destroying the handles in
+// any order (interpreter shutdown) is safe, and a model's destructor can always hand its buffers back.
+struct CtxBox {
   std::unique_ptr<Ctx> c;
   void* owned_stream = nullptr;
+  ~CtxBox() { c.reset(); if (owned_stream) stream_destroy(owned_stream); }
+};
+struct swn_ctx {
+  std::shared_ptr<CtxBox> box;
+  Ctx* c = nullptr;
 };
 struct swn_model {
+  std::shared_ptr<CtxBox> keep;     // declared first: released after the model
   std::unique_ptr<Model> m;
 };
 struct swn_pipeline {
+  std::shared_ptr<CtxBox> keep;
   std::unique_ptr<Pipeline> p;
 };
 
@@ -52,11 +61,13 @@ int swn_ctx_create(int device, void* hip_stream, int create_stream, size_t works
   return guard([&] {
     REQUIRE(out, "swn_ctx_create: out is NULL");
     auto h = std::make_unique<swn_ctx>();
+    h->box = std::make_shared<CtxBox>();
     void* st = hip_stream;
-    if (create_stream) { st = stream_create(device); h->owned_stream = st; }
+    if (create_stream) { st = stream_create(device); h->box->owned_stream = st; }
     else device_check(device);
     if (workspace_bytes < (size_t)64 << 20) workspace_bytes = (size_t)64 << 20;
-    h->c = std::make_unique<Ctx>(st, workspace_bytes);
+    h->box->c = std::make_unique<Ctx>(st, workspace_bytes);
+    h->c = h->box->c.get();
     if (!(getenv("SWN_OVERLAP") && atoi(getenv("SWN_OVERLAP")) == 0)) h->c->enable_side(device);
     *out = h.release();
   });
@@ -64,9 +75,7 @@ int swn_ctx_create(int device, void* hip_stream, int create_stream, size_t works
 int swn_ctx_destroy(swn_ctx* ctx) {
   return guard([&] {
     if (!ctx) return;
-    ctx->c.reset();
-    if (ctx->owned_stream) stream_destroy(ctx->owned_stream);
-    delete ctx;
+    delete ctx;           // the context itself goes with its last model / pipeline
   });
 }
 int swn_ctx_set_overlap(swn_ctx* ctx, int on) {
@@ -94,6 +103,7 @@ int swn_warp_model_create(swn_ctx* ctx, int batch, int height, int width, int is
     REQUIRE(ctx && out, "NULL argument");
     REQUIRE(batch > 0 && height > 0 && width > 0, "bad shape");
     auto h = std::make_unique<swn_model>();
+    h->keep = ctx->box;
     h->m.reset(create_warp_model(*ctx->c, batch, height, width, is_train != 0, dropout));
     *out = h.release();
   });
@@ -103,6 +113,7 @@ int swn_texture_model_create(swn_ctx* ctx, int batch, int height, int width, int
   return guard([&] {
     REQUIRE(ctx && out, "NULL argument");
     auto h = std::make_unique<swn_model>();
+    h->keep = ctx->box;
     h->m.reset(create_texture_model(*ctx->c, batch, height, width, is_train != 0, num_roi));
     *out = h.release();
   });
@@ -289,6 +300,7 @@ int swn_pipeline_create(swn_model* warp, swn_model* texture, swn_pipeline** out)
   return guard([&] {
     REQUIRE(warp && texture && out, "NULL argument");
     auto h = std::make_unique<swn_pipeline>();
+    h->keep = warp->keep;
     h->p = std::make_unique<Pipeline>(*warp->m, *texture->m);
     *out = h.release();
   });

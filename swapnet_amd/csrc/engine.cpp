@@ -15,7 +15,7 @@ Ctx::Ctx(void* stream, size_t ws_bytes) {
 }
 Ctx::Ctx(const Stream& shared) : s(shared), owns_ws(false) {}
 Ctx::~Ctx() {
-  for (void* p : allocs) dev_free(p);
+  release(allocs);
   if (owns_ws) dev_free(s.ws);
   if (has_side) {
     dev_free(side.ws);
@@ -49,9 +49,17 @@ void Ctx::join_side() {
 }
 void* Ctx::alloc(size_t bytes) {
   void* p = dev_alloc(bytes);
-  allocs.push_back(p);
+  (sink ? *sink : allocs).push_back({p, bytes});
   bytes_allocated += bytes;
   return p;
+}
+void Ctx::release(AllocList& list) {
+  for (auto& a : list) { dev_free(a.first); bytes_allocated -= a.second; }
+  list.clear();
+}
+Model::~Model() {
+  gp_.reset(); D3_.reset(); G.reset(); D2.reset(); D1.reset();
+  if (ctx) ctx->release(owned_allocs);
 }
 
 Var Var::slice(int c0, int c) const {
@@ -721,6 +729,7 @@ void Model::discriminate(const float* x_nchw, float* pred_nchw) {
   if (!is_train || !D2) throw Error(1, "discriminate: the model has no discriminator (created with is_train = 0)");
   if (d_cimap_.empty()) throw Error(1, "discriminate: model did not publish its conditional-input channel map");
   if (!D3_) {
+    AllocScope mine(*ctx, owned_allocs);
     D3_ = std::make_unique<Net>(*ctx, arenaD);
     d3_in_ = D3_->alloc_var(B, H, W, (int)d_cimap_.size(), false);
     d3_pred_ = build_patchgan(*D3_, d3_in_, 3, d_cimap_);
@@ -749,7 +758,7 @@ void Model::discriminate(const float* x_nchw, float* pred_nchw) {
 }
 void Model::set_gp_random(const float* alpha_dev, const float* beta_nchw_dev) {
   if (!is_train || d_cimap_.empty()) throw Error(1, "set_gp_random: the model has no discriminator");
-  if (!gp_) gp_ = std::make_unique<GradPenalty>(*ctx, arenaD, B, H, W);
+  if (!gp_) { AllocScope mine(*ctx, owned_allocs); gp_ = std::make_unique<GradPenalty>(*ctx, arenaD, B, H, W); }
   if (alpha_dev) { dev_copy(ctx->s, gp_->alpha_buffer(), alpha_dev, (size_t)B * sizeof(float)); gp_alpha_set_ = true; }
   if (beta_nchw_dev) {                       // reference channel order (B, 22, H, W) -> buffer order, pads stay 0
     const int nb = (int)d_cimap_.size();
@@ -771,7 +780,7 @@ void Model::set_gp_random(const float* alpha_dev, const float* beta_nchw_dev) {
   }
 }
 void Model::run_gradient_penalty(const TView& real, const TView& fake) {
-  if (!gp_) gp_ = std::make_unique<GradPenalty>(*ctx, arenaD, B, H, W);
+  if (!gp_) { AllocScope mine(*ctx, owned_allocs); gp_ = std::make_unique<GradPenalty>(*ctx, arenaD, B, H, W); }
   const TView beta = gp_->beta_buffer();
   gp_->run(real, fake, hyper.gp_mode, hyper.grad_scale, hyper.lambda_gp, gp_alpha_set_ ? gp_->alpha_buffer() : nullptr,
            gp_beta_set_ ? &beta : nullptr, (uint64_t)arenaD.step * 7919ull + 13ull, losses + L_D_GP);

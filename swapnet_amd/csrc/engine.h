@@ -30,7 +30,12 @@ struct Ctx {
   void enable_side(int device);
   Stream& fork_side();        // side stream, ordered after everything enqueued on `s` so far
   void join_side();           // `s` continues after the side stream's work (no-op if nothing was forked)
-  std::vector<void*> allocs;
+  // Device allocations are owned by the context, or -- while an AllocScope is open -- by the object that opened it
+  // (a Model: everything it allocates, at construction or lazily, is released by its destructor).
+  typedef std::vector<std::pair<void*, size_t>> AllocList;
+  AllocList allocs;
+  AllocList* sink = nullptr;
+  void release(AllocList& list);          // frees the list's buffers (device-synchronising) and empties it
   size_t bytes_allocated = 0;
   explicit Ctx(void* stream, size_t ws_bytes);
   explicit Ctx(const Stream& shared);      // borrows stream + workspace of another context
@@ -39,6 +44,14 @@ struct Ctx {
   void* alloc(size_t bytes);
   Ctx(const Ctx&) = delete;
   Ctx& operator=(const Ctx&) = delete;
+};
+
+struct AllocScope {              // RAII: allocations made while it lives go to `list`
+  Ctx& c; Ctx::AllocList* prev;
+  AllocScope(Ctx& ctx, Ctx::AllocList& list) : c(ctx), prev(ctx.sink) { c.sink = &list; }
+  ~AllocScope() { c.sink = prev; }
+  AllocScope(const AllocScope&) = delete;
+  AllocScope& operator=(const AllocScope&) = delete;
 };
 
 // activation + its gradient (same geometry).  gbase = start of the gradient allocation
@@ -224,7 +237,8 @@ enum LossSlot {
 
 class Model {
  public:
-  virtual ~Model() {}
+  virtual ~Model();                // derived destructors run first (nets, graphs), then the buffers go
+  Ctx::AllocList owned_allocs;     // every device buffer this model allocated (AllocScope in its entry points)
   Ctx* ctx = nullptr;
   int B = 0, H = 0, W = 0;
   bool is_train = true;
@@ -310,6 +324,8 @@ class Pipeline {
   Model& warp_;
   Model& tex_;
   int32_t* labels_ = nullptr;
+  Ctx::AllocList owned_;
+  Ctx* ctx_ = nullptr;
   void* exec_ = nullptr;
   void* cap_stream_ = nullptr;     // capture happens on a private stream: the caller's may be the legacy default stream,
                                    // which cannot be captured; the instantiated graph is launched on the caller's stream

@@ -156,6 +156,7 @@ class WarpModel final : public Model {
 
   WarpModel(Ctx& c, int B_, int H_, int W_, bool train, float drop) {
     ctx = &c; B = B_; H = H_; W = W_; is_train = train; dropout = drop;
+    AllocScope mine(c, owned_allocs);
     G = std::make_unique<Net>(c, arenaG);
     G->keep_wino_inputs = train;
     body = G->alloc_var(B, H, W, 4, false);

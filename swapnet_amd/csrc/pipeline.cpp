@@ -8,11 +8,14 @@ Pipeline::Pipeline(Model& warp, Model& texture) : warp_(warp), tex_(texture) {
   if (warp.ctx != texture.ctx) throw Error(1, "pipeline: both models must live in the same context");
   if (warp.B != texture.B || warp.H != texture.H || warp.W != texture.W)
     throw Error(1, "pipeline: warp and texture models must share (B, H, W)");
+  ctx_ = warp.ctx;
+  AllocScope mine(*ctx_, owned_);
   labels_ = static_cast<int32_t*>(warp.ctx->alloc((size_t)warp.B * warp.H * warp.W * sizeof(int32_t)));
 }
 Pipeline::~Pipeline() {
   graph_destroy(exec_);
   stream_destroy(cap_stream_);
+  ctx_->release(owned_);
 }
 
 void Pipeline::enqueue() {

@@ -140,6 +140,7 @@ class TextureModel final : public Model {
 
   TextureModel(Ctx& c, int B_, int H_, int W_, bool train, int nroi) {
     ctx = &c; B = B_; H = H_; W = W_; is_train = train; num_roi = nroi;
+    AllocScope mine(c, owned_allocs);
     G = std::make_unique<Net>(c, arenaG);
     G->keep_wino_inputs = train;
     tex = G->alloc_var(B, H, W, 4, false);
@@ -192,6 +193,7 @@ class TextureModel final : public Model {
     if (!is_train) throw Error(1, "perceptual: the model was created without its loss networks (is_train = 0)");
     Stream& s = ctx->s;
     if (!p_out_.v.p) {
+      AllocScope mine(*ctx, owned_allocs);
       p_out_ = G->alloc_var(B, H, W, 4, true);
       p_tgt_ = G->alloc_var(B, H, W, 4, false);
     }
@@ -227,6 +229,7 @@ class TextureModel final : public Model {
     if (!is_train) throw Error(1, "set_style_context: training model required");
     if (n_total < B || n0 < 0 || n0 + B > n_total) throw Error(1, "set_style_context: local range outside the global batch");
     if (!g_out_.v.p || g_out_.v.N != n_total) {
+      AllocScope mine(*ctx, owned_allocs);
       g_out_ = G->alloc_var(n_total, H, W, 4, false);
       g_tgt_ = G->alloc_var(n_total, H, W, 4, false);
     }

@@ -24,8 +24,10 @@ def build_hostsim():
 _ctx = {}
 
 
-def hostsim_ctx():
+def hostsim_ctx(fresh=False):
     from swapnet_amd import _C, engine
+    if fresh:
+        return engine.Context(lib=_C.Lib(build_hostsim()), workspace_mb=64)
     if "sim" not in _ctx:
         _ctx["sim"] = engine.Context(lib=_C.Lib(build_hostsim()), workspace_mb=256)
     return _ctx["sim"]
@@ -53,7 +55,7 @@ def assert_grads_vs_fp64(got, ref32, ref64, skip, what, floor=1e-3):
     2M on PatchGAN's 31x31 map) are the whole distance to the fp64 gradient -- a Poisson count proportional to the
     forward round-off, 0.4e-3 .. 4e-3 for torch's own fp32 backward, 1.5e-3 .. 4e-3 here -- so those call sites pass
     floor = 5e-3 and the rigorous comparison is the pinned one (tests/test_pattern_replay.py: activation pattern
-    replayed in the oracle, tolerance 5e-5).  Returns (worst native, worst torch-fp32)."""
+    replayed in the oracle, tolerance 1e-4).  Returns (worst native, worst torch-fp32)."""
     w_hip = w_t32 = 0.0
     for k, v in ref64.items():
         if skip(k):

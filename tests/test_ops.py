@@ -89,6 +89,10 @@ CONV_CASES_GPU = CONV_CASES_SIM + [
     # the 128-wide tile past Npad are fetched out of range), ragged M, zero / reflect padding rows out of range
     (K4S2, 0, 2, 48, 24, 96, True), (K4S2, 0, 1, 16, 32, 64, True), (K3ZERO, 0, 2, 48, 12, 80, True),
     (K3REFL, 0, 1, 16, 10, 48, True), (K4S1, 0, 3, 48, 9, 40, True), (K4S2, 1, 1, 48, 6, 72, True),
+    # Cin % 16 != 0 next to the ring kernel's shapes (register-staged generic loader: per-lane (tap, channel) decode)
+    (K4S2, 0, 2, 12, 32, 48, True), (K3REFL, 0, 1, 20, 10, 80, True), (K4S1, 0, 2, 36, 9, 40, True),
+    (K4S2, 1, 1, 24, 6, 72, True), (K3ZERO, 0, 2, 3, 32, 64, True), (K4S2, 0, 1, 55, 64, 64, True),
+    (K3ZERO, 0, 1, 7, 12, 160, False),
 ]
 
 

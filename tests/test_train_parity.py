@@ -294,7 +294,7 @@ def test_gradients_against_fp64_oracle(backend, winograd, monkeypatch):
 def test_gradients_against_fp64_oracle_at_full_resolution():
     """The same yardstick at 256x256 (bs 2): F(4x4,3x3) on the 16x16 maps with 1024-channel reductions, the fused
     tail kernels, F(3x3,4x4) on PatchGAN's 31x31 map.  Un-pinned, so bounded by the sign-flip floor (5e-3, see
-    backends.assert_grads_vs_fp64); the same case with the activation pattern pinned is held to 5e-5 in
+    backends.assert_grads_vs_fp64); the same case with the activation pattern pinned is held to 1e-4 in
     tests/test_pattern_replay.py."""
     ctx = backends.gpu_ctx()
     labels = [0.9, 0.8, 1.0]
@@ -343,3 +343,28 @@ def test_training_mode_loss_statistics_match_oracle():
         assert 0.5 < got.std(ddof=1) / ref.std(ddof=1) < 2.0
     finally:
         m.close()
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_destroying_a_model_returns_its_memory(backend):
+    """A model owns every device buffer it allocates -- at construction and lazily (private PatchGAN of
+    discriminate(), gradient-penalty operands, perceptual scratch) -- and swn_model_destroy hands them back: a process
+    that builds models for several shapes (NativeBackend's per-shape cache, the two-stage pipeline) does not
+    accumulate HBM.  Handles may be destroyed in any order (the context lives until its last model)."""
+    ctx = _ctx(backend)
+    base = ctx.bytes_allocated()
+    sizes = []
+    for kind in ("warp", "texture", "warp"):
+        m = engine.NativeModel(ctx, kind, 2, 64, 64)
+        if kind == "warp":
+            m.discriminate(torch.zeros(2, 22, 64, 64))        # lazily built private PatchGAN
+        sizes.append(ctx.bytes_allocated() - base)
+        assert sizes[-1] > (1 << 20)
+        m.close()
+        assert ctx.bytes_allocated() == base
+    assert sizes[0] == sizes[2]
+    # a context handle destroyed before its model: the model still works and still frees
+    c2 = engine.Context(workspace_mb=64) if backend == "gpu" else backends.hostsim_ctx(fresh=True)
+    m = engine.NativeModel(c2, "warp", 1, 64, 64)
+    c2.close()
+    m.close()
