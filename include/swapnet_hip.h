@@ -70,6 +70,14 @@ int swn_warp_model_create(swn_ctx* ctx, int batch, int height, int width, int is
                           swn_model** out);
 int swn_texture_model_create(swn_ctx* ctx, int batch, int height, int width, int is_train, int num_roi,
                              swn_model** out);
+/* The same with the reference's representation options (options/base_options.py:75-105, models/warp_model.py:49-55,
+ * models/texture_model.py:94-109): body_channels = 3 for --body_representation rgb, --body_channels (12) for labels;
+ * cloth_channels = --cloth_channels (19) for --cloth_representation labels, 3 for rgb.  The plain constructors above
+ * are the defaults (3, 19).  swn_model_destroy releases every device buffer the model allocated. */
+int swn_warp_model_create_ex(swn_ctx* ctx, int batch, int height, int width, int is_train, float dropout,
+                             int body_channels, int cloth_channels, swn_model** out);
+int swn_texture_model_create_ex(swn_ctx* ctx, int batch, int height, int width, int is_train, int num_roi,
+                                int cloth_channels, swn_model** out);
 int swn_model_destroy(swn_model* m);
 
 /* hyper-parameters = the opt.* fields read by the step (models/base_gan.py:87-120,

@@ -42,6 +42,8 @@ _PROTOS = {
     "swn_prof_report": ([C.c_char_p, _i], _i),
     "swn_warp_model_create": ([_vp, _i, _i, _i, _i, _f, C.POINTER(_vp)], _i),
     "swn_texture_model_create": ([_vp, _i, _i, _i, _i, _i, C.POINTER(_vp)], _i),
+    "swn_warp_model_create_ex": ([_vp, _i, _i, _i, _i, _f, _i, _i, C.POINTER(_vp)], _i),
+    "swn_texture_model_create_ex": ([_vp, _i, _i, _i, _i, _i, _i, C.POINTER(_vp)], _i),
     "swn_model_destroy": ([_vp], _i),
     "swn_model_set_hyper": ([_vp, C.POINTER(SwnHyper)], _i),
     "swn_model_param_count": ([_vp, _i, C.POINTER(_i)], _i),

@@ -97,26 +97,34 @@ int swn_prof_enable(int on) { return guard([&] { prof_enable(on); }); }
 int swn_prof_reset(void) { return guard([&] { prof_reset(); }); }
 int swn_prof_report(char* buf, int len) { return prof_report(buf, len); }
 
-int swn_warp_model_create(swn_ctx* ctx, int batch, int height, int width, int is_train, float dropout,
-                          swn_model** out) {
+int swn_warp_model_create_ex(swn_ctx* ctx, int batch, int height, int width, int is_train, float dropout,
+                             int body_channels, int cloth_channels, swn_model** out) {
   return guard([&] {
     REQUIRE(ctx && out, "NULL argument");
     REQUIRE(batch > 0 && height > 0 && width > 0, "bad shape");
     auto h = std::make_unique<swn_model>();
     h->keep = ctx->box;
-    h->m.reset(create_warp_model(*ctx->c, batch, height, width, is_train != 0, dropout));
+    h->m.reset(create_warp_model(*ctx->c, batch, height, width, is_train != 0, dropout, body_channels, cloth_channels));
+    *out = h.release();
+  });
+}
+int swn_warp_model_create(swn_ctx* ctx, int batch, int height, int width, int is_train, float dropout,
+                          swn_model** out) {
+  return swn_warp_model_create_ex(ctx, batch, height, width, is_train, dropout, 3, 19, out);
+}
+int swn_texture_model_create_ex(swn_ctx* ctx, int batch, int height, int width, int is_train, int num_roi,
+                                int cloth_channels, swn_model** out) {
+  return guard([&] {
+    REQUIRE(ctx && out, "NULL argument");
+    auto h = std::make_unique<swn_model>();
+    h->keep = ctx->box;
+    h->m.reset(create_texture_model(*ctx->c, batch, height, width, is_train != 0, num_roi, cloth_channels));
     *out = h.release();
   });
 }
 int swn_texture_model_create(swn_ctx* ctx, int batch, int height, int width, int is_train, int num_roi,
                              swn_model** out) {
-  return guard([&] {
-    REQUIRE(ctx && out, "NULL argument");
-    auto h = std::make_unique<swn_model>();
-    h->keep = ctx->box;
-    h->m.reset(create_texture_model(*ctx->c, batch, height, width, is_train != 0, num_roi));
-    *out = h.release();
-  });
+  return swn_texture_model_create_ex(ctx, batch, height, width, is_train, num_roi, 19, out);
 }
 int swn_model_destroy(swn_model* m) {
   return guard([&] { delete m; });

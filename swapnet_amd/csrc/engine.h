@@ -175,10 +175,11 @@ class Net {
 };
 
 // ---- network builders (reference layouts in the .cpp) ----------------------------------
-void build_warp_generator(Net& net, const Var& body, const Var& cloth, const Var& out, float dropout);
+void build_warp_generator(Net& net, const Var& body, const Var& cloth, const Var& out, float dropout, int body_channels = 3,
+                          int cloth_channels = 19);
 Var build_patchgan(Net& net, const Var& x, int n_layers, const std::vector<int32_t>& cimap);
 void build_texture_generator(Net& net, const Var& tex, const float* rois_dev, int num_roi, const Var& cloth_cat,
-                             const Var& unet_in, const Var& out, int img_size);
+                             const Var& unet_in, const Var& out, int img_size, int cloth_channels = 19);
 std::vector<Var> build_vgg16_slices(Net& net, const Var& img);
 
 // ---- gradient penalty (gp.cpp): second-order pass through PatchGAN for --gan_mode wgan-gp / dragan-gp / dragan-lp ----
@@ -211,6 +212,8 @@ class GradPenalty {
   Ctx& ctx_;
   ParamArena& A_;
   int B_;
+  int Cd_ = 24, Cd_logical_ = 22;      // D input buffer channels / the reference's channel count
+ 
   std::unique_ptr<Net> net_;
   std::vector<Layer> L_;
   Var xh_;
@@ -249,7 +252,8 @@ class Model {
   virtual void set_input(int slot, const float* dev_nchw, int N, int C, int Hh, int Ww) = 0;
   virtual void set_input_labels(int slot, const int32_t* dev_labels, int N, int Hh, int Ww) = 0;
   virtual void get_output(int slot, float* dev_nchw) = 0;
-  virtual TView output_view() = 0;              // NHWC view of self.fakes (logical channels: 19 warp / 3 texture)
+  virtual TView output_view() = 0;              // NHWC view of self.fakes (logical channels: cloth_channels warp / 3 texture)
+  virtual int output_channels() const = 0;
   virtual void forward(bool training, uint64_t seed) = 0;
   virtual void backward_D(float label_fake, float label_real) = 0;
   virtual void backward_G(float label_real) = 0;
@@ -332,7 +336,9 @@ class Pipeline {
   bool warmed_ = false;
 };
 
-Model* create_warp_model(Ctx& ctx, int B, int H, int W, bool is_train, float dropout);
-Model* create_texture_model(Ctx& ctx, int B, int H, int W, bool is_train, int num_roi);
+// body_channels / cloth_channels: --body_representation / --cloth_representation / --body_channels / --cloth_channels
+// of the reference (models/warp_model.py:49-55, options/base_options.py:75-105); defaults 3 (rgb) / 19 (labels)
+Model* create_warp_model(Ctx& ctx, int B, int H, int W, bool is_train, float dropout, int body_channels = 3, int cloth_channels = 19);
+Model* create_texture_model(Ctx& ctx, int B, int H, int W, bool is_train, int num_roi, int cloth_channels = 19);
 
 }  // namespace swn

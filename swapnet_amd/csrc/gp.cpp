@@ -31,8 +31,11 @@ GradPenalty::GradPenalty(Ctx& c, ParamArena& arenaD, int B, int H, int W) : ctx_
   Net& n = *net_;
   static const char* names[5] = {"model.0", "model.2", "model.5", "model.8", "model.11"};
   int h = H, w = W;
-  xh_ = n.alloc_var(B, H, W, 24, true);
-  u0_ = n.alloc_var(B, H, W, 24, false).v;
+  const ParamDesc& w0 = arenaD.params[arenaD.index.at("model.0.weight")];
+  Cd_ = w0.ws.Cip;                        // channels of D's conditional input buffer (padded layout of the model)
+  Cd_logical_ = w0.ws.Ci;
+  xh_ = n.alloc_var(B, H, W, Cd_, true);
+  u0_ = n.alloc_var(B, H, W, Cd_, false).v;
   L_.resize(5);
   for (int l = 0; l < 5; ++l) {
     Layer& y = L_[l];
@@ -63,7 +66,7 @@ GradPenalty::GradPenalty(Ctx& c, ParamArena& arenaD, int B, int H, int W) : ctx_
   alpha_ = static_cast<float*>(c.alloc(round_up(B, 4) * sizeof(float)));
   half_std_ = static_cast<float*>(c.alloc(16));
   tmp_loss_ = static_cast<float*>(c.alloc(16));
-  beta_ = n.alloc_var(B, H, W, 24, false).v;
+  beta_ = n.alloc_var(B, H, W, Cd_, false).v;
 }
 GradPenalty::~GradPenalty() {}
 
@@ -116,8 +119,8 @@ void GradPenalty::run(const TView& real, const TView& fake, int gp_mode, float g
     alpha = alpha_;
   }
   if (dragan) {
-    if (!beta) { gp_uniform(s, beta_, 24, seed * 2 + 2); /* pads are multiplied by zero weights */ beta = &beta_; }
-    gp_half_std(s, real, (size_t)real.N * real.H * real.W * 22, half_std_);
+    if (!beta) { gp_uniform(s, beta_, Cd_, seed * 2 + 2); /* pads are multiplied by zero weights */ beta = &beta_; }
+    gp_half_std(s, real, (size_t)real.N * real.H * real.W * Cd_logical_, half_std_);
     gp_interpolate(s, real, nullptr, alpha, beta, half_std_, xh_.v);
   } else {
     gp_interpolate(s, real, &fake, alpha, nullptr, nullptr, xh_.v);

@@ -31,7 +31,7 @@ static void up_block(Net& n, const std::string& name, const Var& x, const Var& y
   n.norm_act(raw, y, true, ACT_RELU, dropout);
 }
 
-void build_warp_generator(Net& n, const Var& body, const Var& cloth, const Var& out, float dropout) {
+void build_warp_generator(Net& n, const Var& body, const Var& cloth, const Var& out, float dropout, int Cb, int Cc) {
   const int B = body.v.N, H = body.v.H, W = body.v.W;
   if (H % 64 || W % 64) throw Error(1, "WarpModule needs H and W to be multiples of 64");
   Var cat3 = n.alloc_var(B, H / 2, W / 2, 192, true);
@@ -43,7 +43,7 @@ void build_warp_generator(Net& n, const Var& body, const Var& cloth, const Var& 
   Var body_d3 = cat1.slice(256, 256), cloth_d3 = cat1.slice(512, 256);
   Var body_d4 = bc.slice(0, 512), cloth_u2 = bc.slice(512, 512);
   // body encoder (:34-37)
-  down_block(n, "body_down1.model.0", body, body_d1, 3, 64, false, 0.f, true);
+  down_block(n, "body_down1.model.0", body, body_d1, Cb, 64, false, 0.f, true);
   down_block(n, "body_down2.model.0", body_d1, body_d2, 64, 128, true, 0.f);
   down_block(n, "body_down3.model.0", body_d2, body_d3, 128, 256, true, 0.f);
   down_block(n, "body_down4.model.0", body_d3, body_d4, 256, 512, true, dropout);
@@ -52,7 +52,7 @@ void build_warp_generator(Net& n, const Var& body, const Var& cloth, const Var& 
   Var cloth_d5 = n.alloc_var(B, H / 32, W / 32, 1024, true);
   Var cloth_d6 = n.alloc_var(B, H / 64, W / 64, 1024, true);
   Var cloth_u1 = n.alloc_var(B, H / 32, W / 32, 1024, true);
-  down_block(n, "cloth_down1.model.0", cloth, cloth_d1, 19, 64, false, 0.f, true);
+  down_block(n, "cloth_down1.model.0", cloth, cloth_d1, Cc, 64, false, 0.f, true);
   down_block(n, "cloth_down2.model.0", cloth_d1, cloth_d2, 64, 128, true, 0.f);
   down_block(n, "cloth_down3.model.0", cloth_d2, cloth_d3, 128, 256, true, 0.f);
   down_block(n, "cloth_down4.model.0", cloth_d3, cloth_d4, 256, 512, true, 0.f);
@@ -81,7 +81,7 @@ void build_warp_generator(Net& n, const Var& body, const Var& cloth, const Var& 
   up_block(n, "dual_up2.model.0", cat1, cat2.slice(0, 128), 128, false, 0.f);
   up_block(n, "dual_up3.model.0", cat2, cat3.slice(0, 64), 64, false, 0.f);
   // upsample_and_pad (:85-90): Upsample x2 + ZeroPad(1,0,1,0) + Conv k4 p1 (bias) + Tanh
-  n.conv("upsample_and_pad.2", cat3, out, CK_TAIL_UP, 192, 19, true, ACT_TANH);
+  n.conv("upsample_and_pad.2", cat3, out, CK_TAIL_UP, 192, Cc, true, ACT_TANH);
   n.taps["body_d1"] = body_d1; n.taps["body_d2"] = body_d2; n.taps["body_d3"] = body_d3; n.taps["body_d4"] = body_d4;
   n.taps["cloth_d1"] = cloth_d1; n.taps["cloth_d2"] = cloth_d2; n.taps["cloth_d3"] = cloth_d3;
   n.taps["cloth_d4"] = cloth_d4; n.taps["cloth_d5"] = cloth_d5; n.taps["cloth_d6"] = cloth_d6;
@@ -153,24 +153,27 @@ class WarpModel final : public Model {
  public:
   Var body, cloth, Dx, pred2, pred1;
   float dropout = 0.5f;
+  int Cb = 3, Cc = 19, Cbp = 4, Ccp = 20;      // logical / padded channel counts of the body and cloth representations
 
-  WarpModel(Ctx& c, int B_, int H_, int W_, bool train, float drop) {
+  WarpModel(Ctx& c, int B_, int H_, int W_, bool train, float drop, int body_channels, int cloth_channels) {
     ctx = &c; B = B_; H = H_; W = W_; is_train = train; dropout = drop;
+    Cb = body_channels; Cc = cloth_channels; Cbp = round_up(Cb, 4); Ccp = round_up(Cc, 4);
+    if (Cb < 1 || Cc < 2 || Cb > 64 || Cc > 64) throw Error(1, "WarpModel: body_channels in [1,64], cloth_channels in [2,64]");
     AllocScope mine(c, owned_allocs);
     G = std::make_unique<Net>(c, arenaG);
     G->keep_wino_inputs = train;
-    body = G->alloc_var(B, H, W, 4, false);
-    cloth = G->alloc_var(B, H, W, 20, false);
-    Dx = G->alloc_var(train ? 2 * B : B, H, W, 24, train);
-    Var fake_slot = Dx.batch(0, B).slice(0, 20);
-    build_warp_generator(*G, body, cloth, fake_slot, dropout);
+    body = G->alloc_var(B, H, W, Cbp, false);
+    cloth = G->alloc_var(B, H, W, Ccp, false);
+    Dx = G->alloc_var(train ? 2 * B : B, H, W, Ccp + Cbp, train);
+    Var fake_slot = Dx.batch(0, B).slice(0, Ccp);
+    build_warp_generator(*G, body, cloth, fake_slot, dropout, Cb, Cc);
     arenaG.allocate(c);
     G->finalize({fake_slot});
     losses = static_cast<float*>(c.alloc(L_COUNT * sizeof(float)));
     if (train) {
-      std::vector<int32_t> cimap(24, -1);
-      for (int i = 0; i < 19; ++i) cimap[i] = 3 + i;     // cloth channels follow the 3 body channels
-      for (int i = 0; i < 3; ++i) cimap[20 + i] = i;
+      std::vector<int32_t> cimap(Ccp + Cbp, -1);
+      for (int i = 0; i < Cc; ++i) cimap[i] = Cb + i;     // cloth channels follow the body channels (warp_model.py:115)
+      for (int i = 0; i < Cb; ++i) cimap[Ccp + i] = i;
       d_cimap_ = cimap;
       D2 = std::make_unique<Net>(c, arenaD);
       D2->keep_wino_inputs = true;
@@ -186,33 +189,34 @@ class WarpModel final : public Model {
   void set_input(int slot, const float* src, int N, int C, int Hh, int Ww) override {
     if (N != B || Hh != H || Ww != W) throw Error(1, "set_input: shape mismatch with the model's (B,H,W)");
     Stream& s = ctx->s;
-    if (slot == 0) {            // bodys (B,3,H,W)
-      if (C != 3) throw Error(1, "bodys must have 3 channels");
+    if (slot == 0) {            // bodys (B,Cb,H,W)
+      if (C != Cb) throw Error(1, "bodys must have " + std::to_string(Cb) + " channels");
       nchw_to_nhwc(s, src, N, C, H, W, body.v);
-      nchw_to_nhwc(s, src, N, C, H, W, Dx.batch(0, B).v.slice(20, 4));
-      if (is_train) nchw_to_nhwc(s, src, N, C, H, W, Dx.batch(B, B).v.slice(20, 4));
-    } else if (slot == 1) {     // input_cloths (B,19,H,W)
-      if (C != 19) throw Error(1, "input_cloths must have 19 channels");
+      nchw_to_nhwc(s, src, N, C, H, W, Dx.batch(0, B).v.slice(Ccp, Cbp));
+      if (is_train) nchw_to_nhwc(s, src, N, C, H, W, Dx.batch(B, B).v.slice(Ccp, Cbp));
+    } else if (slot == 1) {     // input_cloths (B,Cc,H,W)
+      if (C != Cc) throw Error(1, "input_cloths must have " + std::to_string(Cc) + " channels");
       nchw_to_nhwc(s, src, N, C, H, W, cloth.v);
     } else if (slot == 2) {     // target_cloths
       if (!is_train) throw Error(1, "targets are only used in training");
-      if (C != 19) throw Error(1, "target_cloths must have 19 channels");
-      nchw_to_nhwc(s, src, N, C, H, W, Dx.batch(B, B).v.slice(0, 20));
+      if (C != Cc) throw Error(1, "target_cloths must have " + std::to_string(Cc) + " channels");
+      nchw_to_nhwc(s, src, N, C, H, W, Dx.batch(B, B).v.slice(0, Ccp));
     } else {
       throw Error(1, "set_input: unknown slot");
     }
   }
   void set_input_labels(int slot, const int32_t* lab, int N, int Hh, int Ww) override {
     if (N != B || Hh != H || Ww != W) throw Error(1, "set_input_labels: shape mismatch with the model's (B,H,W)");
-    if (slot == 1) labels_to_onehot(ctx->s, lab, cloth.v, 19);
-    else if (slot == 2 && is_train) labels_to_onehot(ctx->s, lab, Dx.batch(B, B).v.slice(0, 20), 19);
+    if (slot == 1) labels_to_onehot(ctx->s, lab, cloth.v, Cc);
+    else if (slot == 2 && is_train) labels_to_onehot(ctx->s, lab, Dx.batch(B, B).v.slice(0, Ccp), Cc);
     else throw Error(1, "set_input_labels: slot has no label form");
   }
   void get_output(int slot, float* dst) override {
     if (slot != 0) throw Error(1, "get_output: unknown slot");
-    nhwc_to_nchw(ctx->s, Dx.batch(0, B).v.slice(0, 20), dst, 19);
+    nhwc_to_nchw(ctx->s, Dx.batch(0, B).v.slice(0, Ccp), dst, Cc);
   }
-  TView output_view() override { return Dx.batch(0, B).v.slice(0, 20); }
+  TView output_view() override { return Dx.batch(0, B).v.slice(0, Ccp); }
+  int output_channels() const override { return Cc; }
   bool supports_gradient_penalty() const override { return true; }
   void forward(bool training, uint64_t seed) override {       // warp_model.py:106-107
     G->training = training; G->seed = seed;
@@ -240,9 +244,9 @@ class WarpModel final : public Model {
   }
   void backward_G_head(float label_real) override {
     Stream& s = ctx->s;
-    TView fakes = Dx.batch(0, B).v.slice(0, 20);
-    TView dfakes = Dx.batch(0, B).g.slice(0, 20);
-    TView targets = Dx.batch(B, B).v.slice(0, 20);
+    TView fakes = Dx.batch(0, B).v.slice(0, Ccp);
+    TView dfakes = Dx.batch(0, B).g.slice(0, Ccp);
+    TView targets = Dx.batch(B, B).v.slice(0, Ccp);
     if (!hyper.warp_mode_ce_only) {
       D1->refresh_dgrad();
       D1->training = false;
@@ -250,18 +254,18 @@ class WarpModel final : public Model {
       gan_loss_op(s, hyper.gan_mode, pred1.v, label_real, true, hyper.lambda_gan * hyper.grad_scale, losses + L_TMP0, &pred1.g);
       scalar_axpby(s, losses + L_TMP0, hyper.lambda_gan, nullptr, 0.f, losses + L_G_GAN);
       D1->backward(false, true);                       // D weight grads would be discarded (quirk 5)
-      ce_argmax_loss(s, fakes, targets, 19, hyper.lambda_ce * hyper.grad_scale, losses + L_TMP1, &dfakes, 1);
+      ce_argmax_loss(s, fakes, targets, Cc, hyper.lambda_ce * hyper.grad_scale, losses + L_TMP1, &dfakes, 1);
     } else {
       dev_memset(s, losses + L_G_GAN, 0, sizeof(float));
-      ce_argmax_loss(s, fakes, targets, 19, hyper.lambda_ce * hyper.grad_scale, losses + L_TMP1, &dfakes, 0);
+      ce_argmax_loss(s, fakes, targets, Cc, hyper.lambda_ce * hyper.grad_scale, losses + L_TMP1, &dfakes, 0);
     }
     scalar_axpby(s, losses + L_TMP1, hyper.lambda_ce, nullptr, 0.f, losses + L_G_CE);
     scalar_axpby(s, losses + L_G_GAN, 1.f, losses + L_G_CE, 1.f, losses + L_G);
   }
 };
 
-Model* create_warp_model(Ctx& ctx, int B, int H, int W, bool is_train, float dropout) {
-  return new WarpModel(ctx, B, H, W, is_train, dropout);
+Model* create_warp_model(Ctx& ctx, int B, int H, int W, bool is_train, float dropout, int body_channels, int cloth_channels) {
+  return new WarpModel(ctx, B, H, W, is_train, dropout, body_channels, cloth_channels);
 }
 
 }  // namespace swn

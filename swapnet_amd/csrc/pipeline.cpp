@@ -21,7 +21,7 @@ Pipeline::~Pipeline() {
 void Pipeline::enqueue() {
   Stream& s = warp_.ctx->s;
   warp_.forward(false, 0);
-  argmax_labels(s, warp_.output_view(), 19, labels_);
+  argmax_labels(s, warp_.output_view(), warp_.output_channels(), labels_);
   tex_.set_input_labels(2, labels_, tex_.B, tex_.H, tex_.W);
   tex_.forward(false, 0);
 }

@@ -26,7 +26,7 @@ static std::string unet_prefix(int d) {
 }
 
 void build_texture_generator(Net& n, const Var& tex, const float* rois_dev, int num_roi, const Var& cloth_slot,
-                             const Var& unet_in, const Var& out, int img_size) {
+                             const Var& unet_in, const Var& out, int img_size, int cloth_channels) {
   const int B = tex.v.N, H = tex.v.H, W = tex.v.W;
   const int depth = (int)std::lround(std::log2((double)img_size));
   if ((1 << depth) != img_size || H != img_size || W != img_size || depth < 6)
@@ -56,7 +56,7 @@ void build_texture_generator(Net& n, const Var& tex, const float* rois_dev, int 
     R[d] = n.alloc_var(B, hw, hw, 2 * ch, true);
   }
   // down path
-  n.conv(unet_prefix(0) + ".model.0", unet_in, C[1].slice(0, 64), CK_K4S2, 55, 64, true, ACT_LRELU);
+  n.conv(unet_prefix(0) + ".model.0", unet_in, C[1].slice(0, 64), CK_K4S2, RC + cloth_channels, 64, true, ACT_LRELU);
   Var innermost_mid;
   for (int d = 1; d < depth; ++d) {
     const int cin = inner(d - 1), cout = inner(d), hw = H >> (d + 1);
@@ -138,24 +138,27 @@ class TextureModel final : public Model {
     return Model::arena_ptr(net);
   }
 
-  TextureModel(Ctx& c, int B_, int H_, int W_, bool train, int nroi) {
+  int Cc = 19, Ccp = 20, RC = 36;       // cloth channels (logical / padded), ROI-pooled texture channels 3 * num_roi
+  TextureModel(Ctx& c, int B_, int H_, int W_, bool train, int nroi, int cloth_channels) {
     ctx = &c; B = B_; H = H_; W = W_; is_train = train; num_roi = nroi;
+    Cc = cloth_channels; Ccp = round_up(Cc, 4); RC = 3 * num_roi;
+    if (Cc < 1 || Cc > 64) throw Error(1, "TextureModel: cloth_channels in [1,64]");
     AllocScope mine(c, owned_allocs);
     G = std::make_unique<Net>(c, arenaG);
     G->keep_wino_inputs = train;
     tex = G->alloc_var(B, H, W, 4, false);
-    unet_in = G->alloc_var(B, H, W, 56, true);     // d(unet_in)[0:36) feeds the encode branch
-    Dx = G->alloc_var(train ? 2 * B : B, H, W, 24, train);
+    unet_in = G->alloc_var(B, H, W, RC + Ccp, true);     // d(unet_in)[0:RC) feeds the encode branch
+    Dx = G->alloc_var(train ? 2 * B : B, H, W, 4 + Ccp, train);
     rois = static_cast<float*>(c.alloc((size_t)B * num_roi * 4 * sizeof(float)));
     Var fake_slot = Dx.batch(0, B).slice(0, 4);
-    build_texture_generator(*G, tex, rois, num_roi, unet_in.slice(36, 20), unet_in, fake_slot, H);
+    build_texture_generator(*G, tex, rois, num_roi, unet_in.slice(RC, Ccp), unet_in, fake_slot, H, Cc);
     arenaG.allocate(c);
     G->finalize({fake_slot});
     losses = static_cast<float*>(c.alloc(L_COUNT * sizeof(float)));
     if (!train) return;
-    std::vector<int32_t> cimap(24, -1);
-    for (int i = 0; i < 3; ++i) cimap[i] = 19 + i;       // textures follow the 19 cloth channels
-    for (int i = 0; i < 19; ++i) cimap[4 + i] = i;
+    std::vector<int32_t> cimap(4 + Ccp, -1);
+    for (int i = 0; i < 3; ++i) cimap[i] = Cc + i;       // textures follow the cloth channels (texture_model.py:135)
+    for (int i = 0; i < Cc; ++i) cimap[4 + i] = i;
     d_cimap_ = cimap;
     D2 = std::make_unique<Net>(c, arenaD);
     D2->keep_wino_inputs = true;
@@ -250,10 +253,10 @@ class TextureModel final : public Model {
       if (C != 3) throw Error(1, "input_textures must have 3 channels");
       nchw_to_nhwc(s, src, N, C, H, W, tex.v);
     } else if (slot == 2) {                            // cloths
-      if (C != 19) throw Error(1, "cloths must have 19 channels");
-      nchw_to_nhwc(s, src, N, C, H, W, unet_in.v.slice(36, 20));
-      nchw_to_nhwc(s, src, N, C, H, W, Dx.batch(0, B).v.slice(4, 20));
-      if (is_train) nchw_to_nhwc(s, src, N, C, H, W, Dx.batch(B, B).v.slice(4, 20));
+      if (C != Cc) throw Error(1, "cloths must have " + std::to_string(Cc) + " channels");
+      nchw_to_nhwc(s, src, N, C, H, W, unet_in.v.slice(RC, Ccp));
+      nchw_to_nhwc(s, src, N, C, H, W, Dx.batch(0, B).v.slice(4, Ccp));
+      if (is_train) nchw_to_nhwc(s, src, N, C, H, W, Dx.batch(B, B).v.slice(4, Ccp));
     } else if (slot == 3) {                            // target_textures
       if (!is_train) throw Error(1, "targets are only used in training");
       if (C != 3) throw Error(1, "target_textures must have 3 channels");
@@ -265,15 +268,16 @@ class TextureModel final : public Model {
   void set_input_labels(int slot, const int32_t* lab, int N, int Hh, int Ww) override {
     if (N != B || Hh != H || Ww != W) throw Error(1, "set_input_labels: shape mismatch with the model's (B,H,W)");
     if (slot != 2) throw Error(1, "set_input_labels: slot has no label form");
-    labels_to_onehot(ctx->s, lab, unet_in.v.slice(36, 20), 19);
-    labels_to_onehot(ctx->s, lab, Dx.batch(0, B).v.slice(4, 20), 19);
-    if (is_train) labels_to_onehot(ctx->s, lab, Dx.batch(B, B).v.slice(4, 20), 19);
+    labels_to_onehot(ctx->s, lab, unet_in.v.slice(RC, Ccp), Cc);
+    labels_to_onehot(ctx->s, lab, Dx.batch(0, B).v.slice(4, Ccp), Cc);
+    if (is_train) labels_to_onehot(ctx->s, lab, Dx.batch(B, B).v.slice(4, Ccp), Cc);
   }
   void get_output(int slot, float* dst) override {
     if (slot != 0) throw Error(1, "get_output: unknown slot");
     nhwc_to_nchw(ctx->s, Dx.batch(0, B).v.slice(0, 4), dst, 3);
   }
   TView output_view() override { return Dx.batch(0, B).v.slice(0, 4); }
+  int output_channels() const override { return 3; }
   void forward(bool training, uint64_t seed) override {        // texture_model.py:121-125
     G->training = training; G->seed = seed;
     G->forward();
@@ -346,8 +350,8 @@ class TextureModel final : public Model {
   }
 };
 
-Model* create_texture_model(Ctx& ctx, int B, int H, int W, bool is_train, int num_roi) {
-  return new TextureModel(ctx, B, H, W, is_train, num_roi);
+Model* create_texture_model(Ctx& ctx, int B, int H, int W, bool is_train, int num_roi, int cloth_channels) {
+  return new TextureModel(ctx, B, H, W, is_train, num_roi, cloth_channels);
 }
 
 }  // namespace swn

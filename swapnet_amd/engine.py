@@ -120,17 +120,19 @@ class NativeModel:
     """swn_model handle: generator (+ discriminator, optimizers) living in library-owned
     NHWC arenas.  Tensors cross the boundary as NCHW fp32, exactly as the reference holds them."""
 
-    def __init__(self, ctx, kind, batch, height, width, is_train=True, dropout=0.5, num_roi=12):
+    def __init__(self, ctx, kind, batch, height, width, is_train=True, dropout=0.5, num_roi=12, body_channels=3,
+                 cloth_channels=19):
         self.ctx, self.lib, self.kind = ctx, ctx.lib, kind
         self.B, self.H, self.W, self.is_train = batch, height, width, is_train
+        self.body_channels, self.cloth_channels = body_channels, cloth_channels
         h = C.c_void_p()
         if kind == "warp":
-            self.lib.call("swn_warp_model_create", ctx.handle, batch, height, width, int(is_train),
-                          C.c_float(dropout), C.byref(h))
-            self.out_channels = 19
+            self.lib.call("swn_warp_model_create_ex", ctx.handle, batch, height, width, int(is_train),
+                          C.c_float(dropout), body_channels, cloth_channels, C.byref(h))
+            self.out_channels = cloth_channels
         elif kind == "texture":
-            self.lib.call("swn_texture_model_create", ctx.handle, batch, height, width, int(is_train), num_roi,
-                          C.byref(h))
+            self.lib.call("swn_texture_model_create_ex", ctx.handle, batch, height, width, int(is_train), num_roi,
+                          cloth_channels, C.byref(h))
             self.out_channels = 3
         else:
             raise ValueError("unknown model kind " + kind)
@@ -268,17 +270,19 @@ class NativeModel:
         self._style_keep = (o, t)
 
     def set_gp_random(self, alpha=None, beta=None):
-        """alpha (B,) / (B,1,1,1) and beta (B,22,H,W): the gradient-penalty draws of the next backward_D (one-shot)."""
+        """alpha (B,) / (B,1,1,1) and beta (B,C_D,H,W): the gradient-penalty draws of the next backward_D (one-shot)."""
         a = None if alpha is None else alpha.detach().reshape(-1).to(device=self.ctx.device, dtype=torch.float32).contiguous()
         b = None if beta is None else beta.detach().to(device=self.ctx.device, dtype=torch.float32).contiguous()
         self.lib.call("swn_model_set_gp_random", self.handle, _C.ptr(a), _C.ptr(b))
         self._gp_keep = (a, b)
 
     def discriminate(self, x):
-        """NLayerDiscriminator.forward on a conditioned input in the reference's channel order (B,22,H,W)."""
+        """NLayerDiscriminator.forward on a conditioned input in the reference's channel order (B,C_D,H,W),
+        C_D = body + cloth channels (warp, 22 by default) / texture + cloth channels (texture)."""
         xd = x.detach().to(device=self.ctx.device, dtype=torch.float32).contiguous()
-        if tuple(xd.shape) != (self.B, 22, self.H, self.W):
-            raise ValueError("discriminator input must be (%d, 22, %d, %d), got %s" % (self.B, self.H, self.W, tuple(xd.shape)))
+        cd = self.cloth_channels + (self.body_channels if self.kind == "warp" else 3)
+        if tuple(xd.shape) != (self.B, cd, self.H, self.W):
+            raise ValueError("discriminator input must be (%d, %d, %d, %d), got %s" % (self.B, cd, self.H, self.W, tuple(xd.shape)))
         pred = torch.empty((self.B, 1, self.H // 8 - 2, self.W // 8 - 2), dtype=torch.float32, device=self.ctx.device)
         self.lib.call("swn_model_discriminate", self.handle, _C.ptr(xd), _C.ptr(pred))
         self.ctx.sync()

@@ -51,7 +51,11 @@ class BaseGAN(BaseModel, ABC):
                                      num_roi=getattr(opt, "body_channels", 12), device=self.gpu_id,
                                      lib=getattr(opt, "_swapnet_lib", None),
                                      default_shape=(getattr(opt, "batch_size", 1), getattr(opt, "crop_size", 128),
-                                                    getattr(opt, "crop_size", 128)))
+                                                    getattr(opt, "crop_size", 128)),
+                                     # warp: the representation flags resolved by WarpModel.__init__ (warp_model.py:49-55);
+                                     # texture: cloths are always label one-hots of --cloth_channels (texture_model.py:105)
+                                     body_channels=getattr(self, "body_channels", 3),
+                                     cloth_channels=getattr(self, "cloth_channels", getattr(opt, "cloth_channels", 19)))
         self.net_generator = self.define_G()
         modules.init_weights(self.net_generator, opt.init_type, opt.init_gain)      # base_gan.py:141
         self.model_names = ["generator"]
@@ -135,7 +139,7 @@ class BaseGAN(BaseModel, ABC):
             # from the global torch RNG in the reference's order so that a seeded run reproduces the reference's CPU path;
             # by default the library draws them on the device (no host round trip of a (B,22,H,W) tensor)
             m = self._native()
-            beta = torch.rand(m.B, 22, m.H, m.W) if c.gp_mode >= 2 else None
+            beta = torch.rand(m.B, self.get_D_inchannels(), m.H, m.W) if c.gp_mode >= 2 else None
             alpha = torch.rand([m.B, 1, 1, 1])
             m.set_gp_random(alpha, beta)
         labels.append(c.sample_label(True))

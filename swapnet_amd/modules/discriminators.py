@@ -10,8 +10,10 @@ class NLayerDiscriminator(NativeNet):
     """70x70 PatchGAN, n_layers=3, ndf=64, instance norm, bias on every conv (:91-136)."""
 
     def __init__(self, backend, input_nc=22, ndf=64, n_layers=3):
-        if input_nc != 22 or ndf != 64 or n_layers != 3:
-            raise NotImplementedError("native PatchGAN is the reference default: 22 input channels, ndf 64, 3 layers")
+        want = backend.cloth_channels + (backend.body_channels if backend.kind == "warp" else 3)
+        if input_nc != want or ndf != 64 or n_layers != 3:
+            raise NotImplementedError("native PatchGAN: ndf 64, 3 layers, input channels = the stage's conditional "
+                                      "input (%d here), got input_nc=%d ndf=%d n_layers=%d" % (want, input_nc, ndf, n_layers))
         super().__init__(backend, engine.NET_D)
 
     def forward(self, input):

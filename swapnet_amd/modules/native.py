@@ -17,8 +17,9 @@ class NativeBackend:
     state is moved over with four flat device-to-device copies per network."""
 
     def __init__(self, kind, is_train=True, dropout=0.5, num_roi=12, ctx=None, lib=None, device=None,
-                 default_shape=(1, 64, 64)):
+                 default_shape=(1, 64, 64), body_channels=3, cloth_channels=19):
         self.kind, self.is_train, self.dropout, self.num_roi = kind, is_train, dropout, num_roi
+        self.body_channels, self.cloth_channels = body_channels, cloth_channels
         self.default_shape = tuple(default_shape)
         self.ctx = ctx or engine.default_context(device=device, lib=lib)
         self.models = {}
@@ -33,7 +34,8 @@ class NativeBackend:
         m = self.models.get(key)
         if m is None:
             m = engine.NativeModel(self.ctx, self.kind, key[0], key[1], key[2], is_train=self.is_train,
-                                   dropout=self.dropout, num_roi=self.num_roi)
+                                   dropout=self.dropout, num_roi=self.num_roi, body_channels=self.body_channels,
+                                   cloth_channels=self.cloth_channels)
             m.set_hyper(**self.hyper)
             self.models[key] = m
             if self.cur is not None:

@@ -19,9 +19,11 @@ class WarpModule(NativeNet):
     """Dual-encoder U-Net with 4 residual blocks (swapnet_modules.py:28-151)."""
 
     def __init__(self, body_channels=3, cloth_channels=19, dropout=0.5, backend=None, lib=None):
-        if body_channels != 3 or cloth_channels != 19:
-            raise ValueError("swapnet_amd WarpModule supports the reference default 3 body / 19 cloth channels")
-        backend = backend or NativeBackend("warp", is_train=False, dropout=dropout, lib=lib)
+        if backend is not None and (backend.body_channels, backend.cloth_channels) != (body_channels, cloth_channels):
+            raise ValueError("WarpModule(%d, %d) on a backend built for (%d, %d) channels" % (
+                body_channels, cloth_channels, backend.body_channels, backend.cloth_channels))
+        backend = backend or NativeBackend("warp", is_train=False, dropout=dropout, lib=lib,
+                                           body_channels=body_channels, cloth_channels=cloth_channels)
         super().__init__(backend, engine.NET_G)
         self.training = True
 
@@ -45,12 +47,15 @@ class TextureModule(NativeNet):
             raise NotImplementedError("normalization layer [%s] is not implemented (instance only)" % norm_type)
         if unet_type != "pix2pix":
             raise NotImplementedError("unet_type [%s] is not implemented" % unet_type)
-        if texture_channels != 3 or cloth_channels != 19:
-            raise ValueError("swapnet_amd TextureModule supports 3 texture / 19 cloth channels")
+        if texture_channels != 3:
+            raise ValueError("swapnet_amd TextureModule supports 3 texture channels (the VGG16 perceptual loss and the "
+                             "image Gram are defined on RGB)")
+        if backend is not None and backend.cloth_channels != cloth_channels:
+            raise ValueError("TextureModule(cloth_channels=%d) on a backend built for %d" % (cloth_channels, backend.cloth_channels))
         self.img_size = img_size
         self.num_downs = math.frexp(img_size)[1] - 1          # swapnet_modules.py:178
         backend = backend or NativeBackend("texture", is_train=False, dropout=dropout, num_roi=num_roi, lib=lib,
-                                           default_shape=(1, img_size, img_size))
+                                           default_shape=(1, img_size, img_size), cloth_channels=cloth_channels)
         super().__init__(backend, engine.NET_G)
         self.num_roi = num_roi
         self.training = True

@@ -12,8 +12,8 @@ def _blocky_labels(B, H, W, n_labels, tile, g):
 def onehot_zero_background(lab, n_labels=19):
     """datasets/data_utils.py:330-343: the scipy-sparse label matrix drops label 0, so the
     background pixel is the ALL-ZERO vector."""
-    oh = torch.nn.functional.one_hot(lab.long(), n_labels).movedim(-1, -3).float()
-    oh[..., 0, :, :] = 0.0
+    oh = torch.nn.functional.one_hot(lab.long(), n_labels).movedim(-1, -3).float().contiguous()   # NCHW-dense, like a
+    oh[..., 0, :, :] = 0.0                                                                       # DataLoader batch
     return oh
 
 

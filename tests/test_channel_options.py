@@ -1,0 +1,117 @@
+"""The reference's representation options (options/base_options.py:75-105): --body_representation labels with
+--body_channels 12 (neural-body-fitting segmentations), --cloth_representation rgb (3 channels), other
+--cloth_channels.  WarpModel resolves them to the channel counts of WarpModule and of the conditional PatchGAN
+(models/warp_model.py:49-55,89,97); TextureModel concatenates --cloth_channels cloth channels behind the 36 ROI-pooled
+ones (models/texture_model.py:94-109).  A full native step against the oracle for each combination."""
+import pytest
+import torch
+
+from oracle import swapnet_oracle as O
+from swapnet_amd import engine
+from tests import backends
+from tests.test_texture_step import vgg_state_dict
+from tests.test_train_parity import BACKENDS, _ctx, _phased_step, noise_bias, rel
+
+
+def _blocky_onehot(B, H, C, g):
+    lab = torch.randint(0, C, (B, H // 8, H // 8), generator=g).repeat_interleave(8, 1).repeat_interleave(8, 2)
+    return lab, O.labels_to_onehot(lab, C).contiguous()
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("channels", [(12, 19), (3, 3), (12, 7)], ids=["body-labels", "cloth-rgb", "body12-cloth7"])
+def test_warp_step_with_other_representations(backend, channels):
+    Cb, Cc = channels
+    ctx = _ctx(backend)
+    B, H = 2, 64
+    torch.manual_seed(0)
+    G, D = O.warp_module_params(Cb, Cc), O.patchgan_params(Cb + Cc)
+    g = torch.Generator().manual_seed(5)
+    bodys = torch.randn(B, Cb, H, H, generator=g)
+    lab, targets = _blocky_onehot(B, H, Cc, g)
+    inputs = O.labels_to_onehot(torch.roll(lab.flip(2), (3, -2), (1, 2)), Cc).contiguous()
+    labels = [0.9, 0.8, 1.0]
+    m = engine.NativeModel(ctx, "warp", B, H, H, body_channels=Cb, cloth_channels=Cc)
+    try:
+        assert m.param_infos(engine.NET_G)["cloth_down1.model.0.weight"] == (64, Cc, 4, 4)
+        assert m.param_infos(engine.NET_D)["model.0.weight"] == (64, Cb + Cc, 4, 4)
+        backends.reset_state(m, {engine.NET_G: G, engine.NET_D: D})
+        m.set_input(0, bodys); m.set_input(1, inputs)
+        m.set_input_labels(2, lab.to(torch.int32))              # device-side one-hot with Cc classes
+        gD, gG = _phased_step(m, labels, False, 0)
+        # float64 oracle with the native pass's activation pattern pinned (tests/test_pattern_replay.py)
+        st = O.WarpStepOracle(G, D, dtype=torch.float64)
+        st.patterns = O.PatternReplay(backends.collect_patterns(m))
+        st.step(bodys, inputs, targets, labels=labels)
+        st.patterns.check()
+        L = m.losses()
+        for k, v in st.losses.items():
+            assert abs(L[k] - v) <= 2e-5 * abs(v) + 1e-6, (k, L[k], v)
+        assert tuple(m.output().shape) == (B, Cc, H, H) and rel(m.output(), st.fakes) < 2e-5
+        backends.assert_grads_replayed(gD, st.grads_D, noise_bias, 1e-4, ("D", Cb, Cc))
+        backends.assert_grads_replayed(gG, st.grads_G, noise_bias, 1e-4, ("G", Cb, Cc))
+        with pytest.raises(ValueError):
+            m.set_input(1, torch.zeros(B, Cc + 1, H, H))
+        pred = m.discriminate(torch.cat((bodys, targets), 1))
+        assert rel(pred, O.patchgan_forward(st.D, torch.cat((bodys, targets), 1).double())) < 1e-3      # the updated D
+    finally:
+        m.close()
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_texture_step_with_other_cloth_channels(backend):
+    ctx = _ctx(backend)
+    B, H, Cc = 2, 64, 7
+    torch.manual_seed(9)
+    G, D = O.texture_module_params(cloth_channels=Cc, img_size=H), O.patchgan_params(3 + Cc)
+    vgg = O.vgg16_feature_params()
+    tex, rois, _, tgt = O.synth_texture_batch(B, H, H, seed=31)
+    _, cloths = _blocky_onehot(B, H, Cc, torch.Generator().manual_seed(2))
+    labels = [0.85, 0.95, 0.75]
+    m = engine.NativeModel(ctx, "texture", B, H, H, cloth_channels=Cc)
+    try:
+        backends.reset_state(m, {engine.NET_G: G, engine.NET_D: D})
+        m.load_state_dict(engine.NET_VGG, vgg_state_dict(m, vgg))
+        for i, t in enumerate((tex, rois, cloths, tgt)):
+            m.set_input(i, t)
+        gD, gG = _phased_step(m, labels, False, 0)
+        st = O.TextureStepOracle(G, D, vgg, dtype=torch.float64)
+        st.patterns = O.PatternReplay(backends.collect_patterns(m, vgg=True))
+        st.step(tex, rois, cloths, tgt, labels=labels)
+        st.patterns.check()
+        L = m.losses()
+        for k, v in st.losses.items():
+            assert abs(L[k] - v) <= 2e-5 * abs(v) + 1e-6, (k, L[k], v)
+        assert rel(m.output(), st.fakes) < 2e-5
+        backends.assert_grads_replayed(gD, st.grads_D, lambda k: noise_bias(k, list(st.grads_D)), 1e-4, ("tex D", Cc))
+        backends.assert_grads_replayed(gG, st.grads_G, lambda k: noise_bias(k, list(st.grads_G)), 1e-4, ("tex G", Cc))
+    finally:
+        m.close()
+
+
+def test_warp_model_resolves_the_representation_flags(tmp_path):
+    """models/warp_model.py:49-55: body channels = --body_channels under --body_representation labels (else 3), cloth
+    channels = 3 under --cloth_representation rgb (else --cloth_channels); the generator, the conditional PatchGAN and
+    one optimize_parameters() step follow."""
+    from swapnet_amd.models import create_model
+    from tests.test_models_api import make_opt
+    for kw, (cb, cc) in ((dict(body_representation="labels", body_channels=12), (12, 19)),
+                         (dict(cloth_representation="rgb"), (3, 3)),
+                         (dict(cloth_channels=7), (3, 7))):
+        opt = make_opt(tmp_path, "sim", **kw)
+        torch.manual_seed(0)
+        model = create_model(opt)
+        model.setup(opt)
+        sdG, sdD = model.net_generator.state_dict(), model.net_discriminator.state_dict()
+        assert tuple(sdG["body_down1.model.0.weight"].shape) == (64, cb, 4, 4)
+        assert tuple(sdG["cloth_down1.model.0.weight"].shape) == (64, cc, 4, 4)
+        assert tuple(sdG["upsample_and_pad.2.weight"].shape) == (cc, 192, 4, 4)
+        assert tuple(sdD["model.0.weight"].shape) == (64, cb + cc, 4, 4) and model.get_D_inchannels() == cb + cc
+        g = torch.Generator().manual_seed(1)
+        lab, targets = _blocky_onehot(2, 64, cc, g)
+        model.set_input(dict(bodys=torch.randn(2, cb, 64, 64, generator=g), input_cloths=targets.flip(3).contiguous(),
+                             target_cloths=targets, cloth_paths=["", ""], body_paths=["", ""]))
+        model.optimize_parameters()
+        losses = model.get_current_losses()
+        assert all(v == v and abs(v) < 1e6 for v in losses.values()), losses
+        assert tuple(model.fakes.shape) == (2, cc, 64, 64)
