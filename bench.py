@@ -266,6 +266,7 @@ def main():
             rp_name = {"conv_fwd_128x128_fast": "conv_fwd_kernel<2, 2, 2, 2, true>",
                        "conv_fwd_256x128_fast": "conv_fwd_kernel<2, 2, 4, 2, true>",
                        "conv_fwd_dma_128x128": "conv_fwd_dma_kernel<2, 2>", "conv_fwd_dma_256x64": "conv_fwd_dma_kernel<4, 1>",
+                       "conv_fwd_dma_128x256": "conv_fwd_dma_kernel<2, 4>",
                        "conv_wgrad_dma_128x128": "conv_wgrad_dma_kernel<2, 2>",
                        "conv_wgrad_dma_256x64": "conv_wgrad_dma_kernel<4, 1>"}.get(dom.split("[")[0], dom)
             for tname in ("traffic_r02.json", "traffic_r01.json"):

@@ -381,7 +381,7 @@ struct DmaTile {
 };
 
 template <int WGM, int WGN>
-__global__ __launch_bounds__(64 * WGM * WGN) void conv_fwd_dma_kernel(GemmP p, DmaSched sc) {
+__global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN >= 8 ? 2 : 1)) void conv_fwd_dma_kernel(GemmP p, DmaSched sc) {
 #if defined(__HIP_DEVICE_COMPILE__)
   using T = DmaTile<WGM, WGN>;
   constexpr int BM = T::BM, BN = T::BN, BK = T::BK, NST = T::NST, AI = T::AI, BI = T::BI;
@@ -1798,12 +1798,16 @@ static void launch_fwd_narrow(Stream& s, GemmP& p, bool fast, int batch) {
 // ---- LDS-DMA forward kernel: schedule + launch ------------------------------------------------------------------
 // T tiles of `work` stages on `slots` resident workgroups.  Whole rounds run one tile per unit; the remainder tiles
 // (all tiles when T < slots) are split s ways along K so that the last round is as full as the others.
-static DmaSched plan_dma(int tiles_total, int tiles_per_z, int work, int slots, size_t tile_bytes, size_t ws_bytes) {
+// `unit` = stage-time of this tile configuration relative to the 128x128 one (waves per SIMD / 3); *cost_out receives the
+// estimated launch time in 128x128 stage units, comparable across tile configurations.
+static DmaSched plan_dma(int tiles_total, int tiles_per_z, int work, int slots, size_t tile_bytes, size_t ws_bytes,
+                         double* cost_out = nullptr, double unit = 1.0) {
   DmaSched sc{};
   sc.tiles_per_z = tiles_per_z;
   const int rounds = tiles_total / slots;
   int rem = tiles_total - rounds * slots;
   sc.full = rounds * slots; sc.tail_tiles = rem; sc.tail_s = 1; sc.per_split = work;
+  if (cost_out) *cost_out = rounds * (work + 4.0) * unit;
   if (rem == 0) return sc;
   // cost in units of one stage-time of a resident workgroup (32 MFMAs per wave, three waves sharing a SIMD: ~2.7 us):
   // tail rounds x (stages per unit + ~4 of prologue / epilogue) + the slab round trip of the split tiles at ~5 TB/s
@@ -1817,14 +1821,30 @@ static DmaSched plan_dma(int tiles_total, int tiles_per_z, int work, int slots, 
     const int per = ceil_div(work, sp), eff = ceil_div(work, per);
     const double tail_rounds = std::ceil((double)rem * eff / slots);
     double cost = tail_rounds * (per + 4.0);
-    if (eff > 1) cost += (double)rem * eff * (double)tile_bytes * 2.0 / 13.5e6 + 2.0;
+    if (eff > 1) cost += (double)rem * eff * (double)tile_bytes * 2.0 / (13.5e6 * unit) + 2.0;
     if (cost < best_cost * 0.985) { best_cost = cost; best = eff; }
   }
+  if (cost_out) *cost_out += best_cost * unit;
   sc.tail_s = best;
   sc.per_split = ceil_div(work, best);
   sc.tail_s = ceil_div(work, sc.per_split);
   if (sc.tail_s == 1) { sc.full = tiles_total; sc.tail_tiles = 0; }
   return sc;
+}
+
+// resident workgroups per CU: LDS (160 KB) and registers -- the kernels use ~104 VGPRs: 4 waves per SIMD (16 per CU) for
+// the 8-wave tiles, and 3 per SIMD are kept for the 4-wave tiles (3 x 48 KB of LDS)
+template <int WGM, int WGN>
+static constexpr int dma_wg_per_cu() {
+  using T = DmaTile<WGM, WGN>;
+  return T::NW >= 8 ? std::min(160 * 1024 / T::SMEM, 16 / T::NW) : std::min(160 * 1024 / T::SMEM, 12 / T::NW);
+}
+template <int WGM, int WGN>
+static DmaSched plan_fwd_dma(const GemmP& p, int nb, size_t ws_bytes, double* cost) {
+  using T = DmaTile<WGM, WGN>;
+  const int ntiles = ceil_div(p.M, T::BM) * ceil_div(p.Npad, T::BN);
+  constexpr int wg = dma_wg_per_cu<WGM, WGN>();
+  return plan_dma(ntiles * nb, ntiles, p.K / T::BK, 256 * wg, (size_t)T::BM * T::BN * 4, ws_bytes, cost, wg * T::NW / 12.0);
 }
 
 template <int WGM, int WGN>
@@ -1833,9 +1853,7 @@ static void launch_fwd_dma(Stream& s, GemmP& p, int nb) {
   const int tiles_m = ceil_div(p.M, T::BM);
   p.tiles_n = ceil_div(p.Npad, T::BN);
   p.ntiles = tiles_m * p.tiles_n;
-  const int nkb = p.K / T::BK;
-  const int wg_per_cu = std::min(160 * 1024 / T::SMEM, 12 / T::NW);        // LDS and 3 waves/SIMD (<= 168 VGPRs)
-  const DmaSched sc = plan_dma(p.ntiles * nb, p.ntiles, nkb, 256 * wg_per_cu, (size_t)T::BM * T::BN * 4, s.ws_bytes);
+  const DmaSched sc = plan_fwd_dma<WGM, WGN>(p, nb, s.ws_bytes, nullptr);
   p.slab = reinterpret_cast<float*>(s.ws);
   p.splits = sc.tail_s;
   static bool once = (set_smem(conv_fwd_dma_kernel<WGM, WGN>, T::SMEM), true);
@@ -1931,7 +1949,16 @@ void conv_fwd(Stream& s, const ConvFwdArgs& a) {
   // N in (128, 192] (the tail conv's input gradient into the 192-channel concat): a 128x192 tile instead
   // of two 128-wide column tiles of which the second is half empty
   if (dma_ok(a, p)) {
-    if (a.Npad > 64) launch_fwd_dma<2, 2>(s, p, nb);     // 128 x 128, 4 waves, 3 workgroups / CU
+    if (a.Npad > 64) {
+      // 128 x 128 (4 waves, 3 workgroups / CU) unless the 128 x 256 tile (8 waves, 2 / CU: 512 slots instead of 768)
+      // quantises the launch better: the resblock input gradient (M 800, N 1024 x 36 planes) is 2016 tiles = 2.6
+      // rounds of 768 but 1008 = 1.97 rounds of 512
+      const int wide = getenv("SWN_DMA_WIDE") ? atoi(getenv("SWN_DMA_WIDE")) : 1;   // 0 never, 1 by cost, 2 always (tests); per launch
+      double c22 = 0, c24 = 0;
+      if (wide && a.Npad % 256 == 0) { plan_fwd_dma<2, 2>(p, nb, s.ws_bytes, &c22); plan_fwd_dma<2, 4>(p, nb, s.ws_bytes, &c24); }
+      if (c24 > 0 && (wide == 2 || c24 < 0.95 * c22)) launch_fwd_dma<2, 4>(s, p, nb);
+      else launch_fwd_dma<2, 2>(s, p, nb);
+    }
     else launch_fwd_dma<4, 1>(s, p, nb);                 // 256 x 64
     return;
   }

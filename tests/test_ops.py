@@ -225,3 +225,28 @@ def test_label_decode_and_onehot_bit_exact(backend):
     oh = torch.empty((B, Cn, H, H), device=ctx.device)
     ctx.lib.call("swn_op_labels_to_onehot", ctx.handle, _C.ptr(lab), B, Cn, H, H, _C.ptr(oh))
     assert torch.equal(oh.cpu(), O.labels_to_onehot(lab.cpu().long(), Cn))
+
+
+@pytest.mark.gpu
+def test_conv_wide_ring_tile(monkeypatch):
+    """The 128 x 256 (8-wave) instantiation of the LDS-DMA ring kernel, forced (SWN_DMA_WIDE=2; by default it is
+    chosen by the launch cost model only where it quantises better): forward, input gradient and the hybrid split-K
+    tail, ragged M, N = 256 / 512, against torch."""
+    ctx = _ctx("gpu")
+    monkeypatch.setenv("SWN_DMA_WIDE", "2")
+    g = torch.Generator().manual_seed(3)
+    for kind, tr, n, ci, h, co, bias in ((K3REFL, 0, 2, 64, 10, 256, True), (K4S2, 0, 3, 32, 36, 512, False),
+                                         (K4S1, 0, 1, 48, 13, 256, True), (K4S2, 1, 2, 64, 9, 256, False),
+                                         (K3ZERO, 0, 2, 256, 16, 256, True)):
+        k = 3 if kind in (K3REFL, K3ZERO) else 4
+        x = torch.randn(n, ci, h, h, generator=g)
+        w = torch.randn((ci, co, k, k) if tr else (co, ci, k, k), generator=g) * (2.0 / (ci * k * k)) ** 0.5
+        b = torch.randn(co, generator=g) * 0.1 if bias else None
+        ref = ref_conv(x, w, b, kind, tr)
+        out = run_conv(ctx, kind, tr, 0, False, x, w, b, 0, ref.shape)
+        assert rel(out, ref) < 1e-4, (kind, tr, n, ci, h, co, rel(out, ref))
+        dy = torch.randn(ref.shape, generator=g)
+        xr = x.clone().requires_grad_(True)
+        ref_conv(xr, w, b, kind, tr).backward(dy)
+        dx = run_conv(ctx, kind, tr, 2, False, torch.zeros_like(x), w, None, 0, dy=dy)
+        assert rel(dx, xr.grad) < 1e-4, ("dgrad", kind, tr, n, ci, h, co, rel(dx, xr.grad))
