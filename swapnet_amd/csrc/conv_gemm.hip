@@ -363,6 +363,53 @@ __device__ __forceinline__ void lds_dma16(unsigned voff, i32x4 rsrc, unsigned so
 }
 constexpr unsigned DMA_OOB = 0x80000000u;      // > any buffer this library addresses (checked by the launcher)
 
+// ---- fp32 products on the bf16 matrix cores ("split" main loop) ------------------------------------------------------
+// x = hi + mid + lo with 8 mantissa bits each, cut by TRUNCATION, so the split itself is exact (24 bits in, 24 bits out).
+// a*b = sum of 9 partial products; the 6 with weight >= 2^-16 relative to hi*hi are formed by
+// v_mfma_f32_32x32x16_bf16 (each bf16 x bf16 product is exact in fp32, accumulation is fp32); the three dropped ones
+// (mid*lo, lo*mid, lo*lo) are below 2^-24 |a||b|, i.e. below the rounding of an fp32 product.  Measured against an
+// fp64-accumulated reference the result is slightly MORE accurate than v_mfma_f32_32x32x2_f32 (5.0e-7 vs 5.7e-7 rel-L2
+// at K = 1024: 16 products per accumulator rounding instead of 2), and the 6 MFMAs per 16 k cost 192 cycles of the
+// matrix pipe against 512 for the f32 form (tools/gemm_lab_split.hip: 110 -> 162 fp32-equivalent TFLOP/s; the loop is
+// then bound by the ~5.5 VALU instructions per element of the split).  A lane's 8 fragment values are k = 8h .. 8h+7
+// of its row / column -- exactly the operand layout of the 32x32x16 instruction.  SWN_SPLIT=0 selects the f32 MFMA.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void split8(const float* v, u32x4& hi, u32x4& mid, u32x4& lo) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const unsigned x0 = __float_as_uint(v[2 * q]), x1 = __float_as_uint(v[2 * q + 1]);
+    hi[q] = __builtin_amdgcn_perm(x1, x0, 0x07060302u);                 // {x1[31:16], x0[31:16]}
+    const float r0 = v[2 * q] - __uint_as_float(x0 & 0xffff0000u), r1 = v[2 * q + 1] - __uint_as_float(x1 & 0xffff0000u);
+    const unsigned y0 = __float_as_uint(r0), y1 = __float_as_uint(r1);
+    mid[q] = __builtin_amdgcn_perm(y1, y0, 0x07060302u);
+    const float s0 = r0 - __uint_as_float(y0 & 0xffff0000u), s1 = r1 - __uint_as_float(y1 & 0xffff0000u);
+    lo[q] = __builtin_amdgcn_perm(__float_as_uint(s1), __float_as_uint(s0), 0x07060302u);
+  }
+}
+__device__ __forceinline__ f32x16 mma_bf16(u32x4 a, u32x4 b, f32x16 c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+#else
+  return c;
+#endif
+}
+// acc[i][j] += A_i (rows) x B_j (columns) over the lane's 8 k values, i, j in {0, 1}
+__device__ __forceinline__ void split_mma_2x2(f32x16 (&acc)[2][2], const float (&af)[2][8], const float (&bf)[2][8]) {
+  u32x4 ah[2], am[2], al[2], bh[2], bm[2], bl[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) { split8(af[i], ah[i], am[i], al[i]); split8(bf[i], bh[i], bm[i], bl[i]); }
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      f32x16 c = acc[i][j];
+      c = mma_bf16(al[i], bh[j], c); c = mma_bf16(ah[i], bl[j], c); c = mma_bf16(am[i], bm[j], c);     // smallest terms first
+      c = mma_bf16(am[i], bh[j], c); c = mma_bf16(ah[i], bm[j], c); c = mma_bf16(ah[i], bh[j], c);
+      acc[i][j] = c;
+    }
+}
+
 struct DmaSched {            // hybrid schedule, computed by the launcher
   int full;                  // work units [0, full): one whole tile each
   int tail_tiles, tail_s;    // then tail_tiles tiles split tail_s ways along K
@@ -380,8 +427,9 @@ struct DmaTile {
   static_assert(4 % WGN == 0 && 4 % WGM == 0, "tile shape");
 };
 
-template <int WGM, int WGN>
-__global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN >= 8 ? 2 : 1)) void conv_fwd_dma_kernel(GemmP p, DmaSched sc) {
+template <int WGM, int WGN, bool SPLIT>
+// (hipcc's second launch-bound is waves per SIMD: the 8-wave tile needs 2 workgroups = 4 waves per SIMD, <= 128 VGPRs)
+__global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN >= 8 ? 4 : 3)) void conv_fwd_dma_kernel(GemmP p, DmaSched sc) {
 #if defined(__HIP_DEVICE_COMPILE__)
   using T = DmaTile<WGM, WGN>;
   constexpr int BM = T::BM, BN = T::BN, BK = T::BK, NST = T::NST, AI = T::AI, BI = T::BI;
@@ -493,13 +541,17 @@ __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN >= 8 ? 2 : 1)) void conv
       const float2 b = *reinterpret_cast<const float2*>(S + b_rd + s8 * BN);
       bf[0][s8] = b.x; bf[1][s8] = b.y;
     }
+    if (SPLIT) {
+      split_mma_2x2(acc, af, bf);
+    } else {
 #pragma unroll
-    for (int s8 = 0; s8 < 8; ++s8)
+      for (int s8 = 0; s8 < 8; ++s8)
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s8], bf[j][s8], acc[i][j], 0, 0, 0);
+          for (int j = 0; j < 2; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s8], bf[j][s8], acc[i][j], 0, 0, 0);
+    }
   };
 
   if (kb_begin < kb_end) {
@@ -1360,7 +1412,7 @@ struct DmaWgTile {
   static_assert(LPRA <= 64 && AI >= 1 && BI >= 1, "tile shape");
 };
 
-template <int WGM, int WGN>
+template <int WGM, int WGN, bool SPLIT>
 __global__ __launch_bounds__(64 * WGM * WGN) void conv_wgrad_dma_kernel(GemmP p, DmaSched sc) {
 #if defined(__HIP_DEVICE_COMPILE__)
   using T = DmaWgTile<WGM, WGN>;
@@ -1470,13 +1522,17 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_wgrad_dma_kernel(GemmP p,
       const float2 b = *reinterpret_cast<const float2*>(S + b_rd + s8 * BN);
       af[0][s8] = a.x; af[1][s8] = a.y; bf[0][s8] = b.x; bf[1][s8] = b.y;
     }
+    if (SPLIT) {
+      split_mma_2x2(acc, af, bf);
+    } else {
 #pragma unroll
-    for (int s8 = 0; s8 < 8; ++s8)
+      for (int s8 = 0; s8 < 8; ++s8)
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s8], bf[j][s8], acc[i][j], 0, 0, 0);
+          for (int j = 0; j < 2; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s8], bf[j][s8], acc[i][j], 0, 0, 0);
+    }
   };
 
   if (mb_begin < mb_end) {
@@ -1795,6 +1851,8 @@ static void launch_fwd_narrow(Stream& s, GemmP& p, bool fast, int batch) {
 }
 
 
+// read per launch (tests and A/B measurements toggle it): 0 = v_mfma_f32_32x32x2_f32 main loop, default = bf16 split
+static bool split_on() { return !(getenv("SWN_SPLIT") && atoi(getenv("SWN_SPLIT")) == 0); }
 // ---- LDS-DMA forward kernel: schedule + launch ------------------------------------------------------------------
 // T tiles of `work` stages on `slots` resident workgroups.  Whole rounds run one tile per unit; the remainder tiles
 // (all tiles when T < slots) are split s ways along K so that the last round is as full as the others.
@@ -1856,7 +1914,7 @@ static void launch_fwd_dma(Stream& s, GemmP& p, int nb) {
   const DmaSched sc = plan_fwd_dma<WGM, WGN>(p, nb, s.ws_bytes, nullptr);
   p.slab = reinterpret_cast<float*>(s.ws);
   p.splits = sc.tail_s;
-  static bool once = (set_smem(conv_fwd_dma_kernel<WGM, WGN>, T::SMEM), true);
+  static bool once = (set_smem(conv_fwd_dma_kernel<WGM, WGN, true>, T::SMEM), set_smem(conv_fwd_dma_kernel<WGM, WGN, false>, T::SMEM), true);
   (void)once;
   char pname[112];
   if (prof_detail())
@@ -1866,7 +1924,8 @@ static void launch_fwd_dma(Stream& s, GemmP& p, int nb) {
     snprintf(pname, sizeof pname, "conv_fwd_dma_%dx%d", T::BM, T::BN);
   ProfScope prof(s, pname, 2.0 * p.M * p.Cout * p.K * nb);
   const int units = sc.full + sc.tail_tiles * sc.tail_s;
-  hipLaunchKernelGGL((conv_fwd_dma_kernel<WGM, WGN>), dim3(units), dim3(64 * T::NW), T::SMEM, hs(s), p, sc);
+  if (split_on()) hipLaunchKernelGGL((conv_fwd_dma_kernel<WGM, WGN, true>), dim3(units), dim3(64 * T::NW), T::SMEM, hs(s), p, sc);
+  else hipLaunchKernelGGL((conv_fwd_dma_kernel<WGM, WGN, false>), dim3(units), dim3(64 * T::NW), T::SMEM, hs(s), p, sc);
   check_launch("conv_fwd_dma");
   if (sc.tail_tiles > 0 && sc.tail_s > 1) {
     hipLaunchKernelGGL((conv_dma_reduce_kernel<T::BM, T::BN>), dim3(T::BM * T::BN / 4 / 256, sc.tail_tiles), dim3(256), 0, hs(s), p, sc);
@@ -1955,7 +2014,8 @@ void conv_fwd(Stream& s, const ConvFwdArgs& a) {
       // rounds of 768 but 1008 = 1.97 rounds of 512
       const int wide = getenv("SWN_DMA_WIDE") ? atoi(getenv("SWN_DMA_WIDE")) : 1;   // 0 never, 1 by cost, 2 always (tests); per launch
       double c22 = 0, c24 = 0;
-      if (wide && a.Npad % 256 == 0) { plan_fwd_dma<2, 2>(p, nb, s.ws_bytes, &c22); plan_fwd_dma<2, 4>(p, nb, s.ws_bytes, &c24); }
+      // (with the split main loop the 8-wave tile spills at its 128-VGPR budget and measures slower: f32-MFMA form only)
+      if (wide && (wide == 2 || !split_on()) && a.Npad % 256 == 0) { plan_fwd_dma<2, 2>(p, nb, s.ws_bytes, &c22); plan_fwd_dma<2, 4>(p, nb, s.ws_bytes, &c24); }
       if (c24 > 0 && (wide == 2 || c24 < 0.95 * c22)) launch_fwd_dma<2, 4>(s, p, nb);
       else launch_fwd_dma<2, 2>(s, p, nb);
     }
@@ -2025,7 +2085,7 @@ static void launch_wgrad_dma(Stream& s, GemmP& p, int nb) {
   const DmaSched sc = plan_dma(p.ntiles * nb, p.ntiles, nmb, 256 * wg_per_cu, (size_t)T::BMK * T::BN * 4, s.ws_bytes);
   p.slab = reinterpret_cast<float*>(s.ws);
   p.splits = sc.tail_s;
-  static bool once = (set_smem(conv_wgrad_dma_kernel<WGM, WGN>, T::SMEM), true);
+  static bool once = (set_smem(conv_wgrad_dma_kernel<WGM, WGN, true>, T::SMEM), set_smem(conv_wgrad_dma_kernel<WGM, WGN, false>, T::SMEM), true);
   (void)once;
   char pname[112];
   if (prof_detail())
@@ -2035,7 +2095,8 @@ static void launch_wgrad_dma(Stream& s, GemmP& p, int nb) {
     snprintf(pname, sizeof pname, "conv_wgrad_dma_%dx%d", T::BMK, T::BN);
   ProfScope prof(s, pname, 2.0 * p.M * p.Cout * p.K * nb);
   const int units = sc.full + sc.tail_tiles * sc.tail_s;
-  hipLaunchKernelGGL((conv_wgrad_dma_kernel<WGM, WGN>), dim3(units), dim3(64 * T::NW), T::SMEM, hs(s), p, sc);
+  if (split_on()) hipLaunchKernelGGL((conv_wgrad_dma_kernel<WGM, WGN, true>), dim3(units), dim3(64 * T::NW), T::SMEM, hs(s), p, sc);
+  else hipLaunchKernelGGL((conv_wgrad_dma_kernel<WGM, WGN, false>), dim3(units), dim3(64 * T::NW), T::SMEM, hs(s), p, sc);
   check_launch("conv_wgrad_dma");
   if (sc.tail_tiles > 0 && sc.tail_s > 1) {
     hipLaunchKernelGGL((wgrad_dma_reduce_kernel<T::BMK, T::BN>), dim3(T::BMK * T::BN / 4 / 256, sc.tail_tiles), dim3(256), 0, hs(s), p, sc);

@@ -250,3 +250,32 @@ def test_conv_wide_ring_tile(monkeypatch):
         ref_conv(xr, w, b, kind, tr).backward(dy)
         dx = run_conv(ctx, kind, tr, 2, False, torch.zeros_like(x), w, None, 0, dy=dy)
         assert rel(dx, xr.grad) < 1e-4, ("dgrad", kind, tr, n, ci, h, co, rel(dx, xr.grad))
+
+
+@pytest.mark.gpu
+def test_split_main_loop_is_as_accurate_as_the_f32_mfma(monkeypatch):
+    """The ring kernels form fp32 products from an exact 3-way bf16 split (6 bf16 MFMA products, fp32 accumulate;
+    conv_gemm.hip).  Against a float64 convolution the result must be at least as close as the v_mfma_f32_32x32x2_f32
+    form (SWN_SPLIT=0) -- forward, input gradient and weight gradient -- and the two forms must agree to fp32
+    round-off.  Inputs carry full 24-bit mantissas (randn)."""
+    ctx = _ctx("gpu")
+    g = torch.Generator().manual_seed(11)
+    for kind, n, ci, h, co in ((K4S2, 4, 128, 64, 256), (K3REFL, 2, 256, 32, 256), (K4S2, 2, 512, 16, 512)):
+        k = 3 if kind == K3REFL else 4
+        x = torch.randn(n, ci, h, h, generator=g)
+        w = torch.randn(co, ci, k, k, generator=g) * (2.0 / (ci * k * k)) ** 0.5
+        xd, wd = x.double().requires_grad_(True), w.double().requires_grad_(True)
+        y64 = ref_conv(xd, wd, None, kind, 0)
+        dy = torch.randn(y64.shape, generator=g)
+        gx64, gw64 = torch.autograd.grad(y64, (xd, wd), dy.double())
+        res = {}
+        for mode in ("1", "0"):
+            monkeypatch.setenv("SWN_SPLIT", mode)
+            monkeypatch.setenv("SWN_WINOGRAD", "0")
+            res[mode] = (run_conv(ctx, kind, 0, 0, False, x, w, None, 0, y64.shape),
+                         run_conv(ctx, kind, 0, 2, False, torch.zeros_like(x), w, None, 0, dy=dy),
+                         run_conv(ctx, kind, 0, 1, False, x, torch.zeros_like(w), None, 0, dy=dy))
+        for what, i, ref in (("fwd", 0, y64), ("dgrad", 1, gx64), ("wgrad", 2, gw64)):
+            e_split, e_f32 = rel(res["1"][i], ref), rel(res["0"][i], ref)
+            assert e_split <= 1.15 * e_f32 + 2e-8, (what, kind, ci, co, "split %.3e" % e_split, "f32 mfma %.3e" % e_f32)
+            assert e_split < 2e-6 and rel(res["1"][i], res["0"][i]) < 2e-6

@@ -1,0 +1,308 @@
+// gemm_lab_split -- stand-alone bench: the LDS-DMA ring GEMM with the fp32 products formed on the bf16 matrix cores from
+// an exact 3-way bf16 split of both operands (x = hi + mid + lo, 8 mantissa bits each, by truncation: no rounding
+// error in the split), 6 of the 9 partial products (all with weight >= 2^-16; the dropped ones are below 2^-24),
+// fp32 accumulation.  MODE 0 = v_mfma_f32_32x32x2_f32 (reference), 1 = 6-term split, 2 = 3-term split (hi*hi + hi*mid
+// + mid*hi: ~2^-16, tf32-like, for comparison only).  Not part of the library.
+// (derived from gemm_lab.hip)
+// C[m][n] = sum_k A[m][k] B[k][n], A row-major (k contiguous: an NHWC activation seen through a 1x1 tap),
+// B row-major [K][N] (the packed weight panel), batched over blockIdx.z (Winograd planes).
+//
+//   v1<WGM>: LDS-DMA staging (buffer_load_dwordx4 ... lds: no staging VGPRs, no ds_write), BK = 16, 3-stage LDS
+//            ring with counted vmcnt (two stages in flight across the barrier), XOR-swizzled A rows
+//            (conflict-free ds_read_b128), B fragments as ds_read_b64 of adjacent columns (float2 epilogue
+//            stores), <= 128 VGPRs so that two 8-wave workgroups (or three 4-wave ones) share a CU.
+//   prod   : the library's conv_fwd on the same shape (1x1 gather), linked from libswapnet_hip.so.
+// Build:  hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/gemm_lab.hip -Iswapnet_amd/csrc -Lswapnet_amd/csrc
+//               -lswapnet_hip -Wl,-rpath,'$ORIGIN/../swapnet_amd/csrc' -o tools/gemm_lab
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+struct LabP {
+  const float* A; const float* B; float* C;
+  int M, N, K, lda, ldb, ldc;
+  size_t a_bs, b_bs, c_bs;
+  int tiles_n, ntiles;
+  unsigned a_bytes, b_bytes;
+  unsigned long long* trace;
+  int padsim;        // rows m with m % 7 == 3 are "padding taps": fetched out of range (must read as 0)
+};
+
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+// raw buffer descriptor (stride 0, num_records = bytes; out-of-range offsets read 0)
+__device__ __forceinline__ i32x4 make_rsrc(const void* ptr, unsigned bytes) {
+  const unsigned long long a = (unsigned long long)ptr;
+  i32x4 r;
+  r[0] = (int)(unsigned)(a & 0xffffffffull); r[1] = (int)(unsigned)((a >> 32) & 0xffffull); r[2] = (int)bytes; r[3] = 0x00020000;
+  return r;
+}
+// One LDS-DMA instruction: every lane fetches 16 bytes at rsrc.base + voff + soff; the wave's 1 KiB lands at LDS byte
+// address lds_dst + 16 * lane.  Issued from an asm statement so that hipcc does NOT know LDS is written: its waitcnt
+// pass would otherwise put s_waitcnt vmcnt(0) in front of every following ds_read (one pending LDS-DMA = "may alias"),
+// which serialises the ring.  Completion is counted by hand (s_waitcnt vmcnt(N) + s_barrier before the reads).
+__device__ __forceinline__ void lds_dma16(unsigned voff, i32x4 rsrc, unsigned soff, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 4\n\tbuffer_load_dwordx4 %1, %2, %4 offen lds\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(voff), "s"(rsrc), "s"(lds_dst), "s"(soff) : "memory");
+}
+
+__device__ __forceinline__ int xcd_swz(int bid, int n) {
+  const int q = n >> 3, r = n & 7, xcd = bid & 7, i = bid >> 3;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + i;
+}
+
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+// 8 floats -> three registers-quadruples of packed bf16 (element j of the MFMA operand = value j)
+__device__ __forceinline__ void split8(const float* v, u32x4& hi, u32x4& mid, u32x4& lo) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const unsigned x0 = __float_as_uint(v[2 * q]), x1 = __float_as_uint(v[2 * q + 1]);
+    hi[q] = __builtin_amdgcn_perm(x1, x0, 0x07060302u);                 // {x1[31:16], x0[31:16]}
+    const float r0 = v[2 * q] - __uint_as_float(x0 & 0xffff0000u), r1 = v[2 * q + 1] - __uint_as_float(x1 & 0xffff0000u);
+    const unsigned y0 = __float_as_uint(r0), y1 = __float_as_uint(r1);
+    mid[q] = __builtin_amdgcn_perm(y1, y0, 0x07060302u);
+    const float s0 = r0 - __uint_as_float(y0 & 0xffff0000u), s1 = r1 - __uint_as_float(y1 & 0xffff0000u);
+    lo[q] = __builtin_amdgcn_perm(__float_as_uint(s1), __float_as_uint(s0), 0x07060302u);
+  }
+}
+__device__ __forceinline__ f32x16 mma(u32x4 a, u32x4 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256, 3)
+void gemm_v1(LabP p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int WGM = 2;
+  constexpr int NW = 2 * WGM, BM = 64 * WGM, BN = 128, BK = 16, NST = 3;
+  constexpr int A_FL = BM * BK, B_FL = BK * BN, ST_FL = A_FL + B_FL;
+  constexpr int AI = (BM / 16) / NW;
+  constexpr int BI = 8 / NW;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int t = threadIdx.x, lane = t & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wm = wid >> 1, wn = wid & 1;
+  const int tile = xcd_swz(blockIdx.x, p.ntiles);
+  const int tile_n = tile % p.tiles_n, tile_m = tile / p.tiles_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const float* Ab = p.A + (size_t)blockIdx.z * p.a_bs;
+  const float* Bb = p.B + (size_t)blockIdx.z * p.b_bs;
+  float* Cb = p.C + (size_t)blockIdx.z * p.c_bs;
+  const i32x4 rsA = make_rsrc(Ab, p.a_bytes), rsB = make_rsrc(Bb, p.b_bytes);
+  const unsigned lds0 = (unsigned)(size_t)(lds_ptr_t)smem;
+  unsigned a_voff[AI], b_voff[BI];
+#pragma unroll
+  for (int r = 0; r < AI; ++r) {
+    const int row = 16 * (wid * AI + r) + (lane >> 2);
+    const int c = (lane & 3) ^ ((row >> 2) & 3);
+    const int gm = m0 + row;
+    a_voff[r] = gm < p.M ? (unsigned)(gm * p.lda + 4 * c) * 4u : 0x80000000u;
+  }
+#pragma unroll
+  for (int r = 0; r < BI; ++r) {
+    const int krow = 2 * (wid * BI + r) + (lane >> 5);
+    const int nn = n0 + 4 * (lane & 31);
+    b_voff[r] = nn < p.N ? (unsigned)(krow * p.ldb + nn) * 4u : 0x80000000u;
+  }
+  auto issue = [&](int st, int kb) {
+    const unsigned As = lds0 + (unsigned)(st * ST_FL) * 4u, Bs = As + A_FL * 4u;
+#pragma unroll
+    for (int r = 0; r < AI; ++r) lds_dma16(a_voff[r], rsA, (unsigned)kb * (BK * 4), As + (unsigned)(wid * AI + r) * 1024u);
+#pragma unroll
+    for (int r = 0; r < BI; ++r)
+      lds_dma16(b_voff[r], rsB, (unsigned)kb * (BK * 4) * (unsigned)p.ldb, Bs + (unsigned)(wid * BI + r) * 1024u);
+  };
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  const int h = lane >> 5, l31 = lane & 31;
+  const int f = (l31 >> 2) & 3;
+  const int a_rd = (wm * 64 + l31) * BK;
+  const int a_c0 = ((2 * h) ^ f) * 4, a_c1 = ((2 * h + 1) ^ f) * 4;
+  const int b_rd = A_FL + (8 * h) * BN + wn * 64 + 2 * l31;
+  auto compute = [&](int st) {
+    const float* S = smem + st * ST_FL;
+    float af[2][8], bf[2][8];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const float4 v0 = *reinterpret_cast<const float4*>(S + a_rd + i * 32 * BK + a_c0);
+      const float4 v1 = *reinterpret_cast<const float4*>(S + a_rd + i * 32 * BK + a_c1);
+      af[i][0] = v0.x; af[i][1] = v0.y; af[i][2] = v0.z; af[i][3] = v0.w;
+      af[i][4] = v1.x; af[i][5] = v1.y; af[i][6] = v1.z; af[i][7] = v1.w;
+    }
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      const float2 b = *reinterpret_cast<const float2*>(S + b_rd + s * BN);
+      bf[0][s] = b.x; bf[1][s] = b.y;
+    }
+    if (MODE == 0) {
+#pragma unroll
+      for (int s = 0; s < 8; ++s)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s], bf[j][s], acc[i][j], 0, 0, 0);
+    } else if (MODE >= 3) {
+      // same 6-term split, ordered so that the splits of B1 / A1 can issue in the shadow of the first pairs' MFMAs
+      u32x4 ah[2], am[2], al[2], bh[2], bm[2], bl[2];
+      auto pair = [&](int i, int j) {
+        f32x16 c = acc[i][j];
+        c = mma(al[i], bh[j], c); c = mma(ah[i], bl[j], c); c = mma(am[i], bm[j], c);
+        c = mma(am[i], bh[j], c); c = mma(ah[i], bm[j], c); c = mma(ah[i], bh[j], c);
+        acc[i][j] = c;
+      };
+      split8(af[0], ah[0], am[0], al[0]); split8(bf[0], bh[0], bm[0], bl[0]);
+      pair(0, 0);
+      split8(bf[1], bh[1], bm[1], bl[1]);
+      pair(0, 1);
+      split8(af[1], ah[1], am[1], al[1]);
+      pair(1, 0);
+      pair(1, 1);
+      if (MODE == 4) {
+#pragma unroll
+        for (int g = 0; g < 12; ++g) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 8, 0); }
+        __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);
+      }
+    } else {
+      // lane (l31, h) holds k = 8h .. 8h+7 of its A row / B column: exactly the 32x32x16 operand layout
+      u32x4 ah[2], am[2], al[2], bh[2], bm[2], bl[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) { split8(af[i], ah[i], am[i], al[i]); split8(bf[i], bh[i], bm[i], bl[i]); }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          f32x16 c = acc[i][j];
+          if (MODE == 1) { c = mma(al[i], bh[j], c); c = mma(ah[i], bl[j], c); c = mma(am[i], bm[j], c); }   // smallest first
+          c = mma(am[i], bh[j], c); c = mma(ah[i], bm[j], c); c = mma(ah[i], bh[j], c);
+          acc[i][j] = c;
+        }
+    }
+  };
+  const int nkb = p.K / BK;
+  issue(0, 0);
+  if (nkb > 1) issue(1, 1);
+  int st = 0;
+  for (int kb = 0; kb < nkb; ++kb) {
+    if (kb + 1 < nkb) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(AI + BI) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    int st2 = st + 2; if (st2 >= NST) st2 -= NST;
+    if (kb + 2 < nkb) issue(st2, kb + 2);
+    compute(st);
+    st = st + 1 == NST ? 0 : st + 1;
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int row = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+      const int col = n0 + wn * 64 + 2 * l31;
+      if (row < p.M && col < p.N)
+        *reinterpret_cast<float2*>(Cb + (size_t)row * p.ldc + col) = make_float2(acc[i][0][e], acc[i][1][e]);
+    }
+#endif
+}
+__global__ void gemm_ref(LabP p) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)p.M * p.N) return;
+  const int m = (int)(i / p.N), n = (int)(i % p.N);
+  const float* A = p.A + (size_t)blockIdx.z * p.a_bs + (size_t)m * p.lda;
+  const float* B = p.B + (size_t)blockIdx.z * p.b_bs + n;
+  double acc = 0;
+  for (int k = 0; k < p.K; ++k) acc += (double)A[k] * B[(size_t)k * p.ldb];
+  p.C[(size_t)blockIdx.z * p.c_bs + (size_t)m * p.ldc + n] = (float)acc;
+}
+
+
+struct Shape { const char* name; int M, N, K, batch; };
+// full 24-bit mantissas, magnitudes spread over ~2^8 (a 16-bit-quantised fill would hide the split error)
+static void fill(std::vector<float>& v, unsigned seed) {
+  unsigned s = seed * 2654435761u + 12345u;
+  for (auto& x : v) {
+    s = s * 1664525u + 1013904223u; const float m = ((s >> 8) & 0xFFFFFF) / 8388608.0f - 1.0f;
+    s = s * 1664525u + 1013904223u; x = std::ldexp(m, -(int)((s >> 24) & 7));
+  }
+}
+template <int MODE>
+static void launch(hipStream_t st, LabP p, int batch) {
+  constexpr int smem = 3 * (128 * 16 + 16 * 128) * 4;
+  static bool once = false;
+  if (!once) { CK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_v1<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, smem)); once = true; }
+  p.tiles_n = (p.N + 127) / 128;
+  p.ntiles = ((p.M + 127) / 128) * p.tiles_n;
+  hipLaunchKernelGGL((gemm_v1<MODE>), dim3(p.ntiles, 1, batch), dim3(256), smem, st, p);
+}
+int main(int argc, char** argv) {
+  const int reps = argc > 1 ? atoi(argv[1]) : 10;
+  std::vector<Shape> shapes = {
+      {"wino_resblock  (36 planes 512x1024x1024)", 512, 1024, 1024, 36},
+      {"down4 (8192x512x4096)", 8192, 512, 4096, 1},
+      {"down2 (131072x128x1024)", 131072, 128, 1024, 1},
+  };
+  hipStream_t st; CK(hipStreamCreate(&st));
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  for (const Shape& s : shapes) {
+    const size_t na = (size_t)s.M * s.K * s.batch, nb = (size_t)s.K * s.N * s.batch, nc = (size_t)s.M * s.N * s.batch;
+    std::vector<float> ha(na), hb(nb);
+    fill(ha, 1); fill(hb, 2);
+    float *dA, *dB, *dC, *dR;
+    CK(hipMalloc((void**)&dA, na * 4)); CK(hipMalloc((void**)&dB, nb * 4)); CK(hipMalloc((void**)&dC, nc * 4)); CK(hipMalloc((void**)&dR, nc * 4));
+    CK(hipMemcpy(dA, ha.data(), na * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(dB, hb.data(), nb * 4, hipMemcpyHostToDevice));
+    LabP p{};
+    p.A = dA; p.B = dB; p.C = dR; p.M = s.M; p.N = s.N; p.K = s.K; p.lda = s.K; p.ldb = s.N; p.ldc = s.N;
+    p.a_bs = (size_t)s.M * s.K; p.b_bs = (size_t)s.K * s.N; p.c_bs = (size_t)s.M * s.N;
+    p.a_bytes = (unsigned)((size_t)s.M * s.K * 4); p.b_bytes = (unsigned)((size_t)s.K * s.N * 4);
+    hipLaunchKernelGGL(gemm_ref, dim3((unsigned)(((size_t)s.M * s.N + 255) / 256), 1, s.batch), dim3(256), 0, st, p);
+    CK(hipStreamSynchronize(st));
+    p.C = dC;
+    const double flops = 2.0 * s.M * s.N * s.K * s.batch;
+    printf("== %s\n", s.name);
+    std::vector<float> r(nc); CK(hipMemcpy(r.data(), dR, nc * 4, hipMemcpyDeviceToHost));
+    auto run = [&](const char* what, auto&& fn) {
+      CK(hipMemsetAsync(dC, 0, nc * 4, st));
+      fn(); CK(hipStreamSynchronize(st));
+      std::vector<float> c(nc); CK(hipMemcpy(c.data(), dC, nc * 4, hipMemcpyDeviceToHost));
+      double num = 0, den = 0;
+      for (size_t i = 0; i < nc; ++i) { const double d = (double)c[i] - r[i]; num += d * d; den += (double)r[i] * r[i]; }
+      float best = 1e30f;
+      for (int rnd = 0; rnd < 3; ++rnd) {
+        CK(hipEventRecord(e0, st));
+        for (int i = 0; i < reps; ++i) fn();
+        CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1));
+        float t; CK(hipEventElapsedTime(&t, e0, e1)); best = std::min(best, t / reps);
+      }
+      printf("   %-12s rel-L2 vs fp64-accumulated reference %.3e   %8.3f ms  %7.1f fp32-equivalent TFLOP/s\n", what, std::sqrt(num / den), best, flops / best * 1e-9);
+    };
+    for (int rnd = 0; rnd < 2; ++rnd) {
+      run("fp32 mfma", [&] { launch<0>(st, p, s.batch); });
+      run("bf16 x6", [&] { launch<1>(st, p, s.batch); });
+      run("bf16 x3", [&] { launch<2>(st, p, s.batch); });
+      run("x6 ordered", [&] { launch<3>(st, p, s.batch); });
+      run("x6 sched", [&] { launch<4>(st, p, s.batch); });
+    }
+    CK(hipFree(dA)); CK(hipFree(dB)); CK(hipFree(dC)); CK(hipFree(dR));
+  }
+  return 0;
+}
