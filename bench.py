@@ -269,13 +269,14 @@ def main():
             ach = k["flops"] / (k["ms"] * 1e-3) / 1e12
             gemm_ms = sum(v["ms"] for v in kernels.values()) / nprof
             traffic, traffic_src = None, None
+            sp = "true" if SPLIT else "false"
             rp_name = {"conv_fwd_128x128_fast": "conv_fwd_kernel<2, 2, 2, 2, true>",
                        "conv_fwd_256x128_fast": "conv_fwd_kernel<2, 2, 4, 2, true>",
-                       "conv_fwd_dma_128x128": "conv_fwd_dma_kernel<2, 2>", "conv_fwd_dma_256x64": "conv_fwd_dma_kernel<4, 1>",
-                       "conv_fwd_dma_128x256": "conv_fwd_dma_kernel<2, 4>",
-                       "conv_wgrad_dma_128x128": "conv_wgrad_dma_kernel<2, 2>",
-                       "conv_wgrad_dma_256x64": "conv_wgrad_dma_kernel<4, 1>"}.get(dom.split("[")[0], dom)
-            for tname in ("traffic_r02.json", "traffic_r01.json"):
+                       "conv_fwd_dma_128x128": "conv_fwd_dma_kernel<2, 2, %s>" % sp, "conv_fwd_dma_256x64": "conv_fwd_dma_kernel<4, 1, %s>" % sp,
+                       "conv_fwd_dma_128x256": "conv_fwd_dma_kernel<2, 4, %s>" % sp,
+                       "conv_wgrad_dma_128x128": "conv_wgrad_dma_kernel<2, 2, %s>" % sp,
+                       "conv_wgrad_dma_256x64": "conv_wgrad_dma_kernel<4, 1, %s>" % sp}.get(dom.split("[")[0], dom)
+            for tname in ("traffic_r02b.json", "traffic_r02.json", "traffic_r01.json"):
                 tpath = os.path.join(REPO, "profiles", tname)
                 if os.path.exists(tpath):
                     # HBM bytes per launch from the committed rocprofv3 PMC passes of this same command

@@ -79,6 +79,18 @@ __device__ __forceinline__ void split8(const float* v, u32x4& hi, u32x4& mid, u3
     lo[q] = __builtin_amdgcn_perm(__float_as_uint(s1), __float_as_uint(s0), 0x07060302u);
   }
 }
+// variant: both residual levels cut from x itself (two parallel and/sub pairs instead of a 4-deep chain)
+__device__ __forceinline__ void split8p(const float* v, u32x4& hi, u32x4& mid, u32x4& lo) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const unsigned x0 = __float_as_uint(v[2 * q]), x1 = __float_as_uint(v[2 * q + 1]);
+    hi[q] = __builtin_amdgcn_perm(x1, x0, 0x07060302u);
+    const float a0 = __uint_as_float(x0 & 0xffff0000u), a1 = __uint_as_float(x1 & 0xffff0000u);
+    const float b0 = __uint_as_float(x0 & 0xffffff00u), b1 = __uint_as_float(x1 & 0xffffff00u);
+    mid[q] = __builtin_amdgcn_perm(__float_as_uint(b1 - a1), __float_as_uint(b0 - a0), 0x07060302u);
+    lo[q] = __builtin_amdgcn_perm(__float_as_uint(v[2 * q + 1] - b1), __float_as_uint(v[2 * q] - b0), 0x07060302u);
+  }
+}
 __device__ __forceinline__ f32x16 mma(u32x4 a, u32x4 b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
@@ -162,26 +174,18 @@ void gemm_v1(LabP p) {
           for (int j = 0; j < 2; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s], bf[j][s], acc[i][j], 0, 0, 0);
     } else if (MODE >= 3) {
-      // same 6-term split, ordered so that the splits of B1 / A1 can issue in the shadow of the first pairs' MFMAs
       u32x4 ah[2], am[2], al[2], bh[2], bm[2], bl[2];
-      auto pair = [&](int i, int j) {
-        f32x16 c = acc[i][j];
-        c = mma(al[i], bh[j], c); c = mma(ah[i], bl[j], c); c = mma(am[i], bm[j], c);
-        c = mma(am[i], bh[j], c); c = mma(ah[i], bm[j], c); c = mma(ah[i], bh[j], c);
-        acc[i][j] = c;
-      };
-      split8(af[0], ah[0], am[0], al[0]); split8(bf[0], bh[0], bm[0], bl[0]);
-      pair(0, 0);
-      split8(bf[1], bh[1], bm[1], bl[1]);
-      pair(0, 1);
-      split8(af[1], ah[1], am[1], al[1]);
-      pair(1, 0);
-      pair(1, 1);
-      if (MODE == 4) {
 #pragma unroll
-        for (int g = 0; g < 12; ++g) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 8, 0); }
-        __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);
-      }
+      for (int i = 0; i < 2; ++i) { split8p(af[i], ah[i], am[i], al[i]); split8p(bf[i], bh[i], bm[i], bl[i]); }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          f32x16 c = acc[i][j];
+          c = mma(al[i], bh[j], c); c = mma(ah[i], bl[j], c); c = mma(am[i], bm[j], c);
+          c = mma(am[i], bh[j], c); c = mma(ah[i], bm[j], c); c = mma(ah[i], bh[j], c);
+          acc[i][j] = c;
+        }
     } else {
       // lane (l31, h) holds k = 8h .. 8h+7 of its A row / B column: exactly the 32x32x16 operand layout
       u32x4 ah[2], am[2], al[2], bh[2], bm[2], bl[2];
@@ -299,8 +303,7 @@ int main(int argc, char** argv) {
       run("fp32 mfma", [&] { launch<0>(st, p, s.batch); });
       run("bf16 x6", [&] { launch<1>(st, p, s.batch); });
       run("bf16 x3", [&] { launch<2>(st, p, s.batch); });
-      run("x6 ordered", [&] { launch<3>(st, p, s.batch); });
-      run("x6 sched", [&] { launch<4>(st, p, s.batch); });
+      run("x6 parallel-cut", [&] { launch<3>(st, p, s.batch); });
     }
     CK(hipFree(dA)); CK(hipFree(dB)); CK(hipFree(dC)); CK(hipFree(dR));
   }

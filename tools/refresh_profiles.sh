@@ -1,33 +1,33 @@
 # Produces everything under profiles/ for one round: run on the GPU box as
-#   gpurun --timeout 2400 -- 'bash tools/refresh_profiles.sh r02'
-# then, back in the build container, `python tools/collect_profiles.py r02` condenses gpurun_out/ into profiles/.
+#   gpurun --timeout 2400 -- 'bash tools/refresh_profiles.sh r02b'
+# then copy the condensed files from gpurun_out/<tag>/ into profiles/ (README there lists the names).
 # Per-kernel profiles are taken with the library's second stream off (SWN_OVERLAP=0): with it on, kernels of the two
 # streams share the GPU and their individual durations / counters are not attributable.  Counter passes (--pmc) are
-# separate runs without any trace domain, one step each.
-TAG=${1:-r02}
+# separate runs without any trace domain, one step each.  Order: tests and bench lines first (a session may be cut).
+TAG=${1:-r02b}
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/$TAG
 mkdir -p $O
 cd $R
 python -m pytest tests -m gpu -q > $O/tests_gpu.log 2>&1
+tail -3 $O/tests_gpu.log
 python bench.py --steps 10 --warmup 3 --with-h2d > $O/bench_c2.json 2> $O/bench_c2.err
+python -c "import json;d=json.load(open('$O/bench_c2.json'));print(d['value'],d['ms_per_step'],d['roofline']['achieved'],d['roofline']['frac'],d.get('cpu_baseline'))"
 python bench.py --stage texture --steps 10 --warmup 3 > $O/bench_c3.json 2> $O/bench_c3.err
 python bench.py --stage infer > $O/bench_infer.json 2> $O/bench_infer.err
 SWAPNET_BENCH_RCCL1=1 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-roofline > $O/bench_c2_rccl_world1.json 2> $O/bench_c2_rccl_world1.err
+SWN_SPLIT=0 python bench.py --steps 10 --warmup 3 --no-cpu-baseline > $O/bench_c2_f32mfma.json 2> $O/bench_c2_f32mfma.err
 cd /tmp && export TMPDIR=/tmp
 B="python $R/bench.py --no-cpu-baseline --no-roofline"
 SWN_OVERLAP=0 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_warp -o warp -- $B --steps 3 --warmup 1 > $O/prof_warp.log 2>&1
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_warp_ov -o warp -- $B --steps 3 --warmup 1 > $O/prof_warp_ov.log 2>&1
-SWN_OVERLAP=0 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_tex -o tex -- $B --stage texture --steps 3 --warmup 1 > $O/prof_tex.log 2>&1
-SWN_OVERLAP=0 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o warp -- $B --steps 1 --warmup 0 > $O/pmc_fetch.log 2>&1
-SWN_OVERLAP=0 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o warp -- $B --steps 1 --warmup 0 > $O/pmc_write.log 2>&1
 SWN_OVERLAP=0 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $O/pmc_sq -o warp -- $B --steps 1 --warmup 0 > $O/pmc_sq.log 2>&1
 SWN_OVERLAP=0 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SALU --output-format csv -d $O/pmc_sq2 -o warp -- $B --steps 1 --warmup 0 > $O/pmc_sq2.log 2>&1
-# keep the merge small: the raw per-dispatch CSVs of the counter passes are condensed on the box
+SWN_OVERLAP=0 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o warp -- $B --steps 1 --warmup 0 > $O/pmc_fetch.log 2>&1
+SWN_OVERLAP=0 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o warp -- $B --steps 1 --warmup 0 > $O/pmc_write.log 2>&1
+SWN_OVERLAP=0 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_tex -o tex -- $B --stage texture --steps 3 --warmup 1 > $O/prof_tex.log 2>&1
+# keep the merge small: the raw per-dispatch CSVs are condensed on the box
 cd $R
-for d in prof_warp prof_warp_ov prof_tex pmc_fetch pmc_write pmc_sq pmc_sq2; do
+for d in prof_warp prof_tex pmc_fetch pmc_write pmc_sq pmc_sq2; do
   python profiles/summarize_rocprof.py $O/$d ${TAG}_$d --out $O > /dev/null 2>&1
   rm -rf $O/$d
 done
-tail -3 $O/tests_gpu.log
-python -c "import json;d=json.load(open('$O/bench_c2.json'));print(d['value'],d['ms_per_step'],d['roofline']['frac'],d.get('cpu_baseline'))"
