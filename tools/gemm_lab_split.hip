@@ -174,18 +174,13 @@ void gemm_v1(LabP p) {
           for (int j = 0; j < 2; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s], bf[j][s], acc[i][j], 0, 0, 0);
     } else if (MODE >= 3) {
+      // term-outer: consecutive MFMAs write different accumulators (no back-to-back dependent chain)
       u32x4 ah[2], am[2], al[2], bh[2], bm[2], bl[2];
 #pragma unroll
-      for (int i = 0; i < 2; ++i) { split8p(af[i], ah[i], am[i], al[i]); split8p(bf[i], bh[i], bm[i], bl[i]); }
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          f32x16 c = acc[i][j];
-          c = mma(al[i], bh[j], c); c = mma(ah[i], bl[j], c); c = mma(am[i], bm[j], c);
-          c = mma(am[i], bh[j], c); c = mma(ah[i], bm[j], c); c = mma(ah[i], bh[j], c);
-          acc[i][j] = c;
-        }
+      for (int i = 0; i < 2; ++i) { split8(af[i], ah[i], am[i], al[i]); split8(bf[i], bh[i], bm[i], bl[i]); }
+#define TERM(X, Y) _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j) acc[i][j] = mma(X[i], Y[j], acc[i][j]);
+      TERM(al, bh) TERM(ah, bl) TERM(am, bm) TERM(am, bh) TERM(ah, bm) TERM(ah, bh)
+#undef TERM
     } else {
       // lane (l31, h) holds k = 8h .. 8h+7 of its A row / B column: exactly the 32x32x16 operand layout
       u32x4 ah[2], am[2], al[2], bh[2], bm[2], bl[2];
@@ -227,6 +222,133 @@ void gemm_v1(LabP p) {
     }
 #endif
 }
+
+// ---- variant: B (the weight panel) arrives PRE-CUT: three bf16 planes in k-inner layout [plane][K/8][N][8], produced once
+// per step by whoever re-packs the weights.  The B fragment is then three ds_read_b128 per column and costs no VALU; only
+// the A fragments are cut in the loop.  LDS per stage: A 8 KB (fp32) + B 12 KB (3 planes x 2 k-groups x 128 cols x 16 B).
+struct LabQ { LabP p; const unsigned short* Bs; size_t bs_plane, bs_batch; unsigned bs_bytes; };
+template <int NSTQ>
+__global__ __launch_bounds__(256, 2)
+void gemm_bpre(LabQ q) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const LabP& p = q.p;
+  constexpr int BM = 128, BN = 128, BK = 16, NST = NSTQ;
+  constexpr int A_FL = BM * BK;                 // floats
+  constexpr int B_BYTES = 3 * 2 * BN * 16;      // 12 KB
+  constexpr int ST_BYTES = A_FL * 4 + B_BYTES;
+  constexpr int AI = 2, BI = 3;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int t = threadIdx.x, lane = t & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wm = wid >> 1, wn = wid & 1;
+  const int tile = xcd_swz(blockIdx.x, p.ntiles);
+  const int tile_n = tile % p.tiles_n, tile_m = tile / p.tiles_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const float* Ab = p.A + (size_t)blockIdx.z * p.a_bs;
+  float* Cb = p.C + (size_t)blockIdx.z * p.c_bs;
+  const i32x4 rsA = make_rsrc(Ab, p.a_bytes), rsB = make_rsrc(q.Bs + (size_t)blockIdx.z * q.bs_batch, q.bs_bytes);
+  const unsigned lds0 = (unsigned)(size_t)(lds_ptr_t)smem;
+  unsigned a_voff[AI], b_voff[BI];
+#pragma unroll
+  for (int r = 0; r < AI; ++r) {
+    const int row = 16 * (wid * AI + r) + (lane >> 2);
+    const int c = (lane & 3) ^ ((row >> 2) & 3);
+    const int gm = m0 + row;
+    a_voff[r] = gm < p.M ? (unsigned)(gm * p.lda + 4 * c) * 4u : 0x80000000u;
+  }
+  // B instruction x = wid * 3 + r in [0, 12): plane = x / 4, k-group g = (x / 2) & 1, column half = x & 1; lane -> column
+#pragma unroll
+  for (int r = 0; r < BI; ++r) {
+    const int x = wid * BI + r;
+    const int plane = x >> 2, g = (x >> 1) & 1, half = x & 1;
+    const int nn = n0 + half * 64 + lane;
+    b_voff[r] = nn < p.N ? (unsigned)((size_t)plane * q.bs_plane * 2 + ((size_t)g * p.N + nn) * 16) : 0x80000000u;
+  }
+  auto issue = [&](int st, int kb) {
+    const unsigned As = lds0 + (unsigned)(st * ST_BYTES), Bs = As + A_FL * 4u;
+#pragma unroll
+    for (int r = 0; r < AI; ++r) lds_dma16(a_voff[r], rsA, (unsigned)kb * (BK * 4), As + (unsigned)(wid * AI + r) * 1024u);
+#pragma unroll
+    for (int r = 0; r < BI; ++r)        // one stage = 2 k-groups: advance by 2 * N * 16 bytes per stage
+      lds_dma16(b_voff[r], rsB, (unsigned)kb * 2u * (unsigned)p.N * 16u, Bs + (unsigned)(wid * BI + r) * 1024u);
+  };
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  const int h = lane >> 5, l31 = lane & 31;
+  const int f = (l31 >> 2) & 3;
+  const int a_rd = (wm * 64 + l31) * BK;
+  const int a_c0 = ((2 * h) ^ f) * 4, a_c1 = ((2 * h + 1) ^ f) * 4;
+  auto compute = [&](int st) {
+    const char* S = reinterpret_cast<const char*>(smem) + st * ST_BYTES;
+    const float* SA = reinterpret_cast<const float*>(S);
+    const char* SB = S + A_FL * 4;
+    float af[2][8];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const float4 v0 = *reinterpret_cast<const float4*>(SA + a_rd + i * 32 * BK + a_c0);
+      const float4 v1 = *reinterpret_cast<const float4*>(SA + a_rd + i * 32 * BK + a_c1);
+      af[i][0] = v0.x; af[i][1] = v0.y; af[i][2] = v0.z; af[i][3] = v0.w;
+      af[i][4] = v1.x; af[i][5] = v1.y; af[i][6] = v1.z; af[i][7] = v1.w;
+    }
+    u32x4 bh[2], bm[2], bl[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {       // lane's columns wn*64 + 2*l31 + j, k-group h
+      const int col = wn * 64 + 2 * l31 + j;
+      bh[j] = *reinterpret_cast<const u32x4*>(SB + ((0 * 2 + h) * 128 + col) * 16);
+      bm[j] = *reinterpret_cast<const u32x4*>(SB + ((1 * 2 + h) * 128 + col) * 16);
+      bl[j] = *reinterpret_cast<const u32x4*>(SB + ((2 * 2 + h) * 128 + col) * 16);
+    }
+    u32x4 ah[2], am[2], al[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) split8(af[i], ah[i], am[i], al[i]);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        f32x16 c = acc[i][j];
+        c = mma(al[i], bh[j], c); c = mma(ah[i], bl[j], c); c = mma(am[i], bm[j], c);
+        c = mma(am[i], bh[j], c); c = mma(ah[i], bm[j], c); c = mma(ah[i], bh[j], c);
+        acc[i][j] = c;
+      }
+  };
+  const int nkb = p.K / BK;
+  issue(0, 0);
+  if (NST == 3 && nkb > 1) issue(1, 1);
+  int st = 0;
+  for (int kb = 0; kb < nkb; ++kb) {
+    if (NST == 3) {
+      if (kb + 1 < nkb) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(AI + BI) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      int st2 = st + 2; if (st2 >= NST) st2 -= NST;
+      if (kb + 2 < nkb) issue(st2, kb + 2);
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      if (kb + 1 < nkb) issue(st ^ 1, kb + 1);
+    }
+    compute(st);
+    if (NST == 3) st = st + 1 == NST ? 0 : st + 1; else st ^= 1;
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int row = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+      const int col = n0 + wn * 64 + 2 * l31;
+      if (row < p.M && col < p.N)
+        *reinterpret_cast<float2*>(Cb + (size_t)row * p.ldc + col) = make_float2(acc[i][0][e], acc[i][1][e]);
+    }
+#endif
+}
+
 __global__ void gemm_ref(LabP p) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (size_t)p.M * p.N) return;
@@ -299,13 +421,42 @@ int main(int argc, char** argv) {
       }
       printf("   %-12s rel-L2 vs fp64-accumulated reference %.3e   %8.3f ms  %7.1f fp32-equivalent TFLOP/s\n", what, std::sqrt(num / den), best, flops / best * 1e-9);
     };
+    // pre-cut B: [batch][plane][K/8][N][8] bf16 (truncation split, exact)
+    std::vector<unsigned short> hs((size_t)3 * nb);
+    const size_t plane = (size_t)s.K * s.N;
+    for (int z = 0; z < s.batch; ++z)
+      for (int k = 0; k < s.K; ++k)
+        for (int n = 0; n < s.N; ++n) {
+          const float x = hb[(size_t)z * plane + (size_t)k * s.N + n];
+          unsigned u; memcpy(&u, &x, 4);
+          unsigned uh = u & 0xffff0000u; float fh; memcpy(&fh, &uh, 4);
+          const float r = x - fh; unsigned ur; memcpy(&ur, &r, 4);
+          unsigned um = ur & 0xffff0000u; float fm; memcpy(&fm, &um, 4);
+          const float q2 = r - fm; unsigned ul; memcpy(&ul, &q2, 4);
+          const size_t o = ((size_t)(k / 8) * s.N + n) * 8 + (k % 8);
+          hs[((size_t)z * 3 + 0) * plane + o] = (unsigned short)(u >> 16);
+          hs[((size_t)z * 3 + 1) * plane + o] = (unsigned short)(ur >> 16);
+          hs[((size_t)z * 3 + 2) * plane + o] = (unsigned short)(ul >> 16);
+        }
+    unsigned short* dS; CK(hipMalloc((void**)&dS, hs.size() * 2));
+    CK(hipMemcpy(dS, hs.data(), hs.size() * 2, hipMemcpyHostToDevice));
+    LabQ q{}; q.Bs = dS; q.bs_plane = plane; q.bs_batch = 3 * plane; q.bs_bytes = (unsigned)(3 * plane * 2);
+    auto launch_bpre = [&](auto kern, int nst) {
+      const int smem = nst * (128 * 16 * 4 + 3 * 2 * 128 * 16);
+      CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+      q.p = p; q.p.tiles_n = (p.N + 127) / 128; q.p.ntiles = ((p.M + 127) / 128) * q.p.tiles_n;
+      hipLaunchKernelGGL(kern, dim3(q.p.ntiles, 1, s.batch), dim3(256), smem, st, q);
+    };
     for (int rnd = 0; rnd < 2; ++rnd) {
+      run("B pre-cut 3st", [&] { launch_bpre(gemm_bpre<3>, 3); });
+      run("B pre-cut 2st", [&] { launch_bpre(gemm_bpre<2>, 2); });
       run("fp32 mfma", [&] { launch<0>(st, p, s.batch); });
       run("bf16 x6", [&] { launch<1>(st, p, s.batch); });
-      run("bf16 x3", [&] { launch<2>(st, p, s.batch); });
-      run("x6 parallel-cut", [&] { launch<3>(st, p, s.batch); });
+      run("x6 term-outer", [&] { launch<3>(st, p, s.batch); });
+
+
     }
-    CK(hipFree(dA)); CK(hipFree(dB)); CK(hipFree(dC)); CK(hipFree(dR));
+    CK(hipFree(dA)); CK(hipFree(dB)); CK(hipFree(dC)); CK(hipFree(dR)); CK(hipFree(dS));
   }
   return 0;
 }
