@@ -349,6 +349,132 @@ void gemm_bpre(LabQ q) {
 #endif
 }
 
+
+// ---- variant: 64 x 128 wave tile (workgroup 128 x 256, 4 waves, 2 workgroups / CU): the cut of an A fragment is amortised over
+// 4 column blocks, of a B fragment over 2 row blocks: (16 + 32) x 5.5 VALU per 48 MFMAs = 5.5 per MFMA instead of 7.3.
+template <int MODE>
+__global__ __launch_bounds__(256, 2)
+void gemm_w128(LabP p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int BM = 128, BN = 256, BK = 16, NST = 3;
+  constexpr int A_FL = BM * BK, B_FL = BK * BN, ST_FL = A_FL + B_FL;
+  constexpr int AI = 2, BI = 4;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int t = threadIdx.x, lane = t & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wm = wid >> 1, wn = wid & 1;
+  const int tile = xcd_swz(blockIdx.x, p.ntiles);
+  const int tile_n = tile % p.tiles_n, tile_m = tile / p.tiles_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const float* Ab = p.A + (size_t)blockIdx.z * p.a_bs;
+  const float* Bb = p.B + (size_t)blockIdx.z * p.b_bs;
+  float* Cb = p.C + (size_t)blockIdx.z * p.c_bs;
+  const i32x4 rsA = make_rsrc(Ab, p.a_bytes), rsB = make_rsrc(Bb, p.b_bytes);
+  const unsigned lds0 = (unsigned)(size_t)(lds_ptr_t)smem;
+  unsigned a_voff[AI], b_voff[BI];
+#pragma unroll
+  for (int r = 0; r < AI; ++r) {
+    const int row = 16 * (wid * AI + r) + (lane >> 2);
+    const int c = (lane & 3) ^ ((row >> 2) & 3);
+    const int gm = m0 + row;
+    a_voff[r] = gm < p.M ? (unsigned)(gm * p.lda + 4 * c) * 4u : 0x80000000u;
+  }
+#pragma unroll
+  for (int r = 0; r < BI; ++r) {
+    const int krow = wid * BI + r;
+    const int nn = n0 + 4 * lane;
+    b_voff[r] = nn < p.N ? (unsigned)(krow * p.ldb + nn) * 4u : 0x80000000u;
+  }
+  auto issue = [&](int st, int kb) {
+    const unsigned As = lds0 + (unsigned)(st * ST_FL) * 4u, Bs = As + A_FL * 4u;
+#pragma unroll
+    for (int r = 0; r < AI; ++r) lds_dma16(a_voff[r], rsA, (unsigned)kb * (BK * 4), As + (unsigned)(wid * AI + r) * 1024u);
+#pragma unroll
+    for (int r = 0; r < BI; ++r)
+      lds_dma16(b_voff[r], rsB, (unsigned)kb * (BK * 4) * (unsigned)p.ldb, Bs + (unsigned)(wid * BI + r) * 1024u);
+  };
+  f32x16 acc[2][4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  const int h = lane >> 5, l31 = lane & 31;
+  const int f = (l31 >> 2) & 3;
+  const int a_rd = (wm * 64 + l31) * BK;
+  const int a_c0 = ((2 * h) ^ f) * 4, a_c1 = ((2 * h + 1) ^ f) * 4;
+  const int b_rd = A_FL + (8 * h) * BN + wn * 128 + 2 * l31;
+  auto compute = [&](int st) {
+    const float* S = smem + st * ST_FL;
+    float af[2][8], bf[4][8];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const float4 v0 = *reinterpret_cast<const float4*>(S + a_rd + i * 32 * BK + a_c0);
+      const float4 v1 = *reinterpret_cast<const float4*>(S + a_rd + i * 32 * BK + a_c1);
+      af[i][0] = v0.x; af[i][1] = v0.y; af[i][2] = v0.z; af[i][3] = v0.w;
+      af[i][4] = v1.x; af[i][5] = v1.y; af[i][6] = v1.z; af[i][7] = v1.w;
+    }
+#pragma unroll
+    for (int s8 = 0; s8 < 8; ++s8)
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf) {
+        const float2 b = *reinterpret_cast<const float2*>(S + b_rd + s8 * BN + hf * 64);
+        bf[2 * hf][s8] = b.x; bf[2 * hf + 1][s8] = b.y;
+      }
+    if (MODE == 0) {
+#pragma unroll
+      for (int s8 = 0; s8 < 8; ++s8)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s8], bf[j][s8], acc[i][j], 0, 0, 0);
+    } else {
+      u32x4 ah[2], am[2], al[2], bh[4], bm[4], bl[4];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) split8(af[i], ah[i], am[i], al[i]);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) split8(bf[j], bh[j], bm[j], bl[j]);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          f32x16 c = acc[i][j];
+          c = mma(al[i], bh[j], c); c = mma(ah[i], bl[j], c); c = mma(am[i], bm[j], c);
+          c = mma(am[i], bh[j], c); c = mma(ah[i], bm[j], c); c = mma(ah[i], bh[j], c);
+          acc[i][j] = c;
+        }
+    }
+  };
+  const int nkb = p.K / BK;
+  issue(0, 0);
+  if (nkb > 1) issue(1, 1);
+  int st = 0;
+  for (int kb = 0; kb < nkb; ++kb) {
+    if (kb + 1 < nkb) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(AI + BI) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    int st2 = st + 2; if (st2 >= NST) st2 -= NST;
+    if (kb + 2 < nkb) issue(st2, kb + 2);
+    compute(st);
+    st = st + 1 == NST ? 0 : st + 1;
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+        const int col = n0 + wn * 128 + hf * 64 + 2 * l31;
+        if (row < p.M && col < p.N)
+          *reinterpret_cast<float2*>(Cb + (size_t)row * p.ldc + col) = make_float2(acc[i][2 * hf][e], acc[i][2 * hf + 1][e]);
+      }
+#endif
+}
+
 __global__ void gemm_ref(LabP p) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (size_t)p.M * p.N) return;
@@ -447,7 +573,15 @@ int main(int argc, char** argv) {
       q.p = p; q.p.tiles_n = (p.N + 127) / 128; q.p.ntiles = ((p.M + 127) / 128) * q.p.tiles_n;
       hipLaunchKernelGGL(kern, dim3(q.p.ntiles, 1, s.batch), dim3(256), smem, st, q);
     };
+    auto launch_w = [&](auto kern) {
+      const int smem = 3 * (128 * 16 + 16 * 256) * 4;
+      CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+      LabP w = p; w.tiles_n = (p.N + 255) / 256; w.ntiles = ((p.M + 127) / 128) * w.tiles_n;
+      hipLaunchKernelGGL(kern, dim3(w.ntiles, 1, s.batch), dim3(256), smem, st, w);
+    };
     for (int rnd = 0; rnd < 2; ++rnd) {
+      run("w128 f32", [&] { launch_w(gemm_w128<0>); });
+      run("w128 x6", [&] { launch_w(gemm_w128<1>); });
       run("B pre-cut 3st", [&] { launch_bpre(gemm_bpre<3>, 3); });
       run("B pre-cut 2st", [&] { launch_bpre(gemm_bpre<2>, 2); });
       run("fp32 mfma", [&] { launch<0>(st, p, s.batch); });
