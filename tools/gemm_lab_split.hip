@@ -223,6 +223,132 @@ void gemm_v1(LabP p) {
 #endif
 }
 
+template <int MODE>
+__global__ __launch_bounds__(256, 2)
+void gemm_v2(LabP p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int WGM = 2;
+  constexpr int NW = 2 * WGM, BM = 64 * WGM, BN = 128, BK = 16, NST = 4;
+  constexpr int A_FL = BM * BK, B_FL = BK * BN, ST_FL = A_FL + B_FL;
+  constexpr int AI = (BM / 16) / NW;
+  constexpr int BI = 8 / NW;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int t = threadIdx.x, lane = t & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wm = wid >> 1, wn = wid & 1;
+  const int tile = xcd_swz(blockIdx.x, p.ntiles);
+  const int tile_n = tile % p.tiles_n, tile_m = tile / p.tiles_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const float* Ab = p.A + (size_t)blockIdx.z * p.a_bs;
+  const float* Bb = p.B + (size_t)blockIdx.z * p.b_bs;
+  float* Cb = p.C + (size_t)blockIdx.z * p.c_bs;
+  const i32x4 rsA = make_rsrc(Ab, p.a_bytes), rsB = make_rsrc(Bb, p.b_bytes);
+  const unsigned lds0 = (unsigned)(size_t)(lds_ptr_t)smem;
+  unsigned a_voff[AI], b_voff[BI];
+#pragma unroll
+  for (int r = 0; r < AI; ++r) {
+    const int row = 16 * (wid * AI + r) + (lane >> 2);
+    const int c = (lane & 3) ^ ((row >> 2) & 3);
+    const int gm = m0 + row;
+    a_voff[r] = gm < p.M ? (unsigned)(gm * p.lda + 4 * c) * 4u : 0x80000000u;
+  }
+#pragma unroll
+  for (int r = 0; r < BI; ++r) {
+    const int krow = 2 * (wid * BI + r) + (lane >> 5);
+    const int nn = n0 + 4 * (lane & 31);
+    b_voff[r] = nn < p.N ? (unsigned)(krow * p.ldb + nn) * 4u : 0x80000000u;
+  }
+  auto issue = [&](int st, int kb) {
+    const unsigned As = lds0 + (unsigned)(st * ST_FL) * 4u, Bs = As + A_FL * 4u;
+#pragma unroll
+    for (int r = 0; r < AI; ++r) lds_dma16(a_voff[r], rsA, (unsigned)kb * (BK * 4), As + (unsigned)(wid * AI + r) * 1024u);
+#pragma unroll
+    for (int r = 0; r < BI; ++r)
+      lds_dma16(b_voff[r], rsB, (unsigned)kb * (BK * 4) * (unsigned)p.ldb, Bs + (unsigned)(wid * BI + r) * 1024u);
+  };
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  const int h = lane >> 5, l31 = lane & 31;
+  const int f = (l31 >> 2) & 3;
+  const int a_rd = (wm * 64 + l31) * BK;
+  const int a_c0 = ((2 * h) ^ f) * 4, a_c1 = ((2 * h + 1) ^ f) * 4;
+  const int b_rd = A_FL + (8 * h) * BN + wn * 64 + 2 * l31;
+  auto compute = [&](int st) {
+    const float* S = smem + st * ST_FL;
+    float af[2][8], bf[2][8];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const float4 v0 = *reinterpret_cast<const float4*>(S + a_rd + i * 32 * BK + a_c0);
+      const float4 v1 = *reinterpret_cast<const float4*>(S + a_rd + i * 32 * BK + a_c1);
+      af[i][0] = v0.x; af[i][1] = v0.y; af[i][2] = v0.z; af[i][3] = v0.w;
+      af[i][4] = v1.x; af[i][5] = v1.y; af[i][6] = v1.z; af[i][7] = v1.w;
+    }
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      const float2 b = *reinterpret_cast<const float2*>(S + b_rd + s * BN);
+      bf[0][s] = b.x; bf[1][s] = b.y;
+    }
+    if (MODE == 0) {
+#pragma unroll
+      for (int s = 0; s < 8; ++s)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s], bf[j][s], acc[i][j], 0, 0, 0);
+    } else if (MODE >= 3) {
+      // term-outer: consecutive MFMAs write different accumulators (no back-to-back dependent chain)
+      u32x4 ah[2], am[2], al[2], bh[2], bm[2], bl[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) { split8(af[i], ah[i], am[i], al[i]); split8(bf[i], bh[i], bm[i], bl[i]); }
+#define TERM(X, Y) _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j) acc[i][j] = mma(X[i], Y[j], acc[i][j]);
+      TERM(al, bh) TERM(ah, bl) TERM(am, bm) TERM(am, bh) TERM(ah, bm) TERM(ah, bh)
+#undef TERM
+    } else {
+      // lane (l31, h) holds k = 8h .. 8h+7 of its A row / B column: exactly the 32x32x16 operand layout
+      u32x4 ah[2], am[2], al[2], bh[2], bm[2], bl[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) { split8(af[i], ah[i], am[i], al[i]); split8(bf[i], bh[i], bm[i], bl[i]); }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          f32x16 c = acc[i][j];
+          if (MODE == 1) { c = mma(al[i], bh[j], c); c = mma(ah[i], bl[j], c); c = mma(am[i], bm[j], c); }   // smallest first
+          c = mma(am[i], bh[j], c); c = mma(ah[i], bm[j], c); c = mma(ah[i], bh[j], c);
+          acc[i][j] = c;
+        }
+    }
+  };
+  // super-stages of 2 x 16 k: one barrier per 48 MFMAs; slots (2p, 2p+1) hold super-stage parity p
+  const int nk2 = p.K / (2 * BK);
+  issue(0, 0); issue(1, 1);
+  for (int k2 = 0; k2 < nk2; ++k2) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    const int pr = k2 & 1;
+    if (k2 + 1 < nk2) { issue(2 * (pr ^ 1), 2 * k2 + 2); issue(2 * (pr ^ 1) + 1, 2 * k2 + 3); }
+    compute(2 * pr);
+    compute(2 * pr + 1);
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int row = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+      const int col = n0 + wn * 64 + 2 * l31;
+      if (row < p.M && col < p.N)
+        *reinterpret_cast<float2*>(Cb + (size_t)row * p.ldc + col) = make_float2(acc[i][0][e], acc[i][1][e]);
+    }
+#endif
+}
+
 // ---- variant: B (the weight panel) arrives PRE-CUT: three bf16 planes in k-inner layout [plane][K/8][N][8], produced once
 // per step by whoever re-packs the weights.  The B fragment is then three ds_read_b128 per column and costs no VALU; only
 // the A fragments are cut in the loop.  LDS per stage: A 8 KB (fp32) + B 12 KB (3 planes x 2 k-groups x 128 cols x 16 B).
@@ -475,6 +601,121 @@ void gemm_w128(LabP p) {
 #endif
 }
 
+
+// ---- variant: BOTH operands arrive pre-cut (A: three bf16 planes [plane][M][K]; B as in gemm_bpre): no VALU in the loop at all.
+// Upper bound of "producers write activations and weights pre-cut".  LDS per stage: A 12 KB + B 12 KB.
+struct LabR { LabQ q; const unsigned short* As; size_t as_plane, as_batch; unsigned as_bytes; };
+template <int NSTQ>
+__global__ __launch_bounds__(256, 2)
+void gemm_allpre(LabR rr) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const LabQ& q = rr.q; const LabP& p = q.p;
+  constexpr int BM = 128, BN = 128, NST = NSTQ;
+  constexpr int A_BYTES = 3 * BM * 32, B_BYTES = 3 * 2 * BN * 16, ST_BYTES = A_BYTES + B_BYTES;
+  constexpr int AI = 3, BI = 3;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int t = threadIdx.x, lane = t & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wm = wid >> 1, wn = wid & 1;
+  const int tile = xcd_swz(blockIdx.x, p.ntiles);
+  const int tile_n = tile % p.tiles_n, tile_m = tile / p.tiles_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  float* Cb = p.C + (size_t)blockIdx.z * p.c_bs;
+  const i32x4 rsA = make_rsrc(rr.As + (size_t)blockIdx.z * rr.as_batch, rr.as_bytes);
+  const i32x4 rsB = make_rsrc(q.Bs + (size_t)blockIdx.z * q.bs_batch, q.bs_bytes);
+  const unsigned lds0 = (unsigned)(size_t)(lds_ptr_t)smem;
+  unsigned a_voff[AI], b_voff[BI];
+#pragma unroll
+  for (int r = 0; r < AI; ++r) {       // instruction x in [0,12): plane = x/4, rows (x%4)*32 + lane/2, k-half lane%2
+    const int x = wid * AI + r;
+    const int plane = x >> 2, row = (x & 3) * 32 + (lane >> 1), half = lane & 1;
+    const int gm = m0 + row;
+    a_voff[r] = gm < p.M ? (unsigned)((size_t)plane * rr.as_plane * 2 + (size_t)gm * p.K * 2 + half * 16) : 0x80000000u;
+  }
+#pragma unroll
+  for (int r = 0; r < BI; ++r) {
+    const int x = wid * BI + r;
+    const int plane = x >> 2, g = (x >> 1) & 1, half = x & 1;
+    const int nn = n0 + half * 64 + lane;
+    b_voff[r] = nn < p.N ? (unsigned)((size_t)plane * q.bs_plane * 2 + ((size_t)g * p.N + nn) * 16) : 0x80000000u;
+  }
+  auto issue = [&](int st, int kb) {
+    const unsigned As = lds0 + (unsigned)(st * ST_BYTES), Bs = As + A_BYTES;
+#pragma unroll
+    for (int r = 0; r < AI; ++r) lds_dma16(a_voff[r], rsA, (unsigned)kb * 32u, As + (unsigned)(wid * AI + r) * 1024u);
+#pragma unroll
+    for (int r = 0; r < BI; ++r)
+      lds_dma16(b_voff[r], rsB, (unsigned)kb * 2u * (unsigned)p.N * 16u, Bs + (unsigned)(wid * BI + r) * 1024u);
+  };
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  const int h = lane >> 5, l31 = lane & 31;
+  auto compute = [&](int st) {
+    const char* SA = reinterpret_cast<const char*>(smem) + st * ST_BYTES;
+    const char* SB = SA + A_BYTES;
+    u32x4 ah[2], am[2], al[2], bh[2], bm[2], bl[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int row = wm * 64 + i * 32 + l31;
+      ah[i] = *reinterpret_cast<const u32x4*>(SA + ((0 * 128 + row) * 2 + h) * 16);
+      am[i] = *reinterpret_cast<const u32x4*>(SA + ((1 * 128 + row) * 2 + h) * 16);
+      al[i] = *reinterpret_cast<const u32x4*>(SA + ((2 * 128 + row) * 2 + h) * 16);
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int col = wn * 64 + 2 * l31 + j;
+      bh[j] = *reinterpret_cast<const u32x4*>(SB + ((0 * 2 + h) * 128 + col) * 16);
+      bm[j] = *reinterpret_cast<const u32x4*>(SB + ((1 * 2 + h) * 128 + col) * 16);
+      bl[j] = *reinterpret_cast<const u32x4*>(SB + ((2 * 2 + h) * 128 + col) * 16);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        f32x16 c = acc[i][j];
+        c = mma(al[i], bh[j], c); c = mma(ah[i], bl[j], c); c = mma(am[i], bm[j], c);
+        c = mma(am[i], bh[j], c); c = mma(ah[i], bm[j], c); c = mma(ah[i], bh[j], c);
+        acc[i][j] = c;
+      }
+  };
+  const int nkb = p.K / 16;
+  issue(0, 0);
+  if (NST == 3 && nkb > 1) issue(1, 1);
+  int st = 0;
+  for (int kb = 0; kb < nkb; ++kb) {
+    if (NST == 3) {
+      if (kb + 1 < nkb) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(AI + BI) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      int st2 = st + 2; if (st2 >= NST) st2 -= NST;
+      if (kb + 2 < nkb) issue(st2, kb + 2);
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      if (kb + 1 < nkb) issue(st ^ 1, kb + 1);
+    }
+    compute(st);
+    if (NST == 3) st = st + 1 == NST ? 0 : st + 1; else st ^= 1;
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int row = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+      const int col = n0 + wn * 64 + 2 * l31;
+      if (row < p.M && col < p.N)
+        *reinterpret_cast<float2*>(Cb + (size_t)row * p.ldc + col) = make_float2(acc[i][0][e], acc[i][1][e]);
+    }
+#endif
+}
+
 __global__ void gemm_ref(LabP p) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (size_t)p.M * p.N) return;
@@ -573,6 +814,30 @@ int main(int argc, char** argv) {
       q.p = p; q.p.tiles_n = (p.N + 127) / 128; q.p.ntiles = ((p.M + 127) / 128) * q.p.tiles_n;
       hipLaunchKernelGGL(kern, dim3(q.p.ntiles, 1, s.batch), dim3(256), smem, st, q);
     };
+    // pre-cut A: [batch][plane][M][K] bf16
+    std::vector<unsigned short> hsa((size_t)3 * na);
+    const size_t aplane = (size_t)s.M * s.K;
+    for (int z = 0; z < s.batch; ++z)
+      for (size_t e = 0; e < aplane; ++e) {
+        const float x = ha[(size_t)z * aplane + e];
+        unsigned u; memcpy(&u, &x, 4);
+        unsigned uh = u & 0xffff0000u; float fh; memcpy(&fh, &uh, 4);
+        const float r = x - fh; unsigned ur; memcpy(&ur, &r, 4);
+        unsigned um = ur & 0xffff0000u; float fm; memcpy(&fm, &um, 4);
+        const float q2 = r - fm; unsigned ul; memcpy(&ul, &q2, 4);
+        hsa[((size_t)z * 3 + 0) * aplane + e] = (unsigned short)(u >> 16);
+        hsa[((size_t)z * 3 + 1) * aplane + e] = (unsigned short)(ur >> 16);
+        hsa[((size_t)z * 3 + 2) * aplane + e] = (unsigned short)(ul >> 16);
+      }
+    unsigned short* dSA; CK(hipMalloc((void**)&dSA, hsa.size() * 2));
+    CK(hipMemcpy(dSA, hsa.data(), hsa.size() * 2, hipMemcpyHostToDevice));
+    auto launch_all = [&](auto kern, int nst) {
+      const int smem = nst * (3 * 128 * 32 + 3 * 2 * 128 * 16);
+      CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+      LabR rr{}; rr.q = q; rr.q.p = p; rr.q.p.tiles_n = (p.N + 127) / 128; rr.q.p.ntiles = ((p.M + 127) / 128) * rr.q.p.tiles_n;
+      rr.As = dSA; rr.as_plane = aplane; rr.as_batch = 3 * aplane; rr.as_bytes = (unsigned)(3 * aplane * 2);
+      hipLaunchKernelGGL(kern, dim3(rr.q.p.ntiles, 1, s.batch), dim3(256), smem, st, rr);
+    };
     auto launch_w = [&](auto kern) {
       const int smem = 3 * (128 * 16 + 16 * 256) * 4;
       CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
@@ -580,17 +845,28 @@ int main(int argc, char** argv) {
       hipLaunchKernelGGL(kern, dim3(w.ntiles, 1, s.batch), dim3(256), smem, st, w);
     };
     for (int rnd = 0; rnd < 2; ++rnd) {
-      run("w128 f32", [&] { launch_w(gemm_w128<0>); });
-      run("w128 x6", [&] { launch_w(gemm_w128<1>); });
-      run("B pre-cut 3st", [&] { launch_bpre(gemm_bpre<3>, 3); });
-      run("B pre-cut 2st", [&] { launch_bpre(gemm_bpre<2>, 2); });
+      run("x6 BK32 2wg", [&] {
+        const int smem = 4 * (128 * 16 + 16 * 128) * 4;
+        static bool once = false;
+        if (!once) { CK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_v2<1>), hipFuncAttributeMaxDynamicSharedMemorySize, smem)); once = true; }
+        LabP w = p; w.tiles_n = (p.N + 127) / 128; w.ntiles = ((p.M + 127) / 128) * w.tiles_n;
+        hipLaunchKernelGGL((gemm_v2<1>), dim3(w.ntiles, 1, s.batch), dim3(256), smem, st, w);
+      });
+      run("f32 BK32 2wg", [&] {
+        const int smem = 4 * (128 * 16 + 16 * 128) * 4;
+        static bool once = false;
+        if (!once) { CK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_v2<0>), hipFuncAttributeMaxDynamicSharedMemorySize, smem)); once = true; }
+        LabP w = p; w.tiles_n = (p.N + 127) / 128; w.ntiles = ((p.M + 127) / 128) * w.tiles_n;
+        hipLaunchKernelGGL((gemm_v2<0>), dim3(w.ntiles, 1, s.batch), dim3(256), smem, st, w);
+      });
+
       run("fp32 mfma", [&] { launch<0>(st, p, s.batch); });
       run("bf16 x6", [&] { launch<1>(st, p, s.batch); });
-      run("x6 term-outer", [&] { launch<3>(st, p, s.batch); });
+
 
 
     }
-    CK(hipFree(dA)); CK(hipFree(dB)); CK(hipFree(dC)); CK(hipFree(dR)); CK(hipFree(dS));
+    CK(hipFree(dA)); CK(hipFree(dB)); CK(hipFree(dC)); CK(hipFree(dR)); CK(hipFree(dS)); CK(hipFree(dSA));
   }
   return 0;
 }
