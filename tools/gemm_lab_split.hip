@@ -845,6 +845,147 @@ void gemm_allpre(LabR rr) {
 #endif
 }
 
+
+// ---- variant: software-pipelined split loop.  4-slot ring (64 KB: 2 workgroups / CU = 2 waves per SIMD, where the bf16 MFMA
+// issues at full rate).  Iteration k: wait for stage k+1, barrier, issue stage k+3, read stage k+1's fragments, then issue the
+// 24 MFMAs of stage k (operands cut in the previous iteration) INTERLEAVED with the cut of stage k+1 -- the VALU work rides
+// in the shadow of the matrix pipe inside the wave instead of in front of it.
+struct Cut { u32x4 ah[2], am[2], al[2], bh[2], bm[2], bl[2]; };
+template <int SCHED>
+__global__ __launch_bounds__(256, 2)
+void gemm_pipe(LabP p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int WGM = 2;
+  constexpr int NW = 2 * WGM, BM = 64 * WGM, BN = 128, BK = 16, NST = 4;
+  constexpr int A_FL = BM * BK, B_FL = BK * BN, ST_FL = A_FL + B_FL;
+  constexpr int AI = (BM / 16) / NW;
+  constexpr int BI = 8 / NW;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int t = threadIdx.x, lane = t & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wm = wid >> 1, wn = wid & 1;
+  const int tile = xcd_swz(blockIdx.x, p.ntiles);
+  const int tile_n = tile % p.tiles_n, tile_m = tile / p.tiles_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const float* Ab = p.A + (size_t)blockIdx.z * p.a_bs;
+  const float* Bb = p.B + (size_t)blockIdx.z * p.b_bs;
+  float* Cb = p.C + (size_t)blockIdx.z * p.c_bs;
+  const i32x4 rsA = make_rsrc(Ab, p.a_bytes), rsB = make_rsrc(Bb, p.b_bytes);
+  const unsigned lds0 = (unsigned)(size_t)(lds_ptr_t)smem;
+  unsigned a_voff[AI], b_voff[BI];
+#pragma unroll
+  for (int r = 0; r < AI; ++r) {
+    const int row = 16 * (wid * AI + r) + (lane >> 2);
+    const int c = (lane & 3) ^ ((row >> 2) & 3);
+    const int gm = m0 + row;
+    a_voff[r] = gm < p.M ? (unsigned)(gm * p.lda + 4 * c) * 4u : 0x80000000u;
+  }
+#pragma unroll
+  for (int r = 0; r < BI; ++r) {
+    const int krow = 2 * (wid * BI + r) + (lane >> 5);
+    const int nn = n0 + 4 * (lane & 31);
+    b_voff[r] = nn < p.N ? (unsigned)(krow * p.ldb + nn) * 4u : 0x80000000u;
+  }
+  auto issue = [&](int st, int kb) {
+    const unsigned As = lds0 + (unsigned)(st * ST_FL) * 4u, Bs = As + A_FL * 4u;
+#pragma unroll
+    for (int r = 0; r < AI; ++r) lds_dma16(a_voff[r], rsA, (unsigned)kb * (BK * 4), As + (unsigned)(wid * AI + r) * 1024u);
+#pragma unroll
+    for (int r = 0; r < BI; ++r)
+      lds_dma16(b_voff[r], rsB, (unsigned)kb * (BK * 4) * (unsigned)p.ldb, Bs + (unsigned)(wid * BI + r) * 1024u);
+  };
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  const int h = lane >> 5, l31 = lane & 31;
+  const int f = (l31 >> 2) & 3;
+  const int a_rd = (wm * 64 + l31) * BK;
+  const int a_c0 = ((2 * h) ^ f) * 4, a_c1 = ((2 * h + 1) ^ f) * 4;
+  const int b_rd = A_FL + (8 * h) * BN + wn * 64 + 2 * l31;
+  auto read_frags = [&](int st, float (&af)[2][8], float (&bf)[2][8]) {
+    const float* S = smem + st * ST_FL;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const float4 v0 = *reinterpret_cast<const float4*>(S + a_rd + i * 32 * BK + a_c0);
+      const float4 v1 = *reinterpret_cast<const float4*>(S + a_rd + i * 32 * BK + a_c1);
+      af[i][0] = v0.x; af[i][1] = v0.y; af[i][2] = v0.z; af[i][3] = v0.w;
+      af[i][4] = v1.x; af[i][5] = v1.y; af[i][6] = v1.z; af[i][7] = v1.w;
+    }
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      const float2 b = *reinterpret_cast<const float2*>(S + b_rd + s * BN);
+      bf[0][s] = b.x; bf[1][s] = b.y;
+    }
+  };
+  auto cut = [&](const float (&af)[2][8], const float (&bf)[2][8], Cut& c) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) { split8(af[i], c.ah[i], c.am[i], c.al[i]); split8(bf[i], c.bh[i], c.bm[i], c.bl[i]); }
+  };
+  auto mfmas = [&](const Cut& c) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        f32x16 x = acc[i][j];
+        x = mma(c.al[i], c.bh[j], x); x = mma(c.ah[i], c.bl[j], x); x = mma(c.am[i], c.bm[j], x);
+        x = mma(c.am[i], c.bh[j], x); x = mma(c.ah[i], c.bm[j], x); x = mma(c.ah[i], c.bh[j], x);
+        acc[i][j] = x;
+      }
+  };
+  const int nkb = p.K / BK;
+  // prologue: stages 0, 1, 2 in flight; stage 0's fragments cut
+  issue(0, 0);
+  if (nkb > 1) issue(1, 1);
+  if (nkb > 2) issue(2, 2);
+  if (nkb > 2) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(2 * (AI + BI)) : "memory");
+  else if (nkb > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(AI + BI) : "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  Cut cur, nxt;
+  {
+    float af[2][8], bf[2][8];
+    read_frags(0, af, bf);
+    cut(af, bf, cur);
+  }
+  for (int kb = 0; kb < nkb; ++kb) {
+    const bool more = kb + 1 < nkb;
+    if (more) {
+      // stage kb+1 has landed for this wave when at most the loads of stage kb+2 are outstanding
+      if (kb + 2 < nkb) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(AI + BI) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();            // ... and for every wave; everybody has read stage kb (previous iteration)
+      asm volatile("" ::: "memory");
+      if (kb + 3 < nkb) issue((kb + 3) & 3, kb + 3);       // slot of stage kb-1: last read two iterations ago
+      float af[2][8], bf[2][8];
+      read_frags((kb + 1) & 3, af, bf);
+      mfmas(cur);
+      cut(af, bf, nxt);
+      if (SCHED) {
+#pragma unroll
+        for (int g = 0; g < 24; ++g) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 7, 0); }
+      }
+      cur = nxt;
+    } else {
+      mfmas(cur);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int row = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+      const int col = n0 + wn * 64 + 2 * l31;
+      if (row < p.M && col < p.N)
+        *reinterpret_cast<float2*>(Cb + (size_t)row * p.ldc + col) = make_float2(acc[i][0][e], acc[i][1][e]);
+    }
+#endif
+}
+
 __global__ void gemm_ref(LabP p) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (size_t)p.M * p.N) return;
@@ -974,33 +1115,19 @@ int main(int argc, char** argv) {
       hipLaunchKernelGGL(kern, dim3(w.ntiles, 1, s.batch), dim3(256), smem, st, w);
     };
     for (int rnd = 0; rnd < 2; ++rnd) {
-      run("x6 256x128 8w", [&] {
-        const int smem = 3 * (256 * 16 + 16 * 128) * 4;
-        static bool once = false;
-        if (!once) { CK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_v3<1>), hipFuncAttributeMaxDynamicSharedMemorySize, smem)); once = true; }
-        LabP w = p; w.tiles_n = (p.N + 127) / 128; w.ntiles = ((p.M + 255) / 256) * w.tiles_n;
-        hipLaunchKernelGGL((gemm_v3<1>), dim3(w.ntiles, 1, s.batch), dim3(512), smem, st, w);
-      });
-      run("f32 256x128 8w", [&] {
-        const int smem = 3 * (256 * 16 + 16 * 128) * 4;
-        static bool once = false;
-        if (!once) { CK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_v3<0>), hipFuncAttributeMaxDynamicSharedMemorySize, smem)); once = true; }
-        LabP w = p; w.tiles_n = (p.N + 127) / 128; w.ntiles = ((p.M + 255) / 256) * w.tiles_n;
-        hipLaunchKernelGGL((gemm_v3<0>), dim3(w.ntiles, 1, s.batch), dim3(512), smem, st, w);
-      });
-      run("x6 BK32 2wg", [&] {
+      run("x6 pipelined", [&] {
         const int smem = 4 * (128 * 16 + 16 * 128) * 4;
         static bool once = false;
-        if (!once) { CK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_v2<1>), hipFuncAttributeMaxDynamicSharedMemorySize, smem)); once = true; }
+        if (!once) { CK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_pipe<0>), hipFuncAttributeMaxDynamicSharedMemorySize, smem)); once = true; }
         LabP w = p; w.tiles_n = (p.N + 127) / 128; w.ntiles = ((p.M + 127) / 128) * w.tiles_n;
-        hipLaunchKernelGGL((gemm_v2<1>), dim3(w.ntiles, 1, s.batch), dim3(256), smem, st, w);
+        hipLaunchKernelGGL((gemm_pipe<0>), dim3(w.ntiles, 1, s.batch), dim3(256), smem, st, w);
       });
-      run("f32 BK32 2wg", [&] {
+      run("x6 pipe+sched", [&] {
         const int smem = 4 * (128 * 16 + 16 * 128) * 4;
         static bool once = false;
-        if (!once) { CK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_v2<0>), hipFuncAttributeMaxDynamicSharedMemorySize, smem)); once = true; }
+        if (!once) { CK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_pipe<1>), hipFuncAttributeMaxDynamicSharedMemorySize, smem)); once = true; }
         LabP w = p; w.tiles_n = (p.N + 127) / 128; w.ntiles = ((p.M + 127) / 128) * w.tiles_n;
-        hipLaunchKernelGGL((gemm_v2<0>), dim3(w.ntiles, 1, s.batch), dim3(256), smem, st, w);
+        hipLaunchKernelGGL((gemm_pipe<1>), dim3(w.ntiles, 1, s.batch), dim3(256), smem, st, w);
       });
 
       run("fp32 mfma", [&] { launch<0>(st, p, s.batch); });
