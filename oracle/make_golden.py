@@ -210,6 +210,47 @@ def golden_warp_modes(path, H=64, B=2, init_seed=0, step_seed=100):
     print("wrote", path, len(out), "entries")
 
 
+def golden_warp_channels(path, H=64, B=2, init_seed=0, step_seed=100):
+    """One reference step of WarpModel under the representation options (options/base_options.py:75-105,
+    models/warp_model.py:49-55): --body_representation labels (12 body channels), --cloth_representation rgb (3 cloth
+    channels), --cloth_channels 7.  Init weights of the first / last generator convs and of PatchGAN's first conv (the
+    layers whose shape depends on the options), losses, fakes, post-step weights."""
+    from models.warp_model import WarpModel
+    from oracle.swapnet_oracle import synth_channels_batch
+    out = OrderedDict()
+    for tag, opts, (cb, cc) in (("body-labels", dict(body_representation="labels", body_channels=12), (12, 19)),
+                                ("cloth-rgb", dict(cloth_representation="rgb"), (3, 3)),
+                                ("cloth7", dict(cloth_channels=7), (3, 7))):
+        with tempfile.TemporaryDirectory() as tmp:
+            opt = base_opt(tmp, lambda_ce=100.0, model="warp", warp_mode="gan", **opts)
+            torch.manual_seed(init_seed)
+            model = WarpModel(opt)
+            model.eval()
+            pre = tag + "/"
+            sdG, sdD = model.net_generator.state_dict(), model.net_discriminator.state_dict()
+            for k in ("body_down1.model.0.weight", "cloth_down1.model.0.weight", "upsample_and_pad.2.weight"):
+                summarize(out, pre + "init/G/" + k, sdG[k])
+            summarize(out, pre + "init/D/model.0.weight", sdD["model.0.weight"])
+            bodys, inputs, targets = synth_channels_batch(B, H, cb, cc)
+            model.set_input(dict(bodys=bodys, input_cloths=inputs, target_cloths=targets,
+                                 cloth_paths=[""] * B, body_paths=[""] * B))
+            torch.manual_seed(step_seed)
+            model.optimize_parameters()
+            for k, v in model.get_current_losses().items():
+                out[pre + "loss/" + k] = np.float64(v)
+            summarize(out, pre + "fakes", model.fakes)
+            sdG, sdD = model.net_generator.state_dict(), model.net_discriminator.state_dict()
+            for k in ("body_down1.model.0.weight", "cloth_down1.model.0.weight", "upsample_and_pad.2.weight",
+                      "resblocks.3.conv_block.6.weight"):
+                summarize(out, pre + "postG/" + k, sdG[k])
+            summarize(out, pre + "postD/model.0.weight", sdD["model.0.weight"])
+            out[pre + "meta/channels"] = np.array([cb, cc], dtype=np.int64)
+    out["meta/init_seed"] = np.int64(init_seed); out["meta/step_seed"] = np.int64(step_seed)
+    out["meta/B"] = np.int64(B); out["meta/H"] = np.int64(H)
+    np.savez_compressed(path, **out)
+    print("wrote", path, len(out), "entries")
+
+
 def golden_texture(path, H=64, B=2, init_seed=1, step_seeds=(200, 201)):
     from oracle.swapnet_oracle import synth_texture_batch
     from models.texture_model import TextureModel
@@ -296,7 +337,7 @@ if __name__ == "__main__":
     torch.set_num_threads(8)
     gold = os.path.join(REPO, "tests", "golden")
     os.makedirs(gold, exist_ok=True)
-    which = sys.argv[1:] or ["warp", "texture", "roi", "cloth", "roiops", "modes"]
+    which = sys.argv[1:] or ["warp", "texture", "roi", "cloth", "roiops", "modes", "channels"]
     if "warp" in which:
         golden_warp(os.path.join(gold, "warp_step_64.npz"))
     if "texture" in which:
@@ -305,6 +346,8 @@ if __name__ == "__main__":
         golden_roi(os.path.join(gold, "notebook_rois.npz"))
     if "modes" in which:
         golden_warp_modes(os.path.join(gold, "warp_modes_64.npz"))
+    if "channels" in which:
+        golden_warp_channels(os.path.join(gold, "warp_channels_64.npz"))
     if "roiops" in which:
         golden_roi_ops(os.path.join(gold, "roi_ops_reference.npz"))
     if "cloth" in which:

@@ -940,6 +940,17 @@ def synth_warp_batch(B, H, W, seed=1234, n_labels=19, tile=8):
     return bodys, inputs, targets
 
 
+def synth_channels_batch(B, H, Cb, Cc, seed=77):
+    """Warp batch for the representation options (--body_representation labels / --cloth_representation rgb /
+    --cloth_channels): body (B,Cb,H,H) ~ N(0,1); blocky label maps with Cc classes -> plain one-hot input / target
+    cloths (dense NCHW).  Used by oracle/make_golden.py (golden_warp_channels) and tests/test_channel_options.py."""
+    g = torch.Generator().manual_seed(seed)
+    bodys = torch.randn(B, Cb, H, H, generator=g)
+    lab = torch.randint(0, Cc, (B, H // 8, H // 8), generator=g).repeat_interleave(8, 1).repeat_interleave(8, 2)
+    oh = lambda l: F.one_hot(l, Cc).movedim(-1, 1).float().contiguous()
+    return bodys, oh(torch.roll(lab.flip(2), shifts=(3, -2), dims=(1, 2))), oh(lab)
+
+
 def synth_texture_batch(B, H, W, seed=1234, n_labels=19, num_roi=12, tile=8):
     g = torch.Generator().manual_seed(seed)
     tex = torch.randn((B, 3, H, W), generator=g).clamp_(-3, 3)

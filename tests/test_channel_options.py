@@ -115,3 +115,69 @@ def test_warp_model_resolves_the_representation_flags(tmp_path):
         losses = model.get_current_losses()
         assert all(v == v and abs(v) < 1e6 for v in losses.values()), losses
         assert tuple(model.fakes.shape) == (2, cc, 64, 64)
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_channel_options_reproduce_the_reference(backend, golden_dir):
+    """tests/golden/warp_channels_64.npz was recorded from the REAL reference (oracle/make_golden.py channels:
+    WarpModel under --body_representation labels / --cloth_representation rgb / --cloth_channels 7).  The oracle's
+    seeded construction reproduces its initial weights, and the oracle step and the native step reproduce its losses,
+    fakes and post-step weights."""
+    import os
+    import numpy as np
+    from oracle.golden_io import compare
+    from oracle.golden_io import sample_idx
+    gold = np.load(os.path.join(golden_dir, "warp_channels_64.npz"))
+    B, H = int(gold["meta/B"]), int(gold["meta/H"])
+
+    def post_ok(key, t, lr):
+        """Post-step weights: norm to 1e-3 and the 24 samples to 1e-3 -- except that AdamW's first update is
+        lr * g / (|g| + eps), a sign-like +-lr for an element whose gradient is round-off sized: up to two samples may
+        differ by that 2 lr (the reference's own value is as arbitrary as ours there)."""
+        t = t.detach().double().cpu().reshape(-1)
+        gn, gs = float(gold[key + "/norm"]), np.asarray(gold[key + "/samples"], dtype=np.float64)
+        mine = t[torch.from_numpy(sample_idx(t.numel(), key))].numpy()
+        err = np.abs(mine - gs)
+        tol = 1e-3 * np.abs(gs) + 3e-3 * gn / np.sqrt(t.numel())
+        out = err > tol
+        return abs(float(t.norm()) - gn) <= 1e-3 * gn and out.sum() <= 2 and bool(np.all(err[out] <= 2.2 * lr)), (key, err.max())
+    ctx = _ctx(backend)
+    for tag in ("body-labels", "cloth-rgb", "cloth7"):
+        cb, cc = (int(v) for v in gold[tag + "/meta/channels"])
+        pre = tag + "/"
+        torch.manual_seed(int(gold["meta/init_seed"]))
+        G, D = O.warp_module_params(cb, cc), O.patchgan_params(cb + cc)
+        for k in ("body_down1.model.0.weight", "cloth_down1.model.0.weight", "upsample_and_pad.2.weight"):
+            ok, msg = compare(gold, pre + "init/G/" + k, G[k], 1e-6, 1e-6)
+            assert ok, msg
+        ok, msg = compare(gold, pre + "init/D/model.0.weight", D["model.0.weight"], 1e-6, 1e-6)
+        assert ok, msg
+        batch = O.synth_channels_batch(B, H, cb, cc)
+        torch.manual_seed(int(gold["meta/step_seed"]))
+        st = O.WarpStepOracle(G, D)
+        st.step(*batch)                                     # labels drawn from the CPU RNG in the reference's order
+        m = engine.NativeModel(ctx, "warp", B, H, H, body_channels=cb, cloth_channels=cc)
+        try:
+            backends.reset_state(m, {engine.NET_G: G, engine.NET_D: D})
+            for i, t in enumerate(batch):
+                m.set_input(i, t)
+            m.step(st.labels, training=False, seed=0)
+            L = m.losses()
+            for k, v in st.losses.items():
+                ref = float(gold[pre + "loss/" + k])
+                assert abs(v - ref) <= 1e-4 * abs(ref) + 1e-6, (tag, "oracle", k, v, ref)
+                assert abs(L[k] - ref) <= 1e-3 * abs(ref) + 1e-6, (tag, "native", k, L[k], ref)
+            for who, fakes in (("oracle", st.fakes), ("native", m.output())):
+                ok, msg = compare(gold, pre + "fakes", fakes, 1e-3, 1e-3)
+                assert ok, (who, msg)
+            pG, pD = m.state_dict(engine.NET_G, to_cpu=True), m.state_dict(engine.NET_D, to_cpu=True)
+            for k in ("body_down1.model.0.weight", "cloth_down1.model.0.weight", "upsample_and_pad.2.weight",
+                      "resblocks.3.conv_block.6.weight"):
+                for who, sd in (("oracle", st.G), ("native", pG)):
+                    ok, msg = post_ok(pre + "postG/" + k, sd[k], 1e-4)
+                    assert ok, (who, msg)
+            for who, sd in (("oracle", st.D), ("native", pD)):
+                ok, msg = post_ok(pre + "postD/model.0.weight", sd["model.0.weight"], 4e-4)
+                assert ok, (who, msg)
+        finally:
+            m.close()
