@@ -79,6 +79,23 @@ __device__ __forceinline__ void split8(const float* v, u32x4& hi, u32x4& mid, u3
     lo[q] = __builtin_amdgcn_perm(__float_as_uint(s1), __float_as_uint(s0), 0x07060302u);
   }
 }
+// variant: the two residual subtractions of a pair as one packed v_pk_add_f32
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void split8k(const float* v, u32x4& hi, u32x4& mid, u32x4& lo) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const f32x2 x = {v[2 * q], v[2 * q + 1]};
+    const unsigned x0 = __float_as_uint(x[0]), x1 = __float_as_uint(x[1]);
+    hi[q] = __builtin_amdgcn_perm(x1, x0, 0x07060302u);
+    const f32x2 hf = {__uint_as_float(x0 & 0xffff0000u), __uint_as_float(x1 & 0xffff0000u)};
+    const f32x2 r = x - hf;
+    const unsigned y0 = __float_as_uint(r[0]), y1 = __float_as_uint(r[1]);
+    mid[q] = __builtin_amdgcn_perm(y1, y0, 0x07060302u);
+    const f32x2 mf = {__uint_as_float(y0 & 0xffff0000u), __uint_as_float(y1 & 0xffff0000u)};
+    const f32x2 t = r - mf;
+    lo[q] = __builtin_amdgcn_perm(__float_as_uint(t[1]), __float_as_uint(t[0]), 0x07060302u);
+  }
+}
 // variant: both residual levels cut from x itself (two parallel and/sub pairs instead of a 4-deep chain)
 __device__ __forceinline__ void split8p(const float* v, u32x4& hi, u32x4& mid, u32x4& lo) {
 #pragma unroll
@@ -177,7 +194,7 @@ void gemm_v1(LabP p) {
       // term-outer: consecutive MFMAs write different accumulators (no back-to-back dependent chain)
       u32x4 ah[2], am[2], al[2], bh[2], bm[2], bl[2];
 #pragma unroll
-      for (int i = 0; i < 2; ++i) { split8(af[i], ah[i], am[i], al[i]); split8(bf[i], bh[i], bm[i], bl[i]); }
+      for (int i = 0; i < 2; ++i) { split8k(af[i], ah[i], am[i], al[i]); split8k(bf[i], bh[i], bm[i], bl[i]); }
 #define TERM(X, Y) _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j) acc[i][j] = mma(X[i], Y[j], acc[i][j]);
       TERM(al, bh) TERM(ah, bl) TERM(am, bm) TERM(am, bh) TERM(ah, bm) TERM(ah, bh)
 #undef TERM
@@ -306,7 +323,7 @@ void gemm_v3(LabP p) {
       // term-outer: consecutive MFMAs write different accumulators (no back-to-back dependent chain)
       u32x4 ah[2], am[2], al[2], bh[2], bm[2], bl[2];
 #pragma unroll
-      for (int i = 0; i < 2; ++i) { split8(af[i], ah[i], am[i], al[i]); split8(bf[i], bh[i], bm[i], bl[i]); }
+      for (int i = 0; i < 2; ++i) { split8k(af[i], ah[i], am[i], al[i]); split8k(bf[i], bh[i], bm[i], bl[i]); }
 #define TERM(X, Y) _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j) acc[i][j] = mma(X[i], Y[j], acc[i][j]);
       TERM(al, bh) TERM(ah, bl) TERM(am, bm) TERM(am, bh) TERM(ah, bm) TERM(ah, bh)
 #undef TERM
@@ -434,7 +451,7 @@ void gemm_v2(LabP p) {
       // term-outer: consecutive MFMAs write different accumulators (no back-to-back dependent chain)
       u32x4 ah[2], am[2], al[2], bh[2], bm[2], bl[2];
 #pragma unroll
-      for (int i = 0; i < 2; ++i) { split8(af[i], ah[i], am[i], al[i]); split8(bf[i], bh[i], bm[i], bl[i]); }
+      for (int i = 0; i < 2; ++i) { split8k(af[i], ah[i], am[i], al[i]); split8k(bf[i], bh[i], bm[i], bl[i]); }
 #define TERM(X, Y) _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j) acc[i][j] = mma(X[i], Y[j], acc[i][j]);
       TERM(al, bh) TERM(ah, bl) TERM(am, bm) TERM(am, bh) TERM(ah, bm) TERM(ah, bh)
 #undef TERM
@@ -1115,23 +1132,10 @@ int main(int argc, char** argv) {
       hipLaunchKernelGGL(kern, dim3(w.ntiles, 1, s.batch), dim3(256), smem, st, w);
     };
     for (int rnd = 0; rnd < 2; ++rnd) {
-      run("x6 pipelined", [&] {
-        const int smem = 4 * (128 * 16 + 16 * 128) * 4;
-        static bool once = false;
-        if (!once) { CK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_pipe<0>), hipFuncAttributeMaxDynamicSharedMemorySize, smem)); once = true; }
-        LabP w = p; w.tiles_n = (p.N + 127) / 128; w.ntiles = ((p.M + 127) / 128) * w.tiles_n;
-        hipLaunchKernelGGL((gemm_pipe<0>), dim3(w.ntiles, 1, s.batch), dim3(256), smem, st, w);
-      });
-      run("x6 pipe+sched", [&] {
-        const int smem = 4 * (128 * 16 + 16 * 128) * 4;
-        static bool once = false;
-        if (!once) { CK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_pipe<1>), hipFuncAttributeMaxDynamicSharedMemorySize, smem)); once = true; }
-        LabP w = p; w.tiles_n = (p.N + 127) / 128; w.ntiles = ((p.M + 127) / 128) * w.tiles_n;
-        hipLaunchKernelGGL((gemm_pipe<1>), dim3(w.ntiles, 1, s.batch), dim3(256), smem, st, w);
-      });
 
       run("fp32 mfma", [&] { launch<0>(st, p, s.batch); });
       run("bf16 x6", [&] { launch<1>(st, p, s.batch); });
+      run("x6 pk-sub", [&] { launch<3>(st, p, s.batch); });
 
 
 
