@@ -1003,6 +1003,122 @@ void gemm_pipe(LabP p) {
 #endif
 }
 
+
+// ---- variant: v_mfma_f32_16x16x32_bf16 (no issue-rate cliff at 3 waves per SIMD, tools/mfma_dep_probe).  Workgroup tile
+// 128 x 64, 4 waves (2 x 2), wave tile 64 x 32 = 4 x 2 blocks of 16 x 16 (8 accumulators of 4 registers); 32-k stages, double
+// buffered: (128 + 64) x 32 x 4 B = 24 KB per stage, 48 KB per workgroup -> 3 workgroups / CU.
+//   A in LDS: rows of 32 floats (8 chunks of 16 B), physical chunk = logical ^ ((row >> 1) & 7): the 16 lanes of a
+//   ds_read_b128 group (16 consecutive rows, same logical chunk) hit 16 distinct 4-bank groups.
+//   B in LDS: [32 k][64 n] row-major; a lane reads float2 = columns (2c, 2c+1) of its wave's 32 for each of its 8 k.
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4v mma16(u32x4 a, u32x4 b, f32x4v c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+template <int MODE>
+__global__ __launch_bounds__(256, 3)
+void gemm_m16(LabP p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int BM = 128, BN = 64, BK = 32, NST = 2;
+  constexpr int A_FL = BM * BK, B_FL = BK * BN, ST_FL = A_FL + B_FL;      // 4096 + 2048 floats
+  constexpr int AI = 4, BI = 2;                                          // 16 + 8 KB per stage / 4 waves / 1 KB
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int t = threadIdx.x, lane = t & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wm = wid >> 1, wn = wid & 1;
+  const int tile = xcd_swz(blockIdx.x, p.ntiles);
+  const int tile_n = tile % p.tiles_n, tile_m = tile / p.tiles_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const float* Ab = p.A + (size_t)blockIdx.z * p.a_bs;
+  const float* Bb = p.B + (size_t)blockIdx.z * p.b_bs;
+  float* Cb = p.C + (size_t)blockIdx.z * p.c_bs;
+  const i32x4 rsA = make_rsrc(Ab, p.a_bytes), rsB = make_rsrc(Bb, p.b_bytes);
+  const unsigned lds0 = (unsigned)(size_t)(lds_ptr_t)smem;
+  unsigned a_voff[AI], b_voff[BI];
+#pragma unroll
+  for (int r = 0; r < AI; ++r) {            // instruction x = wid*4 + r covers rows 8x .. 8x+7; lane -> (row, physical chunk)
+    const int row = 8 * (wid * AI + r) + (lane >> 3);
+    const int c = (lane & 7) ^ ((row >> 1) & 7);          // logical chunk stored at physical slot lane & 7
+    const int gm = m0 + row;
+    a_voff[r] = gm < p.M ? (unsigned)(gm * p.lda + 4 * c) * 4u : 0x80000000u;
+  }
+#pragma unroll
+  for (int r = 0; r < BI; ++r) {            // instruction x = wid*2 + r covers k rows 4x .. 4x+3 (64 floats = 256 B each)
+    const int krow = 4 * (wid * BI + r) + (lane >> 4);
+    const int nn = n0 + 4 * (lane & 15);
+    b_voff[r] = nn < p.N ? (unsigned)(krow * p.ldb + nn) * 4u : 0x80000000u;
+  }
+  auto issue = [&](int st, int kb) {
+    const unsigned As = lds0 + (unsigned)(st * ST_FL) * 4u, Bs = As + A_FL * 4u;
+#pragma unroll
+    for (int r = 0; r < AI; ++r) lds_dma16(a_voff[r], rsA, (unsigned)kb * (BK * 4), As + (unsigned)(wid * AI + r) * 1024u);
+#pragma unroll
+    for (int r = 0; r < BI; ++r)
+      lds_dma16(b_voff[r], rsB, (unsigned)kb * (BK * 4) * (unsigned)p.ldb, Bs + (unsigned)(wid * BI + r) * 1024u);
+  };
+  f32x4v acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[i][j][e] = 0.f;
+  const int r16 = lane & 15, g = lane >> 4;          // row / column inside a block, k-group (k = 8g .. 8g+7)
+  auto compute = [&](int st) {
+    const float* S = smem + st * ST_FL;
+    float af[4][8], bf[2][8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = wm * 64 + i * 16 + r16;
+      const int sw = (row >> 1) & 7;
+      const float4 v0 = *reinterpret_cast<const float4*>(S + row * BK + (((2 * g) ^ sw) * 4));
+      const float4 v1 = *reinterpret_cast<const float4*>(S + row * BK + (((2 * g + 1) ^ sw) * 4));
+      af[i][0] = v0.x; af[i][1] = v0.y; af[i][2] = v0.z; af[i][3] = v0.w;
+      af[i][4] = v1.x; af[i][5] = v1.y; af[i][6] = v1.z; af[i][7] = v1.w;
+    }
+#pragma unroll
+    for (int s8 = 0; s8 < 8; ++s8) {
+      const float2 b = *reinterpret_cast<const float2*>(S + A_FL + (8 * g + s8) * BN + wn * 32 + 2 * r16);
+      bf[0][s8] = b.x; bf[1][s8] = b.y;
+    }
+    u32x4 ah[4], am[4], al[4], bh[2], bm[2], bl[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) split8(af[i], ah[i], am[i], al[i]);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) split8(bf[j], bh[j], bm[j], bl[j]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        f32x4v c = acc[i][j];
+        if (MODE == 1) { c = mma16(al[i], bh[j], c); c = mma16(ah[i], bl[j], c); c = mma16(am[i], bm[j], c); }
+        c = mma16(am[i], bh[j], c); c = mma16(ah[i], bm[j], c); c = mma16(ah[i], bh[j], c);
+        acc[i][j] = c;
+      }
+  };
+  const int nkb = p.K / BK;
+  issue(0, 0);
+  int st = 0;
+  for (int kb = 0; kb < nkb; ++kb) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (kb + 1 < nkb) issue(st ^ 1, kb + 1);
+    compute(st);
+    st ^= 1;
+  }
+  // C layout of the 16x16 block: col = lane & 15, row = (lane >> 4) * 4 + reg
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int row = m0 + wm * 64 + i * 16 + g * 4 + e;
+      const int col = n0 + wn * 32 + 2 * r16;
+      if (row < p.M && col < p.N)
+        *reinterpret_cast<float2*>(Cb + (size_t)row * p.ldc + col) = make_float2(acc[i][0][e], acc[i][1][e]);
+    }
+#endif
+}
+
 __global__ void gemm_ref(LabP p) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (size_t)p.M * p.N) return;
@@ -1135,7 +1251,13 @@ int main(int argc, char** argv) {
 
       run("fp32 mfma", [&] { launch<0>(st, p, s.batch); });
       run("bf16 x6", [&] { launch<1>(st, p, s.batch); });
-      run("x6 pk-sub", [&] { launch<3>(st, p, s.batch); });
+      run("x6 16x16x32", [&] {
+        const int smem = 2 * (128 * 32 + 32 * 64) * 4;
+        static bool once = false;
+        if (!once) { CK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_m16<1>), hipFuncAttributeMaxDynamicSharedMemorySize, smem)); once = true; }
+        LabP w = p; w.tiles_n = (p.N + 63) / 64; w.ntiles = ((p.M + 127) / 128) * w.tiles_n;
+        hipLaunchKernelGGL((gemm_m16<1>), dim3(w.ntiles, 1, s.batch), dim3(256), smem, st, w);
+      });
 
 
 
