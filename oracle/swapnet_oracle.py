@@ -267,8 +267,11 @@ class PatternReplay:
 
     current = None          # (replay, group name, [next site], batch slice)
 
-    def __init__(self, groups):
-        self.groups = groups
+    def __init__(self, groups=None):
+        """groups=None: RECORD this evaluation's own pattern instead (same scopes; afterwards `groups` holds it in the
+        export's format, so one oracle run can be replayed in another -- e.g. the fp32 run's branches in float64)."""
+        self.recording = groups is None
+        self.groups = {} if groups is None else groups
         self.flips = {}             # group -> elements whose own branch differs from the replayed one
         self.elements = {}
         self.used = {}
@@ -283,7 +286,7 @@ class PatternReplay:
 
         def __exit__(self, *exc):
             r, name, i, _ = self.state
-            if exc[0] is None:
+            if exc[0] is None and not r.recording:
                 assert i[0] == len(r.groups[name]), ("pattern replay", name, "sites used", i[0], "of", len(r.groups[name]))
             r.used[name] = i[0]
             PatternReplay.current = self.prev
@@ -301,8 +304,22 @@ class PatternReplay:
             pat = pat[sl]
         return r, name, pat
 
+    def _record(self, name, i, sl, kind, pat):
+        sites = self.groups.setdefault(name, [])
+        if i[0] == len(sites):
+            sites.append((kind, pat))
+        else:                                   # second pass over the group with another batch slice ([fake | real])
+            k, old = sites[i[0]]
+            assert k == kind and sl is not None and sl.start == old.shape[0], (name, i[0], kind, sl)
+            sites[i[0]] = (kind, torch.cat((old, pat), 0))
+        i[0] += 1
+
     @staticmethod
     def act(x, slope):
+        r0, name0, i0, sl0 = PatternReplay.current
+        if r0.recording:
+            r0._record(name0, i0, sl0, 1, (x.detach() > 0).to(torch.uint8))
+            return F.leaky_relu(x, slope) if slope else F.relu(x)
         r, name, pat = PatternReplay._next(1, x)
         assert pat.shape[0] == x.shape[0] and pat.shape[2:] == x.shape[2:] and pat.shape[1] >= x.shape[1], (name, pat.shape, x.shape)
         mask = pat[:, :x.shape[1]] != 0
@@ -317,6 +334,12 @@ class PatternReplay:
 
     @staticmethod
     def pool(x):
+        r0, name0, i0, sl0 = PatternReplay.current
+        if r0.recording:
+            N, C, H, W = x.shape
+            win = x.detach().reshape(N, C, H // 2, 2, W // 2, 2).permute(0, 1, 2, 4, 3, 5).reshape(N, C, H // 2, W // 2, 4)
+            r0._record(name0, i0, sl0, 2, win.argmax(4).to(torch.uint8))      # first maximum, like max_pool2d
+            return F.max_pool2d(x, 2, 2)
         r, name, pat = PatternReplay._next(2, x)
         assert pat.shape[0] == x.shape[0] and pat.shape[2] * 2 == x.shape[2] and pat.shape[1] >= x.shape[1], (name, pat.shape, x.shape)
         idx = pat[:, :x.shape[1]].long()
