@@ -271,18 +271,16 @@ void Net::conv(const std::string& name, const Var& x, const Var& y, ConvKind kin
   const int wP = (wm + wr - 1) * (wm + wr - 1);
   const int wN = x.v.N, wTh = ceil_div(y.v.H, wm), wTw = ceil_div(y.v.W, wm);
   const size_t wT = (size_t)wN * wTh * wTw;
-  // dgrad = the transposed stride-1 conv over dY (pad r-1-p), producing the (reflect: padded) input grid
-  const int wpad2 = kind == CK_K3S1_ZERO ? 1 : 2;
-  const int wTh2 = ceil_div(x.v.H + (kind == CK_K3S1_REFLECT ? 2 : 0), wm);
-  const int wTw2 = ceil_div(x.v.W + (kind == CK_K3S1_REFLECT ? 2 : 0), wm);
-  const size_t wT2 = (size_t)wN * wTh2 * wTw2;
+  // dgrad = the adjoint of the forward Winograd pipeline, in the forward tiling: dV = (A dY A^T) U^T, dx = adjoint input
+  // transform (ops.h wino_input_adjoint).  (Until round 2: the transposed stride-1 conv over dY on the -- for reflect
+  // padding: padded -- input grid, 25 tiles per 16x16 map instead of 16.)
   size_t uf_off = 0, ub_off = 0;
   float* keepV = nullptr;         // V = B^T d B of the forward input, reused by the weight gradient
   if (wino && keep_wino_inputs && y.has_grad) keepV = static_cast<float*>(ctx.alloc((size_t)wP * wT * Cip * sizeof(float)));
   if (wino) {
     uf_off = reserve_dg(self, (size_t)wP * Cip * Cop);
-    wsV_need = std::max(wsV_need, std::max((size_t)wP * wT * Cip, (size_t)wP * wT2 * Cop));
-    wsM_need = std::max(wsM_need, std::max((size_t)wP * wT * Cop, (size_t)wP * wT2 * Cip));
+    wsV_need = std::max(wsV_need, (size_t)wP * wT * std::max(Cip, Cop));
+    wsM_need = std::max(wsM_need, (size_t)wP * wT * std::max(Cip, Cop));
     wsU_need = std::max(wsU_need, (size_t)wP * Cip * Cop);
   }
   auto plane_view = [](float* p, size_t T, int C) {
@@ -337,7 +335,7 @@ void Net::conv(const std::string& name, const Var& x, const Var& y, ConvKind kin
   if (want_dx) {
     if (wino) ub_off = reserve_dg(self, (size_t)wP * Cop * Cip);
     else dg_off = reserve_dg(self, dgrad_elems(arena.params[wi].ws, dg_mode, Cop, Ndg));
-    if (kind == CK_K3S1_REFLECT) dxpad = alloc_var(x.v.N, dHo, dWo, Cip, false);
+    if (kind == CK_K3S1_REFLECT && !wino) dxpad = alloc_var(x.v.N, dHo, dWo, Cip, false);
     op->grad_targets.push_back(x);
     if (!wino)
       op->repack = [=](Net& n) {
@@ -350,7 +348,7 @@ void Net::conv(const std::string& name, const Var& x, const Var& y, ConvKind kin
     op->repack = [=](Net& n) {
       const ParamDesc& wd = A->params[wi];
       wino_filter_transform(n.ctx.s, wm, wr, wd.ws, 0, A->w + wd.off, n.dg + uf_off);
-      if (wdx) wino_filter_transform(n.ctx.s, wm, wr, wd.ws, 1, A->w + wd.off, n.dg + ub_off);
+      if (wdx) wino_filter_transform(n.ctx.s, wm, wr, wd.ws, 2, A->w + wd.off, n.dg + ub_off);
     };
   }
   if (folded) {
@@ -399,20 +397,16 @@ void Net::conv(const std::string& name, const Var& x, const Var& y, ConvKind kin
     if (!want_dx || (me.reads_net_input && !igrad)) return;
     const int accf = me.acc.empty() ? 0 : me.acc[0];
     if (wino) {
-      // input gradient = the transposed 3x3 conv over dY (flipped, channel-transposed filter)
-      wino_input_transform(n.ctx.s, wm, wr, dY, wpad2, PAD_ZERO, wTh2, wTw2, n.wsV);
+      // input gradient in the forward tiling: dM = A dY A^T, dV = dM U^T (U with the channel axes swapped), then the adjoint
+      // of the input transform scatters the patches BT^T dV BT back through the forward gather (padding rule included)
+      wino_dy_transform(n.ctx.s, wm, wr, dY, wTh, wTw, n.wsV);
       ConvFwdArgs g;
-      g.x = plane_view(n.wsV, wT2, Cop); g.g.Ho = 1; g.g.Wo = (int)wT2;
+      g.x = plane_view(n.wsV, wT, Cop); g.g.Ho = 1; g.g.Wo = (int)wT;
       g.w = n.dg + ub_off; g.Npad = Cip; g.Cout = Cip;
-      g.y = plane_view(n.wsM, wT2, Cip);
-      g.batch = wP; g.x_bs = wT2 * Cop; g.w_bs = (size_t)Cop * Cip; g.y_bs = wT2 * Cip;
+      g.y = plane_view(n.wsM, wT, Cip);
+      g.batch = wP; g.x_bs = wT * Cop; g.w_bs = (size_t)Cop * Cip; g.y_bs = wT * Cip;
       conv_fwd(n.ctx.s, g);
-      if (kind == CK_K3S1_REFLECT) {
-        wino_output_transform(n.ctx.s, wm, wr, n.wsM, Cip, wTh2, wTw2, nullptr, ACT_NONE, dxp, Cip, 0);
-        reflect_fold(n.ctx.s, dxp, xgv, accf);
-      } else {
-        wino_output_transform(n.ctx.s, wm, wr, n.wsM, Cip, wTh2, wTw2, nullptr, ACT_NONE, xgv, Cip, accf);
-      }
+      wino_input_adjoint(n.ctx.s, wm, wr, n.wsM, Cip, 1, gf.pad_mode, wTh, wTw, xgv, accf);
       return;
     }
     if (kind == CK_K4S2) {
@@ -782,8 +776,11 @@ void Model::set_gp_random(const float* alpha_dev, const float* beta_nchw_dev) {
 void Model::run_gradient_penalty(const TView& real, const TView& fake) {
   if (!gp_) { AllocScope mine(*ctx, owned_allocs); gp_ = std::make_unique<GradPenalty>(*ctx, arenaD, B, H, W); }
   const TView beta = gp_->beta_buffer();
+  // library RNG: a function of the step seed the caller handed to forward() (torch.initial_seed(), the step counter and --
+  // under data parallelism -- the rank: every rank draws its own alpha / beta) and of the optimizer step
+  const uint64_t gp_seed = (G ? G->seed : 0) * 0x9E3779B97F4A7C15ull + (uint64_t)arenaD.step * 7919ull + 13ull;
   gp_->run(real, fake, hyper.gp_mode, hyper.grad_scale, hyper.lambda_gp, gp_alpha_set_ ? gp_->alpha_buffer() : nullptr,
-           gp_beta_set_ ? &beta : nullptr, (uint64_t)arenaD.step * 7919ull + 13ull, losses + L_D_GP);
+           gp_beta_set_ ? &beta : nullptr, gp_seed, losses + L_D_GP);
   gp_alpha_set_ = gp_beta_set_ = false;
   scalar_axpby(ctx->s, losses + L_D, 1.f, losses + L_D_GP, 1.f, losses + L_D);     // loss_D += loss_D_gp (warp_model.py:136)
 }

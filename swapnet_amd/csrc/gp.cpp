@@ -119,7 +119,9 @@ void GradPenalty::run(const TView& real, const TView& fake, int gp_mode, float g
     alpha = alpha_;
   }
   if (dragan) {
-    if (!beta) { gp_uniform(s, beta_, Cd_, seed * 2 + 2); /* pads are multiplied by zero weights */ beta = &beta_; }
+    // layout pads (cimap < 0) must stay exactly 0: x_hat feeds wgrad(0, x_hat, .), and a non-zero pad channel would put a
+    // gradient on the pad rows of model.0.weight, which AdamW would then move off zero
+    if (!beta) { gp_uniform(s, beta_, Cd_, seed * 2 + 2, L_[0].ws.cimap); beta = &beta_; }
     gp_half_std(s, real, (size_t)real.N * real.H * real.W * Cd_logical_, half_std_);
     gp_interpolate(s, real, nullptr, alpha, beta, half_std_, xh_.v);
   } else {

@@ -433,12 +433,14 @@ __global__ __launch_bounds__(64) void gp_std_finalize_kernel(const double* parti
   if (var < 0) var = 0;
   out[0] = (float)(0.5 * sqrt(var));
 }
-__global__ __launch_bounds__(256) void gp_uniform_kernel(float* v, int cs, size_t pixels, int C, int Clog, uint64_t seed) {
+__global__ __launch_bounds__(256) void gp_uniform_kernel(float* v, int cs, size_t pixels, int C, int Clog, uint64_t seed,
+                                                          const int32_t* cimap) {
   const size_t total = pixels * C;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
     const size_t e = i / C;
     const int c = (int)(i - e * C);
-    v[e * cs + c] = c < Clog ? (float)(mix64(seed * 0xD1342543DE82EF95ull + i) & 0xFFFFFFu) * (1.0f / 16777216.0f) : 0.f;
+    const bool live = c < Clog && (!cimap || cimap[c] >= 0);
+    v[e * cs + c] = live ? (float)(mix64(seed * 0xD1342543DE82EF95ull + i) & 0xFFFFFFu) * (1.0f / 16777216.0f) : 0.f;
   }
 }
 
@@ -591,8 +593,9 @@ void gp_penalty(Stream& s, const TView& g, int lp, float scale, float* loss_out,
   hipLaunchKernelGGL(gp_scale_kernel, dim3(loss_grid((size_t)g.N * per)), dim3(256), 0, hs(s), g.p, g.cs, coef, u.p, u.cs, g.N, HW, g.C);
   check_launch("gp_penalty");
 }
-void gp_uniform(Stream& s, const TView& v, int Clog, uint64_t seed) {
-  hipLaunchKernelGGL(gp_uniform_kernel, dim3(loss_grid(v.pixels() * v.C)), dim3(256), 0, hs(s), v.p, v.cs, v.pixels(), v.C, Clog, seed);
+void gp_uniform(Stream& s, const TView& v, int Clog, uint64_t seed, const int32_t* cimap) {
+  hipLaunchKernelGGL(gp_uniform_kernel, dim3(loss_grid(v.pixels() * v.C)), dim3(256), 0, hs(s), v.p, v.cs, v.pixels(), v.C, Clog, seed,
+                     cimap);
   check_launch("gp_uniform");
 }
 

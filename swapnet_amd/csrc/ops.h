@@ -114,8 +114,14 @@ void reflect_fold(Stream& s, const TView& dxpad, const TView& dx, int accumulate
 // tile (n,ty,tx) covers outputs (m*ty..m*ty+m-1, m*tx..) and input rows m*ty-pad .. m*ty-pad+m+r-2;
 // P = (m+r-1)^2 transform planes (16 for F(2,3): 2.25x fewer multiplies; 36 for F(4,3) / F(3,4): 4x fewer)
 void wino_input_transform(Stream& s, int m, int r, const TView& x, int pad, int pad_mode, int Th, int Tw, float* V);  // V[P][T][x.C]
-// mode 0: U[P][Cip][Npad] for the forward conv; mode 1: U[P][Npad][Cip] (flipped, transposed) for dgrad
+// mode 0: U[P][Cip][Npad] for the forward conv; mode 1: U[P][Npad][Cip] (flipped, transposed) for the transposed-conv form of
+// dgrad; mode 2: U[P][Npad][Cip] = mode 0 with the channel axes swapped, the operand of the adjoint form (wino_input_adjoint)
 void wino_filter_transform(Stream& s, int m, int r, const WShape& w, int mode, const float* packed, float* U);
+// Input gradient in the forward tiling: dV[P][T][C] = dM U^T (dM = wino_dy_transform of dY, T = dx.N * Th * Tw forward tiles).
+// dx (+)= sum over tiles of the patches BT^T dV_t BT placed where wino_input_transform(pad, pad_mode, Th, Tw) gathered them
+// (reflected / dropped exactly like the forward gather).  dV is overwritten (scratch).
+void wino_input_adjoint(Stream& s, int m, int r, float* dV, int C, int pad, int pad_mode, int Th, int Tw, const TView& dx,
+                        int accumulate);
 void wino_output_transform(Stream& s, int m, int r, const float* M, int Cm, int Th, int Tw, const float* bias, int act,
                            const TView& y, int Cout, int accumulate);                                      // M[P][T][Cm]
 void wino_dy_transform(Stream& s, int m, int r, const TView& dy, int Th, int Tw, float* dM);               // dM[P][T][dy.C]
@@ -232,8 +238,10 @@ void gp_half_std(Stream& s, const TView& a, size_t numel, float* out);
 // per-sample L2 norm of g over all its elements; penalty = mean_n (norm_n - 1)^2 (lp != 0: max(0, norm_n - 1)^2);
 // loss_out[0] = penalty, u = scale * d(penalty)/dg   (same geometry as g)
 void gp_penalty(Stream& s, const TView& g, int lp, float scale, float* loss_out, const TView& u);
-// fills a view with U[0,1) from the library's counter RNG (logical channels only, pads 0): beta of dragan
-void gp_uniform(Stream& s, const TView& v, int Clog, uint64_t seed);
+// fills a view with U[0,1) from the library's counter RNG: beta of dragan.  Channels c >= Clog and, when a device channel map
+// is given (WShape::cimap of the layer that reads the buffer), channels with cimap[c] < 0 are layout pads and stay 0 -- a
+// non-zero pad would reach the pad rows of the first conv's weight gradient.
+void gp_uniform(Stream& s, const TView& v, int Clog, uint64_t seed, const int32_t* cimap = nullptr);
 // Second-order step through y = act(InstanceNorm(x)) (reverse over reverse).  The first backward computed
 // gx = IN'(x)^T (act'(xh) * gy).  Given u = adjoint of gx:  uy = act'(xh) * IN'(x) u   (adjoint of gy; IN' is symmetric)
 // and ax = (d gx / d x)^T u (adjoint of the raw activation x):

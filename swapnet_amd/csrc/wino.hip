@@ -80,7 +80,9 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const float* x, int xcs
 }
 
 // U[t][k][n] = (G g G^T)[t];  mode 0: g[ky][kx] = W[(ky,kx,k=ci)][n=co]
-//                              mode 1: g[ky][kx] = W[(2-ky,2-kx,ci=n)][co=k]   (input-gradient operand)
+//                              mode 1: g[ky][kx] = W[(2-ky,2-kx,ci=n)][co=k]   (transposed-conv form of the input gradient)
+//                              mode 2: g[ky][kx] = W[(ky,kx,ci=n)][co=k]       (= mode 0 with the channel axes swapped: the
+//                                      operand of the ADJOINT form dV = dM U^T, see wino_input_adjoint)
 __global__ __launch_bounds__(256) void wino_filter_kernel(WShape w, int mode, int K, int Nn, const float* packed, float* U) {
   const size_t total = (size_t)K * Nn;
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -94,8 +96,10 @@ __global__ __launch_bounds__(256) void wino_filter_kernel(WShape w, int mode, in
       float v = 0.f;
       if (mode == 0) {
         if (k < w.Cip && n < w.Npad) v = packed[((size_t)(a * 3 + b) * w.Cip + k) * w.Npad + n];
-      } else {
+      } else if (mode == 1) {
         if (n < w.Cip && k < w.Npad) v = packed[((size_t)((2 - a) * 3 + (2 - b)) * w.Cip + n) * w.Npad + k];
+      } else {
+        if (n < w.Cip && k < w.Npad) v = packed[((size_t)(a * 3 + b) * w.Cip + n) * w.Npad + k];
       }
       g[a][b] = v;
     }
@@ -333,8 +337,10 @@ __global__ __launch_bounds__(256) void winog_filter_kernel(WShape w, int mode, i
       float v = 0.f;
       if (mode == 0) {
         if (k < w.Cip && n < w.Npad) v = packed[((size_t)(a * R + b) * w.Cip + k) * w.Npad + n];
-      } else {
+      } else if (mode == 1) {
         if (n < w.Cip && k < w.Npad) v = packed[((size_t)((R - 1 - a) * R + (R - 1 - b)) * w.Cip + n) * w.Npad + k];
+      } else {
+        if (n < w.Cip && k < w.Npad) v = packed[((size_t)(a * R + b) * w.Cip + n) * w.Npad + k];
       }
       g[a][b] = v;
     }
@@ -486,6 +492,105 @@ __global__ __launch_bounds__(256) void winog_filter_grad_kernel(WShape w, const 
     }
 }
 
+
+// ---------------------------------------------------------------------------------------
+// Adjoint of the input transform: the input gradient of a Winograd convolution in its own tiling.
+//   forward   V_t = BT d_t BT^T ,  d_t[a][b] = x[src(m ty - pad + a)][src(m tx - pad + b)]      (zero / reflect padding folded in)
+//   backward  dx[y][x] = sum over (t, a, b) with src(.) = (y, x) of (BT^T dV_t BT)[a][b]
+// The transposed-convolution form used until round 2 ran the same GEMMs over the (for reflect padding: padded) INPUT grid --
+// 25 tiles per 16x16 map where the forward pass has 16 -- and needed its own input transform of dY; here dV = dM U^T reuses
+// dM = A dY A^T (the weight gradient's operand) on the forward tiling: 36 % fewer GEMM rows on the resblock convs.
+// Two kernels: the per-tile patch BT^T dV BT in place, then a gather per input pixel (fixed summation order, no atomics).
+// ---------------------------------------------------------------------------------------
+struct F23 {
+  static constexpr int M = 2, R = 3, A = 4;
+  static constexpr float BT[4][4] = {{1, 0, -1, 0}, {0, 1, 1, 0}, {0, -1, 1, 0}, {0, 1, 0, -1}};
+};
+
+template <class F>
+__global__ __launch_bounds__(256) void winog_patch_kernel(float* V, int C, size_t T) {
+  constexpr int A = F::A;
+  const int C4 = C >> 2;
+  const size_t total = T * C4;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const size_t tile = i / C4;
+    const int c = (int)(i - tile * C4) * 4;
+    float4 t[A][A];
+#pragma unroll
+    for (int b = 0; b < A; ++b) {            // BT^T v, one column of planes at a time
+      float4 v[A];
+#pragma unroll
+      for (int a = 0; a < A; ++a) v[a] = *reinterpret_cast<const float4*>(V + ((size_t)(a * A + b) * T + tile) * C + c);
+#pragma unroll
+      for (int r = 0; r < A; ++r) {
+        float4 s = F4ZERO;
+#pragma unroll
+        for (int k = 0; k < A; ++k) f4mac(s, F::BT[k][r], v[k]);
+        t[r][b] = s;
+      }
+    }
+#pragma unroll
+    for (int a = 0; a < A; ++a)              // (.) BT
+#pragma unroll
+      for (int j = 0; j < A; ++j) {
+        float4 s = F4ZERO;
+#pragma unroll
+        for (int k = 0; k < A; ++k) f4mac(s, F::BT[k][j], t[a][k]);
+        *reinterpret_cast<float4*>(V + ((size_t)(a * A + j) * T + tile) * C + c) = s;
+      }
+  }
+}
+
+// candidates e (tile coordinates, -pad <= e <= emax) with src(e) == y: y itself and its single-bounce reflections
+__device__ __forceinline__ int adj_sources(int y, int ext, int pad, int pad_mode, int emax, int (&e)[3]) {
+  int n = 0;
+  if (y <= emax) e[n++] = y;
+  if (pad_mode == PAD_REFLECT) {
+    if (y >= 1 && -y >= -pad) e[n++] = -y;
+    const int r = 2 * ext - 2 - y;
+    if (r >= ext && r <= emax) e[n++] = r;
+  }
+  return n;
+}
+
+__global__ __launch_bounds__(256) void wino_fold_kernel(const float* P, int C, int N, int H, int W, int m, int A, int pad,
+                                                        int pad_mode, int Th, int Tw, float* dx, int dcs, int accumulate) {
+  const int C4 = C >> 2;
+  const size_t T = (size_t)N * Th * Tw;
+  const size_t total = (size_t)N * H * W * C4;
+  const int emax_y = m * (Th - 1) - pad + A - 1, emax_x = m * (Tw - 1) - pad + A - 1;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const size_t px = i / C4;
+    const int c = (int)(i - px * C4) * 4;
+    const int n = (int)(px / ((size_t)H * W));
+    const int rem = (int)(px - (size_t)n * H * W);
+    const int y = rem / W, x = rem - y * W;
+    int ey[3], ex[3];
+    const int ny = adj_sources(y, H, pad, pad_mode, emax_y, ey), nx = adj_sources(x, W, pad, pad_mode, emax_x, ex);
+    float4 acc = F4ZERO;
+    for (int iy = 0; iy < ny; ++iy) {
+      const int qy = ey[iy] + pad;                                   // = m ty + a
+      const int ty1 = min(qy / m, Th - 1);
+      for (int ty = ty1; ty >= 0 && qy - m * ty < A; --ty) {
+        const int a = qy - m * ty;
+        for (int ix = 0; ix < nx; ++ix) {
+          const int qx = ex[ix] + pad;
+          const int tx1 = min(qx / m, Tw - 1);
+          for (int tx = tx1; tx >= 0 && qx - m * tx < A; --tx) {
+            const int b = qx - m * tx;
+            const size_t tile = ((size_t)n * Th + ty) * Tw + tx;
+            const float4 v = *reinterpret_cast<const float4*>(P + ((size_t)(a * A + b) * T + tile) * C + c);
+            acc = f4add(acc, v);
+          }
+        }
+      }
+    }
+    float* d = dx + px * dcs + c;
+    if (accumulate) acc = f4add(acc, *reinterpret_cast<const float4*>(d));
+    *reinterpret_cast<float4*>(d) = acc;
+  }
+}
+
 inline unsigned wgrid(size_t total) { return (unsigned)std::min<size_t>(std::max<size_t>((total + 255) / 256, 1), 256 * 32); }
 
 }  // namespace
@@ -514,7 +619,7 @@ void wino_input_transform(Stream& s, int m, int r, const TView& x, int pad, int 
 }
 void wino_filter_transform(Stream& s, int m, int r, const WShape& w, int mode, const float* packed, float* U) {
   const int v = variant(m, r);
-  const int K = mode == 0 ? w.Cip : w.Npad, Nn = mode == 0 ? w.Npad : w.Cip;
+  const int K = mode == 0 ? w.Cip : w.Npad, Nn = mode == 0 ? w.Npad : w.Cip;      // modes 1, 2: [Npad][Cip]
   const dim3 grid((unsigned)(((size_t)K * Nn + 255) / 256));
   if (v == 0) hipLaunchKernelGGL(wino_filter_kernel, grid, dim3(256), 0, hs(s), w, mode, K, Nn, packed, U);
   else if (v == 1) hipLaunchKernelGGL(winog_filter_kernel<F43>, grid, dim3(256), 0, hs(s), w, mode, K, Nn, packed, U);
@@ -549,6 +654,20 @@ void wino_dy_transform(Stream& s, int m, int r, const TView& dy, int Th, int Tw,
   else
     hipLaunchKernelGGL(winog_dy_kernel<F34>, grid, dim3(256), 0, hs(s), dy.p, dy.cs, dy.N, dy.H, dy.W, dy.C, Th, Tw, dM);
   check_launch("wino_dy_transform");
+}
+void wino_input_adjoint(Stream& s, int m, int r, float* dV, int C, int pad, int pad_mode, int Th, int Tw, const TView& dx,
+                        int accumulate) {
+  const int v = variant(m, r);
+  if (C % 4 || dx.C != C || dx.cs % 4) throw Error(1, "wino_input_adjoint: bad channel count");
+  const size_t T = (size_t)dx.N * Th * Tw;
+  const dim3 grid(wgrid(T * (C / 4)));
+  if (v == 0) hipLaunchKernelGGL(winog_patch_kernel<F23>, grid, dim3(256), 0, hs(s), dV, C, T);
+  else if (v == 1) hipLaunchKernelGGL(winog_patch_kernel<F43>, grid, dim3(256), 0, hs(s), dV, C, T);
+  else hipLaunchKernelGGL(winog_patch_kernel<F34>, grid, dim3(256), 0, hs(s), dV, C, T);
+  const int A = m + r - 1;
+  hipLaunchKernelGGL(wino_fold_kernel, dim3(wgrid(dx.pixels() * (C / 4))), dim3(256), 0, hs(s), dV, C, dx.N, dx.H, dx.W, m, A, pad,
+                     pad_mode, Th, Tw, dx.p, dx.cs, accumulate);
+  check_launch("wino_input_adjoint");
 }
 void wino_filter_grad(Stream& s, int m, int r, const WShape& w, const float* dU, float* dpacked) {
   const int v = variant(m, r);

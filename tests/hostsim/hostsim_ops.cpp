@@ -235,7 +235,8 @@ void wino_filter_transform(Stream&, int m, int r, const WShape& w, int mode, con
     float g[4][4], t[6][4];
     for (int a = 0; a < R; ++a) for (int b = 0; b < R; ++b)
       g[a][b] = mode == 0 ? packed[((size_t)(a * R + b) * w.Cip + k) * w.Npad + n]
-                          : packed[((size_t)((R - 1 - a) * R + (R - 1 - b)) * w.Cip + n) * w.Npad + k];
+              : mode == 1 ? packed[((size_t)((R - 1 - a) * R + (R - 1 - b)) * w.Cip + n) * w.Npad + k]
+                          : packed[((size_t)(a * R + b) * w.Cip + n) * w.Npad + k];
     for (int a = 0; a < A; ++a) for (int b = 0; b < R; ++b) { float s = 0; for (int q = 0; q < R; ++q) s += wm.G[a * R + q] * g[q][b]; t[a][b] = s; }
     for (int a = 0; a < A; ++a) for (int b = 0; b < A; ++b) { float s = 0; for (int q = 0; q < R; ++q) s += t[a][q] * wm.G[b * R + q];
       U[(size_t)(a * A + b) * total + (size_t)k * Nn + n] = s; }
@@ -282,6 +283,33 @@ void wino_dy_transform(Stream&, int m, int r, const TView& dy, int Th, int Tw, f
         float s = 0;
         for (int a = 0; a < m; ++a) for (int b = 0; b < m; ++b) s += wm.AT[a * A + i] * g[a][b] * wm.AT[b * A + j];
         dM[((size_t)(i * A + j) * T + tile) * dy.C + c] = s;
+      }
+    }
+  }
+}
+// adjoint of wino_input_transform as a plain scatter over (tile, a, b): the second opinion on the HIP gather kernel
+void wino_input_adjoint(Stream&, int m, int r, float* dV, int C, int pad, int pad_mode, int Th, int Tw, const TView& dx, int accumulate) {
+  const WinoMats wm = wino_mats(m, r);
+  const int A = wm.A;
+  const size_t T = (size_t)dx.N * Th * Tw;
+  if (!accumulate)
+    for (size_t e = 0; e < dx.pixels(); ++e) std::memset(dx.p + e * dx.cs, 0, C * sizeof(float));
+  for (int n = 0; n < dx.N; ++n) for (int ty = 0; ty < Th; ++ty) for (int tx = 0; tx < Tw; ++tx) {
+    const size_t tile = ((size_t)n * Th + ty) * Tw + tx;
+    for (int c = 0; c < C; ++c) {
+      float v[6][6], t[6][6];
+      for (int a = 0; a < A; ++a) for (int b = 0; b < A; ++b) v[a][b] = dV[((size_t)(a * A + b) * T + tile) * C + c];
+      // patch = BT^T v BT
+      for (int a = 0; a < A; ++a) for (int b = 0; b < A; ++b) { float s = 0; for (int k = 0; k < A; ++k) s += wm.BT[k * A + a] * v[k][b]; t[a][b] = s; }
+      for (int a = 0; a < A; ++a) {
+        const int sy = srcc(m * ty - pad + a, dx.H, pad_mode, 0);
+        if (sy < 0) continue;
+        for (int b = 0; b < A; ++b) {
+          const int sx = srcc(m * tx - pad + b, dx.W, pad_mode, 0);
+          if (sx < 0) continue;
+          float s = 0; for (int k = 0; k < A; ++k) s += t[a][k] * wm.BT[k * A + b];
+          at(dx, n, sy, sx)[c] += s;
+        }
       }
     }
   }
@@ -694,12 +722,13 @@ void gp_penalty(Stream&, const TView& g, int lp, float scale, float* loss_out, c
   }
   loss_out[0] = (float)(loss / g.N);
 }
-void gp_uniform(Stream&, const TView& v, int Clog, uint64_t seed) {
+void gp_uniform(Stream&, const TView& v, int Clog, uint64_t seed, const int32_t* cimap) {
   for (size_t e = 0; e < v.pixels(); ++e)
     for (int c = 0; c < v.C; ++c) {
       uint64_t z = seed * 0xD1342543DE82EF95ull + (e * v.C + c) + 0x9E3779B97F4A7C15ull;
       z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; z ^= z >> 31;
-      v.p[e * v.cs + c] = c < Clog ? (float)((uint32_t)(z >> 11) & 0xFFFFFFu) * (1.0f / 16777216.0f) : 0.f;
+      const bool live = c < Clog && (!cimap || cimap[c] >= 0);
+      v.p[e * v.cs + c] = live ? (float)((uint32_t)(z >> 11) & 0xFFFFFFu) * (1.0f / 16777216.0f) : 0.f;
     }
 }
 void norm_act_bwd2(Stream&, const NormActBwd2Args& a) {
