@@ -242,6 +242,141 @@ __global__ __launch_bounds__(256) void in2_apply_kernel(NA2p p) {
   }
 }
 
+
+// ---------------------------------------------------------------------------------------
+// Register-resident InstanceNorm for maps of up to 1024 pixels (every IN of the two networks below 64x64: the resblocks,
+// the deep encoder / decoder levels, PatchGAN's 32x32 and 31x31 maps).  One block owns one image x CG channels and keeps
+// the whole H*W slab in registers: statistics and apply are ONE pass over HBM (read x once, write y once; backward: read x
+// and dy once, write dx once) and one launch, where the chunked three-kernel path reads x twice (thrice backward) and
+// launches three kernels per layer.  Same arithmetic: fp64 sums, a fixed reduction tree (deterministic), mean / rstd rounded
+// to fp32 exactly like in_finalize_kernel.
+// ---------------------------------------------------------------------------------------
+template <int ROWS, int NV>
+__device__ __forceinline__ void block_tree_sum(double* red, double (&v)[NV], int tx, int ty, int C4) {
+  // red[(ty * C4 + tx) * NV + j]; result broadcast from row 0
+#pragma unroll
+  for (int j = 0; j < NV; ++j) red[(ty * C4 + tx) * NV + j] = v[j];
+  __syncthreads();
+#pragma unroll
+  for (int stride = ROWS / 2; stride >= 1; stride >>= 1) {
+    if (ty < stride) {
+#pragma unroll
+      for (int j = 0; j < NV; ++j) red[(ty * C4 + tx) * NV + j] += red[((ty + stride) * C4 + tx) * NV + j];
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int j = 0; j < NV; ++j) v[j] = red[tx * NV + j];
+}
+
+template <int CG, int NP>
+__global__ __launch_bounds__(256) void in_fused_fwd_kernel(NAp p) {
+  constexpr int C4 = CG / 4, ROWS = 256 / C4;
+  __shared__ double red[256 * 8];
+  const int t = threadIdx.x, tx = t % C4, ty = t / C4;
+  const int n = blockIdx.y, c = blockIdx.x * CG + tx * 4;
+  float4 v[NP];
+  double s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+  for (int i = 0; i < NP; ++i) {
+    const int pix = ty + i * ROWS;
+    if (pix < p.HW) {
+      v[i] = *reinterpret_cast<const float4*>(p.x + ((size_t)n * p.HW + pix) * p.xcs + c);
+      s[0] += v[i].x; s[1] += v[i].y; s[2] += v[i].z; s[3] += v[i].w;
+      s[4] += (double)v[i].x * v[i].x; s[5] += (double)v[i].y * v[i].y; s[6] += (double)v[i].z * v[i].z; s[7] += (double)v[i].w * v[i].w;
+    }
+  }
+  block_tree_sum<ROWS, 8>(red, s, tx, ty, C4);
+  float mean[4], rstd[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const double m = s[j] / p.HW;
+    double var = s[4 + j] / p.HW - m * m;
+    if (var < 0) var = 0;
+    mean[j] = (float)m; rstd[j] = (float)(1.0 / sqrt(var + (double)IN_EPS));
+  }
+  if (ty == 0) {
+    float* st = p.stats + ((size_t)n * p.C + c) * 2;
+    *reinterpret_cast<float4*>(st) = make_float4(mean[0], rstd[0], mean[1], rstd[1]);
+    *reinterpret_cast<float4*>(st + 4) = make_float4(mean[2], rstd[2], mean[3], rstd[3]);
+  }
+#pragma unroll
+  for (int i = 0; i < NP; ++i) {
+    const int pix = ty + i * ROWS;
+    if (pix >= p.HW) continue;
+    const size_t e = (size_t)n * p.HW + pix;
+    float o[4] = {(v[i].x - mean[0]) * rstd[0], (v[i].y - mean[1]) * rstd[1], (v[i].z - mean[2]) * rstd[2], (v[i].w - mean[3]) * rstd[3]};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      o[j] = act_apply(o[j], p.act);
+      if (p.drop_p > 0.f) o[j] *= drop_scale(p.seed, e * p.C + c + j, p.drop_p);
+    }
+    if (p.res) {
+      const float4 r = *reinterpret_cast<const float4*>(p.res + e * p.rescs + c);
+      o[0] += r.x; o[1] += r.y; o[2] += r.z; o[3] += r.w;
+    }
+    *reinterpret_cast<float4*>(p.y + e * p.ycs + c) = make_float4(o[0], o[1], o[2], o[3]);
+  }
+}
+
+template <int CG, int NP>
+__global__ __launch_bounds__(256) void in_fused_bwd_kernel(NAp p) {
+  constexpr int C4 = CG / 4, ROWS = 256 / C4;
+  __shared__ double red[256 * 8];
+  const int t = threadIdx.x, tx = t % C4, ty = t / C4;
+  const int n = blockIdx.y, c = blockIdx.x * CG + tx * 4;
+  float mean[4], rstd[4];
+  {
+    const float* st = p.stats + ((size_t)n * p.C + c) * 2;
+    const float4 s0 = *reinterpret_cast<const float4*>(st), s1 = *reinterpret_cast<const float4*>(st + 4);
+    mean[0] = s0.x; rstd[0] = s0.y; mean[1] = s0.z; rstd[1] = s0.w; mean[2] = s1.x; rstd[2] = s1.y; mean[3] = s1.z; rstd[3] = s1.w;
+  }
+  float4 xv[NP], gv[NP];
+  double s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+  for (int i = 0; i < NP; ++i) {
+    const int pix = ty + i * ROWS;
+    if (pix < p.HW) {
+      const size_t e = (size_t)n * p.HW + pix;
+      xv[i] = *reinterpret_cast<const float4*>(p.x + e * p.xcs + c);
+      const float4 d = *reinterpret_cast<const float4*>(p.dy + e * p.dycs + c);
+      const float xa[4] = {xv[i].x, xv[i].y, xv[i].z, xv[i].w};
+      float g[4] = {d.x, d.y, d.z, d.w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float xh = (xa[j] - mean[j]) * rstd[j];                  // the forward's value (selects the activation branch)
+        g[j] *= act_grad_from_in(xh, p.act);
+        if (p.drop_p > 0.f) g[j] *= drop_scale(p.seed, e * p.C + c + j, p.drop_p);
+        s[j] += g[j];
+        s[4 + j] += (double)g[j] * (((double)xa[j] - (double)mean[j]) * (double)rstd[j]);
+      }
+      gv[i] = make_float4(g[0], g[1], g[2], g[3]);
+    }
+  }
+  block_tree_sum<ROWS, 8>(red, s, tx, ty, C4);
+  double m1[4], m2[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { m1[j] = s[j] / p.HW; m2[j] = s[4 + j] / p.HW; }
+#pragma unroll
+  for (int i = 0; i < NP; ++i) {
+    const int pix = ty + i * ROWS;
+    if (pix >= p.HW) continue;
+    const size_t e = (size_t)n * p.HW + pix;
+    const float xa[4] = {xv[i].x, xv[i].y, xv[i].z, xv[i].w};
+    const float g[4] = {gv[i].x, gv[i].y, gv[i].z, gv[i].w};
+    float o[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      o[j] = (float)((double)rstd[j] * ((double)g[j] - m1[j] - (((double)xa[j] - (double)mean[j]) * (double)rstd[j]) * m2[j]));
+    *reinterpret_cast<float4*>(p.y + e * p.ycs + c) = make_float4(o[0], o[1], o[2], o[3]);
+  }
+}
+
+static bool fused_in_on() {
+  const bool on = !(getenv("SWN_FUSED_IN") && atoi(getenv("SWN_FUSED_IN")) == 0);       // read per launch: tests toggle it
+  return on;
+}
+
 struct EWp {
   const float* a; int acs;
   const float* b; int bcs;
@@ -394,8 +529,16 @@ void norm_act_fwd(Stream& s, const NormActArgs& a) {
   p.res = a.residual ? a.residual->p : nullptr; p.rescs = a.residual ? a.residual->cs : 0;
   p.stats = a.stats; p.N = a.x.N; p.HW = a.x.H * a.x.W; p.C = a.x.C;
   p.norm = a.norm; p.act = a.act; p.drop_p = a.drop_p; p.seed = a.seed;
+  if (a.norm && !a.stats) throw Error(1, "norm_act_fwd: stats buffer required");
+  if (a.norm && p.HW <= 1024 && p.C % 32 == 0 && fused_in_on()) {
+    const dim3 grid(p.C / 32, p.N);
+    if (p.HW <= 64) hipLaunchKernelGGL((in_fused_fwd_kernel<32, 2>), grid, dim3(256), 0, hs(s), p);
+    else if (p.HW <= 256) hipLaunchKernelGGL((in_fused_fwd_kernel<32, 8>), grid, dim3(256), 0, hs(s), p);
+    else hipLaunchKernelGGL((in_fused_fwd_kernel<32, 32>), grid, dim3(256), 0, hs(s), p);
+    check_launch("norm_act_fwd (fused)");
+    return;
+  }
   if (a.norm) {
-    if (!a.stats) throw Error(1, "norm_act_fwd: stats buffer required");
     plan_chunks(p.HW, p.N, p.C, p.nchunk, p.chunk);
     p.partial = reinterpret_cast<double*>(s.ws);
     if ((size_t)p.N * p.nchunk * p.C * 16 > s.ws_bytes) throw Error(1, "norm_act: workspace too small");
@@ -412,6 +555,14 @@ void norm_act_bwd(Stream& s, const NormActBwdArgs& a) {
   p.x = a.x.p; p.xcs = a.x.cs; p.dy = a.dy.p; p.dycs = a.dy.cs; p.y = a.dx.p; p.ycs = a.dx.cs;
   p.stats = const_cast<float*>(a.stats); p.N = a.x.N; p.HW = a.x.H * a.x.W; p.C = a.x.C;
   p.norm = a.norm; p.act = a.act; p.drop_p = a.drop_p; p.seed = a.seed;
+  if (a.norm && p.HW <= 1024 && p.C % 32 == 0 && fused_in_on()) {
+    if (p.HW <= 64) hipLaunchKernelGGL((in_fused_bwd_kernel<32, 2>), dim3(p.C / 32, p.N), dim3(256), 0, hs(s), p);
+    else if (p.HW <= 256) hipLaunchKernelGGL((in_fused_bwd_kernel<32, 8>), dim3(p.C / 32, p.N), dim3(256), 0, hs(s), p);
+    else if (p.HW <= 512) hipLaunchKernelGGL((in_fused_bwd_kernel<32, 16>), dim3(p.C / 32, p.N), dim3(256), 0, hs(s), p);
+    else hipLaunchKernelGGL((in_fused_bwd_kernel<16, 16>), dim3(p.C / 16, p.N), dim3(256), 0, hs(s), p);
+    check_launch("norm_act_bwd (fused)");
+    return;
+  }
   if (a.norm) {
     plan_chunks(p.HW, p.N, p.C, p.nchunk, p.chunk);
     p.partial = reinterpret_cast<double*>(s.ws);

@@ -141,7 +141,8 @@ def test_conv_backward(backend):
 def test_instance_norm_act(backend):
     ctx = _ctx(backend)
     g = torch.Generator().manual_seed(2)
-    shapes = [(2, 8, 5, 7), (3, 36, 4, 4), (1, 1024, 2, 2)] + ([(4, 64, 128, 128), (2, 512, 31, 31)] if backend == "gpu" else [])
+    shapes = [(2, 8, 5, 7), (3, 36, 4, 4), (1, 1024, 2, 2)] + ([(4, 64, 128, 128), (2, 512, 31, 31), (2, 64, 8, 8), (2, 96, 16, 16), (2, 64, 20, 20), (2, 32, 32, 32), (1, 64, 33, 32)]
+                                                          if backend == "gpu" else [])      # <= 1024 pixels, C % 32 == 0: the register-resident kernels
     for n, c, h, w in shapes:
         x = (torch.randn(n, c, h, w, generator=g) * 3 + 1.5).requires_grad_(True)
         for act, fn in ((0, lambda t: t), (1, lambda t: F.leaky_relu(t, 0.2)), (2, F.relu)):
