@@ -50,7 +50,8 @@ PEAK_SPLIT_TFLOPS = round(PEAK_BF16_MFMA_TFLOPS / 6.0, 1)
 
 
 def cpu_baseline(sample_bs=4, size=256, warm=2, timed=5):
-    """Oracle = functional port of the reference's WarpModel step on torch CPU ("kind": "port")."""
+    """Oracle = functional port of the reference's WarpModel step on torch CPU ("kind": "port": /root/reference does not
+    exist on the GPU box; the port is pinned to golden vectors recorded from the real reference, tests/test_oracle_golden.py)."""
     from oracle import swapnet_oracle as O
     # threads actually usable by this process (cgroup / affinity aware), capped: beyond ~32 threads
     # torch-CPU convolutions at this size stop scaling and oversubscription only slows them down
@@ -70,9 +71,27 @@ def cpu_baseline(sample_bs=4, size=256, warm=2, timed=5):
     for _ in range(timed):
         st.step(*batch)
     dt = (time.time() - t0) / timed
-    return {"value": round(sample_bs / dt, 4), "unit": "images/sec", "cores": cores, "kind": "port",
-            "sample": f"warp G+D step {size}x{size} bs {sample_bs}, {warm} warm-up + {timed} timed steps, "
-                      f"torch {torch.__version__} CPU fp32, {cores} threads"}
+    out = {"value": round(sample_bs / dt, 4), "unit": "images/sec", "cores": cores, "kind": "port",
+           "sample": f"warp G+D step {size}x{size} bs {sample_bs}, {warm} warm-up + {timed} timed steps, "
+                     f"torch {torch.__version__} CPU fp32, {cores} threads"}
+    # BASELINE.json configs[0] (C1): warp 64x64, bs 4 on the CPU path -- one "epoch" of 8 synthetic batches after 2 warm-up steps
+    batch1 = O.synth_warp_batch(4, 64, 64, seed=1234)
+    st1 = O.WarpStepOracle(G, D, training=True)
+    for _ in range(2):
+        st1.step(*batch1)
+    t0 = time.time()
+    for _ in range(8):
+        st1.step(*batch1)
+    d1 = (time.time() - t0) / 8
+    out["c1_64x64_bs4"] = {"value": round(4 / d1, 3), "unit": "images/sec", "s_per_step": round(d1, 4), "steps": 8}
+    return out
+
+
+def _rccl_version():
+    try:
+        return ".".join(str(v) for v in torch.cuda.nccl.version())
+    except Exception:          # noqa: BLE001 -- informational field only
+        return None
 
 
 def bench_infer(args):
@@ -217,6 +236,10 @@ def main():
         t = torch.tensor([dt], device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    if world > 1:          # every rank reports the device it drove (rank 0 prints them)
+        mine = [rank, torch.cuda.current_device()]
+        gathered = [None] * world
+        dist.all_gather_object(gathered, mine)
     losses = model.losses()
     ms = dt / args.steps * 1e3
     ips = world * B * args.steps / dt
@@ -231,13 +254,23 @@ def main():
         "config": {"workload": (f"texture-stage G+D optimize_parameters step, {S}x{S}, bs {B}/GPU, fp32, 12 ROIs/img, "
                                 f"L1 + VGG16 content + style losses, TextureModule 54.5M + PatchGAN 2.8M params, AdamW"
                                 if texture else
-                                f"warp-stage G+D optimize_parameters step, {S}x{S}, bs {B}/GPU, fp32, "
-                                f"train mode (dropout 0.5), WarpModule 137.6M + PatchGAN 2.8M params, AdamW"),
+                                f"warp-stage G+D optimize_parameters step, {S}x{S}, bs {B}/GPU, fp32 storage and "
+                                f"accumulation" + (", GEMM products via an exact 3 x bf16 split of both operands (6 of 9 terms, the "
+                                                   "dropped ones below 2^-24) on the bf16 MFMA pipe" if SPLIT else
+                                                   ", GEMM products on v_mfma_f32_32x32x2_f32") +
+                                f", train mode (dropout 0.5), WarpModule 137.6M + PatchGAN 2.8M params, AdamW"),
                    "global_batch": world * B, "parallelism": f"dp{world}" + (" (1-rank RCCL exchange exercised)" if rccl1 else "")},
         "losses_finite": all(v == v and abs(v) < 1e30 for v in losses.values()),
+        # proof of the launch shape for the driver's scaling table: ranks, the device each rank drives, the collective library
+        "world": world,
+        "ranks": ([{"rank": rank, "device": torch.cuda.current_device(), "name": torch.cuda.get_device_name()}] if world == 1 else None),
+        "rccl_version": _rccl_version(),
+        "dist_backend": (dist.get_backend() if dist.is_initialized() else None),
         "hbm_allocated_gb": round(ctx.bytes_allocated() / 1e9, 2),      # arenas + activations (+ 2 x 1 GB split workspaces)
     }
 
+    if world > 1:
+        out["ranks"] = [{"rank": r, "device": d} for r, d in gathered]
     if rank == 0 and not args.no_roofline:
         # HIP events around every implicit-GEMM launch, on the stream they are launched on.  The timed region
         # above runs weight-gradient work on the library's second stream, where a kernel's wall time includes
@@ -274,21 +307,29 @@ def main():
                        "conv_fwd_256x128_fast": "conv_fwd_kernel<2, 2, 4, 2, true>",
                        "conv_fwd_dma_128x128": "conv_fwd_dma_kernel<2, 2, %s>" % sp, "conv_fwd_dma_256x64": "conv_fwd_dma_kernel<4, 1, %s>" % sp,
                        "conv_fwd_dma_128x256": "conv_fwd_dma_kernel<2, 4, %s>" % sp,
+                       "conv_fwd_pc_128x128": "conv_fwd_pc_kernel<4, 4, 2, 4>", "conv_fwd_pc_256x64": "conv_fwd_pc_kernel<8, 2, 3, 2>",
                        "conv_wgrad_dma_128x128": "conv_wgrad_dma_kernel<2, 2, %s>" % sp,
                        "conv_wgrad_dma_256x64": "conv_wgrad_dma_kernel<4, 1, %s>" % sp}.get(dom.split("[")[0], dom)
-            for tname in ("traffic_r02b.json", "traffic_r02.json", "traffic_r01.json"):
+            step_hbm = None
+            for tname in ("traffic_r03.json", "traffic_r02b.json", "traffic_r02.json", "traffic_r01.json"):
                 tpath = os.path.join(REPO, "profiles", tname)
                 if os.path.exists(tpath):
                     # HBM bytes per launch from the committed rocprofv3 PMC passes of this same command
                     # (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE; see profiles/README.md)
-                    t = json.load(open(tpath))["kernels"].get(rp_name)
+                    tk = json.load(open(tpath))["kernels"]
+                    t = tk.get(rp_name)
                     if t:
                         traffic = t["fetch_bytes_per_launch"] + t["write_bytes_per_launch"]
                         traffic_src = "profiles/" + tname + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command; not collected in this run)"
+                        # whole step: the pass profiles ONE step from process start, so allocation-time work (zero fills, the
+                        # initial weight packing, the NCHW -> NHWC upload of the resident batch) is in the file; excluded here
+                        setup = ("__amd_rocclr_fillBufferAligned", "__amd_rocclr_copyBuffer", "pack_kernel", "nchw_to_nhwc_kernel")
+                        step_hbm = sum((v["fetch_bytes_per_launch"] + v["write_bytes_per_launch"]) * v["launches"]
+                                       for kname, v in tk.items() if kname not in setup)
                         break
             exec_flops_step = sum(v["flops"] for v in kernels.values()) / nprof
             dense_flops_step = flop_per_img * B
-            is_split = SPLIT and "_dma_" in dom
+            is_split = SPLIT and ("_dma_" in dom or "_pc_" in dom)
             peak = PEAK_SPLIT_TFLOPS if is_split else PEAK_FP32_MFMA_TFLOPS
             out["roofline"] = {
                 "bound": "mfma", "kernel": dom, "measured": "HIP events, in-order pass (second stream off)", "achieved": round(ach, 2), "peak": peak,
@@ -297,6 +338,10 @@ def main():
                                     "bf16 / 6 bf16 MFMA products per fp32 product (exact 3-way split, fp32 accumulate)" if is_split else
                                     "v_mfma_f32_32x32x2_f32 dense peak"),
                 "fp32_mfma_peak": PEAK_FP32_MFMA_TFLOPS, "frac_of_fp32_mfma_peak": round(ach / PEAK_FP32_MFMA_TFLOPS, 4),
+                # HBM side of the same step: bytes of the PMC passes (same source as `traffic`) over this run's step time, against
+                # the 6.3 TB/s the guide measures as achievable (8 TB/s spec)
+                "step_hbm_bytes": step_hbm,
+                "step_hbm_frac": (round(step_hbm / (ms * 1e-3) / 6.3e12, 4) if step_hbm else None),
                 "avg_launch_ms": round(k["ms"] / k["launches"], 4), "launches_per_step": k["launches"] // nprof,
                 "step_frac_executed": round(exec_flops_step / (ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
                 "executed_tflop_per_step": round(exec_flops_step / 1e12, 3),

@@ -664,6 +664,278 @@ __global__ __launch_bounds__(256) void conv_dma_reduce_kernel(GemmP p, DmaSched 
   }
 }
 
+
+// ---------------------------------------------------------------------------------------
+// forward-type kernel on the LDS-DMA ring with the weight operand PRE-CUT (round 3).  conv_fwd_dma_kernel<SPLIT> spends
+// 176 of its ~290 instructions per wave and 16-k stage cutting fragments, and half of that on the WEIGHT fragment: the same
+// bf16 pieces of the same weights, recomputed by every workgroup of every launch.  Here whoever produces the weight operand
+// (conv_precut after an optimizer step / a re-pack) hands it over as three bf16 planes already in MFMA operand order, and
+// the waves are laid out WGM x 1: each wave owns 32 rows x ALL BN columns of the tile, so ONE activation-fragment cut (44
+// VALU) feeds 6 NB MFMAs, the B fragments are plain ds_read_b128 (no VALU), and a wave only ever reads the A rows it
+// fetched itself.  ~115 instructions per wave-stage instead of ~290 (tools/ring_lab.hip, same box, fp32-equivalent TFLOP/s:
+// Winograd planes 157 -> 179, 8192x512x4096 133 -> 169, 131072x128x1024 163 -> 190, 131072x64x1536 (256 x 64 tile) 96 -> 139).
+// Pre-cut layout (conv_precut): Wp[stage = k / 16][tile_n][kq 2][plane 3][pos BN][8 k] bf16, pos = (n % NB) * 32 + n / NB
+// inside a BN-column tile: the lane at position l31 of column block j holds column NB * l31 + j, i.e. NB adjacent columns
+// over its NB accumulators -> 16-byte epilogue stores.  One (stage, tile_n) block is 12 * BN / 128 contiguous KiB = the
+// LDS image of the stage, fetched by plain consecutive 1-KiB LDS-DMA pieces.
+// Everything else (gather through out-of-range zero fill, XOR-swizzled A rows, hybrid split-K schedule, epilogue) is
+// conv_fwd_dma_kernel's.
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ void lds_dma16c(unsigned voff, i32x4 rsrc, unsigned soff, unsigned lds_dst) {
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %3 offen lds"
+               : : "v"(voff), "s"(rsrc), "s"(lds_dst), "s"(soff) : "memory", "m0");
+}
+
+template <int WGM, int NB, int NSTG>
+struct PcTile {
+  static constexpr int NW = WGM, BM = 32 * WGM, BN = 32 * NB, BK = 16, NST = NSTG;
+  static constexpr int A_BYTES = BM * BK * 4, B_BYTES = 2 * 3 * BN * 16, ST_BYTES = A_BYTES + B_BYTES;
+  static constexpr int APC = A_BYTES / 1024, BPC = B_BYTES / 1024;
+  static constexpr int AI = APC / WGM, BI = BPC / WGM, BREM = BPC % WGM;   // pieces per wave; waves < BREM carry one more of B
+  static constexpr int SMEM = NST * ST_BYTES;
+  static_assert(APC % WGM == 0, "tile shape");
+};
+
+// WGCU = workgroups per CU the tile is sized for (LDS) -> waves per SIMD the register allocation must allow
+template <int WGM, int NB, int NSTG, int WGCU>
+__global__ __launch_bounds__(64 * WGM, WGCU * WGM / 4) void conv_fwd_pc_kernel(GemmP p, DmaSched sc, const unsigned short* wpc, size_t wpc_bs) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  using T = PcTile<WGM, NB, NSTG>;
+  constexpr int BM = T::BM, BN = T::BN, BK = T::BK, NST = T::NST, AI = T::AI, BI = T::BI, BREM = T::BREM;
+  extern __shared__ __attribute__((aligned(16))) char smem_c[];
+  const int t = threadIdx.x, lane = t & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(t >> 6);
+
+  // ---- work unit -> (tile, K range)
+  int u = blockIdx.x, gtile, split = 0, nsplit = 1, tt = 0;
+  if (u < sc.full) {
+    gtile = xcd_swizzle(u, sc.full);
+  } else {
+    u -= sc.full;
+    tt = u / sc.tail_s; split = u - tt * sc.tail_s; nsplit = sc.tail_s;
+    gtile = sc.full + tt;
+  }
+  const int z = gtile / sc.tiles_per_z, tile = gtile - z * sc.tiles_per_z;
+  const int tile_n = tile % p.tiles_n, tile_m = tile / p.tiles_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  p.x += (size_t)z * p.x_bs; p.y += (size_t)z * p.y_bs;
+  wpc += (size_t)z * wpc_bs;
+  if (p.phases) { const int a = z >> 1, b = z & 1; p.pad_t -= a; p.pad_l -= b; p.yoff = a; p.xoff = b; }
+  const int nkb_all = p.K / BK;
+  const int kb_begin = nsplit > 1 ? split * sc.per_split : 0;
+  const int kb_end = nsplit > 1 ? min(nkb_all, kb_begin + sc.per_split) : nkb_all;
+
+  const unsigned x_bytes = (unsigned)((((size_t)p.xH * p.xW * (size_t)(p.M / (p.Ho * p.Wo)) - 1) * p.xcs + p.xC) * 4);
+  const unsigned b_stage = (unsigned)p.tiles_n * T::B_BYTES;        // bytes of one 16-k stage of the pre-cut panel
+  const i32x4 rsA = make_rsrc(p.x, x_bytes), rsB = make_rsrc(wpc, (unsigned)nkb_all * b_stage);
+  const unsigned lds0 = (unsigned)(size_t)(lds_ptr_t)smem_c;
+
+  // ---- loader state.  A: this lane owns AI rows of its OWN wave's 32 (row = 32 wid + 16 r + lane / 4) and one swizzled chunk.
+  int a_iy0[AI], a_ix0[AI], a_base[AI];
+  unsigned a_voff[AI];
+  const int HoWo = p.Ho * p.Wo;
+  const int He = p.xH << p.ups, We = p.xW << p.ups;
+#pragma unroll
+  for (int r = 0; r < AI; ++r) {
+    const int row = 16 * (wid * AI + r) + (lane >> 2);
+    const int m = m0 + row;
+    if (m < p.M) {
+      const int n = m / HoWo, rem = m - n * HoWo;
+      const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+      a_iy0[r] = oy * p.stride - p.pad_t;
+      a_ix0[r] = ox * p.stride - p.pad_l;
+      a_base[r] = n * p.xH * p.xW * p.xcs + 4 * ((lane & 3) ^ ((row >> 2) & 3));
+    } else {
+      a_iy0[r] = 0; a_ix0[r] = 0; a_base[r] = -1;
+    }
+  }
+  auto set_tap = [&](int tap) {
+    const int kh = tap / p.KW, kw = tap - kh * p.KW;
+#pragma unroll
+    for (int r = 0; r < AI; ++r) {
+      unsigned off = DMA_OOB;
+      if (a_base[r] >= 0) {
+        const int sy = src_coord(a_iy0[r] + kh, He, p.pad_mode, p.ups);
+        const int sx = src_coord(a_ix0[r] + kw, We, p.pad_mode, p.ups);
+        if (sy >= 0 && sx >= 0) off = (unsigned)(a_base[r] + (sy * p.xW + sx) * p.xcs) * 4u;
+      }
+      a_voff[r] = off;
+    }
+  };
+  int ld_tap = (kb_begin * BK) / p.xC, ld_ci = kb_begin * BK - ld_tap * p.xC;
+  set_tap(ld_tap);
+  const bool extra = BREM > 0 && wid < BREM;
+  const unsigned b_voff = (unsigned)lane * 16u;
+  const unsigned b_tile = (unsigned)tile_n * T::B_BYTES;
+  auto issue = [&](int st, int kb) {
+    const unsigned S = lds0 + (unsigned)(st * T::ST_BYTES), SB = S + T::A_BYTES;
+    const unsigned bsrc = (unsigned)kb * b_stage + b_tile;
+#pragma unroll
+    for (int r = 0; r < AI; ++r) lds_dma16c(a_voff[r], rsA, (unsigned)ld_ci * 4u, S + (unsigned)(wid * AI + r) * 1024u);
+#pragma unroll
+    for (int r = 0; r < BI; ++r) lds_dma16c(b_voff, rsB, bsrc + (unsigned)(wid * BI + r) * 1024u, SB + (unsigned)(wid * BI + r) * 1024u);
+    if (extra) lds_dma16c(b_voff, rsB, bsrc + (unsigned)(WGM * BI + wid) * 1024u, SB + (unsigned)(WGM * BI + wid) * 1024u);
+    ld_ci += BK;
+    if (ld_ci >= p.xC) { ld_ci = 0; ld_tap += 1; if (ld_tap < p.KH * p.KW) set_tap(ld_tap); }
+  };
+
+  f32x16 acc[NB];
+#pragma unroll
+  for (int j = 0; j < NB; ++j)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+
+  const int h = lane >> 5, l31 = lane & 31;
+  const int f = (l31 >> 2) & 3;
+  const int a_rd = (wid * 32 + l31) * 64;
+  const int a_c0 = ((2 * h) ^ f) * 16, a_c1 = ((2 * h + 1) ^ f) * 16;
+  const int b_rd = T::A_BYTES + (h * 3 * BN + l31) * 16;                   // + (plane * BN + 32 j) * 16
+  auto compute = [&](int st) {
+    const char* S = smem_c + st * T::ST_BYTES;
+    float af[8];
+    {
+      const float4 v0 = *reinterpret_cast<const float4*>(S + a_rd + a_c0);
+      const float4 v1 = *reinterpret_cast<const float4*>(S + a_rd + a_c1);
+      af[0] = v0.x; af[1] = v0.y; af[2] = v0.z; af[3] = v0.w; af[4] = v1.x; af[5] = v1.y; af[6] = v1.z; af[7] = v1.w;
+    }
+    u32x4 bh[NB], bm[NB], bl[NB];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      bh[j] = *reinterpret_cast<const u32x4*>(S + b_rd + (0 * BN + 32 * j) * 16);
+      bm[j] = *reinterpret_cast<const u32x4*>(S + b_rd + (1 * BN + 32 * j) * 16);
+      bl[j] = *reinterpret_cast<const u32x4*>(S + b_rd + (2 * BN + 32 * j) * 16);
+    }
+    u32x4 ah, am, al;
+    split8(af, ah, am, al);
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      f32x16 c = acc[j];
+      c = mma_bf16(al, bh[j], c); c = mma_bf16(ah, bl[j], c); c = mma_bf16(am, bm[j], c);        // smallest terms first
+      c = mma_bf16(am, bh[j], c); c = mma_bf16(ah, bm[j], c); c = mma_bf16(ah, bh[j], c);
+      acc[j] = c;
+    }
+  };
+
+  if (kb_begin < kb_end) {
+#pragma unroll
+    for (int s = 0; s < NST - 1; ++s)
+      if (kb_begin + s < kb_end) issue(s, kb_begin + s);
+    int st = 0;
+    for (int kb = kb_begin; kb < kb_end; ++kb) {
+      // this wave's share of stage kb has landed: only the (at most NST - 2) younger stages may still be in flight
+      const int younger = min(NST - 2, kb_end - 1 - kb);
+      if (extra) {
+        if (younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(2 * (AI + BI + 1)) : "memory");
+        else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(AI + BI + 1) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      } else {
+        if (younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(2 * (AI + BI)) : "memory");
+        else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(AI + BI) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      __builtin_amdgcn_s_barrier();          // everybody's share of B landed; everybody finished reading stage kb - 1
+      asm volatile("" ::: "memory");
+      int stn = st + NST - 1; if (stn >= NST) stn -= NST;
+      if (kb + NST - 1 < kb_end) issue(stn, kb + NST - 1);
+      compute(st);
+      st = st + 1 == NST ? 0 : st + 1;
+    }
+  }
+
+  // ---- epilogue.  lane: rows wid*32 + (e&3) + 8*(e>>2) + 4*h, columns n0 + NB*l31 + j
+  const int colr = NB * l31;
+  if (nsplit > 1) {
+    float* slab = p.slab + ((size_t)(tt * nsplit + split) * BM) * BN;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int row = wid * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+      float* dst = slab + (size_t)row * BN + colr;
+      if constexpr (NB == 4) *reinterpret_cast<float4*>(dst) = make_float4(acc[0][e], acc[1][e], acc[2][e], acc[3][e]);
+      else *reinterpret_cast<float2*>(dst) = make_float2(acc[0][e], acc[1][e]);
+    }
+    return;
+  }
+  __syncthreads();                                      // the ring is dead: reuse it for the per-row output offsets
+  int* rowoff = reinterpret_cast<int*>(smem_c);
+  if (t < BM) {
+    const int m = m0 + t;
+    int off = -1;
+    if (m < p.M) {
+      const int n = m / HoWo, rem = m - n * HoWo;
+      const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+      off = ((n * p.yH + oy * p.ymul + p.yoff) * p.yW + ox * p.xmul + p.xoff) * p.ycs;
+    }
+    rowoff[t] = off;
+  }
+  __syncthreads();
+  const int col = n0 + colr;
+  if (col < p.Cout) {
+    float bj[NB];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) bj[j] = (p.bias && col + j < p.Cout) ? p.bias[col + j] : 0.f;
+    const bool full = col + NB - 1 < p.Cout;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int off = rowoff[wid * 32 + (e & 3) + 8 * (e >> 2) + 4 * h];
+      if (off < 0) continue;
+      float v[NB];
+#pragma unroll
+      for (int j = 0; j < NB; ++j) v[j] = act_apply(acc[j][e] + bj[j], p.act);
+      float* dst = p.y + (size_t)off + col;
+      if (full) {
+        if constexpr (NB == 4) {
+          float4 o = make_float4(v[0], v[1], v[2], v[3]);
+          if (p.accumulate) { const float4 q = *reinterpret_cast<const float4*>(dst); o.x += q.x; o.y += q.y; o.z += q.z; o.w += q.w; }
+          *reinterpret_cast<float4*>(dst) = o;
+        } else {
+          float2 o = make_float2(v[0], v[1]);
+          if (p.accumulate) { const float2 q = *reinterpret_cast<const float2*>(dst); o.x += q.x; o.y += q.y; }
+          *reinterpret_cast<float2*>(dst) = o;
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < NB; ++j)
+          if (col + j < p.Cout) dst[j] = p.accumulate ? dst[j] + v[j] : v[j];
+      }
+    }
+  }
+#endif
+}
+
+// producer of the pre-cut operand: one thread per (k / 8, tile_n, pos) writes the three 16-byte plane entries
+__global__ __launch_bounds__(256) void conv_precut_kernel(const float* w, unsigned short* out, int K, int Npad, int BN, size_t w_bs,
+                                                          size_t out_bs) {
+  const int NBc = BN / 32;
+  const int tiles_n = (Npad + BN - 1) / BN;
+  const size_t total = (size_t)(K / 8) * tiles_n * BN;
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int pos = (int)(i % BN); const size_t q = i / BN;
+  const int tn = (int)(q % tiles_n), kq = (int)(q / tiles_n);
+  const int n = tn * BN + (pos % 32) * NBc + pos / 32;                 // pos = (nl % NB) * 32 + nl / NB
+  w += (size_t)blockIdx.y * w_bs; out += (size_t)blockIdx.y * out_bs;
+  unsigned hi[4], mid[4], lo[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    float x[2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) x[e] = n < Npad ? w[(size_t)(kq * 8 + 2 * j + e) * Npad + n] : 0.f;
+    const unsigned u0 = __float_as_uint(x[0]), u1 = __float_as_uint(x[1]);
+    const float r0 = x[0] - __uint_as_float(u0 & 0xffff0000u), r1 = x[1] - __uint_as_float(u1 & 0xffff0000u);
+    const unsigned v0 = __float_as_uint(r0), v1 = __float_as_uint(r1);
+    const float s0 = r0 - __uint_as_float(v0 & 0xffff0000u), s1 = r1 - __uint_as_float(v1 & 0xffff0000u);
+    hi[j] = (u0 >> 16) | (u1 & 0xffff0000u);
+    mid[j] = (v0 >> 16) | (v1 & 0xffff0000u);
+    lo[j] = (__float_as_uint(s0) >> 16) | (__float_as_uint(s1) & 0xffff0000u);
+  }
+  // [stage = kq / 2][tile_n][kq & 1][plane][pos][8 bf16]
+  const size_t base = ((((size_t)(kq >> 1) * tiles_n + tn) * 2 + (kq & 1)) * 3) * BN;
+  u32x4* o = reinterpret_cast<u32x4*>(out);
+  o[base + pos] = u32x4{hi[0], hi[1], hi[2], hi[3]};
+  o[base + (size_t)BN + pos] = u32x4{mid[0], mid[1], mid[2], mid[3]};
+  o[base + 2 * (size_t)BN + pos] = u32x4{lo[0], lo[1], lo[2], lo[3]};
+}
+
 // ---------------------------------------------------------------------------------------
 // narrow-N forward-type kernel (Cout <= 32: the 19-channel tail conv, PatchGAN's 1-channel
 // prediction conv, dgrads into few-channel inputs).  The 32-wide MFMA tile wastes 13/32 of
@@ -1937,6 +2209,60 @@ static bool dma_on() {
   static const bool on = !(getenv("SWN_DMA") && atoi(getenv("SWN_DMA")) == 0);
   return on;
 }
+
+// ---- pre-cut ring kernel: schedule + launch ------------------------------------------------------------------------
+static bool pc_on() {
+  const bool on = !(getenv("SWN_PRECUT") && atoi(getenv("SWN_PRECUT")) == 0);      // read per launch (tests / A-B runs)
+  return on;
+}
+template <int WGM, int NB, int NSTG, int WGCU>
+static void launch_fwd_pc(Stream& s, GemmP& p, int nb, const unsigned short* wpc, size_t wpc_bs) {
+  using T = PcTile<WGM, NB, NSTG>;
+  const int tiles_m = ceil_div(p.M, T::BM);
+  p.tiles_n = ceil_div(p.Npad, T::BN);
+  p.ntiles = tiles_m * p.tiles_n;
+  constexpr int wg = WGCU;
+  static_assert(wg * T::SMEM <= 160 * 1024, "tile does not fit a CU");
+  const DmaSched sc = plan_dma(p.ntiles * nb, p.ntiles, p.K / T::BK, 256 * wg, (size_t)T::BM * T::BN * 4, s.ws_bytes, nullptr,
+                               wg * T::NW / 12.0);
+  p.slab = reinterpret_cast<float*>(s.ws);
+  p.splits = sc.tail_s;
+  static bool once = (set_smem(conv_fwd_pc_kernel<WGM, NB, NSTG, WGCU>, T::SMEM), true);
+  (void)once;
+  char pname[112];
+  if (prof_detail())
+    snprintf(pname, sizeof pname, "conv_fwd_pc_%dx%d[M%d,N%d,K%d,b%d,full%d,tail%dx%d]", T::BM, T::BN, p.M, p.Cout, p.K, nb, sc.full,
+             sc.tail_tiles, sc.tail_s);
+  else
+    snprintf(pname, sizeof pname, "conv_fwd_pc_%dx%d", T::BM, T::BN);
+  ProfScope prof(s, pname, 2.0 * p.M * p.Cout * p.K * nb);
+  const int units = sc.full + sc.tail_tiles * sc.tail_s;
+  hipLaunchKernelGGL((conv_fwd_pc_kernel<WGM, NB, NSTG, WGCU>), dim3(units), dim3(64 * T::NW), T::SMEM, hs(s), p, sc, wpc, wpc_bs);
+  check_launch("conv_fwd_pc");
+  if (sc.tail_tiles > 0 && sc.tail_s > 1) {
+    hipLaunchKernelGGL((conv_dma_reduce_kernel<T::BM, T::BN>), dim3(T::BM * T::BN / 4 / 256, sc.tail_tiles), dim3(256), 0, hs(s), p, sc);
+    check_launch("conv_dma_reduce");
+  }
+}
+
+// ops.h: which column tile a forward-type launch over an input with xC channels into Npad columns wants its weight operand
+// pre-cut for (0 = the launch does not take the pre-cut ring kernel: no operand needs to be produced)
+int conv_precut_tile(int xC, int Npad) {
+  static const bool off = getenv("SWN_PRECUT") && atoi(getenv("SWN_PRECUT")) == 0;
+  if (off || !dma_on() || !split_on() || xC % 16 || Npad <= 32) return 0;
+  return Npad > 64 ? 128 : 64;
+}
+size_t conv_precut_elems(int K, int Npad, int bn) {
+  return (size_t)(K / 16) * ceil_div(Npad, bn) * 6 * bn * 8;
+}
+void conv_precut(Stream& s, const float* w, int K, int Npad, int bn, int batch, size_t w_bs, uint16_t* out) {
+  if (K % 16 || (bn != 64 && bn != 128)) throw Error(1, "conv_precut: K must be a multiple of 16, tile 64 or 128");
+  const size_t total = (size_t)(K / 8) * ceil_div(Npad, bn) * bn;
+  hipLaunchKernelGGL(conv_precut_kernel, dim3((unsigned)((total + 255) / 256), batch), dim3(256), 0, hs(s), w, out, K, Npad, bn, w_bs,
+                     conv_precut_elems(K, Npad, bn));
+  check_launch("conv_precut");
+}
+
 // the LDS-DMA kernel addresses activations through 32-bit buffer offsets and marks padding with offsets >= 2^31
 static bool dma_ok(const ConvFwdArgs& a, const GemmP& p) {
   if (!dma_on() || a.x.C % 16 || a.Npad <= 32) return false;
@@ -2008,6 +2334,13 @@ void conv_fwd(Stream& s, const ConvFwdArgs& a) {
   // N in (128, 192] (the tail conv's input gradient into the 192-channel concat): a 128x192 tile instead
   // of two 128-wide column tiles of which the second is half empty
   if (dma_ok(a, p)) {
+    // weight operand handed over pre-cut (conv_precut) for this launch's column tile: the round-3 kernel
+    if (a.wpc && pc_on() && split_on() && a.wpc_bn == (a.Npad > 64 ? 128 : 64) &&
+        (size_t)(p.K / 16) * ceil_div(a.Npad, a.wpc_bn) * 12 * a.wpc_bn * 8 < ((size_t)1 << 31)) {
+      if (a.Npad > 64) launch_fwd_pc<4, 4, 2, 4>(s, p, nb, a.wpc, a.wpc_bs);       // 128 x 128, 2 stages, 4 workgroups / CU
+      else launch_fwd_pc<8, 2, 3, 2>(s, p, nb, a.wpc, a.wpc_bs);                   // 256 x 64, 3 stages, 2 workgroups / CU
+      return;
+    }
     if (a.Npad > 64) {
       // 128 x 128 (4 waves, 3 workgroups / CU) unless the 128 x 256 tile (8 waves, 2 / CU: 512 slots instead of 768)
       // quantises the launch better: the resblock input gradient (M 800, N 1024 x 36 planes) is 2016 tiles = 2.6

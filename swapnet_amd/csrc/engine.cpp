@@ -211,7 +211,7 @@ void Net::conv(const std::string& name, const Var& x, const Var& y, ConvKind kin
       head_pack(n.ctx.s, wd.ws, A->w + wd.off, n.dg + wt_off, n.dg + wt2_off);
     };
     op->fwd = [=](Net& n) {
-      n.refresh_dgrad();
+      n.need(self);
       ConvFwdArgs a;
       a.x = xv; a.g.Ho = xv.H; a.g.Wo = xv.W;               // 1x1, stride 1
       a.w = n.dg + wt_off; a.Npad = 16; a.Cout = 16; a.y = zv;
@@ -286,14 +286,19 @@ void Net::conv(const std::string& name, const Var& x, const Var& y, ConvKind kin
   auto plane_view = [](float* p, size_t T, int C) {
     TView v; v.p = p; v.N = 1; v.H = 1; v.W = (int)T; v.C = C; v.cs = C; return v;   // T x C matrix
   };
+  // weight panel pre-cut for the ring kernel (ops.h conv_precut): plain forward convs multiply by the arena weights themselves
+  const int Kf = KH * KH * Cip;
+  const int pc_f = (!wino && !folded) ? conv_precut_tile(Cip, arena.params[wi].ws.Npad) : 0;
+  const size_t pcf_off = pc_f ? reserve_dgp(conv_precut_elems(Kf, arena.params[wi].ws.Npad, pc_f)) : 0;
   op->fwd = [=](Net& n) {
     const ParamDesc& wd = A->params[wi];
     ConvFwdArgs a;
     a.x = xv; a.g = gf; a.w = A->w + wd.off; a.Npad = wd.ws.Npad;
+    if (pc_f) { n.need(self); a.wpc = n.dgp + pcf_off; a.wpc_bn = pc_f; }
     a.bias = bi >= 0 ? A->w + A->params[bi].off : nullptr;
     a.act = actf; a.y = yv; a.Cout = Co;
     if (wino) {
-      n.refresh_dgrad();
+      n.need(self);
       float* V = keepV ? keepV : n.wsV;
       wino_input_transform(n.ctx.s, wm, wr, xv, 1, gf.pad_mode, wTh, wTw, V);
       ConvFwdArgs g;
@@ -306,7 +311,7 @@ void Net::conv(const std::string& name, const Var& x, const Var& y, ConvKind kin
       return;
     }
     if (!folded) { conv_fwd(n.ctx.s, a); return; }
-    n.refresh_dgrad();                       // folded weights are derived operands too
+    n.need(self);                            // folded weights are derived operands too
     a.g = Gather(); a.g.KH = a.g.KW = 3; a.g.stride = 1; a.g.pad_t = a.g.pad_l = 1; a.g.Ho = xv.H; a.g.Wo = xv.W;
     a.om.ymul = a.om.xmul = 2; a.tail4 = 1;
     a.w = n.dg + fold_off;
@@ -330,18 +335,27 @@ void Net::conv(const std::string& name, const Var& x, const Var& y, ConvKind kin
   }
   gd.Ho = dHo; gd.Wo = dWo;
   const bool want_dx = x.has_grad && y.has_grad;
-  size_t dg_off = 0;
+  size_t dg_off = 0, pcd_off = 0;
+  int pc_d = 0, dpanels = 1, dKp = 0;
   const int Ndg = Cip;   // dgrad output channels = input buffer channels
   if (want_dx) {
     if (wino) ub_off = reserve_dg(self, (size_t)wP * Cop * Cip);
     else dg_off = reserve_dg(self, dgrad_elems(arena.params[wi].ws, dg_mode, Cop, Ndg));
     if (kind == CK_K3S1_REFLECT && !wino) dxpad = alloc_var(x.v.N, dHo, dWo, Cip, false);
     op->grad_targets.push_back(x);
-    if (!wino)
+    if (!wino) {
+      // K4S2: four phase panels of 2x2 taps; stride-1: one panel of KH x KW taps over dY (Cop channels)
+      dpanels = kind == CK_K4S2 ? 4 : 1;
+      dKp = (kind == CK_K4S2 ? 4 : gd.KH * gd.KW) * Cop;
+      pc_d = conv_precut_tile(Cop, Ndg);
+      if (pc_d) pcd_off = reserve_dgp(conv_precut_elems(dKp, Ndg, pc_d) * dpanels);
+      const int pcd = pc_d, dK = dKp, dP = dpanels; const size_t pcdo = pcd_off;
       op->repack = [=](Net& n) {
         const ParamDesc& wd = A->params[wi];
         repack_dgrad(n.ctx.s, wd.ws, dg_mode, Cop, Ndg, A->w + wd.off, n.dg + dg_off);
+        if (pcd) conv_precut(n.ctx.s, n.dg + dg_off, dK, Ndg, pcd, dP, (size_t)dK * Ndg, n.dgp + pcdo);
       };
+    }
   }
   if (wino) {
     const bool wdx = want_dx;
@@ -359,6 +373,15 @@ void Net::conv(const std::string& name, const Var& x, const Var& y, ConvKind kin
       tail_fold_weights(n.ctx.s, wd.ws, A->w + wd.off, n.dg + fold_off);
     };
   }
+  if (pc_f) {
+    auto prev = op->repack;
+    op->repack = [=](Net& n) {
+      const ParamDesc& wd = A->params[wi];
+      conv_precut(n.ctx.s, A->w + wd.off, Kf, wd.ws.Npad, pc_f, 1, 0, n.dgp + pcf_off);     // forward operand first
+      if (prev) prev(n);
+    };
+  }
+  const int pcd_k = pc_d; const size_t pcd_o = pcd_off, pcd_bs = pc_d ? conv_precut_elems(dKp, Ndg, pc_d) : 0;
   const TView ygv = y.g, xgv = x.g, scr = scratch.v, dxp = dxpad.v;
   const bool has_ygrad = y.has_grad;
   op->bwd = [=](Net& n, Op& me, bool wgrad, bool igrad) {
@@ -416,10 +439,12 @@ void Net::conv(const std::string& name, const Var& x, const Var& y, ConvKind kin
       d.g.Ho = dY.H; d.g.Wo = dY.W;
       d.w = n.dg + dg_off; d.w_bs = (size_t)4 * Cop * Ndg; d.Npad = Ndg;
       d.y = xgv; d.om.ymul = 2; d.om.xmul = 2; d.phases = 4; d.Cout = Ndg; d.accumulate = accf;
+      if (pcd_k) { d.wpc = n.dgp + pcd_o; d.wpc_bn = pcd_k; d.wpc_bs = pcd_bs; }
       conv_fwd(n.ctx.s, d);
     } else {
       ConvFwdArgs d;
       d.x = dY; d.g = gd; d.w = n.dg + dg_off; d.Npad = Ndg; d.Cout = Ndg;
+      if (pcd_k) { d.wpc = n.dgp + pcd_o; d.wpc_bn = pcd_k; d.wpc_bs = pcd_bs; }
       if (kind == CK_K3S1_REFLECT) {
         d.y = dxp; d.accumulate = 0;
         conv_fwd(n.ctx.s, d);
@@ -447,9 +472,14 @@ void Net::convT(const std::string& name, const Var& x, const Var& y, int Co, boo
   ParamArena* A = &arena;
   const TView xv = x.v, yv = y.v, ygv = y.g, xgv = x.g;
   const size_t phase_elems = (size_t)4 * Cip * round_up(Co, 4);
+  // pre-cut panels for the ring kernel: the four forward phase panels (arena layout) and the k4 s2 input-gradient operand
+  const int pc_f = conv_precut_tile(Cip, Cop);
+  const size_t pcf_bs = pc_f ? conv_precut_elems(4 * Cip, Cop, pc_f) : 0;
+  const size_t pcf_off = pc_f ? reserve_dgp(pcf_bs * 4) : 0;
   op->fwd = [=](Net& n) {
     const ParamDesc& wd = A->params[wi];
     ConvFwdArgs f;                          // 4 sub-pixel phases (2x2 taps each), one launch
+    if (pc_f) { n.need(self); f.wpc = n.dgp + pcf_off; f.wpc_bn = pc_f; f.wpc_bs = pcf_bs; }
     f.x = xv; f.g.KH = f.g.KW = 2; f.g.stride = 1; f.g.pad_t = 1; f.g.pad_l = 1; f.g.Ho = xv.H; f.g.Wo = xv.W;
     f.w = A->w + wd.off; f.w_bs = phase_elems; f.Npad = wd.ws.Npad;
     f.bias = bi >= 0 ? A->w + A->params[bi].off : nullptr;
@@ -457,15 +487,22 @@ void Net::convT(const std::string& name, const Var& x, const Var& y, int Co, boo
     conv_fwd(n.ctx.s, f);
   };
   const bool want_dx = x.has_grad && y.has_grad;
-  size_t dg_off = 0;
+  size_t dg_off = 0, pcd_off = 0;
+  const int pc_d = want_dx ? conv_precut_tile(Cop, Cip) : 0;
   if (want_dx) {
     dg_off = reserve_dg(self, dgrad_elems(arena.params[wi].ws, 2, Cop, Cip));
+    if (pc_d) pcd_off = reserve_dgp(conv_precut_elems(16 * Cop, Cip, pc_d));
     op->grad_targets.push_back(x);
+  }
+  if (want_dx || pc_f)
     op->repack = [=](Net& n) {
       const ParamDesc& wd = A->params[wi];
-      repack_dgrad(n.ctx.s, wd.ws, 2, Cop, Cip, A->w + wd.off, n.dg + dg_off);
+      if (pc_f) conv_precut(n.ctx.s, A->w + wd.off, 4 * Cip, Cop, pc_f, 4, phase_elems, n.dgp + pcf_off);
+      if (want_dx) {
+        repack_dgrad(n.ctx.s, wd.ws, 2, Cop, Cip, A->w + wd.off, n.dg + dg_off);
+        if (pc_d) conv_precut(n.ctx.s, n.dg + dg_off, 16 * Cop, Cip, pc_d, 1, 0, n.dgp + pcd_off);
+      }
     };
-  }
   const bool has_ygrad = y.has_grad;
   op->bwd = [=](Net& n, Op& me, bool wgrad, bool igrad) {
     if (!has_ygrad) return;
@@ -484,6 +521,7 @@ void Net::convT(const std::string& name, const Var& x, const Var& y, int Co, boo
     ConvFwdArgs d;
     d.x = ygv; d.g.KH = d.g.KW = 4; d.g.stride = 2; d.g.pad_t = d.g.pad_l = 1; d.g.Ho = xv.H; d.g.Wo = xv.W;
     d.w = n.dg + dg_off; d.Npad = Cip; d.Cout = Cip; d.y = xgv; d.accumulate = me.acc.empty() ? 0 : me.acc[0];
+    if (pc_d) { d.wpc = n.dgp + pcd_off; d.wpc_bn = pc_d; }
     conv_fwd(n.ctx.s, d);
   };
   ops.push_back(std::move(op));
@@ -622,6 +660,7 @@ void Net::finalize(const std::vector<Var>& pre) {
     }
   }
   dg = dg_n ? static_cast<float*>(ctx.alloc(dg_n * sizeof(float))) : nullptr;
+  dgp = dgp_n ? static_cast<uint16_t*>(ctx.alloc(dgp_n * sizeof(uint16_t))) : nullptr;
   if (wsM_need && ctx.has_side && keep_wino_inputs) wsM2 = static_cast<float*>(ctx.alloc(wsM_need * sizeof(float)));
   if (wsV_need) wsV = static_cast<float*>(ctx.alloc(wsV_need * sizeof(float)));
   if (wsM_need) wsM = static_cast<float*>(ctx.alloc(wsM_need * sizeof(float)));
@@ -649,7 +688,12 @@ void Net::prefetch_dgrad() {
   std::swap(ctx.s, ctx.side);      // the re-pack launchers use ctx.s
   try {
     for (auto& op : ops)
-      if (op->repack) op->repack(*this);
+      if (op->repack) {
+        op->repack(*this);
+        if (!op->ready) op->ready = event_create();
+        event_record(op->ready, ctx.s);        // (ctx.s is the side stream here)
+        op->ready_pending = true;
+      }
   } catch (...) { std::swap(ctx.s, ctx.side); throw; }
   std::swap(ctx.s, ctx.side);
   if (!refresh_event) refresh_event = event_create();
@@ -657,10 +701,19 @@ void Net::prefetch_dgrad() {
   refresh_pending = true;
   dg_version = arena.version;
 }
+void Net::need(Op* op) {
+  if (refresh_pending && op->ready_pending) {
+    stream_wait_event(ctx.s, op->ready);
+    op->ready_pending = false;
+    return;
+  }
+  if (!refresh_pending) refresh_dgrad();
+}
 void Net::refresh_dgrad() {
   if (refresh_pending) {
     stream_wait_event(ctx.s, refresh_event);
     refresh_pending = false;
+    for (auto& op : ops) op->ready_pending = false;
   }
   if (dg_version == arena.version) return;
   for (auto& op : ops)

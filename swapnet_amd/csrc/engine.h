@@ -101,13 +101,20 @@ struct Op {
   std::vector<int> acc;            // planned: 0 overwrite / 1 accumulate
   bool reads_net_input = false;
   size_t param_off = (size_t)-1;   // arena offset of this op's weight (ops without parameters: -1)
-  std::function<void(Net&)> repack;   // refresh the dgrad operand from the arena
+  std::function<void(Net&)> repack;   // refresh the derived operands (dgrad re-packs, Winograd filters, pre-cut panels) from the arena
+  // with a side stream the refresh of all ops is started there at the top of forward(); `ready` is recorded behind this op's
+  // share, so the op waits for its own operands only (Net::need)
+  void* ready = nullptr;
+  bool ready_pending = false;
 };
 
 class Net {
  public:
   Net(Ctx& c, ParamArena& a) : ctx(c), arena(a) {}
-  ~Net() { if (refresh_event) event_destroy(refresh_event); }
+  ~Net() {
+    if (refresh_event) event_destroy(refresh_event);
+    for (auto& op : ops) if (op->ready) event_destroy(op->ready);
+  }
   Ctx& ctx;
   ParamArena& arena;
   std::vector<std::unique_ptr<Op>> ops;
@@ -116,6 +123,11 @@ class Net {
   uint64_t seed = 0;
   float* dg = nullptr;      // dgrad operands of this net's convs
   size_t dg_n = 0;
+  // weight operands pre-cut into bf16 planes for the round-3 ring kernel (ops.h conv_precut): forward and input-gradient
+  // panels of every conv whose launches take it
+  uint16_t* dgp = nullptr;
+  size_t dgp_n = 0;
+  size_t reserve_dgp(size_t elems) { const size_t off = dgp_n; dgp_n += (elems + 7) / 8 * 8; return off; }
   int dg_version = 0;       // arena.version the operands were derived from
   // set by the model for nets whose weight gradients are taken (G, the 2B discriminator instance): the
   // Winograd-transformed input of every such conv is kept from forward for its weight gradient
@@ -163,6 +175,7 @@ class Net {
   // first op whose parameters start at or after `frac` of the arena (ops are registered in arena order)
   int split_point(double frac, size_t* arena_off) const;
   void refresh_dgrad();     // no-op when the operands are current (waits for a prefetch in flight)
+  void need(Op* op);        // forward ops: wait for THIS op's share of a prefetch in flight (else refresh_dgrad())
   // with a side stream: start the refresh there (forward() calls it, so the HBM-bound re-packs /
   // filter transforms overlap the first layers); refresh_dgrad() is the wait point
   void prefetch_dgrad();

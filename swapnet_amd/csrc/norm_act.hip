@@ -277,14 +277,19 @@ __global__ __launch_bounds__(256) void in_fused_fwd_kernel(NAp p) {
   const int n = blockIdx.y, c = blockIdx.x * CG + tx * 4;
   float4 v[NP];
   double s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  // all loads first, unconditionally (rows past the map re-read its last pixel and are masked below): inside `if (pix < HW)`
+  // every load sits in its own basic block and the NP round trips to HBM serialise
 #pragma unroll
   for (int i = 0; i < NP; ++i) {
-    const int pix = ty + i * ROWS;
-    if (pix < p.HW) {
-      v[i] = *reinterpret_cast<const float4*>(p.x + ((size_t)n * p.HW + pix) * p.xcs + c);
-      s[0] += v[i].x; s[1] += v[i].y; s[2] += v[i].z; s[3] += v[i].w;
-      s[4] += (double)v[i].x * v[i].x; s[5] += (double)v[i].y * v[i].y; s[6] += (double)v[i].z * v[i].z; s[7] += (double)v[i].w * v[i].w;
-    }
+    const int pix = min(ty + i * ROWS, p.HW - 1);
+    v[i] = *reinterpret_cast<const float4*>(p.x + ((size_t)n * p.HW + pix) * p.xcs + c);
+  }
+#pragma unroll
+  for (int i = 0; i < NP; ++i) {
+    const float k = ty + i * ROWS < p.HW ? 1.f : 0.f;
+    const float a0 = v[i].x * k, a1 = v[i].y * k, a2 = v[i].z * k, a3 = v[i].w * k;
+    s[0] += a0; s[1] += a1; s[2] += a2; s[3] += a3;
+    s[4] += (double)a0 * a0; s[5] += (double)a1 * a1; s[6] += (double)a2 * a2; s[7] += (double)a3 * a3;
   }
   block_tree_sum<ROWS, 8>(red, s, tx, ty, C4);
   float mean[4], rstd[4];
@@ -334,12 +339,17 @@ __global__ __launch_bounds__(256) void in_fused_bwd_kernel(NAp p) {
   float4 xv[NP], gv[NP];
   double s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
+  for (int i = 0; i < NP; ++i) {          // all loads first, unconditionally (see the forward kernel)
+    const size_t e = (size_t)n * p.HW + min(ty + i * ROWS, p.HW - 1);
+    xv[i] = *reinterpret_cast<const float4*>(p.x + e * p.xcs + c);
+    gv[i] = *reinterpret_cast<const float4*>(p.dy + e * p.dycs + c);
+  }
+#pragma unroll
   for (int i = 0; i < NP; ++i) {
     const int pix = ty + i * ROWS;
     if (pix < p.HW) {
       const size_t e = (size_t)n * p.HW + pix;
-      xv[i] = *reinterpret_cast<const float4*>(p.x + e * p.xcs + c);
-      const float4 d = *reinterpret_cast<const float4*>(p.dy + e * p.dycs + c);
+      const float4 d = gv[i];
       const float xa[4] = {xv[i].x, xv[i].y, xv[i].z, xv[i].w};
       float g[4] = {d.x, d.y, d.z, d.w};
 #pragma unroll

@@ -78,8 +78,20 @@ struct ConvFwdArgs {
   // union gather (KH = KW = 3, stride 1, pad 1 on the un-upsampled input), om.ymul = om.xmul = 2; phase
   // (a,b) uses taps u < 2+a, v < 2+b and writes outputs (2oy + a, 2ox + b).
   int tail4 = 0;
+  // optional: the weight operand pre-cut into bf16 planes (conv_precut below) for the column tile `wpc_bn`; `w` stays valid
+  // (the launch falls back to it when it does not take the pre-cut kernel).  wpc_bs = elements between batch / phase panels.
+  const uint16_t* wpc = nullptr;
+  int wpc_bn = 0;
+  size_t wpc_bs = 0;
 };
 void conv_fwd(Stream& s, const ConvFwdArgs& a);
+// Pre-cut weight operand of the LDS-DMA ring kernel (conv_gemm.hip conv_fwd_pc_kernel): x = hi + mid + lo, three bf16 planes by
+// truncation (exact), laid out in MFMA operand order per 16-k stage and column tile.  conv_precut_tile: the column tile (64 /
+// 128) a forward-type launch over xC input channels into Npad columns takes, 0 = it would not use a pre-cut operand (host
+// simulator, narrow / first-layer launches, SWN_PRECUT=0): callers then need not produce one.
+int conv_precut_tile(int xC, int Npad);
+size_t conv_precut_elems(int K, int Npad, int bn);       // uint16 elements of one [K][Npad] panel
+void conv_precut(Stream& s, const float* w, int K, int Npad, int bn, int batch, size_t w_bs, uint16_t* out);
 
 // dw[k][co] = sum_m A[m][k] * dy[map(m)][co]      (dw: [K][Npad], overwritten)
 struct ConvWgradArgs {

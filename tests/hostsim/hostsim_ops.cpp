@@ -139,6 +139,9 @@ void conv_fwd(Stream& s, const ConvFwdArgs& a) {
   }
 }
 void conv_fwd_naive(Stream& s, const ConvFwdArgs& a) { conv_fwd(s, a); }
+int conv_precut_tile(int, int) { return 0; }             // the simulator multiplies in plain fp32 / fp64: no pre-cut operands
+size_t conv_precut_elems(int, int, int) { return 0; }
+void conv_precut(Stream&, const float*, int, int, int, int, size_t, uint16_t*) {}
 
 static void conv_wgrad_one(const ConvWgradArgs& a) {
   const TView& X = a.x; const Gather& g = a.g;
