@@ -89,7 +89,7 @@ typedef struct swn_hyper {
   int warp_mode_ce;  /* 1 = --warp_mode ce (generator only) */
   float grad_scale;  /* multiplies every loss gradient: 1/world_size under data parallelism so the
                         RCCL all-reduce(SUM) of the arenas yields the mean without an extra pass */
-  float d_b1, d_b2;  /* AdamW betas of optimizer_D (0 = same as b1 / b2): the two torch optimizers of the
+  float d_b1, d_b2;  /* AdamW betas of optimizer_D (negative = same as b1 / b2; 0 is a valid beta): the two torch optimizers of the
                         reference are independent objects (models/base_gan.py:87-120) */
   int gp_mode;       /* gradient penalty of --gan_mode (modules/loss.py:133-184): 0 none, 1 wgan-gp (with gan_mode 2),
                         2 dragan-gp, 3 dragan-lp (with gan_mode 0); warp model only */

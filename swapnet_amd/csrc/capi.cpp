@@ -140,7 +140,8 @@ int swn_model_set_hyper(swn_model* m, const swn_hyper* h) {
     REQUIRE(h->gan_mode >= 0 && h->gan_mode <= 2, "gan mode not implemented");
     y.gan_mode = h->gan_mode; y.warp_mode_ce_only = h->warp_mode_ce;
     y.grad_scale = h->grad_scale > 0.f ? h->grad_scale : 1.f;
-    y.d_b1 = h->d_b1 > 0.f ? h->d_b1 : h->b1; y.d_b2 = h->d_b2 > 0.f ? h->d_b2 : h->b2;
+    // negative = inherit optimizer_G's value; 0 is a legitimate beta (WGAN-GP style (0, 0.9) betas)
+    y.d_b1 = h->d_b1 >= 0.f ? h->d_b1 : h->b1; y.d_b2 = h->d_b2 >= 0.f ? h->d_b2 : h->b2;
     REQUIRE(h->gp_mode >= 0 && h->gp_mode <= 3, "gradient penalty mode not implemented");
     REQUIRE(h->gp_mode == 0 || m->m->supports_gradient_penalty(),
             "gradient penalty modes are not implemented for the texture model (the reference's call fails there too)");

@@ -73,6 +73,12 @@ void* graph_end(Stream& s) {
   if (e != hipSuccess) throw Error(2, std::string("hipGraphInstantiate failed: ") + hipGetErrorString(e));
   return (void*)exec;
 }
+void graph_abort(Stream& s) {
+  hipGraph_t g = nullptr;
+  (void)hipStreamEndCapture(hs(s), &g);
+  if (g) (void)hipGraphDestroy(g);
+  (void)hipGetLastError();
+}
 void graph_launch(void* exec, Stream& s) { SWN_HIP_CHECK(hipGraphLaunch((hipGraphExec_t)exec, hs(s))); }
 void graph_destroy(void* exec) {
   if (exec) (void)hipGraphExecDestroy((hipGraphExec_t)exec);

@@ -558,9 +558,19 @@ void gram_style_loss(Stream& s, const TView& a, const TView& b, int C, float sca
   hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(64), 0, hs(s), lp, fgrid, 1.0 / numel, loss_out);
   if (da) {
     const size_t smem = (size_t)R * 33 * 4;
-    static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(gram_bwd_generic_kernel),
-                                                  hipFuncAttributeMaxDynamicSharedMemorySize, 1024 * 33 * 4), true);
-    (void)once;
+    // R * 33 floats of LDS (up to 135 KB at R = 1024): fits gfx950's 160 KB only -- fail with a clear message elsewhere
+    static int lds_limit = -1;
+    if (lds_limit < 0) {
+      int dev = 0, lim = 0;
+      SWN_HIP_CHECK(hipGetDevice(&dev));
+      SWN_HIP_CHECK(hipDeviceGetAttribute(&lim, hipDeviceAttributeMaxSharedMemoryPerBlock, dev));
+      SWN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gram_bwd_generic_kernel),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, std::min(lim, 1024 * 33 * 4)));
+      lds_limit = lim;
+    }
+    if (smem > (size_t)lds_limit)
+      throw Error(1, "gram_style_loss: the style gradient over R = " + std::to_string(R) + " Gram rows needs " + std::to_string(smem) +
+                         " bytes of LDS, this device offers " + std::to_string(lds_limit));
     hipLaunchKernelGGL(gram_bwd_generic_kernel, dim3(ceil_div(HW, 32)), dim3(256), smem, hs(s), a.p, a.cs, dG, a.N, HW, C,
                        n0 * C, nloc * C, da->p, da->cs, accumulate);
   }

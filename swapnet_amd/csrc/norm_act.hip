@@ -542,9 +542,12 @@ void norm_act_fwd(Stream& s, const NormActArgs& a) {
   if (a.norm && !a.stats) throw Error(1, "norm_act_fwd: stats buffer required");
   if (a.norm && p.HW <= 1024 && p.C % 32 == 0 && fused_in_on()) {
     const dim3 grid(p.C / 32, p.N);
+    // (above 512 pixels: 16-channel slabs of 64 KB, so several blocks share a CU and one block's load phase runs under
+    // another's store phase -- a 128 KB slab per block leaves one block per CU and the two phases serialise chip-wide)
     if (p.HW <= 64) hipLaunchKernelGGL((in_fused_fwd_kernel<32, 2>), grid, dim3(256), 0, hs(s), p);
     else if (p.HW <= 256) hipLaunchKernelGGL((in_fused_fwd_kernel<32, 8>), grid, dim3(256), 0, hs(s), p);
-    else hipLaunchKernelGGL((in_fused_fwd_kernel<32, 32>), grid, dim3(256), 0, hs(s), p);
+    else if (p.HW <= 512) hipLaunchKernelGGL((in_fused_fwd_kernel<32, 16>), grid, dim3(256), 0, hs(s), p);
+    else hipLaunchKernelGGL((in_fused_fwd_kernel<16, 16>), dim3(p.C / 16, p.N), dim3(256), 0, hs(s), p);
     check_launch("norm_act_fwd (fused)");
     return;
   }

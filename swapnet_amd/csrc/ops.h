@@ -30,6 +30,7 @@ void stream_wait_event(Stream& s, void* ev);      // work enqueued on s afterwar
 void* stream_create_current();        // a new non-blocking stream on the calling thread's current device (NULL on the simulator)
 void graph_begin(Stream& s);
 void* graph_end(Stream& s);
+void graph_abort(Stream& s);          // ends a capture that failed half way: status ignored, any partial graph destroyed
 void graph_launch(void* exec, Stream& s);
 void graph_destroy(void* exec);
 

@@ -41,7 +41,7 @@ void Pipeline::run(bool use_graph) {
       s.handle = cap_stream_;
       try {
         graph_begin(s);
-        try { enqueue(); } catch (...) { graph_end(s); throw; }
+        try { enqueue(); } catch (...) { graph_abort(s); throw; }      // leave capture mode, keep the original error
         exec_ = graph_end(s);
       } catch (...) { s.handle = caller; throw; }
       s.handle = caller;

@@ -202,7 +202,7 @@ class NativeModel:
     def set_hyper(self, **kw):
         h = _C.SwnHyper(lr=1e-4, d_lr=4e-4, weight_decay=0.0, d_weight_decay=0.01, b1=0.9, b2=0.999,
                         lambda_gan=1.0, lambda_ce=100.0, lambda_l1=10.0, lambda_content=20.0,
-                        lambda_style=1e-8, gan_mode=0, warp_mode_ce=0, grad_scale=1.0, d_b1=0.0, d_b2=0.0,
+                        lambda_style=1e-8, gan_mode=0, warp_mode_ce=0, grad_scale=1.0, d_b1=-1.0, d_b2=-1.0,
                         gp_mode=0, lambda_gp=10.0)
         for k, v in kw.items():
             setattr(h, k, v)

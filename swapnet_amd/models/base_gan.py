@@ -88,6 +88,11 @@ class BaseGAN(BaseModel, ABC):
                                    gp_mode=self.criterion_GAN.gp_mode, lambda_gp=getattr(opt, "lambda_gp", 10.0))
             for n in ("D", "D_real", "D_fake", "G", "G_gan", "G_ce", "G_l1", "G_content", "G_style", "D_gp"):
                 setattr(self, "loss_" + n, 0.0)
+            if parallel.launched_data_parallel():      # the unchanged train.py under torchrun (parallel.py)
+                rank, _ = parallel.init_from_env()
+                self.enable_data_parallel()
+                # every rank walks the dataset in its own order (the DataLoader's sampler seeds itself from this RNG)
+                torch.manual_seed(torch.initial_seed() + 7919 * rank)
 
     # ---- data parallel (new design; the reference is single-device: SURVEY.md 2a) ---------
     def enable_data_parallel(self):
@@ -157,6 +162,7 @@ class BaseGAN(BaseModel, ABC):
             m.step(labels, training=training, seed=seed)
         else:
             rank = torch.distributed.get_rank()
+            labels = parallel.broadcast_floats(labels)          # rank 0's smooth-label draws on every rank
             m.forward(training, seed + rank)
             if not self._ce_only():                             # --warp_mode ce: generator only (warp_model.py:178-183)
                 m.backward_D(labels[0], labels[1])

@@ -1,6 +1,11 @@
 """BaseModel API of the reference (/root/reference/models/base_model.py:10-245): what train.py
 and inference.py call on a model.  Behaviour kept: attribute names, checkpoint file names
-(`{epoch}_net_{name}.pth`, `{epoch}_optim_{name}.pth`) and their state-dict key layout."""
+(`{epoch}_net_{name}.pth`, `{epoch}_optim_{name}.pth`) and their state-dict key layout.
+
+This file is a RESTATEMENT of the reference's boundary class ("KEEP"): pure control plane --
+getters, checkpoint file naming, `setup` / `eval` / `test` / `print_networks` -- that the reference's unchanged train.py and
+inference.py call by name, so most of its methods necessarily read like the reference's.  Nothing here is on the hot path;
+it is not to grow (the step, the networks and the losses live behind the C ABI)."""
 import os
 from abc import ABC, abstractmethod
 from collections import OrderedDict
@@ -13,6 +18,11 @@ from ..util.util import PromptOnce
 class BaseModel(ABC):
     def __init__(self, opt):
         self.opt = opt
+        from .. import parallel
+        self._dp_rank = 0
+        if parallel.launched_data_parallel():          # started under torchrun: one process per GPU (parallel.py)
+            opt.gpu_id = parallel.launch_device(opt.gpu_id)
+            self._dp_rank = int(os.environ.get("RANK", "0"))
         self.gpu_id = opt.gpu_id
         self.is_train = opt.is_train
         # the reference maps gpu_id None -> CPU (base_model.py:36-40); this back end is HIP-only
@@ -21,6 +31,8 @@ class BaseModel(ABC):
                                "is not part of this library" % (self.gpu_id,))
         self.device = torch.device(f"cuda:{self.gpu_id}")
         self.save_dir = os.path.join(opt.checkpoints_dir, opt.name)
+        if self._dp_rank:        # replicas hold the same weights: ranks > 0 keep theirs out of rank 0's way
+            self.save_dir = os.path.join(self.save_dir, f"rank{self._dp_rank}")
         if self.is_train:
             PromptOnce.makedirs(self.save_dir, not getattr(opt, "no_confirm", True))
         self.loss_names = []

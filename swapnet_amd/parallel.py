@@ -31,6 +31,31 @@ def init_from_env(backend=None):
     return rank, world
 
 
+def launched_data_parallel():
+    """Opt-in data parallelism for the reference's UNCHANGED train.py: start it under torchrun
+    (`python -m torch.distributed.run --nproc-per-node N train.py ...`, i.e. WORLD_SIZE > 1 in the environment) and
+    every model it creates trains data-parallel -- rank r drives GPU LOCAL_RANK, the weights start from rank 0's, each
+    rank shuffles its own way through the dataset, gradients are averaged over RCCL.  SWAPNET_DATA_PARALLEL=0 opts out
+    (e.g. N independent runs under one launcher)."""
+    return int(os.environ.get("WORLD_SIZE", "1")) > 1 and os.environ.get("SWAPNET_DATA_PARALLEL", "1") != "0"
+
+
+def launch_device(gpu_id):
+    """The device of this rank under launched_data_parallel(): torchrun's LOCAL_RANK (one process per GPU)."""
+    return int(os.environ.get("SWAPNET_FORCE_DEVICE", os.environ.get("LOCAL_RANK", gpu_id if gpu_id is not None else 0)))
+
+
+def broadcast_floats(values, src=0):
+    """Rank `src`'s host scalars on every rank (the smooth-label draws of GANLoss: ranks that shuffle differently have
+    consumed their RNGs differently, and all of them must train against the same targets, SURVEY.md 8(e) caveat 2)."""
+    if not (dist.is_initialized() and dist.get_world_size() > 1):
+        return list(values)
+    dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+    t = torch.tensor(list(values), dtype=torch.float64, device=dev)
+    dist.broadcast(t, src=src)
+    return [float(v) for v in t.cpu()]
+
+
 class GradExchange:
     """Averages a flat gradient arena across ranks.  `begin()` launches the collective on
     RCCL's own stream (it depends on the kernels already enqueued on the compute stream);

@@ -34,6 +34,7 @@ int is_device_build() { return 0; }
 void* stream_create_current() { return nullptr; }
 void graph_begin(Stream&) {}
 void* graph_end(Stream&) { return nullptr; }
+void graph_abort(Stream&) {}
 void graph_launch(void*, Stream&) {}
 void graph_destroy(void*) {}
 void conv_force_naive(int) {}

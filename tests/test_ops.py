@@ -280,3 +280,36 @@ def test_split_main_loop_is_as_accurate_as_the_f32_mfma(monkeypatch):
             e_split, e_f32 = rel(res["1"][i], ref), rel(res["0"][i], ref)
             assert e_split <= 1.15 * e_f32 + 2e-8, (what, kind, ci, co, "split %.3e" % e_split, "f32 mfma %.3e" % e_f32)
             assert e_split < 2e-6 and rel(res["1"][i], res["0"][i]) < 2e-6
+
+
+@pytest.mark.gpu
+def test_split_main_loop_on_one_signed_operands(monkeypatch):
+    """The cut of the split main loop is by TRUNCATION, so the three dropped terms (mid*lo, lo*mid, lo*lo, each below
+    2^-24 |a||b|) all carry the sign of a*b: with zero-mean operands they average out, with one-signed operands -- post-ReLU
+    activations against a positive filter, the image Gram -- they add up to a BIAS.  K = 9216 (the resblock conv run
+    direct), non-negative activations, positive weights: the relative error against float64 must stay at the f32 MFMA
+    form's level and the signed mean error (the bias) below one fp32 ulp of the result."""
+    ctx = _ctx("gpu")
+    g = torch.Generator().manual_seed(12)
+    monkeypatch.setenv("SWN_WINOGRAD", "0")
+    for kind, n, ci, h, co in ((K3REFL, 2, 1024, 16, 256), (K4S2, 2, 256, 32, 128)):
+        k = 3 if kind == K3REFL else 4
+        x = torch.relu(torch.randn(n, ci, h, h, generator=g)) + 0.01
+        w = torch.randn(co, ci, k, k, generator=g).abs() * (2.0 / (ci * k * k)) ** 0.5
+        y64 = ref_conv(x.double(), w.double(), None, kind, 0)
+        dy = torch.rand(y64.shape, generator=g) + 0.1
+        xd, wd = x.double().requires_grad_(True), w.double().requires_grad_(True)
+        gx64, gw64 = torch.autograd.grad(ref_conv(xd, wd, None, kind, 0), (xd, wd), dy.double())
+        res = {}
+        for mode in ("1", "0"):
+            monkeypatch.setenv("SWN_SPLIT", mode)
+            res[mode] = (run_conv(ctx, kind, 0, 0, False, x, w, None, 0, y64.shape),
+                         run_conv(ctx, kind, 0, 2, False, torch.zeros_like(x), w, None, 0, dy=dy),
+                         run_conv(ctx, kind, 0, 1, False, x, torch.zeros_like(w), None, 0, dy=dy))
+        for what, i, ref in (("fwd", 0, y64), ("dgrad", 1, gx64), ("wgrad", 2, gw64)):
+            e_split, e_f32 = rel(res["1"][i], ref), rel(res["0"][i], ref)
+            bias = float(((res["1"][i].double() - ref) / ref).mean())
+            bias32 = float(((res["0"][i].double() - ref) / ref).mean())
+            print("one-signed K=%d %s: split %.2e (bias %+.2e)  f32 mfma %.2e (bias %+.2e)" % (ci * k * k, what, e_split, bias, e_f32, bias32))
+            assert e_split <= 1.25 * e_f32 + 6e-8, (what, kind, "split %.3e" % e_split, "f32 mfma %.3e" % e_f32)
+            assert abs(bias) < 1.2e-7, (what, kind, "relative bias of the split form", bias)

