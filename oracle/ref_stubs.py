@@ -97,7 +97,18 @@ class _Inert:
         return self
 
     def __getattr__(self, name):
+        if name.startswith("__"):
+            raise AttributeError(name)
         return _Inert()
+
+    def __enter__(self):            # `with dominate.document(...)`, `with tr():` (util/html.py)
+        return self
+
+    def __exit__(self, *exc):
+        return False
+
+    def render(self, *a, **k):
+        return "<html></html>"
 
 
 class _ToTensor:
@@ -122,6 +133,28 @@ class _Normalize:
         return (t - self.mean[:, None, None]) / self.std[:, None, None]
 
 
+def _tf_resize(img, size, interpolation=2):
+    """transforms.functional.resize on a PIL image: int = the smaller edge (torchvision semantics), bilinear"""
+    w, h = img.size
+    if isinstance(size, int):
+        if (w <= h and w == size) or (h <= w and h == size):
+            return img
+        size = (size, int(size * h / w)) if w < h else (int(size * w / h), size)
+    else:
+        size = (size[1], size[0])
+    return img.resize(size, 2)
+
+
+def _tf_hflip(img):
+    from PIL import Image
+    return img.transpose(Image.FLIP_LEFT_RIGHT)
+
+
+def _tf_vflip(img):
+    from PIL import Image
+    return img.transpose(Image.FLIP_TOP_BOTTOM)
+
+
 def install(functional_transforms=False):
     """Install the stand-ins and put the reference first on sys.path.  functional_transforms=True makes ToTensor /
     Normalize real (needed when the reference's own dataloader is run, tests/test_reference_scripts.py)."""
@@ -140,6 +173,10 @@ def install(functional_transforms=False):
         if functional_transforms:
             tf.ToTensor, tf.Normalize = _ToTensor, _Normalize
         tf.functional = _mod("torchvision.transforms.functional")
+        if functional_transforms:       # what datasets/texture_dataset.py and data_utils.random_image_roi_flip call
+            tf.functional.to_tensor = _ToTensor()
+            tf.functional.resize = _tf_resize
+            tf.functional.hflip, tf.functional.vflip = _tf_hflip, _tf_vflip
         tf.transforms = tf                      # `from torchvision.transforms import transforms`
         sys.modules["torchvision.transforms.transforms"] = tf
         tv.transforms = tf

@@ -109,3 +109,52 @@ def test_reference_train_script_runs_data_parallel_under_a_torchrun_environment(
     d1 = torch.load(os.path.join(ckpt, "warp", "rank1", "latest_net_discriminator.pth"))
     assert all(torch.equal(d0[k], d1[k]) for k in d0)
     assert float(torch.load(os.path.join(ckpt, "warp", "rank1", "latest_optim_G.pth"))["state"][0]["step"]) == 3.0
+
+
+def _make_texture_dataset(root, n=6, size=64):
+    """dataroot/texture/*.png + the matching cloth/*.npz + rois.csv (12 rows of xmin, ymin, xmax, ymax per image id,
+    datasets/texture_dataset.py:74-78,116-119) in the reference's formats."""
+    from PIL import Image
+    _make_dataset(root, n, size)
+    rs = np.random.RandomState(1)
+    os.makedirs(os.path.join(root, "texture"), exist_ok=True)
+    rows = ["id,xmin,ymin,xmax,ymax"]
+    for i in range(n):
+        Image.fromarray(rs.randint(0, 255, size=(size, size, 3), dtype=np.uint8)).save(os.path.join(root, "texture", "s%03d.png" % i))
+        for r in range(12):
+            x1, y1 = rs.randint(0, size - 2, size=2)
+            w, h = rs.randint(0, size // 2, size=2)
+            if r == 5:
+                w = h = 0                                   # a degenerate box per image, as in real rois.csv files
+            rows.append("s%03d,%d,%d,%d,%d" % (i, x1, y1, min(x1 + w, size - 1), min(y1 + h, size - 1)))
+    with open(os.path.join(root, "rois.csv"), "w") as f:
+        f.write("\n".join(rows) + "\n")
+
+
+def test_reference_scripts_run_the_texture_stage_unchanged(tmp_path):
+    """`train.py --model texture` on a texture/ + cloth/ + rois.csv dataset (the reference's TextureDataset,
+    ROI flips and all) and `inference.py --texture_checkpoint`, both unchanged, against this package."""
+    import torch
+    data, ckpt, res = str(tmp_path / "data"), str(tmp_path / "ckpt"), str(tmp_path / "results")
+    _make_texture_dataset(data)
+    out = _run("train.py", str(tmp_path), [
+        "--name", "texture", "--model", "texture", "--dataroot", data, "--checkpoints_dir", ckpt, "--batch_size", "2",
+        "--load_size", "64", "--crop_size", "64", "--max_dataset_size", "6", "--n_epochs", "1", "--num_workers", "0",
+        "--display_id", "0", "--no_html", "--no_confirm", "--print_freq", "2", "--checkpoint_freq", "1"])
+    assert "The number of training images = 6" in out
+    run_dir = os.path.join(ckpt, "texture")
+    args = json.load(open(os.path.join(run_dir, "args.json")))
+    assert args["model"] == "texture"
+    sd = torch.load(os.path.join(run_dir, "latest_net_generator.pth"))
+    assert "encode.model.0.weight" in sd and sd["encode.model.0.weight"].shape == (36, 36, 4, 4)
+    osd = torch.load(os.path.join(run_dir, "latest_optim_G.pth"))
+    assert float(osd["state"][0]["step"]) == 3.0
+    log = open(os.path.join(run_dir, "loss_log.txt")).read()
+    assert "G_l1" in log and "D_fake" in log
+    # ---- inference.py, texture stage alone, from that checkpoint (cloth_dir = the dataset's own segmentations)
+    out = _run("inference.py", str(tmp_path), [
+        "--texture_checkpoint", os.path.join(run_dir, "latest_net_generator.pth"), "--dataroot", data, "--results_dir", res,
+        "--max_dataset_size", "3", "--num_workers", "0", "--no_confirm", "--checkpoints_dir", ckpt])
+    assert "Textured results stored in" in out
+    imgs = [f for _, _, fs in os.walk(os.path.join(res, "texture")) for f in fs if f.endswith(".png")]
+    assert len(imgs) >= 3, imgs
