@@ -174,6 +174,25 @@ ConvGeom conv_geom(ConvKind kind, int H, int W) {
 }
 }  // namespace
 
+
+// ---- strided Winograd F(4x4, 2x2) for the k4 s2 p1 convolutions and their transposes (ops.h wino_s2_*, wino.hip) ----------
+// Used where the activation side dominates: the transformed filters are 6.25x the weights (per GEMM direction) and are
+// re-derived every optimizer step, so the 8-16 M-parameter layers at 4x4 / 8x8 maps stay on the direct kernels.
+namespace {
+bool s2_wino_wanted(int Cfine, int Ccoarse, int Hc, int Wc) {
+  static const bool off = (getenv("SWN_WINOGRAD") && atoi(getenv("SWN_WINOGRAD")) == 0) ||
+                          (getenv("SWN_WINO_S2") && atoi(getenv("SWN_WINO_S2")) == 0);
+  if (off) return false;
+  const int minc_env = getenv("SWN_WINO_MINC") ? atoi(getenv("SWN_WINO_MINC")) : 0;      // (tests: small channel counts too)
+  const int minc = minc_env > 0 ? minc_env : 256;
+  if (Ccoarse < minc || Cfine < 32 || Cfine % 4 || Ccoarse % 16 || Hc < 2 || Wc < 2) return false;
+  return (size_t)16 * Cfine * Ccoarse <= ((size_t)1 << 22);
+}
+TView plane_mat(float* p, size_t T, int C) {
+  TView v; v.p = p; v.N = 1; v.H = 1; v.W = (int)T; v.C = C; v.cs = C; return v;     // T x C matrix
+}
+}  // namespace
+
 // ---- Conv2d ---------------------------------------------------------------------------
 // y.v receives act(conv(x)+bias).  In backward y.g is the gradient w.r.t. that output.
 void Net::conv(const std::string& name, const Var& x, const Var& y, ConvKind kind, int Ci, int Co, bool bias,
@@ -237,6 +256,81 @@ void Net::conv(const std::string& name, const Var& x, const Var& y, ConvKind kin
       d.x = zv; d.g.Ho = xv.H; d.g.Wo = xv.W;
       d.w = n.dg + wt2_off; d.Npad = Cip; d.Cout = Cip; d.y = xgv; d.accumulate = me.acc.empty() ? 0 : me.acc[0];
       conv_fwd(n.ctx.s, d);
+    };
+    ops.push_back(std::move(op));
+    return;
+  }
+  // k4 s2 convs with enough channels: strided Winograd F(4x4,2x2) (four polyphase 2x2 convolutions in one batched GEMM)
+  if (kind == CK_K4S2 && s2_wino_wanted(Cip, Cop, y.v.H, y.v.W) && Co % 4 == 0) {
+    const int sP = 25, sTh = ceil_div(y.v.H, 4), sTw = ceil_div(y.v.W, 4), CV = 4 * Cip;
+    const size_t sT = (size_t)x.v.N * sTh * sTw;
+    const bool want_dx = x.has_grad && y.has_grad;
+    const size_t uf_off = reserve_dg(self, (size_t)sP * CV * Cop);                      // U  [25][4 Cip][Cop]
+    const size_t ut_off = want_dx ? reserve_dg(self, (size_t)sP * Cop * CV) : 0;        // U^T[25][Cop][4 Cip]
+    float* keepV = (keep_wino_inputs && y.has_grad) ? static_cast<float*>(ctx.alloc(sP * sT * CV * sizeof(float))) : nullptr;
+    wsV_need = std::max(wsV_need, sP * sT * (size_t)std::max(CV, Cop));
+    wsM_need = std::max(wsM_need, sP * sT * (size_t)std::max(CV, Cop));
+    wsU_need = std::max(wsU_need, (size_t)sP * CV * Cop);
+    const int pcf = conv_precut_tile(CV, Cop), pct = want_dx ? conv_precut_tile(Cop, CV) : 0;
+    const size_t pcf_bs = pcf ? conv_precut_elems(CV, Cop, pcf) : 0, pct_bs = pct ? conv_precut_elems(Cop, CV, pct) : 0;
+    const size_t pcf_off = pcf ? reserve_dgp(pcf_bs * sP) : 0, pct_off = pct ? reserve_dgp(pct_bs * sP) : 0;
+    op->repack = [=](Net& n) {
+      const ParamDesc& wd = A->params[wi];
+      wino_s2_filter_transform(n.ctx.s, wd.ws, 0, A->w + wd.off, n.dg + uf_off);
+      if (pcf) conv_precut(n.ctx.s, n.dg + uf_off, CV, Cop, pcf, sP, (size_t)CV * Cop, n.dgp + pcf_off);
+      if (want_dx) {
+        wino_s2_filter_transform(n.ctx.s, wd.ws, 1, A->w + wd.off, n.dg + ut_off);
+        if (pct) conv_precut(n.ctx.s, n.dg + ut_off, Cop, CV, pct, sP, (size_t)Cop * CV, n.dgp + pct_off);
+      }
+    };
+    op->fwd = [=](Net& n) {
+      n.need(self);
+      float* V = keepV ? keepV : n.wsV;
+      wino_s2_input_transform(n.ctx.s, xv, sTh, sTw, V);
+      ConvFwdArgs g;
+      g.x = plane_mat(V, sT, CV); g.g.Ho = 1; g.g.Wo = (int)sT;
+      g.w = n.dg + uf_off; g.Npad = Cop; g.Cout = Co;
+      g.y = plane_mat(n.wsM, sT, Cop);
+      g.batch = sP; g.x_bs = sT * CV; g.w_bs = (size_t)CV * Cop; g.y_bs = sT * Cop;
+      if (pcf) { g.wpc = n.dgp + pcf_off; g.wpc_bn = pcf; g.wpc_bs = pcf_bs; }
+      conv_fwd(n.ctx.s, g);
+      wino_output_transform(n.ctx.s, 4, 2, n.wsM, Cop, sTh, sTw, bi >= 0 ? A->w + A->params[bi].off : nullptr, actf, yv, Co, 0);
+    };
+    Var scratch;
+    if (y.has_grad && actf != ACT_NONE) scratch = alloc_var(yv.N, yv.H, yv.W, Cop, false);
+    if (want_dx) op->grad_targets.push_back(x);
+    const TView ygv = y.g, xgv = x.g, scr = scratch.v;
+    const bool has_ygrad = y.has_grad;
+    op->bwd = [=](Net& n, Op& me, bool wgrad, bool igrad) {
+      if (!has_ygrad) return;
+      TView dY = ygv;
+      if (actf != ACT_NONE) { act_bwd(n.ctx.s, ygv, yv, scr, actf, 0); dY = scr; }
+      const ParamDesc& wd = A->params[wi];
+      if (wgrad) {
+        Stream& sw = n.wgrad_stream();
+        float* V = keepV ? keepV : n.wsV;
+        float* dM = n.wgrad_planes(sw);
+        if (!keepV) wino_s2_input_transform(sw, xv, sTh, sTw, V);
+        wino_dy_transform(sw, 4, 2, dY, sTh, sTw, dM);
+        ConvWgradArgs g;
+        g.x = plane_mat(V, sT, CV); g.g.Ho = 1; g.g.Wo = (int)sT;
+        g.dy = plane_mat(dM, sT, Cop);
+        g.dw = n.wsU; g.Npad = Cop; g.Cout = Co;
+        g.batch = sP; g.x_bs = sT * CV; g.dy_bs = sT * Cop; g.dw_bs = (size_t)CV * Cop;
+        conv_wgrad(sw, g);
+        wino_s2_filter_grad(sw, wd.ws, n.wsU, A->g + wd.off);
+        if (bi >= 0) bias_grad(sw, dY, A->g + A->params[bi].off);
+      }
+      if (!want_dx || (me.reads_net_input && !igrad)) return;
+      wino_dy_transform(n.ctx.s, 4, 2, dY, sTh, sTw, n.wsV);
+      ConvFwdArgs g;
+      g.x = plane_mat(n.wsV, sT, Cop); g.g.Ho = 1; g.g.Wo = (int)sT;
+      g.w = n.dg + ut_off; g.Npad = CV; g.Cout = CV;
+      g.y = plane_mat(n.wsM, sT, CV);
+      g.batch = sP; g.x_bs = sT * Cop; g.w_bs = (size_t)Cop * CV; g.y_bs = sT * CV;
+      if (pct) { g.wpc = n.dgp + pct_off; g.wpc_bn = pct; g.wpc_bs = pct_bs; }
+      conv_fwd(n.ctx.s, g);
+      wino_s2_input_adjoint(n.ctx.s, n.wsM, Cip, sTh, sTw, xgv, nullptr, me.acc.empty() ? 0 : me.acc[0]);
     };
     ops.push_back(std::move(op));
     return;
@@ -471,6 +565,81 @@ void Net::convT(const std::string& name, const Var& x, const Var& y, int Co, boo
   op->param_off = arena.params[wi].off;
   ParamArena* A = &arena;
   const TView xv = x.v, yv = y.v, ygv = y.g, xgv = x.g;
+  // enough channels: strided Winograd F(4x4,2x2) -- the transposed conv is the ADJOINT of a k4 s2 conv fine -> coarse, so its
+  // forward is the coarse -> fine pipeline (dM = A x A^T, dV = dM U^T, adjoint polyphase transform) and its input gradient the
+  // fine -> coarse one
+  if (s2_wino_wanted(Cop, Cip, x.v.H, x.v.W) && Co % 4 == 0) {
+    const int sP = 25, sTh = ceil_div(x.v.H, 4), sTw = ceil_div(x.v.W, 4), CV = 4 * Cop;
+    const size_t sT = (size_t)x.v.N * sTh * sTw;
+    const bool want_dx = x.has_grad && y.has_grad;
+    const size_t ut_off = reserve_dg(self, (size_t)sP * Cip * CV);                      // U^T[25][Cip][4 Cop]   (forward)
+    const size_t uf_off = want_dx ? reserve_dg(self, (size_t)sP * CV * Cip) : 0;        // U  [25][4 Cop][Cip]   (input gradient)
+    float* keepM = (keep_wino_inputs && y.has_grad) ? static_cast<float*>(ctx.alloc(sP * sT * Cip * sizeof(float))) : nullptr;
+    wsV_need = std::max(wsV_need, sP * sT * (size_t)std::max(CV, Cip));
+    wsM_need = std::max(wsM_need, sP * sT * (size_t)std::max(CV, Cip));
+    wsU_need = std::max(wsU_need, (size_t)sP * CV * Cip);
+    const int pct = conv_precut_tile(Cip, CV), pcf = want_dx ? conv_precut_tile(CV, Cip) : 0;
+    const size_t pct_bs = pct ? conv_precut_elems(Cip, CV, pct) : 0, pcf_bs = pcf ? conv_precut_elems(CV, Cip, pcf) : 0;
+    const size_t pct_off = pct ? reserve_dgp(pct_bs * sP) : 0, pcf_off = pcf ? reserve_dgp(pcf_bs * sP) : 0;
+    op->repack = [=](Net& n) {
+      const ParamDesc& wd = A->params[wi];
+      wino_s2_filter_transform(n.ctx.s, wd.ws, 1, A->w + wd.off, n.dg + ut_off);
+      if (pct) conv_precut(n.ctx.s, n.dg + ut_off, Cip, CV, pct, sP, (size_t)Cip * CV, n.dgp + pct_off);
+      if (want_dx) {
+        wino_s2_filter_transform(n.ctx.s, wd.ws, 0, A->w + wd.off, n.dg + uf_off);
+        if (pcf) conv_precut(n.ctx.s, n.dg + uf_off, CV, Cip, pcf, sP, (size_t)CV * Cip, n.dgp + pcf_off);
+      }
+    };
+    op->fwd = [=](Net& n) {
+      n.need(self);
+      const ParamDesc& wd = A->params[wi];
+      (void)wd;
+      float* dM = keepM ? keepM : n.wsV;
+      wino_dy_transform(n.ctx.s, 4, 2, xv, sTh, sTw, dM);
+      ConvFwdArgs g;
+      g.x = plane_mat(dM, sT, Cip); g.g.Ho = 1; g.g.Wo = (int)sT;
+      g.w = n.dg + ut_off; g.Npad = CV; g.Cout = CV;
+      g.y = plane_mat(n.wsM, sT, CV);
+      g.batch = sP; g.x_bs = sT * Cip; g.w_bs = (size_t)Cip * CV; g.y_bs = sT * CV;
+      if (pct) { g.wpc = n.dgp + pct_off; g.wpc_bn = pct; g.wpc_bs = pct_bs; }
+      conv_fwd(n.ctx.s, g);
+      wino_s2_input_adjoint(n.ctx.s, n.wsM, Cop, sTh, sTw, yv, bi >= 0 ? A->w + A->params[bi].off : nullptr, 0);
+    };
+    if (want_dx) op->grad_targets.push_back(x);
+    const bool has_ygrad = y.has_grad;
+    op->bwd = [=](Net& n, Op& me, bool wgrad, bool igrad) {
+      if (!has_ygrad) return;
+      const ParamDesc& wd = A->params[wi];
+      if (wgrad) {
+        // dU[25][4 Cop][Cip] = V(dY fine)^T dM(x coarse)
+        Stream& sw = n.wgrad_stream();
+        float* V = n.wgrad_planes(sw);
+        float* dM = keepM ? keepM : n.wsV;
+        wino_s2_input_transform(sw, ygv, sTh, sTw, V);
+        if (!keepM) wino_dy_transform(sw, 4, 2, xv, sTh, sTw, dM);
+        ConvWgradArgs g;
+        g.x = plane_mat(V, sT, CV); g.g.Ho = 1; g.g.Wo = (int)sT;
+        g.dy = plane_mat(dM, sT, Cip);
+        g.dw = n.wsU; g.Npad = Cip; g.Cout = Cip;
+        g.batch = sP; g.x_bs = sT * CV; g.dy_bs = sT * Cip; g.dw_bs = (size_t)CV * Cip;
+        conv_wgrad(sw, g);
+        wino_s2_filter_grad(sw, wd.ws, n.wsU, A->g + wd.off);
+        if (bi >= 0) bias_grad(sw, ygv, A->g + A->params[bi].off);
+      }
+      if (!want_dx || (me.reads_net_input && !igrad)) return;
+      wino_s2_input_transform(n.ctx.s, ygv, sTh, sTw, n.wsV);
+      ConvFwdArgs g;
+      g.x = plane_mat(n.wsV, sT, CV); g.g.Ho = 1; g.g.Wo = (int)sT;
+      g.w = n.dg + uf_off; g.Npad = Cip; g.Cout = Cip;
+      g.y = plane_mat(n.wsM, sT, Cip);
+      g.batch = sP; g.x_bs = sT * CV; g.w_bs = (size_t)CV * Cip; g.y_bs = sT * Cip;
+      if (pcf) { g.wpc = n.dgp + pcf_off; g.wpc_bn = pcf; g.wpc_bs = pcf_bs; }
+      conv_fwd(n.ctx.s, g);
+      wino_output_transform(n.ctx.s, 4, 2, n.wsM, Cip, sTh, sTw, nullptr, ACT_NONE, xgv, Cip, me.acc.empty() ? 0 : me.acc[0]);
+    };
+    ops.push_back(std::move(op));
+    return;
+  }
   const size_t phase_elems = (size_t)4 * Cip * round_up(Co, 4);
   // pre-cut panels for the ring kernel: the four forward phase panels (arena layout) and the k4 s2 input-gradient operand
   const int pc_f = conv_precut_tile(Cip, Cop);

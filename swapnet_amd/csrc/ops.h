@@ -138,6 +138,16 @@ void wino_input_adjoint(Stream& s, int m, int r, float* dV, int C, int pad, int 
 void wino_output_transform(Stream& s, int m, int r, const float* M, int Cm, int Th, int Tw, const float* bias, int act,
                            const TView& y, int Cout, int accumulate);                                      // M[P][T][Cm]
 void wino_dy_transform(Stream& s, int m, int r, const TView& dy, int Th, int Tw, float* dM);               // dM[P][T][dy.C]
+// ---- strided Winograd F(4x4, 2x2): the k4 s2 p1 convolutions and their transposes as four polyphase 2x2 stride-1 convolutions
+// sharing one batched GEMM (wino.hip).  "fine" = the 2H x 2W side, "coarse" = the H x W side; tiles = 4x4 coarse pixels.
+// (m, r) = (4, 2) is accepted by wino_output_transform (coarse = A^T M A) and wino_dy_transform (dM = A coarse A^T).
+void wino_s2_input_transform(Stream& s, const TView& fine, int Th, int Tw, float* V);       // V[25][T][4 * fine.C], channel (2s+t)*C + c
+// fine (+)= [bias +] adjoint of the transform above applied to dV[25][T][4 * Cf] (overwritten: scratch)
+void wino_s2_input_adjoint(Stream& s, float* dV, int Cf, int Th, int Tw, const TView& fine, const float* bias, int accumulate);
+// w: the layer's WShape (WK_CONV: fine = input, coarse = output; WK_CONVT: fine = output, coarse = input).
+// mode 0: U[25][4 * Cf][Cc] (fine -> coarse GEMM); mode 1: U[25][Cc][4 * Cf] (coarse -> fine GEMM); Cf, Cc = padded counts
+void wino_s2_filter_transform(Stream& s, const WShape& w, int mode, const float* packed, float* U);
+void wino_s2_filter_grad(Stream& s, const WShape& w, const float* dU, float* dpacked);       // dU[25][4 * Cf][Cc]
 void wino_filter_grad(Stream& s, int m, int r, const WShape& w, const float* dU, float* dpacked);          // dU[P][Cip][Npad]
 
 // ---- InstanceNorm / activation / dropout -------------------------------------------

@@ -591,6 +591,183 @@ __global__ __launch_bounds__(256) void wino_fold_kernel(const float* P, int C, i
   }
 }
 
+
+// ---------------------------------------------------------------------------------------
+// Strided Winograd F(4x4, 2x2) for the k4 s2 p1 convolutions (UNetDown, PatchGAN) and their transposes (UNetUp)
+// (modules/layers.py:15,31; modules/discriminators.py:110-120; modules/pix2pix_modules.py:216-246), round 3.
+// A 4x4 stride-2 convolution is the sum of four 2x2 STRIDE-1 convolutions over the polyphase components of its input
+// (rows 2q - 1 + s, columns 2q' - 1 + t, s, t in {0, 1}) with the filters g_st[a][b] = w[2a + s][2b + t].  Each of them takes
+// the 5-point Winograd form F(4x4, 2x2) (points 0, +-1, 1/2, inf: 25 multiplies per 16 outputs instead of 64), and in the
+// transformed domain the four phases are simply four times the input channels of ONE batched GEMM:
+//   fine -> coarse  (conv forward, convT input gradient):  V[25][T][4 Cf] (this file) -> M = V U -> coarse = A^T M A
+//   coarse -> fine  (convT forward, conv input gradient):  dM = A c A^T -> dV = dM U^T [25][T][4 Cf] -> adjoint of the
+//                                                          polyphase input transform (patch + gather, no atomics)
+//   weight gradient:                                       dU = V^T dM -> dW = G^T dU G per phase
+// 2.56x fewer multiplies than the direct implicit GEMM; fp32 error against float64 ~1.7e-6 (between the direct kernels and
+// F(4x4,3x3)).  Used where the activation side dominates (engine.cpp: coarse channels >= 256, weights <= 4 M).
+// ---------------------------------------------------------------------------------------
+struct F42 {
+  static constexpr int M = 4, R = 2, A = 5;
+  static constexpr float BT[5][5] = {{0.5f, -1, -0.5f, 1, 0}, {0, -0.5f, 0.5f, 1, 0}, {0, 0.5f, -1.5f, 1, 0}, {0, -1, 0, 1, 0},
+                                     {0, 0.5f, -1, -0.5f, 1}};
+  static constexpr float G[5][2] = {{2, 0}, {1, 1}, {-1.f / 3, 1.f / 3}, {-8.f / 3, -4.f / 3}, {0, 1}};
+  static constexpr float AT[4][5] = {{1, 1, 1, 1, 0}, {0, 1, -1, 0.5f, 0}, {0, 1, 1, 0.25f, 0}, {0, 1, -1, 0.125f, 1}};
+};
+
+// V[(a*5+j)][tile][q*C + c] = (BT d_q BT^T)[a][j],  d_q[i][j] = x[2 (4 ty + i) - 1 + s][2 (4 tx + j) - 1 + t],  q = 2 s + t
+__global__ __launch_bounds__(256) void wino_s2_input_kernel(const float* x, int xcs, int N, int H, int W, int C, int Th, int Tw,
+                                                            float* V) {
+  constexpr int A = 5;
+  const int C4 = C >> 2;
+  const size_t T = (size_t)N * Th * Tw;
+  const size_t total = T * 4 * C4;
+  const int CV = 4 * C;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int c = (int)(i % C4) * 4; size_t r = i / C4;
+    const int q = (int)(r & 3); const size_t tile = r >> 2;
+    const int s = q >> 1, t = q & 1;
+    const int tx = (int)(tile % Tw); size_t u = tile / Tw;
+    const int ty = (int)(u % Th); const int n = (int)(u / Th);
+    int sy[A];
+#pragma unroll
+    for (int a = 0; a < A; ++a) { const int e = 2 * (4 * ty + a) - 1 + s; sy[a] = (e >= 0 && e < H) ? e : -1; }
+    float4 tt[A][A];
+#pragma unroll
+    for (int b = 0; b < A; ++b) {
+      const int e = 2 * (4 * tx + b) - 1 + t;
+      const int sx = (e >= 0 && e < W) ? e : -1;
+      float4 d[A];
+#pragma unroll
+      for (int a = 0; a < A; ++a)
+        d[a] = (sy[a] >= 0 && sx >= 0) ? *reinterpret_cast<const float4*>(x + ((size_t)(n * H + sy[a]) * W + sx) * xcs + c) : F4ZERO;
+#pragma unroll
+      for (int rr = 0; rr < A; ++rr) {
+        float4 acc = F4ZERO;
+#pragma unroll
+        for (int k = 0; k < A; ++k) f4mac(acc, F42::BT[rr][k], d[k]);
+        tt[rr][b] = acc;
+      }
+    }
+#pragma unroll
+    for (int a = 0; a < A; ++a)
+#pragma unroll
+      for (int j = 0; j < A; ++j) {
+        float4 acc = F4ZERO;
+#pragma unroll
+        for (int k = 0; k < A; ++k) f4mac(acc, F42::BT[j][k], tt[a][k]);
+        *reinterpret_cast<float4*>(V + ((size_t)(a * A + j) * T + tile) * CV + q * C + c) = acc;
+      }
+  }
+}
+
+// gather side of the adjoint: P[25][T][4 C] holds the patches BT^T dV BT; fine pixel (r, cc) of phase (s, t) sits at patch
+// entry (i, j) = (qy - 4 ty, qx - 4 tx) of the tiles that cover phase coordinates qy = (r + 1 - s) / 2, qx likewise
+__global__ __launch_bounds__(256) void wino_s2_fold_kernel(const float* P, int C, int N, int H, int W, int Th, int Tw, const float* bias,
+                                                           float* dx, int dcs, int accumulate) {
+  constexpr int A = 5, M = 4;
+  const int C4 = C >> 2, CV = 4 * C;
+  const size_t T = (size_t)N * Th * Tw;
+  const size_t total = (size_t)N * H * W * C4;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const size_t px = i / C4;
+    const int c = (int)(i - px * C4) * 4;
+    const int n = (int)(px / ((size_t)H * W));
+    const int rem = (int)(px - (size_t)n * H * W);
+    const int r = rem / W, cc = rem - r * W;
+    const int s = (r + 1) & 1, t = (cc + 1) & 1;
+    const int qy = (r + 1 - s) >> 1, qx = (cc + 1 - t) >> 1;
+    float4 acc = F4ZERO;
+    for (int ty = min(qy / M, Th - 1); ty >= 0 && qy - M * ty < A; --ty) {
+      const int a = qy - M * ty;
+      for (int tx = min(qx / M, Tw - 1); tx >= 0 && qx - M * tx < A; --tx) {
+        const int b = qx - M * tx;
+        const size_t tile = ((size_t)n * Th + ty) * Tw + tx;
+        acc = f4add(acc, *reinterpret_cast<const float4*>(P + ((size_t)(a * A + b) * T + tile) * CV + (2 * s + t) * C + c));
+      }
+    }
+    if (bias) { acc.x += bias[c]; acc.y += bias[c + 1]; acc.z += bias[c + 2]; acc.w += bias[c + 3]; }
+    float* d = dx + px * dcs + c;
+    if (accumulate) acc = f4add(acc, *reinterpret_cast<const float4*>(d));
+    *reinterpret_cast<float4*>(d) = acc;
+  }
+}
+
+// the weight of the k4 s2 p1 convolution fine -> coarse that the layer is (conv) or is the adjoint of (convT), from the packed
+// arena layouts of ops.h: conv [(kh*4+kw)*Cip + ci][co]; convT phase blocks p = a*2+b of [(dy*2+dx)*Cip + ci][co],
+// tap (ky, kx) = (3 - a - 2 dy, 3 - b - 2 dx), with W_convT[ci][co][ky][kx] = Wc[ky][kx][fine = co][coarse = ci]
+__device__ __forceinline__ size_t s2_widx(const WShape& w, int kh, int kw, int cf, int cc) {
+  if (w.kind == WK_CONV) return ((size_t)(kh * 4 + kw) * w.Cip + cf) * w.Npad + cc;
+  const int a = (3 - kh) & 1, dy = (3 - kh - a) >> 1, b = (3 - kw) & 1, dx = (3 - kw - b) >> 1;
+  return (size_t)(a * 2 + b) * 4 * w.Cip * w.Npad + ((size_t)(dy * 2 + dx) * w.Cip + cc) * w.Npad + cf;
+}
+
+// mode 0: U[p][q*Cf + cf][cc] (threads: cc fastest); mode 1: U[p][cc][q*Cf + cf] (threads: cf fastest)
+__global__ __launch_bounds__(256) void wino_s2_filter_kernel(WShape w, int mode, int Cf, int Cc, const float* packed, float* U) {
+  constexpr int A = 5;
+  const size_t total = (size_t)Cf * Cc;
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int cf = mode == 0 ? (int)(i / Cc) : (int)(i % Cf), cc = mode == 0 ? (int)(i % Cc) : (int)(i / Cf);
+  const size_t plane = (size_t)4 * Cf * Cc;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int s = q >> 1, t = q & 1;
+    float g[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b) g[a][b] = packed[s2_widx(w, 2 * a + s, 2 * b + t, cf, cc)];
+    float tt[A][2];
+#pragma unroll
+    for (int r = 0; r < A; ++r)
+#pragma unroll
+      for (int b = 0; b < 2; ++b) tt[r][b] = F42::G[r][0] * g[0][b] + F42::G[r][1] * g[1][b];
+    const size_t o = mode == 0 ? ((size_t)(q * Cf + cf) * Cc + cc) : ((size_t)cc * 4 * Cf + q * Cf + cf);
+#pragma unroll
+    for (int a = 0; a < A; ++a)
+#pragma unroll
+      for (int j = 0; j < A; ++j) U[(size_t)(a * A + j) * plane + o] = tt[a][0] * F42::G[j][0] + tt[a][1] * F42::G[j][1];
+  }
+}
+
+// dW[2a+s][2b+t][cf][cc] = (G^T dU_q G)[a][b],  dU[p][q*Cf + cf][cc]
+__global__ __launch_bounds__(256) void wino_s2_filter_grad_kernel(WShape w, int Cf, int Cc, const float* dU, float* dpacked) {
+  constexpr int A = 5;
+  const size_t total = (size_t)Cf * Cc;
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int cf = (int)(i / Cc), cc = (int)(i % Cc);
+  const size_t plane = (size_t)4 * Cf * Cc;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int s = q >> 1, t = q & 1;
+    const size_t o = (size_t)(q * Cf + cf) * Cc + cc;
+    float tt[2][A];
+#pragma unroll
+    for (int b = 0; b < A; ++b) {
+      float u[A];
+#pragma unroll
+      for (int a = 0; a < A; ++a) u[a] = dU[(size_t)(a * A + b) * plane + o];
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        float acc = 0.f;
+#pragma unroll
+        for (int a = 0; a < A; ++a) f1mac(acc, F42::G[a][r], u[a]);
+        tt[r][b] = acc;
+      }
+    }
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        float acc = 0.f;
+#pragma unroll
+        for (int k = 0; k < A; ++k) f1mac(acc, F42::G[k][b], tt[a][k]);
+        dpacked[s2_widx(w, 2 * a + s, 2 * b + t, cf, cc)] = acc;
+      }
+  }
+}
+
 inline unsigned wgrid(size_t total) { return (unsigned)std::min<size_t>(std::max<size_t>((total + 255) / 256, 1), 256 * 32); }
 
 }  // namespace
@@ -600,10 +777,12 @@ static int variant(int m, int r) {
   if (m == 2 && r == 3) return 0;
   if (m == 4 && r == 3) return 1;
   if (m == 3 && r == 4) return 2;
-  throw Error(1, "winograd: supported forms are F(2,3), F(4,3) and F(3,4)");
+  if (m == 4 && r == 2) return 3;            // strided form: output / dy / patch transforms only
+  throw Error(1, "winograd: supported forms are F(2,3), F(4,3), F(3,4) and the strided F(4,2)");
 }
 void wino_input_transform(Stream& s, int m, int r, const TView& x, int pad, int pad_mode, int Th, int Tw, float* V) {
   const int v = variant(m, r);
+  if (v == 3) throw Error(1, "wino_input_transform: F(4,2) is the strided form (wino_s2_input_transform)");
   if (x.C % 4 || x.cs % 4) throw Error(1, "wino_input_transform: C must be a multiple of 4");
   const size_t total = (size_t)x.N * Th * Tw * (x.C / 4);
   const dim3 grid(wgrid(total));
@@ -619,6 +798,7 @@ void wino_input_transform(Stream& s, int m, int r, const TView& x, int pad, int 
 }
 void wino_filter_transform(Stream& s, int m, int r, const WShape& w, int mode, const float* packed, float* U) {
   const int v = variant(m, r);
+  if (v == 3) throw Error(1, "wino_filter_transform: F(4,2) is the strided form (wino_s2_filter_transform)");
   const int K = mode == 0 ? w.Cip : w.Npad, Nn = mode == 0 ? w.Npad : w.Cip;      // modes 1, 2: [Npad][Cip]
   const dim3 grid((unsigned)(((size_t)K * Nn + 255) / 256));
   if (v == 0) hipLaunchKernelGGL(wino_filter_kernel, grid, dim3(256), 0, hs(s), w, mode, K, Nn, packed, U);
@@ -637,8 +817,11 @@ void wino_output_transform(Stream& s, int m, int r, const float* M, int Cm, int 
   else if (v == 1)
     hipLaunchKernelGGL(winog_output_kernel<F43>, grid, dim3(256), 0, hs(s), M, Cm, y.N, Th, Tw, bias, act, y.p, y.cs, y.H,
                        y.W, Cout, accumulate);
-  else
+  else if (v == 2)
     hipLaunchKernelGGL(winog_output_kernel<F34>, grid, dim3(256), 0, hs(s), M, Cm, y.N, Th, Tw, bias, act, y.p, y.cs, y.H,
+                       y.W, Cout, accumulate);
+  else
+    hipLaunchKernelGGL(winog_output_kernel<F42>, grid, dim3(256), 0, hs(s), M, Cm, y.N, Th, Tw, bias, act, y.p, y.cs, y.H,
                        y.W, Cout, accumulate);
   check_launch("wino_output_transform");
 }
@@ -651,13 +834,47 @@ void wino_dy_transform(Stream& s, int m, int r, const TView& dy, int Th, int Tw,
     hipLaunchKernelGGL(wino_dy_kernel, grid, dim3(256), 0, hs(s), dy.p, dy.cs, dy.N, dy.H, dy.W, dy.C, Th, Tw, dM);
   else if (v == 1)
     hipLaunchKernelGGL(winog_dy_kernel<F43>, grid, dim3(256), 0, hs(s), dy.p, dy.cs, dy.N, dy.H, dy.W, dy.C, Th, Tw, dM);
-  else
+  else if (v == 2)
     hipLaunchKernelGGL(winog_dy_kernel<F34>, grid, dim3(256), 0, hs(s), dy.p, dy.cs, dy.N, dy.H, dy.W, dy.C, Th, Tw, dM);
+  else
+    hipLaunchKernelGGL(winog_dy_kernel<F42>, grid, dim3(256), 0, hs(s), dy.p, dy.cs, dy.N, dy.H, dy.W, dy.C, Th, Tw, dM);
   check_launch("wino_dy_transform");
+}
+void wino_s2_input_transform(Stream& s, const TView& x, int Th, int Tw, float* V) {
+  if (x.C % 4 || x.cs % 4) throw Error(1, "wino_s2_input_transform: C must be a multiple of 4");
+  const size_t total = (size_t)x.N * Th * Tw * 4 * (x.C / 4);
+  hipLaunchKernelGGL(wino_s2_input_kernel, dim3(wgrid(total)), dim3(256), 0, hs(s), x.p, x.cs, x.N, x.H, x.W, x.C, Th, Tw, V);
+  check_launch("wino_s2_input_transform");
+}
+void wino_s2_input_adjoint(Stream& s, float* dV, int Cf, int Th, int Tw, const TView& dx, const float* bias, int accumulate) {
+  if (Cf % 4 || dx.C != Cf || dx.cs % 4) throw Error(1, "wino_s2_input_adjoint: bad channel count");
+  const size_t T = (size_t)dx.N * Th * Tw;
+  hipLaunchKernelGGL(winog_patch_kernel<F42>, dim3(wgrid(T * Cf)), dim3(256), 0, hs(s), dV, 4 * Cf, T);
+  hipLaunchKernelGGL(wino_s2_fold_kernel, dim3(wgrid(dx.pixels() * (Cf / 4))), dim3(256), 0, hs(s), dV, Cf, dx.N, dx.H, dx.W, Th, Tw,
+                     bias, dx.p, dx.cs, accumulate);
+  check_launch("wino_s2_input_adjoint");
+}
+static void s2_dims(const WShape& w, int& Cf, int& Cc) {
+  if (w.KH != 4 || w.KW != 4) throw Error(1, "strided Winograd: k4 s2 layers only");
+  Cf = w.kind == WK_CONV ? w.Cip : w.Npad;
+  Cc = w.kind == WK_CONV ? w.Npad : w.Cip;
+}
+void wino_s2_filter_transform(Stream& s, const WShape& w, int mode, const float* packed, float* U) {
+  int Cf, Cc;
+  s2_dims(w, Cf, Cc);
+  hipLaunchKernelGGL(wino_s2_filter_kernel, dim3((unsigned)(((size_t)Cf * Cc + 255) / 256)), dim3(256), 0, hs(s), w, mode, Cf, Cc, packed, U);
+  check_launch("wino_s2_filter_transform");
+}
+void wino_s2_filter_grad(Stream& s, const WShape& w, const float* dU, float* dpacked) {
+  int Cf, Cc;
+  s2_dims(w, Cf, Cc);
+  hipLaunchKernelGGL(wino_s2_filter_grad_kernel, dim3((unsigned)(((size_t)Cf * Cc + 255) / 256)), dim3(256), 0, hs(s), w, Cf, Cc, dU, dpacked);
+  check_launch("wino_s2_filter_grad");
 }
 void wino_input_adjoint(Stream& s, int m, int r, float* dV, int C, int pad, int pad_mode, int Th, int Tw, const TView& dx,
                         int accumulate) {
   const int v = variant(m, r);
+  if (v == 3) throw Error(1, "wino_input_adjoint: F(4,2) is the strided form (wino_s2_input_adjoint)");
   if (C % 4 || dx.C != C || dx.cs % 4) throw Error(1, "wino_input_adjoint: bad channel count");
   const size_t T = (size_t)dx.N * Th * Tw;
   const dim3 grid(wgrid(T * (C / 4)));
@@ -671,6 +888,7 @@ void wino_input_adjoint(Stream& s, int m, int r, float* dV, int C, int pad, int 
 }
 void wino_filter_grad(Stream& s, int m, int r, const WShape& w, const float* dU, float* dpacked) {
   const int v = variant(m, r);
+  if (v == 3) throw Error(1, "wino_filter_grad: F(4,2) is the strided form (wino_s2_filter_grad)");
   const size_t total = (size_t)w.Cip * w.Npad;
   const dim3 grid((unsigned)((total + 255) / 256));
   if (v == 0) hipLaunchKernelGGL(wino_filter_grad_kernel, grid, dim3(256), 0, hs(s), w, dU, dpacked);

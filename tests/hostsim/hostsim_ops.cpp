@@ -204,7 +204,11 @@ static const float kAT43[24] = {1, 1, 1, 1, 1, 0, 0, 1, -1, 2, -2, 0, 0, 1, 1, 4
 static const float kG34[24] = {1.f / 4, 0, 0, 0, -1.f / 6, -1.f / 6, -1.f / 6, -1.f / 6, -1.f / 6, 1.f / 6, -1.f / 6, 1.f / 6,
                                1.f / 24, 1.f / 12, 1.f / 6, 1.f / 3, 1.f / 24, -1.f / 12, 1.f / 6, -1.f / 3, 0, 0, 0, 1};
 static const float kAT34[18] = {1, 1, 1, 1, 1, 0, 0, 1, -1, 2, -2, 0, 0, 1, 1, 4, 4, 1};
+static const float kBT42[25] = {0.5f, -1, -0.5f, 1, 0, 0, -0.5f, 0.5f, 1, 0, 0, 0.5f, -1.5f, 1, 0, 0, -1, 0, 1, 0, 0, 0.5f, -1, -0.5f, 1};
+static const float kG42[10] = {2, 0, 1, 1, -1.f / 3, 1.f / 3, -8.f / 3, -4.f / 3, 0, 1};
+static const float kAT42[20] = {1, 1, 1, 1, 0, 0, 1, -1, 0.5f, 0, 0, 1, 1, 0.25f, 0, 0, 1, -1, 0.125f, 1};
 static WinoMats wino_mats(int m, int r) {
+  if (m == 4 && r == 2) return {4, 2, 5, kBT42, kG42, kAT42};
   if (m == 2 && r == 3) return {2, 3, 4, kBT2, kG2, kAT2};
   if (m == 4 && r == 3) return {4, 3, 6, kBT6, kG43, kAT43};
   if (m == 3 && r == 4) return {3, 4, 6, kBT6, kG34, kAT34};
@@ -288,6 +292,89 @@ void wino_dy_transform(Stream&, int m, int r, const TView& dy, int Th, int Tw, f
         for (int a = 0; a < m; ++a) for (int b = 0; b < m; ++b) s += wm.AT[a * A + i] * g[a][b] * wm.AT[b * A + j];
         dM[((size_t)(i * A + j) * T + tile) * dy.C + c] = s;
       }
+    }
+  }
+}
+// ---- strided Winograd F(4x4, 2x2) (ops.h): plain loops straight from the definition
+void wino_s2_input_transform(Stream&, const TView& x, int Th, int Tw, float* V) {
+  const WinoMats wm = wino_mats(4, 2);
+  const int A = 5, C = x.C;
+  const size_t T = (size_t)x.N * Th * Tw;
+#pragma omp parallel for collapse(3)
+  for (int n = 0; n < x.N; ++n) for (int ty = 0; ty < Th; ++ty) for (int tx = 0; tx < Tw; ++tx) {
+    const size_t tile = ((size_t)n * Th + ty) * Tw + tx;
+    for (int q = 0; q < 4; ++q) for (int c = 0; c < C; ++c) {
+      const int s = q >> 1, t = q & 1;
+      float d[5][5], u[5][5];
+      for (int a = 0; a < A; ++a) for (int b = 0; b < A; ++b) {
+        const int sy = 2 * (4 * ty + a) - 1 + s, sx = 2 * (4 * tx + b) - 1 + t;
+        d[a][b] = (sy >= 0 && sy < x.H && sx >= 0 && sx < x.W) ? at(x, n, sy, sx)[c] : 0.f;
+      }
+      for (int a = 0; a < A; ++a) for (int b = 0; b < A; ++b) { float acc = 0; for (int k = 0; k < A; ++k) acc += wm.BT[a * A + k] * d[k][b]; u[a][b] = acc; }
+      for (int a = 0; a < A; ++a) for (int b = 0; b < A; ++b) { float acc = 0; for (int k = 0; k < A; ++k) acc += u[a][k] * wm.BT[b * A + k];
+        V[((size_t)(a * A + b) * T + tile) * 4 * C + q * C + c] = acc; }
+    }
+  }
+}
+void wino_s2_input_adjoint(Stream&, float* dV, int Cf, int Th, int Tw, const TView& dx, const float* bias, int accumulate) {
+  const WinoMats wm = wino_mats(4, 2);
+  const int A = 5;
+  const size_t T = (size_t)dx.N * Th * Tw;
+  if (!accumulate)
+    for (size_t e = 0; e < dx.pixels(); ++e) std::memset(dx.p + e * dx.cs, 0, Cf * sizeof(float));
+  for (int n = 0; n < dx.N; ++n) for (int ty = 0; ty < Th; ++ty) for (int tx = 0; tx < Tw; ++tx) {
+    const size_t tile = ((size_t)n * Th + ty) * Tw + tx;
+    for (int q = 0; q < 4; ++q) for (int c = 0; c < Cf; ++c) {
+      const int s = q >> 1, t = q & 1;
+      float v[5][5], u[5][5];
+      for (int a = 0; a < A; ++a) for (int b = 0; b < A; ++b) v[a][b] = dV[((size_t)(a * A + b) * T + tile) * 4 * Cf + q * Cf + c];
+      for (int a = 0; a < A; ++a) for (int b = 0; b < A; ++b) { float acc = 0; for (int k = 0; k < A; ++k) acc += wm.BT[k * A + a] * v[k][b]; u[a][b] = acc; }
+      for (int a = 0; a < A; ++a) {
+        const int sy = 2 * (4 * ty + a) - 1 + s;
+        if (sy < 0 || sy >= dx.H) continue;
+        for (int b = 0; b < A; ++b) {
+          const int sx = 2 * (4 * tx + b) - 1 + t;
+          if (sx < 0 || sx >= dx.W) continue;
+          float acc = 0; for (int k = 0; k < A; ++k) acc += u[a][k] * wm.BT[k * A + b];
+          at(dx, n, sy, sx)[c] += acc;
+        }
+      }
+    }
+  }
+  if (bias)
+    for (size_t e = 0; e < dx.pixels(); ++e) for (int c = 0; c < Cf; ++c) dx.p[e * dx.cs + c] += bias[c];
+}
+static size_t s2_widx(const WShape& w, int kh, int kw, int cf, int cc) {
+  if (w.kind == WK_CONV) return ((size_t)(kh * 4 + kw) * w.Cip + cf) * w.Npad + cc;
+  const int a = (3 - kh) & 1, dy = (3 - kh - a) >> 1, b = (3 - kw) & 1, dx = (3 - kw - b) >> 1;
+  return (size_t)(a * 2 + b) * 4 * w.Cip * w.Npad + ((size_t)(dy * 2 + dx) * w.Cip + cc) * w.Npad + cf;
+}
+void wino_s2_filter_transform(Stream&, const WShape& w, int mode, const float* packed, float* U) {
+  const WinoMats wm = wino_mats(4, 2);
+  const int A = 5, Cf = w.kind == WK_CONV ? w.Cip : w.Npad, Cc = w.kind == WK_CONV ? w.Npad : w.Cip;
+  const size_t plane = (size_t)4 * Cf * Cc;
+#pragma omp parallel for
+  for (int cf = 0; cf < Cf; ++cf) for (int cc = 0; cc < Cc; ++cc) for (int q = 0; q < 4; ++q) {
+    const int s = q >> 1, t = q & 1;
+    float g[2][2], u[5][2];
+    for (int a = 0; a < 2; ++a) for (int b = 0; b < 2; ++b) g[a][b] = packed[s2_widx(w, 2 * a + s, 2 * b + t, cf, cc)];
+    for (int a = 0; a < A; ++a) for (int b = 0; b < 2; ++b) u[a][b] = wm.G[a * 2] * g[0][b] + wm.G[a * 2 + 1] * g[1][b];
+    const size_t o = mode == 0 ? ((size_t)(q * Cf + cf) * Cc + cc) : ((size_t)cc * 4 * Cf + q * Cf + cf);
+    for (int a = 0; a < A; ++a) for (int b = 0; b < A; ++b) U[(size_t)(a * A + b) * plane + o] = u[a][0] * wm.G[b * 2] + u[a][1] * wm.G[b * 2 + 1];
+  }
+}
+void wino_s2_filter_grad(Stream&, const WShape& w, const float* dU, float* dpacked) {
+  const WinoMats wm = wino_mats(4, 2);
+  const int A = 5, Cf = w.kind == WK_CONV ? w.Cip : w.Npad, Cc = w.kind == WK_CONV ? w.Npad : w.Cip;
+  const size_t plane = (size_t)4 * Cf * Cc;
+#pragma omp parallel for
+  for (int cf = 0; cf < Cf; ++cf) for (int cc = 0; cc < Cc; ++cc) for (int q = 0; q < 4; ++q) {
+    const int s = q >> 1, t = q & 1;
+    const size_t o = (size_t)(q * Cf + cf) * Cc + cc;
+    for (int a = 0; a < 2; ++a) for (int b = 0; b < 2; ++b) {
+      float acc = 0;
+      for (int i = 0; i < A; ++i) for (int j = 0; j < A; ++j) acc += wm.G[i * 2 + a] * dU[(size_t)(i * A + j) * plane + o] * wm.G[j * 2 + b];
+      dpacked[s2_widx(w, 2 * a + s, 2 * b + t, cf, cc)] = acc;
     }
   }
 }
