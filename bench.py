@@ -351,6 +351,20 @@ def main():
                 "all_gemm_kernels": {n: {"tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2),
                                          "ms_per_step": round(v["ms"] / nprof, 3)} for n, v in sorted(kernels.items())},
             }
+    if rank == 0 and (world > 1 or os.environ.get("SWAPNET_BENCH_PHASED") or rccl1):
+        # measured back-propagation time and gradient bytes of each exchange bucket (what engine.cpp's bucket boundaries are
+        # sized on): HIP events around swn_model_backward_G_part, no exchange in between
+        lab = draw_labels()
+        model.forward(True, 7)
+        model.backward_D(lab[0], lab[1])
+        torch.cuda.synchronize()
+        evs, sizes = [torch.cuda.Event(enable_timing=True)], []
+        evs[0].record()
+        for part in range(model.backward_G_parts()):
+            off, cnt = model.backward_G_part(lab[2], part)
+            e = torch.cuda.Event(enable_timing=True); e.record(); evs.append(e); sizes.append(cnt * 4)
+        torch.cuda.synchronize()
+        out["dp_buckets"] = [{"grad_bytes": sizes[i], "backward_ms": round(evs[i].elapsed_time(evs[i + 1]), 3)} for i in range(len(sizes))]
     if rank == 0 and world == 1 and args.with_h2d and not texture:
         # the boundary hands over host buffers (warp_model.py:99-104): PCIe-inclusive rate, one-hot fp32
         # cloths (the reference's format) and integer label maps (device-side one-hot)

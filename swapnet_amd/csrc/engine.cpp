@@ -180,8 +180,8 @@ ConvGeom conv_geom(ConvKind kind, int H, int W) {
 // re-derived every optimizer step, so the 8-16 M-parameter layers at 4x4 / 8x8 maps stay on the direct kernels.
 namespace {
 bool s2_wino_wanted(int Cfine, int Ccoarse, int Hc, int Wc) {
-  static const bool off = (getenv("SWN_WINOGRAD") && atoi(getenv("SWN_WINOGRAD")) == 0) ||
-                          (getenv("SWN_WINO_S2") && atoi(getenv("SWN_WINO_S2")) == 0);
+  const bool off = (getenv("SWN_WINOGRAD") && atoi(getenv("SWN_WINOGRAD")) == 0) ||       // read per layer built (tests toggle it)
+                   (getenv("SWN_WINO_S2") && atoi(getenv("SWN_WINO_S2")) == 0);
   if (off) return false;
   const int minc_env = getenv("SWN_WINO_MINC") ? atoi(getenv("SWN_WINO_MINC")) : 0;      // (tests: small channel counts too)
   const int minc = minc_env > 0 ? minc_env : 256;
@@ -906,19 +906,44 @@ int Net::split_point(double frac, size_t* arena_off) const {
 }
 
 // Bucket boundaries (fractions of the generator's gradient arena, high to low = backward order).
-// WarpModule: [.70,1] = decoder + resblock convs 5-7, [.41,.70) = resblock convs 1-4, [.10,.41) =
-// cloth_down6, cloth_up1/2, resblock conv 0, [0,.10) = the encoders -- the last (exposed) exchange is
-// 10 % of the bytes, the others overlap the rest of the backward pass.
-static const double kGradCuts[] = {0.70, 0.41, 0.10};
-int Model::backward_G_parts() const { return (int)(sizeof(kGradCuts) / sizeof(kGradCuts[0])) + 1; }
+// WarpModule: [.70,1] = decoder + resblock convs 5-7, [.41,.70) = resblock convs 1-4, [.04,.41) = cloth_down5/6,
+// cloth_up1/2, resblock conv 0, [0,.04) = body_down1-4 + cloth_down1-4.  Sized on the measured back-propagation time of the
+// buckets (bench.py `dp_buckets`, 1 x MI355X, profiles/README.md): a bucket's exchange runs under the NEXT bucket's backward
+// pass, so what matters is (a) every bucket but the last is followed by more backward time than its transfer takes at the
+// ~170 GB/s algorithmic all-reduce rate of 8 GPUs over xGMI, and (b) the last bucket -- whose exchange and AdamW are exposed --
+// is as small as (a) allows for the bucket before it: 22 MB (0.13 ms) instead of the 55 MB of round 2, with 2.5 ms of
+// encoder back-propagation above the 240 MB transfer (1.4 ms) of the third bucket.  SWAPNET_GRAD_CUTS="f1,f2,..." overrides
+// (descending fractions of the arena; read once).
+static std::vector<double> grad_cuts() {
+  static std::vector<double> cuts = [] {
+    std::vector<double> c = {0.70, 0.41, 0.04};
+    if (const char* e = getenv("SWAPNET_GRAD_CUTS")) {
+      std::vector<double> u;
+      for (const char* p = e; *p;) {
+        char* end = nullptr;
+        const double v = strtod(p, &end);
+        if (end == p) break;
+        u.push_back(v);
+        p = *end == ',' ? end + 1 : end;
+      }
+      bool ok = !u.empty() && u.size() <= 15;
+      for (size_t i = 0; i < u.size(); ++i) ok = ok && u[i] > 0.0 && u[i] < 1.0 && (i == 0 || u[i] < u[i - 1]);
+      if (ok) c = u;
+    }
+    return c;
+  }();
+  return cuts;
+}
+int Model::backward_G_parts() const { return (int)grad_cuts().size() + 1; }
 
 void Model::backward_G_part(float label_real, int part, size_t* ready_off, size_t* ready_count) {
   const int np = backward_G_parts();
   if (part < 0 || part >= np) throw Error(1, "backward_G_part: part out of range");
   size_t hi_off = arenaG.n, lo_off = 0;
   int hi_op = (int)G->ops.size(), lo_op = 0;
-  if (part > 0) hi_op = G->split_point(kGradCuts[part - 1], &hi_off);
-  if (part < np - 1) lo_op = G->split_point(kGradCuts[part], &lo_off);
+  const std::vector<double> cuts = grad_cuts();
+  if (part > 0) hi_op = G->split_point(cuts[part - 1], &hi_off);
+  if (part < np - 1) lo_op = G->split_point(cuts[part], &lo_off);
   if (part == 0) {
     backward_G_head(label_real);
     G->refresh_dgrad();
