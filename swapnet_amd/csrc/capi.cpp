@@ -451,6 +451,9 @@ int swn_op_conv(swn_ctx* ctx, int kind, int transposed, int what, int naive, flo
     REQUIRE(ctx && x && wgt && y, "NULL argument");
     REQUIRE(kind >= 0 && kind <= 4 && what >= 0 && what <= 2, "bad kind/what");
     REQUIRE(what == 0 || act == ACT_NONE, "backward entry points take the gradient of the pre-activation output");
+    // (set before the net is built: with the checkers forced no pre-cut-only operands are planned)
+    struct Restore { ~Restore() { conv_force_naive(0); } } restore;
+    conv_force_naive(naive);
     Ctx tmp(ctx->c->s);
     ParamArena A;
     Net net(tmp, A);
@@ -469,8 +472,6 @@ int swn_op_conv(swn_ctx* ctx, int kind, int transposed, int what, int naive, flo
     net.finalize({});
     Stream& s = tmp.s;
     const ParamDesc& wd = A.params[A.index.at("l.weight")];
-    struct Restore { ~Restore() { conv_force_naive(0); } } restore;
-    conv_force_naive(naive);
     if (what != 2) nchw_to_nhwc(s, x, n, ci, h, w, xv.v);
     if (what != 1) pack_weight(s, wd.ws, wgt, A.w + wd.off);
     if (bias) dev_copy(s, A.w + A.params[A.index.at("l.bias")].off, bias, co * sizeof(float));

@@ -2210,6 +2210,9 @@ static bool dma_on() {
   return on;
 }
 
+static int g_force_naive = 0;
+void conv_force_naive(int on) { g_force_naive = on; }
+
 // ---- pre-cut ring kernel: schedule + launch ------------------------------------------------------------------------
 static bool pc_on() {
   const bool on = !(getenv("SWN_PRECUT") && atoi(getenv("SWN_PRECUT")) == 0);      // read per launch (tests / A-B runs)
@@ -2249,7 +2252,7 @@ static void launch_fwd_pc(Stream& s, GemmP& p, int nb, const unsigned short* wpc
 // pre-cut for (0 = the launch does not take the pre-cut ring kernel: no operand needs to be produced)
 int conv_precut_tile(int xC, int Npad) {
   static const bool off = getenv("SWN_PRECUT") && atoi(getenv("SWN_PRECUT")) == 0;
-  if (off || !dma_on() || !split_on() || xC % 16 || Npad <= 32) return 0;
+  if (off || g_force_naive || !dma_on() || !split_on() || xC % 16 || Npad <= 32) return 0;
   return Npad > 64 ? 128 : 64;
 }
 size_t conv_precut_elems(int K, int Npad, int bn) {
@@ -2275,8 +2278,6 @@ static bool narrow_on() {
   return on;
 }
 
-static int g_force_naive = 0;
-void conv_force_naive(int on) { g_force_naive = on; }
 
 // per-phase form of a tail4 launch (ops.h): the reference path and the fallback of the fused kernels
 template <class Args>
@@ -2341,6 +2342,8 @@ void conv_fwd(Stream& s, const ConvFwdArgs& a) {
       else launch_fwd_pc<8, 2, 3, 2>(s, p, nb, a.wpc, a.wpc_bs);                   // 256 x 64, 3 stages, 2 workgroups / CU
       return;
     }
+    if (!a.w) throw Error(1, "conv_fwd: the weight operand exists in pre-cut form only, but this launch cannot take the pre-cut "
+                             "kernel (SWN_SPLIT / SWN_PRECUT / SWN_DMA must not change after a model is built)");
     if (a.Npad > 64) {
       // 128 x 128 (4 waves, 3 workgroups / CU) unless the 128 x 256 tile (8 waves, 2 / CU: 512 slots instead of 768)
       // quantises the launch better: the resblock input gradient (M 800, N 1024 x 36 planes) is 2016 tiles = 2.6
@@ -2355,6 +2358,7 @@ void conv_fwd(Stream& s, const ConvFwdArgs& a) {
     else launch_fwd_dma<4, 1>(s, p, nb);                 // 256 x 64
     return;
   }
+  if (!a.w) throw Error(1, "conv_fwd: pre-cut-only weight operand on a launch outside the ring kernel's shapes");
   if (t192 && a.Npad > 128 && a.Npad <= 192) launch_fwd<2, 3, 2, 2>(s, p, fast, nb);
   else if (a.Npad > 64 && big && fast && p.M >= 2048) launch_fwd<2, 2, 4, 2>(s, p, fast, nb);
   else if (a.Npad > 64) launch_fwd<2, 2, 2, 2>(s, p, fast, nb);

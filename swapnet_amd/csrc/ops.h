@@ -130,6 +130,10 @@ void wino_input_transform(Stream& s, int m, int r, const TView& x, int pad, int 
 // mode 0: U[P][Cip][Npad] for the forward conv; mode 1: U[P][Npad][Cip] (flipped, transposed) for the transposed-conv form of
 // dgrad; mode 2: U[P][Npad][Cip] = mode 0 with the channel axes swapped, the operand of the adjoint form (wino_input_adjoint)
 void wino_filter_transform(Stream& s, int m, int r, const WShape& w, int mode, const float* packed, float* U);
+// the same transform (modes 0 and 2, 6-point forms) written straight into the pre-cut operand layout of the ring kernel
+// (conv_precut's, one panel of `panel_elems` = conv_precut_elems(K, N, bn) uint16 per Winograd plane): no fp32 U at all
+void wino_filter_transform_pc(Stream& s, int m, int r, const WShape& w, int mode, const float* packed, int bn, uint16_t* out,
+                              size_t panel_elems);
 // Input gradient in the forward tiling: dV[P][T][C] = dM U^T (dM = wino_dy_transform of dY, T = dx.N * Th * Tw forward tiles).
 // dx (+)= sum over tiles of the patches BT^T dV_t BT placed where wino_input_transform(pad, pad_mode, Th, Tw) gathered them
 // (reflected / dropped exactly like the forward gather).  dV is overwritten (scratch).

@@ -768,6 +768,84 @@ __global__ __launch_bounds__(256) void wino_s2_filter_grad_kernel(WShape w, int 
   }
 }
 
+
+// ---- filter transform straight into the PRE-CUT operand layout of the ring kernel (conv_gemm.hip conv_fwd_pc_kernel) ----------
+// U[p][k][n] as above (mode 0: k = ci, n = co; mode 2: k = co, n = ci), but each thread produces the 8 consecutive k of one
+// (k / 8, column) entry, cuts them into the three bf16 planes and writes the 16-byte entries of
+//   out[p][stage = k / 16][tile_n][kq 2][plane 3][pos BN][8 k],  pos = (n % NB) * 32 + n / NB  (NB = BN / 32).
+// The fp32 U is never materialised: 6 B instead of 4 B written per element, nothing re-read by a separate conv_precut pass.
+typedef unsigned wu32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void cut8_store(const float (&u)[8], wu32x4* o, size_t e0, size_t plane_stride) {
+  unsigned hi[4], mid[4], lo[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float x0 = u[2 * j], x1 = u[2 * j + 1];
+    const unsigned u0 = __float_as_uint(x0), u1 = __float_as_uint(x1);
+    const float r0 = x0 - __uint_as_float(u0 & 0xffff0000u), r1 = x1 - __uint_as_float(u1 & 0xffff0000u);
+    const unsigned v0 = __float_as_uint(r0), v1 = __float_as_uint(r1);
+    const float s0 = r0 - __uint_as_float(v0 & 0xffff0000u), s1 = r1 - __uint_as_float(v1 & 0xffff0000u);
+    hi[j] = (u0 >> 16) | (u1 & 0xffff0000u);
+    mid[j] = (v0 >> 16) | (v1 & 0xffff0000u);
+    lo[j] = (__float_as_uint(s0) >> 16) | (__float_as_uint(s1) & 0xffff0000u);
+  }
+  o[e0] = wu32x4{hi[0], hi[1], hi[2], hi[3]};
+  o[e0 + plane_stride] = wu32x4{mid[0], mid[1], mid[2], mid[3]};
+  o[e0 + 2 * plane_stride] = wu32x4{lo[0], lo[1], lo[2], lo[3]};
+}
+
+template <class F>
+__global__ __launch_bounds__(256) void winog_filter_pc_kernel(WShape w, int mode, int K, int Nn, int BN, const float* packed,
+                                                              unsigned short* out, size_t panel_elems) {
+  constexpr int A = F::A, R = F::R;
+  const int NBc = BN / 32, tiles_n = (Nn + BN - 1) / BN;
+  const size_t total = (size_t)(K / 8) * tiles_n * BN;
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int pos = (int)(i % BN); const size_t q = i / BN;
+  const int tn = (int)(q % tiles_n), kq = (int)(q / tiles_n);
+  const int n = tn * BN + (pos % 32) * NBc + pos / 32;
+  // t[k][r][b] = (G g)[r][b] for the 8 k of this entry
+  float t[8][A][R];
+#pragma unroll
+  for (int kk = 0; kk < 8; ++kk) {
+    const int k = kq * 8 + kk;
+    float g[R][R];
+#pragma unroll
+    for (int a = 0; a < R; ++a)
+#pragma unroll
+      for (int b = 0; b < R; ++b) {
+        float v = 0.f;
+        if (mode == 0) { if (k < w.Cip && n < w.Npad) v = packed[((size_t)(a * R + b) * w.Cip + k) * w.Npad + n]; }
+        else { if (n < w.Cip && k < w.Npad) v = packed[((size_t)(a * R + b) * w.Cip + n) * w.Npad + k]; }
+        g[a][b] = v;
+      }
+#pragma unroll
+    for (int r = 0; r < A; ++r)
+#pragma unroll
+      for (int b = 0; b < R; ++b) {
+        float s = 0.f;
+#pragma unroll
+        for (int qq = 0; qq < R; ++qq) f1mac(s, F::G[r][qq], g[qq][b]);
+        t[kk][r][b] = s;
+      }
+  }
+  const size_t e0 = ((((size_t)(kq >> 1) * tiles_n + tn) * 2 + (kq & 1)) * 3) * BN + pos;      // in 16-byte entries
+#pragma unroll
+  for (int a = 0; a < A; ++a)
+#pragma unroll
+    for (int j = 0; j < A; ++j) {
+      float u[8];
+#pragma unroll
+      for (int kk = 0; kk < 8; ++kk) {
+        float s = 0.f;
+#pragma unroll
+        for (int qq = 0; qq < R; ++qq) f1mac(s, F::G[j][qq], t[kk][a][qq]);
+        u[kk] = s;
+      }
+      cut8_store(u, reinterpret_cast<wu32x4*>(out + (size_t)(a * A + j) * panel_elems), e0, (size_t)BN);
+    }
+}
+
 inline unsigned wgrid(size_t total) { return (unsigned)std::min<size_t>(std::max<size_t>((total + 255) / 256, 1), 256 * 32); }
 
 }  // namespace
@@ -805,6 +883,21 @@ void wino_filter_transform(Stream& s, int m, int r, const WShape& w, int mode, c
   else if (v == 1) hipLaunchKernelGGL(winog_filter_kernel<F43>, grid, dim3(256), 0, hs(s), w, mode, K, Nn, packed, U);
   else hipLaunchKernelGGL(winog_filter_kernel<F34>, grid, dim3(256), 0, hs(s), w, mode, K, Nn, packed, U);
   check_launch("wino_filter_transform");
+}
+void wino_filter_transform_pc(Stream& s, int m, int r, const WShape& w, int mode, const float* packed, int bn, uint16_t* out,
+                              size_t panel_elems) {
+  const int v = variant(m, r);
+  if (v != 1 && v != 2) throw Error(1, "wino_filter_transform_pc: the 6-point forms F(4,3) / F(3,4) only");
+  if (mode != 0 && mode != 2) throw Error(1, "wino_filter_transform_pc: mode 0 or 2");
+  const int K = mode == 0 ? w.Cip : w.Npad, Nn = mode == 0 ? w.Npad : w.Cip;
+  if (K % 16 || (bn != 64 && bn != 128)) throw Error(1, "wino_filter_transform_pc: K must be a multiple of 16, tile 64 or 128");
+  const size_t total = (size_t)(K / 8) * ((Nn + bn - 1) / bn) * bn;
+  const dim3 grid((unsigned)((total + 255) / 256));
+  if (v == 1)
+    hipLaunchKernelGGL(winog_filter_pc_kernel<F43>, grid, dim3(256), 0, hs(s), w, mode, K, Nn, bn, packed, out, panel_elems);
+  else
+    hipLaunchKernelGGL(winog_filter_pc_kernel<F34>, grid, dim3(256), 0, hs(s), w, mode, K, Nn, bn, packed, out, panel_elems);
+  check_launch("wino_filter_transform_pc");
 }
 void wino_output_transform(Stream& s, int m, int r, const float* M, int Cm, int Th, int Tw, const float* bias, int act,
                            const TView& y, int Cout, int accumulate) {

@@ -143,6 +143,9 @@ void conv_fwd_naive(Stream& s, const ConvFwdArgs& a) { conv_fwd(s, a); }
 int conv_precut_tile(int, int) { return 0; }             // the simulator multiplies in plain fp32 / fp64: no pre-cut operands
 size_t conv_precut_elems(int, int, int) { return 0; }
 void conv_precut(Stream&, const float*, int, int, int, int, size_t, uint16_t*) {}
+void wino_filter_transform_pc(Stream&, int, int, const WShape&, int, const float*, int, uint16_t*, size_t) {
+  throw Error(1, "hostsim: no pre-cut operands");
+}
 
 static void conv_wgrad_one(const ConvWgradArgs& a) {
   const TView& X = a.x; const Gather& g = a.g;

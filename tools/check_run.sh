@@ -6,8 +6,8 @@ R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/$TAG
 mkdir -p $O
 cd $R
-timeout 900 python -m pytest $SEL -m gpu -x -q > $O/tests_gpu.log 2>&1
-tail -15 $O/tests_gpu.log
+SWAPNET_TEST_VERBOSE=1 timeout 1200 python -m pytest $SEL -m gpu -q -s > $O/tests_gpu.log 2>&1
+grep -E 'native .* torch fp32|passed|failed|FAILED|one-signed' $O/tests_gpu.log | tail -80
 timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline > $O/bench_c2.json 2> $O/bench_c2.err
 python -c "import json;d=json.load(open('$O/bench_c2.json'));print(d['value'],d['ms_per_step'],d['roofline']['achieved'],d['roofline']['frac'])"
 SWN_PRECUT=0 timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-roofline > $O/bench_c2_noprecut.json 2> /dev/null
