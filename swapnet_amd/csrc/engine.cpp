@@ -254,7 +254,7 @@ void Net::conv(const std::string& name, const Var& x, const Var& y, ConvKind kin
         wa.dw = n.dg + dwt_off; wa.Npad = 16; wa.Cout = 16;
         conv_wgrad(sw, wa);
         head_unpack_grad(sw, wd.ws, n.dg + dwt_off, A->g + wd.off);
-        if (bi >= 0) bias_grad(sw, ygv, A->g + A->params[bi].off);
+        if (bi >= 0) n.bias_grad_of(sw, ygv, A->g + A->params[bi].off);
       }
       if (me.reads_net_input && !igrad) return;
       ConvFwdArgs d;
@@ -324,7 +324,7 @@ void Net::conv(const std::string& name, const Var& x, const Var& y, ConvKind kin
         g.batch = sP; g.x_bs = sT * CV; g.dy_bs = sT * Cop; g.dw_bs = (size_t)CV * Cop;
         conv_wgrad(sw, g);
         wino_s2_filter_grad(sw, wd.ws, n.wsU, A->g + wd.off);
-        if (bi >= 0) bias_grad(sw, dY, A->g + A->params[bi].off);
+        if (bi >= 0) n.bias_grad_of(sw, dY, A->g + A->params[bi].off);
       }
       if (!want_dx || (me.reads_net_input && !igrad)) return;
       wino_dy_transform(n.ctx.s, 4, 2, dY, sTh, sTw, n.wsV);
@@ -370,9 +370,17 @@ void Net::conv(const std::string& name, const Var& x, const Var& y, ConvKind kin
   const int wP = (wm + wr - 1) * (wm + wr - 1);
   const int wN = x.v.N, wTh = ceil_div(y.v.H, wm), wTw = ceil_div(y.v.W, wm);
   const size_t wT = (size_t)wN * wTh * wTw;
-  // dgrad = the adjoint of the forward Winograd pipeline, in the forward tiling: dV = (A dY A^T) U^T, dx = adjoint input
-  // transform (ops.h wino_input_adjoint).  (Until round 2: the transposed stride-1 conv over dY on the -- for reflect
-  // padding: padded -- input grid, 25 tiles per 16x16 map instead of 16.)
+  // dgrad of the REFLECT-padded convs (the resblocks) = the adjoint of the forward Winograd pipeline, in the forward tiling:
+  // dV = (A dY A^T) U^T, dx = adjoint input transform (ops.h wino_input_adjoint) -- 16 tiles per 16x16 map where the
+  // transposed-conv form below walks the 18x18 padded gradient grid in 25.  The zero-padded convs (VGG16, PatchGAN's k4 s1)
+  // keep the transposed stride-1 conv over dY (pad r-1-p): same tile count either way, and it is the better-conditioned form
+  // (its large-entry matrices B^T / A^T act on data, not on the GEMM's output).  SWN_WINO_ADJOINT=0/2: never / always adjoint.
+  const int wadj_env = getenv("SWN_WINO_ADJOINT") ? atoi(getenv("SWN_WINO_ADJOINT")) : 1;
+  const bool wadj = wadj_env == 2 || (wadj_env == 1 && kind == CK_K3S1_REFLECT);
+  const int wpad2 = kind == CK_K3S1_ZERO ? 1 : 2;
+  const int wTh2 = ceil_div(x.v.H + (kind == CK_K3S1_REFLECT ? 2 : 0), wm);
+  const int wTw2 = ceil_div(x.v.W + (kind == CK_K3S1_REFLECT ? 2 : 0), wm);
+  const size_t wT2 = wadj ? 0 : (size_t)wN * wTh2 * wTw2;
   size_t uf_off = 0, ub_off = 0;
   float* keepV = nullptr;         // V = B^T d B of the forward input, reused by the weight gradient
   if (wino && keep_wino_inputs && y.has_grad) keepV = static_cast<float*>(ctx.alloc((size_t)wP * wT * Cip * sizeof(float)));
@@ -385,8 +393,8 @@ void Net::conv(const std::string& name, const Var& x, const Var& y, ConvKind kin
   if (wino) {
     if (pcw) pcw_off = reserve_dgp(pcw_bs * wP);
     else uf_off = reserve_dg(self, (size_t)wP * Cip * Cop);
-    wsV_need = std::max(wsV_need, (size_t)wP * wT * std::max(Cip, Cop));
-    wsM_need = std::max(wsM_need, (size_t)wP * wT * std::max(Cip, Cop));
+    wsV_need = std::max(wsV_need, std::max((size_t)wP * wT * std::max(Cip, Cop), (size_t)wP * wT2 * Cop));
+    wsM_need = std::max(wsM_need, std::max((size_t)wP * wT * std::max(Cip, Cop), (size_t)wP * wT2 * Cip));
     wsU_need = std::max(wsU_need, (size_t)wP * Cip * Cop);
   }
   auto plane_view = [](float* p, size_t T, int C) {
@@ -453,7 +461,7 @@ void Net::conv(const std::string& name, const Var& x, const Var& y, ConvKind kin
       else ub_off = reserve_dg(self, (size_t)wP * Cop * Cip);
     }
     else dg_off = reserve_dg(self, dgrad_elems(arena.params[wi].ws, dg_mode, Cop, Ndg));
-    if (kind == CK_K3S1_REFLECT && !wino) dxpad = alloc_var(x.v.N, dHo, dWo, Cip, false);
+    if (kind == CK_K3S1_REFLECT && !(wino && wadj)) dxpad = alloc_var(x.v.N, dHo, dWo, Cip, false);
     op->grad_targets.push_back(x);
     if (!wino) {
       // K4S2: four phase panels of 2x2 taps; stride-1: one panel of KH x KW taps over dY (Cop channels)
@@ -477,8 +485,8 @@ void Net::conv(const std::string& name, const Var& x, const Var& y, ConvKind kin
       if (pcw) wino_filter_transform_pc(n.ctx.s, wm, wr, wd.ws, 0, A->w + wd.off, pcw, n.dgp + pcw_off, pcw_bs);
       else wino_filter_transform(n.ctx.s, wm, wr, wd.ws, 0, A->w + wd.off, n.dg + uf_off);
       if (wdx) {
-        if (pcwt_c) wino_filter_transform_pc(n.ctx.s, wm, wr, wd.ws, 2, A->w + wd.off, pcwt_c, n.dgp + pcwt_o, pcwt_b);
-        else wino_filter_transform(n.ctx.s, wm, wr, wd.ws, 2, A->w + wd.off, n.dg + ub_off);
+        if (pcwt_c) wino_filter_transform_pc(n.ctx.s, wm, wr, wd.ws, wadj ? 2 : 1, A->w + wd.off, pcwt_c, n.dgp + pcwt_o, pcwt_b);
+        else wino_filter_transform(n.ctx.s, wm, wr, wd.ws, wadj ? 2 : 1, A->w + wd.off, n.dg + ub_off);
       }
     };
   }
@@ -532,10 +540,28 @@ void Net::conv(const std::string& name, const Var& x, const Var& y, ConvKind kin
         conv_wgrad(sw, wa);
         tail_unfold_wgrad(sw, wd.ws, n.dg + dfold_off, A->g + wd.off);
       }
-      if (bi >= 0) bias_grad(sw, dY, A->g + A->params[bi].off);
+      if (bi >= 0) n.bias_grad_of(sw, dY, A->g + A->params[bi].off);
     }
     if (!want_dx || (me.reads_net_input && !igrad)) return;
     const int accf = me.acc.empty() ? 0 : me.acc[0];
+    if (wino && !wadj) {
+      // input gradient = the transposed stride-1 conv over dY (flipped, channel-transposed filter)
+      wino_input_transform(n.ctx.s, wm, wr, dY, wpad2, PAD_ZERO, wTh2, wTw2, n.wsV);
+      ConvFwdArgs g;
+      g.x = plane_view(n.wsV, wT2, Cop); g.g.Ho = 1; g.g.Wo = (int)wT2;
+      g.w = pcwt ? nullptr : n.dg + ub_off; g.Npad = Cip; g.Cout = Cip;
+      if (pcwt) { g.wpc = n.dgp + pcwt_off; g.wpc_bn = pcwt; g.wpc_bs = pcwt_bs; }
+      g.y = plane_view(n.wsM, wT2, Cip);
+      g.batch = wP; g.x_bs = wT2 * Cop; g.w_bs = (size_t)Cop * Cip; g.y_bs = wT2 * Cip;
+      conv_fwd(n.ctx.s, g);
+      if (kind == CK_K3S1_REFLECT) {
+        wino_output_transform(n.ctx.s, wm, wr, n.wsM, Cip, wTh2, wTw2, nullptr, ACT_NONE, dxp, Cip, 0);
+        reflect_fold(n.ctx.s, dxp, xgv, accf);
+      } else {
+        wino_output_transform(n.ctx.s, wm, wr, n.wsM, Cip, wTh2, wTw2, nullptr, ACT_NONE, xgv, Cip, accf);
+      }
+      return;
+    }
     if (wino) {
       // input gradient in the forward tiling: dM = A dY A^T, dV = dM U^T (U with the channel axes swapped), then the adjoint
       // of the input transform scatters the patches BT^T dV BT back through the forward gather (padding rule included)
@@ -648,7 +674,7 @@ void Net::convT(const std::string& name, const Var& x, const Var& y, int Co, boo
         g.batch = sP; g.x_bs = sT * CV; g.dy_bs = sT * Cip; g.dw_bs = (size_t)CV * Cip;
         conv_wgrad(sw, g);
         wino_s2_filter_grad(sw, wd.ws, n.wsU, A->g + wd.off);
-        if (bi >= 0) bias_grad(sw, ygv, A->g + A->params[bi].off);
+        if (bi >= 0) n.bias_grad_of(sw, ygv, A->g + A->params[bi].off);
       }
       if (!want_dx || (me.reads_net_input && !igrad)) return;
       wino_s2_input_transform(n.ctx.s, ygv, sTh, sTw, n.wsV);
@@ -708,7 +734,7 @@ void Net::convT(const std::string& name, const Var& x, const Var& y, int Co, boo
       wa.dw = A->g + wd.off; wa.dw_bs = phase_elems; wa.Npad = wd.ws.Npad; wa.Cout = Co;
       Stream& sw = n.wgrad_stream();
       conv_wgrad(sw, wa);
-      if (bi >= 0) bias_grad(sw, ygv, A->g + A->params[bi].off);
+      if (bi >= 0) n.bias_grad_of(sw, ygv, A->g + A->params[bi].off);
     }
     if (!want_dx || (me.reads_net_input && !igrad)) return;
     ConvFwdArgs d;
@@ -742,11 +768,16 @@ void Net::norm_act(const Var& raw, const Var& y, bool norm, int actf, float drop
   };
   if (has_res && res.has_grad && y.has_grad) op->grad_targets.push_back(res);
   const bool do_bwd = y.has_grad && raw.has_grad;
+  double* colsum = nullptr;
+  if (do_bwd && norm && norm_act_bwd_emits_colsum(raw.v.H * raw.v.W, raw.v.C) && raw.g.cs == raw.g.C) {
+    colsum = static_cast<double*>(ctx.alloc((size_t)raw.v.N * raw.v.C * sizeof(double)));
+    colsums[raw.g.p] = {colsum, raw.v.N};
+  }
   op->bwd = [=](Net& n, Op& me, bool, bool) {
     if (!do_bwd) return;
     if (has_res && res.has_grad) axpy(n.ctx.s, yg, res.g, 1.f, me.acc.empty() ? 0 : me.acc[0]);
     NormActBwdArgs b;
-    b.dy = yg; b.x = rv; b.stats = stats; b.dx = rg; b.norm = norm; b.act = actf;
+    b.dy = yg; b.x = rv; b.stats = stats; b.dx = rg; b.norm = norm; b.act = actf; b.colsum = colsum;
     b.drop_p = n.training ? drop_p : 0.f; b.seed = Net::drop_seed(n.seed, salt);
     norm_act_bwd(n.ctx.s, b);
   };

@@ -143,6 +143,14 @@ class Net {
   std::vector<std::pair<Op*, size_t>> dg_layout;
   // dropout sites in forward order (one per norm_act with drop_p > 0): what swn_model_dropout_mask exports
   float* last_stats = nullptr;        // (mean, rstd) buffer of the most recently built norm_act op (op-level entry points)
+  // gradient buffers whose per-image column sums the InstanceNorm backward leaves behind (ops.h NormActBwdArgs::colsum): the
+  // bias gradient of the conv that produced the normalised tensor is then a sum over N values per channel
+  std::map<const float*, std::pair<double*, int>> colsums;
+  void bias_grad_of(Stream& s, const TView& dy, float* db) {
+    auto it = colsums.find(dy.p);
+    if (it != colsums.end() && it->second.second == dy.N) bias_grad_from_colsums(s, it->second.first, dy.N, dy.C, db);
+    else bias_grad(s, dy, db);
+  }
   struct DropSite { uint64_t salt; int N, H, W, C; float p; };
   std::vector<DropSite> drop_sites;
   static uint64_t drop_seed(uint64_t seed, uint64_t salt) { return seed * 0x9E3779B1ull + salt; }

@@ -28,6 +28,7 @@ struct NAp {
   const float* dy; int dycs;    // bwd only
   const float* res; int rescs;  // fwd residual
   float* stats;                 // [N][C][2]
+  double* colsum;               // bwd, optional: [N][C] column sums of dx
   double* partial;              // [N][nchunk][C][2]
   double* sums;                 // bwd: [N][C][2] = mean(dxh), mean(dxh*xh)
   int N, HW, C, nchunk, chunk;
@@ -367,6 +368,7 @@ __global__ __launch_bounds__(256) void in_fused_bwd_kernel(NAp p) {
   double m1[4], m2[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) { m1[j] = s[j] / p.HW; m2[j] = s[4 + j] / p.HW; }
+  double cs[4] = {0, 0, 0, 0};
 #pragma unroll
   for (int i = 0; i < NP; ++i) {
     const int pix = ty + i * ROWS;
@@ -376,14 +378,23 @@ __global__ __launch_bounds__(256) void in_fused_bwd_kernel(NAp p) {
     const float g[4] = {gv[i].x, gv[i].y, gv[i].z, gv[i].w};
     float o[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int j = 0; j < 4; ++j) {
       o[j] = (float)((double)rstd[j] * ((double)g[j] - m1[j] - (((double)xa[j] - (double)mean[j]) * (double)rstd[j]) * m2[j]));
+      cs[j] += o[j];
+    }
     *reinterpret_cast<float4*>(p.y + e * p.ycs + c) = make_float4(o[0], o[1], o[2], o[3]);
+  }
+  if (p.colsum) {                      // (block-uniform) bias gradient of the producing conv: sum of dx over this image's pixels
+    block_tree_sum<ROWS, 4>(red, cs, tx, ty, C4);
+    if (ty == 0) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) p.colsum[(size_t)n * p.C + c + j] = cs[j];
+    }
   }
 }
 
 static bool fused_in_on() {
-  const bool on = !(getenv("SWN_FUSED_IN") && atoi(getenv("SWN_FUSED_IN")) == 0);       // read per launch: tests toggle it
+  static const bool on = !(getenv("SWN_FUSED_IN") && atoi(getenv("SWN_FUSED_IN")) == 0);  // fixed per process (buffers are planned on it)
   return on;
 }
 
@@ -568,6 +579,8 @@ void norm_act_bwd(Stream& s, const NormActBwdArgs& a) {
   p.x = a.x.p; p.xcs = a.x.cs; p.dy = a.dy.p; p.dycs = a.dy.cs; p.y = a.dx.p; p.ycs = a.dx.cs;
   p.stats = const_cast<float*>(a.stats); p.N = a.x.N; p.HW = a.x.H * a.x.W; p.C = a.x.C;
   p.norm = a.norm; p.act = a.act; p.drop_p = a.drop_p; p.seed = a.seed;
+  p.colsum = a.colsum;
+  if (a.colsum && !(a.norm && norm_act_bwd_emits_colsum(p.HW, p.C))) throw Error(1, "norm_act_bwd: colsum requested on the chunked path");
   if (a.norm && p.HW <= 1024 && p.C % 32 == 0 && fused_in_on()) {
     if (p.HW <= 64) hipLaunchKernelGGL((in_fused_bwd_kernel<32, 2>), dim3(p.C / 32, p.N), dim3(256), 0, hs(s), p);
     else if (p.HW <= 256) hipLaunchKernelGGL((in_fused_bwd_kernel<32, 8>), dim3(p.C / 32, p.N), dim3(256), 0, hs(s), p);
@@ -589,6 +602,14 @@ void norm_act_bwd(Stream& s, const NormActBwdArgs& a) {
   check_launch("norm_act_bwd");
 }
 
+bool norm_act_bwd_emits_colsum(int HW, int C) {
+  static const bool on = !(getenv("SWN_FUSED_IN") && atoi(getenv("SWN_FUSED_IN")) == 0);     // (fixed per process: buffers are planned on it)
+  return on && HW <= 1024 && C % 32 == 0;
+}
+void bias_grad_from_colsums(Stream& s, const double* partial, int N, int C, float* db) {
+  hipLaunchKernelGGL(colsum_final_kernel, dim3(ceil_div(C, 16)), dim3(256), 0, hs(s), partial, N, C, db);
+  check_launch("bias_grad_from_colsums");
+}
 void dropout_mask(Stream& s, int N, int H, int W, int C, float p, uint64_t seed, float* out_nchw) {
   hipLaunchKernelGGL(dropout_mask_kernel, dim3(ew_grid((size_t)N * H * W * C)), dim3(256), 0, hs(s), N, H * W, C, p, seed,
                      out_nchw);

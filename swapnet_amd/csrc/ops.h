@@ -176,8 +176,14 @@ struct NormActBwdArgs {
   int act = ACT_NONE;
   float drop_p = 0.f;
   uint64_t seed = 0;
+  // optional [N][C] (fp64): per-image column sums of dx -- the bias gradient of the conv that produced x, for free while the
+  // slab is in registers.  Written only by launches for which norm_act_bwd_emits_colsum(H * W, C) holds.
+  double* colsum = nullptr;
 };
 void norm_act_bwd(Stream& s, const NormActBwdArgs& a);
+bool norm_act_bwd_emits_colsum(int HW, int C);
+// db[c] = sum_n partial[n][c]   (fixed order)
+void bias_grad_from_colsums(Stream& s, const double* partial, int N, int C, float* db);
 
 // The keep/scale factor norm_act_fwd / norm_act_bwd apply at a dropout site, written out as an NCHW tensor
 // (N,C,H,W): element (n,c,h,w) = drop_scale(seed, ((n*H*W + h*W + w)*C + c), p) -- 0 or 1/(1-p).

@@ -816,6 +816,7 @@ __global__ __launch_bounds__(256) void winog_filter_pc_kernel(WShape w, int mode
       for (int b = 0; b < R; ++b) {
         float v = 0.f;
         if (mode == 0) { if (k < w.Cip && n < w.Npad) v = packed[((size_t)(a * R + b) * w.Cip + k) * w.Npad + n]; }
+        else if (mode == 1) { if (n < w.Cip && k < w.Npad) v = packed[((size_t)((R - 1 - a) * R + (R - 1 - b)) * w.Cip + n) * w.Npad + k]; }
         else { if (n < w.Cip && k < w.Npad) v = packed[((size_t)(a * R + b) * w.Cip + n) * w.Npad + k]; }
         g[a][b] = v;
       }
@@ -888,7 +889,7 @@ void wino_filter_transform_pc(Stream& s, int m, int r, const WShape& w, int mode
                               size_t panel_elems) {
   const int v = variant(m, r);
   if (v != 1 && v != 2) throw Error(1, "wino_filter_transform_pc: the 6-point forms F(4,3) / F(3,4) only");
-  if (mode != 0 && mode != 2) throw Error(1, "wino_filter_transform_pc: mode 0 or 2");
+  if (mode < 0 || mode > 2) throw Error(1, "wino_filter_transform_pc: mode 0, 1 or 2");
   const int K = mode == 0 ? w.Cip : w.Npad, Nn = mode == 0 ? w.Npad : w.Cip;
   if (K % 16 || (bn != 64 && bn != 128)) throw Error(1, "wino_filter_transform_pc: K must be a multiple of 16, tile 64 or 128");
   const size_t total = (size_t)(K / 8) * ((Nn + bn - 1) / bn) * bn;

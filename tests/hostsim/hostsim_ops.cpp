@@ -524,6 +524,10 @@ void norm_act_bwd(Stream&, const NormActBwdArgs& a) {
     }
 }
 
+bool norm_act_bwd_emits_colsum(int, int) { return false; }
+void bias_grad_from_colsums(Stream&, const double* partial, int N, int C, float* db) {
+  for (int c = 0; c < C; ++c) { double a = 0; for (int n = 0; n < N; ++n) a += partial[(size_t)n * C + c]; db[c] = (float)a; }
+}
 void act_fwd(Stream&, const TView& x, const TView& y, int act) {
   for (size_t e = 0; e < x.pixels(); ++e)
     for (int c = 0; c < x.C; ++c) y.p[e * y.cs + c] = actf(x.p[e * x.cs + c], act);

@@ -6,7 +6,12 @@ R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/$TAG
 mkdir -p $O
 cd $R
-SWAPNET_TEST_VERBOSE=1 timeout 1200 python -m pytest $SEL -m gpu -q -s > $O/tests_gpu.log 2>&1
+KEXPR=${3:-}
+if [ -n "$KEXPR" ]; then
+  SWAPNET_TEST_VERBOSE=1 timeout 1500 python -m pytest $SEL -m gpu -q -s -k "$KEXPR" > $O/tests_gpu.log 2>&1
+else
+  SWAPNET_TEST_VERBOSE=1 timeout 1500 python -m pytest $SEL -m gpu -q -s > $O/tests_gpu.log 2>&1
+fi
 grep -E 'native .* torch fp32|passed|failed|FAILED|one-signed' $O/tests_gpu.log | tail -80
 timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline > $O/bench_c2.json 2> $O/bench_c2.err
 python -c "import json;d=json.load(open('$O/bench_c2.json'));print(d['value'],d['ms_per_step'],d['roofline']['achieved'],d['roofline']['frac'])"
