@@ -266,7 +266,7 @@ void Net::conv(const std::string& name, const Var& x, const Var& y, ConvKind kin
     return;
   }
   // k4 s2 convs with enough channels: strided Winograd F(4x4,2x2) (four polyphase 2x2 convolutions in one batched GEMM)
-  if (kind == CK_K4S2 && s2_wino_wanted(Cip, Cop, y.v.H, y.v.W) && Co % 4 == 0) {
+  if (kind == CK_K4S2 && s2_wino && s2_wino_wanted(Cip, Cop, y.v.H, y.v.W) && Co % 4 == 0) {
     const int sP = 25, sTh = ceil_div(y.v.H, 4), sTw = ceil_div(y.v.W, 4), CV = 4 * Cip;
     const size_t sT = (size_t)x.v.N * sTh * sTw;
     const bool want_dx = x.has_grad && y.has_grad;
@@ -618,7 +618,7 @@ void Net::convT(const std::string& name, const Var& x, const Var& y, int Co, boo
   // enough channels: strided Winograd F(4x4,2x2) -- the transposed conv is the ADJOINT of a k4 s2 conv fine -> coarse, so its
   // forward is the coarse -> fine pipeline (dM = A x A^T, dV = dM U^T, adjoint polyphase transform) and its input gradient the
   // fine -> coarse one
-  if (s2_wino_wanted(Cop, Cip, x.v.H, x.v.W) && Co % 4 == 0) {
+  if (s2_wino && s2_wino_wanted(Cop, Cip, x.v.H, x.v.W) && Co % 4 == 0) {
     const int sP = 25, sTh = ceil_div(x.v.H, 4), sTw = ceil_div(x.v.W, 4), CV = 4 * Cop;
     const size_t sT = (size_t)x.v.N * sTh * sTw;
     const bool want_dx = x.has_grad && y.has_grad;

@@ -132,6 +132,11 @@ class Net {
   // set by the model for nets whose weight gradients are taken (G, the 2B discriminator instance): the
   // Winograd-transformed input of every such conv is kept from forward for its weight gradient
   bool keep_wino_inputs = false;
+  // strided Winograd F(4x4,2x2) for this net's k4 s2 convs / transposed convs (engine.cpp s2_wino_wanted).  Off for the texture
+  // generator: the 8-level pix2pix U-Net back-propagates through InstanceNorms over 64 ... 4 pixels, which amplify the (2.5x
+  // larger) round-off of the Winograd form by an order of magnitude -- its gradients moved from 1.8e-5 to 1e-4 of the pinned
+  // float64 oracle with it on (tools/bisect_run.sh); WarpModule and PatchGAN stay at 1.2e-5 / 6e-6.  SWN_WINO_S2=2 forces it.
+  bool s2_wino = true;
   // Winograd scratch shared by all 3x3 layers of the net (V/M planes, dU): sized in finalize()
   size_t wsV_need = 0, wsM_need = 0, wsU_need = 0;
   float *wsV = nullptr, *wsM = nullptr, *wsU = nullptr;

@@ -1,6 +1,7 @@
 // swapnet_amd -- texture stage: TextureModule generator, VGG16 perceptual network and the
 // TextureModel training step (reference: modules/swapnet_modules.py:154-260,
 // modules/pix2pix_modules.py:113-262, modules/losses/perceptual.py, models/texture_model.py).
+#include <cstdlib>
 #include <cmath>
 
 #include "engine.h"
@@ -146,6 +147,7 @@ class TextureModel final : public Model {
     AllocScope mine(c, owned_allocs);
     G = std::make_unique<Net>(c, arenaG);
     G->keep_wino_inputs = train;
+    G->s2_wino = getenv("SWN_WINO_S2") && atoi(getenv("SWN_WINO_S2")) == 2;
     tex = G->alloc_var(B, H, W, 4, false);
     unet_in = G->alloc_var(B, H, W, RC + Ccp, true);     // d(unet_in)[0:RC) feeds the encode branch
     Dx = G->alloc_var(train ? 2 * B : B, H, W, 4 + Ccp, train);
