@@ -693,7 +693,7 @@ struct PcTile {
   static constexpr int APC = A_BYTES / 1024, BPC = B_BYTES / 1024;
   static constexpr int AI = APC / WGM, BI = BPC / WGM, BREM = BPC % WGM;   // pieces per wave; waves < BREM carry one more of B
   static constexpr int SMEM = NST * ST_BYTES;
-  static_assert(APC % WGM == 0, "tile shape");
+  static_assert(APC % WGM == 0 && NB % 2 == 0, "tile shape");
 };
 
 // WGCU = workgroups per CU the tile is sized for (LDS) -> waves per SIMD the register allocation must allow
@@ -851,7 +851,10 @@ __global__ __launch_bounds__(64 * WGM, WGCU * WGM / 4) void conv_fwd_pc_kernel(G
       const int row = wid * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
       float* dst = slab + (size_t)row * BN + colr;
       if constexpr (NB == 4) *reinterpret_cast<float4*>(dst) = make_float4(acc[0][e], acc[1][e], acc[2][e], acc[3][e]);
-      else *reinterpret_cast<float2*>(dst) = make_float2(acc[0][e], acc[1][e]);
+      else {
+#pragma unroll
+        for (int j = 0; j < NB; j += 2) *reinterpret_cast<float2*>(dst + j) = make_float2(acc[j][e], acc[j + 1][e]);
+      }
     }
     return;
   }
@@ -888,9 +891,12 @@ __global__ __launch_bounds__(64 * WGM, WGCU * WGM / 4) void conv_fwd_pc_kernel(G
           if (p.accumulate) { const float4 q = *reinterpret_cast<const float4*>(dst); o.x += q.x; o.y += q.y; o.z += q.z; o.w += q.w; }
           *reinterpret_cast<float4*>(dst) = o;
         } else {
-          float2 o = make_float2(v[0], v[1]);
-          if (p.accumulate) { const float2 q = *reinterpret_cast<const float2*>(dst); o.x += q.x; o.y += q.y; }
-          *reinterpret_cast<float2*>(dst) = o;
+#pragma unroll
+          for (int j = 0; j < NB; j += 2) {
+            float2 o = make_float2(v[j], v[j + 1]);
+            if (p.accumulate) { const float2 q = *reinterpret_cast<const float2*>(dst + j); o.x += q.x; o.y += q.y; }
+            *reinterpret_cast<float2*>(dst + j) = o;
+          }
         }
       } else {
 #pragma unroll
@@ -2248,18 +2254,21 @@ static void launch_fwd_pc(Stream& s, GemmP& p, int nb, const unsigned short* wpc
   }
 }
 
+// column tile of the pre-cut kernel by output width: 64 (256 x 64), 128 (128 x 128), or 192 for N in (128, 192] (the tail
+// conv's input gradient into the 192-channel concat: one 128 x 192 tile instead of two 128-wide ones of which one is half empty)
+static int pc_tile_for(int Npad) { return Npad <= 64 ? 64 : ((Npad > 128 && Npad <= 192) ? 192 : 128); }
 // ops.h: which column tile a forward-type launch over an input with xC channels into Npad columns wants its weight operand
 // pre-cut for (0 = the launch does not take the pre-cut ring kernel: no operand needs to be produced)
 int conv_precut_tile(int xC, int Npad) {
   static const bool off = getenv("SWN_PRECUT") && atoi(getenv("SWN_PRECUT")) == 0;
   if (off || g_force_naive || !dma_on() || !split_on() || xC % 16 || Npad <= 32) return 0;
-  return Npad > 64 ? 128 : 64;
+  return pc_tile_for(Npad);
 }
 size_t conv_precut_elems(int K, int Npad, int bn) {
   return (size_t)(K / 16) * ceil_div(Npad, bn) * 6 * bn * 8;
 }
 void conv_precut(Stream& s, const float* w, int K, int Npad, int bn, int batch, size_t w_bs, uint16_t* out) {
-  if (K % 16 || (bn != 64 && bn != 128)) throw Error(1, "conv_precut: K must be a multiple of 16, tile 64 or 128");
+  if (K % 16 || (bn != 64 && bn != 128 && bn != 192)) throw Error(1, "conv_precut: K must be a multiple of 16, tile 64, 128 or 192");
   const size_t total = (size_t)(K / 8) * ceil_div(Npad, bn) * bn;
   hipLaunchKernelGGL(conv_precut_kernel, dim3((unsigned)((total + 255) / 256), batch), dim3(256), 0, hs(s), w, out, K, Npad, bn, w_bs,
                      conv_precut_elems(K, Npad, bn));
@@ -2336,9 +2345,10 @@ void conv_fwd(Stream& s, const ConvFwdArgs& a) {
   // of two 128-wide column tiles of which the second is half empty
   if (dma_ok(a, p)) {
     // weight operand handed over pre-cut (conv_precut) for this launch's column tile: the round-3 kernel
-    if (a.wpc && pc_on() && split_on() && a.wpc_bn == (a.Npad > 64 ? 128 : 64) &&
+    if (a.wpc && pc_on() && split_on() && a.wpc_bn == pc_tile_for(a.Npad) &&
         (size_t)(p.K / 16) * ceil_div(a.Npad, a.wpc_bn) * 12 * a.wpc_bn * 8 < ((size_t)1 << 31)) {
-      if (a.Npad > 64) launch_fwd_pc<4, 4, 2, 4>(s, p, nb, a.wpc, a.wpc_bs);       // 128 x 128, 2 stages, 4 workgroups / CU
+      if (a.wpc_bn == 192) launch_fwd_pc<4, 6, 2, 2>(s, p, nb, a.wpc, a.wpc_bs);   // 128 x 192, 2 stages, 2 workgroups / CU
+      else if (a.Npad > 64) launch_fwd_pc<4, 4, 2, 4>(s, p, nb, a.wpc, a.wpc_bs);  // 128 x 128, 2 stages, 4 workgroups / CU
       else launch_fwd_pc<8, 2, 3, 2>(s, p, nb, a.wpc, a.wpc_bs);                   // 256 x 64, 3 stages, 2 workgroups / CU
       return;
     }

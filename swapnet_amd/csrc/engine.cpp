@@ -385,7 +385,8 @@ void Net::conv(const std::string& name, const Var& x, const Var& y, ConvKind kin
   float* keepV = nullptr;         // V = B^T d B of the forward input, reused by the weight gradient
   if (wino && keep_wino_inputs && y.has_grad) keepV = static_cast<float*>(ctx.alloc((size_t)wP * wT * Cip * sizeof(float)));
   // 6-point forms: the transformed filters go straight into the pre-cut operand layout of the ring kernel (no fp32 U)
-  const int pcw = (wino && wm != 2) ? conv_precut_tile(Cip, Cop) : 0;
+  static const int wino_pc = getenv("SWN_WINO_PC") ? atoi(getenv("SWN_WINO_PC")) : 1;
+  const int pcw = (wino && wm != 2 && wino_pc) ? conv_precut_tile(Cip, Cop) : 0;
   const size_t pcw_bs = pcw ? conv_precut_elems(Cip, Cop, pcw) : 0;
   size_t pcw_off = 0, pcwt_off = 0;
   int pcwt = 0;
@@ -435,7 +436,11 @@ void Net::conv(const std::string& name, const Var& x, const Var& y, ConvKind kin
 
   // ---- backward plan
   Var scratch;       // dR when an activation is fused into the epilogue
-  if (y.has_grad && actf != ACT_NONE) scratch = alloc_var(yv.N, yv.H, yv.W, Cop, false);
+  // tail conv: dR lives in a 32-channel buffer (pads stay zero) so that its input gradient -- a 5x5 stride-2 conv over dR with
+  // K = 25 x Cop -- meets the ring kernel's 16-channel stages (K = 800 on the bf16-split ring kernel instead of K = 500 on the
+  // register-staged f32-MFMA one)
+  const int CopD = (kind == CK_TAIL_UP && actf != ACT_NONE && Cop <= 32 && x.has_grad && conv_precut_tile(32, Cip) == 192) ? 32 : Cop;
+  if (y.has_grad && actf != ACT_NONE) scratch = alloc_var(yv.N, yv.H, yv.W, CopD, false);
   Var dxpad;
   int dg_mode = 0;
   Gather gd;         // dgrad gather over dY
@@ -455,24 +460,24 @@ void Net::conv(const std::string& name, const Var& x, const Var& y, ConvKind kin
   const int Ndg = Cip;   // dgrad output channels = input buffer channels
   if (want_dx) {
     if (wino) {
-      pcwt = wm != 2 ? conv_precut_tile(Cop, Cip) : 0;
+      pcwt = (wm != 2 && wino_pc) ? conv_precut_tile(Cop, Cip) : 0;
       pcwt_bs = pcwt ? conv_precut_elems(Cop, Cip, pcwt) : 0;
       if (pcwt) pcwt_off = reserve_dgp(pcwt_bs * wP);
       else ub_off = reserve_dg(self, (size_t)wP * Cop * Cip);
     }
-    else dg_off = reserve_dg(self, dgrad_elems(arena.params[wi].ws, dg_mode, Cop, Ndg));
+    else dg_off = reserve_dg(self, dgrad_elems(arena.params[wi].ws, dg_mode, CopD, Ndg));
     if (kind == CK_K3S1_REFLECT && !(wino && wadj)) dxpad = alloc_var(x.v.N, dHo, dWo, Cip, false);
     op->grad_targets.push_back(x);
     if (!wino) {
       // K4S2: four phase panels of 2x2 taps; stride-1: one panel of KH x KW taps over dY (Cop channels)
       dpanels = kind == CK_K4S2 ? 4 : 1;
-      dKp = (kind == CK_K4S2 ? 4 : gd.KH * gd.KW) * Cop;
-      pc_d = conv_precut_tile(Cop, Ndg);
+      dKp = (kind == CK_K4S2 ? 4 : gd.KH * gd.KW) * CopD;
+      pc_d = conv_precut_tile(CopD, Ndg);
       if (pc_d) pcd_off = reserve_dgp(conv_precut_elems(dKp, Ndg, pc_d) * dpanels);
       const int pcd = pc_d, dK = dKp, dP = dpanels; const size_t pcdo = pcd_off;
       op->repack = [=](Net& n) {
         const ParamDesc& wd = A->params[wi];
-        repack_dgrad(n.ctx.s, wd.ws, dg_mode, Cop, Ndg, A->w + wd.off, n.dg + dg_off);
+        repack_dgrad(n.ctx.s, wd.ws, dg_mode, CopD, Ndg, A->w + wd.off, n.dg + dg_off);
         if (pcd) conv_precut(n.ctx.s, n.dg + dg_off, dK, Ndg, pcd, dP, (size_t)dK * Ndg, n.dgp + pcdo);
       };
     }
@@ -507,7 +512,7 @@ void Net::conv(const std::string& name, const Var& x, const Var& y, ConvKind kin
     };
   }
   const int pcd_k = pc_d; const size_t pcd_o = pcd_off, pcd_bs = pc_d ? conv_precut_elems(dKp, Ndg, pc_d) : 0;
-  const TView ygv = y.g, xgv = x.g, scr = scratch.v, dxp = dxpad.v;
+  const TView ygv = y.g, xgv = x.g, scr = CopD != Cop ? scratch.v.slice(0, Cop) : scratch.v, scr_full = scratch.v, dxp = dxpad.v;
   const bool has_ygrad = y.has_grad;
   op->bwd = [=](Net& n, Op& me, bool wgrad, bool igrad) {
     if (!has_ygrad) return;
@@ -587,7 +592,7 @@ void Net::conv(const std::string& name, const Var& x, const Var& y, ConvKind kin
       conv_fwd(n.ctx.s, d);
     } else {
       ConvFwdArgs d;
-      d.x = dY; d.g = gd; d.w = n.dg + dg_off; d.Npad = Ndg; d.Cout = Ndg;
+      d.x = CopD != Cop ? scr_full : dY; d.g = gd; d.w = n.dg + dg_off; d.Npad = Ndg; d.Cout = Ndg;
       if (pcd_k) { d.wpc = n.dgp + pcd_o; d.wpc_bn = pcd_k; d.wpc_bs = pcd_bs; }
       if (kind == CK_K3S1_REFLECT) {
         d.y = dxp; d.accumulate = 0;
@@ -903,7 +908,8 @@ void Net::forward_from(int op_begin) {
   for (size_t i = (size_t)op_begin; i < ops.size(); ++i) ops[i]->fwd(*this);
 }
 void Net::prefetch_dgrad() {
-  if (!ctx.use_side() || dg_version == arena.version || refresh_pending) return;
+  static const bool prefetch = !(getenv("SWN_PREFETCH") && atoi(getenv("SWN_PREFETCH")) == 0);    // 0: refresh in order on the main stream
+  if (!prefetch || !ctx.use_side() || dg_version == arena.version || refresh_pending) return;
   bool any = false;
   for (auto& op : ops) any = any || (bool)op->repack;
   if (!any) return;

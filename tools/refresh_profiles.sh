@@ -1,22 +1,24 @@
 # Produces everything under profiles/ for one round: run on the GPU box as
-#   gpurun --timeout 2400 -- 'bash tools/refresh_profiles.sh r02b'
+#   gpurun --timeout 2400 -- 'bash tools/refresh_profiles.sh r03'
 # then copy the condensed files from gpurun_out/<tag>/ into profiles/ (README there lists the names).
 # Per-kernel profiles are taken with the library's second stream off (SWN_OVERLAP=0): with it on, kernels of the two
 # streams share the GPU and their individual durations / counters are not attributable.  Counter passes (--pmc) are
-# separate runs without any trace domain, one step each.  Order: tests and bench lines first (a session may be cut).
-TAG=${1:-r02b}
+# separate runs without any trace domain, one step each.  (The GPU test suite is a separate call: pytest tests -m gpu.)
+TAG=${1:-r03}
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/$TAG
 mkdir -p $O
 cd $R
-python -m pytest tests -m gpu -q > $O/tests_gpu.log 2>&1
-tail -3 $O/tests_gpu.log
-python bench.py --steps 10 --warmup 3 --with-h2d > $O/bench_c2.json 2> $O/bench_c2.err
+python bench.py --steps 20 --warmup 5 --with-h2d > $O/bench_c2.json 2> $O/bench_c2.err
 python -c "import json;d=json.load(open('$O/bench_c2.json'));print(d['value'],d['ms_per_step'],d['roofline']['achieved'],d['roofline']['frac'],d.get('cpu_baseline'))"
 python bench.py --stage texture --steps 10 --warmup 3 > $O/bench_c3.json 2> $O/bench_c3.err
 python bench.py --stage infer > $O/bench_infer.json 2> $O/bench_infer.err
 SWAPNET_BENCH_RCCL1=1 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-roofline > $O/bench_c2_rccl_world1.json 2> $O/bench_c2_rccl_world1.err
-SWN_SPLIT=0 python bench.py --steps 10 --warmup 3 --no-cpu-baseline > $O/bench_c2_f32mfma.json 2> $O/bench_c2_f32mfma.err
+# same-box A/B of this round's switches (ms/step)
+for V in SWN_PRECUT=0 SWN_WINO_S2=0 SWN_FUSED_IN=0 SWN_WINO_ADJOINT=0; do
+  env $V python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-roofline 2> /dev/null | python -c "import sys,json;d=json.loads(sys.stdin.read());print('$V', d['ms_per_step'], d['value'])" >> $O/ab_switches.txt
+done
+cat $O/ab_switches.txt
 cd /tmp && export TMPDIR=/tmp
 B="python $R/bench.py --no-cpu-baseline --no-roofline"
 SWN_OVERLAP=0 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_warp -o warp -- $B --steps 3 --warmup 1 > $O/prof_warp.log 2>&1
@@ -31,3 +33,5 @@ for d in prof_warp prof_tex pmc_fetch pmc_write pmc_sq pmc_sq2; do
   python profiles/summarize_rocprof.py $O/$d ${TAG}_$d --out $O > /dev/null 2>&1
   rm -rf $O/$d
 done
+python profiles/summarize_rocprof.py traffic ${TAG}_pmc_fetch ${TAG}_pmc_write ${TAG} --out $O
+ls $O
