@@ -340,6 +340,92 @@ void Net::conv(const std::string& name, const Var& x, const Var& y, ConvKind kin
     ops.push_back(std::move(op));
     return;
   }
+  // The tail conv in Winograd form (ops.h tailw_*): the four folded sub-pixel phases share one F(4x4,3x3) input transform of the
+  // un-upsampled map and one batched GEMM with N = 4 Npad; forward and weight gradient (the input gradient stays the folded
+  // 5x5 stride-2 conv on the ring kernel: its Winograd form would be bound by the adjoint transform of a 0.9 GB operand)
+  if (kind == CK_TAIL_UP) {
+    const int twminc_env = getenv("SWN_WINO_MINC") ? atoi(getenv("SWN_WINO_MINC")) : 0;
+    const bool tw_on = !(getenv("SWN_WINOGRAD") && atoi(getenv("SWN_WINOGRAD")) == 0) && !(getenv("SWN_TAIL_WINO") && atoi(getenv("SWN_TAIL_WINO")) == 0);
+    if (tw_on && Cip % 32 == 0 && Cip >= (twminc_env > 0 ? twminc_env : 64) && x.v.H >= 4 && x.v.W >= 4 && Cop <= 32) {
+      const ParamDesc wd0 = arena.params[wi];
+      const int tP = 36, tTh = ceil_div(x.v.H, 4), tTw = ceil_div(x.v.W, 4), N4 = 4 * Cop;
+      const size_t tT = (size_t)x.v.N * tTh * tTw;
+      const size_t fe = tail_fold_offset(wd0.ws, 4);
+      const size_t fold_off = reserve_dg(self, fe), dfold_off = reserve_dg(self, fe);
+      const size_t tu_off = reserve_dg(self, (size_t)tP * Cip * N4);
+      float* keepV = (keep_wino_inputs && y.has_grad) ? static_cast<float*>(ctx.alloc(tP * tT * Cip * sizeof(float))) : nullptr;
+      wsV_need = std::max(wsV_need, tP * tT * (size_t)std::max(Cip, N4));
+      wsM_need = std::max(wsM_need, tP * tT * (size_t)std::max(Cip, N4));
+      wsU_need = std::max(wsU_need, (size_t)tP * Cip * N4);
+      const int pcu = conv_precut_tile(Cip, N4);
+      const size_t pcu_bs = pcu ? conv_precut_elems(Cip, N4, pcu) : 0, pcu_off = pcu ? reserve_dgp(pcu_bs * tP) : 0;
+      // input gradient: the folded 5x5 stride-2 conv over dR (32-channel buffer, see CopD below)
+      const bool want_dx = x.has_grad && y.has_grad;
+      const int CopD = (actf != ACT_NONE && want_dx && conv_precut_tile(32, Cip) == 192) ? 32 : Cop;
+      const size_t dg_off = want_dx ? reserve_dg(self, dgrad_elems(wd0.ws, 3, CopD, Cip)) : 0;
+      const int pc_d = want_dx ? conv_precut_tile(CopD, Cip) : 0;
+      const size_t pcd_bs = pc_d ? conv_precut_elems(25 * CopD, Cip, pc_d) : 0, pcd_off = pc_d ? reserve_dgp(pcd_bs) : 0;
+      op->repack = [=](Net& n) {
+        const ParamDesc& wd = A->params[wi];
+        tail_fold_weights(n.ctx.s, wd.ws, A->w + wd.off, n.dg + fold_off);
+        tailw_filter_transform(n.ctx.s, wd.ws, n.dg + fold_off, n.dg + tu_off);
+        if (pcu) conv_precut(n.ctx.s, n.dg + tu_off, Cip, N4, pcu, tP, (size_t)Cip * N4, n.dgp + pcu_off);
+        if (want_dx) {
+          repack_dgrad(n.ctx.s, wd.ws, 3, CopD, Cip, A->w + wd.off, n.dg + dg_off);
+          if (pc_d) conv_precut(n.ctx.s, n.dg + dg_off, 25 * CopD, Cip, pc_d, 1, 0, n.dgp + pcd_off);
+        }
+      };
+      op->fwd = [=](Net& n) {
+        n.need(self);
+        float* V = keepV ? keepV : n.wsV;
+        wino_input_transform(n.ctx.s, 4, 3, xv, 1, PAD_ZERO, tTh, tTw, V);
+        ConvFwdArgs g;
+        g.x = plane_mat(V, tT, Cip); g.g.Ho = 1; g.g.Wo = (int)tT;
+        g.w = n.dg + tu_off; g.Npad = N4; g.Cout = N4;
+        g.y = plane_mat(n.wsM, tT, N4);
+        g.batch = tP; g.x_bs = tT * Cip; g.w_bs = (size_t)Cip * N4; g.y_bs = tT * N4;
+        if (pcu) { g.wpc = n.dgp + pcu_off; g.wpc_bn = pcu; g.wpc_bs = pcu_bs; }
+        conv_fwd(n.ctx.s, g);
+        tailw_output_transform(n.ctx.s, n.wsM, tTh, tTw, Cop, bi >= 0 ? A->w + A->params[bi].off : nullptr, actf, yv, Co);
+      };
+      Var scratch;
+      if (y.has_grad && actf != ACT_NONE) scratch = alloc_var(yv.N, yv.H, yv.W, CopD, false);
+      if (want_dx) op->grad_targets.push_back(x);
+      const TView ygv = y.g, xgv = x.g, scr = CopD != Cop ? scratch.v.slice(0, Cop) : scratch.v, scr_full = scratch.v;
+      const bool has_ygrad = y.has_grad;
+      op->bwd = [=](Net& n, Op& me, bool wgrad, bool igrad) {
+        if (!has_ygrad) return;
+        TView dY = ygv;
+        if (actf != ACT_NONE) { act_bwd(n.ctx.s, ygv, yv, scr, actf, 0); dY = scr; }
+        const ParamDesc& wd = A->params[wi];
+        if (wgrad) {
+          Stream& sw = n.wgrad_stream();
+          float* V = keepV ? keepV : n.wsV;
+          float* dM = n.wgrad_planes(sw);
+          if (!keepV) wino_input_transform(sw, 4, 3, xv, 1, PAD_ZERO, tTh, tTw, V);
+          tailw_dy_transform(sw, dY, tTh, tTw, Cop, dM);
+          ConvWgradArgs g;
+          g.x = plane_mat(V, tT, Cip); g.g.Ho = 1; g.g.Wo = (int)tT;
+          g.dy = plane_mat(dM, tT, N4);
+          g.dw = n.wsU; g.Npad = N4; g.Cout = N4;
+          g.batch = tP; g.x_bs = tT * Cip; g.dy_bs = tT * N4; g.dw_bs = (size_t)Cip * N4;
+          conv_wgrad(sw, g);
+          tailw_filter_grad(sw, wd.ws, n.wsU, n.dg + dfold_off);
+          tail_unfold_wgrad(sw, wd.ws, n.dg + dfold_off, A->g + wd.off);
+          if (bi >= 0) n.bias_grad_of(sw, dY, A->g + A->params[bi].off);
+        }
+        if (!want_dx || (me.reads_net_input && !igrad)) return;
+        ConvFwdArgs d;
+        d.x = CopD != Cop ? scr_full : dY;
+        d.g.KH = d.g.KW = 5; d.g.stride = 2; d.g.pad_t = d.g.pad_l = 1; d.g.Ho = xv.H; d.g.Wo = xv.W;
+        d.w = n.dg + dg_off; d.Npad = Cip; d.Cout = Cip; d.y = xgv; d.accumulate = me.acc.empty() ? 0 : me.acc[0];
+        if (pc_d) { d.wpc = n.dgp + pcd_off; d.wpc_bn = pc_d; d.wpc_bs = pcd_bs; }
+        conv_fwd(n.ctx.s, d);
+      };
+      ops.push_back(std::move(op));
+      return;
+    }
+  }
   // tail conv: run as 4 folded sub-pixel phases on the un-upsampled input (25 instead of 64
   // taps per 2x2 outputs; see ops.h tail_fold_weights).  The folded weights and the folded
   // weight-gradient scratch live next to the dgrad operands and follow arena.version.

@@ -142,6 +142,14 @@ void wino_input_adjoint(Stream& s, int m, int r, float* dV, int C, int pad, int 
 void wino_output_transform(Stream& s, int m, int r, const float* M, int Cm, int Th, int Tw, const float* bias, int act,
                            const TView& y, int Cout, int accumulate);                                      // M[P][T][Cm]
 void wino_dy_transform(Stream& s, int m, int r, const TView& dy, int Th, int Tw, float* dM);               // dM[P][T][dy.C]
+// ---- the folded tail conv (tail_fold_weights below) in Winograd form: its four sub-pixel phases are (2+a)x(2+b)-tap stride-1
+// convolutions over the same input, i.e. four F(4x4,3x3) convolutions sharing ONE wino_input_transform(4, 3, x, pad 1, zero);
+// their filters sit side by side on the N axis (N = 4 * Npad) of one batched GEMM.  Th, Tw = tiles of 4x4 INPUT positions.
+void tailw_filter_transform(Stream& s, const WShape& w, const float* folded, float* U);        // U[36][Cip][4 * Npad]
+void tailw_filter_grad(Stream& s, const WShape& w, const float* dU, float* dfolded);          // dU[36][Cip][4 * Npad] -> folded layout
+// y (2H x 2W, Npad channels): y[2 i + a][2 j + b] = act(A^T M_ab A + bias),  M[36][T][4 * Npad]
+void tailw_output_transform(Stream& s, const float* M, int Th, int Tw, int Npad, const float* bias, int act, const TView& y, int Cout);
+void tailw_dy_transform(Stream& s, const TView& dy, int Th, int Tw, int Npad, float* dM);      // dM[36][T][4 * Npad]
 // ---- strided Winograd F(4x4, 2x2): the k4 s2 p1 convolutions and their transposes as four polyphase 2x2 stride-1 convolutions
 // sharing one batched GEMM (wino.hip).  "fine" = the 2H x 2W side, "coarse" = the H x W side; tiles = 4x4 coarse pixels.
 // (m, r) = (4, 2) is accepted by wino_output_transform (coarse = A^T M A) and wino_dy_transform (dM = A coarse A^T).

@@ -847,6 +847,182 @@ __global__ __launch_bounds__(256) void winog_filter_pc_kernel(WShape w, int mode
     }
 }
 
+
+// ---------------------------------------------------------------------------------------
+// The folded tail conv (Upsample x2 + ZeroPad(1,0,1,0) + Conv k4 p1, swapnet_modules.py:85-90; ops.h tail_fold_weights) in
+// Winograd form.  Its four sub-pixel phases are (2+a) x (2+b)-tap stride-1 convolutions over the SAME un-upsampled input with the
+// same top-left offset, i.e. four F(4x4,3x3) convolutions (the 2-tap axes zero-extended) that share ONE input transform; their
+// transformed filters sit side by side on the N axis of one batched GEMM (N = 4 Npad = 80 for the 19-channel output).  36
+// multiplies per 4x4 input positions and output channel pair instead of the 25 x 16 of the folded direct form (2.8x fewer), on
+// the 32-wide bf16-split MFMA tiles instead of the 4x4x1 f32 blocks the N = 19 direct kernels are confined to.
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ size_t tailw_fold_off(int Cip, int Npad, int ph) {
+  const int pre = ph == 0 ? 0 : (ph == 1 ? 4 : (ph == 2 ? 10 : 16));
+  return (size_t)pre * Cip * Npad;
+}
+// U[p][ci][ph * Npad + co] = (G g_ph G^T)[p],  g_ph[r][c] = folded_ph[(r * (2 + b) + c) * Cip + ci][co]  (0 beyond the phase's taps)
+__global__ __launch_bounds__(256) void tailw_filter_kernel(int Cip, int Npad, const float* folded, float* U) {
+  constexpr int A = 6, R = 3;
+  const int N4 = 4 * Npad;
+  const size_t total = (size_t)Cip * N4;
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int ci = (int)(i / N4), n = (int)(i % N4);
+  const int ph = n / Npad, co = n - ph * Npad, a = ph >> 1, b = ph & 1;
+  const float* f = folded + tailw_fold_off(Cip, Npad, ph);
+  float g[R][R];
+#pragma unroll
+  for (int r = 0; r < R; ++r)
+#pragma unroll
+    for (int c = 0; c < R; ++c) g[r][c] = (r < 2 + a && c < 2 + b) ? f[((size_t)(r * (2 + b) + c) * Cip + ci) * Npad + co] : 0.f;
+  float t[A][R];
+#pragma unroll
+  for (int r = 0; r < A; ++r)
+#pragma unroll
+    for (int c = 0; c < R; ++c) {
+      float s = 0.f;
+#pragma unroll
+      for (int q = 0; q < R; ++q) f1mac(s, F43::G[r][q], g[q][c]);
+      t[r][c] = s;
+    }
+#pragma unroll
+  for (int r = 0; r < A; ++r)
+#pragma unroll
+    for (int j = 0; j < A; ++j) {
+      float s = 0.f;
+#pragma unroll
+      for (int q = 0; q < R; ++q) f1mac(s, F43::G[j][q], t[r][q]);
+      U[(size_t)(r * A + j) * total + i] = s;
+    }
+}
+// dfolded_ph[(r * (2 + b) + c) * Cip + ci][co] = (G^T dU_ph G)[r][c] for the phase's taps
+__global__ __launch_bounds__(256) void tailw_filter_grad_kernel(int Cip, int Npad, const float* dU, float* dfolded) {
+  constexpr int A = 6, R = 3;
+  const int N4 = 4 * Npad;
+  const size_t total = (size_t)Cip * N4;
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int ci = (int)(i / N4), n = (int)(i % N4);
+  const int ph = n / Npad, co = n - ph * Npad, a = ph >> 1, b = ph & 1;
+  float t[R][A];
+#pragma unroll
+  for (int j = 0; j < A; ++j) {
+    float u[A];
+#pragma unroll
+    for (int r = 0; r < A; ++r) u[r] = dU[(size_t)(r * A + j) * total + i];
+#pragma unroll
+    for (int q = 0; q < R; ++q) {
+      float s = 0.f;
+#pragma unroll
+      for (int r = 0; r < A; ++r) f1mac(s, F43::G[r][q], u[r]);
+      t[q][j] = s;
+    }
+  }
+  float* f = dfolded + tailw_fold_off(Cip, Npad, ph);
+#pragma unroll
+  for (int r = 0; r < R; ++r)
+#pragma unroll
+    for (int c = 0; c < R; ++c) {
+      if (r >= 2 + a || c >= 2 + b) continue;
+      float s = 0.f;
+#pragma unroll
+      for (int j = 0; j < A; ++j) f1mac(s, F43::G[j][c], t[r][j]);
+      f[((size_t)(r * (2 + b) + c) * Cip + ci) * Npad + co] = s;
+    }
+}
+// y[2 (4 ty + i) + a][2 (4 tx + j) + b][co] = act((A^T M_ph A)[i][j] + bias),  M[p][tile][ph * Npad + co]
+__global__ __launch_bounds__(256) void tailw_output_kernel(const float* Mx, int N, int Th, int Tw, int Npad, const float* bias, int act,
+                                                           float* y, int ycs, int yH, int yW, int Cout) {
+  constexpr int A = 6, M = 4;
+  const int C4 = Npad >> 2, CM = 4 * Npad;
+  const size_t T = (size_t)N * Th * Tw;
+  const size_t total = T * 4 * C4;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int c = (int)(i % C4) * 4; size_t r = i / C4;
+    const int ph = (int)(r & 3); const size_t tile = r >> 2;
+    const int a = ph >> 1, b = ph & 1;
+    const int tx = (int)(tile % Tw); size_t u = tile / Tw;
+    const int ty = (int)(u % Th); const int n = (int)(u / Th);
+    float4 s1[M][A];
+#pragma unroll
+    for (int j = 0; j < A; ++j) {
+      float4 m[A];
+#pragma unroll
+      for (int k = 0; k < A; ++k) m[k] = *reinterpret_cast<const float4*>(Mx + ((size_t)(k * A + j) * T + tile) * CM + ph * Npad + c);
+#pragma unroll
+      for (int q = 0; q < M; ++q) {
+        float4 s = F4ZERO;
+#pragma unroll
+        for (int k = 0; k < A; ++k) f4mac(s, F43::AT[q][k], m[k]);
+        s1[q][j] = s;
+      }
+    }
+    float4 bv = F4ZERO;
+    if (bias) bv = make_float4(c < Cout ? bias[c] : 0.f, c + 1 < Cout ? bias[c + 1] : 0.f, c + 2 < Cout ? bias[c + 2] : 0.f,
+                               c + 3 < Cout ? bias[c + 3] : 0.f);
+#pragma unroll
+    for (int q = 0; q < M; ++q)
+#pragma unroll
+      for (int jj = 0; jj < M; ++jj) {
+        const int oy = 2 * (M * ty + q) + a, ox = 2 * (M * tx + jj) + b;
+        if (oy >= yH || ox >= yW) continue;
+        float4 v = F4ZERO;
+#pragma unroll
+        for (int k = 0; k < A; ++k) f4mac(v, F43::AT[jj][k], s1[q][k]);
+        v = f4add(v, bv);
+        v.x = act_apply(v.x, act); v.y = act_apply(v.y, act); v.z = act_apply(v.z, act); v.w = act_apply(v.w, act);
+        float* dst = y + ((size_t)(n * yH + oy) * yW + ox) * ycs + c;
+        if (c + 3 < Cout) {
+          *reinterpret_cast<float4*>(dst) = v;
+        } else {
+          const float vv[4] = {v.x, v.y, v.z, v.w};
+          for (int e = 0; e < 4 && c + e < Cout; ++e) dst[e] = vv[e];
+        }
+      }
+  }
+}
+// dM[p][tile][ph * Npad + c] = (A g_ph A^T)[p],  g_ph[i][j] = dy[2 (4 ty + i) + a][2 (4 tx + j) + b][c]
+__global__ __launch_bounds__(256) void tailw_dy_kernel(const float* dy, int dcs, int N, int yH, int yW, int Th, int Tw, int Npad,
+                                                       float* dM) {
+  constexpr int A = 6, M = 4;
+  const int C4 = Npad >> 2, CM = 4 * Npad;
+  const size_t T = (size_t)N * Th * Tw;
+  const size_t total = T * 4 * C4;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int c = (int)(i % C4) * 4; size_t r = i / C4;
+    const int ph = (int)(r & 3); const size_t tile = r >> 2;
+    const int a = ph >> 1, b = ph & 1;
+    const int tx = (int)(tile % Tw); size_t u = tile / Tw;
+    const int ty = (int)(u % Th); const int n = (int)(u / Th);
+    float4 rr[A][M];
+#pragma unroll
+    for (int jj = 0; jj < M; ++jj) {
+      float4 g[M];
+#pragma unroll
+      for (int q = 0; q < M; ++q) {
+        const int oy = 2 * (M * ty + q) + a, ox = 2 * (M * tx + jj) + b;
+        g[q] = (oy < yH && ox < yW) ? *reinterpret_cast<const float4*>(dy + ((size_t)(n * yH + oy) * yW + ox) * dcs + c) : F4ZERO;
+      }
+#pragma unroll
+      for (int p = 0; p < A; ++p) {
+        float4 s = F4ZERO;
+#pragma unroll
+        for (int q = 0; q < M; ++q) f4mac(s, F43::AT[q][p], g[q]);
+        rr[p][jj] = s;
+      }
+    }
+#pragma unroll
+    for (int p = 0; p < A; ++p)
+#pragma unroll
+      for (int j = 0; j < A; ++j) {
+        float4 s = F4ZERO;
+#pragma unroll
+        for (int jj = 0; jj < M; ++jj) f4mac(s, F43::AT[jj][j], rr[p][jj]);
+        *reinterpret_cast<float4*>(dM + ((size_t)(p * A + j) * T + tile) * CM + ph * Npad + c) = s;
+      }
+  }
+}
+
 inline unsigned wgrid(size_t total) { return (unsigned)std::min<size_t>(std::max<size_t>((total + 255) / 256, 1), 256 * 32); }
 
 }  // namespace
@@ -933,6 +1109,28 @@ void wino_dy_transform(Stream& s, int m, int r, const TView& dy, int Th, int Tw,
   else
     hipLaunchKernelGGL(winog_dy_kernel<F42>, grid, dim3(256), 0, hs(s), dy.p, dy.cs, dy.N, dy.H, dy.W, dy.C, Th, Tw, dM);
   check_launch("wino_dy_transform");
+}
+void tailw_filter_transform(Stream& s, const WShape& w, const float* folded, float* U) {
+  const size_t total = (size_t)w.Cip * 4 * w.Npad;
+  hipLaunchKernelGGL(tailw_filter_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, hs(s), w.Cip, w.Npad, folded, U);
+  check_launch("tailw_filter_transform");
+}
+void tailw_filter_grad(Stream& s, const WShape& w, const float* dU, float* dfolded) {
+  const size_t total = (size_t)w.Cip * 4 * w.Npad;
+  hipLaunchKernelGGL(tailw_filter_grad_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, hs(s), w.Cip, w.Npad, dU, dfolded);
+  check_launch("tailw_filter_grad");
+}
+void tailw_output_transform(Stream& s, const float* M, int Th, int Tw, int Npad, const float* bias, int act, const TView& y, int Cout) {
+  if (Npad % 4 || y.cs % 4 || y.C < Npad) throw Error(1, "tailw_output_transform: bad channel counts");
+  const size_t total = (size_t)y.N * Th * Tw * 4 * (Npad / 4);
+  hipLaunchKernelGGL(tailw_output_kernel, dim3(wgrid(total)), dim3(256), 0, hs(s), M, y.N, Th, Tw, Npad, bias, act, y.p, y.cs, y.H, y.W, Cout);
+  check_launch("tailw_output_transform");
+}
+void tailw_dy_transform(Stream& s, const TView& dy, int Th, int Tw, int Npad, float* dM) {
+  if (Npad % 4 || dy.cs % 4 || dy.C < Npad) throw Error(1, "tailw_dy_transform: bad channel counts");
+  const size_t total = (size_t)dy.N * Th * Tw * 4 * (Npad / 4);
+  hipLaunchKernelGGL(tailw_dy_kernel, dim3(wgrid(total)), dim3(256), 0, hs(s), dy.p, dy.cs, dy.N, dy.H, dy.W, Th, Tw, Npad, dM);
+  check_launch("tailw_dy_transform");
 }
 void wino_s2_input_transform(Stream& s, const TView& x, int Th, int Tw, float* V) {
   if (x.C % 4 || x.cs % 4) throw Error(1, "wino_s2_input_transform: C must be a multiple of 4");

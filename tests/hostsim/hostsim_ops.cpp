@@ -298,6 +298,78 @@ void wino_dy_transform(Stream&, int m, int r, const TView& dy, int Th, int Tw, f
     }
   }
 }
+// ---- folded tail conv in Winograd form (ops.h tailw_*): plain loops
+static size_t tailw_off(int Cip, int Npad, int ph) { static const int pre[4] = {0, 4, 10, 16}; return (size_t)pre[ph] * Cip * Npad; }
+void tailw_filter_transform(Stream&, const WShape& w, const float* folded, float* U) {
+  const WinoMats wm = wino_mats(4, 3);
+  const int A = 6, R = 3, N4 = 4 * w.Npad;
+  const size_t total = (size_t)w.Cip * N4;
+  for (int ci = 0; ci < w.Cip; ++ci) for (int n = 0; n < N4; ++n) {
+    const int ph = n / w.Npad, co = n % w.Npad, a = ph >> 1, b = ph & 1;
+    const float* f = folded + tailw_off(w.Cip, w.Npad, ph);
+    float g[3][3], t[6][3];
+    for (int r = 0; r < R; ++r) for (int c = 0; c < R; ++c)
+      g[r][c] = (r < 2 + a && c < 2 + b) ? f[((size_t)(r * (2 + b) + c) * w.Cip + ci) * w.Npad + co] : 0.f;
+    for (int r = 0; r < A; ++r) for (int c = 0; c < R; ++c) { float s = 0; for (int q = 0; q < R; ++q) s += wm.G[r * R + q] * g[q][c]; t[r][c] = s; }
+    for (int r = 0; r < A; ++r) for (int j = 0; j < A; ++j) { float s = 0; for (int q = 0; q < R; ++q) s += t[r][q] * wm.G[j * R + q];
+      U[(size_t)(r * A + j) * total + (size_t)ci * N4 + n] = s; }
+  }
+}
+void tailw_filter_grad(Stream&, const WShape& w, const float* dU, float* dfolded) {
+  const WinoMats wm = wino_mats(4, 3);
+  const int A = 6, R = 3, N4 = 4 * w.Npad;
+  const size_t total = (size_t)w.Cip * N4;
+  for (int ci = 0; ci < w.Cip; ++ci) for (int n = 0; n < N4; ++n) {
+    const int ph = n / w.Npad, co = n % w.Npad, a = ph >> 1, b = ph & 1;
+    float* f = dfolded + tailw_off(w.Cip, w.Npad, ph);
+    for (int r = 0; r < 2 + a; ++r) for (int c = 0; c < 2 + b; ++c) {
+      float s = 0;
+      for (int p = 0; p < A; ++p) for (int j = 0; j < A; ++j) s += wm.G[p * R + r] * dU[(size_t)(p * A + j) * total + (size_t)ci * N4 + n] * wm.G[j * R + c];
+      f[((size_t)(r * (2 + b) + c) * w.Cip + ci) * w.Npad + co] = s;
+    }
+  }
+}
+void tailw_output_transform(Stream&, const float* M, int Th, int Tw, int Npad, const float* bias, int act, const TView& y, int Cout) {
+  const WinoMats wm = wino_mats(4, 3);
+  const int A = 6, CM = 4 * Npad;
+  const size_t T = (size_t)y.N * Th * Tw;
+  for (int n = 0; n < y.N; ++n) for (int ty = 0; ty < Th; ++ty) for (int tx = 0; tx < Tw; ++tx) {
+    const size_t tile = ((size_t)n * Th + ty) * Tw + tx;
+    for (int ph = 0; ph < 4; ++ph) for (int c = 0; c < Cout; ++c) {
+      const int a = ph >> 1, b = ph & 1;
+      for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) {
+        const int oy = 2 * (4 * ty + i) + a, ox = 2 * (4 * tx + j) + b;
+        if (oy >= y.H || ox >= y.W) continue;
+        float s = 0;
+        for (int p = 0; p < A; ++p) for (int q = 0; q < A; ++q)
+          s += wm.AT[i * A + p] * M[((size_t)(p * A + q) * T + tile) * CM + ph * Npad + c] * wm.AT[j * A + q];
+        if (bias) s += bias[c];
+        at(y, n, oy, ox)[c] = actf(s, act);
+      }
+    }
+  }
+}
+void tailw_dy_transform(Stream&, const TView& dy, int Th, int Tw, int Npad, float* dM) {
+  const WinoMats wm = wino_mats(4, 3);
+  const int A = 6, CM = 4 * Npad;
+  const size_t T = (size_t)dy.N * Th * Tw;
+  for (int n = 0; n < dy.N; ++n) for (int ty = 0; ty < Th; ++ty) for (int tx = 0; tx < Tw; ++tx) {
+    const size_t tile = ((size_t)n * Th + ty) * Tw + tx;
+    for (int ph = 0; ph < 4; ++ph) for (int c = 0; c < Npad; ++c) {
+      const int a = ph >> 1, b = ph & 1;
+      float g[4][4];
+      for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) {
+        const int oy = 2 * (4 * ty + i) + a, ox = 2 * (4 * tx + j) + b;
+        g[i][j] = (oy < dy.H && ox < dy.W && c < dy.C) ? at(dy, n, oy, ox)[c] : 0.f;
+      }
+      for (int p = 0; p < A; ++p) for (int q = 0; q < A; ++q) {
+        float s = 0;
+        for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) s += wm.AT[i * A + p] * g[i][j] * wm.AT[j * A + q];
+        dM[((size_t)(p * A + q) * T + tile) * CM + ph * Npad + c] = s;
+      }
+    }
+  }
+}
 // ---- strided Winograd F(4x4, 2x2) (ops.h): plain loops straight from the definition
 void wino_s2_input_transform(Stream&, const TView& x, int Th, int Tw, float* V) {
   const WinoMats wm = wino_mats(4, 2);

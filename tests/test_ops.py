@@ -73,6 +73,7 @@ CONV_CASES_SIM = [
     (K4S1, 0, 2, 32, 6, 1, True),                                          # 1-channel head: taps on the N axis
     # strided Winograd F(4x4,2x2): k4 s2 conv (8x8 -> 4x4: one tile; 12x12 -> 6x6: ragged 2x2 tiles) and transposed conv
     (K4S2, 0, 2, 32, 8, 32, True), (K4S2, 0, 1, 32, 12, 64, False), (K4S2, 1, 2, 32, 4, 32, True), (K4S2, 1, 1, 48, 3, 32, False),
+    (TAIL, 0, 2, 32, 8, 19, True), (TAIL, 0, 1, 64, 6, 19, True),         # tail conv in Winograd form (ragged 6x6 -> 2x2 tiles)
 ]
 CONV_CASES_GPU = CONV_CASES_SIM + [
     (K4S2, 0, 3, 64, 40, 128, False),        # fast path, M = 3*400 (ragged tile), N = 128
