@@ -2458,7 +2458,9 @@ static bool wgrad_dma_ok(const ConvWgradArgs& a, const GemmP& p) {
   // the k-tile is 128 rows (N > 64) or 256 rows (N <= 64): shapes that would leave a quarter or more of the tile rows
   // empty (the K = 64 / 320 / 384 first-layer weight gradients) stay on the 128-row register-staged kernel
   const int bmk = a.Npad > 64 ? 128 : 256;
-  const bool fill = (double)p.K / (double)(ceil_div(p.K, bmk) * bmk) > 0.8;
+  // (128-row tiles from 0.75: K = 192, the tail conv's Winograd-domain weight gradient, is 1.5 tiles of a long reduction)
+  const double fillf = (double)p.K / (double)(ceil_div(p.K, bmk) * bmk);
+  const bool fill = fillf > 0.8 || (bmk == 128 && fillf >= 0.75);
   return geom && fill && p.M % 16 == 0 && xbytes < ((size_t)1 << 31) && ybytes < ((size_t)1 << 31);
 }
 

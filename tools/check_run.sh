@@ -16,8 +16,8 @@ grep -E 'native .* torch fp32|passed|failed|FAILED|one-signed' $O/tests_gpu.log 
 timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline > $O/bench_c2.json 2> $O/bench_c2.err
 python -c "import json;d=json.load(open('$O/bench_c2.json'));print(d['value'],d['ms_per_step'],d['roofline']['achieved'],d['roofline']['frac'])"
 SWN_PRECUT=0 timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-roofline > $O/bench_c2_noprecut.json 2> /dev/null
-SWN_WINO_S2=0 timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-roofline > $O/bench_c2_nofusedin.json 2> /dev/null
-python -c "import json;print('A/B same box: no-precut', json.load(open('$O/bench_c2_noprecut.json'))['ms_per_step'], ' no-strided-winograd', json.load(open('$O/bench_c2_nofusedin.json'))['ms_per_step'])"
+SWN_TAIL_WINO=0 timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-roofline > $O/bench_c2_nofusedin.json 2> /dev/null
+python -c "import json;print('A/B same box: no-precut', json.load(open('$O/bench_c2_noprecut.json'))['ms_per_step'], ' no-tail-winograd', json.load(open('$O/bench_c2_nofusedin.json'))['ms_per_step'])"
 timeout 300 python bench.py --stage texture --steps 10 --warmup 3 --no-cpu-baseline > $O/bench_c3.json 2> $O/bench_c3.err
 python -c "import json;d=json.load(open('$O/bench_c3.json'));print(d['value'],d['ms_per_step'])"
 cd /tmp && export TMPDIR=/tmp
