@@ -116,3 +116,30 @@ def test_texture_stage_rejects_gradient_penalty_modes(tmp_path):
         create_model(make_opt(tmp_path, "sim", model="texture", gan_mode="wgan-gp"))
     with pytest.raises(NotImplementedError):
         create_model(make_opt(tmp_path, "sim", gan_mode="mescheder-r1-gp"))                     # like modules/loss.py:62
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_library_rng_keeps_the_layout_pad_channels_out_of_the_penalty(backend):
+    """dragan-gp with the LIBRARY's random draws (the default: no set_gp_random): beta is drawn on the device for the 24-channel
+    buffer layout of D's conditional input, whose channels 19 and 23 are layout pads.  They must stay exactly zero -- a non-zero
+    pad channel of x_hat puts a gradient on the pad rows of model.0.weight, AdamW then moves those weights off zero and every
+    later penalty sees noise x W_pad (advisor finding, round 2).  Checked on the raw gradient arena (state_dict() would hide it)."""
+    ctx = _ctx(backend)
+    B, H = 2, 64
+    torch.manual_seed(0)
+    G, D = O.warp_module_params(), O.patchgan_params(22)
+    batch = O.synth_warp_batch(B, H, H, seed=1234)
+    m = backends.get_model(ctx, "warp", B, H)
+    backends.reset_state(m, {engine.NET_G: G, engine.NET_D: D})
+    m.set_hyper(gan_mode=0, gp_mode=2, lambda_gp=10.0)
+    for i, t in enumerate(batch):
+        m.set_input(i, t)
+    m.forward(False, 0)
+    m.backward_D(0.9, 0.8)
+    assert m.losses()["D_gp"] > 0
+    g = m.grad_arena(engine.NET_D).cpu()
+    # model.0.weight is the arena's first tensor: packed [(kh*4+kw) * 24 + ci][64], ci = buffer channel (19 and 23 are pads)
+    w0 = g[:16 * 24 * 64].view(16, 24, 64)
+    assert float(w0[:, [19, 23], :].abs().max()) == 0.0
+    assert float(w0[:, :19, :].abs().max()) > 0
+    m.set_hyper()
