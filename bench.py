@@ -47,6 +47,11 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0      # dense bf16 (v_mfma_f32_32x32x16_bf16)
 # roofline in fp32-equivalent FLOP/s is the bf16 peak / 6; SWN_SPLIT=0 runs the f32 MFMA form against the 157.3 peak.
 SPLIT = os.environ.get("SWN_SPLIT", "1") != "0"
 PEAK_SPLIT_TFLOPS = round(PEAK_BF16_MFMA_TFLOPS / 6.0, 1)
+# The pre-cut forward-type ring kernel (conv_fwd_pc_*) takes its operands as TWO fp16 planes of (operand x 2^k), k from the
+# operand's amax: x = h + l, products h h + h l + l h = 3 fp16 MFMAs per fp32 product (same dense rate as bf16), error of the
+# dropped l l term 2^-22.  SWN_PC_PLANES=3 keeps the three-plane bf16 form (6 MFMAs) for that family as well.
+PC_PLANES = 3 if os.environ.get("SWN_PC_PLANES", "2") == "3" else 2
+PEAK_PC_TFLOPS = round(PEAK_BF16_MFMA_TFLOPS / (3.0 if PC_PLANES == 2 else 6.0), 1)
 
 
 def cpu_baseline(sample_bs=4, size=256, warm=2, timed=5):
@@ -255,8 +260,11 @@ def main():
                                 f"L1 + VGG16 content + style losses, TextureModule 54.5M + PatchGAN 2.8M params, AdamW"
                                 if texture else
                                 f"warp-stage G+D optimize_parameters step, {S}x{S}, bs {B}/GPU, fp32 storage and "
-                                f"accumulation" + (", GEMM products via an exact 3 x bf16 split of both operands (6 of 9 terms, the "
-                                                   "dropped ones below 2^-24) on the bf16 MFMA pipe" if SPLIT else
+                                f"accumulation" + ((", GEMM products on the 16-bit MFMA pipe from exact operand splits: forward / input-gradient GEMMs "
+                                                    "as 2 fp16 planes of amax-scaled operands (3 of 4 terms, the dropped one below 2^-22), "
+                                                    "weight-gradient GEMMs as 3 bf16 planes (6 of 9 terms, dropped below 2^-24)" if PC_PLANES == 2 else
+                                                    ", GEMM products via an exact 3 x bf16 split of both operands (6 of 9 terms, the "
+                                                    "dropped ones below 2^-24) on the bf16 MFMA pipe") if SPLIT else
                                                    ", GEMM products on v_mfma_f32_32x32x2_f32") +
                                 f", train mode (dropout 0.5), WarpModule 137.6M + PatchGAN 2.8M params, AdamW"),
                    "global_batch": world * B, "parallelism": f"dp{world}" + (" (1-rank RCCL exchange exercised)" if rccl1 else "")},
@@ -307,7 +315,9 @@ def main():
                        "conv_fwd_256x128_fast": "conv_fwd_kernel<2, 2, 4, 2, true>",
                        "conv_fwd_dma_128x128": "conv_fwd_dma_kernel<2, 2, %s>" % sp, "conv_fwd_dma_256x64": "conv_fwd_dma_kernel<4, 1, %s>" % sp,
                        "conv_fwd_dma_128x256": "conv_fwd_dma_kernel<2, 4, %s>" % sp,
-                       "conv_fwd_pc_128x128": "conv_fwd_pc_kernel<4, 4, 2, 4>", "conv_fwd_pc_256x64": "conv_fwd_pc_kernel<8, 2, 3, 2>",
+                       "conv_fwd_pc_128x128": "conv_fwd_pc_kernel<4, 4, 2, 4, %d>" % PC_PLANES,
+                       "conv_fwd_pc_256x64": "conv_fwd_pc_kernel<8, 2, 3, 2, %d>" % PC_PLANES,
+                       "conv_fwd_pc_128x192": "conv_fwd_pc_kernel<4, 6, 2, 2, %d>" % PC_PLANES,
                        "conv_wgrad_dma_128x128": "conv_wgrad_dma_kernel<2, 2, %s>" % sp,
                        "conv_wgrad_dma_256x64": "conv_wgrad_dma_kernel<4, 1, %s>" % sp}.get(dom.split("[")[0], dom)
             step_hbm = None
@@ -330,11 +340,16 @@ def main():
             exec_flops_step = sum(v["flops"] for v in kernels.values()) / nprof
             dense_flops_step = flop_per_img * B
             is_split = SPLIT and ("_dma_" in dom or "_pc_" in dom)
-            peak = PEAK_SPLIT_TFLOPS if is_split else PEAK_FP32_MFMA_TFLOPS
+            is_pc2 = is_split and "_pc_" in dom and PC_PLANES == 2
+            peak = PEAK_PC_TFLOPS if is_pc2 else (PEAK_SPLIT_TFLOPS if is_split else PEAK_FP32_MFMA_TFLOPS)
             out["roofline"] = {
                 "bound": "mfma", "kernel": dom, "measured": "HIP events, in-order pass (second stream off)", "achieved": round(ach, 2), "peak": peak,
                 "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic, "traffic_source": traffic_src,
-                "peak_definition": ("fp32-equivalent FLOP/s of the bf16 matrix pipe for this kernel's formulation: 2500 TFLOP/s dense "
+                "peak_definition": ("fp32-equivalent FLOP/s of the 16-bit matrix pipe for this kernel's formulation: 2500 TFLOP/s dense "
+                                    "fp16 / 3 fp16 MFMA products per fp32 product (two amax-scaled fp16 planes per operand, fp32 "
+                                    "accumulate).  Nominal clock: with random operands the chip sustains 1.1-1.5 GHz in these loops "
+                                    "(profiles/ring_lab_r03_clock.txt), i.e. about half of this figure is reachable" if is_pc2 else
+                                    "fp32-equivalent FLOP/s of the bf16 matrix pipe for this kernel's formulation: 2500 TFLOP/s dense "
                                     "bf16 / 6 bf16 MFMA products per fp32 product (exact 3-way split, fp32 accumulate)" if is_split else
                                     "v_mfma_f32_32x32x2_f32 dense peak"),
                 "fp32_mfma_peak": PEAK_FP32_MFMA_TFLOPS, "frac_of_fp32_mfma_peak": round(ach / PEAK_FP32_MFMA_TFLOPS, 4),

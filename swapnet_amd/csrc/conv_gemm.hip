@@ -686,21 +686,105 @@ __device__ __forceinline__ void lds_dma16c(unsigned voff, i32x4 rsrc, unsigned s
                : : "v"(voff), "s"(rsrc), "s"(lds_dst), "s"(soff) : "memory", "m0");
 }
 
-template <int WGM, int NB, int NSTG>
+// ---- two fp16 planes instead of three bf16 ones (round 3, late; tools/ring_lab.hip gemm_h) -------------------------------------
+// The six-term bf16 loop sits on the chip's POWER cap, not on an issue limit: with random operands every lab variant (no VALU
+// at all, 16x16x32 MFMAs, 8 accumulators, one barrier per 32 k) lands at 180-200 fp32-equivalent TFLOP/s while the shader clock
+// falls to 1.1-1.3 GHz (s_memtime / s_memrealtime inside the kernel), and zero-filled operands run the same binary at
+// 1.7-2.0 GHz and 233-269 (profiles/ring_lab_r03_clock.txt).  So the remaining factor is in the matrix work per product:
+// x = h + l with h = fp16(x), l = fp16(x - h) carries 22 mantissa bits, and h h + h l + l h is THREE MFMAs at an error of the
+// dropped l l term, 2^-22 relative (lab: 3.9e-7 rel-L2 against 5.0e-7 for the six bf16 terms, 300-325 TFLOP/s against 183).
+// fp16's exponent range is what this costs: each operand is scaled by a power of two chosen from its amax (exact, removed
+// from the fp32 accumulators in the epilogue): A -- the activations / gradients cut in the loop -- from 256 partial maxima
+// that amax_partials_kernel leaves in the stream scratch right before the launch (amax * 2^kA in [2^11, 2^12): overflow-free
+// with a factor 16 to spare, 22 bits for every element within 2^-14 of the largest, an ABSOLUTE floor of amax * 2^-37
+// below); B -- the pre-cut weight operand -- by its producer (amax of the source * 2^kB in [2^9, 2^10), derived operands
+// such as Winograd-transformed filters stay within a factor 32 of that), which stores kB in a 16-byte trailer of the panel.
+// Unscaled gradient-magnitude operands lose everything (lab: 1.2e-1), a scale off by 2^-8 costs two digits (3.7e-5), a
+// scale too large by 2^8 nothing: profiles/ring_lab_r03_range.txt.  SWN_PC_PLANES=3 keeps the bf16 form.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x16 mma_f16(u32x4 a, u32x4 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+// h by truncation (one v_cvt_pkrtz for two elements; x - h is exact whatever the rounding), l rounded to nearest
+__device__ __forceinline__ void split8h(const float* v, float sa, u32x4& hi, u32x4& lo) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const float x0 = v[2 * q] * sa, x1 = v[2 * q + 1] * sa;
+    const f16x2 h = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(x0, x1));
+    const float r0 = x0 - (float)h[0], r1 = x1 - (float)h[1];
+    hi[q] = __builtin_bit_cast(unsigned, h);
+    lo[q] = __builtin_bit_cast(unsigned, f16x2{(_Float16)r0, (_Float16)r1});
+  }
+}
+// k with amax * 2^k in [2^(top-1), 2^top); 0 for an all-zero (or non-finite) operand.  |k| <= 100 keeps 2^k a normal float.
+__host__ __device__ __forceinline__ int scale_exp(float amax, int top) {
+  if (!(amax > 0.f) || amax > 3.0e38f) return 0;
+  unsigned bits; memcpy(&bits, &amax, 4);
+  const int e = (int)((bits >> 23) & 255u) - 127;
+  const int k = top - 1 - e;
+  return k < -100 ? -100 : (k > 100 ? 100 : k);
+}
+__device__ __forceinline__ float pow2f(int k) { return __uint_as_float((unsigned)(127 + k) << 23); }
+// every lane ends up with the maximum of the 256 partials (whole wave active)
+__device__ __forceinline__ float amax256(const float* part, int lane) {
+  float m = fmaxf(fmaxf(part[lane], part[lane + 64]), fmaxf(part[lane + 128], part[lane + 192]));
+#pragma unroll
+  for (int o = 32; o; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  return m;
+}
+constexpr int PC_TOP_A = 12, PC_TOP_B = 10;
+constexpr int PC_TRAILER = 8;           // bf16/f16 elements (16 bytes) behind a two-plane panel: int kB
+// 256 partial maxima of |x| over [batch][rows][C] (row stride rs, batch stride bs floats; C % 4 == 0, 16-byte aligned rows).
+// 256 blocks x 1024 threads, four independent 16-byte loads in flight per thread (64 KB per CU); `flat`: the region is one
+// dense array of `total4` float4s (no index arithmetic).  No atomics: the consumers reduce the 256 partials themselves.
+__device__ __forceinline__ float amax4(const float4& v) { return fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))); }
+__global__ __launch_bounds__(1024) void amax_partials_kernel(const float* x, size_t rows, int C4, size_t rs, int batch, size_t bs, int flat,
+                                                             float* out) {
+  const size_t total = (size_t)batch * rows * C4;
+  constexpr size_t S = (size_t)256 * 1024;
+  float m = 0.f;
+  auto at = [&](size_t i) -> const float4* {
+    if (flat) return reinterpret_cast<const float4*>(x) + i;
+    const size_t r = i / C4; const int c = (int)(i - r * C4);
+    const size_t b = r / rows, rr = r - b * rows;
+    return reinterpret_cast<const float4*>(x + b * bs + rr * rs + 4 * c);
+  };
+  size_t i = (size_t)blockIdx.x * 1024 + threadIdx.x;
+  for (; i + 3 * S < total; i += 4 * S) {
+    const float4 v0 = *at(i), v1 = *at(i + S), v2 = *at(i + 2 * S), v3 = *at(i + 3 * S);
+    m = fmaxf(m, fmaxf(fmaxf(amax4(v0), amax4(v1)), fmaxf(amax4(v2), amax4(v3))));
+  }
+  for (; i < total; i += S) m = fmaxf(m, amax4(*at(i)));
+#pragma unroll
+  for (int o = 32; o; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  __shared__ float red[16];
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x < 16) {
+    float r = red[threadIdx.x];
+#pragma unroll
+    for (int o = 8; o; o >>= 1) r = fmaxf(r, __shfl_xor(r, o));
+    if (threadIdx.x == 0) out[blockIdx.x] = r;
+  }
+}
+
+template <int WGM, int NB, int NSTG, int PL = 3>
 struct PcTile {
   static constexpr int NW = WGM, BM = 32 * WGM, BN = 32 * NB, BK = 16, NST = NSTG;
-  static constexpr int A_BYTES = BM * BK * 4, B_BYTES = 2 * 3 * BN * 16, ST_BYTES = A_BYTES + B_BYTES;
+  static constexpr int A_BYTES = BM * BK * 4, B_BYTES = 2 * PL * BN * 16, ST_BYTES = A_BYTES + B_BYTES;
   static constexpr int APC = A_BYTES / 1024, BPC = B_BYTES / 1024;
   static constexpr int AI = APC / WGM, BI = BPC / WGM, BREM = BPC % WGM;   // pieces per wave; waves < BREM carry one more of B
   static constexpr int SMEM = NST * ST_BYTES;
-  static_assert(APC % WGM == 0 && NB % 2 == 0, "tile shape");
+  static_assert(APC % WGM == 0 && NB % 2 == 0 && (PL == 2 || PL == 3), "tile shape");
 };
 
 // WGCU = workgroups per CU the tile is sized for (LDS) -> waves per SIMD the register allocation must allow
-template <int WGM, int NB, int NSTG, int WGCU>
-__global__ __launch_bounds__(64 * WGM, WGCU * WGM / 4) void conv_fwd_pc_kernel(GemmP p, DmaSched sc, const unsigned short* wpc, size_t wpc_bs) {
+template <int WGM, int NB, int NSTG, int WGCU, int PL>
+__global__ __launch_bounds__(64 * WGM, WGCU * WGM / 4) void conv_fwd_pc_kernel(GemmP p, DmaSched sc, const unsigned short* wpc, size_t wpc_bs,
+                                                                               const float* a_amax) {
 #if defined(__HIP_DEVICE_COMPILE__)
-  using T = PcTile<WGM, NB, NSTG>;
+  using T = PcTile<WGM, NB, NSTG, PL>;
   constexpr int BM = T::BM, BN = T::BN, BK = T::BK, NST = T::NST, AI = T::AI, BI = T::BI, BREM = T::BREM;
   extern __shared__ __attribute__((aligned(16))) char smem_c[];
   const int t = threadIdx.x, lane = t & 63;
@@ -729,6 +813,13 @@ __global__ __launch_bounds__(64 * WGM, WGCU * WGM / 4) void conv_fwd_pc_kernel(G
   const unsigned b_stage = (unsigned)p.tiles_n * T::B_BYTES;        // bytes of one 16-k stage of the pre-cut panel
   const i32x4 rsA = make_rsrc(p.x, x_bytes), rsB = make_rsrc(wpc, (unsigned)nkb_all * b_stage);
   const unsigned lds0 = (unsigned)(size_t)(lds_ptr_t)smem_c;
+  // two-plane form: the power-of-two operand scales (A from the partial maxima of this launch, B from the panel's trailer)
+  int kA = 0, kB = 0;
+  if constexpr (PL == 2) {
+    kA = __builtin_amdgcn_readfirstlane(scale_exp(amax256(a_amax, lane), PC_TOP_A));
+    kB = *reinterpret_cast<const int*>(wpc + (size_t)nkb_all * (b_stage / 2));
+  }
+  const float sa = pow2f(kA);
 
   // ---- loader state.  A: this lane owns AI rows of its OWN wave's 32 (row = 32 wid + 16 r + lane / 4) and one swizzled chunk.
   int a_iy0[AI], a_ix0[AI], a_base[AI];
@@ -789,7 +880,7 @@ __global__ __launch_bounds__(64 * WGM, WGCU * WGM / 4) void conv_fwd_pc_kernel(G
   const int f = (l31 >> 2) & 3;
   const int a_rd = (wid * 32 + l31) * 64;
   const int a_c0 = ((2 * h) ^ f) * 16, a_c1 = ((2 * h + 1) ^ f) * 16;
-  const int b_rd = T::A_BYTES + (h * 3 * BN + l31) * 16;                   // + (plane * BN + 32 j) * 16
+  const int b_rd = T::A_BYTES + (h * PL * BN + l31) * 16;                  // + (plane * BN + 32 j) * 16
   auto compute = [&](int st) {
     const char* S = smem_c + st * T::ST_BYTES;
     float af[8];
@@ -797,6 +888,23 @@ __global__ __launch_bounds__(64 * WGM, WGCU * WGM / 4) void conv_fwd_pc_kernel(G
       const float4 v0 = *reinterpret_cast<const float4*>(S + a_rd + a_c0);
       const float4 v1 = *reinterpret_cast<const float4*>(S + a_rd + a_c1);
       af[0] = v0.x; af[1] = v0.y; af[2] = v0.z; af[3] = v0.w; af[4] = v1.x; af[5] = v1.y; af[6] = v1.z; af[7] = v1.w;
+    }
+    if constexpr (PL == 2) {
+      u32x4 bh[NB], bl[NB];
+#pragma unroll
+      for (int j = 0; j < NB; ++j) {
+        bh[j] = *reinterpret_cast<const u32x4*>(S + b_rd + (0 * BN + 32 * j) * 16);
+        bl[j] = *reinterpret_cast<const u32x4*>(S + b_rd + (1 * BN + 32 * j) * 16);
+      }
+      u32x4 ah, al;
+      split8h(af, sa, ah, al);
+#pragma unroll
+      for (int j = 0; j < NB; ++j) {
+        f32x16 c = acc[j];
+        c = mma_f16(al, bh[j], c); c = mma_f16(ah, bl[j], c); c = mma_f16(ah, bh[j], c);          // smallest terms first
+        acc[j] = c;
+      }
+      return;
     }
     u32x4 bh[NB], bm[NB], bl[NB];
 #pragma unroll
@@ -842,6 +950,13 @@ __global__ __launch_bounds__(64 * WGM, WGCU * WGM / 4) void conv_fwd_pc_kernel(G
     }
   }
 
+  if constexpr (PL == 2) {                                // remove the operand scales (two exact power-of-two factors)
+    const float ca = pow2f(-kA), cb = pow2f(-kB);
+#pragma unroll
+    for (int j = 0; j < NB; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[j][e] = (acc[j][e] * ca) * cb;
+  }
   // ---- epilogue.  lane: rows wid*32 + (e&3) + 8*(e>>2) + 4*h, columns n0 + NB*l31 + j
   const int colr = NB * l31;
   if (nsplit > 1) {
@@ -908,18 +1023,41 @@ __global__ __launch_bounds__(64 * WGM, WGCU * WGM / 4) void conv_fwd_pc_kernel(G
 #endif
 }
 
-// producer of the pre-cut operand: one thread per (k / 8, tile_n, pos) writes the three 16-byte plane entries
+// producer of the pre-cut operand: one thread per (k / 8, tile_n, pos) writes the 16-byte plane entries (three bf16 planes, or --
+// wamax != NULL -- two fp16 planes of w * 2^kB with kB from the 256 partial maxima of the source, stored in the panel's trailer)
 __global__ __launch_bounds__(256) void conv_precut_kernel(const float* w, unsigned short* out, int K, int Npad, int BN, size_t w_bs,
-                                                          size_t out_bs) {
+                                                          size_t out_bs, const float* wamax) {
   const int NBc = BN / 32;
   const int tiles_n = (Npad + BN - 1) / BN;
   const size_t total = (size_t)(K / 8) * tiles_n * BN;
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  int kB = 0;
+  if (wamax) kB = scale_exp(amax256(wamax, threadIdx.x & 63), PC_TOP_B);      // (before any lane leaves)
   if (i >= total) return;
   const int pos = (int)(i % BN); const size_t q = i / BN;
   const int tn = (int)(q % tiles_n), kq = (int)(q / tiles_n);
   const int n = tn * BN + (pos % 32) * NBc + pos / 32;                 // pos = (nl % NB) * 32 + nl / NB
   w += (size_t)blockIdx.y * w_bs; out += (size_t)blockIdx.y * out_bs;
+  u32x4* o = reinterpret_cast<u32x4*>(out);
+  if (wamax) {
+    const float sb = pow2f(kB);
+    unsigned hi[4], lo[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float x[2];
+#pragma unroll
+      for (int e = 0; e < 2; ++e) x[e] = (n < Npad ? w[(size_t)(kq * 8 + 2 * j + e) * Npad + n] : 0.f) * sb;
+      const f16x2 hh = f16x2{(_Float16)x[0], (_Float16)x[1]};
+      hi[j] = __builtin_bit_cast(unsigned, hh);
+      lo[j] = __builtin_bit_cast(unsigned, f16x2{(_Float16)(x[0] - (float)hh[0]), (_Float16)(x[1] - (float)hh[1])});
+    }
+    // [stage = kq / 2][tile_n][kq & 1][plane 2][pos][8 f16], then the trailer
+    const size_t base = ((((size_t)(kq >> 1) * tiles_n + tn) * 2 + (kq & 1)) * 2) * BN;
+    o[base + pos] = u32x4{hi[0], hi[1], hi[2], hi[3]};
+    o[base + (size_t)BN + pos] = u32x4{lo[0], lo[1], lo[2], lo[3]};
+    if (i == 0) *reinterpret_cast<int*>(out + (size_t)(K / 16) * tiles_n * 4 * BN * 8) = kB;
+    return;
+  }
   unsigned hi[4], mid[4], lo[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
@@ -936,7 +1074,6 @@ __global__ __launch_bounds__(256) void conv_precut_kernel(const float* w, unsign
   }
   // [stage = kq / 2][tile_n][kq & 1][plane][pos][8 bf16]
   const size_t base = ((((size_t)(kq >> 1) * tiles_n + tn) * 2 + (kq & 1)) * 3) * BN;
-  u32x4* o = reinterpret_cast<u32x4*>(out);
   o[base + pos] = u32x4{hi[0], hi[1], hi[2], hi[3]};
   o[base + (size_t)BN + pos] = u32x4{mid[0], mid[1], mid[2], mid[3]};
   o[base + 2 * (size_t)BN + pos] = u32x4{lo[0], lo[1], lo[2], lo[3]};
@@ -2224,19 +2361,47 @@ static bool pc_on() {
   const bool on = !(getenv("SWN_PRECUT") && atoi(getenv("SWN_PRECUT")) == 0);      // read per launch (tests / A-B runs)
   return on;
 }
-template <int WGM, int NB, int NSTG, int WGCU>
-static void launch_fwd_pc(Stream& s, GemmP& p, int nb, const unsigned short* wpc, size_t wpc_bs) {
-  using T = PcTile<WGM, NB, NSTG>;
+// 2 (default): two fp16 planes per operand, three MFMAs per product; 3: three bf16 planes, six.  Read once: the operands a model
+// holds are cut for one of the two forms.
+static int pc_planes() {
+  static const int pl = (getenv("SWN_PC_PLANES") && atoi(getenv("SWN_PC_PLANES")) == 3) ? 3 : 2;
+  return pl;
+}
+int conv_precut_planes() { return pc_planes(); }
+// the last 2 KiB of a stream's scratch hold the partial maxima of the launch in flight (A operand) and of the operand a producer
+// is cutting; the split-K slabs of the same launch stay below
+constexpr size_t PC_WS_TAIL = 2048;
+static float* ws_amax(Stream& s, int which) {
+  if (!s.ws || s.ws_bytes < (1u << 20)) throw Error(1, "two-plane pre-cut kernels need the stream scratch");
+  return reinterpret_cast<float*>(s.ws + s.ws_bytes - PC_WS_TAIL + (size_t)which * 1024);
+}
+static void amax_partials(Stream& s, const float* x, size_t rows, int C, size_t rs, int batch, size_t bs, float* out) {
+  if (C % 4 || rs % 4 || bs % 4 || ((uintptr_t)x & 15)) throw Error(1, "amax_partials: operand not 16-byte aligned");
+  const int flat = rs == (size_t)C && (batch == 1 || bs == rows * (size_t)C);
+  hipLaunchKernelGGL(amax_partials_kernel, dim3(256), dim3(1024), 0, hs(s), x, rows, C / 4, rs, batch, bs, flat, out);
+  check_launch("amax_partials");
+}
+template <int WGM, int NB, int NSTG, int WGCU, int PL>
+static void launch_fwd_pc(Stream& s, GemmP& p, int nb, const unsigned short* wpc, size_t wpc_bs, bool phases) {
+  using T = PcTile<WGM, NB, NSTG, PL>;
   const int tiles_m = ceil_div(p.M, T::BM);
   p.tiles_n = ceil_div(p.Npad, T::BN);
   p.ntiles = tiles_m * p.tiles_n;
   constexpr int wg = WGCU;
   static_assert(wg * T::SMEM <= 160 * 1024, "tile does not fit a CU");
-  const DmaSched sc = plan_dma(p.ntiles * nb, p.ntiles, p.K / T::BK, 256 * wg, (size_t)T::BM * T::BN * 4, s.ws_bytes, nullptr,
+  const size_t ws_cap = PL == 2 ? s.ws_bytes - PC_WS_TAIL : s.ws_bytes;
+  const float* a_amax = nullptr;
+  if (PL == 2) {
+    // |A|max over the whole input tensor of the launch (all images, all channels the gather reads; batched planes too)
+    float* part = ws_amax(s, 0);
+    amax_partials(s, p.x, (size_t)(p.M / (p.Ho * p.Wo)) * p.xH * p.xW, p.xC, (size_t)p.xcs, phases ? 1 : nb, p.x_bs, part);
+    a_amax = part;
+  }
+  const DmaSched sc = plan_dma(p.ntiles * nb, p.ntiles, p.K / T::BK, 256 * wg, (size_t)T::BM * T::BN * 4, ws_cap, nullptr,
                                wg * T::NW / 12.0);
   p.slab = reinterpret_cast<float*>(s.ws);
   p.splits = sc.tail_s;
-  static bool once = (set_smem(conv_fwd_pc_kernel<WGM, NB, NSTG, WGCU>, T::SMEM), true);
+  static bool once = (set_smem(conv_fwd_pc_kernel<WGM, NB, NSTG, WGCU, PL>, T::SMEM), true);
   (void)once;
   char pname[112];
   if (prof_detail())
@@ -2246,7 +2411,8 @@ static void launch_fwd_pc(Stream& s, GemmP& p, int nb, const unsigned short* wpc
     snprintf(pname, sizeof pname, "conv_fwd_pc_%dx%d", T::BM, T::BN);
   ProfScope prof(s, pname, 2.0 * p.M * p.Cout * p.K * nb);
   const int units = sc.full + sc.tail_tiles * sc.tail_s;
-  hipLaunchKernelGGL((conv_fwd_pc_kernel<WGM, NB, NSTG, WGCU>), dim3(units), dim3(64 * T::NW), T::SMEM, hs(s), p, sc, wpc, wpc_bs);
+  hipLaunchKernelGGL((conv_fwd_pc_kernel<WGM, NB, NSTG, WGCU, PL>), dim3(units), dim3(64 * T::NW), T::SMEM, hs(s), p, sc, wpc, wpc_bs,
+                     a_amax);
   check_launch("conv_fwd_pc");
   if (sc.tail_tiles > 0 && sc.tail_s > 1) {
     hipLaunchKernelGGL((conv_dma_reduce_kernel<T::BM, T::BN>), dim3(T::BM * T::BN / 4 / 256, sc.tail_tiles), dim3(256), 0, hs(s), p, sc);
@@ -2265,13 +2431,22 @@ int conv_precut_tile(int xC, int Npad) {
   return pc_tile_for(Npad);
 }
 size_t conv_precut_elems(int K, int Npad, int bn) {
+  if (pc_planes() == 2) return (size_t)(K / 16) * ceil_div(Npad, bn) * 4 * bn * 8 + PC_TRAILER;
   return (size_t)(K / 16) * ceil_div(Npad, bn) * 6 * bn * 8;
+}
+const float* conv_precut_amax(Stream& s, const float* src, size_t rows, int C, int batch, size_t bs) {
+  if (pc_planes() != 2) return nullptr;
+  float* part = ws_amax(s, 1);
+  amax_partials(s, src, rows, C, (size_t)C, batch, bs, part);
+  return part;
 }
 void conv_precut(Stream& s, const float* w, int K, int Npad, int bn, int batch, size_t w_bs, uint16_t* out) {
   if (K % 16 || (bn != 64 && bn != 128 && bn != 192)) throw Error(1, "conv_precut: K must be a multiple of 16, tile 64, 128 or 192");
   const size_t total = (size_t)(K / 8) * ceil_div(Npad, bn) * bn;
+  // two-plane form: one scale for all `batch` panels of the launch (they are cut from one weight tensor)
+  const float* wamax = conv_precut_amax(s, w, (size_t)K, Npad, batch, w_bs);
   hipLaunchKernelGGL(conv_precut_kernel, dim3((unsigned)((total + 255) / 256), batch), dim3(256), 0, hs(s), w, out, K, Npad, bn, w_bs,
-                     conv_precut_elems(K, Npad, bn));
+                     conv_precut_elems(K, Npad, bn), wamax);
   check_launch("conv_precut");
 }
 
@@ -2347,9 +2522,16 @@ void conv_fwd(Stream& s, const ConvFwdArgs& a) {
     // weight operand handed over pre-cut (conv_precut) for this launch's column tile: the round-3 kernel
     if (a.wpc && pc_on() && split_on() && a.wpc_bn == pc_tile_for(a.Npad) &&
         (size_t)(p.K / 16) * ceil_div(a.Npad, a.wpc_bn) * 12 * a.wpc_bn * 8 < ((size_t)1 << 31)) {
-      if (a.wpc_bn == 192) launch_fwd_pc<4, 6, 2, 2>(s, p, nb, a.wpc, a.wpc_bs);   // 128 x 192, 2 stages, 2 workgroups / CU
-      else if (a.Npad > 64) launch_fwd_pc<4, 4, 2, 4>(s, p, nb, a.wpc, a.wpc_bs);  // 128 x 128, 2 stages, 4 workgroups / CU
-      else launch_fwd_pc<8, 2, 3, 2>(s, p, nb, a.wpc, a.wpc_bs);                   // 256 x 64, 3 stages, 2 workgroups / CU
+      const bool ph = a.phases != 0;
+      if (pc_planes() == 2) {
+        if (a.wpc_bn == 192) launch_fwd_pc<4, 6, 2, 2, 2>(s, p, nb, a.wpc, a.wpc_bs, ph);
+        else if (a.Npad > 64) launch_fwd_pc<4, 4, 2, 4, 2>(s, p, nb, a.wpc, a.wpc_bs, ph);
+        else launch_fwd_pc<8, 2, 3, 2, 2>(s, p, nb, a.wpc, a.wpc_bs, ph);
+        return;
+      }
+      if (a.wpc_bn == 192) launch_fwd_pc<4, 6, 2, 2, 3>(s, p, nb, a.wpc, a.wpc_bs, ph);   // 128 x 192, 2 stages, 2 workgroups / CU
+      else if (a.Npad > 64) launch_fwd_pc<4, 4, 2, 4, 3>(s, p, nb, a.wpc, a.wpc_bs, ph);  // 128 x 128, 2 stages, 4 workgroups / CU
+      else launch_fwd_pc<8, 2, 3, 2, 3>(s, p, nb, a.wpc, a.wpc_bs, ph);                   // 256 x 64, 3 stages, 2 workgroups / CU
       return;
     }
     if (!a.w) throw Error(1, "conv_fwd: the weight operand exists in pre-cut form only, but this launch cannot take the pre-cut "

@@ -93,6 +93,12 @@ void conv_fwd(Stream& s, const ConvFwdArgs& a);
 int conv_precut_tile(int xC, int Npad);
 size_t conv_precut_elems(int K, int Npad, int bn);       // uint16 elements of one [K][Npad] panel
 void conv_precut(Stream& s, const float* w, int K, int Npad, int bn, int batch, size_t w_bs, uint16_t* out);
+// Plane format of the pre-cut operands: 3 = three bf16 planes (six MFMAs per product), 2 = two fp16 planes of the operand times a
+// power of two chosen from its amax (three MFMAs; conv_gemm.hip "two fp16 planes").  In the two-plane form a panel carries a
+// 16-byte trailer with the scale exponent (counted by conv_precut_elems) and a producer first takes the 256 partial maxima of its
+// SOURCE tensor ([batch][rows][C] floats, dense rows, batch stride bs) with conv_precut_amax (NULL in the three-plane form).
+int conv_precut_planes();
+const float* conv_precut_amax(Stream& s, const float* src, size_t rows, int C, int batch, size_t bs);
 
 // dw[k][co] = sum_m A[m][k] * dy[map(m)][co]      (dw: [K][Npad], overwritten)
 struct ConvWgradArgs {

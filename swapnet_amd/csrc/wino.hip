@@ -793,13 +793,40 @@ __device__ __forceinline__ void cut8_store(const float (&u)[8], wu32x4* o, size_
   o[e0 + 2 * plane_stride] = wu32x4{lo[0], lo[1], lo[2], lo[3]};
 }
 
+// two-plane fp16 form (conv_gemm.hip): u * 2^kB as h + l
+typedef _Float16 wf16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void cut8_store_h(const float (&u)[8], float sb, wu32x4* o, size_t e0, size_t plane_stride) {
+  unsigned hi[4], lo[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float x0 = u[2 * j] * sb, x1 = u[2 * j + 1] * sb;
+    const wf16x2 hh = wf16x2{(_Float16)x0, (_Float16)x1};
+    hi[j] = __builtin_bit_cast(unsigned, hh);
+    lo[j] = __builtin_bit_cast(unsigned, wf16x2{(_Float16)(x0 - (float)hh[0]), (_Float16)(x1 - (float)hh[1])});
+  }
+  o[e0] = wu32x4{hi[0], hi[1], hi[2], hi[3]};
+  o[e0 + plane_stride] = wu32x4{lo[0], lo[1], lo[2], lo[3]};
+}
+__device__ __forceinline__ int wino_scale_exp(const float* part, int lane, int top) {      // as conv_gemm.hip scale_exp(amax256())
+  float m = fmaxf(fmaxf(part[lane], part[lane + 64]), fmaxf(part[lane + 128], part[lane + 192]));
+#pragma unroll
+  for (int o = 32; o; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  if (!(m > 0.f) || m > 3.0e38f) return 0;
+  const int e = (int)((__float_as_uint(m) >> 23) & 255u) - 127;
+  const int k = top - 1 - e;
+  return k < -100 ? -100 : (k > 100 ? 100 : k);
+}
+
 template <class F>
 __global__ __launch_bounds__(256) void winog_filter_pc_kernel(WShape w, int mode, int K, int Nn, int BN, const float* packed,
-                                                              unsigned short* out, size_t panel_elems) {
+                                                              unsigned short* out, size_t panel_elems, const float* wamax) {
   constexpr int A = F::A, R = F::R;
   const int NBc = BN / 32, tiles_n = (Nn + BN - 1) / BN;
   const size_t total = (size_t)(K / 8) * tiles_n * BN;
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const int PL = wamax ? 2 : 3;
+  int kB = 0;
+  if (wamax) kB = wino_scale_exp(wamax, threadIdx.x & 63, 10);       // PC_TOP_B; |G g G^T| <= |g|max for both 6-point forms
   if (i >= total) return;
   const int pos = (int)(i % BN); const size_t q = i / BN;
   const int tn = (int)(q % tiles_n), kq = (int)(q / tiles_n);
@@ -830,7 +857,8 @@ __global__ __launch_bounds__(256) void winog_filter_pc_kernel(WShape w, int mode
         t[kk][r][b] = s;
       }
   }
-  const size_t e0 = ((((size_t)(kq >> 1) * tiles_n + tn) * 2 + (kq & 1)) * 3) * BN + pos;      // in 16-byte entries
+  const size_t e0 = ((((size_t)(kq >> 1) * tiles_n + tn) * 2 + (kq & 1)) * PL) * BN + pos;     // in 16-byte entries
+  const float sb = __uint_as_float((unsigned)(127 + kB) << 23);
 #pragma unroll
   for (int a = 0; a < A; ++a)
 #pragma unroll
@@ -843,7 +871,13 @@ __global__ __launch_bounds__(256) void winog_filter_pc_kernel(WShape w, int mode
         for (int qq = 0; qq < R; ++qq) f1mac(s, F::G[j][qq], t[kk][a][qq]);
         u[kk] = s;
       }
-      cut8_store(u, reinterpret_cast<wu32x4*>(out + (size_t)(a * A + j) * panel_elems), e0, (size_t)BN);
+      unsigned short* panel = out + (size_t)(a * A + j) * panel_elems;
+      if (wamax) {
+        cut8_store_h(u, sb, reinterpret_cast<wu32x4*>(panel), e0, (size_t)BN);
+        if (i == 0) *reinterpret_cast<int*>(panel + (size_t)(K / 16) * tiles_n * 4 * BN * 8) = kB;       // trailer of every panel
+      } else {
+        cut8_store(u, reinterpret_cast<wu32x4*>(panel), e0, (size_t)BN);
+      }
     }
 }
 
@@ -1070,10 +1104,12 @@ void wino_filter_transform_pc(Stream& s, int m, int r, const WShape& w, int mode
   if (K % 16 || (bn != 64 && bn != 128)) throw Error(1, "wino_filter_transform_pc: K must be a multiple of 16, tile 64 or 128");
   const size_t total = (size_t)(K / 8) * ((Nn + bn - 1) / bn) * bn;
   const dim3 grid((unsigned)((total + 255) / 256));
+  // two-plane form: the scale comes from the amax of the layer's packed weights ([r * r][Cip][Npad])
+  const float* wamax = conv_precut_amax(s, packed, (size_t)r * r * w.Cip, w.Npad, 1, 0);
   if (v == 1)
-    hipLaunchKernelGGL(winog_filter_pc_kernel<F43>, grid, dim3(256), 0, hs(s), w, mode, K, Nn, bn, packed, out, panel_elems);
+    hipLaunchKernelGGL(winog_filter_pc_kernel<F43>, grid, dim3(256), 0, hs(s), w, mode, K, Nn, bn, packed, out, panel_elems, wamax);
   else
-    hipLaunchKernelGGL(winog_filter_pc_kernel<F34>, grid, dim3(256), 0, hs(s), w, mode, K, Nn, bn, packed, out, panel_elems);
+    hipLaunchKernelGGL(winog_filter_pc_kernel<F34>, grid, dim3(256), 0, hs(s), w, mode, K, Nn, bn, packed, out, panel_elems, wamax);
   check_launch("wino_filter_transform_pc");
 }
 void wino_output_transform(Stream& s, int m, int r, const float* M, int Cm, int Th, int Tw, const float* bias, int act,

@@ -140,7 +140,9 @@ void conv_fwd(Stream& s, const ConvFwdArgs& a) {
   }
 }
 void conv_fwd_naive(Stream& s, const ConvFwdArgs& a) { conv_fwd(s, a); }
-int conv_precut_tile(int, int) { return 0; }             // the simulator multiplies in plain fp32 / fp64: no pre-cut operands
+int conv_precut_tile(int, int) { return 0; }
+int conv_precut_planes() { return 3; }
+const float* conv_precut_amax(Stream&, const float*, size_t, int, int, size_t) { return nullptr; }             // the simulator multiplies in plain fp32 / fp64: no pre-cut operands
 size_t conv_precut_elems(int, int, int) { return 0; }
 void conv_precut(Stream&, const float*, int, int, int, int, size_t, uint16_t*) {}
 void wino_filter_transform_pc(Stream&, int, int, const WShape&, int, const float*, int, uint16_t*, size_t) {

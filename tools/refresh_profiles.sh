@@ -15,7 +15,7 @@ python bench.py --stage texture --steps 10 --warmup 3 > $O/bench_c3.json 2> $O/b
 python bench.py --stage infer > $O/bench_infer.json 2> $O/bench_infer.err
 SWAPNET_BENCH_RCCL1=1 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-roofline > $O/bench_c2_rccl_world1.json 2> $O/bench_c2_rccl_world1.err
 # same-box A/B of this round's switches (ms/step)
-for V in X=default SWN_PRECUT=0 SWN_WINO_S2=0 SWN_TAIL_WINO=0 SWN_FUSED_IN=0 SWN_WINO_ADJOINT=0 SWN_PREFETCH=0 SWN_OVERLAP=0; do
+for V in X=default SWN_PC_PLANES=3 SWN_PRECUT=0 SWN_WINO_S2=0 SWN_TAIL_WINO=0 SWN_FUSED_IN=0 SWN_WINO_ADJOINT=0 SWN_PREFETCH=0 SWN_OVERLAP=0; do
   env $V python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-roofline 2> /dev/null | python -c "import sys,json;d=json.loads(sys.stdin.read());print('$V', d['ms_per_step'], d['value'])" >> $O/ab_switches.txt
 done
 cat $O/ab_switches.txt
