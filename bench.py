@@ -321,7 +321,7 @@ def main():
                        "conv_wgrad_dma_128x128": "conv_wgrad_dma_kernel<2, 2, %s>" % sp,
                        "conv_wgrad_dma_256x64": "conv_wgrad_dma_kernel<4, 1, %s>" % sp}.get(dom.split("[")[0], dom)
             step_hbm = None
-            for tname in ("traffic_r03.json", "traffic_r02b.json", "traffic_r02.json", "traffic_r01.json"):
+            for tname in ("traffic_r03b.json", "traffic_r03.json", "traffic_r02b.json", "traffic_r02.json", "traffic_r01.json"):
                 tpath = os.path.join(REPO, "profiles", tname)
                 if os.path.exists(tpath):
                     # HBM bytes per launch from the committed rocprofv3 PMC passes of this same command

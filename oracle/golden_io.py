@@ -42,10 +42,13 @@ def store_full(out, key, t):
     out[key + "/full"] = t.detach().float().cpu().numpy()
 
 
-def compare_full(gold, key, t, rtol=1e-3):
+def compare_full(gold, key, t, rtol=1e-3, flip_slices=0, flip_cap=1e-2):
     """Whole-tensor check against key/full: rel-L2 <= rtol AND every element within
     rtol*|ref| + 4*rtol*rms(ref) (round-off outliers of a few sigma pass, a wrong tile / channel -- an error
-    of order rms -- cannot).  Returns (ok, message)."""
+    of order rms -- cannot).  flip_slices > 0 (gradient tensors): if that fails, the same two criteria are applied
+    with the `flip_slices` output-channel slices (dim 0) of largest squared error left out, and the whole tensor must
+    stay within flip_cap -- the signature of single LeakyReLU / ReLU sign flips between two fp32 evaluations
+    (tests/backends.py assert_grads_vs_fp64), not of a diffuse error.  Returns (ok, message)."""
     ref = torch.from_numpy(np.asarray(gold[key + "/full"])).double()
     t = t.detach().double().cpu()
     if tuple(t.shape) != tuple(ref.shape):
@@ -56,8 +59,17 @@ def compare_full(gold, key, t, rtol=1e-3):
     rl2 = float((t - ref).norm() / (ref.norm() + 1e-30))
     bad = int((err > tol).sum())
     ok = rl2 <= rtol and bad == 0
-    return ok, "%s: rel-L2 %.2e (tol %.0e), %d / %d elements outside tol, worst |d| %.3e" % (
+    msg = "%s: rel-L2 %.2e (tol %.0e), %d / %d elements outside tol, worst |d| %.3e" % (
         key, rl2, rtol, bad, ref.numel(), float(err.max()))
+    if not ok and flip_slices > 0 and t.dim() >= 1 and t.shape[0] > flip_slices and rl2 <= flip_cap:
+        d2 = (err ** 2).reshape(t.shape[0], -1).sum(dim=1)
+        keep = d2.argsort()[: t.shape[0] - flip_slices]
+        rl2k = float(d2[keep].sum().sqrt() / (ref.norm() + 1e-30))
+        badk = int((err[keep] > tol[keep]).sum())
+        ok = rl2k <= rtol and badk == 0
+        msg += "; without the %d worst output channels: rel-L2 %.2e, %d outside tol (sign-flip signature %s)" % (
+            flip_slices, rl2k, badk, "accepted" if ok else "NOT met")
+    return ok, msg
 
 
 def compare(gold, key, t, rtol=1e-3, atol_frac=1e-3):
