@@ -16,6 +16,12 @@
  *     for the duration of the call and never frees caller memory.
  *   - one context per process/GPU, driven by one host thread; all work is enqueued on the
  *     context's HIP stream.
+ *   - arithmetic: storage and accumulation are fp32 throughout.  The large implicit-GEMM kernels form each fp32 product
+ *     on the 16-bit matrix cores from an exact split of both operands -- two fp16 planes of the operand scaled by a power
+ *     of two taken from its amax (3 MFMAs, dropped term < 2^-22 relative) in the forward-type kernel, three bf16 planes
+ *     (6 MFMAs, dropped terms < 2^-24) in the weight-gradient kernel -- and are held to the f32-MFMA kernels' error by
+ *     tests/test_ops.py.  Environment: SWN_PC_PLANES=3 (bf16 planes everywhere), SWN_SPLIT=0 (v_mfma_f32_32x32x2_f32);
+ *     DESIGN.md section 4.
  */
 #ifndef SWAPNET_HIP_H
 #define SWAPNET_HIP_H

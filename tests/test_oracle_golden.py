@@ -282,3 +282,32 @@ def test_onehot_background_is_all_zero():
     assert oh.shape == (19, 2, 2)
     assert oh[:, 0, 0].sum() == 0 and oh[3, 0, 1] == 1 and oh[18, 1, 0] == 1
     assert torch.equal(O.onehot_to_labels(oh), lab)
+
+
+def test_flip_aware_gradient_checks_accept_only_the_sign_flip_signature():
+    """tests/backends.assert_grads_vs_fp64 and golden_io.compare_full let a gradient tensor exceed its bar only when the excess
+    is confined to a few output-channel slices (one LeakyReLU / ReLU flip changes ONE output channel of that layer's weight and
+    bias gradient); the same amount of error spread over the tensor, or too many affected channels, still fails."""
+    from tests import backends
+    g = torch.Generator().manual_seed(5)
+    ref = torch.randn(64, 22, 4, 4, generator=g, dtype=torch.float64)
+    ref32 = {"w": (ref + 1e-6 * torch.randn(ref.shape, generator=g, dtype=torch.float64)).float()}
+    flipped = ref.clone(); flipped[17] += 0.03 * torch.randn(22, 4, 4, generator=g, dtype=torch.float64)
+    e_full = backends.rel_l2(flipped, ref)
+    assert 2e-3 < e_full < 1e-2 and backends.rel_l2_without_worst_slices(flipped, ref, 3) == 0.0
+    backends.assert_grads_vs_fp64({"w": flipped.float()}, ref32, {"w": ref}, lambda k: False, "flip")        # accepted
+    diffuse = ref + e_full * ref.norm() / ref.numel() ** 0.5 * torch.randn(ref.shape, generator=g, dtype=torch.float64)
+    assert abs(backends.rel_l2(diffuse, ref) / e_full - 1) < 0.1
+    with pytest.raises(AssertionError):
+        backends.assert_grads_vs_fp64({"w": diffuse.float()}, ref32, {"w": ref}, lambda k: False, "diffuse")
+    many = ref.clone(); many[::8] += 0.02 * torch.randn(8, 22, 4, 4, generator=g, dtype=torch.float64)   # 8 channels > FLIP_SLICES
+    with pytest.raises(AssertionError):
+        backends.assert_grads_vs_fp64({"w": many.float()}, ref32, {"w": ref}, lambda k: False, "many")
+    big = ref.clone(); big[3] += 2.0 * torch.randn(22, 4, 4, generator=g, dtype=torch.float64)            # one channel, but > FLIP_CAP
+    with pytest.raises(AssertionError):
+        backends.assert_grads_vs_fp64({"w": big.float()}, ref32, {"w": ref}, lambda k: False, "big")
+    gold = {"k/full": ref.numpy()}
+    assert compare_full(gold, "k", flipped, rtol=3e-3 if e_full > 3e-3 else e_full / 2, flip_slices=3)[0]
+    assert not compare_full(gold, "k", flipped, rtol=e_full / 2)[0]                                        # gradient groups only
+    assert not compare_full(gold, "k", diffuse, rtol=e_full / 2, flip_slices=3)[0]
+    assert not compare_full(gold, "k", big, rtol=3e-3, flip_slices=3)[0]
