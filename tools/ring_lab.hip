@@ -703,7 +703,8 @@ __global__ void precut_a_kernel(const float* A, unsigned short* Ap, int M, int K
 
 // the round-2 kernel (both operands cut in the loop, 2 x 2 waves of 64 x 64), for the A/B on the same box
 struct LabO { const float* A; const float* B; float* C; int M, N, K, lda, ldb, ldc; size_t a_bs, b_bs, c_bs; int tiles_n, ntiles; unsigned a_bytes, b_bytes; };
-template <int FAST>
+// H2 = 1: both operands cut in the loop into two fp16 planes (3 MFMAs per product) -- the weight-gradient kernel's situation
+template <int FAST, int H2 = 0>
 __global__ __launch_bounds__(256, 3)
 void gemm_r2(LabO p) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -772,6 +773,19 @@ void gemm_r2(LabO p) {
       bf[0][s8] = b.x; bf[1][s8] = b.y;
     }
     u32x4 ah[2], am[2], al[2], bh[2], bm[2], bl[2];
+    if (H2) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) { split8h(af[i], 1.f, ah[i], al[i]); split8h(bf[i], 1.f, bh[i], bl[i]); }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          f32x16 c = acc[i][j];
+          c = mma_h(al[i], bh[j], c); c = mma_h(ah[i], bl[j], c); c = mma_h(ah[i], bh[j], c);
+          acc[i][j] = c;
+        }
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < 2; ++i) { split8(af[i], ah[i], am[i], al[i]); split8(bf[i], bh[i], bm[i], bl[i]); }
 #pragma unroll
@@ -1045,6 +1059,8 @@ int main(int argc, char** argv) {
       run("q16 128x128 4wv x32r 2ss 2w", [&] { launch_q(gemm_q<4, 2, 8, 2, 2>, 4, 2, 8, 2); });
       run("q16 256x128 8wv x32r 2ss 2w", [&] { launch_q(gemm_q<8, 2, 8, 2, 2>, 8, 2, 8, 2); });
       run("q16 128x128 8wv x16r 3ss 2w", [&] { launch_q(gemm_q<8, 1, 8, 3, 2>, 8, 1, 8, 3); });
+      run("r2 2x2 both cut bf16x3 (wgrad-style)", [&] { launch_r2(gemm_r2<1, 0>); });
+      run("r2 2x2 both cut fp16x2 (wgrad-style)", [&] { launch_r2(gemm_r2<1, 1>); });
       if (s.N <= 64 || s.N % 64 == 0) {
         run("q16 128x64 8wv x16r 2ss 4w", [&] { launch_q(gemm_q<8, 1, 4, 2, 4>, 8, 1, 4, 2); });
         run("q16 256x64 8wv x32r 2ss 2w", [&] { launch_q(gemm_q<8, 2, 4, 2, 2>, 8, 2, 4, 2); });
