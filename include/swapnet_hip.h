@@ -54,6 +54,11 @@ int swn_ctx_destroy(swn_ctx* ctx);
  * per-kernel roofline pass so that kernel durations are not inflated by co-running kernels); results
  * are identical either way.  Synchronises. */
 int swn_ctx_set_overlap(swn_ctx* ctx, int on);
+/* discriminators.define_D(input_nc, 64, opt.discriminator, opt.n_layers_D, opt.norm) (modules/discriminators.py:45-88,
+ * models/base_gan.py:147-149): the number of stride-2 levels of the NLayerDiscriminator (:91-136) of every model created on
+ * this context AFTERWARDS; 3 = "basic", the 70x70 PatchGAN (default).  1..5; the input must keep >= 3 pixels per side after
+ * the stride-2 levels.  The gradient-penalty modes exist for n_layers = 3 only (NotImplementedError otherwise). */
+int swn_ctx_set_patchgan_layers(swn_ctx* ctx, int n_layers);
 int swn_ctx_sync(swn_ctx* ctx);
 int swn_ctx_bytes_allocated(swn_ctx* ctx, size_t* out);
 
@@ -176,7 +181,7 @@ int swn_model_set_style_context(swn_model* m, const float* all_out_nchw, const f
 int swn_model_set_gp_random(swn_model* m, const float* alpha_dev, const float* beta_nchw_dev);
 /* NLayerDiscriminator.forward(input) (modules/discriminators.py:134-136) as a standalone call on the model's
  * discriminator weights: x = conditioned input in the reference's channel order, (B, 22, H, W); pred receives
- * (B, 1, H/8-2, W/8-2).  Uses a private activation set: self.fakes and the staged batch stay untouched. */
+ * (B, 1, (H >> n) - 2, (W >> n) - 2), n = the PatchGAN depth (3: H/8-2).  Uses a private activation set: self.fakes and the staged batch stay untouched. */
 int swn_model_discriminate(swn_model* m, const float* x_nchw, float* pred_nchw);
 /* PerceptualLoss(use_style)(output, target) -> (content, style) (modules/losses/perceptual.py:49-66), texture model:
  * output / target (B, 3, H, W); out2 = device float[2] = { sum over the 5 VGG16 slices of MSE(normalised features),

@@ -451,9 +451,12 @@ def warp_module_forward(P, body, cloth, dropout=0.5, training=False, taps=None):
     return torch.tanh(out)
 
 
-def patchgan_forward(P, x, n_layers=3, taps=None):
-    """NLayerDiscriminator.forward (modules/discriminators.py:110-136)."""
+def patchgan_forward(P, x, n_layers=None, taps=None):
+    """NLayerDiscriminator.forward (modules/discriminators.py:110-136).  n_layers None: read off the parameter set
+    (n_layers stride-2 convs + the stride-1 conv + the prediction conv)."""
     t = taps if taps is not None else {}
+    if n_layers is None:
+        n_layers = sum(1 for k in P if k.endswith(".weight")) - 2
     x = t["d0"] = _lrelu(F.conv2d(x, P["model.0.weight"], P["model.0.bias"], stride=2, padding=1))
     idx = 2
     for n in range(1, n_layers):

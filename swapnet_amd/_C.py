@@ -36,6 +36,7 @@ _PROTOS = {
     "swn_ctx_destroy": ([_vp], _i),
     "swn_ctx_sync": ([_vp], _i),
     "swn_ctx_set_overlap": ([_vp, _i], _i),
+    "swn_ctx_set_patchgan_layers": ([_vp, _i], _i),
     "swn_ctx_bytes_allocated": ([_vp, C.POINTER(C.c_size_t)], _i),
     "swn_prof_enable": ([_i], _i),
     "swn_prof_reset": ([], _i),

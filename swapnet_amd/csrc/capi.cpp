@@ -86,6 +86,13 @@ int swn_ctx_set_overlap(swn_ctx* ctx, int on) {
     ctx->c->side_enabled = on != 0;
   });
 }
+int swn_ctx_set_patchgan_layers(swn_ctx* ctx, int n_layers) {
+  return guard([&] {
+    REQUIRE(ctx, "ctx is NULL");
+    REQUIRE(n_layers >= 1 && n_layers <= 5, "n_layers_D must be in [1, 5]");
+    ctx->c->patchgan_layers = n_layers;
+  });
+}
 int swn_ctx_sync(swn_ctx* ctx) {
   return guard([&] { REQUIRE(ctx, "ctx is NULL"); stream_sync(ctx->c->s); });
 }

@@ -1120,7 +1120,7 @@ void Model::discriminate(const float* x_nchw, float* pred_nchw) {
     AllocScope mine(*ctx, owned_allocs);
     D3_ = std::make_unique<Net>(*ctx, arenaD);
     d3_in_ = D3_->alloc_var(B, H, W, (int)d_cimap_.size(), false);
-    d3_pred_ = build_patchgan(*D3_, d3_in_, 3, d_cimap_);
+    d3_pred_ = build_patchgan(*D3_, d3_in_, d_layers_, d_cimap_);
     D3_->finalize({});
   }
   // scatter the reference-ordered channels into the buffer order: maximal runs of consecutive channels
@@ -1146,7 +1146,10 @@ void Model::discriminate(const float* x_nchw, float* pred_nchw) {
 }
 void Model::set_gp_random(const float* alpha_dev, const float* beta_nchw_dev) {
   if (!is_train || d_cimap_.empty()) throw Error(1, "set_gp_random: the model has no discriminator");
-  if (!gp_) { AllocScope mine(*ctx, owned_allocs); gp_ = std::make_unique<GradPenalty>(*ctx, arenaD, B, H, W); }
+  if (!gp_) {
+    if (d_layers_ != 3) throw Error(3, "gradient penalty with n_layers_D = " + std::to_string(d_layers_) + " is not implemented (3-level PatchGAN only)");
+    AllocScope mine(*ctx, owned_allocs); gp_ = std::make_unique<GradPenalty>(*ctx, arenaD, B, H, W);
+  }
   if (alpha_dev) { dev_copy(ctx->s, gp_->alpha_buffer(), alpha_dev, (size_t)B * sizeof(float)); gp_alpha_set_ = true; }
   if (beta_nchw_dev) {                       // reference channel order (B, 22, H, W) -> buffer order, pads stay 0
     const int nb = (int)d_cimap_.size();
@@ -1168,7 +1171,10 @@ void Model::set_gp_random(const float* alpha_dev, const float* beta_nchw_dev) {
   }
 }
 void Model::run_gradient_penalty(const TView& real, const TView& fake) {
-  if (!gp_) { AllocScope mine(*ctx, owned_allocs); gp_ = std::make_unique<GradPenalty>(*ctx, arenaD, B, H, W); }
+  if (!gp_) {
+    if (d_layers_ != 3) throw Error(3, "gradient penalty with n_layers_D = " + std::to_string(d_layers_) + " is not implemented (3-level PatchGAN only)");
+    AllocScope mine(*ctx, owned_allocs); gp_ = std::make_unique<GradPenalty>(*ctx, arenaD, B, H, W);
+  }
   const TView beta = gp_->beta_buffer();
   // library RNG: a function of the step seed the caller handed to forward() (torch.initial_seed(), the step counter and --
   // under data parallelism -- the rank: every rank draws its own alpha / beta) and of the optimizer step

@@ -37,6 +37,9 @@ struct Ctx {
   AllocList* sink = nullptr;
   void release(AllocList& list);          // frees the list's buffers (device-synchronising) and empties it
   size_t bytes_allocated = 0;
+  // discriminators.define_D(..., n_layers_D) (modules/discriminators.py:45-88, base_gan.py:147): stride-2 levels of the PatchGAN of
+  // every model created on this context afterwards (3 = the reference's "basic" 70x70 PatchGAN)
+  int patchgan_layers = 3;
   explicit Ctx(void* stream, size_t ws_bytes);
   explicit Ctx(const Stream& shared);      // borrows stream + workspace of another context
   bool owns_ws = true;
@@ -321,6 +324,7 @@ class Model {
   std::unique_ptr<Net> D3_;       // discriminate(): own input buffer + activations, shared (frozen) arenaD
   Var d3_in_, d3_pred_;
   std::vector<int32_t> d_cimap_;  // buffer channel -> reference channel of the conditional D input (set by the model)
+  int d_layers_ = 3;              // PatchGAN depth the model was built with (Ctx::patchgan_layers at construction)
  public:
   ParamArena& arena(int net) { return net == 0 ? arenaG : arenaD; }
   virtual ParamArena* arena_ptr(int net) {

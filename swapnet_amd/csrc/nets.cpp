@@ -99,6 +99,9 @@ Var build_patchgan(Net& n, const Var& x, int n_layers, const std::vector<int32_t
   int ci = 0;
   for (int v : cimap) ci += v >= 0;
   const int ndf = 64;
+  if (n_layers < 1 || n_layers > 5) throw Error(1, "PatchGAN: n_layers_D must be in [1, 5]");
+  if ((x.v.H >> n_layers) < 3 || (x.v.W >> n_layers) < 3)
+    throw Error(1, "PatchGAN: the input is too small for " + std::to_string(n_layers) + " stride-2 levels followed by two 4x4 stride-1 convs");
   int H = x.v.H / 2, W = x.v.W / 2;
   Var a = n.alloc_var(N, H, W, ndf, true);
   n.conv("model.0", x, a, CK_K4S2, ci, ndf, true, ACT_LRELU, &cimap, true);       // :110
@@ -174,15 +177,15 @@ class WarpModel final : public Model {
       std::vector<int32_t> cimap(Ccp + Cbp, -1);
       for (int i = 0; i < Cc; ++i) cimap[i] = Cb + i;     // cloth channels follow the body channels (warp_model.py:115)
       for (int i = 0; i < Cb; ++i) cimap[Ccp + i] = i;
-      d_cimap_ = cimap;
+      d_cimap_ = cimap; d_layers_ = c.patchgan_layers;
       D2 = std::make_unique<Net>(c, arenaD);
       D2->keep_wino_inputs = true;
-      pred2 = build_patchgan(*D2, Dx, 3, cimap);
+      pred2 = build_patchgan(*D2, Dx, c.patchgan_layers, cimap);
       arenaD.allocate(c);
       D2->finalize({pred2});
       // second instance over the first B images, bound to the same (now frozen) arena
       D1 = std::make_unique<Net>(c, arenaD);
-      pred1 = build_patchgan(*D1, Dx.batch(0, B), 3, cimap);
+      pred1 = build_patchgan(*D1, Dx.batch(0, B), c.patchgan_layers, cimap);
       D1->finalize({pred1});
     }
   }

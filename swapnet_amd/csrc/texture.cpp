@@ -161,14 +161,14 @@ class TextureModel final : public Model {
     std::vector<int32_t> cimap(4 + Ccp, -1);
     for (int i = 0; i < 3; ++i) cimap[i] = Cc + i;       // textures follow the cloth channels (texture_model.py:135)
     for (int i = 0; i < Cc; ++i) cimap[4 + i] = i;
-    d_cimap_ = cimap;
+    d_cimap_ = cimap; d_layers_ = c.patchgan_layers;
     D2 = std::make_unique<Net>(c, arenaD);
     D2->keep_wino_inputs = true;
-    pred2 = build_patchgan(*D2, Dx, 3, cimap);
+    pred2 = build_patchgan(*D2, Dx, c.patchgan_layers, cimap);
     arenaD.allocate(c);
     D2->finalize({pred2});
     D1 = std::make_unique<Net>(c, arenaD);
-    pred1 = build_patchgan(*D1, Dx.batch(0, B), 3, cimap);
+    pred1 = build_patchgan(*D1, Dx.batch(0, B), c.patchgan_layers, cimap);
     D1->finalize({pred1});
     // perceptual network: one instance with gradients (fakes), one without (targets, no_grad :52-53)
     VF = std::make_unique<Net>(c, arenaV);

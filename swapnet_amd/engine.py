@@ -121,10 +121,14 @@ class NativeModel:
     NHWC arenas.  Tensors cross the boundary as NCHW fp32, exactly as the reference holds them."""
 
     def __init__(self, ctx, kind, batch, height, width, is_train=True, dropout=0.5, num_roi=12, body_channels=3,
-                 cloth_channels=19):
+                 cloth_channels=19, n_layers_D=3):
         self.ctx, self.lib, self.kind = ctx, ctx.lib, kind
         self.B, self.H, self.W, self.is_train = batch, height, width, is_train
         self.body_channels, self.cloth_channels = body_channels, cloth_channels
+        self.n_layers_D = int(n_layers_D)
+        # a context-level option read at model construction (define_D's n_layers_D, base_gan.py:147): set it for this model,
+        # whatever an earlier model on the same context asked for
+        self.lib.call("swn_ctx_set_patchgan_layers", ctx.handle, self.n_layers_D)
         h = C.c_void_p()
         if kind == "warp":
             self.lib.call("swn_warp_model_create_ex", ctx.handle, batch, height, width, int(is_train),
@@ -283,7 +287,8 @@ class NativeModel:
         cd = self.cloth_channels + (self.body_channels if self.kind == "warp" else 3)
         if tuple(xd.shape) != (self.B, cd, self.H, self.W):
             raise ValueError("discriminator input must be (%d, %d, %d, %d), got %s" % (self.B, cd, self.H, self.W, tuple(xd.shape)))
-        pred = torch.empty((self.B, 1, self.H // 8 - 2, self.W // 8 - 2), dtype=torch.float32, device=self.ctx.device)
+        k = self.n_layers_D                     # n stride-2 levels, then two 4x4 stride-1 convs with padding 1 (-1 pixel each)
+        pred = torch.empty((self.B, 1, (self.H >> k) - 2, (self.W >> k) - 2), dtype=torch.float32, device=self.ctx.device)
         self.lib.call("swn_model_discriminate", self.handle, _C.ptr(xd), _C.ptr(pred))
         self.ctx.sync()
         return pred

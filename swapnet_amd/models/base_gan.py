@@ -56,6 +56,9 @@ class BaseGAN(BaseModel, ABC):
                                      # texture: cloths are always label one-hots of --cloth_channels (texture_model.py:105)
                                      body_channels=getattr(self, "body_channels", 3),
                                      cloth_channels=getattr(self, "cloth_channels", getattr(opt, "cloth_channels", 19)))
+        if self.is_train and getattr(opt, "discriminator", "basic") == "n_layers":
+            # define_D(..., opt.n_layers_D) (base_gan.py:147): the native networks of a stage are built together, on first use
+            self.backend.n_layers_D = int(opt.n_layers_D)
         self.net_generator = self.define_G()
         modules.init_weights(self.net_generator, opt.init_type, opt.init_gain)      # base_gan.py:141
         self.model_names = ["generator"]

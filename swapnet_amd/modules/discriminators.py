@@ -7,18 +7,24 @@ from .native import NativeNet
 
 
 class NLayerDiscriminator(NativeNet):
-    """70x70 PatchGAN, n_layers=3, ndf=64, instance norm, bias on every conv (:91-136)."""
+    """PatchGAN with `n_layers` stride-2 levels (3 = the 70x70 "basic" one), ndf=64, instance norm, bias on every conv
+    (:91-136).  ndf is fixed at 64 as in the reference's only call site (models/base_gan.py:147)."""
 
     def __init__(self, backend, input_nc=22, ndf=64, n_layers=3):
         want = backend.cloth_channels + (backend.body_channels if backend.kind == "warp" else 3)
-        if input_nc != want or ndf != 64 or n_layers != 3:
-            raise NotImplementedError("native PatchGAN: ndf 64, 3 layers, input channels = the stage's conditional "
-                                      "input (%d here), got input_nc=%d ndf=%d n_layers=%d" % (want, input_nc, ndf, n_layers))
+        if input_nc != want or ndf != 64:
+            raise NotImplementedError("native PatchGAN: ndf 64, input channels = the stage's conditional "
+                                      "input (%d here), got input_nc=%d ndf=%d" % (want, input_nc, ndf))
+        if not 1 <= int(n_layers) <= 5:
+            raise NotImplementedError("native PatchGAN: n_layers_D in [1, 5], got %d" % n_layers)
+        if backend.models and backend.n_layers_D != int(n_layers):
+            raise RuntimeError("the stage's networks already exist with n_layers_D = %d" % backend.n_layers_D)
+        backend.n_layers_D = int(n_layers)
         super().__init__(backend, engine.NET_D)
 
     def forward(self, input):
         """NLayerDiscriminator.forward (:134-136): `input` = the conditioned batch in the reference's channel
-        order, (B, 22, H, W) -> prediction map (B, 1, H/8-2, W/8-2).  Inference-only call on the current
+        order, (B, 22, H, W) -> prediction map (B, 1, (H >> n_layers) - 2, (W >> n_layers) - 2).  Inference-only call on the current
         weights (inside a training step the discriminator runs fused in model.backward_D / backward_G)."""
         b, c, h, w = input.shape
         m = self._backend.ensure(b, h, w)

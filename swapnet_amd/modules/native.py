@@ -21,6 +21,7 @@ class NativeBackend:
         self.kind, self.is_train, self.dropout, self.num_roi = kind, is_train, dropout, num_roi
         self.body_channels, self.cloth_channels = body_channels, cloth_channels
         self.default_shape = tuple(default_shape)
+        self.n_layers_D = 3         # define_D(..., n_layers_D): set by NLayerDiscriminator before the first model exists
         self.ctx = ctx or engine.default_context(device=device, lib=lib)
         self.models = {}
         self.cur = None
@@ -35,7 +36,7 @@ class NativeBackend:
         if m is None:
             m = engine.NativeModel(self.ctx, self.kind, key[0], key[1], key[2], is_train=self.is_train,
                                    dropout=self.dropout, num_roi=self.num_roi, body_channels=self.body_channels,
-                                   cloth_channels=self.cloth_channels)
+                                   cloth_channels=self.cloth_channels, n_layers_D=self.n_layers_D)
             m.set_hyper(**self.hyper)
             self.models[key] = m
             if self.cur is not None:

@@ -181,3 +181,72 @@ def test_channel_options_reproduce_the_reference(backend, golden_dir):
                 assert ok, (who, msg)
         finally:
             m.close()
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_patchgan_depth_option_reproduces_the_reference(backend, golden_dir):
+    """--discriminator n_layers --n_layers_D 2 / 4 (modules/discriminators.py:45-88,91-136; models/base_gan.py:147-149).
+    tests/golden/warp_depths_64.npz was recorded from the REAL reference (oracle/make_golden.py depths): parameter set after
+    init, the discriminator's prediction map on the conditioned targets, one WarpModel step.  The oracle reproduces all of it;
+    the native PatchGAN (swn_ctx_set_patchgan_layers) has the reference's parameter names / shapes, its standalone forward
+    matches, and its fused step reproduces losses, fakes and every post-step D weight."""
+    import os
+    import numpy as np
+    from oracle.golden_io import compare
+    gold = np.load(os.path.join(golden_dir, "warp_depths_64.npz"))
+    B, H = int(gold["meta/B"]), int(gold["meta/H"])
+    ctx = _ctx(backend)
+    bodys, inputs, targets = O.synth_warp_batch(B, H, H, seed=1234)
+    for n in (2, 4):
+        pre = "n%d/" % n
+        torch.manual_seed(int(gold["meta/init_seed"]))
+        G, D = O.warp_module_params(), O.patchgan_params(22, n_layers=n)
+        assert list(D.keys()) == [str(k) for k in gold[pre + "D_keys"]]
+        for k, v in D.items():
+            assert tuple(v.shape) == tuple(int(x) for x in gold[pre + "D_shape/" + k])
+            ok, msg = compare(gold, pre + "initD/" + k, v, 1e-6, 1e-6)
+            assert ok, msg
+        x = torch.cat((bodys, targets), 1)
+        with torch.no_grad():
+            pred = O.patchgan_forward(D, x)
+        ok, msg = compare(gold, pre + "pred_real", pred, 1e-4, 1e-4)
+        assert ok, ("oracle", msg)
+        torch.manual_seed(int(gold["meta/step_seed"]))
+        st = O.WarpStepOracle(G, D)
+        st.step(bodys, inputs, targets)
+        m = engine.NativeModel(ctx, "warp", B, H, H, n_layers_D=n)
+        try:
+            infos = m.param_infos(engine.NET_D)
+            assert list(infos.keys()) == list(D.keys()) and all(tuple(infos[k]) == tuple(D[k].shape) for k in D)
+            backends.reset_state(m, {engine.NET_G: G, engine.NET_D: D})
+            got = m.discriminate(x)
+            assert tuple(got.shape) == tuple(pred.shape) and rel(got, pred) < 1e-3, (n, rel(got, pred))
+            ok, msg = compare(gold, pre + "pred_real", got, 1e-3, 1e-3)
+            assert ok, ("native", msg)
+            for i, t in enumerate((bodys, inputs, targets)):
+                m.set_input(i, t)
+            m.step(st.labels, training=False, seed=0)
+            L = m.losses()
+            for k, v in st.losses.items():
+                ref = float(gold[pre + "loss/" + k])
+                assert abs(v - ref) <= 1e-4 * abs(ref) + 1e-6, (n, "oracle", k, v, ref)
+                assert abs(L[k] - ref) <= 1e-3 * abs(ref) + 1e-6, (n, "native", k, L[k], ref)
+            for who, fakes in (("oracle", st.fakes), ("native", m.output())):
+                ok, msg = compare(gold, pre + "fakes", fakes, 1e-3, 1e-3)
+                assert ok, (who, msg)
+            pD = m.state_dict(engine.NET_D, to_cpu=True)
+            for k in D:
+                if k.endswith(".weight"):
+                    assert rel(pD[k], st.D[k]) < 1e-3, (n, k, rel(pD[k], st.D[k]))
+                    ok, msg = compare(gold, pre + "postD/" + k, st.D[k], 1e-3, 3e-3)
+                    assert ok, ("oracle", msg)
+            # gradient-penalty objectives exist for the 3-level PatchGAN only
+            m.set_hyper(gan_mode=2, gp_mode=1)                      # wgan-gp (tests/test_gradient_penalty.py)
+            with pytest.raises(NotImplementedError):
+                m.step(st.labels, training=False, seed=0)
+        finally:
+            m.close()
+    with pytest.raises(ValueError):
+        engine.NativeModel(ctx, "warp", B, H, H, n_layers_D=6)
+    with pytest.raises(ValueError):
+        engine.NativeModel(ctx, "warp", 1, 32, 32, n_layers_D=4)          # 32 >> 4 = 2 pixels: too small
