@@ -488,6 +488,7 @@ int swn_op_conv(swn_ctx* ctx, int kind, int transposed, int what, int naive, flo
     } else {
       nchw_to_nhwc(s, y, n, co, Ho, Wo, yv.g);
       if (what == 1) {
+        net.refresh_dgrad();        // a layer that is not the net's first also forms its input gradient: from operands that exist
         net.backward(true, false);
         unpack_weight(s, wd.ws, A.g + wd.off, wgt);
       } else {

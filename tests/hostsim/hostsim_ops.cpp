@@ -10,6 +10,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <string>
 #include <vector>
 
 #include "../../swapnet_amd/csrc/ops.h"
@@ -120,7 +121,72 @@ static size_t tail_panel(int ph, int xC, int Npad) {
   static const int pre[4] = {0, 4, 10, 16};
   return (size_t)pre[ph] * xC * Npad;
 }
+// ---- pre-cut weight operands (ops.h conv_precut_*).  The simulator multiplies in plain fp32 / fp64, so it has no use for fp16 planes;
+// it keeps the PLUMBING of the product honest instead: a "panel" here is the fp32 operand itself (a two-plane panel has exactly fp32's
+// 4 bytes per element) in [K][tiles * bn] order plus the 16-byte trailer, written by the same producers and consumed through the same
+// ConvFwdArgs::wpc / wpc_bn / wpc_bs fields, so the engine's panel sizes, offsets, batch strides and refresh order are exercised in CI.
+// A consumer checks the trailer's magic (a wrong offset / stride / tile shows up as an error, not as a silently different result).
+static const int kPanelMagic = 0x5EC07E00;
+static int sim_tile_for(int Npad) { return Npad <= 64 ? 64 : ((Npad > 128 && Npad <= 192) ? 192 : 128); }
+int conv_precut_tile(int xC, int Npad) {
+  const char* e = getenv("SWN_PRECUT");
+  if ((e && atoi(e) == 0) || xC % 16 || Npad <= 32) return 0;
+  return sim_tile_for(Npad);
+}
+int conv_precut_planes() { return 2; }
+const float* conv_precut_amax(Stream&, const float*, size_t, int, int, size_t) { return nullptr; }
+static size_t sim_np(int Npad, int bn) { return (size_t)((Npad + bn - 1) / bn) * bn; }
+size_t conv_precut_elems(int K, int Npad, int bn) { return (size_t)(K / 16) * ((Npad + bn - 1) / bn) * 4 * bn * 8 + 8; }
+static void sim_store_panel(const float* w, int K, int Npad, int bn, uint16_t* out) {
+  const size_t NP = sim_np(Npad, bn);
+  float* f = reinterpret_cast<float*>(out);
+  for (int k = 0; k < K; ++k)
+    for (size_t n = 0; n < NP; ++n) f[(size_t)k * NP + n] = n < (size_t)Npad ? w[(size_t)k * Npad + n] : 0.f;
+  reinterpret_cast<int*>(f + (size_t)K * NP)[0] = kPanelMagic + bn;
+}
+void conv_precut(Stream&, const float* w, int K, int Npad, int bn, int batch, size_t w_bs, uint16_t* out) {
+  if (K % 16 || (bn != 64 && bn != 128 && bn != 192)) throw Error(1, "conv_precut: K must be a multiple of 16, tile 64, 128 or 192");
+  const size_t pe = conv_precut_elems(K, Npad, bn);
+  for (int z = 0; z < batch; ++z) sim_store_panel(w + (size_t)z * w_bs, K, Npad, bn, out + (size_t)z * pe);
+}
+void wino_filter_transform(Stream&, int m, int r, const WShape& w, int mode, const float* packed, float* U);
+void wino_filter_transform_pc(Stream& s, int m, int r, const WShape& w, int mode, const float* packed, int bn, uint16_t* out,
+                              size_t panel_elems) {
+  const int K = mode == 0 ? w.Cip : w.Npad, Nn = mode == 0 ? w.Npad : w.Cip;
+  if (K % 16 || (bn != 64 && bn != 128)) throw Error(1, "wino_filter_transform_pc: K must be a multiple of 16, tile 64 or 128");
+  if (panel_elems != conv_precut_elems(K, Nn, bn)) throw Error(1, "wino_filter_transform_pc: panel stride does not match conv_precut_elems");
+  const int A = m + r - 1, P = A * A;
+  std::vector<float> U((size_t)P * K * Nn);
+  wino_filter_transform(s, m, r, w, mode, packed, U.data());
+  for (int p = 0; p < P; ++p) sim_store_panel(U.data() + (size_t)p * K * Nn, K, Nn, bn, out + (size_t)p * panel_elems);
+}
+
 void conv_fwd(Stream& s, const ConvFwdArgs& a) {
+  if (a.wpc) {
+    // decode the panels back into the fp32 operand the loops below read
+    if (a.tail4) throw Error(1, "hostsim conv_fwd: pre-cut operand on a tail4 launch");
+    const int nb = a.phases ? a.phases : (a.batch > 0 ? a.batch : 1);
+    const int K = a.g.KH * a.g.KW * a.x.C, bn = a.wpc_bn;
+    if (bn != sim_tile_for(a.Npad)) throw Error(1, "hostsim conv_fwd: operand pre-cut for another column tile");
+    const size_t NP = sim_np(a.Npad, bn), pe = conv_precut_elems(K, a.Npad, bn);
+    if (nb > 1 && a.wpc_bs != pe) throw Error(1, "hostsim conv_fwd: panel stride does not match conv_precut_elems");
+    std::vector<float> wf((size_t)nb * K * a.Npad);
+    for (int z = 0; z < nb; ++z) {
+      const float* f = reinterpret_cast<const float*>(a.wpc + (size_t)z * a.wpc_bs);
+      if (reinterpret_cast<const int*>(f + (size_t)K * NP)[0] != kPanelMagic + bn)
+        throw Error(1, "hostsim conv_fwd: pre-cut panel trailer not found (wrong offset, stride, K or tile): K " + std::to_string(K) + " Npad " +
+                           std::to_string(a.Npad) + " bn " + std::to_string(bn) + " panel " + std::to_string(z) + "/" + std::to_string(nb) + " KH " +
+                           std::to_string(a.g.KH) + " stride " + std::to_string(a.g.stride) + " xC " + std::to_string(a.x.C) + " found " +
+                           std::to_string(reinterpret_cast<const int*>(f + (size_t)K * NP)[0]));
+      for (int k = 0; k < K; ++k)
+        for (int n = 0; n < a.Npad; ++n) wf[((size_t)z * K + k) * a.Npad + n] = f[(size_t)k * NP + n];
+    }
+    ConvFwdArgs c = a;
+    c.wpc = nullptr; c.w = wf.data(); c.w_bs = (size_t)K * a.Npad;
+    conv_fwd(s, c);
+    return;
+  }
+  if (!a.w) throw Error(1, "hostsim conv_fwd: no weight operand");
   if (a.tail4) {
     for (int ph = 0; ph < 4; ++ph) {
       ConvFwdArgs c = tail_phase(a, ph);
@@ -140,14 +206,6 @@ void conv_fwd(Stream& s, const ConvFwdArgs& a) {
   }
 }
 void conv_fwd_naive(Stream& s, const ConvFwdArgs& a) { conv_fwd(s, a); }
-int conv_precut_tile(int, int) { return 0; }
-int conv_precut_planes() { return 3; }
-const float* conv_precut_amax(Stream&, const float*, size_t, int, int, size_t) { return nullptr; }             // the simulator multiplies in plain fp32 / fp64: no pre-cut operands
-size_t conv_precut_elems(int, int, int) { return 0; }
-void conv_precut(Stream&, const float*, int, int, int, int, size_t, uint16_t*) {}
-void wino_filter_transform_pc(Stream&, int, int, const WShape&, int, const float*, int, uint16_t*, size_t) {
-  throw Error(1, "hostsim: no pre-cut operands");
-}
 
 static void conv_wgrad_one(const ConvWgradArgs& a) {
   const TView& X = a.x; const Gather& g = a.g;
