@@ -137,27 +137,37 @@ int conv_precut_planes() { return 2; }
 const float* conv_precut_amax(Stream&, const float*, size_t, int, int, size_t) { return nullptr; }
 static size_t sim_np(int Npad, int bn) { return (size_t)((Npad + bn - 1) / bn) * bn; }
 size_t conv_precut_elems(int K, int Npad, int bn) { return (size_t)(K / 16) * ((Npad + bn - 1) / bn) * 4 * bn * 8 + 8; }
+static void sim_trailer(uint16_t* panel, int K, int Npad, int bn) {
+  reinterpret_cast<int*>(reinterpret_cast<float*>(panel) + (size_t)K * sim_np(Npad, bn))[0] = kPanelMagic + bn;
+}
 static void sim_store_panel(const float* w, int K, int Npad, int bn, uint16_t* out) {
   const size_t NP = sim_np(Npad, bn);
   float* f = reinterpret_cast<float*>(out);
-  for (int k = 0; k < K; ++k)
-    for (size_t n = 0; n < NP; ++n) f[(size_t)k * NP + n] = n < (size_t)Npad ? w[(size_t)k * Npad + n] : 0.f;
-  reinterpret_cast<int*>(f + (size_t)K * NP)[0] = kPanelMagic + bn;
+  if (NP == (size_t)Npad) memcpy(f, w, (size_t)K * Npad * sizeof(float));
+  else
+    for (int k = 0; k < K; ++k)
+      for (size_t n = 0; n < NP; ++n) f[(size_t)k * NP + n] = n < (size_t)Npad ? w[(size_t)k * Npad + n] : 0.f;
+  sim_trailer(out, K, Npad, bn);
 }
 void conv_precut(Stream&, const float* w, int K, int Npad, int bn, int batch, size_t w_bs, uint16_t* out) {
   if (K % 16 || (bn != 64 && bn != 128 && bn != 192)) throw Error(1, "conv_precut: K must be a multiple of 16, tile 64, 128 or 192");
   const size_t pe = conv_precut_elems(K, Npad, bn);
   for (int z = 0; z < batch; ++z) sim_store_panel(w + (size_t)z * w_bs, K, Npad, bn, out + (size_t)z * pe);
 }
-void wino_filter_transform(Stream&, int m, int r, const WShape& w, int mode, const float* packed, float* U);
-void wino_filter_transform_pc(Stream& s, int m, int r, const WShape& w, int mode, const float* packed, int bn, uint16_t* out,
+static void wino_filter_transform_strided(int m, int r, const WShape& w, int mode, const float* packed, float* U, size_t total);
+void wino_filter_transform_pc(Stream&, int m, int r, const WShape& w, int mode, const float* packed, int bn, uint16_t* out,
                               size_t panel_elems) {
   const int K = mode == 0 ? w.Cip : w.Npad, Nn = mode == 0 ? w.Npad : w.Cip;
   if (K % 16 || (bn != 64 && bn != 128)) throw Error(1, "wino_filter_transform_pc: K must be a multiple of 16, tile 64 or 128");
   if (panel_elems != conv_precut_elems(K, Nn, bn)) throw Error(1, "wino_filter_transform_pc: panel stride does not match conv_precut_elems");
   const int A = m + r - 1, P = A * A;
+  if (sim_np(Nn, bn) == (size_t)Nn) {             // dense panels: transform straight into them (plane stride = the panel stride)
+    wino_filter_transform_strided(m, r, w, mode, packed, reinterpret_cast<float*>(out), panel_elems / 2);
+    for (int p = 0; p < P; ++p) sim_trailer(out + (size_t)p * panel_elems, K, Nn, bn);
+    return;
+  }
   std::vector<float> U((size_t)P * K * Nn);
-  wino_filter_transform(s, m, r, w, mode, packed, U.data());
+  wino_filter_transform_strided(m, r, w, mode, packed, U.data(), (size_t)K * Nn);
   for (int p = 0; p < P; ++p) sim_store_panel(U.data() + (size_t)p * K * Nn, K, Nn, bn, out + (size_t)p * panel_elems);
 }
 
@@ -170,7 +180,6 @@ void conv_fwd(Stream& s, const ConvFwdArgs& a) {
     if (bn != sim_tile_for(a.Npad)) throw Error(1, "hostsim conv_fwd: operand pre-cut for another column tile");
     const size_t NP = sim_np(a.Npad, bn), pe = conv_precut_elems(K, a.Npad, bn);
     if (nb > 1 && a.wpc_bs != pe) throw Error(1, "hostsim conv_fwd: panel stride does not match conv_precut_elems");
-    std::vector<float> wf((size_t)nb * K * a.Npad);
     for (int z = 0; z < nb; ++z) {
       const float* f = reinterpret_cast<const float*>(a.wpc + (size_t)z * a.wpc_bs);
       if (reinterpret_cast<const int*>(f + (size_t)K * NP)[0] != kPanelMagic + bn)
@@ -178,11 +187,21 @@ void conv_fwd(Stream& s, const ConvFwdArgs& a) {
                            std::to_string(a.Npad) + " bn " + std::to_string(bn) + " panel " + std::to_string(z) + "/" + std::to_string(nb) + " KH " +
                            std::to_string(a.g.KH) + " stride " + std::to_string(a.g.stride) + " xC " + std::to_string(a.x.C) + " found " +
                            std::to_string(reinterpret_cast<const int*>(f + (size_t)K * NP)[0]));
-      for (int k = 0; k < K; ++k)
-        for (int n = 0; n < a.Npad; ++n) wf[((size_t)z * K + k) * a.Npad + n] = f[(size_t)k * NP + n];
     }
     ConvFwdArgs c = a;
-    c.wpc = nullptr; c.w = wf.data(); c.w_bs = (size_t)K * a.Npad;
+    c.wpc = nullptr;
+    std::vector<float> wf;
+    if (NP == (size_t)a.Npad) {                     // dense panel = the fp32 operand itself
+      c.w = reinterpret_cast<const float*>(a.wpc); c.w_bs = a.wpc_bs / 2;
+    } else {
+      wf.resize((size_t)nb * K * a.Npad);
+      for (int z = 0; z < nb; ++z) {
+        const float* f = reinterpret_cast<const float*>(a.wpc + (size_t)z * a.wpc_bs);
+        for (int k = 0; k < K; ++k)
+          for (int n = 0; n < a.Npad; ++n) wf[((size_t)z * K + k) * a.Npad + n] = f[(size_t)k * NP + n];
+      }
+      c.w = wf.data(); c.w_bs = (size_t)K * a.Npad;
+    }
     conv_fwd(s, c);
     return;
   }
@@ -296,11 +315,11 @@ void wino_input_transform(Stream&, int m, int r, const TView& x, int pad, int pa
     }
   }
 }
-void wino_filter_transform(Stream&, int m, int r, const WShape& w, int mode, const float* packed, float* U) {
+static void wino_filter_transform_strided(int m, int r, const WShape& w, int mode, const float* packed, float* U, size_t total) {
+  // total = floats between consecutive transform-point planes (K * Nn when dense)
   const WinoMats wm = wino_mats(m, r);
   const int A = wm.A, R = wm.r;
   const int K = mode == 0 ? w.Cip : w.Npad, Nn = mode == 0 ? w.Npad : w.Cip;
-  const size_t total = (size_t)K * Nn;
 #pragma omp parallel for
   for (int k = 0; k < K; ++k) for (int n = 0; n < Nn; ++n) {
     float g[4][4], t[6][4];
@@ -312,6 +331,10 @@ void wino_filter_transform(Stream&, int m, int r, const WShape& w, int mode, con
     for (int a = 0; a < A; ++a) for (int b = 0; b < A; ++b) { float s = 0; for (int q = 0; q < R; ++q) s += t[a][q] * wm.G[b * R + q];
       U[(size_t)(a * A + b) * total + (size_t)k * Nn + n] = s; }
   }
+}
+void wino_filter_transform(Stream&, int m, int r, const WShape& w, int mode, const float* packed, float* U) {
+  const int K = mode == 0 ? w.Cip : w.Npad, Nn = mode == 0 ? w.Npad : w.Cip;
+  wino_filter_transform_strided(m, r, w, mode, packed, U, (size_t)K * Nn);
 }
 void wino_output_transform(Stream&, int m, int r, const float* M, int Cm, int Th, int Tw, const float* bias, int act,
                            const TView& y, int Cout, int accumulate) {
