@@ -353,6 +353,11 @@ def main():
                                     "bf16 / 6 bf16 MFMA products per fp32 product (exact 3-way split, fp32 accumulate)" if is_split else
                                     "v_mfma_f32_32x32x2_f32 dense peak"),
                 "fp32_mfma_peak": PEAK_FP32_MFMA_TFLOPS, "frac_of_fp32_mfma_peak": round(ach / PEAK_FP32_MFMA_TFLOPS, 4),
+                # the yardstick of the round-2 / early round-3 lines (three bf16 planes, 6 MFMAs per product: 2500 / 6), so that the
+                # fp32-equivalent rate can be followed across rounds although this kernel's own roofline doubled with the two-plane form
+                "frac_of_bf16x6_roofline": round(ach / PEAK_SPLIT_TFLOPS, 4),
+                "power_note": ("six-term bf16 loop measured on the power cap: 1.06-1.3 GHz shader clock on random operands, 1.7-2.0 GHz on "
+                               "zeros, every loop variant within 3 % (profiles/ring_lab_r03_clock.txt, ring_lab_r03_variants.txt)"),
                 # HBM side of the same step: bytes of the PMC passes (same source as `traffic`) over this run's step time, against
                 # the 6.3 TB/s the guide measures as achievable (8 TB/s spec)
                 "step_hbm_bytes": step_hbm,
