@@ -17,11 +17,13 @@
  *   - one context per process/GPU, driven by one host thread; all work is enqueued on the
  *     context's HIP stream.
  *   - arithmetic: storage and accumulation are fp32 throughout.  The large implicit-GEMM kernels form each fp32 product
- *     on the 16-bit matrix cores from an exact split of both operands -- two fp16 planes of the operand scaled by a power
- *     of two taken from its amax (3 MFMAs, dropped term < 2^-22 relative) in the forward-type kernel, three bf16 planes
- *     (6 MFMAs, dropped terms < 2^-24) in the weight-gradient kernel -- and are held to the f32-MFMA kernels' error by
- *     tests/test_ops.py.  Environment: SWN_PC_PLANES=3 (bf16 planes everywhere), SWN_SPLIT=0 (v_mfma_f32_32x32x2_f32);
- *     DESIGN.md section 4.
+ *     on the 16-bit matrix cores from a split of both operands into two fp16 planes, x * 2^k = h + l with k chosen per TENSOR
+ *     from its amax: h + l carries 22 of fp32's 24 mantissa bits for every element within 2^-14 of the tensor's largest and
+ *     progressively fewer below that (absolute floor amax * 2^-37), and three of the four partial products are formed (the
+ *     dropped l*l term is < 2^-22 relative).  This is NOT an exact representation of fp32: it is held to the f32-MFMA
+ *     kernels' error on well-conditioned and on heavy-tailed operands by tests/test_ops.py (rel-L2 and element-wise).
+ *     Environment: SWN_PC_PLANES=3 / SWN_WGRAD_PLANES=3 (three bf16 planes by truncation -- that split IS exact, 24 bits
+ *     in, 24 out -- six MFMAs, dropped terms < 2^-24), SWN_SPLIT=0 (v_mfma_f32_32x32x2_f32); DESIGN.md section 4.
  */
 #ifndef SWAPNET_HIP_H
 #define SWAPNET_HIP_H
@@ -36,7 +38,7 @@ extern "C" {
 typedef struct swn_ctx swn_ctx;
 typedef struct swn_model swn_model;
 
-int swn_abi_version(void);   /* 2: swn_hyper gained d_b1, d_b2; 3: gp_mode, lambda_gp */
+int swn_abi_version(void);   /* 2: swn_hyper gained d_b1, d_b2; 3: gp_mode, lambda_gp; 4: swn_route_*, swn_comm_* */
 const char* swn_last_error(void);
 /* 1 when this library executes on a HIP device (libswapnet_hip.so), 0 for the CI simulator */
 int swn_is_device_build(void);
@@ -68,6 +70,14 @@ int swn_ctx_bytes_allocated(swn_ctx* ctx, size_t* out);
 int swn_prof_enable(int on);
 int swn_prof_reset(void);
 int swn_prof_report(char* buf, int len);
+/* Routing trace: which kernel family / algorithmic form each layer takes under the CURRENT environment (the SWN_* switches of
+ * DESIGN.md section 4 select among kernels; models/base_gan.py:194-203 is the step whose launches are listed).  While on, every
+ * implicit-GEMM launch (name, M, N, K, batch, split schedule) and every Winograd transform is recorded against the layer
+ * (state_dict prefix) and phase (f forward, b backward, r operand refresh) that issued it; report = the distinct lines in
+ * first-use order, returns the bytes the full report needs.  tests/ compare the list of a scrubbed-environment run (what
+ * bench.py times) with the list of the run they check against the oracle. */
+int swn_route_trace(int on);
+int swn_route_report(char* buf, int len);
 
 /* ---- models ---------------------------------------------------------------------------
  * swn_warp_model_create    <-> models.create_model(opt) with --model warp

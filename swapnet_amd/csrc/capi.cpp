@@ -53,7 +53,7 @@ static int guard(F f) {
 
 extern "C" {
 
-int swn_abi_version(void) { return 3; }
+int swn_abi_version(void) { return 4; }
 const char* swn_last_error(void) { return g_err.c_str(); }
 int swn_is_device_build(void) { return is_device_build(); }
 
@@ -103,6 +103,8 @@ int swn_ctx_bytes_allocated(swn_ctx* ctx, size_t* out) {
 int swn_prof_enable(int on) { return guard([&] { prof_enable(on); }); }
 int swn_prof_reset(void) { return guard([&] { prof_reset(); }); }
 int swn_prof_report(char* buf, int len) { return prof_report(buf, len); }
+int swn_route_trace(int on) { return guard([&] { route_enable(on); }); }
+int swn_route_report(char* buf, int len) { return route_report(buf, len); }
 
 int swn_warp_model_create_ex(swn_ctx* ctx, int batch, int height, int width, int is_train, float dropout,
                              int body_channels, int cloth_channels, swn_model** out) {
@@ -152,6 +154,9 @@ int swn_model_set_hyper(swn_model* m, const swn_hyper* h) {
     REQUIRE(h->gp_mode >= 0 && h->gp_mode <= 3, "gradient penalty mode not implemented");
     REQUIRE(h->gp_mode == 0 || m->m->supports_gradient_penalty(),
             "gradient penalty modes are not implemented for the texture model (the reference's call fails there too)");
+    if (h->gp_mode != 0 && m->m->patchgan_layers() != 3)          // at configuration time, not in the middle of the first step
+      throw Error(3, "gradient penalty with n_layers_D = " + std::to_string(m->m->patchgan_layers()) +
+                         " is not implemented (3-level PatchGAN only)");
     y.gp_mode = h->gp_mode; y.lambda_gp = h->lambda_gp;
   });
 }

@@ -717,6 +717,20 @@ __device__ __forceinline__ void split8h(const float* v, float sa, u32x4& hi, u32
     lo[q] = __builtin_bit_cast(unsigned, f16x2{(_Float16)r0, (_Float16)r1});
   }
 }
+// both operands fp32 in LDS (the weight-gradient kernel): acc[i][j] += A_i x B_j over the lane's 8 k values, two fp16 planes each
+__device__ __forceinline__ void split_mma_2x2_h(f32x16 (&acc)[2][2], const float (&af)[2][8], const float (&bf)[2][8], float sa, float sb) {
+  u32x4 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) { split8h(af[i], sa, ah[i], al[i]); split8h(bf[i], sb, bh[i], bl[i]); }
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      f32x16 c = acc[i][j];
+      c = mma_f16(al[i], bh[j], c); c = mma_f16(ah[i], bl[j], c); c = mma_f16(ah[i], bh[j], c);          // smallest terms first
+      acc[i][j] = c;
+    }
+}
 // k with amax * 2^k in [2^(top-1), 2^top); 0 for an all-zero (or non-finite) operand.  |k| <= 100 keeps 2^k a normal float.
 __host__ __device__ __forceinline__ int scale_exp(float amax, int top) {
   if (!(amax > 0.f) || amax > 3.0e38f) return 0;
@@ -1827,8 +1841,10 @@ struct DmaWgTile {
   static_assert(LPRA <= 64 && AI >= 1 && BI >= 1, "tile shape");
 };
 
-template <int WGM, int WGN, bool SPLIT>
-__global__ __launch_bounds__(64 * WGM * WGN) void conv_wgrad_dma_kernel(GemmP p, DmaSched sc) {
+// SPLIT: 0 = v_mfma_f32_32x32x2_f32, 1 = three bf16 planes per operand (six MFMAs per product), 2 = two fp16 planes of the operands
+// scaled by powers of two from their amax (three MFMAs; x_amax / dy_amax: 256 floats each whose maximum is the operand's amax)
+template <int WGM, int WGN, int SPLIT>
+__global__ __launch_bounds__(64 * WGM * WGN) void conv_wgrad_dma_kernel(GemmP p, DmaSched sc, const float* x_amax, const float* dy_amax) {
 #if defined(__HIP_DEVICE_COMPILE__)
   using T = DmaWgTile<WGM, WGN>;
   constexpr int BMK = T::BMK, BN = T::BN, PX = T::PX, NST = T::NST, AI = T::AI, BI = T::BI;
@@ -1924,6 +1940,12 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_wgrad_dma_kernel(GemmP p,
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
+  int kx = 0, ky = 0;
+  if constexpr (SPLIT == 2) {
+    kx = __builtin_amdgcn_readfirstlane(scale_exp(amax256(x_amax, lane), PC_TOP_A));
+    ky = __builtin_amdgcn_readfirstlane(scale_exp(amax256(dy_amax, lane), PC_TOP_A));
+  }
+  const float sx = pow2f(kx), sy = pow2f(ky);
   const int h = lane >> 5, l31 = lane & 31;
   const int a_rd = (8 * h) * BMK + wm * 64 + 2 * l31;
   const int b_rd = T::A_FL + (8 * h) * BN + wn * 64 + 2 * l31;
@@ -1937,7 +1959,9 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_wgrad_dma_kernel(GemmP p,
       const float2 b = *reinterpret_cast<const float2*>(S + b_rd + s8 * BN);
       af[0][s8] = a.x; af[1][s8] = a.y; bf[0][s8] = b.x; bf[1][s8] = b.y;
     }
-    if (SPLIT) {
+    if constexpr (SPLIT == 2) {
+      split_mma_2x2_h(acc, af, bf, sx, sy);
+    } else if constexpr (SPLIT == 1) {
       split_mma_2x2(acc, af, bf);
     } else {
 #pragma unroll
@@ -1966,6 +1990,15 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_wgrad_dma_kernel(GemmP p,
     }
   }
 
+  if constexpr (SPLIT == 2) {                              // remove the operand scales (two exact power-of-two factors)
+    const float cx = pow2f(-kx), cy = pow2f(-ky);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][j][e] = (acc[i][j][e] * cx) * cy;
+  }
   // ---- epilogue: lane holds k-rows kt0 + wm*64 + 2*rr + i (rr = (e&3) + 8*(e>>2) + 4*h), columns n0 + wn*64 + 2*l31 + j
   const int colr = wn * 64 + 2 * l31;
   if (nsplit > 1) {
@@ -2100,6 +2133,7 @@ std::vector<ProfRec> g_recs;
 struct ProfScope {
   hipStream_t st; bool on; ProfRec r;
   ProfScope(const Stream& s, const char* name, double flops) : st(hs(s)), on(g_prof != 0) {
+    if (route_on()) route_note(name);
     if (!on) return;
     r.name = name; r.flops = flops;
     (void)hipEventCreate(&r.a); (void)hipEventCreate(&r.b);
@@ -2186,7 +2220,7 @@ static int choose_splits(int ntiles, int work, int slots, int min_work, size_t s
 
 static bool prof_detail() {
   static const bool on = getenv("SWN_PROF_DETAIL") != nullptr;
-  return on;
+  return on || route_on();
 }
 
 template <typename K>
@@ -2375,6 +2409,8 @@ static float* ws_amax(Stream& s, int which) {
   if (!s.ws || s.ws_bytes < (1u << 20)) throw Error(1, "two-plane pre-cut kernels need the stream scratch");
   return reinterpret_cast<float*>(s.ws + s.ws_bytes - PC_WS_TAIL + (size_t)which * 1024);
 }
+// SWN_AMAX_FUSED=0: every launch takes the amax of its operands itself (A/B against the producer-side slots; read per launch)
+static bool amax_fused_on() { return !(getenv("SWN_AMAX_FUSED") && atoi(getenv("SWN_AMAX_FUSED")) == 0); }
 static void amax_partials(Stream& s, const float* x, size_t rows, int C, size_t rs, int batch, size_t bs, float* out) {
   if (C % 4 || rs % 4 || bs % 4 || ((uintptr_t)x & 15)) throw Error(1, "amax_partials: operand not 16-byte aligned");
   const int flat = rs == (size_t)C && (batch == 1 || bs == rows * (size_t)C);
@@ -2382,7 +2418,7 @@ static void amax_partials(Stream& s, const float* x, size_t rows, int C, size_t 
   check_launch("amax_partials");
 }
 template <int WGM, int NB, int NSTG, int WGCU, int PL>
-static void launch_fwd_pc(Stream& s, GemmP& p, int nb, const unsigned short* wpc, size_t wpc_bs, bool phases) {
+static void launch_fwd_pc(Stream& s, GemmP& p, int nb, const unsigned short* wpc, size_t wpc_bs, bool phases, const float* x_amax) {
   using T = PcTile<WGM, NB, NSTG, PL>;
   const int tiles_m = ceil_div(p.M, T::BM);
   p.tiles_n = ceil_div(p.Npad, T::BN);
@@ -2391,7 +2427,9 @@ static void launch_fwd_pc(Stream& s, GemmP& p, int nb, const unsigned short* wpc
   static_assert(wg * T::SMEM <= 160 * 1024, "tile does not fit a CU");
   const size_t ws_cap = PL == 2 ? s.ws_bytes - PC_WS_TAIL : s.ws_bytes;
   const float* a_amax = nullptr;
-  if (PL == 2) {
+  if (PL == 2 && x_amax && amax_fused_on()) {
+    a_amax = x_amax;          // the producer of the operand left its amax (256 floats, maximum = amax) in a slot: no pass of our own
+  } else if (PL == 2) {
     // |A|max over the whole input tensor of the launch (all images, all channels the gather reads; batched planes too)
     float* part = ws_amax(s, 0);
     amax_partials(s, p.x, (size_t)(p.M / (p.Ho * p.Wo)) * p.xH * p.xW, p.xC, (size_t)p.xcs, phases ? 1 : nb, p.x_bs, part);
@@ -2541,14 +2579,14 @@ void conv_fwd(Stream& s, const ConvFwdArgs& a) {
         (size_t)(p.K / 16) * ceil_div(a.Npad, a.wpc_bn) * 12 * a.wpc_bn * 8 < ((size_t)1 << 31)) {
       const bool ph = a.phases != 0;
       if (pc_planes() == 2) {
-        if (a.wpc_bn == 192) launch_fwd_pc<4, 6, 2, 2, 2>(s, p, nb, a.wpc, a.wpc_bs, ph);
-        else if (a.Npad > 64) launch_fwd_pc<4, 4, 2, 4, 2>(s, p, nb, a.wpc, a.wpc_bs, ph);
-        else launch_fwd_pc<8, 2, 3, 2, 2>(s, p, nb, a.wpc, a.wpc_bs, ph);
+        if (a.wpc_bn == 192) launch_fwd_pc<4, 6, 2, 2, 2>(s, p, nb, a.wpc, a.wpc_bs, ph, a.x_amax);
+        else if (a.Npad > 64) launch_fwd_pc<4, 4, 2, 4, 2>(s, p, nb, a.wpc, a.wpc_bs, ph, a.x_amax);
+        else launch_fwd_pc<8, 2, 3, 2, 2>(s, p, nb, a.wpc, a.wpc_bs, ph, a.x_amax);
         return;
       }
-      if (a.wpc_bn == 192) launch_fwd_pc<4, 6, 2, 2, 3>(s, p, nb, a.wpc, a.wpc_bs, ph);   // 128 x 192, 2 stages, 2 workgroups / CU
-      else if (a.Npad > 64) launch_fwd_pc<4, 4, 2, 4, 3>(s, p, nb, a.wpc, a.wpc_bs, ph);  // 128 x 128, 2 stages, 4 workgroups / CU
-      else launch_fwd_pc<8, 2, 3, 2, 3>(s, p, nb, a.wpc, a.wpc_bs, ph);                   // 256 x 64, 3 stages, 2 workgroups / CU
+      if (a.wpc_bn == 192) launch_fwd_pc<4, 6, 2, 2, 3>(s, p, nb, a.wpc, a.wpc_bs, ph, nullptr);   // 128 x 192, 2 stages, 2 workgroups / CU
+      else if (a.Npad > 64) launch_fwd_pc<4, 4, 2, 4, 3>(s, p, nb, a.wpc, a.wpc_bs, ph, nullptr);  // 128 x 128, 2 stages, 4 workgroups / CU
+      else launch_fwd_pc<8, 2, 3, 2, 3>(s, p, nb, a.wpc, a.wpc_bs, ph, nullptr);                   // 256 x 64, 3 stages, 2 workgroups / CU
       return;
     }
     if (!a.w) throw Error(1, "conv_fwd: the weight operand exists in pre-cut form only, but this launch cannot take the pre-cut "
@@ -2620,29 +2658,48 @@ static void launch_wgrad(Stream& s, GemmP& p, int batch) {
 }
 
 
+// 2 (default): the weight-gradient ring kernel on two fp16 planes per operand, both scaled by powers of two from their amax (three
+// MFMAs per product; tools/ring_lab.hip variants 18 / 19: 157-167 -> 266-268 fp32-equivalent TFLOP/s at 4.5e-7); 3: three bf16
+// planes (six MFMAs).  Read per launch (A/B runs, tests).
+static int wgrad_planes() { return (getenv("SWN_WGRAD_PLANES") && atoi(getenv("SWN_WGRAD_PLANES")) == 3) ? 3 : 2; }
 template <int WGM, int WGN>
-static void launch_wgrad_dma(Stream& s, GemmP& p, int nb) {
+static void launch_wgrad_dma(Stream& s, GemmP& p, int nb, const ConvWgradArgs& a) {
   using T = DmaWgTile<WGM, WGN>;
   const int tiles_k = ceil_div(p.K, T::BMK);
   p.tiles_n = ceil_div(p.Npad, T::BN);
   p.ntiles = tiles_k * p.tiles_n;
   const int nmb = p.M / T::PX;
   const int wg_per_cu = std::min(160 * 1024 / T::SMEM, 12 / T::NW);
-  const DmaSched sc = plan_dma(p.ntiles * nb, p.ntiles, nmb, 256 * wg_per_cu, (size_t)T::BMK * T::BN * 4, s.ws_bytes);
+  const bool two = split_on() && wgrad_planes() == 2 && s.ws && s.ws_bytes >= (1u << 20);
+  const float *xa = nullptr, *ya = nullptr;
+  if (two) {
+    // both operands are activations: their amax over the whole tensors the gather / the dY rows come from -- left in a slot by
+    // whoever produced the tensor (ConvWgradArgs::x_amax / dy_amax), else taken here
+    const int nbb = a.phases ? 1 : nb;
+    const size_t nimg = (size_t)(p.M / (p.Ho * p.Wo));
+    const bool fused = amax_fused_on();
+    if (a.x_amax && fused) xa = a.x_amax;
+    else { float* px = ws_amax(s, 0); amax_partials(s, a.x.p, nimg * a.x.H * a.x.W, a.x.C, (size_t)a.x.cs, nbb, a.x_bs, px); xa = px; }
+    if (a.dy_amax && fused) ya = a.dy_amax;
+    else { float* py = ws_amax(s, 1); amax_partials(s, a.dy.p, nimg * a.dy.H * a.dy.W, a.dy.C, (size_t)a.dy.cs, nbb, a.dy_bs, py); ya = py; }
+  }
+  const DmaSched sc = plan_dma(p.ntiles * nb, p.ntiles, nmb, 256 * wg_per_cu, (size_t)T::BMK * T::BN * 4, two ? s.ws_bytes - PC_WS_TAIL : s.ws_bytes);
   p.slab = reinterpret_cast<float*>(s.ws);
   p.splits = sc.tail_s;
-  static bool once = (set_smem(conv_wgrad_dma_kernel<WGM, WGN, true>, T::SMEM), set_smem(conv_wgrad_dma_kernel<WGM, WGN, false>, T::SMEM), true);
+  static bool once = (set_smem(conv_wgrad_dma_kernel<WGM, WGN, 2>, T::SMEM), set_smem(conv_wgrad_dma_kernel<WGM, WGN, 1>, T::SMEM),
+                      set_smem(conv_wgrad_dma_kernel<WGM, WGN, 0>, T::SMEM), true);
   (void)once;
-  char pname[112];
+  char pname[128];
   if (prof_detail())
-    snprintf(pname, sizeof pname, "conv_wgrad_dma_%dx%d[M%d,N%d,K%d,b%d,full%d,tail%dx%d]", T::BMK, T::BN, p.M, p.Cout, p.K, nb,
+    snprintf(pname, sizeof pname, "conv_wgrad_dma_%dx%d%s[M%d,N%d,K%d,b%d,full%d,tail%dx%d]", T::BMK, T::BN, two ? "_h2" : "", p.M, p.Cout, p.K, nb,
              sc.full, sc.tail_tiles, sc.tail_s);
   else
     snprintf(pname, sizeof pname, "conv_wgrad_dma_%dx%d", T::BMK, T::BN);
   ProfScope prof(s, pname, 2.0 * p.M * p.Cout * p.K * nb);
   const int units = sc.full + sc.tail_tiles * sc.tail_s;
-  if (split_on()) hipLaunchKernelGGL((conv_wgrad_dma_kernel<WGM, WGN, true>), dim3(units), dim3(64 * T::NW), T::SMEM, hs(s), p, sc);
-  else hipLaunchKernelGGL((conv_wgrad_dma_kernel<WGM, WGN, false>), dim3(units), dim3(64 * T::NW), T::SMEM, hs(s), p, sc);
+  if (two) hipLaunchKernelGGL((conv_wgrad_dma_kernel<WGM, WGN, 2>), dim3(units), dim3(64 * T::NW), T::SMEM, hs(s), p, sc, xa, ya);
+  else if (split_on()) hipLaunchKernelGGL((conv_wgrad_dma_kernel<WGM, WGN, 1>), dim3(units), dim3(64 * T::NW), T::SMEM, hs(s), p, sc, xa, ya);
+  else hipLaunchKernelGGL((conv_wgrad_dma_kernel<WGM, WGN, 0>), dim3(units), dim3(64 * T::NW), T::SMEM, hs(s), p, sc, xa, ya);
   check_launch("conv_wgrad_dma");
   if (sc.tail_tiles > 0 && sc.tail_s > 1) {
     hipLaunchKernelGGL((wgrad_dma_reduce_kernel<T::BMK, T::BN>), dim3(T::BMK * T::BN / 4 / 256, sc.tail_tiles), dim3(256), 0, hs(s), p, sc);
@@ -2707,8 +2764,8 @@ void conv_wgrad(Stream& s, const ConvWgradArgs& a) {
   const int nb = a.phases ? a.phases : std::max(a.batch, 1);
   static const int big = getenv("SWN_WGRAD256") ? atoi(getenv("SWN_WGRAD256")) : 1;
   if (wgrad_dma_ok(a, p)) {
-    if (a.Npad > 64) launch_wgrad_dma<2, 2>(s, p, nb);    // 128 k-rows x 128 columns
-    else launch_wgrad_dma<4, 1>(s, p, nb);                // 256 x 64
+    if (a.Npad > 64) launch_wgrad_dma<2, 2>(s, p, nb, a);    // 128 k-rows x 128 columns
+    else launch_wgrad_dma<4, 1>(s, p, nb, a);                // 256 x 64
     return;
   }
   // 8-wave 256x128 tile: +3 % on the single-GEMM layers, -7 % on the batched Winograd planes (measured)

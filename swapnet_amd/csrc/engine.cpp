@@ -4,8 +4,37 @@
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
+#include <map>
+#include <string>
+#include <vector>
 
 namespace swn {
+
+// ---- routing trace (ops.h route_*) ------------------------------------------------------
+namespace {
+int g_route = 0;
+std::string g_route_label = "-";
+char g_route_phase = '-';
+std::vector<std::string> g_route_lines;
+std::map<std::string, int> g_route_seen;
+}  // namespace
+void route_enable(int on) {
+  g_route = on;
+  if (on) { g_route_lines.clear(); g_route_seen.clear(); g_route_label = "-"; g_route_phase = '-'; }
+}
+bool route_on() { return g_route != 0; }
+void route_label(const char* label, char phase) { g_route_label = label ? label : "-"; g_route_phase = phase; }
+void route_note(const char* kernel) {
+  if (!g_route) return;
+  std::string line = g_route_label + " " + std::string(1, g_route_phase) + " " + kernel;
+  if (g_route_seen.emplace(line, 1).second) g_route_lines.push_back(line);
+}
+int route_report(char* buf, int len) {
+  std::string out;
+  for (auto& l : g_route_lines) { out += l; out += "\n"; }
+  if (buf && len > 0) { strncpy(buf, out.c_str(), len - 1); buf[len - 1] = 0; }
+  return (int)out.size();
+}
 
 // ---------------------------------------------------------------------------------------
 Ctx::Ctx(void* stream, size_t ws_bytes) {
@@ -279,6 +308,9 @@ void Net::conv(const std::string& name, const Var& x, const Var& y, ConvKind kin
     const int pcf = conv_precut_tile(CV, Cop), pct = want_dx ? conv_precut_tile(Cop, CV) : 0;
     const size_t pcf_bs = pcf ? conv_precut_elems(CV, Cop, pcf) : 0, pct_bs = pct ? conv_precut_elems(Cop, CV, pct) : 0;
     const size_t pcf_off = pcf ? reserve_dgp(pcf_bs * sP) : 0, pct_off = pct ? reserve_dgp(pct_bs * sP) : 0;
+    const size_t slV = reserve_slot(), slD = reserve_slot();      // amax of V (forward planes) and of dM (transformed dY)
+    // dM = A dY A^T serves the weight gradient (side stream) and the input gradient (main stream): one buffer per layer
+    float* keepdM = (y.has_grad && want_dx && share_dy()) ? static_cast<float*>(ctx.alloc(sP * sT * Cop * sizeof(float))) : nullptr;
     op->repack = [=](Net& n) {
       const ParamDesc& wd = A->params[wi];
       wino_s2_filter_transform(n.ctx.s, wd.ws, 0, A->w + wd.off, n.dg + uf_off);
@@ -291,12 +323,13 @@ void Net::conv(const std::string& name, const Var& x, const Var& y, ConvKind kin
     op->fwd = [=](Net& n) {
       n.need(self);
       float* V = keepV ? keepV : n.wsV;
-      wino_s2_input_transform(n.ctx.s, xv, sTh, sTw, V);
+      wino_s2_input_transform(n.ctx.s, xv, sTh, sTw, V, n.amax + slV);
       ConvFwdArgs g;
       g.x = plane_mat(V, sT, CV); g.g.Ho = 1; g.g.Wo = (int)sT;
       g.w = n.dg + uf_off; g.Npad = Cop; g.Cout = Co;
       g.y = plane_mat(n.wsM, sT, Cop);
       g.batch = sP; g.x_bs = sT * CV; g.w_bs = (size_t)CV * Cop; g.y_bs = sT * Cop;
+      g.x_amax = n.amax + slV;
       if (pcf) { g.wpc = n.dgp + pcf_off; g.wpc_bn = pcf; g.wpc_bs = pcf_bs; }
       conv_fwd(n.ctx.s, g);
       wino_output_transform(n.ctx.s, 4, 2, n.wsM, Cop, sTh, sTw, bi >= 0 ? A->w + A->params[bi].off : nullptr, actf, yv, Co, 0);
@@ -311,28 +344,34 @@ void Net::conv(const std::string& name, const Var& x, const Var& y, ConvKind kin
       TView dY = ygv;
       if (actf != ACT_NONE) { act_bwd(n.ctx.s, ygv, yv, scr, actf, 0); dY = scr; }
       const ParamDesc& wd = A->params[wi];
+      const bool dx_now = want_dx && !(me.reads_net_input && !igrad);
+      const bool shared = keepdM && wgrad && dx_now;       // one transform of dY on the main stream, read by both gradients
+      if (shared) wino_dy_transform(n.ctx.s, 4, 2, dY, sTh, sTw, keepdM, n.amax + slD);
       if (wgrad) {
         Stream& sw = n.wgrad_stream();
         float* V = keepV ? keepV : n.wsV;
-        float* dM = n.wgrad_planes(sw);
-        if (!keepV) wino_s2_input_transform(sw, xv, sTh, sTw, V);
-        wino_dy_transform(sw, 4, 2, dY, sTh, sTw, dM);
+        float* dM = shared ? keepdM : n.wgrad_planes(sw);
+        if (!keepV) wino_s2_input_transform(sw, xv, sTh, sTw, V, n.amax + slV);
+        if (!shared) wino_dy_transform(sw, 4, 2, dY, sTh, sTw, dM, n.amax + slD);
         ConvWgradArgs g;
         g.x = plane_mat(V, sT, CV); g.g.Ho = 1; g.g.Wo = (int)sT;
         g.dy = plane_mat(dM, sT, Cop);
         g.dw = n.wsU; g.Npad = Cop; g.Cout = Co;
         g.batch = sP; g.x_bs = sT * CV; g.dy_bs = sT * Cop; g.dw_bs = (size_t)CV * Cop;
+        g.x_amax = n.amax + slV; g.dy_amax = n.amax + slD;
         conv_wgrad(sw, g);
         wino_s2_filter_grad(sw, wd.ws, n.wsU, A->g + wd.off);
         if (bi >= 0) n.bias_grad_of(sw, dY, A->g + A->params[bi].off);
       }
-      if (!want_dx || (me.reads_net_input && !igrad)) return;
-      wino_dy_transform(n.ctx.s, 4, 2, dY, sTh, sTw, n.wsV);
+      if (!dx_now) return;
+      float* dMx = shared ? keepdM : n.wsV;
+      if (!shared) wino_dy_transform(n.ctx.s, 4, 2, dY, sTh, sTw, dMx, n.amax + slD);
       ConvFwdArgs g;
-      g.x = plane_mat(n.wsV, sT, Cop); g.g.Ho = 1; g.g.Wo = (int)sT;
+      g.x = plane_mat(dMx, sT, Cop); g.g.Ho = 1; g.g.Wo = (int)sT;
       g.w = n.dg + ut_off; g.Npad = CV; g.Cout = CV;
       g.y = plane_mat(n.wsM, sT, CV);
       g.batch = sP; g.x_bs = sT * Cop; g.w_bs = (size_t)Cop * CV; g.y_bs = sT * CV;
+      g.x_amax = n.amax + slD;
       if (pct) { g.wpc = n.dgp + pct_off; g.wpc_bn = pct; g.wpc_bs = pct_bs; }
       conv_fwd(n.ctx.s, g);
       wino_s2_input_adjoint(n.ctx.s, n.wsM, Cip, sTh, sTw, xgv, nullptr, me.acc.empty() ? 0 : me.acc[0]);
@@ -359,6 +398,7 @@ void Net::conv(const std::string& name, const Var& x, const Var& y, ConvKind kin
       wsU_need = std::max(wsU_need, (size_t)tP * Cip * N4);
       const int pcu = conv_precut_tile(Cip, N4);
       const size_t pcu_bs = pcu ? conv_precut_elems(Cip, N4, pcu) : 0, pcu_off = pcu ? reserve_dgp(pcu_bs * tP) : 0;
+      const size_t slV = reserve_slot(), slD = reserve_slot();
       // input gradient: the folded 5x5 stride-2 conv over dR (32-channel buffer, see CopD below)
       const bool want_dx = x.has_grad && y.has_grad;
       const int CopD = (actf != ACT_NONE && want_dx && conv_precut_tile(32, Cip) == 192) ? 32 : Cop;
@@ -378,12 +418,13 @@ void Net::conv(const std::string& name, const Var& x, const Var& y, ConvKind kin
       op->fwd = [=](Net& n) {
         n.need(self);
         float* V = keepV ? keepV : n.wsV;
-        wino_input_transform(n.ctx.s, 4, 3, xv, 1, PAD_ZERO, tTh, tTw, V);
+        wino_input_transform(n.ctx.s, 4, 3, xv, 1, PAD_ZERO, tTh, tTw, V, n.amax + slV);
         ConvFwdArgs g;
         g.x = plane_mat(V, tT, Cip); g.g.Ho = 1; g.g.Wo = (int)tT;
         g.w = n.dg + tu_off; g.Npad = N4; g.Cout = N4;
         g.y = plane_mat(n.wsM, tT, N4);
         g.batch = tP; g.x_bs = tT * Cip; g.w_bs = (size_t)Cip * N4; g.y_bs = tT * N4;
+        g.x_amax = n.amax + slV;
         if (pcu) { g.wpc = n.dgp + pcu_off; g.wpc_bn = pcu; g.wpc_bs = pcu_bs; }
         conv_fwd(n.ctx.s, g);
         tailw_output_transform(n.ctx.s, n.wsM, tTh, tTw, Cop, bi >= 0 ? A->w + A->params[bi].off : nullptr, actf, yv, Co);
@@ -402,13 +443,14 @@ void Net::conv(const std::string& name, const Var& x, const Var& y, ConvKind kin
           Stream& sw = n.wgrad_stream();
           float* V = keepV ? keepV : n.wsV;
           float* dM = n.wgrad_planes(sw);
-          if (!keepV) wino_input_transform(sw, 4, 3, xv, 1, PAD_ZERO, tTh, tTw, V);
-          tailw_dy_transform(sw, dY, tTh, tTw, Cop, dM);
+          if (!keepV) wino_input_transform(sw, 4, 3, xv, 1, PAD_ZERO, tTh, tTw, V, n.amax + slV);
+          tailw_dy_transform(sw, dY, tTh, tTw, Cop, dM, n.amax + slD);
           ConvWgradArgs g;
           g.x = plane_mat(V, tT, Cip); g.g.Ho = 1; g.g.Wo = (int)tT;
           g.dy = plane_mat(dM, tT, N4);
           g.dw = n.wsU; g.Npad = N4; g.Cout = N4;
           g.batch = tP; g.x_bs = tT * Cip; g.dy_bs = tT * N4; g.dw_bs = (size_t)Cip * N4;
+          g.x_amax = n.amax + slV; g.dy_amax = n.amax + slD;
           conv_wgrad(sw, g);
           tailw_filter_grad(sw, wd.ws, n.wsU, n.dg + dfold_off);
           tail_unfold_wgrad(sw, wd.ws, n.dg + dfold_off, A->g + wd.off);
@@ -477,6 +519,12 @@ void Net::conv(const std::string& name, const Var& x, const Var& y, ConvKind kin
   size_t pcw_off = 0, pcwt_off = 0;
   int pcwt = 0;
   size_t pcwt_bs = 0;
+  // amax slots of the Winograd-domain operands: V (forward planes), dM (transformed dY), dX (the padded dY planes of the
+  // transposed-conv form of the input gradient); the 6-point forms only (F(2,3) planes feed the fp32-operand kernels)
+  const bool wslots = wino && wm != 2;
+  const size_t slV = wslots ? reserve_slot() : 0, slD = wslots ? reserve_slot() : 0, slX = wslots ? reserve_slot() : 0;
+  float* keepdM = nullptr;        // dM = A dY A^T, shared by the weight gradient (side stream) and the adjoint-form input gradient
+  if (wino && wadj && y.has_grad && x.has_grad && share_dy()) keepdM = static_cast<float*>(ctx.alloc((size_t)wP * wT * Cop * sizeof(float)));
   if (wino) {
     if (pcw) pcw_off = reserve_dgp(pcw_bs * wP);
     else uf_off = reserve_dg(self, (size_t)wP * Cip * Cop);
@@ -501,10 +549,11 @@ void Net::conv(const std::string& name, const Var& x, const Var& y, ConvKind kin
     if (wino) {
       n.need(self);
       float* V = keepV ? keepV : n.wsV;
-      wino_input_transform(n.ctx.s, wm, wr, xv, 1, gf.pad_mode, wTh, wTw, V);
+      wino_input_transform(n.ctx.s, wm, wr, xv, 1, gf.pad_mode, wTh, wTw, V, wslots ? n.amax + slV : nullptr);
       ConvFwdArgs g;
       g.x = plane_view(V, wT, Cip); g.g.Ho = 1; g.g.Wo = (int)wT;
       g.w = pcw ? nullptr : n.dg + uf_off; g.Npad = Cop; g.Cout = Co;
+      if (wslots) g.x_amax = n.amax + slV;
       if (pcw) { g.wpc = n.dgp + pcw_off; g.wpc_bn = pcw; g.wpc_bs = pcw_bs; }
       g.y = plane_view(n.wsM, wT, Cop);
       g.batch = wP; g.x_bs = wT * Cip; g.w_bs = (size_t)Cip * Cop; g.y_bs = wT * Cop;
@@ -605,6 +654,11 @@ void Net::conv(const std::string& name, const Var& x, const Var& y, ConvKind kin
     TView dY = ygv;
     if (actf != ACT_NONE) { act_bwd(n.ctx.s, ygv, yv, scr, actf, 0); dY = scr; }
     const ParamDesc& wd = A->params[wi];
+    const bool dx_now = want_dx && !(me.reads_net_input && !igrad);
+    // adjoint-form layers: the weight gradient and the input gradient multiply by the same dM planes -- transformed once, on the
+    // main stream, into the layer's own buffer (the side stream reads it while the main stream moves on)
+    const bool shared = keepdM && wino && wadj && wgrad && dx_now;
+    if (shared) wino_dy_transform(n.ctx.s, wm, wr, dY, wTh, wTw, keepdM, wslots ? n.amax + slD : nullptr);
     if (wgrad) {
       Stream& sw = n.wgrad_stream();          // dY is final: the weight-gradient work may run beside the dgrad chain
       ConvWgradArgs wa;
@@ -612,14 +666,15 @@ void Net::conv(const std::string& name, const Var& x, const Var& y, ConvKind kin
       if (wino) {
         // dU[t] = V[t]^T dM[t] (wP batched reductions over the tiles), then dW = G^T dU G
         float* V = keepV ? keepV : n.wsV;
-        float* dM = n.wgrad_planes(sw);
-        if (!keepV) wino_input_transform(sw, wm, wr, xv, 1, gf.pad_mode, wTh, wTw, V);
-        wino_dy_transform(sw, wm, wr, dY, wTh, wTw, dM);
+        float* dM = shared ? keepdM : n.wgrad_planes(sw);
+        if (!keepV) wino_input_transform(sw, wm, wr, xv, 1, gf.pad_mode, wTh, wTw, V, wslots ? n.amax + slV : nullptr);
+        if (!shared) wino_dy_transform(sw, wm, wr, dY, wTh, wTw, dM, wslots ? n.amax + slD : nullptr);
         ConvWgradArgs g;
         g.x = plane_view(V, wT, Cip); g.g.Ho = 1; g.g.Wo = (int)wT;
         g.dy = plane_view(dM, wT, Cop);
         g.dw = n.wsU; g.Npad = Cop; g.Cout = Co;
         g.batch = wP; g.x_bs = wT * Cip; g.dy_bs = wT * Cop; g.dw_bs = (size_t)Cip * Cop;
+        if (wslots) { g.x_amax = n.amax + slV; g.dy_amax = n.amax + slD; }
         conv_wgrad(sw, g);
         wino_filter_grad(sw, wm, wr, wd.ws, n.wsU, A->g + wd.off);
       } else if (!folded) {
@@ -633,14 +688,15 @@ void Net::conv(const std::string& name, const Var& x, const Var& y, ConvKind kin
       }
       if (bi >= 0) n.bias_grad_of(sw, dY, A->g + A->params[bi].off);
     }
-    if (!want_dx || (me.reads_net_input && !igrad)) return;
+    if (!dx_now) return;
     const int accf = me.acc.empty() ? 0 : me.acc[0];
     if (wino && !wadj) {
       // input gradient = the transposed stride-1 conv over dY (flipped, channel-transposed filter)
-      wino_input_transform(n.ctx.s, wm, wr, dY, wpad2, PAD_ZERO, wTh2, wTw2, n.wsV);
+      wino_input_transform(n.ctx.s, wm, wr, dY, wpad2, PAD_ZERO, wTh2, wTw2, n.wsV, wslots ? n.amax + slX : nullptr);
       ConvFwdArgs g;
       g.x = plane_view(n.wsV, wT2, Cop); g.g.Ho = 1; g.g.Wo = (int)wT2;
       g.w = pcwt ? nullptr : n.dg + ub_off; g.Npad = Cip; g.Cout = Cip;
+      if (wslots) g.x_amax = n.amax + slX;
       if (pcwt) { g.wpc = n.dgp + pcwt_off; g.wpc_bn = pcwt; g.wpc_bs = pcwt_bs; }
       g.y = plane_view(n.wsM, wT2, Cip);
       g.batch = wP; g.x_bs = wT2 * Cop; g.w_bs = (size_t)Cop * Cip; g.y_bs = wT2 * Cip;
@@ -656,10 +712,12 @@ void Net::conv(const std::string& name, const Var& x, const Var& y, ConvKind kin
     if (wino) {
       // input gradient in the forward tiling: dM = A dY A^T, dV = dM U^T (U with the channel axes swapped), then the adjoint
       // of the input transform scatters the patches BT^T dV BT back through the forward gather (padding rule included)
-      wino_dy_transform(n.ctx.s, wm, wr, dY, wTh, wTw, n.wsV);
+      float* dMx = shared ? keepdM : n.wsV;
+      if (!shared) wino_dy_transform(n.ctx.s, wm, wr, dY, wTh, wTw, dMx, wslots ? n.amax + slD : nullptr);
       ConvFwdArgs g;
-      g.x = plane_view(n.wsV, wT, Cop); g.g.Ho = 1; g.g.Wo = (int)wT;
+      g.x = plane_view(dMx, wT, Cop); g.g.Ho = 1; g.g.Wo = (int)wT;
       g.w = pcwt ? nullptr : n.dg + ub_off; g.Npad = Cip; g.Cout = Cip;
+      if (wslots) g.x_amax = n.amax + slD;
       if (pcwt) { g.wpc = n.dgp + pcwt_off; g.wpc_bn = pcwt; g.wpc_bs = pcwt_bs; }
       g.y = plane_view(n.wsM, wT, Cip);
       g.batch = wP; g.x_bs = wT * Cop; g.w_bs = (size_t)Cop * Cip; g.y_bs = wT * Cip;
@@ -722,6 +780,9 @@ void Net::convT(const std::string& name, const Var& x, const Var& y, int Co, boo
     const int pct = conv_precut_tile(Cip, CV), pcf = want_dx ? conv_precut_tile(CV, Cip) : 0;
     const size_t pct_bs = pct ? conv_precut_elems(Cip, CV, pct) : 0, pcf_bs = pcf ? conv_precut_elems(CV, Cip, pcf) : 0;
     const size_t pct_off = pct ? reserve_dgp(pct_bs * sP) : 0, pcf_off = pcf ? reserve_dgp(pcf_bs * sP) : 0;
+    const size_t slM = reserve_slot(), slV = reserve_slot();     // amax of dM (planes of the coarse input) and of V (planes of dY, fine)
+    // V = polyphase transform of dY serves the weight gradient (side stream) and the input gradient (main stream): one buffer per layer
+    float* keepVg = (y.has_grad && want_dx && share_dy()) ? static_cast<float*>(ctx.alloc(sP * sT * CV * sizeof(float))) : nullptr;
     op->repack = [=](Net& n) {
       const ParamDesc& wd = A->params[wi];
       wino_s2_filter_transform(n.ctx.s, wd.ws, 1, A->w + wd.off, n.dg + ut_off);
@@ -736,12 +797,13 @@ void Net::convT(const std::string& name, const Var& x, const Var& y, int Co, boo
       const ParamDesc& wd = A->params[wi];
       (void)wd;
       float* dM = keepM ? keepM : n.wsV;
-      wino_dy_transform(n.ctx.s, 4, 2, xv, sTh, sTw, dM);
+      wino_dy_transform(n.ctx.s, 4, 2, xv, sTh, sTw, dM, n.amax + slM);
       ConvFwdArgs g;
       g.x = plane_mat(dM, sT, Cip); g.g.Ho = 1; g.g.Wo = (int)sT;
       g.w = n.dg + ut_off; g.Npad = CV; g.Cout = CV;
       g.y = plane_mat(n.wsM, sT, CV);
       g.batch = sP; g.x_bs = sT * Cip; g.w_bs = (size_t)Cip * CV; g.y_bs = sT * CV;
+      g.x_amax = n.amax + slM;
       if (pct) { g.wpc = n.dgp + pct_off; g.wpc_bn = pct; g.wpc_bs = pct_bs; }
       conv_fwd(n.ctx.s, g);
       wino_s2_input_adjoint(n.ctx.s, n.wsM, Cop, sTh, sTw, yv, bi >= 0 ? A->w + A->params[bi].off : nullptr, 0);
@@ -751,29 +813,35 @@ void Net::convT(const std::string& name, const Var& x, const Var& y, int Co, boo
     op->bwd = [=](Net& n, Op& me, bool wgrad, bool igrad) {
       if (!has_ygrad) return;
       const ParamDesc& wd = A->params[wi];
+      const bool dx_now = want_dx && !(me.reads_net_input && !igrad);
+      const bool shared = keepVg && wgrad && dx_now;
+      if (shared) wino_s2_input_transform(n.ctx.s, ygv, sTh, sTw, keepVg, n.amax + slV);
       if (wgrad) {
         // dU[25][4 Cop][Cip] = V(dY fine)^T dM(x coarse)
         Stream& sw = n.wgrad_stream();
-        float* V = n.wgrad_planes(sw);
+        float* V = shared ? keepVg : n.wgrad_planes(sw);
         float* dM = keepM ? keepM : n.wsV;
-        wino_s2_input_transform(sw, ygv, sTh, sTw, V);
-        if (!keepM) wino_dy_transform(sw, 4, 2, xv, sTh, sTw, dM);
+        if (!shared) wino_s2_input_transform(sw, ygv, sTh, sTw, V, n.amax + slV);
+        if (!keepM) wino_dy_transform(sw, 4, 2, xv, sTh, sTw, dM, n.amax + slM);
         ConvWgradArgs g;
         g.x = plane_mat(V, sT, CV); g.g.Ho = 1; g.g.Wo = (int)sT;
         g.dy = plane_mat(dM, sT, Cip);
         g.dw = n.wsU; g.Npad = Cip; g.Cout = Cip;
         g.batch = sP; g.x_bs = sT * CV; g.dy_bs = sT * Cip; g.dw_bs = (size_t)CV * Cip;
+        g.x_amax = n.amax + slV; g.dy_amax = n.amax + slM;
         conv_wgrad(sw, g);
         wino_s2_filter_grad(sw, wd.ws, n.wsU, A->g + wd.off);
         if (bi >= 0) n.bias_grad_of(sw, ygv, A->g + A->params[bi].off);
       }
-      if (!want_dx || (me.reads_net_input && !igrad)) return;
-      wino_s2_input_transform(n.ctx.s, ygv, sTh, sTw, n.wsV);
+      if (!dx_now) return;
+      float* Vx = shared ? keepVg : n.wsV;
+      if (!shared) wino_s2_input_transform(n.ctx.s, ygv, sTh, sTw, Vx, n.amax + slV);
       ConvFwdArgs g;
-      g.x = plane_mat(n.wsV, sT, CV); g.g.Ho = 1; g.g.Wo = (int)sT;
+      g.x = plane_mat(Vx, sT, CV); g.g.Ho = 1; g.g.Wo = (int)sT;
       g.w = n.dg + uf_off; g.Npad = Cip; g.Cout = Cip;
       g.y = plane_mat(n.wsM, sT, Cip);
       g.batch = sP; g.x_bs = sT * CV; g.w_bs = (size_t)CV * Cip; g.y_bs = sT * Cip;
+      g.x_amax = n.amax + slV;
       if (pcf) { g.wpc = n.dgp + pcf_off; g.wpc_bn = pcf; g.wpc_bs = pcf_bs; }
       conv_fwd(n.ctx.s, g);
       wino_output_transform(n.ctx.s, 4, 2, n.wsM, Cip, sTh, sTw, nullptr, ACT_NONE, xgv, Cip, me.acc.empty() ? 0 : me.acc[0]);
@@ -976,6 +1044,7 @@ void Net::finalize(const std::vector<Var>& pre) {
   }
   dg = dg_n ? static_cast<float*>(ctx.alloc(dg_n * sizeof(float))) : nullptr;
   dgp = dgp_n ? static_cast<uint16_t*>(ctx.alloc(dgp_n * sizeof(uint16_t))) : nullptr;
+  amax = amax_n ? static_cast<float*>(ctx.alloc(amax_n * sizeof(float))) : nullptr;
   if (wsM_need && ctx.has_side && keep_wino_inputs) wsM2 = static_cast<float*>(ctx.alloc(wsM_need * sizeof(float)));
   if (wsV_need) wsV = static_cast<float*>(ctx.alloc(wsV_need * sizeof(float)));
   if (wsM_need) wsM = static_cast<float*>(ctx.alloc(wsM_need * sizeof(float)));
@@ -983,15 +1052,23 @@ void Net::finalize(const std::vector<Var>& pre) {
   finalized_ = true;
 }
 
+// SWN_SHARE_DY=0: the weight gradient transforms dY for itself on the side stream (the round-3 behaviour); read once
+bool Net::share_dy() const {
+  static const bool on = !(getenv("SWN_SHARE_DY") && atoi(getenv("SWN_SHARE_DY")) == 0);
+  return on && keep_wino_inputs && ctx.has_side;
+}
 void Net::forward() {
   if (!finalized_) throw Error(1, "Net::forward before finalize");
+  if (amax) dev_memset(ctx.s, amax, 0, amax_n * sizeof(float));       // every slot: the step's producers fold into zeros
   prefetch_dgrad();
-  for (auto& op : ops) op->fwd(*this);
+  for (auto& op : ops) { if (route_on()) route_label(op->label.c_str(), 'f'); op->fwd(*this); }
 }
 void Net::forward_from(int op_begin) {
   if (!finalized_) throw Error(1, "Net::forward before finalize");
+  // (every slot-owning op of the nets that use this entry -- the frozen VGG16 slices -- lies at or behind op_begin = 1)
+  if (amax) dev_memset(ctx.s, amax, 0, amax_n * sizeof(float));
   prefetch_dgrad();
-  for (size_t i = (size_t)op_begin; i < ops.size(); ++i) ops[i]->fwd(*this);
+  for (size_t i = (size_t)op_begin; i < ops.size(); ++i) { if (route_on()) route_label(ops[i]->label.c_str(), 'f'); ops[i]->fwd(*this); }
 }
 void Net::prefetch_dgrad() {
   static const bool prefetch = !(getenv("SWN_PREFETCH") && atoi(getenv("SWN_PREFETCH")) == 0);    // 0: refresh in order on the main stream
@@ -1005,6 +1082,7 @@ void Net::prefetch_dgrad() {
   try {
     for (auto& op : ops)
       if (op->repack) {
+        if (route_on()) route_label(op->label.c_str(), 'r');
         op->repack(*this);
         if (!op->ready) op->ready = event_create();
         event_record(op->ready, ctx.s);        // (ctx.s is the side stream here)
@@ -1033,12 +1111,12 @@ void Net::refresh_dgrad() {
   }
   if (dg_version == arena.version) return;
   for (auto& op : ops)
-    if (op->repack) op->repack(*this);
+    if (op->repack) { if (route_on()) route_label(op->label.c_str(), 'r'); op->repack(*this); }
   dg_version = arena.version;
 }
 void Net::backward(bool wgrad, bool igrad) { backward_range(wgrad, igrad, 0, (int)ops.size()); }
 void Net::backward_range(bool wgrad, bool igrad, int op_begin, int op_end) {
-  for (int i = op_end - 1; i >= op_begin; --i) ops[i]->bwd(*this, *ops[i], wgrad, igrad);
+  for (int i = op_end - 1; i >= op_begin; --i) { if (route_on()) route_label(ops[i]->label.c_str(), 'b'); ops[i]->bwd(*this, *ops[i], wgrad, igrad); }
   ctx.join_side();      // weight gradients of the range are final for whatever the main stream does next
 }
 int Net::split_point(double frac, size_t* arena_off) const {

@@ -131,6 +131,15 @@ class Net {
   uint16_t* dgp = nullptr;
   size_t dgp_n = 0;
   size_t reserve_dgp(size_t elems) { const size_t off = dgp_n; dgp_n += (elems + 7) / 8 * 8; return off; }
+  // amax slots (ops.h ConvFwdArgs::x_amax): one per tensor that feeds a two-plane GEMM and is written by a kernel of ours that
+  // can fold its maximum in for free (the Winograd-domain planes).  All slots of the net are zeroed at the top of forward();
+  // producers of forward AND backward tensors fold into them during the step.
+  float* amax = nullptr;
+  size_t amax_n = 0;
+  size_t reserve_slot() { const size_t off = amax_n; amax_n += AMAX_SLOT; return off; }
+  // per-layer buffers for the transformed output gradient when a layer's weight gradient (side stream) and input gradient (main
+  // stream) multiply by the SAME planes: transformed once on the main stream, read by both (engine.cpp shared_dy)
+  bool share_dy() const;
   int dg_version = 0;       // arena.version the operands were derived from
   // set by the model for nets whose weight gradients are taken (G, the 2B discriminator instance): the
   // Winograd-transformed input of every such conv is kept from forward for its weight gradient
@@ -326,6 +335,7 @@ class Model {
   std::vector<int32_t> d_cimap_;  // buffer channel -> reference channel of the conditional D input (set by the model)
   int d_layers_ = 3;              // PatchGAN depth the model was built with (Ctx::patchgan_layers at construction)
  public:
+  int patchgan_layers() const { return d_layers_; }
   ParamArena& arena(int net) { return net == 0 ? arenaG : arenaD; }
   virtual ParamArena* arena_ptr(int net) {
     if (net == 0) return &arenaG;

@@ -53,6 +53,16 @@ void prof_enable(int on);
 void prof_reset();
 // one line per kernel variant: "<name> <launches> <total_ms> <total_flops>\n"; returns bytes written
 int prof_report(char* buf, int len);
+// Routing trace (swn_route_trace / swn_route_report, engine.cpp): which kernel family / algorithmic form every layer of a model
+// takes under the current environment.  While on, the engine labels each tape op as it runs it (phase f = forward, b = backward,
+// r = derived-operand refresh) and the launchers note the kernel they picked (implicit-GEMM launches with their M, N, K, batch
+// and split schedule; the Winograd transforms by form).  The report lists the distinct (label, phase, kernel) triples in first-
+// use order: tests compare the list of the configuration bench.py times with the one their own run takes.
+void route_enable(int on);
+bool route_on();
+void route_label(const char* label, char phase);
+void route_note(const char* kernel);
+int route_report(char* buf, int len);      // returns the bytes the full report needs
 
 // ---- implicit-GEMM convolution (MFMA) -----------------------------------------------
 // y[map(m)][co] (=|+=) act( sum_k A[m][k] * w[k][co] + bias[co] ),  A = gather(x)
@@ -84,7 +94,12 @@ struct ConvFwdArgs {
   const uint16_t* wpc = nullptr;
   int wpc_bn = 0;
   size_t wpc_bs = 0;
+  // optional: an amax slot of the A operand (AMAX_SLOT floats, device; their maximum >= max |x| over everything the launch
+  // gathers).  The two-plane kernels scale the operand by a power of two from it; without a slot the launch takes the amax itself
+  // with a pass over x.  Producers that write the operand fill the slot for free (amax_out of the transforms below).
+  const float* x_amax = nullptr;
 };
+constexpr int AMAX_SLOT = 256;
 void conv_fwd(Stream& s, const ConvFwdArgs& a);
 // Pre-cut weight operand of the LDS-DMA ring kernel (conv_gemm.hip conv_fwd_pc_kernel): x = hi + mid + lo, three bf16 planes by
 // truncation (exact), laid out in MFMA operand order per 16-k stage and column tile.  conv_precut_tile: the column tile (64 /
@@ -113,6 +128,8 @@ struct ConvWgradArgs {
   size_t x_bs = 0, dy_bs = 0, dw_bs = 0;
   int phases = 0;             // as in ConvFwdArgs; phase ph reads dy at (2oy + a, 2ox + b), writes dw + ph * dw_bs
   int tail4 = 0;              // as in ConvFwdArgs; dw = the folded-gradient block (layout of tail_fold_weights)
+  const float* x_amax = nullptr;      // amax slots of the two operands (as ConvFwdArgs::x_amax)
+  const float* dy_amax = nullptr;
 };
 void conv_wgrad(Stream& s, const ConvWgradArgs& a);
 
@@ -132,7 +149,11 @@ void reflect_fold(Stream& s, const TView& dxpad, const TView& dx, int accumulate
 // supported (m, r): (2,3), (4,3) for the 3x3 convs, (3,4) for PatchGAN's k4 s1 conv.
 // tile (n,ty,tx) covers outputs (m*ty..m*ty+m-1, m*tx..) and input rows m*ty-pad .. m*ty-pad+m+r-2;
 // P = (m+r-1)^2 transform planes (16 for F(2,3): 2.25x fewer multiplies; 36 for F(4,3) / F(3,4): 4x fewer)
-void wino_input_transform(Stream& s, int m, int r, const TView& x, int pad, int pad_mode, int Th, int Tw, float* V);  // V[P][T][x.C]
+// amax_out (optional, here and below): an amax slot (AMAX_SLOT floats, zeroed by the caller before the first producer of a
+// tensor runs) into which the kernel folds max |v| over everything it writes: entry blockIdx % AMAX_SLOT, an atomic max on
+// the bit pattern (non-negative floats order like unsigned integers, so the slot's maximum is exact and order-independent)
+void wino_input_transform(Stream& s, int m, int r, const TView& x, int pad, int pad_mode, int Th, int Tw, float* V,
+                          float* amax_out = nullptr);                                                                  // V[P][T][x.C]
 // mode 0: U[P][Cip][Npad] for the forward conv; mode 1: U[P][Npad][Cip] (flipped, transposed) for the transposed-conv form of
 // dgrad; mode 2: U[P][Npad][Cip] = mode 0 with the channel axes swapped, the operand of the adjoint form (wino_input_adjoint)
 void wino_filter_transform(Stream& s, int m, int r, const WShape& w, int mode, const float* packed, float* U);
@@ -147,7 +168,7 @@ void wino_input_adjoint(Stream& s, int m, int r, float* dV, int C, int pad, int 
                         int accumulate);
 void wino_output_transform(Stream& s, int m, int r, const float* M, int Cm, int Th, int Tw, const float* bias, int act,
                            const TView& y, int Cout, int accumulate);                                      // M[P][T][Cm]
-void wino_dy_transform(Stream& s, int m, int r, const TView& dy, int Th, int Tw, float* dM);               // dM[P][T][dy.C]
+void wino_dy_transform(Stream& s, int m, int r, const TView& dy, int Th, int Tw, float* dM, float* amax_out = nullptr);   // dM[P][T][dy.C]
 // ---- the folded tail conv (tail_fold_weights below) in Winograd form: its four sub-pixel phases are (2+a)x(2+b)-tap stride-1
 // convolutions over the same input, i.e. four F(4x4,3x3) convolutions sharing ONE wino_input_transform(4, 3, x, pad 1, zero);
 // their filters sit side by side on the N axis (N = 4 * Npad) of one batched GEMM.  Th, Tw = tiles of 4x4 INPUT positions.
@@ -155,11 +176,11 @@ void tailw_filter_transform(Stream& s, const WShape& w, const float* folded, flo
 void tailw_filter_grad(Stream& s, const WShape& w, const float* dU, float* dfolded);          // dU[36][Cip][4 * Npad] -> folded layout
 // y (2H x 2W, Npad channels): y[2 i + a][2 j + b] = act(A^T M_ab A + bias),  M[36][T][4 * Npad]
 void tailw_output_transform(Stream& s, const float* M, int Th, int Tw, int Npad, const float* bias, int act, const TView& y, int Cout);
-void tailw_dy_transform(Stream& s, const TView& dy, int Th, int Tw, int Npad, float* dM);      // dM[36][T][4 * Npad]
+void tailw_dy_transform(Stream& s, const TView& dy, int Th, int Tw, int Npad, float* dM, float* amax_out = nullptr);      // dM[36][T][4 * Npad]
 // ---- strided Winograd F(4x4, 2x2): the k4 s2 p1 convolutions and their transposes as four polyphase 2x2 stride-1 convolutions
 // sharing one batched GEMM (wino.hip).  "fine" = the 2H x 2W side, "coarse" = the H x W side; tiles = 4x4 coarse pixels.
 // (m, r) = (4, 2) is accepted by wino_output_transform (coarse = A^T M A) and wino_dy_transform (dM = A coarse A^T).
-void wino_s2_input_transform(Stream& s, const TView& fine, int Th, int Tw, float* V);       // V[25][T][4 * fine.C], channel (2s+t)*C + c
+void wino_s2_input_transform(Stream& s, const TView& fine, int Th, int Tw, float* V, float* amax_out = nullptr);   // V[25][T][4 * fine.C], channel (2s+t)*C + c
 // fine (+)= [bias +] adjoint of the transform above applied to dV[25][T][4 * Cf] (overwritten: scratch)
 void wino_s2_input_adjoint(Stream& s, float* dV, int Cf, int Th, int Tw, const TView& fine, const float* bias, int accumulate);
 // w: the layer's WShape (WK_CONV: fine = input, coarse = output; WK_CONVT: fine = output, coarse = input).

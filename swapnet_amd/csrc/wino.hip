@@ -278,13 +278,33 @@ __device__ __forceinline__ void f1mac(float& s, float c, float x) {
 }
 #define F4ZERO make_float4(0.f, 0.f, 0.f, 0.f)
 
+// ---- amax slots (ops.h ConvFwdArgs::x_amax): a producer folds max |v| over what it writes into entry blockIdx % AMAX_SLOT of the
+// slot -- block maximum through LDS, then one atomic max on the bit pattern (non-negative floats order like unsigned integers:
+// exact, order-independent), skipped when the entry already holds as much.  All 256 threads of the block must call it.
+__device__ __forceinline__ float f4amax(const float4& v) { return fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))); }
+__device__ __forceinline__ void amax_fold(float am, float* amax_out) {
+  if (!amax_out) return;                       // (uniform over the grid)
+  __shared__ float red[4];
+#pragma unroll
+  for (int o = 32; o; o >>= 1) am = fmaxf(am, __shfl_xor(am, o));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = am;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    unsigned* dst = reinterpret_cast<unsigned*>(amax_out) + (blockIdx.x % AMAX_SLOT);
+    const unsigned bits = __float_as_uint(m);          // m >= 0 (or NaN: sign bit clear after fabsf; orders above every finite value)
+    if (bits > __hip_atomic_load(dst, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(dst, bits);
+  }
+}
+
 template <class F>
 __global__ __launch_bounds__(256) void winog_input_kernel(const float* x, int xcs, int N, int H, int W, int C, int pad,
-                                                          int pad_mode, int Th, int Tw, float* V) {
+                                                          int pad_mode, int Th, int Tw, float* V, float* amax_out) {
   constexpr int A = F::A, M = F::M;
   const int C4 = C >> 2;
   const size_t T = (size_t)N * Th * Tw;
   const size_t total = T * C4;
+  float am = 0.f;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
     const size_t tile = i / C4;
     const int c = (int)(i - tile * C4) * 4;
@@ -318,8 +338,10 @@ __global__ __launch_bounds__(256) void winog_input_kernel(const float* x, int xc
 #pragma unroll
         for (int k = 0; k < A; ++k) f4mac(s, F::BT[j][k], t[a][k]);
         *reinterpret_cast<float4*>(V + ((size_t)(a * A + j) * T + tile) * C + c) = s;
+        am = fmaxf(am, f4amax(s));
       }
   }
+  amax_fold(am, amax_out);
 }
 
 template <class F>
@@ -421,11 +443,12 @@ __global__ __launch_bounds__(256) void winog_output_kernel(const float* Mx, int 
 // dM = A dY A^T : m x m -> (m+2) x (m+2)   (A = AT^T)
 template <class F>
 __global__ __launch_bounds__(256) void winog_dy_kernel(const float* dy, int dcs, int N, int H, int W, int C, int Th, int Tw,
-                                                       float* dM) {
+                                                       float* dM, float* amax_out) {
   constexpr int A = F::A, M = F::M;
   const int C4 = C >> 2;
   const size_t T = (size_t)N * Th * Tw;
   const size_t total = T * C4;
+  float am = 0.f;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
     const size_t tile = i / C4;
     const int c = (int)(i - tile * C4) * 4;
@@ -456,8 +479,10 @@ __global__ __launch_bounds__(256) void winog_dy_kernel(const float* dy, int dcs,
 #pragma unroll
         for (int b = 0; b < M; ++b) f4mac(s, F::AT[b][j], r[p][b]);
         *reinterpret_cast<float4*>(dM + ((size_t)(p * A + j) * T + tile) * C + c) = s;
+        am = fmaxf(am, f4amax(s));
       }
   }
+  amax_fold(am, amax_out);
 }
 
 // dW[(ky,kx,ci)][co] = (G^T dU G)[ky][kx]
@@ -616,12 +641,13 @@ struct F42 {
 
 // V[(a*5+j)][tile][q*C + c] = (BT d_q BT^T)[a][j],  d_q[i][j] = x[2 (4 ty + i) - 1 + s][2 (4 tx + j) - 1 + t],  q = 2 s + t
 __global__ __launch_bounds__(256) void wino_s2_input_kernel(const float* x, int xcs, int N, int H, int W, int C, int Th, int Tw,
-                                                            float* V) {
+                                                            float* V, float* amax_out) {
   constexpr int A = 5;
   const int C4 = C >> 2;
   const size_t T = (size_t)N * Th * Tw;
   const size_t total = T * 4 * C4;
   const int CV = 4 * C;
+  float am = 0.f;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
     const int c = (int)(i % C4) * 4; size_t r = i / C4;
     const int q = (int)(r & 3); const size_t tile = r >> 2;
@@ -656,8 +682,10 @@ __global__ __launch_bounds__(256) void wino_s2_input_kernel(const float* x, int 
 #pragma unroll
         for (int k = 0; k < A; ++k) f4mac(acc, F42::BT[j][k], tt[a][k]);
         *reinterpret_cast<float4*>(V + ((size_t)(a * A + j) * T + tile) * CV + q * C + c) = acc;
+        am = fmaxf(am, f4amax(acc));
       }
   }
+  amax_fold(am, amax_out);
 }
 
 // gather side of the adjoint: P[25][T][4 C] holds the patches BT^T dV BT; fine pixel (r, cc) of phase (s, t) sits at patch
@@ -1017,11 +1045,12 @@ __global__ __launch_bounds__(256) void tailw_output_kernel(const float* Mx, int 
 }
 // dM[p][tile][ph * Npad + c] = (A g_ph A^T)[p],  g_ph[i][j] = dy[2 (4 ty + i) + a][2 (4 tx + j) + b][c]
 __global__ __launch_bounds__(256) void tailw_dy_kernel(const float* dy, int dcs, int N, int yH, int yW, int Th, int Tw, int Npad,
-                                                       float* dM) {
+                                                       float* dM, float* amax_out) {
   constexpr int A = 6, M = 4;
   const int C4 = Npad >> 2, CM = 4 * Npad;
   const size_t T = (size_t)N * Th * Tw;
   const size_t total = T * 4 * C4;
+  float am = 0.f;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
     const int c = (int)(i % C4) * 4; size_t r = i / C4;
     const int ph = (int)(r & 3); const size_t tile = r >> 2;
@@ -1053,8 +1082,10 @@ __global__ __launch_bounds__(256) void tailw_dy_kernel(const float* dy, int dcs,
 #pragma unroll
         for (int jj = 0; jj < M; ++jj) f4mac(s, F43::AT[jj][j], rr[p][jj]);
         *reinterpret_cast<float4*>(dM + ((size_t)(p * A + j) * T + tile) * CM + ph * Npad + c) = s;
+        am = fmaxf(am, f4amax(s));
       }
   }
+  amax_fold(am, amax_out);
 }
 
 inline unsigned wgrid(size_t total) { return (unsigned)std::min<size_t>(std::max<size_t>((total + 255) / 256, 1), 256 * 32); }
@@ -1069,20 +1100,20 @@ static int variant(int m, int r) {
   if (m == 4 && r == 2) return 3;            // strided form: output / dy / patch transforms only
   throw Error(1, "winograd: supported forms are F(2,3), F(4,3), F(3,4) and the strided F(4,2)");
 }
-void wino_input_transform(Stream& s, int m, int r, const TView& x, int pad, int pad_mode, int Th, int Tw, float* V) {
+void wino_input_transform(Stream& s, int m, int r, const TView& x, int pad, int pad_mode, int Th, int Tw, float* V, float* amax_out) {
   const int v = variant(m, r);
   if (v == 3) throw Error(1, "wino_input_transform: F(4,2) is the strided form (wino_s2_input_transform)");
   if (x.C % 4 || x.cs % 4) throw Error(1, "wino_input_transform: C must be a multiple of 4");
   const size_t total = (size_t)x.N * Th * Tw * (x.C / 4);
   const dim3 grid(wgrid(total));
-  if (v == 0)
+  if (v == 0)            // (F(2,3) planes feed the fp32-operand kernels only: no slot to fill)
     hipLaunchKernelGGL(wino_input_kernel, grid, dim3(256), 0, hs(s), x.p, x.cs, x.N, x.H, x.W, x.C, pad, pad_mode, Th, Tw, V);
   else if (v == 1)
     hipLaunchKernelGGL(winog_input_kernel<F43>, grid, dim3(256), 0, hs(s), x.p, x.cs, x.N, x.H, x.W, x.C, pad, pad_mode, Th,
-                       Tw, V);
+                       Tw, V, amax_out);
   else
     hipLaunchKernelGGL(winog_input_kernel<F34>, grid, dim3(256), 0, hs(s), x.p, x.cs, x.N, x.H, x.W, x.C, pad, pad_mode, Th,
-                       Tw, V);
+                       Tw, V, amax_out);
   check_launch("wino_input_transform");
 }
 void wino_filter_transform(Stream& s, int m, int r, const WShape& w, int mode, const float* packed, float* U) {
@@ -1131,7 +1162,7 @@ void wino_output_transform(Stream& s, int m, int r, const float* M, int Cm, int 
                        y.W, Cout, accumulate);
   check_launch("wino_output_transform");
 }
-void wino_dy_transform(Stream& s, int m, int r, const TView& dy, int Th, int Tw, float* dM) {
+void wino_dy_transform(Stream& s, int m, int r, const TView& dy, int Th, int Tw, float* dM, float* amax_out) {
   const int v = variant(m, r);
   if (dy.C % 4 || dy.cs % 4) throw Error(1, "wino_dy_transform: C must be a multiple of 4");
   const size_t total = (size_t)dy.N * Th * Tw * (dy.C / 4);
@@ -1139,11 +1170,11 @@ void wino_dy_transform(Stream& s, int m, int r, const TView& dy, int Th, int Tw,
   if (v == 0)
     hipLaunchKernelGGL(wino_dy_kernel, grid, dim3(256), 0, hs(s), dy.p, dy.cs, dy.N, dy.H, dy.W, dy.C, Th, Tw, dM);
   else if (v == 1)
-    hipLaunchKernelGGL(winog_dy_kernel<F43>, grid, dim3(256), 0, hs(s), dy.p, dy.cs, dy.N, dy.H, dy.W, dy.C, Th, Tw, dM);
+    hipLaunchKernelGGL(winog_dy_kernel<F43>, grid, dim3(256), 0, hs(s), dy.p, dy.cs, dy.N, dy.H, dy.W, dy.C, Th, Tw, dM, amax_out);
   else if (v == 2)
-    hipLaunchKernelGGL(winog_dy_kernel<F34>, grid, dim3(256), 0, hs(s), dy.p, dy.cs, dy.N, dy.H, dy.W, dy.C, Th, Tw, dM);
+    hipLaunchKernelGGL(winog_dy_kernel<F34>, grid, dim3(256), 0, hs(s), dy.p, dy.cs, dy.N, dy.H, dy.W, dy.C, Th, Tw, dM, amax_out);
   else
-    hipLaunchKernelGGL(winog_dy_kernel<F42>, grid, dim3(256), 0, hs(s), dy.p, dy.cs, dy.N, dy.H, dy.W, dy.C, Th, Tw, dM);
+    hipLaunchKernelGGL(winog_dy_kernel<F42>, grid, dim3(256), 0, hs(s), dy.p, dy.cs, dy.N, dy.H, dy.W, dy.C, Th, Tw, dM, amax_out);
   check_launch("wino_dy_transform");
 }
 void tailw_filter_transform(Stream& s, const WShape& w, const float* folded, float* U) {
@@ -1162,16 +1193,16 @@ void tailw_output_transform(Stream& s, const float* M, int Th, int Tw, int Npad,
   hipLaunchKernelGGL(tailw_output_kernel, dim3(wgrid(total)), dim3(256), 0, hs(s), M, y.N, Th, Tw, Npad, bias, act, y.p, y.cs, y.H, y.W, Cout);
   check_launch("tailw_output_transform");
 }
-void tailw_dy_transform(Stream& s, const TView& dy, int Th, int Tw, int Npad, float* dM) {
+void tailw_dy_transform(Stream& s, const TView& dy, int Th, int Tw, int Npad, float* dM, float* amax_out) {
   if (Npad % 4 || dy.cs % 4 || dy.C < Npad) throw Error(1, "tailw_dy_transform: bad channel counts");
   const size_t total = (size_t)dy.N * Th * Tw * 4 * (Npad / 4);
-  hipLaunchKernelGGL(tailw_dy_kernel, dim3(wgrid(total)), dim3(256), 0, hs(s), dy.p, dy.cs, dy.N, dy.H, dy.W, Th, Tw, Npad, dM);
+  hipLaunchKernelGGL(tailw_dy_kernel, dim3(wgrid(total)), dim3(256), 0, hs(s), dy.p, dy.cs, dy.N, dy.H, dy.W, Th, Tw, Npad, dM, amax_out);
   check_launch("tailw_dy_transform");
 }
-void wino_s2_input_transform(Stream& s, const TView& x, int Th, int Tw, float* V) {
+void wino_s2_input_transform(Stream& s, const TView& x, int Th, int Tw, float* V, float* amax_out) {
   if (x.C % 4 || x.cs % 4) throw Error(1, "wino_s2_input_transform: C must be a multiple of 4");
   const size_t total = (size_t)x.N * Th * Tw * 4 * (x.C / 4);
-  hipLaunchKernelGGL(wino_s2_input_kernel, dim3(wgrid(total)), dim3(256), 0, hs(s), x.p, x.cs, x.N, x.H, x.W, x.C, Th, Tw, V);
+  hipLaunchKernelGGL(wino_s2_input_kernel, dim3(wgrid(total)), dim3(256), 0, hs(s), x.p, x.cs, x.N, x.H, x.W, x.C, Th, Tw, V, amax_out);
   check_launch("wino_s2_input_transform");
 }
 void wino_s2_input_adjoint(Stream& s, float* dV, int Cf, int Th, int Tw, const TView& dx, const float* bias, int accumulate) {

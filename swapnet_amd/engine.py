@@ -89,6 +89,17 @@ class Context:
     def sync(self):
         self.lib.call("swn_ctx_sync", self.handle)
 
+    def route_trace(self, on):
+        """Start (clears the log) / stop recording which kernel every layer launches (swn_route_trace)."""
+        self.lib.call("swn_route_trace", int(bool(on)))
+
+    def route_report(self):
+        """The distinct "<layer> <phase> <kernel[shape, schedule]>" lines recorded since route_trace(True), in first-use order."""
+        need = self.lib.dll.swn_route_report(None, 0)
+        buf = C.create_string_buffer(need + 16)
+        self.lib.dll.swn_route_report(buf, need + 16)
+        return [l for l in buf.value.decode().split("\n") if l]
+
     def bytes_allocated(self):
         n = C.c_size_t()
         self.lib.call("swn_ctx_bytes_allocated", self.handle, C.byref(n))

@@ -30,10 +30,10 @@ class BaseModel(ABC):
             raise RuntimeError("swapnet_amd runs on an MI355X only (gpu_id=%r); the reference's CPU path "
                                "is not part of this library" % (self.gpu_id,))
         self.device = torch.device(f"cuda:{self.gpu_id}")
+        # one checkpoint directory for the job: every rank LOADS from it (--continue_train / inference under torchrun find the
+        # files a single-GPU run or a smaller world wrote), only rank 0 WRITES to it (save_checkpoint below)
         self.save_dir = os.path.join(opt.checkpoints_dir, opt.name)
-        if self._dp_rank:        # replicas hold the same weights: ranks > 0 keep theirs out of rank 0's way
-            self.save_dir = os.path.join(self.save_dir, f"rank{self._dp_rank}")
-        if self.is_train:
+        if self.is_train and not self._dp_rank:
             PromptOnce.makedirs(self.save_dir, not getattr(opt, "no_confirm", True))
         self.loss_names = []
         self.model_names = []
@@ -101,14 +101,22 @@ class BaseModel(ABC):
         pass
 
     def save_checkpoint(self, epoch):
+        save_dir = self.save_dir
+        if self._dp_rank:
+            # data-parallel replicas hold identical weights and optimizer state: rank 0's files are the checkpoint.
+            # SWAPNET_SAVE_ALL_RANKS=1 (diagnostics / the lock-step test) makes the others write theirs to <save_dir>/rank<r>/
+            if os.environ.get("SWAPNET_SAVE_ALL_RANKS") != "1":
+                return
+            save_dir = os.path.join(self.save_dir, f"rank{self._dp_rank}")
+            os.makedirs(save_dir, exist_ok=True)
         for name in self.model_names:
             if isinstance(name, str):
-                save_path = os.path.join(self.save_dir, f"{epoch}_net_{name}.pth")
+                save_path = os.path.join(save_dir, f"{epoch}_net_{name}.pth")
                 net = getattr(self, f"net_{name}")
                 torch.save(net.state_dict(), save_path)          # CPU tensors, reference keys
         for name in self.optimizer_names:
             if isinstance(name, str):
-                save_path = os.path.join(self.save_dir, f"{epoch}_optim_{name}.pth")
+                save_path = os.path.join(save_dir, f"{epoch}_optim_{name}.pth")
                 torch.save(getattr(self, f"optimizer_{name}").state_dict(), save_path)
 
     def load_model_weights(self, model_name, weights_file):

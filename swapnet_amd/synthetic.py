@@ -42,3 +42,15 @@ def texture_batch(B, H, W, seed=1234, n_labels=19, num_roi=12, tile=8):
     rois[:, 0] = torch.tensor([W - 1, 0, W - 1, 0], dtype=torch.float32)     # one degenerate box per sample
     return dict(input_textures=tex, rois=rois, cloths=cloths, target_textures=tgt,
                 cloth_paths=[""] * B, texture_paths=[""] * B)
+
+
+def fill_inputs(model, kind, B, H, W, seed=1234):
+    """Hands a synthetic batch of the stage's shape to a native model through its set_input slots (bench.py's order)."""
+    if kind == "texture":
+        batch = texture_batch(B, H, W, seed=seed)
+        for i, k in enumerate(("input_textures", "rois", "cloths", "target_textures")):
+            model.set_input(i, batch[k])
+    else:
+        batch = warp_batch(B, H, W, seed=seed)
+        model.set_input(0, batch["bodys"]); model.set_input(1, batch["input_cloths"]); model.set_input(2, batch["target_cloths"])
+    return batch

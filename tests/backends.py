@@ -52,7 +52,7 @@ def rel_l2_without_worst_slices(a, b, k):
     """rel-L2(a, b) after dropping the k output-channel slices (dim 0) that carry the most squared error."""
     a, b = a.double().cpu(), b.double().cpu()
     if a.dim() == 0 or a.shape[0] <= k:
-        return 0.0
+        return float("inf")          # nothing left to judge: no exemption (as oracle/golden_io.py compare_full)
     d2 = ((a - b) ** 2).reshape(a.shape[0], -1).sum(dim=1)
     keep = d2.argsort()[: a.shape[0] - k]
     return float(d2[keep].sum().sqrt() / (b.norm() + 1e-30))
@@ -108,7 +108,7 @@ def get_model(ctx, kind, B, H, is_train=True):
     """Native models are expensive to create on the host simulator (GBs of zeroed arenas): the
     parity tests share one per (backend, stage, shape) and reset its training state instead."""
     from swapnet_amd import engine
-    key = (id(ctx), kind, B, H, is_train)
+    key = (id(ctx), kind, B, H, is_train, os.environ.get("SWN_WINO_MINC"))      # a model keeps the routing it was built under
     if key not in _models:
         _models[key] = engine.NativeModel(ctx, kind, B, H, H, is_train=is_train)
     return _models[key]
@@ -149,3 +149,66 @@ def assert_grads_replayed(got, ref64, skip, tol, what):
         worst = max(worst, e)
         assert e <= tol, (what, k, "rel-L2 %.2e > %.1e" % (e, tol))
     return worst
+
+
+# ---- kernel routing of the full-size tests ------------------------------------------------------------------------------
+_ROUTE_SCRIPT = r"""
+import sys, json
+sys.path.insert(0, %(repo)r)
+import torch
+from swapnet_amd import engine, synthetic
+kind, B, H = %(kind)r, %(B)d, %(H)d
+ctx = engine.Context(workspace_mb=1024)
+m = engine.NativeModel(ctx, kind, B, H, H, is_train=True)
+m.set_hyper()
+synthetic.fill_inputs(m, kind, B, H, H, seed=1)
+ctx.route_trace(True)
+m.forward(True, 3); m.backward_D(0.9, 0.8); m.optimizer_step(1); m.backward_G(1.0); m.optimizer_step(0)
+ctx.sync(); ctx.route_trace(False)
+print("ROUTE" + json.dumps(ctx.route_report()))
+"""
+_default_routes = {}
+
+
+def default_route(kind, B, H):
+    """The launch list of one phased training step of a `kind` model built and run in a SEPARATE process whose environment
+    carries no SWN_* variable at all -- what `python bench.py` / smoke() / a user gets.  Cached per (kind, B, H)."""
+    import json
+    import sys
+    key = (kind, B, H)
+    if key not in _default_routes:
+        env = {k: v for k, v in os.environ.items() if not k.startswith("SWN_")}
+        out = subprocess.run([sys.executable, "-c", _ROUTE_SCRIPT % dict(repo=REPO, kind=kind, B=B, H=H)], env=env, check=True,
+                             capture_output=True, text=True, timeout=900).stdout
+        line = [l for l in out.splitlines() if l.startswith("ROUTE")][-1]
+        _default_routes[key] = json.loads(line[5:])
+    return _default_routes[key]
+
+
+class traced_route:
+    """with traced_route(ctx) as r: <the step under test>; r.lines is its launch list."""
+
+    def __init__(self, ctx):
+        self.ctx, self.lines = ctx, []
+
+    def __enter__(self):
+        self.ctx.route_trace(True)
+        return self
+
+    def __exit__(self, *exc):
+        self.ctx.sync()
+        self.ctx.route_trace(False)
+        self.lines = self.ctx.route_report()
+        return False
+
+
+def assert_default_routing(lines, kind, B, H):
+    """The step just checked against the oracle launched exactly what a default-environment process launches for this model
+    (VERDICT r03 weak #1: the parity suite used to run under SWN_WINO_MINC=32, which re-routes three of C2's largest GEMMs)."""
+    leaked = sorted(k for k in os.environ if k.startswith("SWN_") and k not in ("SWN_PROF_DETAIL", "SWN_PC_DEBUG"))
+    assert not leaked, ("kernel-routing switches set in a default-routing test", leaked)
+    want = default_route(kind, B, H)
+    assert len(want) > 20, want
+    missing = [l for l in want if l not in lines]
+    extra = [l for l in lines if l not in want]
+    assert not missing and not extra, ("launch list differs from the default-environment one", missing[:8], extra[:8])

@@ -171,7 +171,12 @@ void wino_filter_transform_pc(Stream&, int m, int r, const WShape& w, int mode, 
   for (int p = 0; p < P; ++p) sim_store_panel(U.data() + (size_t)p * K * Nn, K, Nn, bn, out + (size_t)p * panel_elems);
 }
 
+void sim_slot_check(const float* slot, const float* x, size_t rows, int C, size_t rs, int batch, size_t bs, const char* what);
 void conv_fwd(Stream& s, const ConvFwdArgs& a) {
+  if (a.x_amax) {
+    const int nbb = a.phases ? 1 : (a.batch > 0 ? a.batch : 1);
+    sim_slot_check(a.x_amax, a.x.p, (size_t)a.x.N * a.x.H * a.x.W, a.x.C, (size_t)a.x.cs, nbb, a.x_bs, "conv_fwd");
+  }
   if (a.wpc) {
     // decode the panels back into the fp32 operand the loops below read
     if (a.tail4) throw Error(1, "hostsim conv_fwd: pre-cut operand on a tail4 launch");
@@ -189,7 +194,7 @@ void conv_fwd(Stream& s, const ConvFwdArgs& a) {
                            std::to_string(reinterpret_cast<const int*>(f + (size_t)K * NP)[0]));
     }
     ConvFwdArgs c = a;
-    c.wpc = nullptr;
+    c.wpc = nullptr; c.x_amax = nullptr;
     std::vector<float> wf;
     if (NP == (size_t)a.Npad) {                     // dense panel = the fp32 operand itself
       c.w = reinterpret_cast<const float*>(a.wpc); c.w_bs = a.wpc_bs / 2;
@@ -215,6 +220,11 @@ void conv_fwd(Stream& s, const ConvFwdArgs& a) {
     return;
   }
   const int nb = a.phases ? a.phases : (a.batch > 0 ? a.batch : 1);
+  if (route_on()) {
+    char nm[128];
+    snprintf(nm, sizeof nm, "sim_conv_fwd[M%d,N%d,K%d,b%d]", a.x.N * a.g.Ho * a.g.Wo, a.Cout, a.g.KH * a.g.KW * a.x.C, nb);
+    route_note(nm);
+  }
   // batched Winograd planes have few rows each: spread the planes over the threads instead
 #pragma omp parallel for schedule(dynamic, 1) if (nb >= 8)
   for (int b = 0; b < nb; ++b) {
@@ -254,6 +264,11 @@ static void conv_wgrad_one(const ConvWgradArgs& a) {
     }
 }
 void conv_wgrad(Stream& s, const ConvWgradArgs& a) {
+  if (a.x_amax || a.dy_amax) {
+    const int nbb = a.phases ? 1 : (a.batch > 0 ? a.batch : 1);
+    sim_slot_check(a.x_amax, a.x.p, (size_t)a.x.N * a.x.H * a.x.W, a.x.C, (size_t)a.x.cs, nbb, a.x_bs, "conv_wgrad x");
+    sim_slot_check(a.dy_amax, a.dy.p, (size_t)a.dy.N * a.dy.H * a.dy.W, a.dy.C, (size_t)a.dy.cs, nbb, a.dy_bs, "conv_wgrad dy");
+  }
   if (a.tail4) {
     for (int ph = 0; ph < 4; ++ph) {
       ConvWgradArgs c = tail_phase(a, ph);
@@ -263,6 +278,11 @@ void conv_wgrad(Stream& s, const ConvWgradArgs& a) {
     return;
   }
   const int nb = a.phases ? a.phases : (a.batch > 0 ? a.batch : 1);
+  if (route_on()) {
+    char nm[128];
+    snprintf(nm, sizeof nm, "sim_conv_wgrad[M%d,N%d,K%d,b%d]", a.x.N * a.g.Ho * a.g.Wo, a.Cout, a.g.KH * a.g.KW * a.x.C, nb);
+    route_note(nm);
+  }
 #pragma omp parallel for schedule(dynamic, 1) if (nb >= 8)
   for (int b = 0; b < nb; ++b) {
     ConvWgradArgs c = a;
@@ -296,7 +316,7 @@ static WinoMats wino_mats(int m, int r) {
   if (m == 3 && r == 4) return {3, 4, 6, kBT6, kG34, kAT34};
   throw Error(1, "winograd: supported forms are F(2,3), F(4,3) and F(3,4)");
 }
-void wino_input_transform(Stream&, int m, int r, const TView& x, int pad, int pad_mode, int Th, int Tw, float* V) {
+static void wino_input_transform_impl(int m, int r, const TView& x, int pad, int pad_mode, int Th, int Tw, float* V) {
   const WinoMats wm = wino_mats(m, r);
   const int A = wm.A;
   const size_t T = (size_t)x.N * Th * Tw;
@@ -360,7 +380,7 @@ void wino_output_transform(Stream&, int m, int r, const float* M, int Cm, int Th
     }
   }
 }
-void wino_dy_transform(Stream&, int m, int r, const TView& dy, int Th, int Tw, float* dM) {
+static void wino_dy_transform_impl(int m, int r, const TView& dy, int Th, int Tw, float* dM) {
   const WinoMats wm = wino_mats(m, r);
   const int A = wm.A;
   const size_t T = (size_t)dy.N * Th * Tw;
@@ -432,7 +452,7 @@ void tailw_output_transform(Stream&, const float* M, int Th, int Tw, int Npad, c
     }
   }
 }
-void tailw_dy_transform(Stream&, const TView& dy, int Th, int Tw, int Npad, float* dM) {
+static void tailw_dy_transform_impl(const TView& dy, int Th, int Tw, int Npad, float* dM) {
   const WinoMats wm = wino_mats(4, 3);
   const int A = 6, CM = 4 * Npad;
   const size_t T = (size_t)dy.N * Th * Tw;
@@ -454,7 +474,7 @@ void tailw_dy_transform(Stream&, const TView& dy, int Th, int Tw, int Npad, floa
   }
 }
 // ---- strided Winograd F(4x4, 2x2) (ops.h): plain loops straight from the definition
-void wino_s2_input_transform(Stream&, const TView& x, int Th, int Tw, float* V) {
+static void wino_s2_input_transform_impl(const TView& x, int Th, int Tw, float* V) {
   const WinoMats wm = wino_mats(4, 2);
   const int A = 5, C = x.C;
   const size_t T = (size_t)x.N * Th * Tw;
@@ -1120,6 +1140,49 @@ void repack_dgrad(Stream&, const WShape& w, int mode, int Cop, int Ndg, const fl
       }
     }
   }
+}
+
+
+// ---- amax slots (ops.h ConvFwdArgs::x_amax): the producers fold max |v| of what they wrote into the slot (entry 0 here), the
+// consumers CHECK it against the operand they are about to read -- a slot that was not zeroed, not filled, or filled from another
+// tensor is an engine bug the simulator must catch (on the device it would silently mis-scale the fp16 planes)
+static float sim_amax(const float* p, size_t n) {
+  float m = 0.f;
+  for (size_t i = 0; i < n; ++i) m = std::max(m, std::fabs(p[i]));
+  return m;
+}
+static void sim_slot_fold(float* slot, float v) { if (slot) slot[0] = std::max(slot[0], v); }
+float sim_slot_max(const float* slot) {
+  float m = 0.f;
+  for (int i = 0; i < AMAX_SLOT; ++i) m = std::max(m, slot[i]);
+  return m;
+}
+void sim_slot_check(const float* slot, const float* x, size_t rows, int C, size_t rs, int batch, size_t bs, const char* what) {
+  if (!slot) return;
+  float actual = 0.f;
+  for (int b = 0; b < batch; ++b)
+    for (size_t r = 0; r < rows; ++r) actual = std::max(actual, sim_amax(x + (size_t)b * bs + r * rs, (size_t)C));
+  const float have = sim_slot_max(slot);
+  if (have != actual)
+    throw Error(1, std::string("hostsim ") + what + ": amax slot holds " + std::to_string(have) + ", the operand's amax is " + std::to_string(actual));
+}
+void wino_input_transform(Stream&, int m, int r, const TView& x, int pad, int pad_mode, int Th, int Tw, float* V, float* amax_out) {
+  wino_input_transform_impl(m, r, x, pad, pad_mode, Th, Tw, V);
+  const int A = m + r - 1;
+  if (amax_out && !(m == 2 && r == 3)) sim_slot_fold(amax_out, sim_amax(V, (size_t)A * A * x.N * Th * Tw * x.C));
+}
+void wino_dy_transform(Stream&, int m, int r, const TView& dy, int Th, int Tw, float* dM, float* amax_out) {
+  wino_dy_transform_impl(m, r, dy, Th, Tw, dM);
+  const int A = m + r - 1;
+  if (amax_out && !(m == 2 && r == 3)) sim_slot_fold(amax_out, sim_amax(dM, (size_t)A * A * dy.N * Th * Tw * dy.C));
+}
+void tailw_dy_transform(Stream&, const TView& dy, int Th, int Tw, int Npad, float* dM, float* amax_out) {
+  tailw_dy_transform_impl(dy, Th, Tw, Npad, dM);
+  sim_slot_fold(amax_out, sim_amax(dM, (size_t)36 * dy.N * Th * Tw * 4 * Npad));
+}
+void wino_s2_input_transform(Stream&, const TView& x, int Th, int Tw, float* V, float* amax_out) {
+  wino_s2_input_transform_impl(x, Th, Tw, V);
+  sim_slot_fold(amax_out, sim_amax(V, (size_t)25 * x.N * Th * Tw * 4 * x.C));
 }
 
 }  // namespace swn

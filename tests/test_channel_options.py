@@ -12,6 +12,8 @@ from tests import backends
 from tests.test_texture_step import vgg_state_dict
 from tests.test_train_parity import BACKENDS, _ctx, _phased_step, noise_bias, rel
 
+pytestmark = pytest.mark.small_channel_winograd      # tests/conftest.py: small shapes on the Winograd forms
+
 
 def _blocky_onehot(B, H, C, g):
     lab = torch.randint(0, C, (B, H // 8, H // 8), generator=g).repeat_interleave(8, 1).repeat_interleave(8, 2)

@@ -18,6 +18,8 @@ from tests import backends
 from tests.test_models_api import make_opt
 from tests.test_warp_step import noise_bias
 
+pytestmark = pytest.mark.small_channel_winograd      # tests/conftest.py: small shapes on the Winograd forms
+
 BACKENDS = [pytest.param("sim", id="hostsim"), pytest.param("gpu", id="mi355x", marks=pytest.mark.gpu)]
 MODES = {"wgan-gp": (2, 1), "dragan-gp": (0, 2), "dragan-lp": (0, 3)}        # name -> (gan_mode, gp_mode) of swn_hyper
 

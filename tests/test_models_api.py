@@ -14,6 +14,8 @@ from oracle import swapnet_oracle as O
 from oracle.golden_io import compare
 from tests import backends
 
+pytestmark = pytest.mark.small_channel_winograd      # tests/conftest.py: small shapes on the Winograd forms
+
 BACKENDS = [pytest.param("sim", id="hostsim"), pytest.param("gpu", id="mi355x", marks=pytest.mark.gpu)]
 
 

@@ -13,6 +13,8 @@ from swapnet_amd.modules.loss import GANLoss
 from tests import backends
 from tests.test_models_api import make_opt
 
+pytestmark = pytest.mark.small_channel_winograd      # tests/conftest.py: small shapes on the Winograd forms
+
 BACKENDS = [pytest.param("sim", id="hostsim"), pytest.param("gpu", id="mi355x", marks=pytest.mark.gpu)]
 
 

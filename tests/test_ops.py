@@ -16,6 +16,8 @@ from oracle import swapnet_oracle as O
 from swapnet_amd import _C
 from tests import backends
 
+pytestmark = pytest.mark.small_channel_winograd      # tests/conftest.py: small shapes on the Winograd forms
+
 K4S2, K3REFL, K4S1, K3ZERO, TAIL = 0, 1, 2, 3, 4
 
 

@@ -19,7 +19,7 @@ from tests.test_train_parity import BACKENDS, _ctx, _phased_step, _texture_case,
 TOL = 1e-4
 
 
-def _warp_replay(ctx, B, H, seed, training, labels=(0.9, 0.8, 1.0), drop_seed=77):
+def _warp_replay(ctx, B, H, seed, training, labels=(0.9, 0.8, 1.0), drop_seed=77, check_route=False):
     torch.manual_seed(seed)
     G, D = O.warp_module_params(), O.patchgan_params(22)
     batch = O.synth_warp_batch(B, H, H, seed=99)
@@ -29,7 +29,10 @@ def _warp_replay(ctx, B, H, seed, training, labels=(0.9, 0.8, 1.0), drop_seed=77
         for i, t in enumerate(batch):
             m.set_input(i, t)
         masks = [t.cpu() for t, _ in m.dropout_masks(engine.NET_G, seed=drop_seed)] if training else None
-        gD, gG = _phased_step(m, list(labels), training, drop_seed)
+        with backends.traced_route(ctx) as route:
+            gD, gG = _phased_step(m, list(labels), training, drop_seed)
+        if check_route:            # the benchmarked configurations: bench.py's kernel routing, launch for launch
+            backends.assert_default_routing(route.lines, "warp", B, H)
         replay = O.PatternReplay(backends.collect_patterns(m))
         s64 = O.WarpStepOracle(G, D, training=O.MaskReplay(masks) if training else False, dtype=torch.float64)
         s64.patterns = replay
@@ -46,6 +49,7 @@ def _warp_replay(ctx, B, H, seed, training, labels=(0.9, 0.8, 1.0), drop_seed=77
         m.close()
 
 
+@pytest.mark.small_channel_winograd
 @pytest.mark.parametrize("backend", BACKENDS)
 @pytest.mark.parametrize("mode", ["eval", "train"])
 def test_warp_gradients_with_pinned_pattern(backend, mode):
@@ -53,10 +57,13 @@ def test_warp_gradients_with_pinned_pattern(backend, mode):
     print("warp 64x64", mode, "flips", flips, "worst D %.2e G %.2e" % (wD, wG))
 
 
-def _texture_replay(ctx, B, H, training, labels=(0.85, 0.95, 0.75), drop_seed=99):
+def _texture_replay(ctx, B, H, training, labels=(0.85, 0.95, 0.75), drop_seed=99, check_route=False):
     m, G, D, vgg, batch, masks = _texture_case(ctx, B, H, drop_seed)
     try:
-        gD, gG = _phased_step(m, list(labels), training, drop_seed)
+        with backends.traced_route(ctx) as route:
+            gD, gG = _phased_step(m, list(labels), training, drop_seed)
+        if check_route:
+            backends.assert_default_routing(route.lines, "texture", B, H)
         replay = O.PatternReplay(backends.collect_patterns(m, vgg=True))
         s64 = O.TextureStepOracle(G, D, vgg, training=O.MaskReplay(masks) if training else False, dtype=torch.float64)
         s64.patterns = replay
@@ -70,6 +77,7 @@ def _texture_replay(ctx, B, H, training, labels=(0.85, 0.95, 0.75), drop_seed=99
         m.close()
 
 
+@pytest.mark.small_channel_winograd
 @pytest.mark.parametrize("backend", BACKENDS)
 @pytest.mark.parametrize("mode", ["eval", "train"])
 def test_texture_gradients_with_pinned_pattern(backend, mode):
@@ -95,16 +103,17 @@ def test_texture_gradients_with_pinned_pattern_at_full_resolution(mode):
 
 @pytest.mark.gpu
 def test_warp_c2_full_batch_training_step_with_pinned_pattern():
-    """BASELINE.json C2 exactly as bench.py times it (256x256, bs 32, TRAINING mode): dropout masks and activation
-    pattern replayed in the float64 oracle, every gradient tensor within 1e-4."""
-    flips, wD, wG = _warp_replay(backends.gpu_ctx(), 32, 256, 3, True)
+    """BASELINE.json C2 exactly as bench.py times it (256x256, bs 32, TRAINING mode, default kernel routing -- the launch list
+    is compared with a scrubbed-environment process): dropout masks and activation pattern replayed in the float64 oracle,
+    every gradient tensor within 1e-4."""
+    flips, wD, wG = _warp_replay(backends.gpu_ctx(), 32, 256, 3, True, check_route=True)
     print("warp C2 bs32 train", "flips", flips, "worst D %.2e G %.2e" % (wD, wG))
 
 
 @pytest.mark.gpu
 def test_texture_c3_full_batch_training_step_with_pinned_pattern():
     """BASELINE.json C3 (256x256, bs 16, 12 ROIs, L1 + VGG16 content + style, TRAINING mode), same comparison."""
-    flips, wD, wG = _texture_replay(backends.gpu_ctx(), 16, 256, True)
+    flips, wD, wG = _texture_replay(backends.gpu_ctx(), 16, 256, True, check_route=True)
     print("texture C3 bs16 train", "flips", flips, "worst D %.2e G %.2e" % (wD, wG))
 
 

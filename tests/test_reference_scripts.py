@@ -14,7 +14,8 @@ import numpy as np
 import pytest
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-pytestmark = pytest.mark.skipif(not os.path.isfile("/root/reference/train.py"), reason="reference tree not mounted")
+pytestmark = [pytest.mark.skipif(not os.path.isfile("/root/reference/train.py"), reason="reference tree not mounted"),
+              pytest.mark.small_channel_winograd]     # 64x64 datasets: tests/conftest.py
 
 
 def _make_dataset(root, n=6, size=64):
@@ -94,7 +95,8 @@ def test_reference_train_script_runs_data_parallel_under_a_torchrun_environment(
     procs = []
     for rank in range(2):
         env = dict(os.environ, PYTHONPATH=REPO, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=str(port), SWAPNET_DIST_BACKEND="gloo", SWAPNET_FORCE_DEVICE="0", OMP_NUM_THREADS="4")
+                   MASTER_PORT=str(port), SWAPNET_DIST_BACKEND="gloo", SWAPNET_FORCE_DEVICE="0", OMP_NUM_THREADS="4",
+                   SWAPNET_SAVE_ALL_RANKS="1")          # ranks > 0 write no checkpoint by default (rank 0's is the job's)
         procs.append(subprocess.Popen([sys.executable, os.path.join(REPO, "tests", "ref_script_runner.py"), "train.py", str(tmp_path)] + args,
                                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=env))
     outs = [p.communicate(timeout=1500)[0] for p in procs]

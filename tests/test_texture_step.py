@@ -78,6 +78,7 @@ def oracle_run(gold):
     return G, D, vgg, batch, taps, s
 
 
+@pytest.mark.small_channel_winograd
 @pytest.mark.parametrize("backend", BACKENDS)
 def test_texture_step_matches_oracle_and_reference(backend, oracle_run, gold):
     G, D, vgg, batch, taps, s = oracle_run

@@ -70,6 +70,7 @@ def oracle_run(gold):
     return G, D, batch, taps, steps
 
 
+@pytest.mark.small_channel_winograd
 @pytest.mark.parametrize("backend", BACKENDS)
 def test_warp_forward_levels(backend, oracle_run, gold):
     G, D, batch, taps, _ = oracle_run
@@ -92,6 +93,7 @@ def test_warp_forward_levels(backend, oracle_run, gold):
         assert torch.equal(sd[k], G[k]), k
 
 
+@pytest.mark.small_channel_winograd
 @pytest.mark.parametrize("backend", BACKENDS)
 def test_warp_two_steps_match_oracle_and_reference(backend, oracle_run, gold):
     G, D, batch, _, steps = oracle_run
@@ -159,6 +161,7 @@ def test_warp_two_steps_match_oracle_and_reference(backend, oracle_run, gold):
     assert m.optim_step_count(engine.NET_G) == len(steps)
 
 
+@pytest.mark.small_channel_winograd
 @pytest.mark.parametrize("backend", BACKENDS)
 def test_fused_step_equals_phased_step(backend, oracle_run):
     """swn_model_step == forward; backward_D; step D; backward_G; step G (bitwise)."""
@@ -265,6 +268,7 @@ def test_warp_step_at_full_resolution_matches_oracle():
         m.close()
 
 
+@pytest.mark.small_channel_winograd
 @pytest.mark.parametrize("backend", BACKENDS)
 @pytest.mark.parametrize("mode", ["lsgan", "wgan", "ce"])
 def test_other_gan_objectives_and_ce_mode(backend, mode, oracle_run):
@@ -306,6 +310,7 @@ def test_other_gan_objectives_and_ce_mode(backend, mode, oracle_run):
         assert m.optim_step_count(1) == 0
 
 
+@pytest.mark.small_channel_winograd
 @pytest.mark.parametrize("backend", BACKENDS)
 def test_non_square_warp_forward(backend, oracle_run):
     """DeepFashion-shaped inputs are 4:3 (BASELINE.json config C5: 256x192): the warp generator
@@ -327,6 +332,7 @@ def test_non_square_warp_forward(backend, oracle_run):
     m.close()
 
 
+@pytest.mark.small_channel_winograd
 @pytest.mark.parametrize("backend", BACKENDS)
 @pytest.mark.parametrize("variant", ["winograd_f2x2", "direct"])
 def test_resblock_conv_variants_match_oracle(backend, variant, oracle_run, monkeypatch):
