@@ -33,7 +33,7 @@ def main(src, tag):
         with open(os.path.join(HERE, f"rocprof_{tag}_kernel_stats.md"), "w") as f:
             f.write(f"# rocprofv3 --kernel-trace --stats ({tag})\n\n")
             f.write("| kernel | calls | total ms | avg us | % |\n|---|---|---|---|---|\n")
-            for r in rows[:40]:
+            for r in rows[:90]:
                 f.write("| %s | %s | %.3f | %.1f | %.2f |\n" % (
                     short(r["Name"]), r["Calls"], float(r["TotalDurationNs"]) / 1e6,
                     float(r["AverageNs"]) / 1e3, 100 * float(r["TotalDurationNs"]) / tot))

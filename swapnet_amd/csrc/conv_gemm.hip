@@ -47,6 +47,7 @@ struct GemmP {
   size_t x_bs, w_bs, y_bs, slab_bs;   // batched mode (blockIdx.z)
   int phases;                         // sub-pixel phase mode: blockIdx.z = 2a + b shifts pads / output offsets
   int tail4;                          // fused folded-tail kernels
+  float* y_amax;                      // optional amax slot of everything the launch stores (pre-cut ring kernel + its reduce)
 };
 
 __device__ __forceinline__ void apply_phase(GemmP& p) {
@@ -652,6 +653,7 @@ __global__ __launch_bounds__(256) void conv_dma_reduce_kernel(GemmP p, DmaSched 
   const int n = m / HoWo, rem = m - n * HoWo;
   const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
   float* dst = p.y + (size_t)((n * p.yH + oy * p.ymul + p.yoff) * p.yW + ox * p.xmul + p.xoff) * p.ycs + col;
+  float am = 0.f;
   if (col + 3 < p.Cout) {
     float4 o = make_float4(v[0], v[1], v[2], v[3]);
     if (p.accumulate) {
@@ -659,9 +661,12 @@ __global__ __launch_bounds__(256) void conv_dma_reduce_kernel(GemmP p, DmaSched 
       o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w;
     }
     *reinterpret_cast<float4*>(dst) = o;
+    am = f4amax(o);
   } else {
-    for (int j = 0; j < 4 && col + j < p.Cout; ++j) dst[j] = p.accumulate ? dst[j] + v[j] : v[j];
+    for (int j = 0; j < 4 && col + j < p.Cout; ++j) { const float o = p.accumulate ? dst[j] + v[j] : v[j]; dst[j] = o; am = fmaxf(am, fabsf(o)); }
   }
+  // (threads that returned above hold nothing: a per-thread atomic with the pre-check costs a load for all but a few)
+  if (p.y_amax && am > 0.f) amax_store(am, p.y_amax, blockIdx.x + blockIdx.y * gridDim.x);
 }
 
 
@@ -717,11 +722,24 @@ __device__ __forceinline__ void split8h(const float* v, float sa, u32x4& hi, u32
     lo[q] = __builtin_bit_cast(unsigned, f16x2{(_Float16)r0, (_Float16)r1});
   }
 }
+// h rounded to NEAREST (v_cvt_pk_f16_f32): the residual l then has no preferred sign.  With both operands cut by truncation the
+// dropped l_a l_b term always carries the sign of a b -- a relative bias of ~2^-22.6 on one-signed operands (measured: -1.5e-7 on
+// post-ReLU x against positive dY); one operand rounded to nearest makes the term zero-mean.
+__device__ __forceinline__ void split8h_rn(const float* v, float sa, u32x4& hi, u32x4& lo) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const float x0 = v[2 * q] * sa, x1 = v[2 * q + 1] * sa;
+    const f16x2 h = f16x2{(_Float16)x0, (_Float16)x1};
+    const float r0 = x0 - (float)h[0], r1 = x1 - (float)h[1];
+    hi[q] = __builtin_bit_cast(unsigned, h);
+    lo[q] = __builtin_bit_cast(unsigned, f16x2{(_Float16)r0, (_Float16)r1});
+  }
+}
 // both operands fp32 in LDS (the weight-gradient kernel): acc[i][j] += A_i x B_j over the lane's 8 k values, two fp16 planes each
 __device__ __forceinline__ void split_mma_2x2_h(f32x16 (&acc)[2][2], const float (&af)[2][8], const float (&bf)[2][8], float sa, float sb) {
   u32x4 ah[2], al[2], bh[2], bl[2];
 #pragma unroll
-  for (int i = 0; i < 2; ++i) { split8h(af[i], sa, ah[i], al[i]); split8h(bf[i], sb, bh[i], bl[i]); }
+  for (int i = 0; i < 2; ++i) { split8h(af[i], sa, ah[i], al[i]); split8h_rn(bf[i], sb, bh[i], bl[i]); }
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -753,11 +771,13 @@ constexpr int PC_TRAILER = 8;           // bf16/f16 elements (16 bytes) behind a
 // 256 blocks x 1024 threads, four independent 16-byte loads in flight per thread (64 KB per CU); `flat`: the region is one
 // dense array of `total4` float4s (no index arithmetic).  No atomics: the consumers reduce the 256 partials themselves.
 __device__ __forceinline__ float amax4(const float4& v) { return fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))); }
+// fold != 0: the block maxima are folded into the slot `out` (atomic max, hip_util.h amax_store) instead of overwriting it;
+// floor: a value the result is at least (a known bound of what another producer writes into the same buffer)
 __global__ __launch_bounds__(1024) void amax_partials_kernel(const float* x, size_t rows, int C4, size_t rs, int batch, size_t bs, int flat,
-                                                             float* out) {
+                                                             float* out, int fold, float floor) {
   const size_t total = (size_t)batch * rows * C4;
   constexpr size_t S = (size_t)256 * 1024;
-  float m = 0.f;
+  float m = floor;
   auto at = [&](size_t i) -> const float4* {
     if (flat) return reinterpret_cast<const float4*>(x) + i;
     const size_t r = i / C4; const int c = (int)(i - r * C4);
@@ -779,7 +799,10 @@ __global__ __launch_bounds__(1024) void amax_partials_kernel(const float* x, siz
     float r = red[threadIdx.x];
 #pragma unroll
     for (int o = 8; o; o >>= 1) r = fmaxf(r, __shfl_xor(r, o));
-    if (threadIdx.x == 0) out[blockIdx.x] = r;
+    if (threadIdx.x == 0) {
+      if (fold) amax_store(r, out, blockIdx.x);
+      else out[blockIdx.x] = r;
+    }
   }
 }
 
@@ -1001,6 +1024,7 @@ __global__ __launch_bounds__(64 * WGM, WGCU * WGM / 4) void conv_fwd_pc_kernel(G
   }
   __syncthreads();
   const int col = n0 + colr;
+  float am = 0.f;
   if (col < p.Cout) {
     float bj[NB];
 #pragma unroll
@@ -1019,21 +1043,24 @@ __global__ __launch_bounds__(64 * WGM, WGCU * WGM / 4) void conv_fwd_pc_kernel(G
           float4 o = make_float4(v[0], v[1], v[2], v[3]);
           if (p.accumulate) { const float4 q = *reinterpret_cast<const float4*>(dst); o.x += q.x; o.y += q.y; o.z += q.z; o.w += q.w; }
           *reinterpret_cast<float4*>(dst) = o;
+          am = fmaxf(am, f4amax(o));
         } else {
 #pragma unroll
           for (int j = 0; j < NB; j += 2) {
             float2 o = make_float2(v[j], v[j + 1]);
             if (p.accumulate) { const float2 q = *reinterpret_cast<const float2*>(dst + j); o.x += q.x; o.y += q.y; }
             *reinterpret_cast<float2*>(dst + j) = o;
+            am = fmaxf(am, fmaxf(fabsf(o.x), fabsf(o.y)));
           }
         }
       } else {
 #pragma unroll
         for (int j = 0; j < NB; ++j)
-          if (col + j < p.Cout) dst[j] = p.accumulate ? dst[j] + v[j] : v[j];
+          if (col + j < p.Cout) { const float o = p.accumulate ? dst[j] + v[j] : v[j]; dst[j] = o; am = fmaxf(am, fabsf(o)); }
       }
     }
   }
+  if (p.y_amax) amax_fold_wave(am, p.y_amax, blockIdx.x * WGM + wid);        // (every wave arrives here converged)
 #endif
 }
 
@@ -1587,6 +1614,7 @@ __global__ void conv_fwd_reduce_kernel(GemmP p) {
   const int n = m / HoWo, rem = m - n * HoWo;
   const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
   float* dst = p.y + (size_t)((n * p.yH + oy * p.ymul + p.yoff) * p.yW + ox * p.xmul + p.xoff) * p.ycs + col;
+  float am = 0.f;
   if (col + 3 < p.Cout) {
     float4 o = make_float4(v[0], v[1], v[2], v[3]);
     if (p.accumulate) {
@@ -1594,9 +1622,12 @@ __global__ void conv_fwd_reduce_kernel(GemmP p) {
       o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w;
     }
     *reinterpret_cast<float4*>(dst) = o;
+    am = f4amax(o);
   } else {
-    for (int j = 0; j < 4 && col + j < p.Cout; ++j) dst[j] = p.accumulate ? dst[j] + v[j] : v[j];
+    for (int j = 0; j < 4 && col + j < p.Cout; ++j) { const float o = p.accumulate ? dst[j] + v[j] : v[j]; dst[j] = o; am = fmaxf(am, fabsf(o)); }
   }
+  // (threads that returned above hold nothing: a per-thread atomic with the pre-check costs a load for all but a few)
+  if (p.y_amax && am > 0.f) amax_store(am, p.y_amax, blockIdx.x + blockIdx.y * gridDim.x);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -2402,6 +2433,11 @@ static int pc_planes() {
   return pl;
 }
 int conv_precut_planes() { return pc_planes(); }
+static int pc_stages() {
+  const char* e = getenv("SWN_PC_STAGES");
+  const int v = e ? atoi(e) : 2;
+  return (v == 3 || v == 4) ? v : 2;
+}
 // the last 2 KiB of a stream's scratch hold the partial maxima of the launch in flight (A operand) and of the operand a producer
 // is cutting; the split-K slabs of the same launch stay below
 constexpr size_t PC_WS_TAIL = 2048;
@@ -2411,10 +2447,11 @@ static float* ws_amax(Stream& s, int which) {
 }
 // SWN_AMAX_FUSED=0: every launch takes the amax of its operands itself (A/B against the producer-side slots; read per launch)
 static bool amax_fused_on() { return !(getenv("SWN_AMAX_FUSED") && atoi(getenv("SWN_AMAX_FUSED")) == 0); }
-static void amax_partials(Stream& s, const float* x, size_t rows, int C, size_t rs, int batch, size_t bs, float* out) {
+static void amax_partials(Stream& s, const float* x, size_t rows, int C, size_t rs, int batch, size_t bs, float* out, int fold = 0,
+                          float floor = 0.f) {
   if (C % 4 || rs % 4 || bs % 4 || ((uintptr_t)x & 15)) throw Error(1, "amax_partials: operand not 16-byte aligned");
   const int flat = rs == (size_t)C && (batch == 1 || bs == rows * (size_t)C);
-  hipLaunchKernelGGL(amax_partials_kernel, dim3(256), dim3(1024), 0, hs(s), x, rows, C / 4, rs, batch, bs, flat, out);
+  hipLaunchKernelGGL(amax_partials_kernel, dim3(256), dim3(1024), 0, hs(s), x, rows, C / 4, rs, batch, bs, flat, out, fold, floor);
   check_launch("amax_partials");
 }
 template <int WGM, int NB, int NSTG, int WGCU, int PL>
@@ -2505,6 +2542,14 @@ void conv_precut(Stream& s, const float* w, int K, int Npad, int bn, int batch, 
   check_launch("conv_precut");
 }
 
+void tensor_amax(Stream& s, const TView& x, float* slot, float floor) {
+  amax_partials(s, x.p, x.pixels(), x.C, (size_t)x.cs, 1, 0, slot, 0, floor);
+}
+// ConvFwdArgs::y_amax on a launch whose kernel has no folding epilogue: a pass over the output view
+static void fold_output_amax(Stream& s, const ConvFwdArgs& a) {
+  amax_partials(s, a.y.p, a.y.pixels(), a.y.C, (size_t)a.y.cs, 1, 0, a.y_amax, 1);
+}
+
 // the LDS-DMA kernel addresses activations through 32-bit buffer offsets and marks padding with offsets >= 2^31
 static bool dma_ok(const ConvFwdArgs& a, const GemmP& p) {
   if (!dma_on() || a.x.C % 16 || a.Npad <= 32) return false;
@@ -2561,9 +2606,10 @@ void conv_fwd(Stream& s, const ConvFwdArgs& a) {
     check_launch("tail_fwd4");
     return;
   }
-  if (g_force_naive) { conv_fwd_naive(s, a); return; }
+  if (g_force_naive) { conv_fwd_naive(s, a); if (a.y_amax) fold_output_amax(s, a); return; }
   GemmP p = make_params(a.x, a.g, a.y, a.om, a.phases, a.batch);
   p.w = a.w; p.Npad = a.Npad; p.bias = a.bias; p.act = a.act; p.accumulate = a.accumulate; p.Cout = a.Cout;
+  p.y_amax = a.y_amax;
   if (a.Npad % 4 || a.Cout > a.Npad) throw Error(1, "conv_fwd: bad Npad/Cout");
   if (a.accumulate && a.act != ACT_NONE) throw Error(1, "conv_fwd: accumulate with activation");
   const bool fast = (a.x.C % 32) == 0;
@@ -2580,7 +2626,14 @@ void conv_fwd(Stream& s, const ConvFwdArgs& a) {
       const bool ph = a.phases != 0;
       if (pc_planes() == 2) {
         if (a.wpc_bn == 192) launch_fwd_pc<4, 6, 2, 2, 2>(s, p, nb, a.wpc, a.wpc_bs, ph, a.x_amax);
-        else if (a.Npad > 64) launch_fwd_pc<4, 4, 2, 4, 2>(s, p, nb, a.wpc, a.wpc_bs, ph, a.x_amax);
+        else if (a.Npad > 64) {
+          // 128 x 128: LDS stages x workgroups per CU.  2 x 4 (round 3: 64 KB in flight per CU), 3 x 3 (96 KB in flight, two stages of
+          // prefetch distance), 4 x 2.  SWN_PC_STAGES selects (A/B runs; read per launch)
+          const int stg = pc_stages();
+          if (stg == 3) launch_fwd_pc<4, 4, 3, 3, 2>(s, p, nb, a.wpc, a.wpc_bs, ph, a.x_amax);
+          else if (stg == 4) launch_fwd_pc<4, 4, 4, 2, 2>(s, p, nb, a.wpc, a.wpc_bs, ph, a.x_amax);
+          else launch_fwd_pc<4, 4, 2, 4, 2>(s, p, nb, a.wpc, a.wpc_bs, ph, a.x_amax);
+        }
         else launch_fwd_pc<8, 2, 3, 2, 2>(s, p, nb, a.wpc, a.wpc_bs, ph, a.x_amax);
         return;
       }
@@ -2591,6 +2644,7 @@ void conv_fwd(Stream& s, const ConvFwdArgs& a) {
     }
     if (!a.w) throw Error(1, "conv_fwd: the weight operand exists in pre-cut form only, but this launch cannot take the pre-cut "
                              "kernel (SWN_SPLIT / SWN_PRECUT / SWN_DMA must not change after a model is built)");
+    p.y_amax = nullptr;
     if (a.Npad > 64) {
       // 128 x 128 (4 waves, 3 workgroups / CU) unless the 128 x 256 tile (8 waves, 2 / CU: 512 slots instead of 768)
       // quantises the launch better: the resblock input gradient (M 800, N 1024 x 36 planes) is 2016 tiles = 2.6
@@ -2603,9 +2657,12 @@ void conv_fwd(Stream& s, const ConvFwdArgs& a) {
       else launch_fwd_dma<2, 2>(s, p, nb);
     }
     else launch_fwd_dma<4, 1>(s, p, nb);                 // 256 x 64
+    if (a.y_amax) fold_output_amax(s, a);
     return;
   }
   if (!a.w) throw Error(1, "conv_fwd: pre-cut-only weight operand on a launch outside the ring kernel's shapes");
+  p.y_amax = nullptr;
+  // every register-staged route: the amax of the output, if asked for, by a pass behind the launch
   if (t192 && a.Npad > 128 && a.Npad <= 192) launch_fwd<2, 3, 2, 2>(s, p, fast, nb);
   else if (a.Npad > 64 && big && fast && p.M >= 2048) launch_fwd<2, 2, 4, 2>(s, p, fast, nb);
   else if (a.Npad > 64) launch_fwd<2, 2, 2, 2>(s, p, fast, nb);
@@ -2617,6 +2674,7 @@ void conv_fwd(Stream& s, const ConvFwdArgs& a) {
   else if (a.Npad <= 20) launch_fwd_narrow<5>(s, p, fast, nb);
   else if (a.Npad <= 24) launch_fwd_narrow<6>(s, p, fast, nb);
   else launch_fwd_narrow<8>(s, p, fast, nb);
+  if (a.y_amax) fold_output_amax(s, a);
 }
 
 template <int MT, int NT, int WGM, int WGN, int NG = 0, bool ROWU = false>

@@ -166,6 +166,7 @@ Var Net::alloc_var(int N, int H, int W, int C, bool need_grad) {
   const size_t bytes = (size_t)N * H * W * C * sizeof(float);
   r.v.p = static_cast<float*>(ctx.alloc(bytes));
   r.v.N = N; r.v.H = H; r.v.W = W; r.v.C = C; r.v.cs = C;
+  r.vbase = r.v.p;
   r.has_grad = need_grad;
   if (need_grad) {
     r.g = r.v;
@@ -256,6 +257,7 @@ void Net::conv(const std::string& name, const Var& x, const Var& y, ConvKind kin
   if (head_on && kind == CK_K4S1 && Co == 1 && Cip % 32 == 0 && actf == ACT_NONE && x.has_grad == y.has_grad) {
     const size_t wt_off = reserve_dg(self, (size_t)Cip * 16), wt2_off = reserve_dg(self, (size_t)16 * Cip);
     const size_t dwt_off = reserve_dg(self, (size_t)Cip * 16);
+    note_writer(y.vbase, false);
     Var Z = alloc_var(xv.N, xv.H, xv.W, 16, false);          // Z forward, dZ backward (same scratch)
     const TView zv = Z.v, ygv = y.g, xgv = x.g;
     const bool has_grad = y.has_grad;
@@ -295,7 +297,9 @@ void Net::conv(const std::string& name, const Var& x, const Var& y, ConvKind kin
     return;
   }
   // k4 s2 convs with enough channels: strided Winograd F(4x4,2x2) (four polyphase 2x2 convolutions in one batched GEMM)
-  if (kind == CK_K4S2 && s2_wino && s2_wino_wanted(Cip, Cop, y.v.H, y.v.W) && Co % 4 == 0) {
+  // (never the layers that read a network input: their buffers carry layout pad channels -- 19 -> 32, 22 -> 32 -- that would
+  // be transformed for nothing, and the channel threshold of the test routing must not reach them through the padding)
+  if (kind == CK_K4S2 && s2_wino && !x_is_input && s2_wino_wanted(Cip, Cop, y.v.H, y.v.W) && Co % 4 == 0) {
     const int sP = 25, sTh = ceil_div(y.v.H, 4), sTw = ceil_div(y.v.W, 4), CV = 4 * Cip;
     const size_t sT = (size_t)x.v.N * sTh * sTw;
     const bool want_dx = x.has_grad && y.has_grad;
@@ -309,6 +313,7 @@ void Net::conv(const std::string& name, const Var& x, const Var& y, ConvKind kin
     const size_t pcf_bs = pcf ? conv_precut_elems(CV, Cop, pcf) : 0, pct_bs = pct ? conv_precut_elems(Cop, CV, pct) : 0;
     const size_t pcf_off = pcf ? reserve_dgp(pcf_bs * sP) : 0, pct_off = pct ? reserve_dgp(pct_bs * sP) : 0;
     const size_t slV = reserve_slot(), slD = reserve_slot();      // amax of V (forward planes) and of dM (transformed dY)
+    note_writer(y.vbase, false);
     // dM = A dY A^T serves the weight gradient (side stream) and the input gradient (main stream): one buffer per layer
     float* keepdM = (y.has_grad && want_dx && share_dy()) ? static_cast<float*>(ctx.alloc(sP * sT * Cop * sizeof(float))) : nullptr;
     op->repack = [=](Net& n) {
@@ -399,6 +404,7 @@ void Net::conv(const std::string& name, const Var& x, const Var& y, ConvKind kin
       const int pcu = conv_precut_tile(Cip, N4);
       const size_t pcu_bs = pcu ? conv_precut_elems(Cip, N4, pcu) : 0, pcu_off = pcu ? reserve_dgp(pcu_bs * tP) : 0;
       const size_t slV = reserve_slot(), slD = reserve_slot();
+      note_writer(y.vbase, false);
       // input gradient: the folded 5x5 stride-2 conv over dR (32-channel buffer, see CopD below)
       const bool want_dx = x.has_grad && y.has_grad;
       const int CopD = (actf != ACT_NONE && want_dx && conv_precut_tile(32, Cip) == 192) ? 32 : Cop;
@@ -434,10 +440,12 @@ void Net::conv(const std::string& name, const Var& x, const Var& y, ConvKind kin
       if (want_dx) op->grad_targets.push_back(x);
       const TView ygv = y.g, xgv = x.g, scr = CopD != Cop ? scratch.v.slice(0, Cop) : scratch.v, scr_full = scratch.v;
       const bool has_ygrad = y.has_grad;
+      const size_t scrSlot = (y.has_grad && actf != ACT_NONE) ? note_writer(scratch.v.p, true) : 0;
       op->bwd = [=](Net& n, Op& me, bool wgrad, bool igrad) {
         if (!has_ygrad) return;
         TView dY = ygv;
-        if (actf != ACT_NONE) { act_bwd(n.ctx.s, ygv, yv, scr, actf, 0); dY = scr; }
+        const float* dy_slot = nullptr;
+        if (actf != ACT_NONE) { act_bwd(n.ctx.s, ygv, yv, scr, actf, 0, n.amax + scrSlot); dY = scr; dy_slot = n.amax + scrSlot; }
         const ParamDesc& wd = A->params[wi];
         if (wgrad) {
           Stream& sw = n.wgrad_stream();
@@ -461,6 +469,7 @@ void Net::conv(const std::string& name, const Var& x, const Var& y, ConvKind kin
         d.x = CopD != Cop ? scr_full : dY;
         d.g.KH = d.g.KW = 5; d.g.stride = 2; d.g.pad_t = d.g.pad_l = 1; d.g.Ho = xv.H; d.g.Wo = xv.W;
         d.w = n.dg + dg_off; d.Npad = Cip; d.Cout = Cip; d.y = xgv; d.accumulate = me.acc.empty() ? 0 : me.acc[0];
+        d.x_amax = dy_slot;
         if (pc_d) { d.wpc = n.dgp + pcd_off; d.wpc_bn = pc_d; d.wpc_bs = pcd_bs; }
         conv_fwd(n.ctx.s, d);
       };
@@ -539,10 +548,18 @@ void Net::conv(const std::string& name, const Var& x, const Var& y, ConvKind kin
   const int Kf = KH * KH * Cip;
   const int pc_f = (!wino && !folded) ? conv_precut_tile(Cip, arena.params[wi].ws.Npad) : 0;
   const size_t pcf_off = pc_f ? reserve_dgp(conv_precut_elems(Kf, arena.params[wi].ws.Npad, pc_f)) : 0;
+  // amax slot of the output buffer: a direct conv with a fused activation feeds the next GEMM without a normalisation in
+  // between (UNetDown without InstanceNorm, PatchGAN model.0), so it folds its output's amax (in the ring kernel's epilogue, else
+  // by a pass: ops.h ConvFwdArgs::y_amax); everything else here is followed by a norm_act, which folds for its own output
+  const bool y_folds = !wino && !folded && actf != ACT_NONE && actf != ACT_TANH;
+  const size_t ySlot = note_writer(y.vbase, y_folds);
+  const float* xbase = x.vbase;
   op->fwd = [=](Net& n) {
     const ParamDesc& wd = A->params[wi];
     ConvFwdArgs a;
     a.x = xv; a.g = gf; a.w = A->w + wd.off; a.Npad = wd.ws.Npad;
+    a.x_amax = n.slot_if_complete(xbase);
+    if (y_folds) a.y_amax = n.amax + ySlot;
     if (pc_f) { n.need(self); a.wpc = n.dgp + pcf_off; a.wpc_bn = pc_f; }
     a.bias = bi >= 0 ? A->w + A->params[bi].off : nullptr;
     a.act = actf; a.y = yv; a.Cout = Co;
@@ -563,6 +580,7 @@ void Net::conv(const std::string& name, const Var& x, const Var& y, ConvKind kin
     }
     if (!folded) { conv_fwd(n.ctx.s, a); return; }
     n.need(self);                            // folded weights are derived operands too
+    a.x_amax = nullptr;
     a.g = Gather(); a.g.KH = a.g.KW = 3; a.g.stride = 1; a.g.pad_t = a.g.pad_l = 1; a.g.Ho = xv.H; a.g.Wo = xv.W;
     a.om.ymul = a.om.xmul = 2; a.tail4 = 1;
     a.w = n.dg + fold_off;
@@ -649,10 +667,16 @@ void Net::conv(const std::string& name, const Var& x, const Var& y, ConvKind kin
   const int pcd_k = pc_d; const size_t pcd_o = pcd_off, pcd_bs = pc_d ? conv_precut_elems(dKp, Ndg, pc_d) : 0;
   const TView ygv = y.g, xgv = x.g, scr = CopD != Cop ? scratch.v.slice(0, Cop) : scratch.v, scr_full = scratch.v, dxp = dxpad.v;
   const bool has_ygrad = y.has_grad;
+  // dY as a GEMM operand: dR from act_bwd (which folds its amax into the scratch buffer's slot) or y.g itself, whose slot --
+  // if it has one -- the norm_act behind this conv fills in its backward
+  const size_t scrSlot = (y.has_grad && actf != ACT_NONE) ? note_writer(scratch.v.p, true) : 0;
+  const float* ygbase = y.gbase;
   op->bwd = [=](Net& n, Op& me, bool wgrad, bool igrad) {
     if (!has_ygrad) return;
     TView dY = ygv;
-    if (actf != ACT_NONE) { act_bwd(n.ctx.s, ygv, yv, scr, actf, 0); dY = scr; }
+    const float* dy_slot = nullptr;
+    if (actf != ACT_NONE) { act_bwd(n.ctx.s, ygv, yv, scr, actf, 0, n.amax + scrSlot); dY = scr; dy_slot = n.amax + scrSlot; }
+    else dy_slot = n.slot_if_complete(ygbase);
     const ParamDesc& wd = A->params[wi];
     const bool dx_now = want_dx && !(me.reads_net_input && !igrad);
     // adjoint-form layers: the weight gradient and the input gradient multiply by the same dM planes -- transformed once, on the
@@ -663,6 +687,7 @@ void Net::conv(const std::string& name, const Var& x, const Var& y, ConvKind kin
       Stream& sw = n.wgrad_stream();          // dY is final: the weight-gradient work may run beside the dgrad chain
       ConvWgradArgs wa;
       wa.x = xv; wa.g = gf; wa.dy = dY; wa.dw = A->g + wd.off; wa.Npad = wd.ws.Npad; wa.Cout = Co;
+      wa.x_amax = n.slot_if_complete(xbase); wa.dy_amax = dy_slot;
       if (wino) {
         // dU[t] = V[t]^T dM[t] (wP batched reductions over the tiles), then dW = G^T dU G
         float* V = keepV ? keepV : n.wsV;
@@ -680,6 +705,7 @@ void Net::conv(const std::string& name, const Var& x, const Var& y, ConvKind kin
       } else if (!folded) {
         conv_wgrad(sw, wa);
       } else {
+        wa.x_amax = wa.dy_amax = nullptr;
         wa.g = Gather(); wa.g.KH = wa.g.KW = 3; wa.g.stride = 1; wa.g.pad_t = wa.g.pad_l = 1; wa.g.Ho = xv.H; wa.g.Wo = xv.W;
         wa.om.ymul = wa.om.xmul = 2; wa.tail4 = 1;
         wa.dw = n.dg + dfold_off;
@@ -732,11 +758,13 @@ void Net::conv(const std::string& name, const Var& x, const Var& y, ConvKind kin
       d.g.Ho = dY.H; d.g.Wo = dY.W;
       d.w = n.dg + dg_off; d.w_bs = (size_t)4 * Cop * Ndg; d.Npad = Ndg;
       d.y = xgv; d.om.ymul = 2; d.om.xmul = 2; d.phases = 4; d.Cout = Ndg; d.accumulate = accf;
+      d.x_amax = dy_slot;
       if (pcd_k) { d.wpc = n.dgp + pcd_o; d.wpc_bn = pcd_k; d.wpc_bs = pcd_bs; }
       conv_fwd(n.ctx.s, d);
     } else {
       ConvFwdArgs d;
       d.x = CopD != Cop ? scr_full : dY; d.g = gd; d.w = n.dg + dg_off; d.Npad = Ndg; d.Cout = Ndg;
+      d.x_amax = dy_slot;
       if (pcd_k) { d.wpc = n.dgp + pcd_o; d.wpc_bn = pcd_k; d.wpc_bs = pcd_bs; }
       if (kind == CK_K3S1_REFLECT) {
         d.y = dxp; d.accumulate = 0;
@@ -764,6 +792,8 @@ void Net::convT(const std::string& name, const Var& x, const Var& y, int Co, boo
   op->param_off = arena.params[wi].off;
   ParamArena* A = &arena;
   const TView xv = x.v, yv = y.v, ygv = y.g, xgv = x.g;
+  note_writer(y.vbase, false);        // (raw output: always followed by an InstanceNorm, never a GEMM operand itself)
+  const float* xbase = x.vbase; const float* ygbase = y.gbase;
   // enough channels: strided Winograd F(4x4,2x2) -- the transposed conv is the ADJOINT of a k4 s2 conv fine -> coarse, so its
   // forward is the coarse -> fine pipeline (dM = A x A^T, dV = dM U^T, adjoint polyphase transform) and its input gradient the
   // fine -> coarse one
@@ -860,6 +890,7 @@ void Net::convT(const std::string& name, const Var& x, const Var& y, int Co, boo
     if (pc_f) { n.need(self); f.wpc = n.dgp + pcf_off; f.wpc_bn = pc_f; f.wpc_bs = pcf_bs; }
     f.x = xv; f.g.KH = f.g.KW = 2; f.g.stride = 1; f.g.pad_t = 1; f.g.pad_l = 1; f.g.Ho = xv.H; f.g.Wo = xv.W;
     f.w = A->w + wd.off; f.w_bs = phase_elems; f.Npad = wd.ws.Npad;
+    f.x_amax = n.slot_if_complete(xbase);
     f.bias = bi >= 0 ? A->w + A->params[bi].off : nullptr;
     f.y = yv; f.om.ymul = 2; f.om.xmul = 2; f.phases = 4; f.Cout = Co;
     conv_fwd(n.ctx.s, f);
@@ -891,6 +922,7 @@ void Net::convT(const std::string& name, const Var& x, const Var& y, int Co, boo
       wa.g.Ho = xv.H; wa.g.Wo = xv.W;
       wa.dy = ygv; wa.om.ymul = 2; wa.om.xmul = 2; wa.phases = 4;
       wa.dw = A->g + wd.off; wa.dw_bs = phase_elems; wa.Npad = wd.ws.Npad; wa.Cout = Co;
+      wa.x_amax = n.slot_if_complete(xbase); wa.dy_amax = n.slot_if_complete(ygbase);
       Stream& sw = n.wgrad_stream();
       conv_wgrad(sw, wa);
       if (bi >= 0) n.bias_grad_of(sw, ygv, A->g + A->params[bi].off);
@@ -899,6 +931,7 @@ void Net::convT(const std::string& name, const Var& x, const Var& y, int Co, boo
     ConvFwdArgs d;
     d.x = ygv; d.g.KH = d.g.KW = 4; d.g.stride = 2; d.g.pad_t = d.g.pad_l = 1; d.g.Ho = xv.H; d.g.Wo = xv.W;
     d.w = n.dg + dg_off; d.Npad = Cip; d.Cout = Cip; d.y = xgv; d.accumulate = me.acc.empty() ? 0 : me.acc[0];
+    d.x_amax = n.slot_if_complete(ygbase);
     if (pc_d) { d.wpc = n.dgp + pcd_off; d.wpc_bn = pc_d; }
     conv_fwd(n.ctx.s, d);
   };
@@ -916,6 +949,8 @@ void Net::norm_act(const Var& raw, const Var& y, bool norm, int actf, float drop
   if (residual && actf != ACT_NONE) throw Error(1, "norm_act: an activation in front of a residual add is not supported");
   note_act(actf, y.v);        // a dropped element reads 0: its gradient is 0 whichever side the pattern records
   const TView rv = raw.v, rg = raw.g, yv = y.v, yg = y.g;
+  const size_t ySlot = note_writer(y.vbase, true);
+  const size_t gSlot = (y.has_grad && raw.has_grad) ? note_writer(raw.gbase, true) : 0;
   const bool has_res = residual != nullptr;
   const Var res = has_res ? *residual : Var();
   op->fwd = [=](Net& n) {
@@ -923,6 +958,7 @@ void Net::norm_act(const Var& raw, const Var& y, bool norm, int actf, float drop
     a.x = rv; a.y = yv; a.stats = stats; a.norm = norm; a.act = actf;
     a.drop_p = n.training ? drop_p : 0.f; a.seed = Net::drop_seed(n.seed, salt);
     a.residual = has_res ? &res.v : nullptr;
+    a.amax_out = n.amax + ySlot;
     norm_act_fwd(n.ctx.s, a);
   };
   if (has_res && res.has_grad && y.has_grad) op->grad_targets.push_back(res);
@@ -938,6 +974,7 @@ void Net::norm_act(const Var& raw, const Var& y, bool norm, int actf, float drop
     NormActBwdArgs b;
     b.dy = yg; b.x = rv; b.stats = stats; b.dx = rg; b.norm = norm; b.act = actf; b.colsum = colsum;
     b.drop_p = n.training ? drop_p : 0.f; b.seed = Net::drop_seed(n.seed, salt);
+    b.amax_out = n.amax + gSlot;
     norm_act_bwd(n.ctx.s, b);
   };
   ops.push_back(std::move(op));
@@ -946,6 +983,7 @@ void Net::norm_act(const Var& raw, const Var& y, bool norm, int actf, float drop
 void Net::act(const Var& x, const Var& y, int actf) {
   auto op = std::make_unique<Op>();
   op->label = "act";
+  note_writer(y.vbase, false);
   note_act(actf, y.v);
   const TView xv = x.v, yv = y.v, xg = x.g, yg = y.g;
   op->fwd = [=](Net& n) { act_fwd(n.ctx.s, xv, yv, actf); };
@@ -960,6 +998,7 @@ void Net::act(const Var& x, const Var& y, int actf) {
 void Net::affine(const Var& x, const Var& y, float alpha, float shift) {
   auto op = std::make_unique<Op>();
   op->label = "affine";
+  note_writer(y.vbase, false);
   const TView xv = x.v, yv = y.v, xg = x.g, yg = y.g;
   op->fwd = [=](Net& n) { axpy(n.ctx.s, xv, yv, alpha, 0, shift); };
   const bool do_bwd = x.has_grad && y.has_grad;
@@ -973,6 +1012,7 @@ void Net::affine(const Var& x, const Var& y, float alpha, float shift) {
 void Net::upsample(const Var& x, const Var& y, int f) {
   auto op = std::make_unique<Op>();
   op->label = "upsample";
+  note_writer(y.vbase, false);
   const TView xv = x.v, yv = y.v, xg = x.g, yg = y.g;
   op->fwd = [=](Net& n) { upsample_nearest_fwd(n.ctx.s, xv, yv, f); };
   const bool do_bwd = x.has_grad && y.has_grad;
@@ -986,6 +1026,7 @@ void Net::upsample(const Var& x, const Var& y, int f) {
 void Net::maxpool(const Var& x, const Var& y) {
   auto op = std::make_unique<Op>();
   op->label = "maxpool";
+  note_writer(y.vbase, false);
   act_sites.push_back({2, y.v, x.v});
   const TView xv = x.v, yv = y.v, xg = x.g, yg = y.g;
   op->fwd = [=](Net& n) { maxpool2_fwd(n.ctx.s, xv, yv); };

@@ -61,6 +61,7 @@ struct AllocScope {              // RAII: allocations made while it lives go to 
 // (identifies the buffer for the accumulate planner).
 struct Var {
   TView v, g;
+  float* vbase = nullptr;      // start of the value allocation (identifies the buffer for the amax-slot registry)
   float* gbase = nullptr;
   bool has_grad = false;
   Var slice(int c0, int c) const;
@@ -137,6 +138,28 @@ class Net {
   float* amax = nullptr;
   size_t amax_n = 0;
   size_t reserve_slot() { const size_t off = amax_n; amax_n += AMAX_SLOT; return off; }
+  // Registry of the amax slots of whole BUFFERS (activations, keyed by Var::vbase; gradients, by the pointer the backward
+  // kernel writes): every op that writes into a buffer announces itself with note_writer(base, folds), folds = it leaves max |v|
+  // of everything it writes in the buffer's slot.  A consumer may take its operand's scale from the slot only if EVERY writer
+  // folds (slot_if_complete, asked at run time); the slot of a concatenation buffer then bounds each of its slices.  Buffers
+  // filled from outside the tape (network inputs) get an external slot from the model (set_external_slot), valid across steps.
+  struct BufSlot { size_t off = 0; bool complete = true; };
+  std::map<const float*, BufSlot> buf_slots;
+  std::map<const float*, const float*> ext_slots;
+  size_t note_writer(const float* base, bool folds) {
+    auto it = buf_slots.find(base);
+    if (it == buf_slots.end()) it = buf_slots.emplace(base, BufSlot{reserve_slot(), true}).first;
+    if (!folds) it->second.complete = false;
+    return it->second.off;
+  }
+  void set_external_slot(const float* base, const float* slot) { ext_slots[base] = slot; }
+  const float* slot_if_complete(const float* base) const {
+    auto e = ext_slots.find(base);
+    auto it = buf_slots.find(base);
+    if (e != ext_slots.end()) return (it == buf_slots.end()) ? e->second : nullptr;    // (also written on the tape: no single slot)
+    if (it == buf_slots.end() || !it->second.complete || !amax) return nullptr;
+    return amax + it->second.off;
+  }
   // per-layer buffers for the transformed output gradient when a layer's weight gradient (side stream) and input gradient (main
   // stream) multiply by the SAME planes: transformed once on the main stream, read by both (engine.cpp shared_dy)
   bool share_dy() const;

@@ -43,6 +43,37 @@ __device__ __forceinline__ float act_grad_from_out(float y, int act) {
   }
 }
 
+// ---- amax slots (ops.h ConvFwdArgs::x_amax): a producer folds max |v| over what it writes into one entry of the slot --
+// an atomic max on the bit pattern (non-negative floats order like unsigned integers: exact and order-independent, so the
+// result is deterministic), skipped when the entry already holds as much.  NaN (sign bit cleared by fabsf) orders above
+// every finite value: a NaN anywhere makes the slot NaN, which the consumers treat as "no scale".
+__device__ __forceinline__ float f4amax(const float4& v) { return fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))); }
+__device__ __forceinline__ void amax_store(float m, float* amax_out, unsigned entry) {
+  unsigned* dst = reinterpret_cast<unsigned*>(amax_out) + (entry % AMAX_SLOT);
+  const unsigned bits = __float_as_uint(m);
+  if (bits > __hip_atomic_load(dst, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(dst, bits);
+}
+// one atomic per wave (no barrier: usable where lanes have left the kernel, as long as the calling wave is converged)
+__device__ __forceinline__ void amax_fold_wave(float am, float* amax_out, unsigned entry) {
+#pragma unroll
+  for (int o = 32; o; o >>= 1) am = fmaxf(am, __shfl_xor(am, o));
+  if ((threadIdx.x & 63) == 0) amax_store(am, amax_out, entry);
+}
+// one atomic per block: ALL threads of a 1-D block of at most 1024 threads must call it
+__device__ __forceinline__ void amax_fold(float am, float* amax_out) {
+  if (!amax_out) return;                       // (uniform over the grid)
+  __shared__ float amax_red[16];
+#pragma unroll
+  for (int o = 32; o; o >>= 1) am = fmaxf(am, __shfl_xor(am, o));
+  if ((threadIdx.x & 63) == 0) amax_red[threadIdx.x >> 6] = am;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float m = amax_red[0];
+    for (int w = 1; w < (int)((blockDim.x + 63) >> 6); ++w) m = fmaxf(m, amax_red[w]);
+    amax_store(m, amax_out, blockIdx.x + blockIdx.y * gridDim.x);
+  }
+}
+
 // counter-based dropout stream: keep decision for element `idx` of the call with `seed`
 __device__ __forceinline__ uint32_t mix64(uint64_t z) {
   z += 0x9E3779B97F4A7C15ull;

@@ -1,5 +1,6 @@
 // swapnet_amd -- network builders and the warp-stage model.
 #include <cmath>
+#include <cstdlib>
 
 #include "engine.h"
 
@@ -152,42 +153,71 @@ static void gan_loss_op(Stream& s, int mode, const TView& pred, float label, boo
 // fakes, [B,2B) conditioned targets -- the two D passes of backward_D run as one 2B batch
 // (InstanceNorm is per-sample, so batching is exact).
 // ---------------------------------------------------------------------------------------
+// First-layer buffers on the ring kernel (round 4).  The convs that read network inputs (cloth_down1: 19 -> 64, PatchGAN model.0:
+// 22 -> 64) ran on the register-staged f32-MFMA kernels because the LDS-DMA ring kernels walk the channels of a tap in 16-channel
+// stages; their NHWC input buffers are now allocated with the channel count rounded up to a multiple of 16 where that costs at
+// most 2x the channels (20 -> 32, 24 -> 32; the 3-channel body stays at 4: 16 would be 4x the work of a layer that is small
+// anyway).  Pad channels hold zeros (allocation zero-fills, nothing writes them) and meet zero weight rows.  SWN_FIRST_RING=0
+// keeps the round-3 layout (read when a model is built).
+static int ring_pad(int Cp) {
+  static const bool on = !(getenv("SWN_FIRST_RING") && atoi(getenv("SWN_FIRST_RING")) == 0);
+  const int r = round_up(Cp, 16);
+  return (on && r <= 2 * Cp) ? r : Cp;
+}
+
 class WarpModel final : public Model {
  public:
   Var body, cloth, Dx, pred2, pred1;
   float dropout = 0.5f;
   int Cb = 3, Cc = 19, Cbp = 4, Ccp = 20;      // logical / padded channel counts of the body and cloth representations
+  int CbB = 4, CcB = 20, CdB = 24;             // buffer channels of the body, cloth and conditional-D inputs (ring_pad)
+  // amax slots of the buffers filled from outside the tape (engine.h ext_slots): taken when an input is handed over.  The
+  // conditional-D buffer also receives the generator's tanh output each step: its slot is floored at 1 = sup |tanh|.
+  float *slot_body = nullptr, *slot_cloth = nullptr, *slot_dx = nullptr;
 
   WarpModel(Ctx& c, int B_, int H_, int W_, bool train, float drop, int body_channels, int cloth_channels) {
     ctx = &c; B = B_; H = H_; W = W_; is_train = train; dropout = drop;
     Cb = body_channels; Cc = cloth_channels; Cbp = round_up(Cb, 4); Ccp = round_up(Cc, 4);
     if (Cb < 1 || Cc < 2 || Cb > 64 || Cc > 64) throw Error(1, "WarpModel: body_channels in [1,64], cloth_channels in [2,64]");
+    CbB = ring_pad(Cbp); CcB = ring_pad(Ccp); CdB = ring_pad(Ccp + Cbp);
     AllocScope mine(c, owned_allocs);
     G = std::make_unique<Net>(c, arenaG);
     G->keep_wino_inputs = train;
-    body = G->alloc_var(B, H, W, Cbp, false);
-    cloth = G->alloc_var(B, H, W, Ccp, false);
-    Dx = G->alloc_var(train ? 2 * B : B, H, W, Ccp + Cbp, train);
+    body = G->alloc_var(B, H, W, CbB, false);
+    cloth = G->alloc_var(B, H, W, CcB, false);
+    Dx = G->alloc_var(train ? 2 * B : B, H, W, CdB, train);
+    float* slots = static_cast<float*>(c.alloc(3 * AMAX_SLOT * sizeof(float)));
+    slot_body = slots; slot_cloth = slots + AMAX_SLOT; slot_dx = slots + 2 * AMAX_SLOT;
+    G->set_external_slot(body.vbase, slot_body);
+    G->set_external_slot(cloth.vbase, slot_cloth);
     Var fake_slot = Dx.batch(0, B).slice(0, Ccp);
     build_warp_generator(*G, body, cloth, fake_slot, dropout, Cb, Cc);
     arenaG.allocate(c);
     G->finalize({fake_slot});
     losses = static_cast<float*>(c.alloc(L_COUNT * sizeof(float)));
     if (train) {
-      std::vector<int32_t> cimap(Ccp + Cbp, -1);
+      std::vector<int32_t> cimap(CdB, -1);
       for (int i = 0; i < Cc; ++i) cimap[i] = Cb + i;     // cloth channels follow the body channels (warp_model.py:115)
       for (int i = 0; i < Cb; ++i) cimap[Ccp + i] = i;
       d_cimap_ = cimap; d_layers_ = c.patchgan_layers;
       D2 = std::make_unique<Net>(c, arenaD);
       D2->keep_wino_inputs = true;
+      D2->set_external_slot(Dx.vbase, slot_dx);
       pred2 = build_patchgan(*D2, Dx, c.patchgan_layers, cimap);
       arenaD.allocate(c);
       D2->finalize({pred2});
       // second instance over the first B images, bound to the same (now frozen) arena
       D1 = std::make_unique<Net>(c, arenaD);
+      D1->set_external_slot(Dx.vbase, slot_dx);
       pred1 = build_patchgan(*D1, Dx.batch(0, B), c.patchgan_layers, cimap);
       D1->finalize({pred1});
     }
+  }
+  void refresh_input_slots(int slot) {
+    Stream& s = ctx->s;
+    if (slot == 0) tensor_amax(s, body.v, slot_body);
+    if (slot == 1) tensor_amax(s, cloth.v, slot_cloth);
+    if (slot != 1) tensor_amax(s, Dx.v, slot_dx, 1.0f);       // bodys and targets live in it; the fakes are bounded by 1
   }
   void set_input(int slot, const float* src, int N, int C, int Hh, int Ww) override {
     if (N != B || Hh != H || Ww != W) throw Error(1, "set_input: shape mismatch with the model's (B,H,W)");
@@ -207,12 +237,14 @@ class WarpModel final : public Model {
     } else {
       throw Error(1, "set_input: unknown slot");
     }
+    refresh_input_slots(slot);
   }
   void set_input_labels(int slot, const int32_t* lab, int N, int Hh, int Ww) override {
     if (N != B || Hh != H || Ww != W) throw Error(1, "set_input_labels: shape mismatch with the model's (B,H,W)");
     if (slot == 1) labels_to_onehot(ctx->s, lab, cloth.v, Cc);
     else if (slot == 2 && is_train) labels_to_onehot(ctx->s, lab, Dx.batch(B, B).v.slice(0, Ccp), Cc);
     else throw Error(1, "set_input_labels: slot has no label form");
+    refresh_input_slots(slot);
   }
   void get_output(int slot, float* dst) override {
     if (slot != 0) throw Error(1, "get_output: unknown slot");

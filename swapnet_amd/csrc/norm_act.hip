@@ -34,6 +34,7 @@ struct NAp {
   int N, HW, C, nchunk, chunk;
   int norm, act;
   float drop_p; uint64_t seed;
+  float* amax_out;              // optional amax slot of what the apply kernels write (fwd: y, bwd: dx)
 };
 
 // partial sums over a pixel chunk: mode 0 -> (sum x, sum x^2); mode 1 -> (sum dxh, sum dxh*xh)
@@ -113,6 +114,7 @@ __global__ void in_finalize_kernel(NAp p) {
 __global__ __launch_bounds__(256) void norm_act_apply_kernel(NAp p) {
   const int C4 = p.C >> 2;
   const size_t total = (size_t)p.N * p.HW * C4;
+  float am = 0.f;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
     const size_t e = i / C4;
     const int c = (int)(i - e * C4) * 4;
@@ -134,13 +136,17 @@ __global__ __launch_bounds__(256) void norm_act_apply_kernel(NAp p) {
       const float4 r = *reinterpret_cast<const float4*>(p.res + e * p.rescs + c);
       v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w;
     }
-    *reinterpret_cast<float4*>(p.y + e * p.ycs + c) = make_float4(v[0], v[1], v[2], v[3]);
+    const float4 o4 = make_float4(v[0], v[1], v[2], v[3]);
+    *reinterpret_cast<float4*>(p.y + e * p.ycs + c) = o4;
+    am = fmaxf(am, f4amax(o4));
   }
+  amax_fold(am, p.amax_out);
 }
 
 __global__ __launch_bounds__(256) void norm_act_bwd_apply_kernel(NAp p) {
   const int C4 = p.C >> 2;
   const size_t total = (size_t)p.N * p.HW * C4;
+  float am = 0.f;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
     const size_t e = i / C4;
     const int c = (int)(i - e * C4) * 4;
@@ -167,8 +173,11 @@ __global__ __launch_bounds__(256) void norm_act_bwd_apply_kernel(NAp p) {
       // double -- the kernel is HBM-bound (20 B per element), the handful of fp64 operations is free
       o[j] = p.norm ? (float)((double)rstd * ((double)g - m1 - (((double)xa[j] - (double)mean) * (double)rstd) * m2)) : g;
     }
-    *reinterpret_cast<float4*>(p.y + e * p.ycs + c) = make_float4(o[0], o[1], o[2], o[3]);
+    const float4 o4 = make_float4(o[0], o[1], o[2], o[3]);
+    *reinterpret_cast<float4*>(p.y + e * p.ycs + c) = o4;
+    am = fmaxf(am, f4amax(o4));
   }
+  amax_fold(am, p.amax_out);
 }
 
 // ---- second-order step through act(IN(x)) -- ops.h norm_act_bwd2 ------------------------------------------------
@@ -306,6 +315,7 @@ __global__ __launch_bounds__(256) void in_fused_fwd_kernel(NAp p) {
     *reinterpret_cast<float4*>(st) = make_float4(mean[0], rstd[0], mean[1], rstd[1]);
     *reinterpret_cast<float4*>(st + 4) = make_float4(mean[2], rstd[2], mean[3], rstd[3]);
   }
+  float am = 0.f;
 #pragma unroll
   for (int i = 0; i < NP; ++i) {
     const int pix = ty + i * ROWS;
@@ -321,8 +331,11 @@ __global__ __launch_bounds__(256) void in_fused_fwd_kernel(NAp p) {
       const float4 r = *reinterpret_cast<const float4*>(p.res + e * p.rescs + c);
       o[0] += r.x; o[1] += r.y; o[2] += r.z; o[3] += r.w;
     }
-    *reinterpret_cast<float4*>(p.y + e * p.ycs + c) = make_float4(o[0], o[1], o[2], o[3]);
+    const float4 o4 = make_float4(o[0], o[1], o[2], o[3]);
+    *reinterpret_cast<float4*>(p.y + e * p.ycs + c) = o4;
+    am = fmaxf(am, f4amax(o4));
   }
+  amax_fold(am, p.amax_out);
 }
 
 template <int CG, int NP>
@@ -369,6 +382,7 @@ __global__ __launch_bounds__(256) void in_fused_bwd_kernel(NAp p) {
 #pragma unroll
   for (int j = 0; j < 4; ++j) { m1[j] = s[j] / p.HW; m2[j] = s[4 + j] / p.HW; }
   double cs[4] = {0, 0, 0, 0};
+  float am = 0.f;
 #pragma unroll
   for (int i = 0; i < NP; ++i) {
     const int pix = ty + i * ROWS;
@@ -382,8 +396,11 @@ __global__ __launch_bounds__(256) void in_fused_bwd_kernel(NAp p) {
       o[j] = (float)((double)rstd[j] * ((double)g[j] - m1[j] - (((double)xa[j] - (double)mean[j]) * (double)rstd[j]) * m2[j]));
       cs[j] += o[j];
     }
-    *reinterpret_cast<float4*>(p.y + e * p.ycs + c) = make_float4(o[0], o[1], o[2], o[3]);
+    const float4 o4 = make_float4(o[0], o[1], o[2], o[3]);
+    *reinterpret_cast<float4*>(p.y + e * p.ycs + c) = o4;
+    am = fmaxf(am, f4amax(o4));
   }
+  amax_fold(am, p.amax_out);
   if (p.colsum) {                      // (block-uniform) bias gradient of the producing conv: sum of dx over this image's pixels
     block_tree_sum<ROWS, 4>(red, cs, tx, ty, C4);
     if (ty == 0) {
@@ -404,6 +421,7 @@ struct EWp {
   float* o; int ocs;
   size_t pixels; int C;
   int act; int accumulate; float alpha; float shift;
+  float* amax_out;              // optional amax slot of what is written
 };
 
 // MODE 0: o = act(a);  1: o (+)= a * act'(.) expressed through b = the activation OUTPUT;  2: o (+)= alpha*a
@@ -411,6 +429,7 @@ template <int MODE>
 __global__ __launch_bounds__(256) void ew_kernel(EWp p) {
   const int C4 = p.C >> 2;
   const size_t total = p.pixels * C4;
+  float am = 0.f;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
     const size_t e = i / C4;
     const int c = (int)(i - e * C4) * 4;
@@ -432,8 +451,11 @@ __global__ __launch_bounds__(256) void ew_kernel(EWp p) {
       const float4 d = *reinterpret_cast<const float4*>(dst);
       v[0] += d.x; v[1] += d.y; v[2] += d.z; v[3] += d.w;
     }
-    *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+    const float4 o4 = make_float4(v[0], v[1], v[2], v[3]);
+    *reinterpret_cast<float4*>(dst) = o4;
+    am = fmaxf(am, f4amax(o4));
   }
+  amax_fold(am, p.amax_out);
 }
 
 // column sums of dy (bias gradient): stage 1 per pixel-chunk partials (fp64), stage 2 sum
@@ -550,6 +572,7 @@ void norm_act_fwd(Stream& s, const NormActArgs& a) {
   p.res = a.residual ? a.residual->p : nullptr; p.rescs = a.residual ? a.residual->cs : 0;
   p.stats = a.stats; p.N = a.x.N; p.HW = a.x.H * a.x.W; p.C = a.x.C;
   p.norm = a.norm; p.act = a.act; p.drop_p = a.drop_p; p.seed = a.seed;
+  p.amax_out = a.amax_out;
   if (a.norm && !a.stats) throw Error(1, "norm_act_fwd: stats buffer required");
   if (a.norm && p.HW <= 1024 && p.C % 32 == 0 && fused_in_on()) {
     const dim3 grid(p.C / 32, p.N);
@@ -580,6 +603,7 @@ void norm_act_bwd(Stream& s, const NormActBwdArgs& a) {
   p.stats = const_cast<float*>(a.stats); p.N = a.x.N; p.HW = a.x.H * a.x.W; p.C = a.x.C;
   p.norm = a.norm; p.act = a.act; p.drop_p = a.drop_p; p.seed = a.seed;
   p.colsum = a.colsum;
+  p.amax_out = a.amax_out;
   if (a.colsum && !(a.norm && norm_act_bwd_emits_colsum(p.HW, p.C))) throw Error(1, "norm_act_bwd: colsum requested on the chunked path");
   if (a.norm && p.HW <= 1024 && p.C % 32 == 0 && fused_in_on()) {
     if (p.HW <= 64) hipLaunchKernelGGL((in_fused_bwd_kernel<32, 2>), dim3(p.C / 32, p.N), dim3(256), 0, hs(s), p);
@@ -648,8 +672,8 @@ void act_fwd(Stream& s, const TView& x, const TView& y, int act) {
   hipLaunchKernelGGL(ew_kernel<0>, dim3(ew_grid(p.pixels * (p.C / 4))), dim3(256), 0, hs(s), p);
   check_launch("act_fwd");
 }
-void act_bwd(Stream& s, const TView& dy, const TView& y, const TView& dx, int act, int accumulate) {
-  EWp p = ew_params(dy, &y, dx); p.act = act; p.accumulate = accumulate;
+void act_bwd(Stream& s, const TView& dy, const TView& y, const TView& dx, int act, int accumulate, float* amax_out) {
+  EWp p = ew_params(dy, &y, dx); p.act = act; p.accumulate = accumulate; p.amax_out = amax_out;
   hipLaunchKernelGGL(ew_kernel<1>, dim3(ew_grid(p.pixels * (p.C / 4))), dim3(256), 0, hs(s), p);
   check_launch("act_bwd");
 }

@@ -98,8 +98,14 @@ struct ConvFwdArgs {
   // gathers).  The two-plane kernels scale the operand by a power of two from it; without a slot the launch takes the amax itself
   // with a pass over x.  Producers that write the operand fill the slot for free (amax_out of the transforms below).
   const float* x_amax = nullptr;
+  // optional: an amax slot the launch folds max |y| of everything it stores into -- in the epilogue of the pre-cut ring kernel
+  // (and the reduce kernel of its split tiles), by a pass over the output view behind every other kernel family
+  float* y_amax = nullptr;
 };
 constexpr int AMAX_SLOT = 256;
+// 256 partial maxima of |x| over a view into `slot` (overwrites all AMAX_SLOT entries): the amax of a tensor no kernel of ours
+// produced (network inputs)
+void tensor_amax(Stream& s, const TView& x, float* slot, float floor = 0.f);
 void conv_fwd(Stream& s, const ConvFwdArgs& a);
 // Pre-cut weight operand of the LDS-DMA ring kernel (conv_gemm.hip conv_fwd_pc_kernel): x = hi + mid + lo, three bf16 planes by
 // truncation (exact), laid out in MFMA operand order per 16-k stage and column tile.  conv_precut_tile: the column tile (64 /
@@ -199,6 +205,7 @@ struct NormActArgs {
   float drop_p = 0.f;         // 0 => no dropout
   uint64_t seed = 0;          // dropout stream for this call (ignored if drop_p==0)
   const TView* residual = nullptr;   // y = ... + residual
+  float* amax_out = nullptr;  // optional amax slot of y (see wino_input_transform)
 };
 void norm_act_fwd(Stream& s, const NormActArgs& a);
 
@@ -214,6 +221,7 @@ struct NormActBwdArgs {
   // optional [N][C] (fp64): per-image column sums of dx -- the bias gradient of the conv that produced x, for free while the
   // slab is in registers.  Written only by launches for which norm_act_bwd_emits_colsum(H * W, C) holds.
   double* colsum = nullptr;
+  float* amax_out = nullptr;  // optional amax slot of dx
 };
 void norm_act_bwd(Stream& s, const NormActBwdArgs& a);
 bool norm_act_bwd_emits_colsum(int HW, int C);
@@ -238,7 +246,7 @@ void pool_pattern(Stream& s, const TView& x, const TView& y, uint8_t* out_nchw);
 // y = act(x) elementwise on views; bwd: dx (+)= dy * act'  (derivative expressed through the
 // activation OUTPUT y: lrelu y>0?1:.2, relu y>0, tanh 1-y^2)
 void act_fwd(Stream& s, const TView& x, const TView& y, int act);
-void act_bwd(Stream& s, const TView& dy, const TView& y, const TView& dx, int act, int accumulate);
+void act_bwd(Stream& s, const TView& dy, const TView& y, const TView& dx, int act, int accumulate, float* amax_out = nullptr);
 // dst (+)= alpha * src + shift   (views)
 void axpy(Stream& s, const TView& src, const TView& dst, float alpha, int accumulate, float shift = 0.f);
 

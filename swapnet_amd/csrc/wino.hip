@@ -278,25 +278,6 @@ __device__ __forceinline__ void f1mac(float& s, float c, float x) {
 }
 #define F4ZERO make_float4(0.f, 0.f, 0.f, 0.f)
 
-// ---- amax slots (ops.h ConvFwdArgs::x_amax): a producer folds max |v| over what it writes into entry blockIdx % AMAX_SLOT of the
-// slot -- block maximum through LDS, then one atomic max on the bit pattern (non-negative floats order like unsigned integers:
-// exact, order-independent), skipped when the entry already holds as much.  All 256 threads of the block must call it.
-__device__ __forceinline__ float f4amax(const float4& v) { return fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))); }
-__device__ __forceinline__ void amax_fold(float am, float* amax_out) {
-  if (!amax_out) return;                       // (uniform over the grid)
-  __shared__ float red[4];
-#pragma unroll
-  for (int o = 32; o; o >>= 1) am = fmaxf(am, __shfl_xor(am, o));
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = am;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    const float m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-    unsigned* dst = reinterpret_cast<unsigned*>(amax_out) + (blockIdx.x % AMAX_SLOT);
-    const unsigned bits = __float_as_uint(m);          // m >= 0 (or NaN: sign bit clear after fabsf; orders above every finite value)
-    if (bits > __hip_atomic_load(dst, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(dst, bits);
-  }
-}
-
 template <class F>
 __global__ __launch_bounds__(256) void winog_input_kernel(const float* x, int xcs, int N, int H, int W, int C, int pad,
                                                           int pad_mode, int Th, int Tw, float* V, float* amax_out) {
