@@ -50,8 +50,25 @@ PEAK_SPLIT_TFLOPS = round(PEAK_BF16_MFMA_TFLOPS / 6.0, 1)
 # The pre-cut forward-type ring kernel (conv_fwd_pc_*) takes its operands as TWO fp16 planes of (operand x 2^k), k from the
 # operand's amax: x = h + l, products h h + h l + l h = 3 fp16 MFMAs per fp32 product (same dense rate as bf16), error of the
 # dropped l l term 2^-22.  SWN_PC_PLANES=3 keeps the three-plane bf16 form (6 MFMAs) for that family as well.
-PC_PLANES = 3 if os.environ.get("SWN_PC_PLANES", "2") == "3" else 2
-PEAK_PC_TFLOPS = round(PEAK_BF16_MFMA_TFLOPS / (3.0 if PC_PLANES == 2 else 6.0), 1)
+PC_PLANES = {"3": 3, "1": 1}.get(os.environ.get("SWN_PC_PLANES", "2"), 2)
+PEAK_PC_TFLOPS = round(PEAK_BF16_MFMA_TFLOPS / {1: 1.0, 2: 3.0}.get(PC_PLANES, 6.0), 1)
+# Round 4: the weight-gradient ring kernel takes the same two-plane form (both operands cut in the loop, scales from amax slots
+# their producers fill); SWN_WGRAD_PLANES=3 keeps its three bf16 planes.
+WGRAD_PLANES = {"3": 3, "1": 1}.get(os.environ.get("SWN_WGRAD_PLANES", "2"), 2)
+
+
+def mfma16_per_product(kernel_name):
+    """16-bit MFMA products the kernel family issues per fp32 product it delivers (0 = it multiplies on the f32 MFMA pipe):
+    the step's `pipe_util_nominal` prices the EXECUTED matrix work against the nominal 2.5 PFLOP/s, whatever the formulation."""
+    if not SPLIT:
+        return 0
+    if "_pc_" in kernel_name:
+        return {1: 1, 2: 3}.get(PC_PLANES, 6)
+    if "conv_wgrad_dma" in kernel_name:
+        return {1: 1, 2: 3}.get(WGRAD_PLANES, 6)
+    if "_dma_" in kernel_name:
+        return 6
+    return 0
 
 
 def cpu_baseline(sample_bs=4, size=256, warm=2, timed=5):
@@ -90,6 +107,31 @@ def cpu_baseline(sample_bs=4, size=256, warm=2, timed=5):
     d1 = (time.time() - t0) / 8
     out["c1_64x64_bs4"] = {"value": round(4 / d1, 3), "unit": "images/sec", "s_per_step": round(d1, 4), "steps": 8}
     return out
+
+
+def cpu_baseline_texture(sample_bs=2, size=256, warm=1, timed=4):
+    """The texture-stage step (TextureModel.optimize_parameters, models/texture_model.py:121-180) of the same port on the host
+    cores: RoIAlign + pix2pix U-Net + PatchGAN + VGG16 perceptual / style losses, seeded-random VGG weights, train mode."""
+    from oracle import swapnet_oracle as O
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    cores = max(1, min(avail, 32))
+    torch.set_num_threads(cores)
+    torch.manual_seed(0)
+    G, D, vgg = O.texture_module_params(img_size=size), O.patchgan_params(22), O.vgg16_feature_params()
+    batch = O.synth_texture_batch(sample_bs, size, size, seed=1234)
+    st = O.TextureStepOracle(G, D, vgg, training=True)
+    for _ in range(warm):
+        st.step(*batch)
+    t0 = time.time()
+    for _ in range(timed):
+        st.step(*batch)
+    dt = (time.time() - t0) / timed
+    return {"value": round(sample_bs / dt, 4), "unit": "images/sec", "cores": cores, "kind": "port",
+            "sample": f"texture G+D step {size}x{size} bs {sample_bs} (12 ROIs, L1 + VGG16 content + style), {warm} warm-up + {timed} "
+                      f"timed steps, torch {torch.__version__} CPU fp32, {cores} threads"}
 
 
 def _rccl_version():
@@ -152,12 +194,21 @@ def main():
     ap.add_argument("--stage", choices=("warp", "texture", "infer"), default="warp",
                     help="warp = config C2 (the headline metric); texture = config C3 (256x256, bs 16, ROIs, "
                          "perceptual + style losses on), reported for reference")
+    ap.add_argument("--precision", choices=("f32", "f16"), default="f32",
+                    help="f32 (the headline, BASELINE.json C2): fp32-equivalent products from two fp16 planes per operand; "
+                         "f16 (the arithmetic of C4 on however many GPUs are given): ONE fp16 plane per amax-scaled operand, "
+                         "one MFMA per product, fp32 accumulation and storage -- reported with its own dtype, never as the headline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--with-h2d", action="store_true",
                     help="additionally time steps that re-upload the batch from host memory every step through "
                          "the model API (set_input + step), reported as `h2d_inclusive` (never `value`)")
     args = ap.parse_args()
+    if args.precision == "f16":        # read once by the library, before the first model is built
+        os.environ["SWN_PC_PLANES"] = "1"; os.environ["SWN_WGRAD_PLANES"] = "1"
+        global PC_PLANES, WGRAD_PLANES, PEAK_PC_TFLOPS
+        PC_PLANES = WGRAD_PLANES = 1
+        PEAK_PC_TFLOPS = PEAK_BF16_MFMA_TFLOPS
     if args.stage == "infer":
         return bench_infer(args)
 
@@ -255,14 +306,20 @@ def main():
                    "images/sec full G+D step, warp-stage 256x256 bs=32/GPU"),
         "value": round(ips, 3), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
+        "dtype": ("f32" if args.precision == "f32" else "f16 operands (one amax-scaled plane), f32 accumulate and storage"),
+        "data": "synthetic",
         "config": {"workload": (f"texture-stage G+D optimize_parameters step, {S}x{S}, bs {B}/GPU, fp32, 12 ROIs/img, "
-                                f"L1 + VGG16 content + style losses, TextureModule 54.5M + PatchGAN 2.8M params, AdamW"
+                                f"L1 + VGG16 content + style losses, train mode, same kernels and arithmetic as the warp stage, "
+                                f"TextureModule 54.5M + PatchGAN 2.8M + frozen VGG16 params, AdamW"
                                 if texture else
                                 f"warp-stage G+D optimize_parameters step, {S}x{S}, bs {B}/GPU, fp32 storage and "
-                                f"accumulation" + ((", GEMM products on the 16-bit MFMA pipe from exact operand splits: forward / input-gradient GEMMs "
-                                                    "as 2 fp16 planes of amax-scaled operands (3 of 4 terms, the dropped one below 2^-22), "
-                                                    "weight-gradient GEMMs as 3 bf16 planes (6 of 9 terms, dropped below 2^-24)" if PC_PLANES == 2 else
+                                f"accumulation" + ((", GEMM products on the 16-bit MFMA pipe from operand splits: forward / input-gradient "
+                                                    "GEMMs as 2 fp16 planes of amax-scaled operands (22 of 24 mantissa bits, 3 of 4 terms, the dropped "
+                                                    "one below 2^-22), weight-gradient GEMMs " +
+                                                    ("in the same two-plane form" if WGRAD_PLANES == 2 else "as 3 bf16 planes (6 of 9 terms, dropped below 2^-24)")
+                                                    if PC_PLANES == 2 else
+                                                    ", REDUCED PRECISION (--precision f16): every ring-kernel GEMM multiplies ONE fp16 plane of "
+                                                    "each amax-scaled operand (11 mantissa bits, one MFMA per product)" if PC_PLANES == 1 else
                                                     ", GEMM products via an exact 3 x bf16 split of both operands (6 of 9 terms, the "
                                                     "dropped ones below 2^-24) on the bf16 MFMA pipe") if SPLIT else
                                                    ", GEMM products on v_mfma_f32_32x32x2_f32") +
@@ -318,10 +375,11 @@ def main():
                        "conv_fwd_pc_128x128": "conv_fwd_pc_kernel<4, 4, 2, 4, %d>" % PC_PLANES,
                        "conv_fwd_pc_256x64": "conv_fwd_pc_kernel<8, 2, 3, 2, %d>" % PC_PLANES,
                        "conv_fwd_pc_128x192": "conv_fwd_pc_kernel<4, 6, 2, 2, %d>" % PC_PLANES,
-                       "conv_wgrad_dma_128x128": "conv_wgrad_dma_kernel<2, 2, %s>" % sp,
-                       "conv_wgrad_dma_256x64": "conv_wgrad_dma_kernel<4, 1, %s>" % sp}.get(dom.split("[")[0], dom)
+                       "conv_wgrad_dma_128x128": "conv_wgrad_dma_kernel<2, 2, %d>" % (0 if not SPLIT else (2 if WGRAD_PLANES == 2 else 1)),
+                       "conv_wgrad_dma_256x64": "conv_wgrad_dma_kernel<4, 1, %d>" % (0 if not SPLIT else (2 if WGRAD_PLANES == 2 else 1))}.get(dom.split("[")[0], dom)
             step_hbm = None
-            for tname in ("traffic_r03b.json", "traffic_r03.json", "traffic_r02b.json", "traffic_r02.json", "traffic_r01.json"):
+            tnames = ("traffic_r04_texture.json",) if texture else ("traffic_r04.json",)
+            for tname in tnames + ("traffic_r03b.json", "traffic_r03.json", "traffic_r02b.json", "traffic_r02.json", "traffic_r01.json"):
                 tpath = os.path.join(REPO, "profiles", tname)
                 if os.path.exists(tpath):
                     # HBM bytes per launch from the committed rocprofv3 PMC passes of this same command
@@ -341,11 +399,16 @@ def main():
             dense_flops_step = flop_per_img * B
             is_split = SPLIT and ("_dma_" in dom or "_pc_" in dom)
             is_pc2 = is_split and "_pc_" in dom and PC_PLANES == 2
-            peak = PEAK_PC_TFLOPS if is_pc2 else (PEAK_SPLIT_TFLOPS if is_split else PEAK_FP32_MFMA_TFLOPS)
+            is_pc1 = is_split and "_pc_" in dom and PC_PLANES == 1
+            is_wg = is_split and "conv_wgrad_dma" in dom
+            peak = (PEAK_PC_TFLOPS if (is_pc2 or is_pc1) else
+                    (round(PEAK_BF16_MFMA_TFLOPS / {1: 1.0, 2: 3.0}.get(WGRAD_PLANES, 6.0), 1) if is_wg else
+                     (PEAK_SPLIT_TFLOPS if is_split else PEAK_FP32_MFMA_TFLOPS)))
             out["roofline"] = {
                 "bound": "mfma", "kernel": dom, "measured": "HIP events, in-order pass (second stream off)", "achieved": round(ach, 2), "peak": peak,
                 "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic, "traffic_source": traffic_src,
-                "peak_definition": ("fp32-equivalent FLOP/s of the 16-bit matrix pipe for this kernel's formulation: 2500 TFLOP/s dense "
+                "peak_definition": ("dense fp16 MFMA peak, 2500 TFLOP/s: one MFMA per product (one fp16 plane per operand)" if is_pc1 else
+                                    "fp32-equivalent FLOP/s of the 16-bit matrix pipe for this kernel's formulation: 2500 TFLOP/s dense "
                                     "fp16 / 3 fp16 MFMA products per fp32 product (two amax-scaled fp16 planes per operand, fp32 "
                                     "accumulate).  Nominal clock: with random operands the chip sustains 1.1-1.5 GHz in these loops "
                                     "(profiles/ring_lab_r03_clock.txt), i.e. about half of this figure is reachable" if is_pc2 else
@@ -368,6 +431,12 @@ def main():
                 "algorithmic_speedup": round(dense_flops_step / exec_flops_step, 3),
                 "dense_equivalent_frac": round(dense_flops_step / (ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
                 "gemm_ms_per_step": round(gemm_ms, 2),
+                # the yardstick that does not move with the formulation: 16-bit MFMA FLOPs actually EXECUTED
+                # (3 per fp32 product in the two-plane kernels, 6 in the three-plane ones) over the nominal 2.5 PFLOP/s dense
+                # peak -- for the dominant kernel's own launches, and for the whole step over the step time
+                "pipe_util_nominal": round(ach * mfma16_per_product(dom) / PEAK_BF16_MFMA_TFLOPS, 4),
+                "pipe_util_nominal_step": round(sum(v["flops"] * mfma16_per_product(n) for n, v in kernels.items()) / nprof
+                                                / (ms * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS, 4),
                 "all_gemm_kernels": {n: {"tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2),
                                          "ms_per_step": round(v["ms"] / nprof, 3)} for n, v in sorted(kernels.items())},
             }
@@ -421,8 +490,21 @@ def main():
         res["h2d_bytes_per_step"] = {"onehot_fp32": sum(t.numel() * 4 for t in host),
                                      "label_maps": host[0].numel() * 4 + sum(t.numel() * 4 for t in labels)}
         out["h2d_inclusive"] = res
-    if rank == 0 and world == 1 and not args.no_cpu_baseline and not texture:
-        out["cpu_baseline"] = cpu_baseline()
+    if rank == 0:
+        # which kernel every layer launched (swn_route_trace): the digest the parity tests compare their own runs with
+        # (tests/backends.py assert_default_routing), and the switches that were set in this process
+        import hashlib
+        ctx.route_trace(True)
+        lab = draw_labels()
+        model.forward(True, 3); model.backward_D(lab[0], lab[1]); model.optimizer_step(engine.NET_D)
+        model.backward_G(lab[2]); model.optimizer_step(engine.NET_G)
+        torch.cuda.synchronize()
+        ctx.route_trace(False)
+        route = ctx.route_report()
+        out["config"]["routing"] = {"launch_lines": len(route), "sha16": hashlib.sha256("\n".join(route).encode()).hexdigest()[:16],
+                                    "switches": sorted(k + "=" + v for k, v in os.environ.items() if k.startswith("SWN_"))}
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline_texture() if texture else cpu_baseline()
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1 or rccl1:

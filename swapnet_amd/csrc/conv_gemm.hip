@@ -735,6 +735,21 @@ __device__ __forceinline__ void split8h_rn(const float* v, float sa, u32x4& hi, 
     lo[q] = __builtin_bit_cast(unsigned, f16x2{(_Float16)r0, (_Float16)r1});
   }
 }
+// ONE fp16 plane (SWN_PC_PLANES=1 / SWN_WGRAD_PLANES=1, the reduced-precision configuration): h = fp16(x * 2^k) rounded to
+// nearest, the low plane is not formed -- one MFMA per product, operands carry 11 mantissa bits (bf16 carries 8)
+__device__ __forceinline__ void split8h1(const float* v, float sa, u32x4& hi) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) hi[q] = __builtin_bit_cast(unsigned, f16x2{(_Float16)(v[2 * q] * sa), (_Float16)(v[2 * q + 1] * sa)});
+}
+__device__ __forceinline__ void split_mma_2x2_h1(f32x16 (&acc)[2][2], const float (&af)[2][8], const float (&bf)[2][8], float sa, float sb) {
+  u32x4 ah[2], bh[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) { split8h1(af[i], sa, ah[i]); split8h1(bf[i], sb, bh[i]); }
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = mma_f16(ah[i], bh[j], acc[i][j]);
+}
 // both operands fp32 in LDS (the weight-gradient kernel): acc[i][j] += A_i x B_j over the lane's 8 k values, two fp16 planes each
 __device__ __forceinline__ void split_mma_2x2_h(f32x16 (&acc)[2][2], const float (&af)[2][8], const float (&bf)[2][8], float sa, float sb) {
   u32x4 ah[2], al[2], bh[2], bl[2];
@@ -813,7 +828,7 @@ struct PcTile {
   static constexpr int APC = A_BYTES / 1024, BPC = B_BYTES / 1024;
   static constexpr int AI = APC / WGM, BI = BPC / WGM, BREM = BPC % WGM;   // pieces per wave; waves < BREM carry one more of B
   static constexpr int SMEM = NST * ST_BYTES;
-  static_assert(APC % WGM == 0 && NB % 2 == 0 && (PL == 2 || PL == 3), "tile shape");
+  static_assert(APC % WGM == 0 && NB % 2 == 0 && (PL == 1 || PL == 2 || PL == 3), "tile shape");
 };
 
 // WGCU = workgroups per CU the tile is sized for (LDS) -> waves per SIMD the register allocation must allow
@@ -852,7 +867,7 @@ __global__ __launch_bounds__(64 * WGM, WGCU * WGM / 4) void conv_fwd_pc_kernel(G
   const unsigned lds0 = (unsigned)(size_t)(lds_ptr_t)smem_c;
   // two-plane form: the power-of-two operand scales (A from the partial maxima of this launch, B from the panel's trailer)
   int kA = 0, kB = 0;
-  if constexpr (PL == 2) {
+  if constexpr (PL <= 2) {
     kA = __builtin_amdgcn_readfirstlane(scale_exp(amax256(a_amax, lane), PC_TOP_A));
     kB = *reinterpret_cast<const int*>(wpc + (size_t)nkb_all * (b_stage / 2));
   }
@@ -926,6 +941,16 @@ __global__ __launch_bounds__(64 * WGM, WGCU * WGM / 4) void conv_fwd_pc_kernel(G
       const float4 v1 = *reinterpret_cast<const float4*>(S + a_rd + a_c1);
       af[0] = v0.x; af[1] = v0.y; af[2] = v0.z; af[3] = v0.w; af[4] = v1.x; af[5] = v1.y; af[6] = v1.z; af[7] = v1.w;
     }
+    if constexpr (PL == 1) {
+      u32x4 bh[NB];
+#pragma unroll
+      for (int j = 0; j < NB; ++j) bh[j] = *reinterpret_cast<const u32x4*>(S + b_rd + (32 * j) * 16);
+      u32x4 ah;
+      split8h1(af, sa, ah);
+#pragma unroll
+      for (int j = 0; j < NB; ++j) acc[j] = mma_f16(ah, bh[j], acc[j]);
+      return;
+    }
     if constexpr (PL == 2) {
       u32x4 bh[NB], bl[NB];
 #pragma unroll
@@ -987,7 +1012,7 @@ __global__ __launch_bounds__(64 * WGM, WGCU * WGM / 4) void conv_fwd_pc_kernel(G
     }
   }
 
-  if constexpr (PL == 2) {                                // remove the operand scales (two exact power-of-two factors)
+  if constexpr (PL <= 2) {                                // remove the operand scales (two exact power-of-two factors)
     const float ca = pow2f(-kA), cb = pow2f(-kB);
 #pragma unroll
     for (int j = 0; j < NB; ++j)
@@ -1067,7 +1092,7 @@ __global__ __launch_bounds__(64 * WGM, WGCU * WGM / 4) void conv_fwd_pc_kernel(G
 // producer of the pre-cut operand: one thread per (k / 8, tile_n, pos) writes the 16-byte plane entries (three bf16 planes, or --
 // wamax != NULL -- two fp16 planes of w * 2^kB with kB from the 256 partial maxima of the source, stored in the panel's trailer)
 __global__ __launch_bounds__(256) void conv_precut_kernel(const float* w, unsigned short* out, int K, int Npad, int BN, size_t w_bs,
-                                                          size_t out_bs, const float* wamax) {
+                                                          size_t out_bs, const float* wamax, int planes) {
   const int NBc = BN / 32;
   const int tiles_n = (Npad + BN - 1) / BN;
   const size_t total = (size_t)(K / 8) * tiles_n * BN;
@@ -1092,11 +1117,11 @@ __global__ __launch_bounds__(256) void conv_precut_kernel(const float* w, unsign
       hi[j] = __builtin_bit_cast(unsigned, hh);
       lo[j] = __builtin_bit_cast(unsigned, f16x2{(_Float16)(x[0] - (float)hh[0]), (_Float16)(x[1] - (float)hh[1])});
     }
-    // [stage = kq / 2][tile_n][kq & 1][plane 2][pos][8 f16], then the trailer
-    const size_t base = ((((size_t)(kq >> 1) * tiles_n + tn) * 2 + (kq & 1)) * 2) * BN;
+    // [stage = kq / 2][tile_n][kq & 1][plane 1 or 2][pos][8 f16], then the trailer
+    const size_t base = ((((size_t)(kq >> 1) * tiles_n + tn) * 2 + (kq & 1)) * planes) * BN;
     o[base + pos] = u32x4{hi[0], hi[1], hi[2], hi[3]};
-    o[base + (size_t)BN + pos] = u32x4{lo[0], lo[1], lo[2], lo[3]};
-    if (i == 0) *reinterpret_cast<int*>(out + (size_t)(K / 16) * tiles_n * 4 * BN * 8) = kB;
+    if (planes == 2) o[base + (size_t)BN + pos] = u32x4{lo[0], lo[1], lo[2], lo[3]};
+    if (i == 0) *reinterpret_cast<int*>(out + (size_t)(K / 16) * tiles_n * 2 * planes * BN * 8) = kB;
     return;
   }
   unsigned hi[4], mid[4], lo[4];
@@ -1873,7 +1898,8 @@ struct DmaWgTile {
 };
 
 // SPLIT: 0 = v_mfma_f32_32x32x2_f32, 1 = three bf16 planes per operand (six MFMAs per product), 2 = two fp16 planes of the operands
-// scaled by powers of two from their amax (three MFMAs; x_amax / dy_amax: 256 floats each whose maximum is the operand's amax)
+// scaled by powers of two from their amax (three MFMAs; x_amax / dy_amax: 256 floats each whose maximum is the operand's amax),
+// 3 = ONE fp16 plane of the scaled operands (one MFMA: the reduced-precision configuration)
 template <int WGM, int WGN, int SPLIT>
 __global__ __launch_bounds__(64 * WGM * WGN) void conv_wgrad_dma_kernel(GemmP p, DmaSched sc, const float* x_amax, const float* dy_amax) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -1972,7 +1998,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_wgrad_dma_kernel(GemmP p,
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
   int kx = 0, ky = 0;
-  if constexpr (SPLIT == 2) {
+  if constexpr (SPLIT >= 2) {
     kx = __builtin_amdgcn_readfirstlane(scale_exp(amax256(x_amax, lane), PC_TOP_A));
     ky = __builtin_amdgcn_readfirstlane(scale_exp(amax256(dy_amax, lane), PC_TOP_A));
   }
@@ -1990,7 +2016,9 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_wgrad_dma_kernel(GemmP p,
       const float2 b = *reinterpret_cast<const float2*>(S + b_rd + s8 * BN);
       af[0][s8] = a.x; af[1][s8] = a.y; bf[0][s8] = b.x; bf[1][s8] = b.y;
     }
-    if constexpr (SPLIT == 2) {
+    if constexpr (SPLIT == 3) {
+      split_mma_2x2_h1(acc, af, bf, sx, sy);
+    } else if constexpr (SPLIT == 2) {
       split_mma_2x2_h(acc, af, bf, sx, sy);
     } else if constexpr (SPLIT == 1) {
       split_mma_2x2(acc, af, bf);
@@ -2021,7 +2049,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_wgrad_dma_kernel(GemmP p,
     }
   }
 
-  if constexpr (SPLIT == 2) {                              // remove the operand scales (two exact power-of-two factors)
+  if constexpr (SPLIT >= 2) {                              // remove the operand scales (two exact power-of-two factors)
     const float cx = pow2f(-kx), cy = pow2f(-ky);
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -2429,7 +2457,10 @@ static bool pc_on() {
 // 2 (default): two fp16 planes per operand, three MFMAs per product; 3: three bf16 planes, six.  Read once: the operands a model
 // holds are cut for one of the two forms.
 static int pc_planes() {
-  static const int pl = (getenv("SWN_PC_PLANES") && atoi(getenv("SWN_PC_PLANES")) == 3) ? 3 : 2;
+  static const int pl = [] {
+    const int v = getenv("SWN_PC_PLANES") ? atoi(getenv("SWN_PC_PLANES")) : 2;
+    return (v == 3 || v == 1) ? v : 2;           // 1: the reduced-precision configuration (one fp16 plane per operand)
+  }();
   return pl;
 }
 int conv_precut_planes() { return pc_planes(); }
@@ -2462,11 +2493,11 @@ static void launch_fwd_pc(Stream& s, GemmP& p, int nb, const unsigned short* wpc
   p.ntiles = tiles_m * p.tiles_n;
   constexpr int wg = WGCU;
   static_assert(wg * T::SMEM <= 160 * 1024, "tile does not fit a CU");
-  const size_t ws_cap = PL == 2 ? s.ws_bytes - PC_WS_TAIL : s.ws_bytes;
+  const size_t ws_cap = PL <= 2 ? s.ws_bytes - PC_WS_TAIL : s.ws_bytes;
   const float* a_amax = nullptr;
-  if (PL == 2 && x_amax && amax_fused_on()) {
+  if (PL <= 2 && x_amax && amax_fused_on()) {
     a_amax = x_amax;          // the producer of the operand left its amax (256 floats, maximum = amax) in a slot: no pass of our own
-  } else if (PL == 2) {
+  } else if (PL <= 2) {
     // |A|max over the whole input tensor of the launch (all images, all channels the gather reads; batched planes too)
     float* part = ws_amax(s, 0);
     amax_partials(s, p.x, (size_t)(p.M / (p.Ho * p.Wo)) * p.xH * p.xW, p.xC, (size_t)p.xcs, phases ? 1 : nb, p.x_bs, part);
@@ -2523,11 +2554,11 @@ int conv_precut_tile(int xC, int Npad) {
   return pc_tile_for(Npad);
 }
 size_t conv_precut_elems(int K, int Npad, int bn) {
-  if (pc_planes() == 2) return (size_t)(K / 16) * ceil_div(Npad, bn) * 4 * bn * 8 + PC_TRAILER;
+  if (pc_planes() <= 2) return (size_t)(K / 16) * ceil_div(Npad, bn) * 2 * pc_planes() * bn * 8 + PC_TRAILER;
   return (size_t)(K / 16) * ceil_div(Npad, bn) * 6 * bn * 8;
 }
 const float* conv_precut_amax(Stream& s, const float* src, size_t rows, int C, int batch, size_t bs) {
-  if (pc_planes() != 2) return nullptr;
+  if (pc_planes() == 3) return nullptr;
   float* part = ws_amax(s, 1);
   amax_partials(s, src, rows, C, (size_t)C, batch, bs, part);
   return part;
@@ -2538,7 +2569,7 @@ void conv_precut(Stream& s, const float* w, int K, int Npad, int bn, int batch, 
   // two-plane form: one scale for all `batch` panels of the launch (they are cut from one weight tensor)
   const float* wamax = conv_precut_amax(s, w, (size_t)K, Npad, batch, w_bs);
   hipLaunchKernelGGL(conv_precut_kernel, dim3((unsigned)((total + 255) / 256), batch), dim3(256), 0, hs(s), w, out, K, Npad, bn, w_bs,
-                     conv_precut_elems(K, Npad, bn), wamax);
+                     conv_precut_elems(K, Npad, bn), wamax, pc_planes());
   check_launch("conv_precut");
 }
 
@@ -2624,6 +2655,12 @@ void conv_fwd(Stream& s, const ConvFwdArgs& a) {
     if (a.wpc && pc_on() && split_on() && a.wpc_bn == pc_tile_for(a.Npad) &&
         (size_t)(p.K / 16) * ceil_div(a.Npad, a.wpc_bn) * 12 * a.wpc_bn * 8 < ((size_t)1 << 31)) {
       const bool ph = a.phases != 0;
+      if (pc_planes() == 1) {
+        if (a.wpc_bn == 192) launch_fwd_pc<4, 6, 2, 2, 1>(s, p, nb, a.wpc, a.wpc_bs, ph, a.x_amax);
+        else if (a.Npad > 64) launch_fwd_pc<4, 4, 2, 4, 1>(s, p, nb, a.wpc, a.wpc_bs, ph, a.x_amax);
+        else launch_fwd_pc<8, 2, 3, 2, 1>(s, p, nb, a.wpc, a.wpc_bs, ph, a.x_amax);
+        return;
+      }
       if (pc_planes() == 2) {
         if (a.wpc_bn == 192) launch_fwd_pc<4, 6, 2, 2, 2>(s, p, nb, a.wpc, a.wpc_bs, ph, a.x_amax);
         else if (a.Npad > 64) {
@@ -2719,7 +2756,10 @@ static void launch_wgrad(Stream& s, GemmP& p, int batch) {
 // 2 (default): the weight-gradient ring kernel on two fp16 planes per operand, both scaled by powers of two from their amax (three
 // MFMAs per product; tools/ring_lab.hip variants 18 / 19: 157-167 -> 266-268 fp32-equivalent TFLOP/s at 4.5e-7); 3: three bf16
 // planes (six MFMAs).  Read per launch (A/B runs, tests).
-static int wgrad_planes() { return (getenv("SWN_WGRAD_PLANES") && atoi(getenv("SWN_WGRAD_PLANES")) == 3) ? 3 : 2; }
+static int wgrad_planes() {
+  const int v = getenv("SWN_WGRAD_PLANES") ? atoi(getenv("SWN_WGRAD_PLANES")) : 2;
+  return (v == 3 || v == 1) ? v : 2;
+}
 template <int WGM, int WGN>
 static void launch_wgrad_dma(Stream& s, GemmP& p, int nb, const ConvWgradArgs& a) {
   using T = DmaWgTile<WGM, WGN>;
@@ -2728,7 +2768,8 @@ static void launch_wgrad_dma(Stream& s, GemmP& p, int nb, const ConvWgradArgs& a
   p.ntiles = tiles_k * p.tiles_n;
   const int nmb = p.M / T::PX;
   const int wg_per_cu = std::min(160 * 1024 / T::SMEM, 12 / T::NW);
-  const bool two = split_on() && wgrad_planes() == 2 && s.ws && s.ws_bytes >= (1u << 20);
+  const int wpl = wgrad_planes();
+  const bool two = split_on() && wpl <= 2 && s.ws && s.ws_bytes >= (1u << 20);        // fp16 planes: scaled operands
   const float *xa = nullptr, *ya = nullptr;
   if (two) {
     // both operands are activations: their amax over the whole tensors the gather / the dY rows come from -- left in a slot by
@@ -2745,17 +2786,18 @@ static void launch_wgrad_dma(Stream& s, GemmP& p, int nb, const ConvWgradArgs& a
   p.slab = reinterpret_cast<float*>(s.ws);
   p.splits = sc.tail_s;
   static bool once = (set_smem(conv_wgrad_dma_kernel<WGM, WGN, 2>, T::SMEM), set_smem(conv_wgrad_dma_kernel<WGM, WGN, 1>, T::SMEM),
-                      set_smem(conv_wgrad_dma_kernel<WGM, WGN, 0>, T::SMEM), true);
+                      set_smem(conv_wgrad_dma_kernel<WGM, WGN, 0>, T::SMEM), set_smem(conv_wgrad_dma_kernel<WGM, WGN, 3>, T::SMEM), true);
   (void)once;
   char pname[128];
   if (prof_detail())
-    snprintf(pname, sizeof pname, "conv_wgrad_dma_%dx%d%s[M%d,N%d,K%d,b%d,full%d,tail%dx%d]", T::BMK, T::BN, two ? "_h2" : "", p.M, p.Cout, p.K, nb,
+    snprintf(pname, sizeof pname, "conv_wgrad_dma_%dx%d%s[M%d,N%d,K%d,b%d,full%d,tail%dx%d]", T::BMK, T::BN, two ? (wpl == 1 ? "_h1" : "_h2") : "", p.M, p.Cout, p.K, nb,
              sc.full, sc.tail_tiles, sc.tail_s);
   else
     snprintf(pname, sizeof pname, "conv_wgrad_dma_%dx%d", T::BMK, T::BN);
   ProfScope prof(s, pname, 2.0 * p.M * p.Cout * p.K * nb);
   const int units = sc.full + sc.tail_tiles * sc.tail_s;
-  if (two) hipLaunchKernelGGL((conv_wgrad_dma_kernel<WGM, WGN, 2>), dim3(units), dim3(64 * T::NW), T::SMEM, hs(s), p, sc, xa, ya);
+  if (two && wpl == 1) hipLaunchKernelGGL((conv_wgrad_dma_kernel<WGM, WGN, 3>), dim3(units), dim3(64 * T::NW), T::SMEM, hs(s), p, sc, xa, ya);
+  else if (two) hipLaunchKernelGGL((conv_wgrad_dma_kernel<WGM, WGN, 2>), dim3(units), dim3(64 * T::NW), T::SMEM, hs(s), p, sc, xa, ya);
   else if (split_on()) hipLaunchKernelGGL((conv_wgrad_dma_kernel<WGM, WGN, 1>), dim3(units), dim3(64 * T::NW), T::SMEM, hs(s), p, sc, xa, ya);
   else hipLaunchKernelGGL((conv_wgrad_dma_kernel<WGM, WGN, 0>), dim3(units), dim3(64 * T::NW), T::SMEM, hs(s), p, sc, xa, ya);
   check_launch("conv_wgrad_dma");

@@ -804,7 +804,7 @@ __device__ __forceinline__ void cut8_store(const float (&u)[8], wu32x4* o, size_
 
 // two-plane fp16 form (conv_gemm.hip): u * 2^kB as h + l
 typedef _Float16 wf16x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ void cut8_store_h(const float (&u)[8], float sb, wu32x4* o, size_t e0, size_t plane_stride) {
+__device__ __forceinline__ void cut8_store_h(const float (&u)[8], float sb, wu32x4* o, size_t e0, size_t plane_stride, bool low_plane) {
   unsigned hi[4], lo[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
@@ -814,7 +814,7 @@ __device__ __forceinline__ void cut8_store_h(const float (&u)[8], float sb, wu32
     lo[j] = __builtin_bit_cast(unsigned, wf16x2{(_Float16)(x0 - (float)hh[0]), (_Float16)(x1 - (float)hh[1])});
   }
   o[e0] = wu32x4{hi[0], hi[1], hi[2], hi[3]};
-  o[e0 + plane_stride] = wu32x4{lo[0], lo[1], lo[2], lo[3]};
+  if (low_plane) o[e0 + plane_stride] = wu32x4{lo[0], lo[1], lo[2], lo[3]};
 }
 __device__ __forceinline__ int wino_scale_exp(const float* part, int lane, int top) {      // as conv_gemm.hip scale_exp(amax256())
   float m = fmaxf(fmaxf(part[lane], part[lane + 64]), fmaxf(part[lane + 128], part[lane + 192]));
@@ -828,12 +828,12 @@ __device__ __forceinline__ int wino_scale_exp(const float* part, int lane, int t
 
 template <class F>
 __global__ __launch_bounds__(256) void winog_filter_pc_kernel(WShape w, int mode, int K, int Nn, int BN, const float* packed,
-                                                              unsigned short* out, size_t panel_elems, const float* wamax) {
+                                                              unsigned short* out, size_t panel_elems, const float* wamax, int planes) {
   constexpr int A = F::A, R = F::R;
   const int NBc = BN / 32, tiles_n = (Nn + BN - 1) / BN;
   const size_t total = (size_t)(K / 8) * tiles_n * BN;
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-  const int PL = wamax ? 2 : 3;
+  const int PL = planes;               // 3 bf16 planes (wamax == NULL), 2 or 1 fp16 planes of the scaled filter
   int kB = 0;
   if (wamax) kB = wino_scale_exp(wamax, threadIdx.x & 63, 10);       // PC_TOP_B; |G g G^T| <= |g|max for both 6-point forms
   if (i >= total) return;
@@ -882,8 +882,8 @@ __global__ __launch_bounds__(256) void winog_filter_pc_kernel(WShape w, int mode
       }
       unsigned short* panel = out + (size_t)(a * A + j) * panel_elems;
       if (wamax) {
-        cut8_store_h(u, sb, reinterpret_cast<wu32x4*>(panel), e0, (size_t)BN);
-        if (i == 0) *reinterpret_cast<int*>(panel + (size_t)(K / 16) * tiles_n * 4 * BN * 8) = kB;       // trailer of every panel
+        cut8_store_h(u, sb, reinterpret_cast<wu32x4*>(panel), e0, (size_t)BN, PL == 2);
+        if (i == 0) *reinterpret_cast<int*>(panel + (size_t)(K / 16) * tiles_n * 2 * PL * BN * 8) = kB;  // trailer of every panel
       } else {
         cut8_store(u, reinterpret_cast<wu32x4*>(panel), e0, (size_t)BN);
       }
@@ -1119,9 +1119,11 @@ void wino_filter_transform_pc(Stream& s, int m, int r, const WShape& w, int mode
   // two-plane form: the scale comes from the amax of the layer's packed weights ([r * r][Cip][Npad])
   const float* wamax = conv_precut_amax(s, packed, (size_t)r * r * w.Cip, w.Npad, 1, 0);
   if (v == 1)
-    hipLaunchKernelGGL(winog_filter_pc_kernel<F43>, grid, dim3(256), 0, hs(s), w, mode, K, Nn, bn, packed, out, panel_elems, wamax);
+    hipLaunchKernelGGL(winog_filter_pc_kernel<F43>, grid, dim3(256), 0, hs(s), w, mode, K, Nn, bn, packed, out, panel_elems, wamax,
+                       conv_precut_planes());
   else
-    hipLaunchKernelGGL(winog_filter_pc_kernel<F34>, grid, dim3(256), 0, hs(s), w, mode, K, Nn, bn, packed, out, panel_elems, wamax);
+    hipLaunchKernelGGL(winog_filter_pc_kernel<F34>, grid, dim3(256), 0, hs(s), w, mode, K, Nn, bn, packed, out, panel_elems, wamax,
+                       conv_precut_planes());
   check_launch("wino_filter_transform_pc");
 }
 void wino_output_transform(Stream& s, int m, int r, const float* M, int Cm, int Th, int Tw, const float* bias, int act,

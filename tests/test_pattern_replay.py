@@ -19,7 +19,7 @@ from tests.test_train_parity import BACKENDS, _ctx, _phased_step, _texture_case,
 TOL = 1e-4
 
 
-def _warp_replay(ctx, B, H, seed, training, labels=(0.9, 0.8, 1.0), drop_seed=77, check_route=False):
+def _warp_replay(ctx, B, H, seed, training, labels=(0.9, 0.8, 1.0), drop_seed=77, check_route=False, tol=TOL, tol_fwd=2e-5):
     torch.manual_seed(seed)
     G, D = O.warp_module_params(), O.patchgan_params(22)
     batch = O.synth_warp_batch(B, H, H, seed=99)
@@ -38,12 +38,13 @@ def _warp_replay(ctx, B, H, seed, training, labels=(0.9, 0.8, 1.0), drop_seed=77
         s64.patterns = replay
         s64.step(*batch, labels=list(labels))
         flips = replay.check()
-        wD = backends.assert_grads_replayed(gD, s64.grads_D, lambda k: noise_bias(k, list(s64.grads_D)), TOL, ("warp", H, "D"))
-        wG = backends.assert_grads_replayed(gG, s64.grads_G, lambda k: noise_bias(k, list(s64.grads_G)), TOL, ("warp", H, "G"))
-        assert rel(m.output(), s64.fakes) < 2e-5
+        wD = backends.assert_grads_replayed(gD, s64.grads_D, lambda k: noise_bias(k, list(s64.grads_D)), tol, ("warp", H, "D"))
+        wG = backends.assert_grads_replayed(gG, s64.grads_G, lambda k: noise_bias(k, list(s64.grads_G)), tol, ("warp", H, "G"))
+        assert rel(m.output(), s64.fakes) < tol_fwd, rel(m.output(), s64.fakes)
         L = m.losses()
         for k, v in s64.losses.items():
-            assert abs(L[k] - v) <= 2e-5 * abs(v) + 1e-7, (k, L[k], v)
+            assert abs(L[k] - v) <= tol_fwd * abs(v) + 1e-7, (k, L[k], v)
+        _warp_replay.last_forward_error = rel(m.output(), s64.fakes)
         return flips, wD, wG
     finally:
         m.close()
@@ -152,3 +153,34 @@ def test_unpinned_gradient_distance_is_branch_flips():
     assert pn < 2e-5
     if flips:                      # (a seed without a single flip would make both distances round-off sized)
         assert un > 20 * pn and flips < 1e-4 * pinned.elements["D"]
+
+
+# ---- the reduced-precision configuration (BASELINE.json C4's arithmetic on one GPU): one fp16 plane per operand --------------
+_F16_SCRIPT = r"""
+import sys
+sys.path.insert(0, %(repo)r)
+from tests import backends
+from tests.test_pattern_replay import _warp_replay
+flips, wD, wG = _warp_replay(backends.gpu_ctx(), 2, 256, 3, True, tol=1.0, tol_fwd=1.0)
+print("F16RESULT %%g %%g %%g" %% (wD, wG, _warp_replay.last_forward_error), flips)
+"""
+
+
+@pytest.mark.gpu
+def test_one_plane_configuration_tolerance_study():
+    """`bench.py --precision f16` (SWN_PC_PLANES=1, SWN_WGRAD_PLANES=1): every ring-kernel GEMM multiplies ONE fp16 plane of
+    each amax-scaled operand (11 mantissa bits; one MFMA per product instead of three), storage and accumulation stay fp32.
+    Not the parity configuration -- north_star's 1e-3 belongs to the two-plane form above -- but held to a measured bound with
+    the same instrument: activation pattern and dropout masks replayed in the float64 oracle, 256x256, training mode.  The plane
+    count is read once per process, so the step runs in a subprocess."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, SWN_PC_PLANES="1", SWN_WGRAD_PLANES="1")
+    out = subprocess.run([sys.executable, "-c", _F16_SCRIPT % dict(repo=backends.REPO)], env=env, capture_output=True, text=True,
+                         timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("F16RESULT")][-1]
+    wD, wG, fwd = (float(v) for v in line.split()[1:4])
+    print("one fp16 plane per operand, warp 256x256 train: worst pinned-pattern gradient error D %.2e G %.2e, output %.2e" % (wD, wG, fwd))
+    assert fwd < 3e-3 and wD < 2e-2 and wG < 2e-2, (wD, wG, fwd)
