@@ -198,6 +198,9 @@ def main():
                     help="f32 (the headline, BASELINE.json C2): fp32-equivalent products from two fp16 planes per operand; "
                          "f16 (the arithmetic of C4 on however many GPUs are given): ONE fp16 plane per amax-scaled operand, "
                          "one MFMA per product, fp32 accumulation and storage -- reported with its own dtype, never as the headline")
+    ap.add_argument("--captured", action="store_true",
+                    help="run the step as a recorded hipGraph (swn_model_step_captured, BASELINE.json C5's captured step); "
+                         "N = 1 only, bit-identical results")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--with-h2d", action="store_true",
@@ -262,7 +265,7 @@ def main():
         step_no[0] += 1
         seed = step_no[0] * 1000 + rank
         if world == 1 and not os.environ.get("SWAPNET_BENCH_PHASED") and not rccl1:
-            model.step(lab, training=True, seed=seed)
+            model.step(lab, training=True, seed=seed, captured=args.captured)
             return
         # (SWAPNET_BENCH_PHASED=1 runs this multi-GPU call sequence on one GPU, exchanges being no-ops, to
         # price the phased / bucketed form against the fused swn_model_step)
@@ -324,6 +327,7 @@ def main():
                                                     "dropped ones below 2^-24) on the bf16 MFMA pipe") if SPLIT else
                                                    ", GEMM products on v_mfma_f32_32x32x2_f32") +
                                 f", train mode (dropout 0.5), WarpModule 137.6M + PatchGAN 2.8M params, AdamW"),
+                   "step_form": ("hipGraph replay (swn_model_step_captured)" if args.captured and world == 1 else "eager launches"),
                    "global_batch": world * B, "parallelism": f"dp{world}" + (" (1-rank RCCL exchange exercised)" if rccl1 else "")},
         "losses_finite": all(v == v and abs(v) < 1e30 for v in losses.values()),
         # proof of the launch shape for the driver's scaling table: ranks, the device each rank drives, the collective library

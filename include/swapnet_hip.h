@@ -222,6 +222,13 @@ int swn_model_optimizer_step(swn_model* m, int net);
 int swn_model_optimizer_step_range(swn_model* m, int net, size_t off, size_t count, int first);
 /* BaseGAN.optimize_parameters (models/base_gan.py:194-203; warp_model.py:169-183) in one call */
 int swn_model_step(swn_model* m, const float labels[3], int training, uint64_t dropout_seed);
+/* The same step recorded once into a hipGraph and replayed (BASELINE.json C5's "hipGraph-captured step"): the three label
+ * draws of GANLoss (modules/loss.py:77-104), the dropout seed and both AdamW bias corrections travel through a 40-byte device
+ * block uploaded in stream order, so one recorded launch sequence serves every step; the loss read-back of train.py:74
+ * (swn_model_get_losses) stays the only synchronisation.  First call per `training` value runs eagerly, the second records,
+ * later ones replay.  Results are bit-identical to swn_model_step.  Falls back to swn_model_step for the gradient-penalty
+ * modes; under data parallelism use the phased calls (the exchange runs between them). */
+int swn_model_step_captured(swn_model* m, const float labels[3], int training, uint64_t dropout_seed);
 /* BaseModel.get_current_losses (models/base_model.py:139-147): host array of 9 floats
  * D, D_real, D_fake, G, G_gan, G_ce, G_l1, G_content, G_style, D_gp  (one small D2H + sync; n <= 10) */
 int swn_model_get_losses(swn_model* m, float* host_out, int n);

@@ -142,6 +142,11 @@ int swn_model_destroy(swn_model* m) {
 int swn_model_set_hyper(swn_model* m, const swn_hyper* h) {
   return guard([&] {
     REQUIRE(m && h, "NULL argument");
+    const Hyper before = m->m->hyper;
+    struct Recheck {          // a recorded step (swn_model_step_captured) carries the hyper-parameters it was recorded with
+      Model& mm; const Hyper& was;
+      ~Recheck() { if (memcmp(&was, &mm.hyper, sizeof(Hyper)) != 0) mm.invalidate_step_graphs(); }
+    } recheck{*m->m, before};
     Hyper& y = m->m->hyper;
     y.lr = h->lr; y.d_lr = h->d_lr; y.weight_decay = h->weight_decay; y.d_weight_decay = h->d_weight_decay;
     y.b1 = h->b1; y.b2 = h->b2; y.lambda_gan = h->lambda_gan; y.lambda_ce = h->lambda_ce; y.lambda_l1 = h->lambda_l1;
@@ -376,6 +381,12 @@ int swn_model_step(swn_model* m, const float labels[3], int training, uint64_t s
   return guard([&] {
     REQUIRE(m && labels && m->m->is_train, "model was not created for training");
     m->m->step(labels, training != 0, seed);
+  });
+}
+int swn_model_step_captured(swn_model* m, const float labels[3], int training, uint64_t seed) {
+  return guard([&] {
+    REQUIRE(m && labels && m->m->is_train, "model was not created for training");
+    m->m->step_captured(labels, training != 0, seed);
   });
 }
 int swn_model_get_losses(swn_model* m, float* host_out, int n) {

@@ -2,6 +2,7 @@
 #include "engine.h"
 
 #include <algorithm>
+#include <cstddef>
 #include <cstdlib>
 #include <cstring>
 #include <map>
@@ -87,6 +88,8 @@ void Ctx::release(AllocList& list) {
   list.clear();
 }
 Model::~Model() {
+  for (void*& g : step_graph_) { graph_destroy(g); g = nullptr; }
+  if (cap_stream_) stream_destroy(cap_stream_);
   gp_.reset(); D3_.reset(); G.reset(); D2.reset(); D1.reset();
   if (ctx) ctx->release(owned_allocs);
 }
@@ -957,6 +960,7 @@ void Net::norm_act(const Var& raw, const Var& y, bool norm, int actf, float drop
     NormActArgs a;
     a.x = rv; a.y = yv; a.stats = stats; a.norm = norm; a.act = actf;
     a.drop_p = n.training ? drop_p : 0.f; a.seed = Net::drop_seed(n.seed, salt);
+    a.seed_base = n.seed_dev; a.salt = salt;
     a.residual = has_res ? &res.v : nullptr;
     a.amax_out = n.amax + ySlot;
     norm_act_fwd(n.ctx.s, a);
@@ -974,6 +978,7 @@ void Net::norm_act(const Var& raw, const Var& y, bool norm, int actf, float drop
     NormActBwdArgs b;
     b.dy = yg; b.x = rv; b.stats = stats; b.dx = rg; b.norm = norm; b.act = actf; b.colsum = colsum;
     b.drop_p = n.training ? drop_p : 0.f; b.seed = Net::drop_seed(n.seed, salt);
+    b.seed_base = n.seed_dev; b.salt = salt;
     b.amax_out = n.amax + gSlot;
     norm_act_bwd(n.ctx.s, b);
   };
@@ -1228,6 +1233,7 @@ void Model::optimizer_step(int net) {
   a.lr = net == 0 ? hyper.lr : hyper.d_lr;
   a.weight_decay = net == 0 ? hyper.weight_decay : hyper.d_weight_decay;
   a.beta1 = net == 0 ? hyper.b1 : hyper.d_b1; a.beta2 = net == 0 ? hyper.b2 : hyper.d_b2; a.eps = 1e-8f; a.step = A.step;
+  if (indirect) a.sched_dev = net == 0 ? reinterpret_cast<const float*>(sp_dev) + 6 : reinterpret_cast<const float*>(sp_dev) + 8;
   adamw_step(ctx->s, a);
   A.version += 1;
 }
@@ -1322,6 +1328,53 @@ void Model::optimizer_step_range(int net, size_t off, size_t count, int first) {
   a.beta1 = net == 0 ? hyper.b1 : hyper.d_b1; a.beta2 = net == 0 ? hyper.b2 : hyper.d_b2; a.eps = 1e-8f; a.step = A.step;
   adamw_step(ctx->s, a);
   A.version += 1;
+}
+
+// BaseGAN.optimize_parameters as a recorded launch sequence (engine.h Model::step_captured)
+void Model::step_captured(const float labels[3], bool training, uint64_t seed) {
+  static_assert(sizeof(StepParams) == 40 && offsetof(StepParams, schedG) == 24 && offsetof(StepParams, schedD) == 32, "StepParams layout");
+  if (hyper.gp_mode) { step(labels, training, seed); return; }          // host-seeded draws per step: not recordable
+  if (!sp_dev) { AllocScope mine(*ctx, owned_allocs); sp_dev = static_cast<StepParams*>(ctx->alloc(64)); }
+  StepParams h{};
+  for (int i = 0; i < 3; ++i) h.labels[i] = labels[i];
+  h.seed = seed;
+  adamw_schedule(hyper.lr, hyper.b1, hyper.b2, arenaG.step + 1, h.schedG);
+  adamw_schedule(hyper.d_lr, hyper.d_b1, hyper.d_b2, arenaD.step + 1, h.schedD);
+  dev_upload(ctx->s, sp_dev, &h, sizeof h);           // stream-ordered: in front of this step's launches
+  struct Indirect {
+    Model& m;
+    explicit Indirect(Model& mm) : m(mm) { m.indirect = true; if (m.G) m.G->seed_dev = &m.sp_dev->seed; }
+    ~Indirect() { m.indirect = false; if (m.G) m.G->seed_dev = nullptr; }
+  } scope(*this);
+  const int gi = training ? 1 : 0;
+  if (!is_device_build() || step_warm_[gi] == 0) {      // first call (and the host simulator): the phases, eagerly, on the device block
+    step(labels, training, seed);
+    step_warm_[gi] = 1;
+    return;
+  }
+  if (!step_graph_[gi]) {
+    // record: the same phases on a private capture stream (the side stream joins the capture through the fork / join events)
+    stream_sync(ctx->s);
+    Stream& s = ctx->s;
+    void* caller = s.handle;
+    if (!cap_stream_) cap_stream_ = stream_create_current();
+    const int stepG = arenaG.step, stepD = arenaD.step, verG = arenaG.version, verD = arenaD.version;
+    s.handle = cap_stream_;
+    try {
+      graph_begin(s);
+      try {
+        step(labels, training, seed);
+        ctx->join_side();
+      } catch (...) { graph_abort(s); throw; }
+      step_graph_[gi] = graph_end(s);
+    } catch (...) { s.handle = caller; throw; }
+    s.handle = caller;
+    // recording executed nothing: undo the host-side bookkeeping of the recorded pass, the replay below redoes it
+    arenaG.step = stepG; arenaD.step = stepD; arenaG.version = verG; arenaD.version = verD;
+  }
+  graph_launch(step_graph_[gi], ctx->s);
+  if (!hyper.warp_mode_ce_only) { arenaD.step += 1; arenaD.version += 1; }
+  arenaG.step += 1; arenaG.version += 1;
 }
 
 // BaseGAN.optimize_parameters (models/base_gan.py:194-203): forward, D step, G step.

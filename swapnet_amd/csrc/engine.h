@@ -125,6 +125,7 @@ class Net {
   std::map<std::string, Var> taps;
   bool training = false;
   uint64_t seed = 0;
+  const uint64_t* seed_dev = nullptr;   // captured step: the step seed in device memory (NormActArgs::seed_base); else NULL
   float* dg = nullptr;      // dgrad operands of this net's convs
   size_t dg_n = 0;
   // weight operands pre-cut into bf16 planes for the round-3 ring kernel (ops.h conv_precut): forward and input-gradient
@@ -329,6 +330,22 @@ class Model {
   // the bias-correction counter); the ranges of one step must tile the arena.
   void optimizer_step_range(int net, size_t off, size_t count, int first);
   void step(const float labels[3], bool training, uint64_t seed);
+  // The same step recorded ONCE into a hipGraph (per value of `training`) and replayed: every per-step scalar -- the three
+  // smooth labels (modules/loss.py:77-104), the dropout seed, the bias corrections of both AdamW steps -- lives in a small
+  // device block (StepParams) that is uploaded in stream order before each launch, so the recorded launch sequence (two
+  // streams, ~620 kernels) is identical for every step.  train.py:74's loss read-back stays the only synchronisation.
+  // First call per mode runs eagerly (kernel attributes, lazy buffers), the second records, later ones replay.  Not for the
+  // gradient-penalty modes (their alpha / beta draws are host-seeded per step) nor under data parallelism (the exchange
+  // runs through torch.distributed between the phases): those keep step().  Results are bit-identical to step().
+  void step_captured(const float labels[3], bool training, uint64_t seed);
+  struct StepParams { float labels[4]; uint64_t seed; float schedG[2]; float schedD[2]; };
+  StepParams* sp_dev = nullptr;
+  bool indirect = false;          // the phases read labels / seed / AdamW schedule from sp_dev
+  const float* label_dev(int i) const { return indirect ? reinterpret_cast<const float*>(sp_dev) + i : nullptr; }
+  void invalidate_step_graphs() { for (void*& g : step_graph_) { graph_destroy(g); g = nullptr; } }
+  void* step_graph_[2] = {nullptr, nullptr};
+  int step_warm_[2] = {0, 0};
+  void* cap_stream_ = nullptr;
   // NLayerDiscriminator.forward (modules/discriminators.py:134-136) as a standalone call: x = the conditioned input
   // in the REFERENCE's channel order (B, 22, H, W) NCHW on the device, pred = (B, 1, H/8-2, W/8-2).  Runs on a
   // private PatchGAN instance bound to the same weights (created on first use), so the model's own buffers

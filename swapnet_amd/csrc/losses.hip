@@ -51,8 +51,9 @@ inline int loss_grid(size_t work) { return (int)std::min<size_t>(std::max<size_t
 // MODE 0 BCE-with-logits, 1 LSGAN (MSE), 2 WGAN (sign * mean)
 template <int MODE>
 __global__ __launch_bounds__(256) void gan_loss_kernel(const float* pred, int pcs, size_t numel, float label,
-                                                       float gscale, float* dpred, int dcs, double* partial) {
+                                                       float gscale, float* dpred, int dcs, double* partial, const float* label_dev) {
   __shared__ double sh[4];
+  if (label_dev) label = *label_dev;          // the label of a captured step lives in device memory (ops.h bce_logits_loss)
   double acc = 0;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < numel; i += (size_t)gridDim.x * 256) {
     const float x = pred[i * pcs];
@@ -449,27 +450,27 @@ __global__ void scalar_axpby_kernel(const float* a, float ca, const float* b, fl
 }
 
 template <int MODE>
-void gan_loss(Stream& s, const TView& pred, float label, float scale, float* loss_out, const TView* dpred) {
+void gan_loss(Stream& s, const TView& pred, float label, float scale, float* loss_out, const TView* dpred, const float* label_dev) {
   const size_t numel = pred.pixels();
   const int grid = loss_grid(numel);
   double* partial = reinterpret_cast<double*>(s.ws);
   const float gs = scale / (float)numel;
   hipLaunchKernelGGL(gan_loss_kernel<MODE>, dim3(grid), dim3(256), 0, hs(s), pred.p, pred.cs, numel, label, gs,
-                     dpred ? dpred->p : nullptr, dpred ? dpred->cs : 0, partial);
+                     dpred ? dpred->p : nullptr, dpred ? dpred->cs : 0, partial, label_dev);
   hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(64), 0, hs(s), partial, grid, 1.0 / (double)numel, loss_out);
   check_launch("gan_loss");
 }
 
 }  // namespace
 
-void bce_logits_loss(Stream& s, const TView& pred, float label, float scale, float* loss_out, const TView* dpred) {
-  gan_loss<0>(s, pred, label, scale, loss_out, dpred);
+void bce_logits_loss(Stream& s, const TView& pred, float label, float scale, float* loss_out, const TView* dpred, const float* label_dev) {
+  gan_loss<0>(s, pred, label, scale, loss_out, dpred, label_dev);
 }
-void lsgan_loss(Stream& s, const TView& pred, float label, float scale, float* loss_out, const TView* dpred) {
-  gan_loss<1>(s, pred, label, scale, loss_out, dpred);
+void lsgan_loss(Stream& s, const TView& pred, float label, float scale, float* loss_out, const TView* dpred, const float* label_dev) {
+  gan_loss<1>(s, pred, label, scale, loss_out, dpred, label_dev);
 }
 void wgan_loss(Stream& s, const TView& pred, float sign, float scale, float* loss_out, const TView* dpred) {
-  gan_loss<2>(s, pred, sign, scale, loss_out, dpred);
+  gan_loss<2>(s, pred, sign, scale, loss_out, dpred, nullptr);
 }
 
 void ce_argmax_loss(Stream& s, const TView& logits, const TView& target, int C, float scale, float* loss_out,

@@ -139,10 +139,10 @@ Var build_patchgan(Net& n, const Var& x, int n_layers, const std::vector<int32_t
 // shared GAN plumbing
 // ---------------------------------------------------------------------------------------
 static void gan_loss_op(Stream& s, int mode, const TView& pred, float label, bool target_is_real, float gscale,
-                        float* out, const TView* dpred) {
+                        float* out, const TView* dpred, const float* label_dev = nullptr) {
   // GANLoss.__call__ (modules/loss.py:110-130)
-  if (mode == 0) bce_logits_loss(s, pred, label, gscale, out, dpred);
-  else if (mode == 1) lsgan_loss(s, pred, label, gscale, out, dpred);
+  if (mode == 0) bce_logits_loss(s, pred, label, gscale, out, dpred, label_dev);
+  else if (mode == 1) lsgan_loss(s, pred, label, gscale, out, dpred, label_dev);
   else wgan_loss(s, pred, target_is_real ? -1.f : 1.f, gscale, out, dpred);
 }
 
@@ -265,8 +265,8 @@ class WarpModel final : public Model {
     TView pf = pred2.batch(0, B).v, pr = pred2.batch(B, B).v;
     TView gf = pred2.batch(0, B).g, gr = pred2.batch(B, B).g;
     // loss_D = 0.5 * (loss_D_fake + loss_D_real); lambda_discriminator is ignored here (:123)
-    gan_loss_op(s, hyper.gan_mode, pf, label_fake, false, 0.5f * hyper.grad_scale, losses + L_D_FAKE, &gf);
-    gan_loss_op(s, hyper.gan_mode, pr, label_real, true, 0.5f * hyper.grad_scale, losses + L_D_REAL, &gr);
+    gan_loss_op(s, hyper.gan_mode, pf, label_fake, false, 0.5f * hyper.grad_scale, losses + L_D_FAKE, &gf, label_dev(0));
+    gan_loss_op(s, hyper.gan_mode, pr, label_real, true, 0.5f * hyper.grad_scale, losses + L_D_REAL, &gr, label_dev(1));
     scalar_axpby(s, losses + L_D_FAKE, 0.5f, losses + L_D_REAL, 0.5f, losses + L_D);
     D2->backward(true, false);
     if (hyper.gp_mode) run_gradient_penalty(Dx.batch(B, B).v, Dx.batch(0, B).v);     // warp_model.py:126-136
@@ -286,7 +286,7 @@ class WarpModel final : public Model {
       D1->refresh_dgrad();
       D1->training = false;
       D1->forward();                                   // D was just updated (base_gan.py:199)
-      gan_loss_op(s, hyper.gan_mode, pred1.v, label_real, true, hyper.lambda_gan * hyper.grad_scale, losses + L_TMP0, &pred1.g);
+      gan_loss_op(s, hyper.gan_mode, pred1.v, label_real, true, hyper.lambda_gan * hyper.grad_scale, losses + L_TMP0, &pred1.g, label_dev(2));
       scalar_axpby(s, losses + L_TMP0, hyper.lambda_gan, nullptr, 0.f, losses + L_G_GAN);
       D1->backward(false, true);                       // D weight grads would be discarded (quirk 5)
       ce_argmax_loss(s, fakes, targets, Cc, hyper.lambda_ce * hyper.grad_scale, losses + L_TMP1, &dfakes, 1);

@@ -35,11 +35,15 @@ struct NAp {
   int norm, act;
   float drop_p; uint64_t seed;
   float* amax_out;              // optional amax slot of what the apply kernels write (fwd: y, bwd: dx)
+  const uint64_t* seed_base;    // captured step: the step seed lives in device memory; seed = *seed_base * 0x9E3779B1 + salt
+  uint64_t salt;
 };
+__device__ __forceinline__ uint64_t na_seed(const NAp& p) { return p.seed_base ? *p.seed_base * 0x9E3779B1ull + p.salt : p.seed; }
 
 // partial sums over a pixel chunk: mode 0 -> (sum x, sum x^2); mode 1 -> (sum dxh, sum dxh*xh)
 template <int MODE>
 __global__ __launch_bounds__(256) void in_partial_kernel(NAp p) {
+  const uint64_t drop_seed_v = na_seed(p);
   __shared__ double red[256 * 8];
   const int C4 = p.C >> 2;
   const int rows = 256 / C4;
@@ -70,7 +74,7 @@ __global__ __launch_bounds__(256) void in_partial_kernel(NAp p) {
         for (int j = 0; j < 4; ++j) {
           const float xh = (xa[j] - mean[j]) * rstd[j];                 // the forward's value (selects the activation branch)
           float g = ga[j] * act_grad_from_in(xh, p.act);
-          if (p.drop_p > 0.f) g *= drop_scale(p.seed, e * p.C + tx * 4 + j, p.drop_p);
+          if (p.drop_p > 0.f) g *= drop_scale(drop_seed_v, e * p.C + tx * 4 + j, p.drop_p);
           s[j] += g; ss[j] += (double)g * (((double)xa[j] - (double)mean[j]) * (double)rstd[j]);
         }
       }
@@ -112,6 +116,7 @@ __global__ void in_finalize_kernel(NAp p) {
 }
 
 __global__ __launch_bounds__(256) void norm_act_apply_kernel(NAp p) {
+  const uint64_t drop_seed_v = na_seed(p);
   const int C4 = p.C >> 2;
   const size_t total = (size_t)p.N * p.HW * C4;
   float am = 0.f;
@@ -130,7 +135,7 @@ __global__ __launch_bounds__(256) void norm_act_apply_kernel(NAp p) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       v[j] = act_apply(v[j], p.act);
-      if (p.drop_p > 0.f) v[j] *= drop_scale(p.seed, e * p.C + c + j, p.drop_p);
+      if (p.drop_p > 0.f) v[j] *= drop_scale(drop_seed_v, e * p.C + c + j, p.drop_p);
     }
     if (p.res) {
       const float4 r = *reinterpret_cast<const float4*>(p.res + e * p.rescs + c);
@@ -144,6 +149,7 @@ __global__ __launch_bounds__(256) void norm_act_apply_kernel(NAp p) {
 }
 
 __global__ __launch_bounds__(256) void norm_act_bwd_apply_kernel(NAp p) {
+  const uint64_t drop_seed_v = na_seed(p);
   const int C4 = p.C >> 2;
   const size_t total = (size_t)p.N * p.HW * C4;
   float am = 0.f;
@@ -168,7 +174,7 @@ __global__ __launch_bounds__(256) void norm_act_bwd_apply_kernel(NAp p) {
       }
       const float xh = (xa[j] - mean) * rstd;
       float g = ga[j] * act_grad_from_in(xh, p.act);
-      if (p.drop_p > 0.f) g *= drop_scale(p.seed, e * p.C + c + j, p.drop_p);
+      if (p.drop_p > 0.f) g *= drop_scale(drop_seed_v, e * p.C + c + j, p.drop_p);
       // g - mean(g) - xh * mean(g xh) cancels heavily (the deep layers lose 3 digits here): the combination is done in
       // double -- the kernel is HBM-bound (20 B per element), the handful of fp64 operations is free
       o[j] = p.norm ? (float)((double)rstd * ((double)g - m1 - (((double)xa[j] - (double)mean) * (double)rstd) * m2)) : g;
@@ -281,6 +287,7 @@ __device__ __forceinline__ void block_tree_sum(double* red, double (&v)[NV], int
 
 template <int CG, int NP>
 __global__ __launch_bounds__(256) void in_fused_fwd_kernel(NAp p) {
+  const uint64_t drop_seed_v = na_seed(p);
   constexpr int C4 = CG / 4, ROWS = 256 / C4;
   __shared__ double red[256 * 8];
   const int t = threadIdx.x, tx = t % C4, ty = t / C4;
@@ -325,7 +332,7 @@ __global__ __launch_bounds__(256) void in_fused_fwd_kernel(NAp p) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       o[j] = act_apply(o[j], p.act);
-      if (p.drop_p > 0.f) o[j] *= drop_scale(p.seed, e * p.C + c + j, p.drop_p);
+      if (p.drop_p > 0.f) o[j] *= drop_scale(drop_seed_v, e * p.C + c + j, p.drop_p);
     }
     if (p.res) {
       const float4 r = *reinterpret_cast<const float4*>(p.res + e * p.rescs + c);
@@ -340,6 +347,7 @@ __global__ __launch_bounds__(256) void in_fused_fwd_kernel(NAp p) {
 
 template <int CG, int NP>
 __global__ __launch_bounds__(256) void in_fused_bwd_kernel(NAp p) {
+  const uint64_t drop_seed_v = na_seed(p);
   constexpr int C4 = CG / 4, ROWS = 256 / C4;
   __shared__ double red[256 * 8];
   const int t = threadIdx.x, tx = t % C4, ty = t / C4;
@@ -370,7 +378,7 @@ __global__ __launch_bounds__(256) void in_fused_bwd_kernel(NAp p) {
       for (int j = 0; j < 4; ++j) {
         const float xh = (xa[j] - mean[j]) * rstd[j];                  // the forward's value (selects the activation branch)
         g[j] *= act_grad_from_in(xh, p.act);
-        if (p.drop_p > 0.f) g[j] *= drop_scale(p.seed, e * p.C + c + j, p.drop_p);
+        if (p.drop_p > 0.f) g[j] *= drop_scale(drop_seed_v, e * p.C + c + j, p.drop_p);
         s[j] += g[j];
         s[4 + j] += (double)g[j] * (((double)xa[j] - (double)mean[j]) * (double)rstd[j]);
       }
@@ -572,7 +580,7 @@ void norm_act_fwd(Stream& s, const NormActArgs& a) {
   p.res = a.residual ? a.residual->p : nullptr; p.rescs = a.residual ? a.residual->cs : 0;
   p.stats = a.stats; p.N = a.x.N; p.HW = a.x.H * a.x.W; p.C = a.x.C;
   p.norm = a.norm; p.act = a.act; p.drop_p = a.drop_p; p.seed = a.seed;
-  p.amax_out = a.amax_out;
+  p.amax_out = a.amax_out; p.seed_base = a.seed_base; p.salt = a.salt;
   if (a.norm && !a.stats) throw Error(1, "norm_act_fwd: stats buffer required");
   if (a.norm && p.HW <= 1024 && p.C % 32 == 0 && fused_in_on()) {
     const dim3 grid(p.C / 32, p.N);
@@ -603,7 +611,7 @@ void norm_act_bwd(Stream& s, const NormActBwdArgs& a) {
   p.stats = const_cast<float*>(a.stats); p.N = a.x.N; p.HW = a.x.H * a.x.W; p.C = a.x.C;
   p.norm = a.norm; p.act = a.act; p.drop_p = a.drop_p; p.seed = a.seed;
   p.colsum = a.colsum;
-  p.amax_out = a.amax_out;
+  p.amax_out = a.amax_out; p.seed_base = a.seed_base; p.salt = a.salt;
   if (a.colsum && !(a.norm && norm_act_bwd_emits_colsum(p.HW, p.C))) throw Error(1, "norm_act_bwd: colsum requested on the chunked path");
   if (a.norm && p.HW <= 1024 && p.C % 32 == 0 && fused_in_on()) {
     if (p.HW <= 64) hipLaunchKernelGGL((in_fused_bwd_kernel<32, 2>), dim3(p.C / 32, p.N), dim3(256), 0, hs(s), p);

@@ -206,6 +206,10 @@ struct NormActArgs {
   uint64_t seed = 0;          // dropout stream for this call (ignored if drop_p==0)
   const TView* residual = nullptr;   // y = ... + residual
   float* amax_out = nullptr;  // optional amax slot of y (see wino_input_transform)
+  // captured training step (engine.h Model::step_captured): the step seed is read from device memory, so that one recorded
+  // launch sequence serves every step -- the kernels use *seed_base * 0x9E3779B1 + salt (= Net::drop_seed) instead of `seed`
+  const uint64_t* seed_base = nullptr;
+  uint64_t salt = 0;
 };
 void norm_act_fwd(Stream& s, const NormActArgs& a);
 
@@ -222,6 +226,8 @@ struct NormActBwdArgs {
   // slab is in registers.  Written only by launches for which norm_act_bwd_emits_colsum(H * W, C) holds.
   double* colsum = nullptr;
   float* amax_out = nullptr;  // optional amax slot of dx
+  const uint64_t* seed_base = nullptr;   // as NormActArgs
+  uint64_t salt = 0;
 };
 void norm_act_bwd(Stream& s, const NormActBwdArgs& a);
 bool norm_act_bwd_emits_colsum(int HW, int C);
@@ -287,9 +293,11 @@ void labels_to_onehot(Stream& s, const int32_t* labels, const TView& y, int C); 
 // ---- losses: each writes the plain MEAN loss into *loss_out (device float) and, if a grad
 // view is given, scale * d(mean loss)/dx into it (scale carries lambda and the 0.5 of loss_D).
 // BCEWithLogits(pred, label) mean over N*H*W of channel 0;  dpred = scale*(sigmoid-t)/numel
+// label_dev (optional): the label is read from device memory instead (captured training step)
 void bce_logits_loss(Stream& s, const TView& pred, float label, float scale, float* loss_out,
-                     const TView* dpred);
-void lsgan_loss(Stream& s, const TView& pred, float label, float scale, float* loss_out, const TView* dpred);
+                     const TView* dpred, const float* label_dev = nullptr);
+void lsgan_loss(Stream& s, const TView& pred, float label, float scale, float* loss_out, const TView* dpred,
+                const float* label_dev = nullptr);
 void wgan_loss(Stream& s, const TView& pred, float sign, float scale, float* loss_out, const TView* dpred);
 // CrossEntropy(logits, argmax_c(target)) mean over pixels; dlogits (+)= scale*(softmax-onehot)/P
 void ce_argmax_loss(Stream& s, const TView& logits, const TView& target, int C, float scale,
@@ -339,8 +347,12 @@ struct AdamWArgs {
   float* p; const float* g; float* m; float* v; size_t n;
   float lr, beta1, beta2, eps, weight_decay;
   int step;   // 1-based
+  // optional (captured training step): {lr / (1 - beta1^step), 1 / sqrt(1 - beta2^step)} of THIS step in device memory, as
+  // adamw_schedule computes them; `step` is then ignored
+  const float* sched_dev = nullptr;
 };
 void adamw_step(Stream& s, const AdamWArgs& a);
+void adamw_schedule(float lr, float beta1, float beta2, int step, float out[2]);
 
 enum WKind : int { WK_CONV = 0, WK_CONVT = 1 };
 // Packed weight layouts (all [K][Npad], row-major):

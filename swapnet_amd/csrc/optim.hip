@@ -10,6 +10,7 @@ namespace swn {
 namespace {
 
 __global__ __launch_bounds__(256) void adamw_kernel(AdamWArgs a, float decay, float step_size, float inv_sqrt_bc2) {
+  if (a.sched_dev) { step_size = a.sched_dev[0]; inv_sqrt_bc2 = a.sched_dev[1]; }      // captured step: this step's bias corrections
   const size_t n4 = a.n / 4;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
     float4 p = reinterpret_cast<float4*>(a.p)[i];
@@ -190,13 +191,19 @@ inline unsigned blocks(size_t n) { return (unsigned)((n + 255) / 256); }
 
 }  // namespace
 
+void adamw_schedule(float lr, float beta1, float beta2, int step, float out[2]) {
+  const double bc1 = 1.0 - pow((double)beta1, step);
+  const double bc2 = 1.0 - pow((double)beta2, step);
+  out[0] = (float)(lr / bc1);
+  out[1] = (float)(1.0 / sqrt(bc2));
+}
 void adamw_step(Stream& s, const AdamWArgs& a) {
   if (a.n % 4) throw Error(1, "adamw_step: arena size must be a multiple of 4");
-  const double bc1 = 1.0 - pow((double)a.beta1, a.step);
-  const double bc2 = 1.0 - pow((double)a.beta2, a.step);
+  float sched[2];
+  adamw_schedule(a.lr, a.beta1, a.beta2, a.step, sched);
   const float decay = 1.f - a.lr * a.weight_decay;
-  const float step_size = (float)(a.lr / bc1);
-  const float inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
+  const float step_size = sched[0];
+  const float inv_sqrt_bc2 = sched[1];
   const unsigned grid = (unsigned)std::min<size_t>(std::max<size_t>((a.n / 4 + 255) / 256, 1), 256 * 16);
   hipLaunchKernelGGL(adamw_kernel, dim3(grid), dim3(256), 0, hs(s), a, decay, step_size, inv_sqrt_bc2);
   check_launch("adamw_step");

@@ -291,8 +291,8 @@ class TextureModel final : public Model {
     TView pf = pred2.batch(0, B).v, pr = pred2.batch(B, B).v;
     TView gf = pred2.batch(0, B).g, gr = pred2.batch(B, B).g;
     const float gs = 0.5f * hyper.grad_scale;
-    if (hyper.gan_mode == 0) { bce_logits_loss(s, pf, label_fake, gs, losses + L_D_FAKE, &gf); bce_logits_loss(s, pr, label_real, gs, losses + L_D_REAL, &gr); }
-    else if (hyper.gan_mode == 1) { lsgan_loss(s, pf, label_fake, gs, losses + L_D_FAKE, &gf); lsgan_loss(s, pr, label_real, gs, losses + L_D_REAL, &gr); }
+    if (hyper.gan_mode == 0) { bce_logits_loss(s, pf, label_fake, gs, losses + L_D_FAKE, &gf, label_dev(0)); bce_logits_loss(s, pr, label_real, gs, losses + L_D_REAL, &gr, label_dev(1)); }
+    else if (hyper.gan_mode == 1) { lsgan_loss(s, pf, label_fake, gs, losses + L_D_FAKE, &gf, label_dev(0)); lsgan_loss(s, pr, label_real, gs, losses + L_D_REAL, &gr, label_dev(1)); }
     else { wgan_loss(s, pf, 1.f, gs, losses + L_D_FAKE, &gf); wgan_loss(s, pr, -1.f, gs, losses + L_D_REAL, &gr); }
     scalar_axpby(s, losses + L_D_FAKE, 0.5f, losses + L_D_REAL, 0.5f, losses + L_D);
     D2->backward(true, false);
@@ -312,8 +312,8 @@ class TextureModel final : public Model {
     TView targets = Dx.batch(B, B).v.slice(0, 4);
     D1->refresh_dgrad();
     D1->forward();
-    if (hyper.gan_mode == 0) bce_logits_loss(s, pred1.v, label_real, hyper.lambda_gan * gsc, losses + L_TMP0, &pred1.g);
-    else if (hyper.gan_mode == 1) lsgan_loss(s, pred1.v, label_real, hyper.lambda_gan * gsc, losses + L_TMP0, &pred1.g);
+    if (hyper.gan_mode == 0) bce_logits_loss(s, pred1.v, label_real, hyper.lambda_gan * gsc, losses + L_TMP0, &pred1.g, label_dev(2));
+    else if (hyper.gan_mode == 1) lsgan_loss(s, pred1.v, label_real, hyper.lambda_gan * gsc, losses + L_TMP0, &pred1.g, label_dev(2));
     else wgan_loss(s, pred1.v, -1.f, hyper.lambda_gan * gsc, losses + L_TMP0, &pred1.g);
     scalar_axpby(s, losses + L_TMP0, hyper.lambda_gan, nullptr, 0.f, losses + L_G_GAN);
     D1->backward(false, true);                           // first writer of d(fakes)

@@ -364,9 +364,12 @@ class NativeModel:
     def optimizer_step_range(self, net, off, count, first):
         self.lib.call("swn_model_optimizer_step_range", self.handle, net, C.c_size_t(off), C.c_size_t(count), int(bool(first)))
 
-    def step(self, labels, training=True, seed=0):
+    def step(self, labels, training=True, seed=0, captured=False):
+        """One G+D optimize_parameters step.  captured=True: the hipGraph form (swn_model_step_captured) -- first call eager,
+        second records, later ones replay; bit-identical results."""
         arr = (C.c_float * 3)(*[float(x) for x in labels])
-        self.lib.call("swn_model_step", self.handle, C.byref(arr), int(training), C.c_uint64(seed))
+        self.lib.call("swn_model_step_captured" if captured else "swn_model_step", self.handle, C.byref(arr), int(training),
+                      C.c_uint64(seed))
 
     def losses(self):
         buf = (C.c_float * len(_C.LOSS_NAMES))()

@@ -3,6 +3,8 @@ GANLoss / optimizer wiring and `optimize_parameters` -- here one fused native st
 from abc import ABC, abstractmethod
 from argparse import ArgumentParser
 
+import os
+
 import torch
 
 from .. import engine, modules, optimizers, parallel
@@ -165,7 +167,8 @@ class BaseGAN(BaseModel, ABC):
         labels = self._draw_labels()
         self.optimizer_G.sync(); self.optimizer_D.sync()          # live param_groups (lr schedulers)
         if self.world == 1:
-            m.step(labels, training=training, seed=seed)
+            # SWAPNET_CAPTURED_STEP=1: the step as a recorded hipGraph (swn_model_step_captured; bit-identical results)
+            m.step(labels, training=training, seed=seed, captured=os.environ.get("SWAPNET_CAPTURED_STEP") == "1")
         else:
             rank = torch.distributed.get_rank()
             labels = parallel.broadcast_floats(labels)          # rank 0's smooth-label draws on every rank

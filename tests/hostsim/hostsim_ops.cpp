@@ -662,7 +662,9 @@ void pool_pattern(Stream&, const TView& x, const TView& y, uint8_t* out) {
         }
 }
 
-void norm_act_fwd(Stream&, const NormActArgs& a) {
+void norm_act_fwd(Stream&, const NormActArgs& a0) {
+  NormActArgs a = a0;
+  if (a.seed_base) a.seed = *a.seed_base * 0x9E3779B1ull + a.salt;       // captured-step form of the seed (ops.h)
   const int N = a.x.N, HW = a.x.H * a.x.W, C = a.x.C;
   for (int n = 0; n < N; ++n)
     for (int c = 0; c < C; ++c) {
@@ -685,7 +687,9 @@ void norm_act_fwd(Stream&, const NormActArgs& a) {
     }
   sim_fold_view(a.amax_out, a.y);
 }
-void norm_act_bwd(Stream&, const NormActBwdArgs& a) {
+void norm_act_bwd(Stream&, const NormActBwdArgs& a0) {
+  NormActBwdArgs a = a0;
+  if (a.seed_base) a.seed = *a.seed_base * 0x9E3779B1ull + a.salt;
   const int N = a.x.N, HW = a.x.H * a.x.W, C = a.x.C;
   for (int n = 0; n < N; ++n)
     for (int c = 0; c < C; ++c) {
@@ -913,8 +917,8 @@ static void gan(const TView& pred, float label, float scale, float* out, const T
   }
   *out = (float)(acc / n);
 }
-void bce_logits_loss(Stream&, const TView& p, float l, float s, float* o, const TView* d) { gan(p, l, s, o, d, 0); }
-void lsgan_loss(Stream&, const TView& p, float l, float s, float* o, const TView* d) { gan(p, l, s, o, d, 1); }
+void bce_logits_loss(Stream&, const TView& p, float l, float s, float* o, const TView* d, const float* ld) { gan(p, ld ? *ld : l, s, o, d, 0); }
+void lsgan_loss(Stream&, const TView& p, float l, float s, float* o, const TView* d, const float* ld) { gan(p, ld ? *ld : l, s, o, d, 1); }
 void wgan_loss(Stream&, const TView& p, float l, float s, float* o, const TView* d) { gan(p, l, s, o, d, 2); }
 
 void ce_argmax_loss(Stream&, const TView& lg, const TView& tg, int C, float scale, float* out, const TView* dl, int accumulate) {
@@ -1048,9 +1052,15 @@ void scalar_axpby(Stream&, const float* a, float ca, const float* b, float cb, f
 }
 
 // ---- optimizer / layouts -----------------------------------------------------------------
+void adamw_schedule(float lr, float beta1, float beta2, int step, float out[2]) {
+  const double bc1 = 1.0 - std::pow((double)beta1, step), bc2 = 1.0 - std::pow((double)beta2, step);
+  out[0] = (float)(lr / bc1); out[1] = (float)(1.0 / std::sqrt(bc2));
+}
 void adamw_step(Stream&, const AdamWArgs& a) {  // (elementwise: threads split the arena)
-  const double bc1 = 1.0 - std::pow((double)a.beta1, a.step), bc2 = 1.0 - std::pow((double)a.beta2, a.step);
-  const float decay = 1.f - a.lr * a.weight_decay, ss = (float)(a.lr / bc1), isb = (float)(1.0 / std::sqrt(bc2));
+  float sched[2];
+  adamw_schedule(a.lr, a.beta1, a.beta2, a.step, sched);
+  if (a.sched_dev) { sched[0] = a.sched_dev[0]; sched[1] = a.sched_dev[1]; }
+  const float decay = 1.f - a.lr * a.weight_decay, ss = sched[0], isb = sched[1];
 #pragma omp parallel for
   for (long i = 0; i < (long)a.n; ++i) {
     float p = a.p[i] * decay;

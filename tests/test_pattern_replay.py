@@ -19,7 +19,8 @@ from tests.test_train_parity import BACKENDS, _ctx, _phased_step, _texture_case,
 TOL = 1e-4
 
 
-def _warp_replay(ctx, B, H, seed, training, labels=(0.9, 0.8, 1.0), drop_seed=77, check_route=False, tol=TOL, tol_fwd=2e-5):
+def _warp_replay(ctx, B, H, seed, training, labels=(0.9, 0.8, 1.0), drop_seed=77, check_route=False, tol=TOL, tol_fwd=2e-5,
+                 flip_fraction=1e-3):
     torch.manual_seed(seed)
     G, D = O.warp_module_params(), O.patchgan_params(22)
     batch = O.synth_warp_batch(B, H, H, seed=99)
@@ -37,7 +38,7 @@ def _warp_replay(ctx, B, H, seed, training, labels=(0.9, 0.8, 1.0), drop_seed=77
         s64 = O.WarpStepOracle(G, D, training=O.MaskReplay(masks) if training else False, dtype=torch.float64)
         s64.patterns = replay
         s64.step(*batch, labels=list(labels))
-        flips = replay.check()
+        flips = replay.check(max_fraction=flip_fraction)
         wD = backends.assert_grads_replayed(gD, s64.grads_D, lambda k: noise_bias(k, list(s64.grads_D)), tol, ("warp", H, "D"))
         wG = backends.assert_grads_replayed(gG, s64.grads_G, lambda k: noise_bias(k, list(s64.grads_G)), tol, ("warp", H, "G"))
         assert rel(m.output(), s64.fakes) < tol_fwd, rel(m.output(), s64.fakes)
@@ -161,7 +162,7 @@ import sys
 sys.path.insert(0, %(repo)r)
 from tests import backends
 from tests.test_pattern_replay import _warp_replay
-flips, wD, wG = _warp_replay(backends.gpu_ctx(), 2, 256, 3, True, tol=1.0, tol_fwd=1.0)
+flips, wD, wG = _warp_replay(backends.gpu_ctx(), 2, 256, 3, True, tol=1.0, tol_fwd=1.0, flip_fraction=0.05)
 print("F16RESULT %%g %%g %%g" %% (wD, wG, _warp_replay.last_forward_error), flips)
 """
 
