@@ -1900,7 +1900,11 @@ struct DmaWgTile {
 // SPLIT: 0 = v_mfma_f32_32x32x2_f32, 1 = three bf16 planes per operand (six MFMAs per product), 2 = two fp16 planes of the operands
 // scaled by powers of two from their amax (three MFMAs; x_amax / dy_amax: 256 floats each whose maximum is the operand's amax),
 // 3 = ONE fp16 plane of the scaled operands (one MFMA: the reduced-precision configuration)
-template <int WGM, int WGN, int SPLIT>
+// PLANE: both operands are plain [M][C] matrices (the batched Winograd-domain reductions dU[p] = V[p]^T dM[p]: 1x1 taps, stride 1,
+// no padding, output map = the row index).  The generic loader recomputes the im2col source of every piece every stage (~90 VALU
+// + ~60 SALU per wave and stage, measured: the wave spends 41 % of its time issuing, 123 % of a SIMD's port at 3 waves); here a
+// piece's offset is a per-lane constant and the stage advances through the scalar offset of the buffer load.
+template <int WGM, int WGN, int SPLIT, bool PLANE = false>
 __global__ __launch_bounds__(64 * WGM * WGN) void conv_wgrad_dma_kernel(GemmP p, DmaSched sc, const float* x_amax, const float* dy_amax) {
 #if defined(__HIP_DEVICE_COMPILE__)
   using T = DmaWgTile<WGM, WGN>;
@@ -1962,8 +1966,26 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_wgrad_dma_kernel(GemmP p,
     c_oy = rem / p.Wo; c_ox = rem - c_oy * p.Wo;
   }
   const int rows_per_stage = wide ? 0 : PX / p.Wo;
+  // PLANE: per-lane byte offsets of the lane's pieces inside a stage (pixel j of the stage, its 16-byte chunk); out of range = zero fill
+  unsigned pa_voff[AI], pb_voff[BI];
+  unsigned p_stage = (unsigned)mb_begin;          // next stage to issue
+  if constexpr (PLANE) {
+#pragma unroll
+    for (int r = 0; r < AI; ++r) pa_voff[r] = kvalid ? (unsigned)(a_dx[r] * p.xcs + ak) * 4u : DMA_OOB;
+#pragma unroll
+    for (int r = 0; r < BI; ++r) pb_voff[r] = nvalid ? (unsigned)(b_dx[r] * p.ycs + bn) * 4u : DMA_OOB;
+  }
   auto issue = [&](int st) {
     const unsigned As = lds0 + (unsigned)(st * T::ST_FL) * 4u, Bs = As + T::A_FL * 4u;
+    if constexpr (PLANE) {
+      const unsigned sa = p_stage * (unsigned)(PX * 4) * (unsigned)p.xcs, sb = p_stage * (unsigned)(PX * 4) * (unsigned)p.ycs;
+#pragma unroll
+      for (int r = 0; r < AI; ++r) lds_dma16c(pa_voff[r], rsA, sa, As + (unsigned)(wid * AI + r) * 1024u);
+#pragma unroll
+      for (int r = 0; r < BI; ++r) lds_dma16c(pb_voff[r], rsB, sb, Bs + (unsigned)(wid * BI + r) * 1024u);
+      p_stage += 1;
+      return;
+    }
     const int xin = c_n * p.xH * p.xW, yin = c_n * p.yH;
 #pragma unroll
     for (int r = 0; r < AI; ++r) {
@@ -2788,15 +2810,25 @@ static void launch_wgrad_dma(Stream& s, GemmP& p, int nb, const ConvWgradArgs& a
   static bool once = (set_smem(conv_wgrad_dma_kernel<WGM, WGN, 2>, T::SMEM), set_smem(conv_wgrad_dma_kernel<WGM, WGN, 1>, T::SMEM),
                       set_smem(conv_wgrad_dma_kernel<WGM, WGN, 0>, T::SMEM), set_smem(conv_wgrad_dma_kernel<WGM, WGN, 3>, T::SMEM), true);
   (void)once;
+  // plain [M][C] operands (batched Winograd planes): the loader without im2col arithmetic.  SWN_WGRAD_PLANE=0: generic (A/B runs)
+  const bool plane = p.KH == 1 && p.KW == 1 && p.stride == 1 && p.pad_t == 0 && p.pad_l == 0 && !p.ups && !p.phases && p.Ho == 1 &&
+                     p.Wo % T::PX == 0 && p.xH == 1 && p.yH == 1 && p.xW == p.Wo && p.yW == p.Wo && p.ymul == 1 && p.xmul == 1 &&
+                     p.yoff == 0 && p.xoff == 0 && p.M == p.Wo && !(getenv("SWN_WGRAD_PLANE") && atoi(getenv("SWN_WGRAD_PLANE")) == 0);
+  const bool plane_name = two && wpl == 2 && plane;
   char pname[128];
   if (prof_detail())
-    snprintf(pname, sizeof pname, "conv_wgrad_dma_%dx%d%s[M%d,N%d,K%d,b%d,full%d,tail%dx%d]", T::BMK, T::BN, two ? (wpl == 1 ? "_h1" : "_h2") : "", p.M, p.Cout, p.K, nb,
+    snprintf(pname, sizeof pname, "conv_wgrad_dma_%dx%d%s[M%d,N%d,K%d,b%d,full%d,tail%dx%d]", T::BMK, T::BN, two ? (wpl == 1 ? "_h1" : (plane_name ? "_h2p" : "_h2")) : "", p.M, p.Cout, p.K, nb,
              sc.full, sc.tail_tiles, sc.tail_s);
   else
     snprintf(pname, sizeof pname, "conv_wgrad_dma_%dx%d", T::BMK, T::BN);
   ProfScope prof(s, pname, 2.0 * p.M * p.Cout * p.K * nb);
   const int units = sc.full + sc.tail_tiles * sc.tail_s;
-  if (two && wpl == 1) hipLaunchKernelGGL((conv_wgrad_dma_kernel<WGM, WGN, 3>), dim3(units), dim3(64 * T::NW), T::SMEM, hs(s), p, sc, xa, ya);
+  if (two && wpl == 2 && plane) {
+    static bool once2 = (set_smem(conv_wgrad_dma_kernel<WGM, WGN, 2, true>, T::SMEM), true);
+    (void)once2;
+    hipLaunchKernelGGL((conv_wgrad_dma_kernel<WGM, WGN, 2, true>), dim3(units), dim3(64 * T::NW), T::SMEM, hs(s), p, sc, xa, ya);
+  }
+  else if (two && wpl == 1) hipLaunchKernelGGL((conv_wgrad_dma_kernel<WGM, WGN, 3>), dim3(units), dim3(64 * T::NW), T::SMEM, hs(s), p, sc, xa, ya);
   else if (two) hipLaunchKernelGGL((conv_wgrad_dma_kernel<WGM, WGN, 2>), dim3(units), dim3(64 * T::NW), T::SMEM, hs(s), p, sc, xa, ya);
   else if (split_on()) hipLaunchKernelGGL((conv_wgrad_dma_kernel<WGM, WGN, 1>), dim3(units), dim3(64 * T::NW), T::SMEM, hs(s), p, sc, xa, ya);
   else hipLaunchKernelGGL((conv_wgrad_dma_kernel<WGM, WGN, 0>), dim3(units), dim3(64 * T::NW), T::SMEM, hs(s), p, sc, xa, ya);
