@@ -494,7 +494,7 @@ def main():
         res["h2d_bytes_per_step"] = {"onehot_fp32": sum(t.numel() * 4 for t in host),
                                      "label_maps": host[0].numel() * 4 + sum(t.numel() * 4 for t in labels)}
         out["h2d_inclusive"] = res
-    if rank == 0:
+    if rank == 0 and not args.no_roofline:      # (the PMC passes of profiles/ run with --no-roofline: exactly the timed steps)
         # which kernel every layer launched (swn_route_trace): the digest the parity tests compare their own runs with
         # (tests/backends.py assert_default_routing), and the switches that were set in this process
         import hashlib
