@@ -735,6 +735,16 @@ __device__ __forceinline__ void split8h_rn(const float* v, float sa, u32x4& hi, 
     lo[q] = __builtin_bit_cast(unsigned, f16x2{(_Float16)r0, (_Float16)r1});
   }
 }
+// operand stored in PAIR form by its producer (wino.hip pair_word: {h | l << 16} per element): the two MFMA operands of 8
+// consecutive k are byte permutes of the 8 words -- 8 VALU instead of the 32 of split8h
+__device__ __forceinline__ void pair8(const float* w, u32x4& hi, u32x4& lo) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const unsigned w0 = __float_as_uint(w[2 * q]), w1 = __float_as_uint(w[2 * q + 1]);
+    hi[q] = __builtin_amdgcn_perm(w1, w0, 0x05040100u);                 // {w1[15:0], w0[15:0]}
+    lo[q] = __builtin_amdgcn_perm(w1, w0, 0x07060302u);                 // {w1[31:16], w0[31:16]}
+  }
+}
 // ONE fp16 plane (SWN_PC_PLANES=1 / SWN_WGRAD_PLANES=1, the reduced-precision configuration): h = fp16(x * 2^k) rounded to
 // nearest, the low plane is not formed -- one MFMA per product, operands carry 11 mantissa bits (bf16 carries 8)
 __device__ __forceinline__ void split8h1(const float* v, float sa, u32x4& hi) {
@@ -832,9 +842,10 @@ struct PcTile {
 };
 
 // WGCU = workgroups per CU the tile is sized for (LDS) -> waves per SIMD the register allocation must allow
-template <int WGM, int NB, int NSTG, int WGCU, int PL>
+// APAIR: the activation operand arrives in pair form (a_kscale = the exponent its producer scaled it by): no cut in the loop
+template <int WGM, int NB, int NSTG, int WGCU, int PL, bool APAIR = false>
 __global__ __launch_bounds__(64 * WGM, WGCU * WGM / 4) void conv_fwd_pc_kernel(GemmP p, DmaSched sc, const unsigned short* wpc, size_t wpc_bs,
-                                                                               const float* a_amax) {
+                                                                               const float* a_amax, const int* a_kscale) {
 #if defined(__HIP_DEVICE_COMPILE__)
   using T = PcTile<WGM, NB, NSTG, PL>;
   constexpr int BM = T::BM, BN = T::BN, BK = T::BK, NST = T::NST, AI = T::AI, BI = T::BI, BREM = T::BREM;
@@ -868,7 +879,8 @@ __global__ __launch_bounds__(64 * WGM, WGCU * WGM / 4) void conv_fwd_pc_kernel(G
   // two-plane form: the power-of-two operand scales (A from the partial maxima of this launch, B from the panel's trailer)
   int kA = 0, kB = 0;
   if constexpr (PL <= 2) {
-    kA = __builtin_amdgcn_readfirstlane(scale_exp(amax256(a_amax, lane), PC_TOP_A));
+    if constexpr (APAIR) kA = __builtin_amdgcn_readfirstlane(*a_kscale);
+    else kA = __builtin_amdgcn_readfirstlane(scale_exp(amax256(a_amax, lane), PC_TOP_A));
     kB = *reinterpret_cast<const int*>(wpc + (size_t)nkb_all * (b_stage / 2));
   }
   const float sa = pow2f(kA);
@@ -959,7 +971,8 @@ __global__ __launch_bounds__(64 * WGM, WGCU * WGM / 4) void conv_fwd_pc_kernel(G
         bl[j] = *reinterpret_cast<const u32x4*>(S + b_rd + (1 * BN + 32 * j) * 16);
       }
       u32x4 ah, al;
-      split8h(af, sa, ah, al);
+      if constexpr (APAIR) pair8(af, ah, al);
+      else split8h(af, sa, ah, al);
 #pragma unroll
       for (int j = 0; j < NB; ++j) {
         f32x16 c = acc[j];
@@ -1904,7 +1917,8 @@ struct DmaWgTile {
 // no padding, output map = the row index).  The generic loader recomputes the im2col source of every piece every stage (~90 VALU
 // + ~60 SALU per wave and stage, measured: the wave spends 41 % of its time issuing, 123 % of a SIMD's port at 3 waves); here a
 // piece's offset is a per-lane constant and the stage advances through the scalar offset of the buffer load.
-template <int WGM, int WGN, int SPLIT, bool PLANE = false>
+// PAIR (bit 0: x, bit 1: dy): that operand is stored in pair form, x_amax / dy_amax then point at the int exponent of its producer
+template <int WGM, int WGN, int SPLIT, bool PLANE = false, int PAIR = 0>
 __global__ __launch_bounds__(64 * WGM * WGN) void conv_wgrad_dma_kernel(GemmP p, DmaSched sc, const float* x_amax, const float* dy_amax) {
 #if defined(__HIP_DEVICE_COMPILE__)
   using T = DmaWgTile<WGM, WGN>;
@@ -2021,8 +2035,10 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_wgrad_dma_kernel(GemmP p,
 
   int kx = 0, ky = 0;
   if constexpr (SPLIT >= 2) {
-    kx = __builtin_amdgcn_readfirstlane(scale_exp(amax256(x_amax, lane), PC_TOP_A));
-    ky = __builtin_amdgcn_readfirstlane(scale_exp(amax256(dy_amax, lane), PC_TOP_A));
+    if constexpr (PAIR & 1) kx = __builtin_amdgcn_readfirstlane(*reinterpret_cast<const int*>(x_amax));
+    else kx = __builtin_amdgcn_readfirstlane(scale_exp(amax256(x_amax, lane), PC_TOP_A));
+    if constexpr (PAIR & 2) ky = __builtin_amdgcn_readfirstlane(*reinterpret_cast<const int*>(dy_amax));
+    else ky = __builtin_amdgcn_readfirstlane(scale_exp(amax256(dy_amax, lane), PC_TOP_A));
   }
   const float sx = pow2f(kx), sy = pow2f(ky);
   const int h = lane >> 5, l31 = lane & 31;
@@ -2040,6 +2056,21 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_wgrad_dma_kernel(GemmP p,
     }
     if constexpr (SPLIT == 3) {
       split_mma_2x2_h1(acc, af, bf, sx, sy);
+    } else if constexpr (SPLIT == 2 && PAIR != 0) {
+      u32x4 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        if constexpr (PAIR & 1) pair8(af[i], ah[i], al[i]); else split8h(af[i], sx, ah[i], al[i]);
+        if constexpr (PAIR & 2) pair8(bf[i], bh[i], bl[i]); else split8h_rn(bf[i], sy, bh[i], bl[i]);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          f32x16 c = acc[i][j];
+          c = mma_f16(al[i], bh[j], c); c = mma_f16(ah[i], bl[j], c); c = mma_f16(ah[i], bh[j], c);
+          acc[i][j] = c;
+        }
     } else if constexpr (SPLIT == 2) {
       split_mma_2x2_h(acc, af, bf, sx, sy);
     } else if constexpr (SPLIT == 1) {
@@ -2471,6 +2502,8 @@ static bool dma_on() {
 static int g_force_naive = 0;
 void conv_force_naive(int on) { g_force_naive = on; }
 
+// SWN_AMAX_FUSED=0: every launch takes the amax of its operands itself (A/B against the producer-side slots; read per launch)
+static bool amax_fused_on() { return !(getenv("SWN_AMAX_FUSED") && atoi(getenv("SWN_AMAX_FUSED")) == 0); }
 // ---- pre-cut ring kernel: schedule + launch ------------------------------------------------------------------------
 static bool pc_on() {
   const bool on = !(getenv("SWN_PRECUT") && atoi(getenv("SWN_PRECUT")) == 0);      // read per launch (tests / A-B runs)
@@ -2486,6 +2519,10 @@ static int pc_planes() {
   return pl;
 }
 int conv_precut_planes() { return pc_planes(); }
+bool wino_pair_planes() {
+  static const bool off = getenv("SWN_PAIR") && atoi(getenv("SWN_PAIR")) == 0;
+  return !off && pc_planes() == 2 && dma_on() && split_on() && !g_force_naive && amax_fused_on();
+}
 static int pc_stages() {
   const char* e = getenv("SWN_PC_STAGES");
   const int v = e ? atoi(e) : 2;
@@ -2498,8 +2535,6 @@ static float* ws_amax(Stream& s, int which) {
   if (!s.ws || s.ws_bytes < (1u << 20)) throw Error(1, "two-plane pre-cut kernels need the stream scratch");
   return reinterpret_cast<float*>(s.ws + s.ws_bytes - PC_WS_TAIL + (size_t)which * 1024);
 }
-// SWN_AMAX_FUSED=0: every launch takes the amax of its operands itself (A/B against the producer-side slots; read per launch)
-static bool amax_fused_on() { return !(getenv("SWN_AMAX_FUSED") && atoi(getenv("SWN_AMAX_FUSED")) == 0); }
 static void amax_partials(Stream& s, const float* x, size_t rows, int C, size_t rs, int batch, size_t bs, float* out, int fold = 0,
                           float floor = 0.f) {
   if (C % 4 || rs % 4 || bs % 4 || ((uintptr_t)x & 15)) throw Error(1, "amax_partials: operand not 16-byte aligned");
@@ -2508,7 +2543,8 @@ static void amax_partials(Stream& s, const float* x, size_t rows, int C, size_t 
   check_launch("amax_partials");
 }
 template <int WGM, int NB, int NSTG, int WGCU, int PL>
-static void launch_fwd_pc(Stream& s, GemmP& p, int nb, const unsigned short* wpc, size_t wpc_bs, bool phases, const float* x_amax) {
+static void launch_fwd_pc(Stream& s, GemmP& p, int nb, const unsigned short* wpc, size_t wpc_bs, bool phases, const float* x_amax,
+                          const int* x_pair_k = nullptr) {
   using T = PcTile<WGM, NB, NSTG, PL>;
   const int tiles_m = ceil_div(p.M, T::BM);
   p.tiles_n = ceil_div(p.Npad, T::BN);
@@ -2517,7 +2553,10 @@ static void launch_fwd_pc(Stream& s, GemmP& p, int nb, const unsigned short* wpc
   static_assert(wg * T::SMEM <= 160 * 1024, "tile does not fit a CU");
   const size_t ws_cap = PL <= 2 ? s.ws_bytes - PC_WS_TAIL : s.ws_bytes;
   const float* a_amax = nullptr;
-  if (PL <= 2 && x_amax && amax_fused_on()) {
+  if (x_pair_k && PL != 2) throw Error(1, "conv_fwd: a pair-form operand needs the two-plane kernel");
+  if (x_pair_k) {
+    // (the producer scaled and cut the operand: nothing to take the amax of)
+  } else if (PL <= 2 && x_amax && amax_fused_on()) {
     a_amax = x_amax;          // the producer of the operand left its amax (256 floats, maximum = amax) in a slot: no pass of our own
   } else if (PL <= 2) {
     // |A|max over the whole input tensor of the launch (all images, all channels the gather reads; batched planes too)
@@ -2550,14 +2589,27 @@ static void launch_fwd_pc(Stream& s, GemmP& p, int nb, const unsigned short* wpc
   (void)once;
   char pname[112];
   if (prof_detail())
-    snprintf(pname, sizeof pname, "conv_fwd_pc_%dx%d[M%d,N%d,K%d,b%d,full%d,tail%dx%d]", T::BM, T::BN, p.M, p.Cout, p.K, nb, sc.full,
+    snprintf(pname, sizeof pname, "conv_fwd_pc_%dx%d%s[M%d,N%d,K%d,b%d,full%d,tail%dx%d]", T::BM, T::BN, x_pair_k ? "_ap" : "", p.M, p.Cout, p.K, nb, sc.full,
              sc.tail_tiles, sc.tail_s);
   else
     snprintf(pname, sizeof pname, "conv_fwd_pc_%dx%d", T::BM, T::BN);
   ProfScope prof(s, pname, 2.0 * p.M * p.Cout * p.K * nb);
   const int units = sc.full + sc.tail_tiles * sc.tail_s;
-  hipLaunchKernelGGL((conv_fwd_pc_kernel<WGM, NB, NSTG, WGCU, PL>), dim3(units), dim3(64 * T::NW), T::SMEM, hs(s), p, sc, wpc, wpc_bs,
-                     a_amax);
+  if constexpr (PL == 2 && NSTG <= 3) {
+    if (x_pair_k) {
+      static bool once2 = (set_smem(conv_fwd_pc_kernel<WGM, NB, NSTG, WGCU, 2, true>, T::SMEM), true);
+      (void)once2;
+      hipLaunchKernelGGL((conv_fwd_pc_kernel<WGM, NB, NSTG, WGCU, 2, true>), dim3(units), dim3(64 * T::NW), T::SMEM, hs(s), p, sc, wpc, wpc_bs,
+                         a_amax, x_pair_k);
+    } else {
+      hipLaunchKernelGGL((conv_fwd_pc_kernel<WGM, NB, NSTG, WGCU, PL>), dim3(units), dim3(64 * T::NW), T::SMEM, hs(s), p, sc, wpc, wpc_bs,
+                         a_amax, x_pair_k);
+    }
+  } else {
+    if (x_pair_k) throw Error(1, "conv_fwd: no pair-form instantiation of this tile configuration");
+    hipLaunchKernelGGL((conv_fwd_pc_kernel<WGM, NB, NSTG, WGCU, PL>), dim3(units), dim3(64 * T::NW), T::SMEM, hs(s), p, sc, wpc, wpc_bs,
+                       a_amax, x_pair_k);
+  }
   check_launch("conv_fwd_pc");
   if (sc.tail_tiles > 0 && sc.tail_s > 1) {
     hipLaunchKernelGGL((conv_dma_reduce_kernel<T::BM, T::BN>), dim3(T::BM * T::BN / 4 / 256, sc.tail_tiles), dim3(256), 0, hs(s), p, sc);
@@ -2684,16 +2736,16 @@ void conv_fwd(Stream& s, const ConvFwdArgs& a) {
         return;
       }
       if (pc_planes() == 2) {
-        if (a.wpc_bn == 192) launch_fwd_pc<4, 6, 2, 2, 2>(s, p, nb, a.wpc, a.wpc_bs, ph, a.x_amax);
+        if (a.wpc_bn == 192) launch_fwd_pc<4, 6, 2, 2, 2>(s, p, nb, a.wpc, a.wpc_bs, ph, a.x_amax, a.x_pair_k);
         else if (a.Npad > 64) {
           // 128 x 128: LDS stages x workgroups per CU.  2 x 4 (round 3: 64 KB in flight per CU), 3 x 3 (96 KB in flight, two stages of
           // prefetch distance), 4 x 2.  SWN_PC_STAGES selects (A/B runs; read per launch)
           const int stg = pc_stages();
-          if (stg == 3) launch_fwd_pc<4, 4, 3, 3, 2>(s, p, nb, a.wpc, a.wpc_bs, ph, a.x_amax);
-          else if (stg == 4) launch_fwd_pc<4, 4, 4, 2, 2>(s, p, nb, a.wpc, a.wpc_bs, ph, a.x_amax);
-          else launch_fwd_pc<4, 4, 2, 4, 2>(s, p, nb, a.wpc, a.wpc_bs, ph, a.x_amax);
+          if (stg == 3) launch_fwd_pc<4, 4, 3, 3, 2>(s, p, nb, a.wpc, a.wpc_bs, ph, a.x_amax, a.x_pair_k);
+          else if (stg == 4 && !a.x_pair_k) launch_fwd_pc<4, 4, 4, 2, 2>(s, p, nb, a.wpc, a.wpc_bs, ph, a.x_amax);
+          else launch_fwd_pc<4, 4, 2, 4, 2>(s, p, nb, a.wpc, a.wpc_bs, ph, a.x_amax, a.x_pair_k);
         }
-        else launch_fwd_pc<8, 2, 3, 2, 2>(s, p, nb, a.wpc, a.wpc_bs, ph, a.x_amax);
+        else launch_fwd_pc<8, 2, 3, 2, 2>(s, p, nb, a.wpc, a.wpc_bs, ph, a.x_amax, a.x_pair_k);
         return;
       }
       if (a.wpc_bn == 192) launch_fwd_pc<4, 6, 2, 2, 3>(s, p, nb, a.wpc, a.wpc_bs, ph, nullptr);   // 128 x 192, 2 stages, 2 workgroups / CU
@@ -2703,6 +2755,7 @@ void conv_fwd(Stream& s, const ConvFwdArgs& a) {
     }
     if (!a.w) throw Error(1, "conv_fwd: the weight operand exists in pre-cut form only, but this launch cannot take the pre-cut "
                              "kernel (SWN_SPLIT / SWN_PRECUT / SWN_DMA must not change after a model is built)");
+    if (a.x_pair_k) throw Error(1, "conv_fwd: pair-form operand on a launch outside the pre-cut ring kernel");
     p.y_amax = nullptr;
     if (a.Npad > 64) {
       // 128 x 128 (4 waves, 3 workgroups / CU) unless the 128 x 256 tile (8 waves, 2 / CU: 512 slots instead of 768)
@@ -2720,6 +2773,7 @@ void conv_fwd(Stream& s, const ConvFwdArgs& a) {
     return;
   }
   if (!a.w) throw Error(1, "conv_fwd: pre-cut-only weight operand on a launch outside the ring kernel's shapes");
+  if (a.x_pair_k) throw Error(1, "conv_fwd: pair-form operand on a launch outside the pre-cut ring kernel");
   p.y_amax = nullptr;
   // every register-staged route: the amax of the output, if asked for, by a pass behind the launch
   if (t192 && a.Npad > 128 && a.Npad <= 192) launch_fwd<2, 3, 2, 2>(s, p, fast, nb);
@@ -2799,9 +2853,11 @@ static void launch_wgrad_dma(Stream& s, GemmP& p, int nb, const ConvWgradArgs& a
     const int nbb = a.phases ? 1 : nb;
     const size_t nimg = (size_t)(p.M / (p.Ho * p.Wo));
     const bool fused = amax_fused_on();
-    if (a.x_amax && fused) xa = a.x_amax;
+    if (a.x_pair_k) xa = reinterpret_cast<const float*>(a.x_pair_k);
+    else if (a.x_amax && fused) xa = a.x_amax;
     else { float* px = ws_amax(s, 0); amax_partials(s, a.x.p, nimg * a.x.H * a.x.W, a.x.C, (size_t)a.x.cs, nbb, a.x_bs, px); xa = px; }
-    if (a.dy_amax && fused) ya = a.dy_amax;
+    if (a.dy_pair_k) ya = reinterpret_cast<const float*>(a.dy_pair_k);
+    else if (a.dy_amax && fused) ya = a.dy_amax;
     else { float* py = ws_amax(s, 1); amax_partials(s, a.dy.p, nimg * a.dy.H * a.dy.W, a.dy.C, (size_t)a.dy.cs, nbb, a.dy_bs, py); ya = py; }
   }
   const DmaSched sc = plan_dma(p.ntiles * nb, p.ntiles, nmb, 256 * wg_per_cu, (size_t)T::BMK * T::BN * 4, two ? s.ws_bytes - PC_WS_TAIL : s.ws_bytes);
@@ -2815,18 +2871,26 @@ static void launch_wgrad_dma(Stream& s, GemmP& p, int nb, const ConvWgradArgs& a
                      p.Wo % T::PX == 0 && p.xH == 1 && p.yH == 1 && p.xW == p.Wo && p.yW == p.Wo && p.ymul == 1 && p.xmul == 1 &&
                      p.yoff == 0 && p.xoff == 0 && p.M == p.Wo && !(getenv("SWN_WGRAD_PLANE") && atoi(getenv("SWN_WGRAD_PLANE")) == 0);
   const bool plane_name = two && wpl == 2 && plane;
+  const int pair_name = (a.x_pair_k ? 1 : 0) | (a.dy_pair_k ? 2 : 0);
   char pname[128];
   if (prof_detail())
-    snprintf(pname, sizeof pname, "conv_wgrad_dma_%dx%d%s[M%d,N%d,K%d,b%d,full%d,tail%dx%d]", T::BMK, T::BN, two ? (wpl == 1 ? "_h1" : (plane_name ? "_h2p" : "_h2")) : "", p.M, p.Cout, p.K, nb,
+    snprintf(pname, sizeof pname, "conv_wgrad_dma_%dx%d%s[M%d,N%d,K%d,b%d,full%d,tail%dx%d]", T::BMK, T::BN, two ? (wpl == 1 ? "_h1" : (plane_name ? (pair_name == 3 ? "_h2pp" : (pair_name ? "_h2p1" : "_h2p")) : "_h2")) : "", p.M, p.Cout, p.K, nb,
              sc.full, sc.tail_tiles, sc.tail_s);
   else
     snprintf(pname, sizeof pname, "conv_wgrad_dma_%dx%d", T::BMK, T::BN);
   ProfScope prof(s, pname, 2.0 * p.M * p.Cout * p.K * nb);
   const int units = sc.full + sc.tail_tiles * sc.tail_s;
+  const int pairm = (a.x_pair_k ? 1 : 0) | (a.dy_pair_k ? 2 : 0);
+  if (pairm && !(two && wpl == 2 && plane)) throw Error(1, "conv_wgrad: pair-form operands need the two-plane plane-form kernel");
   if (two && wpl == 2 && plane) {
-    static bool once2 = (set_smem(conv_wgrad_dma_kernel<WGM, WGN, 2, true>, T::SMEM), true);
+    static bool once2 = (set_smem(conv_wgrad_dma_kernel<WGM, WGN, 2, true, 0>, T::SMEM), set_smem(conv_wgrad_dma_kernel<WGM, WGN, 2, true, 1>, T::SMEM),
+                         set_smem(conv_wgrad_dma_kernel<WGM, WGN, 2, true, 2>, T::SMEM), set_smem(conv_wgrad_dma_kernel<WGM, WGN, 2, true, 3>, T::SMEM), true);
     (void)once2;
-    hipLaunchKernelGGL((conv_wgrad_dma_kernel<WGM, WGN, 2, true>), dim3(units), dim3(64 * T::NW), T::SMEM, hs(s), p, sc, xa, ya);
+    const dim3 g(units), b(64 * T::NW);
+    if (pairm == 3) hipLaunchKernelGGL((conv_wgrad_dma_kernel<WGM, WGN, 2, true, 3>), g, b, T::SMEM, hs(s), p, sc, xa, ya);
+    else if (pairm == 2) hipLaunchKernelGGL((conv_wgrad_dma_kernel<WGM, WGN, 2, true, 2>), g, b, T::SMEM, hs(s), p, sc, xa, ya);
+    else if (pairm == 1) hipLaunchKernelGGL((conv_wgrad_dma_kernel<WGM, WGN, 2, true, 1>), g, b, T::SMEM, hs(s), p, sc, xa, ya);
+    else hipLaunchKernelGGL((conv_wgrad_dma_kernel<WGM, WGN, 2, true, 0>), g, b, T::SMEM, hs(s), p, sc, xa, ya);
   }
   else if (two && wpl == 1) hipLaunchKernelGGL((conv_wgrad_dma_kernel<WGM, WGN, 3>), dim3(units), dim3(64 * T::NW), T::SMEM, hs(s), p, sc, xa, ya);
   else if (two) hipLaunchKernelGGL((conv_wgrad_dma_kernel<WGM, WGN, 2>), dim3(units), dim3(64 * T::NW), T::SMEM, hs(s), p, sc, xa, ya);
@@ -2837,6 +2901,16 @@ static void launch_wgrad_dma(Stream& s, GemmP& p, int nb, const ConvWgradArgs& a
     hipLaunchKernelGGL((wgrad_dma_reduce_kernel<T::BMK, T::BN>), dim3(T::BMK * T::BN / 4 / 256, sc.tail_tiles), dim3(256), 0, hs(s), p, sc);
     check_launch("wgrad_dma_reduce");
   }
+}
+// ops.h: would a batched plane launch with these dimensions take the kernels that read pair-form operands?  (The engine decides the
+// storage form of a layer's Winograd planes with these when the layer is built; the launchers re-check and throw on a mismatch.)
+bool conv_fwd_takes_pairs(int xC, int Npad) { return wino_pair_planes() && conv_precut_tile(xC, Npad) != 0; }
+bool conv_wgrad_takes_pairs(size_t T, int K, int Npad) {
+  if (!wino_pair_planes() || wgrad_planes() != 2 || Npad <= 32 || K % 4 || Npad % 4 || T % 16 || T * (size_t)std::max(K, Npad) * 4 >= ((size_t)1 << 31))
+    return false;
+  const int bmk = Npad > 64 ? 128 : 256;
+  const double fillf = (double)K / (double)(ceil_div(K, bmk) * bmk);
+  return fillf > 0.8 || (bmk == 128 && fillf >= 0.75);
 }
 // stage geometry the LDS-DMA wgrad kernel needs: 16 consecutive pixels inside one image at fixed offsets from the first
 static bool wgrad_dma_ok(const ConvWgradArgs& a, const GemmP& p) {
@@ -2900,6 +2974,7 @@ void conv_wgrad(Stream& s, const ConvWgradArgs& a) {
     else launch_wgrad_dma<4, 1>(s, p, nb, a);                // 256 x 64
     return;
   }
+  if (a.x_pair_k || a.dy_pair_k) throw Error(1, "conv_wgrad: pair-form operands on a launch outside the ring kernel");
   // 8-wave 256x128 tile: +3 % on the single-GEMM layers, -7 % on the batched Winograd planes (measured)
   if (a.Npad > 64 && big && p.K >= 512 && nb == 1) launch_wgrad<2, 2, 4, 2>(s, p, nb);
   else if (a.Npad > 64) launch_wgrad<2, 2, 2, 2>(s, p, nb);

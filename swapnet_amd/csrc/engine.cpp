@@ -317,6 +317,12 @@ void Net::conv(const std::string& name, const Var& x, const Var& y, ConvKind kin
     const size_t pcf_off = pcf ? reserve_dgp(pcf_bs * sP) : 0, pct_off = pct ? reserve_dgp(pct_bs * sP) : 0;
     const size_t slV = reserve_slot(), slD = reserve_slot();      // amax of V (forward planes) and of dM (transformed dY)
     note_writer(y.vbase, false);
+    // pair-form planes (ops.h wino_input_transform) where every GEMM that reads them takes the kernels that can, and -- decided
+    // per pass -- the transform's input has a complete amax slot to bound the planes with
+    const bool pairV_ok = conv_fwd_takes_pairs(CV, Cop) && (!y.has_grad || conv_wgrad_takes_pairs(sT, CV, Cop));
+    const bool pairD_ok = conv_wgrad_takes_pairs(sT, CV, Cop) && (!(x.has_grad && y.has_grad) || conv_fwd_takes_pairs(Cop, CV));
+    const size_t kV = reserve_k(), kD = reserve_k();
+    const float* xbase = x.vbase; const float* ygbase = y.gbase;
     // dM = A dY A^T serves the weight gradient (side stream) and the input gradient (main stream): one buffer per layer
     float* keepdM = (y.has_grad && want_dx && share_dy()) ? static_cast<float*>(ctx.alloc(sP * sT * Cop * sizeof(float))) : nullptr;
     op->repack = [=](Net& n) {
@@ -331,13 +337,14 @@ void Net::conv(const std::string& name, const Var& x, const Var& y, ConvKind kin
     op->fwd = [=](Net& n) {
       n.need(self);
       float* V = keepV ? keepV : n.wsV;
-      wino_s2_input_transform(n.ctx.s, xv, sTh, sTw, V, n.amax + slV);
+      const float* xin = pairV_ok ? n.slot_if_complete(xbase) : nullptr;
+      wino_s2_input_transform(n.ctx.s, xv, sTh, sTw, V, n.amax + slV, xin, n.kscale + kV);
       ConvFwdArgs g;
       g.x = plane_mat(V, sT, CV); g.g.Ho = 1; g.g.Wo = (int)sT;
       g.w = n.dg + uf_off; g.Npad = Cop; g.Cout = Co;
       g.y = plane_mat(n.wsM, sT, Cop);
       g.batch = sP; g.x_bs = sT * CV; g.w_bs = (size_t)CV * Cop; g.y_bs = sT * Cop;
-      g.x_amax = n.amax + slV;
+      if (xin) g.x_pair_k = n.kscale + kV; else g.x_amax = n.amax + slV;
       if (pcf) { g.wpc = n.dgp + pcf_off; g.wpc_bn = pcf; g.wpc_bs = pcf_bs; }
       conv_fwd(n.ctx.s, g);
       wino_output_transform(n.ctx.s, 4, 2, n.wsM, Cop, sTh, sTw, bi >= 0 ? A->w + A->params[bi].off : nullptr, actf, yv, Co, 0);
@@ -350,36 +357,40 @@ void Net::conv(const std::string& name, const Var& x, const Var& y, ConvKind kin
     op->bwd = [=](Net& n, Op& me, bool wgrad, bool igrad) {
       if (!has_ygrad) return;
       TView dY = ygv;
+      // (a fused activation's dR has no amax slot in this branch: its planes stay fp32 and the GEMM takes their amax)
       if (actf != ACT_NONE) { act_bwd(n.ctx.s, ygv, yv, scr, actf, 0); dY = scr; }
       const ParamDesc& wd = A->params[wi];
       const bool dx_now = want_dx && !(me.reads_net_input && !igrad);
       const bool shared = keepdM && wgrad && dx_now;       // one transform of dY on the main stream, read by both gradients
-      if (shared) wino_dy_transform(n.ctx.s, 4, 2, dY, sTh, sTw, keepdM, n.amax + slD);
+      const float* xin = pairV_ok ? n.slot_if_complete(xbase) : nullptr;
+      const float* din = (pairD_ok && actf == ACT_NONE) ? n.slot_if_complete(ygbase) : nullptr;
+      if (shared) wino_dy_transform(n.ctx.s, 4, 2, dY, sTh, sTw, keepdM, n.amax + slD, din, n.kscale + kD);
       if (wgrad) {
         Stream& sw = n.wgrad_stream();
         float* V = keepV ? keepV : n.wsV;
         float* dM = shared ? keepdM : n.wgrad_planes(sw);
-        if (!keepV) wino_s2_input_transform(sw, xv, sTh, sTw, V, n.amax + slV);
-        if (!shared) wino_dy_transform(sw, 4, 2, dY, sTh, sTw, dM, n.amax + slD);
+        if (!keepV) wino_s2_input_transform(sw, xv, sTh, sTw, V, n.amax + slV, xin, n.kscale + kV);
+        if (!shared) wino_dy_transform(sw, 4, 2, dY, sTh, sTw, dM, n.amax + slD, din, n.kscale + kD);
         ConvWgradArgs g;
         g.x = plane_mat(V, sT, CV); g.g.Ho = 1; g.g.Wo = (int)sT;
         g.dy = plane_mat(dM, sT, Cop);
         g.dw = n.wsU; g.Npad = Cop; g.Cout = Co;
         g.batch = sP; g.x_bs = sT * CV; g.dy_bs = sT * Cop; g.dw_bs = (size_t)CV * Cop;
-        g.x_amax = n.amax + slV; g.dy_amax = n.amax + slD;
+        if (xin) g.x_pair_k = n.kscale + kV; else g.x_amax = n.amax + slV;
+        if (din) g.dy_pair_k = n.kscale + kD; else g.dy_amax = n.amax + slD;
         conv_wgrad(sw, g);
         wino_s2_filter_grad(sw, wd.ws, n.wsU, A->g + wd.off);
         if (bi >= 0) n.bias_grad_of(sw, dY, A->g + A->params[bi].off);
       }
       if (!dx_now) return;
       float* dMx = shared ? keepdM : n.wsV;
-      if (!shared) wino_dy_transform(n.ctx.s, 4, 2, dY, sTh, sTw, dMx, n.amax + slD);
+      if (!shared) wino_dy_transform(n.ctx.s, 4, 2, dY, sTh, sTw, dMx, n.amax + slD, din, n.kscale + kD);
       ConvFwdArgs g;
       g.x = plane_mat(dMx, sT, Cop); g.g.Ho = 1; g.g.Wo = (int)sT;
       g.w = n.dg + ut_off; g.Npad = CV; g.Cout = CV;
       g.y = plane_mat(n.wsM, sT, CV);
       g.batch = sP; g.x_bs = sT * Cop; g.w_bs = (size_t)Cop * CV; g.y_bs = sT * CV;
-      g.x_amax = n.amax + slD;
+      if (din) g.x_pair_k = n.kscale + kD; else g.x_amax = n.amax + slD;
       if (pct) { g.wpc = n.dgp + pct_off; g.wpc_bn = pct; g.wpc_bs = pct_bs; }
       conv_fwd(n.ctx.s, g);
       wino_s2_input_adjoint(n.ctx.s, n.wsM, Cip, sTh, sTw, xgv, nullptr, me.acc.empty() ? 0 : me.acc[0]);
@@ -408,6 +419,10 @@ void Net::conv(const std::string& name, const Var& x, const Var& y, ConvKind kin
       const size_t pcu_bs = pcu ? conv_precut_elems(Cip, N4, pcu) : 0, pcu_off = pcu ? reserve_dgp(pcu_bs * tP) : 0;
       const size_t slV = reserve_slot(), slD = reserve_slot();
       note_writer(y.vbase, false);
+      const bool pairV_ok = conv_fwd_takes_pairs(Cip, N4) && (!y.has_grad || conv_wgrad_takes_pairs(tT, Cip, N4));
+      const bool pairD_ok = conv_wgrad_takes_pairs(tT, Cip, N4);
+      const size_t kV = reserve_k(), kD = reserve_k();
+      const float* xbase = x.vbase;
       // input gradient: the folded 5x5 stride-2 conv over dR (32-channel buffer, see CopD below)
       const bool want_dx = x.has_grad && y.has_grad;
       const int CopD = (actf != ACT_NONE && want_dx && conv_precut_tile(32, Cip) == 192) ? 32 : Cop;
@@ -427,13 +442,14 @@ void Net::conv(const std::string& name, const Var& x, const Var& y, ConvKind kin
       op->fwd = [=](Net& n) {
         n.need(self);
         float* V = keepV ? keepV : n.wsV;
-        wino_input_transform(n.ctx.s, 4, 3, xv, 1, PAD_ZERO, tTh, tTw, V, n.amax + slV);
+        const float* xin = pairV_ok ? n.slot_if_complete(xbase) : nullptr;
+        wino_input_transform(n.ctx.s, 4, 3, xv, 1, PAD_ZERO, tTh, tTw, V, n.amax + slV, xin, n.kscale + kV);
         ConvFwdArgs g;
         g.x = plane_mat(V, tT, Cip); g.g.Ho = 1; g.g.Wo = (int)tT;
         g.w = n.dg + tu_off; g.Npad = N4; g.Cout = N4;
         g.y = plane_mat(n.wsM, tT, N4);
         g.batch = tP; g.x_bs = tT * Cip; g.w_bs = (size_t)Cip * N4; g.y_bs = tT * N4;
-        g.x_amax = n.amax + slV;
+        if (xin) g.x_pair_k = n.kscale + kV; else g.x_amax = n.amax + slV;
         if (pcu) { g.wpc = n.dgp + pcu_off; g.wpc_bn = pcu; g.wpc_bs = pcu_bs; }
         conv_fwd(n.ctx.s, g);
         tailw_output_transform(n.ctx.s, n.wsM, tTh, tTw, Cop, bi >= 0 ? A->w + A->params[bi].off : nullptr, actf, yv, Co);
@@ -454,14 +470,17 @@ void Net::conv(const std::string& name, const Var& x, const Var& y, ConvKind kin
           Stream& sw = n.wgrad_stream();
           float* V = keepV ? keepV : n.wsV;
           float* dM = n.wgrad_planes(sw);
-          if (!keepV) wino_input_transform(sw, 4, 3, xv, 1, PAD_ZERO, tTh, tTw, V, n.amax + slV);
-          tailw_dy_transform(sw, dY, tTh, tTw, Cop, dM, n.amax + slD);
+          const float* xin = pairV_ok ? n.slot_if_complete(xbase) : nullptr;
+          const float* din = pairD_ok ? dy_slot : nullptr;
+          if (!keepV) wino_input_transform(sw, 4, 3, xv, 1, PAD_ZERO, tTh, tTw, V, n.amax + slV, xin, n.kscale + kV);
+          tailw_dy_transform(sw, dY, tTh, tTw, Cop, dM, n.amax + slD, din, n.kscale + kD);
           ConvWgradArgs g;
           g.x = plane_mat(V, tT, Cip); g.g.Ho = 1; g.g.Wo = (int)tT;
           g.dy = plane_mat(dM, tT, N4);
           g.dw = n.wsU; g.Npad = N4; g.Cout = N4;
           g.batch = tP; g.x_bs = tT * Cip; g.dy_bs = tT * N4; g.dw_bs = (size_t)Cip * N4;
-          g.x_amax = n.amax + slV; g.dy_amax = n.amax + slD;
+          if (xin) g.x_pair_k = n.kscale + kV; else g.x_amax = n.amax + slV;
+          if (din) g.dy_pair_k = n.kscale + kD; else g.dy_amax = n.amax + slD;
           conv_wgrad(sw, g);
           tailw_filter_grad(sw, wd.ws, n.wsU, n.dg + dfold_off);
           tail_unfold_wgrad(sw, wd.ws, n.dg + dfold_off, A->g + wd.off);
@@ -535,6 +554,13 @@ void Net::conv(const std::string& name, const Var& x, const Var& y, ConvKind kin
   // transposed-conv form of the input gradient); the 6-point forms only (F(2,3) planes feed the fp32-operand kernels)
   const bool wslots = wino && wm != 2;
   const size_t slV = wslots ? reserve_slot() : 0, slD = wslots ? reserve_slot() : 0, slX = wslots ? reserve_slot() : 0;
+  // pair-form planes (ops.h wino_input_transform): V feeds the forward GEMM and the weight gradient, dM the weight gradient and
+  // the adjoint-form input gradient, dX (transposed-conv form of the input gradient) its one GEMM
+  const bool wgrad_pairs = wslots && conv_wgrad_takes_pairs(wT, Cip, Cop);
+  const bool pairV_ok = wslots && conv_fwd_takes_pairs(Cip, Cop) && (!y.has_grad || wgrad_pairs);
+  const bool pairD_ok = wslots && wgrad_pairs && (!(wadj && x.has_grad && y.has_grad) || conv_fwd_takes_pairs(Cop, Cip));
+  const bool pairX_ok = wslots && conv_fwd_takes_pairs(Cop, Cip);
+  const size_t kV = wslots ? reserve_k() : 0, kD = wslots ? reserve_k() : 0, kX = wslots ? reserve_k() : 0;
   float* keepdM = nullptr;        // dM = A dY A^T, shared by the weight gradient (side stream) and the adjoint-form input gradient
   if (wino && wadj && y.has_grad && x.has_grad && share_dy()) keepdM = static_cast<float*>(ctx.alloc((size_t)wP * wT * Cop * sizeof(float)));
   if (wino) {
@@ -569,11 +595,12 @@ void Net::conv(const std::string& name, const Var& x, const Var& y, ConvKind kin
     if (wino) {
       n.need(self);
       float* V = keepV ? keepV : n.wsV;
-      wino_input_transform(n.ctx.s, wm, wr, xv, 1, gf.pad_mode, wTh, wTw, V, wslots ? n.amax + slV : nullptr);
+      const float* xin = pairV_ok ? n.slot_if_complete(xbase) : nullptr;
+      wino_input_transform(n.ctx.s, wm, wr, xv, 1, gf.pad_mode, wTh, wTw, V, wslots ? n.amax + slV : nullptr, xin, n.kscale + kV);
       ConvFwdArgs g;
       g.x = plane_view(V, wT, Cip); g.g.Ho = 1; g.g.Wo = (int)wT;
       g.w = pcw ? nullptr : n.dg + uf_off; g.Npad = Cop; g.Cout = Co;
-      if (wslots) g.x_amax = n.amax + slV;
+      if (xin) g.x_pair_k = n.kscale + kV; else if (wslots) g.x_amax = n.amax + slV;
       if (pcw) { g.wpc = n.dgp + pcw_off; g.wpc_bn = pcw; g.wpc_bs = pcw_bs; }
       g.y = plane_view(n.wsM, wT, Cop);
       g.batch = wP; g.x_bs = wT * Cip; g.w_bs = (size_t)Cip * Cop; g.y_bs = wT * Cop;
@@ -685,7 +712,9 @@ void Net::conv(const std::string& name, const Var& x, const Var& y, ConvKind kin
     // adjoint-form layers: the weight gradient and the input gradient multiply by the same dM planes -- transformed once, on the
     // main stream, into the layer's own buffer (the side stream reads it while the main stream moves on)
     const bool shared = keepdM && wino && wadj && wgrad && dx_now;
-    if (shared) wino_dy_transform(n.ctx.s, wm, wr, dY, wTh, wTw, keepdM, wslots ? n.amax + slD : nullptr);
+    const float* xin = pairV_ok ? n.slot_if_complete(xbase) : nullptr;
+    const float* din = pairD_ok ? dy_slot : nullptr;            // amax of dY bounds its planes
+    if (shared) wino_dy_transform(n.ctx.s, wm, wr, dY, wTh, wTw, keepdM, wslots ? n.amax + slD : nullptr, din, n.kscale + kD);
     if (wgrad) {
       Stream& sw = n.wgrad_stream();          // dY is final: the weight-gradient work may run beside the dgrad chain
       ConvWgradArgs wa;
@@ -695,14 +724,15 @@ void Net::conv(const std::string& name, const Var& x, const Var& y, ConvKind kin
         // dU[t] = V[t]^T dM[t] (wP batched reductions over the tiles), then dW = G^T dU G
         float* V = keepV ? keepV : n.wsV;
         float* dM = shared ? keepdM : n.wgrad_planes(sw);
-        if (!keepV) wino_input_transform(sw, wm, wr, xv, 1, gf.pad_mode, wTh, wTw, V, wslots ? n.amax + slV : nullptr);
-        if (!shared) wino_dy_transform(sw, wm, wr, dY, wTh, wTw, dM, wslots ? n.amax + slD : nullptr);
+        if (!keepV) wino_input_transform(sw, wm, wr, xv, 1, gf.pad_mode, wTh, wTw, V, wslots ? n.amax + slV : nullptr, xin, n.kscale + kV);
+        if (!shared) wino_dy_transform(sw, wm, wr, dY, wTh, wTw, dM, wslots ? n.amax + slD : nullptr, din, n.kscale + kD);
         ConvWgradArgs g;
         g.x = plane_view(V, wT, Cip); g.g.Ho = 1; g.g.Wo = (int)wT;
         g.dy = plane_view(dM, wT, Cop);
         g.dw = n.wsU; g.Npad = Cop; g.Cout = Co;
         g.batch = wP; g.x_bs = wT * Cip; g.dy_bs = wT * Cop; g.dw_bs = (size_t)Cip * Cop;
-        if (wslots) { g.x_amax = n.amax + slV; g.dy_amax = n.amax + slD; }
+        if (xin) g.x_pair_k = n.kscale + kV; else if (wslots) g.x_amax = n.amax + slV;
+        if (din) g.dy_pair_k = n.kscale + kD; else if (wslots) g.dy_amax = n.amax + slD;
         conv_wgrad(sw, g);
         wino_filter_grad(sw, wm, wr, wd.ws, n.wsU, A->g + wd.off);
       } else if (!folded) {
@@ -721,11 +751,12 @@ void Net::conv(const std::string& name, const Var& x, const Var& y, ConvKind kin
     const int accf = me.acc.empty() ? 0 : me.acc[0];
     if (wino && !wadj) {
       // input gradient = the transposed stride-1 conv over dY (flipped, channel-transposed filter)
-      wino_input_transform(n.ctx.s, wm, wr, dY, wpad2, PAD_ZERO, wTh2, wTw2, n.wsV, wslots ? n.amax + slX : nullptr);
+      const float* xdin = pairX_ok ? dy_slot : nullptr;
+      wino_input_transform(n.ctx.s, wm, wr, dY, wpad2, PAD_ZERO, wTh2, wTw2, n.wsV, wslots ? n.amax + slX : nullptr, xdin, n.kscale + kX);
       ConvFwdArgs g;
       g.x = plane_view(n.wsV, wT2, Cop); g.g.Ho = 1; g.g.Wo = (int)wT2;
       g.w = pcwt ? nullptr : n.dg + ub_off; g.Npad = Cip; g.Cout = Cip;
-      if (wslots) g.x_amax = n.amax + slX;
+      if (xdin) g.x_pair_k = n.kscale + kX; else if (wslots) g.x_amax = n.amax + slX;
       if (pcwt) { g.wpc = n.dgp + pcwt_off; g.wpc_bn = pcwt; g.wpc_bs = pcwt_bs; }
       g.y = plane_view(n.wsM, wT2, Cip);
       g.batch = wP; g.x_bs = wT2 * Cop; g.w_bs = (size_t)Cop * Cip; g.y_bs = wT2 * Cip;
@@ -742,11 +773,11 @@ void Net::conv(const std::string& name, const Var& x, const Var& y, ConvKind kin
       // input gradient in the forward tiling: dM = A dY A^T, dV = dM U^T (U with the channel axes swapped), then the adjoint
       // of the input transform scatters the patches BT^T dV BT back through the forward gather (padding rule included)
       float* dMx = shared ? keepdM : n.wsV;
-      if (!shared) wino_dy_transform(n.ctx.s, wm, wr, dY, wTh, wTw, dMx, wslots ? n.amax + slD : nullptr);
+      if (!shared) wino_dy_transform(n.ctx.s, wm, wr, dY, wTh, wTw, dMx, wslots ? n.amax + slD : nullptr, din, n.kscale + kD);
       ConvFwdArgs g;
       g.x = plane_view(dMx, wT, Cop); g.g.Ho = 1; g.g.Wo = (int)wT;
       g.w = pcwt ? nullptr : n.dg + ub_off; g.Npad = Cip; g.Cout = Cip;
-      if (wslots) g.x_amax = n.amax + slD;
+      if (din) g.x_pair_k = n.kscale + kD; else if (wslots) g.x_amax = n.amax + slD;
       if (pcwt) { g.wpc = n.dgp + pcwt_off; g.wpc_bn = pcwt; g.wpc_bs = pcwt_bs; }
       g.y = plane_view(n.wsM, wT, Cip);
       g.batch = wP; g.x_bs = wT * Cop; g.w_bs = (size_t)Cop * Cip; g.y_bs = wT * Cip;
@@ -814,6 +845,10 @@ void Net::convT(const std::string& name, const Var& x, const Var& y, int Co, boo
     const size_t pct_bs = pct ? conv_precut_elems(Cip, CV, pct) : 0, pcf_bs = pcf ? conv_precut_elems(CV, Cip, pcf) : 0;
     const size_t pct_off = pct ? reserve_dgp(pct_bs * sP) : 0, pcf_off = pcf ? reserve_dgp(pcf_bs * sP) : 0;
     const size_t slM = reserve_slot(), slV = reserve_slot();     // amax of dM (planes of the coarse input) and of V (planes of dY, fine)
+    const bool wg_pairs = conv_wgrad_takes_pairs(sT, CV, Cip);
+    const bool pairM_ok = conv_fwd_takes_pairs(Cip, CV) && (!y.has_grad || wg_pairs);
+    const bool pairV_ok = wg_pairs && (!(x.has_grad && y.has_grad) || conv_fwd_takes_pairs(CV, Cip));
+    const size_t kM = reserve_k(), kVg = reserve_k();
     // V = polyphase transform of dY serves the weight gradient (side stream) and the input gradient (main stream): one buffer per layer
     float* keepVg = (y.has_grad && want_dx && share_dy()) ? static_cast<float*>(ctx.alloc(sP * sT * CV * sizeof(float))) : nullptr;
     op->repack = [=](Net& n) {
@@ -830,13 +865,14 @@ void Net::convT(const std::string& name, const Var& x, const Var& y, int Co, boo
       const ParamDesc& wd = A->params[wi];
       (void)wd;
       float* dM = keepM ? keepM : n.wsV;
-      wino_dy_transform(n.ctx.s, 4, 2, xv, sTh, sTw, dM, n.amax + slM);
+      const float* xin = pairM_ok ? n.slot_if_complete(xbase) : nullptr;
+      wino_dy_transform(n.ctx.s, 4, 2, xv, sTh, sTw, dM, n.amax + slM, xin, n.kscale + kM);
       ConvFwdArgs g;
       g.x = plane_mat(dM, sT, Cip); g.g.Ho = 1; g.g.Wo = (int)sT;
       g.w = n.dg + ut_off; g.Npad = CV; g.Cout = CV;
       g.y = plane_mat(n.wsM, sT, CV);
       g.batch = sP; g.x_bs = sT * Cip; g.w_bs = (size_t)Cip * CV; g.y_bs = sT * CV;
-      g.x_amax = n.amax + slM;
+      if (xin) g.x_pair_k = n.kscale + kM; else g.x_amax = n.amax + slM;
       if (pct) { g.wpc = n.dgp + pct_off; g.wpc_bn = pct; g.wpc_bs = pct_bs; }
       conv_fwd(n.ctx.s, g);
       wino_s2_input_adjoint(n.ctx.s, n.wsM, Cop, sTh, sTw, yv, bi >= 0 ? A->w + A->params[bi].off : nullptr, 0);
@@ -848,33 +884,36 @@ void Net::convT(const std::string& name, const Var& x, const Var& y, int Co, boo
       const ParamDesc& wd = A->params[wi];
       const bool dx_now = want_dx && !(me.reads_net_input && !igrad);
       const bool shared = keepVg && wgrad && dx_now;
-      if (shared) wino_s2_input_transform(n.ctx.s, ygv, sTh, sTw, keepVg, n.amax + slV);
+      const float* xin = pairM_ok ? n.slot_if_complete(xbase) : nullptr;
+      const float* din = pairV_ok ? n.slot_if_complete(ygbase) : nullptr;
+      if (shared) wino_s2_input_transform(n.ctx.s, ygv, sTh, sTw, keepVg, n.amax + slV, din, n.kscale + kVg);
       if (wgrad) {
         // dU[25][4 Cop][Cip] = V(dY fine)^T dM(x coarse)
         Stream& sw = n.wgrad_stream();
         float* V = shared ? keepVg : n.wgrad_planes(sw);
         float* dM = keepM ? keepM : n.wsV;
-        if (!shared) wino_s2_input_transform(sw, ygv, sTh, sTw, V, n.amax + slV);
-        if (!keepM) wino_dy_transform(sw, 4, 2, xv, sTh, sTw, dM, n.amax + slM);
+        if (!shared) wino_s2_input_transform(sw, ygv, sTh, sTw, V, n.amax + slV, din, n.kscale + kVg);
+        if (!keepM) wino_dy_transform(sw, 4, 2, xv, sTh, sTw, dM, n.amax + slM, xin, n.kscale + kM);
         ConvWgradArgs g;
         g.x = plane_mat(V, sT, CV); g.g.Ho = 1; g.g.Wo = (int)sT;
         g.dy = plane_mat(dM, sT, Cip);
         g.dw = n.wsU; g.Npad = Cip; g.Cout = Cip;
         g.batch = sP; g.x_bs = sT * CV; g.dy_bs = sT * Cip; g.dw_bs = (size_t)CV * Cip;
-        g.x_amax = n.amax + slV; g.dy_amax = n.amax + slM;
+        if (din) g.x_pair_k = n.kscale + kVg; else g.x_amax = n.amax + slV;
+        if (xin) g.dy_pair_k = n.kscale + kM; else g.dy_amax = n.amax + slM;
         conv_wgrad(sw, g);
         wino_s2_filter_grad(sw, wd.ws, n.wsU, A->g + wd.off);
         if (bi >= 0) n.bias_grad_of(sw, ygv, A->g + A->params[bi].off);
       }
       if (!dx_now) return;
       float* Vx = shared ? keepVg : n.wsV;
-      if (!shared) wino_s2_input_transform(n.ctx.s, ygv, sTh, sTw, Vx, n.amax + slV);
+      if (!shared) wino_s2_input_transform(n.ctx.s, ygv, sTh, sTw, Vx, n.amax + slV, din, n.kscale + kVg);
       ConvFwdArgs g;
       g.x = plane_mat(Vx, sT, CV); g.g.Ho = 1; g.g.Wo = (int)sT;
       g.w = n.dg + uf_off; g.Npad = Cip; g.Cout = Cip;
       g.y = plane_mat(n.wsM, sT, Cip);
       g.batch = sP; g.x_bs = sT * CV; g.w_bs = (size_t)CV * Cip; g.y_bs = sT * Cip;
-      g.x_amax = n.amax + slV;
+      if (din) g.x_pair_k = n.kscale + kVg; else g.x_amax = n.amax + slV;
       if (pcf) { g.wpc = n.dgp + pcf_off; g.wpc_bn = pcf; g.wpc_bs = pcf_bs; }
       conv_fwd(n.ctx.s, g);
       wino_output_transform(n.ctx.s, 4, 2, n.wsM, Cip, sTh, sTw, nullptr, ACT_NONE, xgv, Cip, me.acc.empty() ? 0 : me.acc[0]);
@@ -1091,6 +1130,7 @@ void Net::finalize(const std::vector<Var>& pre) {
   dg = dg_n ? static_cast<float*>(ctx.alloc(dg_n * sizeof(float))) : nullptr;
   dgp = dgp_n ? static_cast<uint16_t*>(ctx.alloc(dgp_n * sizeof(uint16_t))) : nullptr;
   amax = amax_n ? static_cast<float*>(ctx.alloc(amax_n * sizeof(float))) : nullptr;
+  kscale = kscale_n ? static_cast<int*>(ctx.alloc((kscale_n + 4) * sizeof(int))) : nullptr;
   if (wsM_need && ctx.has_side && keep_wino_inputs) wsM2 = static_cast<float*>(ctx.alloc(wsM_need * sizeof(float)));
   if (wsV_need) wsV = static_cast<float*>(ctx.alloc(wsV_need * sizeof(float)));
   if (wsM_need) wsM = static_cast<float*>(ctx.alloc(wsM_need * sizeof(float)));

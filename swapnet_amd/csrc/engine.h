@@ -139,6 +139,11 @@ class Net {
   float* amax = nullptr;
   size_t amax_n = 0;
   size_t reserve_slot() { const size_t off = amax_n; amax_n += AMAX_SLOT; return off; }
+  // scale exponents of Winograd planes stored in pair form (ops.h wino_input_transform): one device int per plane tensor,
+  // written by the transform, read by the GEMMs
+  int* kscale = nullptr;
+  size_t kscale_n = 0;
+  size_t reserve_k() { return kscale_n++; }
   // Registry of the amax slots of whole BUFFERS (activations, keyed by Var::vbase; gradients, by the pointer the backward
   // kernel writes): every op that writes into a buffer announces itself with note_writer(base, folds), folds = it leaves max |v|
   // of everything it writes in the buffer's slot.  A consumer may take its operand's scale from the slot only if EVERY writer

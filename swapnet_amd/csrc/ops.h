@@ -98,6 +98,8 @@ struct ConvFwdArgs {
   // gathers).  The two-plane kernels scale the operand by a power of two from it; without a slot the launch takes the amax itself
   // with a pass over x.  Producers that write the operand fill the slot for free (amax_out of the transforms below).
   const float* x_amax = nullptr;
+  // optional: the A operand is stored in PAIR form (see wino_input_transform): *x_pair_k = the exponent its producer scaled it by
+  const int* x_pair_k = nullptr;
   // optional: an amax slot the launch folds max |y| of everything it stores into -- in the epilogue of the pre-cut ring kernel
   // (and the reduce kernel of its split tiles), by a pass over the output view behind every other kernel family
   float* y_amax = nullptr;
@@ -136,7 +138,15 @@ struct ConvWgradArgs {
   int tail4 = 0;              // as in ConvFwdArgs; dw = the folded-gradient block (layout of tail_fold_weights)
   const float* x_amax = nullptr;      // amax slots of the two operands (as ConvFwdArgs::x_amax)
   const float* dy_amax = nullptr;
+  const int* x_pair_k = nullptr;      // operands stored in pair form (as ConvFwdArgs::x_pair_k): scale exponents of their producers
+  const int* dy_pair_k = nullptr;
 };
+// true when the library's transforms / GEMMs implement the pair form (the device build with two-plane operands; SWN_PAIR=0 disables)
+bool wino_pair_planes();
+// would a batched plane GEMM of these dimensions read pair-form operands? (forward-type: A = planes with xC channels into Npad
+// columns; weight-gradient: T rows reduced, K x Npad outputs).  False on the host simulator.
+bool conv_fwd_takes_pairs(int xC, int Npad);
+bool conv_wgrad_takes_pairs(size_t T, int K, int Npad);
 void conv_wgrad(Stream& s, const ConvWgradArgs& a);
 
 // reference implementations of the two launches above (one thread per output element,
@@ -158,8 +168,11 @@ void reflect_fold(Stream& s, const TView& dxpad, const TView& dx, int accumulate
 // amax_out (optional, here and below): an amax slot (AMAX_SLOT floats, zeroed by the caller before the first producer of a
 // tensor runs) into which the kernel folds max |v| over everything it writes: entry blockIdx % AMAX_SLOT, an atomic max on
 // the bit pattern (non-negative floats order like unsigned integers, so the slot's maximum is exact and order-independent)
+// in_amax / kscale_out (optional, the 6-point and strided forms): write the planes in PAIR form for the two-plane GEMMs -- each
+// element the 32-bit word {h | l << 16} of fp16 planes of (x 2^k), k derived from the amax slot `in_amax` of the transform's INPUT
+// through the transform's gain bound (wino.hip) and published in *kscale_out (device int) for the GEMM (ConvFwdArgs::x_pair_k)
 void wino_input_transform(Stream& s, int m, int r, const TView& x, int pad, int pad_mode, int Th, int Tw, float* V,
-                          float* amax_out = nullptr);                                                                  // V[P][T][x.C]
+                          float* amax_out = nullptr, const float* in_amax = nullptr, int* kscale_out = nullptr);        // V[P][T][x.C]
 // mode 0: U[P][Cip][Npad] for the forward conv; mode 1: U[P][Npad][Cip] (flipped, transposed) for the transposed-conv form of
 // dgrad; mode 2: U[P][Npad][Cip] = mode 0 with the channel axes swapped, the operand of the adjoint form (wino_input_adjoint)
 void wino_filter_transform(Stream& s, int m, int r, const WShape& w, int mode, const float* packed, float* U);
@@ -174,7 +187,8 @@ void wino_input_adjoint(Stream& s, int m, int r, float* dV, int C, int pad, int 
                         int accumulate);
 void wino_output_transform(Stream& s, int m, int r, const float* M, int Cm, int Th, int Tw, const float* bias, int act,
                            const TView& y, int Cout, int accumulate);                                      // M[P][T][Cm]
-void wino_dy_transform(Stream& s, int m, int r, const TView& dy, int Th, int Tw, float* dM, float* amax_out = nullptr);   // dM[P][T][dy.C]
+void wino_dy_transform(Stream& s, int m, int r, const TView& dy, int Th, int Tw, float* dM, float* amax_out = nullptr,
+                       const float* in_amax = nullptr, int* kscale_out = nullptr);                                     // dM[P][T][dy.C]
 // ---- the folded tail conv (tail_fold_weights below) in Winograd form: its four sub-pixel phases are (2+a)x(2+b)-tap stride-1
 // convolutions over the same input, i.e. four F(4x4,3x3) convolutions sharing ONE wino_input_transform(4, 3, x, pad 1, zero);
 // their filters sit side by side on the N axis (N = 4 * Npad) of one batched GEMM.  Th, Tw = tiles of 4x4 INPUT positions.
@@ -182,11 +196,13 @@ void tailw_filter_transform(Stream& s, const WShape& w, const float* folded, flo
 void tailw_filter_grad(Stream& s, const WShape& w, const float* dU, float* dfolded);          // dU[36][Cip][4 * Npad] -> folded layout
 // y (2H x 2W, Npad channels): y[2 i + a][2 j + b] = act(A^T M_ab A + bias),  M[36][T][4 * Npad]
 void tailw_output_transform(Stream& s, const float* M, int Th, int Tw, int Npad, const float* bias, int act, const TView& y, int Cout);
-void tailw_dy_transform(Stream& s, const TView& dy, int Th, int Tw, int Npad, float* dM, float* amax_out = nullptr);      // dM[36][T][4 * Npad]
+void tailw_dy_transform(Stream& s, const TView& dy, int Th, int Tw, int Npad, float* dM, float* amax_out = nullptr,
+                        const float* in_amax = nullptr, int* kscale_out = nullptr);                        // dM[36][T][4 * Npad]
 // ---- strided Winograd F(4x4, 2x2): the k4 s2 p1 convolutions and their transposes as four polyphase 2x2 stride-1 convolutions
 // sharing one batched GEMM (wino.hip).  "fine" = the 2H x 2W side, "coarse" = the H x W side; tiles = 4x4 coarse pixels.
 // (m, r) = (4, 2) is accepted by wino_output_transform (coarse = A^T M A) and wino_dy_transform (dM = A coarse A^T).
-void wino_s2_input_transform(Stream& s, const TView& fine, int Th, int Tw, float* V, float* amax_out = nullptr);   // V[25][T][4 * fine.C], channel (2s+t)*C + c
+void wino_s2_input_transform(Stream& s, const TView& fine, int Th, int Tw, float* V, float* amax_out = nullptr,
+                             const float* in_amax = nullptr, int* kscale_out = nullptr);   // V[25][T][4 * fine.C], channel (2s+t)*C + c
 // fine (+)= [bias +] adjoint of the transform above applied to dV[25][T][4 * Cf] (overwritten: scratch)
 void wino_s2_input_adjoint(Stream& s, float* dV, int Cf, int Th, int Tw, const TView& fine, const float* bias, int accumulate);
 // w: the layer's WShape (WK_CONV: fine = input, coarse = output; WK_CONVT: fine = output, coarse = input).

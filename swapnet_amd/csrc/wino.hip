@@ -278,14 +278,52 @@ __device__ __forceinline__ void f1mac(float& s, float c, float x) {
 }
 #define F4ZERO make_float4(0.f, 0.f, 0.f, 0.f)
 
+// ---- planes handed to the two-plane GEMMs PRE-CUT (round 4): element-wise "pair" words --------------------------------------------
+// A transform that feeds a two-plane GEMM may write each element of its planes as the 32-bit word {h | l << 16}, h = fp16(x 2^k)
+// rounded to nearest, l = fp16(x 2^k - h): the fp32 slot's footprint and addressing, but the GEMM loops then assemble their MFMA
+// operands with byte permutes (8 VALU per 8 elements) instead of cutting (32).  The scale must be known BEFORE the plane is written,
+// so it comes from a bound: |plane| <= gain * amax(input), gain = the squared largest absolute row sum of the transform matrix,
+// amax(input) from the input buffer's amax slot (engine.h buf_slots); k puts the bound in [2^14, 2^15) -- fp16 holds it with a
+// factor 2 to spare, and the bound is typically 2-3 binades above the plane's true amax, which lands where the exact-amax scale
+// of the cut-in-loop form (top 2^12) puts it.  Every block derives the same k; block 0 publishes it for the GEMM (kscale_out).
+typedef _Float16 pf16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ int pair_scale_exp(const float* in_amax, float gain, int* kscale_out) {
+  const int lane = threadIdx.x & 63;
+  float m = fmaxf(fmaxf(in_amax[lane], in_amax[lane + 64]), fmaxf(in_amax[lane + 128], in_amax[lane + 192]));
+#pragma unroll
+  for (int o = 32; o; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  m *= gain;
+  int k = 0;
+  if (m > 0.f && m <= 3.0e38f) {
+    const int e = (int)((__float_as_uint(m) >> 23) & 255u) - 127;
+    k = 14 - e;
+    k = k < -100 ? -100 : (k > 100 ? 100 : k);
+  }
+  if (kscale_out && blockIdx.x == 0 && threadIdx.x == 0) *kscale_out = k;
+  return k;
+}
+__device__ __forceinline__ unsigned pair_word(float x, float sc) {
+  const float xs = x * sc;
+  const _Float16 h = (_Float16)xs;
+  const _Float16 l = (_Float16)(xs - (float)h);
+  return (unsigned)__builtin_bit_cast(unsigned short, h) | ((unsigned)__builtin_bit_cast(unsigned short, l) << 16);
+}
+__device__ __forceinline__ float4 pair4(const float4& v, float sc) {
+  return make_float4(__uint_as_float(pair_word(v.x, sc)), __uint_as_float(pair_word(v.y, sc)), __uint_as_float(pair_word(v.z, sc)),
+                     __uint_as_float(pair_word(v.w, sc)));
+}
+
 template <class F>
 __global__ __launch_bounds__(256) void winog_input_kernel(const float* x, int xcs, int N, int H, int W, int C, int pad,
-                                                          int pad_mode, int Th, int Tw, float* V, float* amax_out) {
+                                                          int pad_mode, int Th, int Tw, float* V, float* amax_out,
+                                                          const float* in_amax, float gain, int* kscale_out) {
   constexpr int A = F::A, M = F::M;
   const int C4 = C >> 2;
   const size_t T = (size_t)N * Th * Tw;
   const size_t total = T * C4;
   float am = 0.f;
+  const bool pair = in_amax != nullptr;
+  const float psc = pair ? __uint_as_float((unsigned)(127 + pair_scale_exp(in_amax, gain, kscale_out)) << 23) : 1.f;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
     const size_t tile = i / C4;
     const int c = (int)(i - tile * C4) * 4;
@@ -318,11 +356,11 @@ __global__ __launch_bounds__(256) void winog_input_kernel(const float* x, int xc
         float4 s = F4ZERO;
 #pragma unroll
         for (int k = 0; k < A; ++k) f4mac(s, F::BT[j][k], t[a][k]);
-        *reinterpret_cast<float4*>(V + ((size_t)(a * A + j) * T + tile) * C + c) = s;
+        *reinterpret_cast<float4*>(V + ((size_t)(a * A + j) * T + tile) * C + c) = pair ? pair4(s, psc) : s;
         am = fmaxf(am, f4amax(s));
       }
   }
-  amax_fold(am, amax_out);
+  if (!pair) amax_fold(am, amax_out);
 }
 
 template <class F>
@@ -424,12 +462,14 @@ __global__ __launch_bounds__(256) void winog_output_kernel(const float* Mx, int 
 // dM = A dY A^T : m x m -> (m+2) x (m+2)   (A = AT^T)
 template <class F>
 __global__ __launch_bounds__(256) void winog_dy_kernel(const float* dy, int dcs, int N, int H, int W, int C, int Th, int Tw,
-                                                       float* dM, float* amax_out) {
+                                                       float* dM, float* amax_out, const float* in_amax, float gain, int* kscale_out) {
   constexpr int A = F::A, M = F::M;
   const int C4 = C >> 2;
   const size_t T = (size_t)N * Th * Tw;
   const size_t total = T * C4;
   float am = 0.f;
+  const bool pair = in_amax != nullptr;
+  const float psc = pair ? __uint_as_float((unsigned)(127 + pair_scale_exp(in_amax, gain, kscale_out)) << 23) : 1.f;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
     const size_t tile = i / C4;
     const int c = (int)(i - tile * C4) * 4;
@@ -459,11 +499,11 @@ __global__ __launch_bounds__(256) void winog_dy_kernel(const float* dy, int dcs,
         float4 s = F4ZERO;
 #pragma unroll
         for (int b = 0; b < M; ++b) f4mac(s, F::AT[b][j], r[p][b]);
-        *reinterpret_cast<float4*>(dM + ((size_t)(p * A + j) * T + tile) * C + c) = s;
+        *reinterpret_cast<float4*>(dM + ((size_t)(p * A + j) * T + tile) * C + c) = pair ? pair4(s, psc) : s;
         am = fmaxf(am, f4amax(s));
       }
   }
-  amax_fold(am, amax_out);
+  if (!pair) amax_fold(am, amax_out);
 }
 
 // dW[(ky,kx,ci)][co] = (G^T dU G)[ky][kx]
@@ -622,13 +662,15 @@ struct F42 {
 
 // V[(a*5+j)][tile][q*C + c] = (BT d_q BT^T)[a][j],  d_q[i][j] = x[2 (4 ty + i) - 1 + s][2 (4 tx + j) - 1 + t],  q = 2 s + t
 __global__ __launch_bounds__(256) void wino_s2_input_kernel(const float* x, int xcs, int N, int H, int W, int C, int Th, int Tw,
-                                                            float* V, float* amax_out) {
+                                                            float* V, float* amax_out, const float* in_amax, float gain, int* kscale_out) {
   constexpr int A = 5;
   const int C4 = C >> 2;
   const size_t T = (size_t)N * Th * Tw;
   const size_t total = T * 4 * C4;
   const int CV = 4 * C;
   float am = 0.f;
+  const bool pair = in_amax != nullptr;
+  const float psc = pair ? __uint_as_float((unsigned)(127 + pair_scale_exp(in_amax, gain, kscale_out)) << 23) : 1.f;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
     const int c = (int)(i % C4) * 4; size_t r = i / C4;
     const int q = (int)(r & 3); const size_t tile = r >> 2;
@@ -662,11 +704,11 @@ __global__ __launch_bounds__(256) void wino_s2_input_kernel(const float* x, int 
         float4 acc = F4ZERO;
 #pragma unroll
         for (int k = 0; k < A; ++k) f4mac(acc, F42::BT[j][k], tt[a][k]);
-        *reinterpret_cast<float4*>(V + ((size_t)(a * A + j) * T + tile) * CV + q * C + c) = acc;
+        *reinterpret_cast<float4*>(V + ((size_t)(a * A + j) * T + tile) * CV + q * C + c) = pair ? pair4(acc, psc) : acc;
         am = fmaxf(am, f4amax(acc));
       }
   }
-  amax_fold(am, amax_out);
+  if (!pair) amax_fold(am, amax_out);
 }
 
 // gather side of the adjoint: P[25][T][4 C] holds the patches BT^T dV BT; fine pixel (r, cc) of phase (s, t) sits at patch
@@ -1026,12 +1068,14 @@ __global__ __launch_bounds__(256) void tailw_output_kernel(const float* Mx, int 
 }
 // dM[p][tile][ph * Npad + c] = (A g_ph A^T)[p],  g_ph[i][j] = dy[2 (4 ty + i) + a][2 (4 tx + j) + b][c]
 __global__ __launch_bounds__(256) void tailw_dy_kernel(const float* dy, int dcs, int N, int yH, int yW, int Th, int Tw, int Npad,
-                                                       float* dM, float* amax_out) {
+                                                       float* dM, float* amax_out, const float* in_amax, float gain, int* kscale_out) {
   constexpr int A = 6, M = 4;
   const int C4 = Npad >> 2, CM = 4 * Npad;
   const size_t T = (size_t)N * Th * Tw;
   const size_t total = T * 4 * C4;
   float am = 0.f;
+  const bool pair = in_amax != nullptr;
+  const float psc = pair ? __uint_as_float((unsigned)(127 + pair_scale_exp(in_amax, gain, kscale_out)) << 23) : 1.f;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
     const int c = (int)(i % C4) * 4; size_t r = i / C4;
     const int ph = (int)(r & 3); const size_t tile = r >> 2;
@@ -1062,11 +1106,11 @@ __global__ __launch_bounds__(256) void tailw_dy_kernel(const float* dy, int dcs,
         float4 s = F4ZERO;
 #pragma unroll
         for (int jj = 0; jj < M; ++jj) f4mac(s, F43::AT[jj][j], rr[p][jj]);
-        *reinterpret_cast<float4*>(dM + ((size_t)(p * A + j) * T + tile) * CM + ph * Npad + c) = s;
+        *reinterpret_cast<float4*>(dM + ((size_t)(p * A + j) * T + tile) * CM + ph * Npad + c) = pair ? pair4(s, psc) : s;
         am = fmaxf(am, f4amax(s));
       }
   }
-  amax_fold(am, amax_out);
+  if (!pair) amax_fold(am, amax_out);
 }
 
 inline unsigned wgrid(size_t total) { return (unsigned)std::min<size_t>(std::max<size_t>((total + 255) / 256, 1), 256 * 32); }
@@ -1081,20 +1125,25 @@ static int variant(int m, int r) {
   if (m == 4 && r == 2) return 3;            // strided form: output / dy / patch transforms only
   throw Error(1, "winograd: supported forms are F(2,3), F(4,3), F(3,4) and the strided F(4,2)");
 }
-void wino_input_transform(Stream& s, int m, int r, const TView& x, int pad, int pad_mode, int Th, int Tw, float* V, float* amax_out) {
+// gains of the pair-form bound (squared largest absolute row sum of the transform matrix)
+static float input_gain(int v) { return v == 3 ? 9.f : 100.f; }                         // B^T of F(4,2): 3; of the 6-point forms: 10
+static float dy_gain(int v) { return v == 1 ? 225.f : (v == 2 ? 49.f : 16.f); }        // A of F(4,3): 15; F(3,4): 7; F(4,2): 4
+void wino_input_transform(Stream& s, int m, int r, const TView& x, int pad, int pad_mode, int Th, int Tw, float* V, float* amax_out,
+                          const float* in_amax, int* kscale_out) {
   const int v = variant(m, r);
   if (v == 3) throw Error(1, "wino_input_transform: F(4,2) is the strided form (wino_s2_input_transform)");
   if (x.C % 4 || x.cs % 4) throw Error(1, "wino_input_transform: C must be a multiple of 4");
   const size_t total = (size_t)x.N * Th * Tw * (x.C / 4);
   const dim3 grid(wgrid(total));
+  if (v == 0 && in_amax) throw Error(1, "wino_input_transform: F(2,3) planes have no pair form");
   if (v == 0)            // (F(2,3) planes feed the fp32-operand kernels only: no slot to fill)
     hipLaunchKernelGGL(wino_input_kernel, grid, dim3(256), 0, hs(s), x.p, x.cs, x.N, x.H, x.W, x.C, pad, pad_mode, Th, Tw, V);
   else if (v == 1)
     hipLaunchKernelGGL(winog_input_kernel<F43>, grid, dim3(256), 0, hs(s), x.p, x.cs, x.N, x.H, x.W, x.C, pad, pad_mode, Th,
-                       Tw, V, amax_out);
+                       Tw, V, amax_out, in_amax, input_gain(v), kscale_out);
   else
     hipLaunchKernelGGL(winog_input_kernel<F34>, grid, dim3(256), 0, hs(s), x.p, x.cs, x.N, x.H, x.W, x.C, pad, pad_mode, Th,
-                       Tw, V, amax_out);
+                       Tw, V, amax_out, in_amax, input_gain(v), kscale_out);
   check_launch("wino_input_transform");
 }
 void wino_filter_transform(Stream& s, int m, int r, const WShape& w, int mode, const float* packed, float* U) {
@@ -1145,19 +1194,24 @@ void wino_output_transform(Stream& s, int m, int r, const float* M, int Cm, int 
                        y.W, Cout, accumulate);
   check_launch("wino_output_transform");
 }
-void wino_dy_transform(Stream& s, int m, int r, const TView& dy, int Th, int Tw, float* dM, float* amax_out) {
+void wino_dy_transform(Stream& s, int m, int r, const TView& dy, int Th, int Tw, float* dM, float* amax_out, const float* in_amax,
+                       int* kscale_out) {
   const int v = variant(m, r);
   if (dy.C % 4 || dy.cs % 4) throw Error(1, "wino_dy_transform: C must be a multiple of 4");
   const size_t total = (size_t)dy.N * Th * Tw * (dy.C / 4);
   const dim3 grid(wgrid(total));
+  if (v == 0 && in_amax) throw Error(1, "wino_dy_transform: F(2,3) planes have no pair form");
   if (v == 0)
     hipLaunchKernelGGL(wino_dy_kernel, grid, dim3(256), 0, hs(s), dy.p, dy.cs, dy.N, dy.H, dy.W, dy.C, Th, Tw, dM);
   else if (v == 1)
-    hipLaunchKernelGGL(winog_dy_kernel<F43>, grid, dim3(256), 0, hs(s), dy.p, dy.cs, dy.N, dy.H, dy.W, dy.C, Th, Tw, dM, amax_out);
+    hipLaunchKernelGGL(winog_dy_kernel<F43>, grid, dim3(256), 0, hs(s), dy.p, dy.cs, dy.N, dy.H, dy.W, dy.C, Th, Tw, dM, amax_out, in_amax,
+                       dy_gain(v), kscale_out);
   else if (v == 2)
-    hipLaunchKernelGGL(winog_dy_kernel<F34>, grid, dim3(256), 0, hs(s), dy.p, dy.cs, dy.N, dy.H, dy.W, dy.C, Th, Tw, dM, amax_out);
+    hipLaunchKernelGGL(winog_dy_kernel<F34>, grid, dim3(256), 0, hs(s), dy.p, dy.cs, dy.N, dy.H, dy.W, dy.C, Th, Tw, dM, amax_out, in_amax,
+                       dy_gain(v), kscale_out);
   else
-    hipLaunchKernelGGL(winog_dy_kernel<F42>, grid, dim3(256), 0, hs(s), dy.p, dy.cs, dy.N, dy.H, dy.W, dy.C, Th, Tw, dM, amax_out);
+    hipLaunchKernelGGL(winog_dy_kernel<F42>, grid, dim3(256), 0, hs(s), dy.p, dy.cs, dy.N, dy.H, dy.W, dy.C, Th, Tw, dM, amax_out, in_amax,
+                       dy_gain(v), kscale_out);
   check_launch("wino_dy_transform");
 }
 void tailw_filter_transform(Stream& s, const WShape& w, const float* folded, float* U) {
@@ -1176,16 +1230,19 @@ void tailw_output_transform(Stream& s, const float* M, int Th, int Tw, int Npad,
   hipLaunchKernelGGL(tailw_output_kernel, dim3(wgrid(total)), dim3(256), 0, hs(s), M, y.N, Th, Tw, Npad, bias, act, y.p, y.cs, y.H, y.W, Cout);
   check_launch("tailw_output_transform");
 }
-void tailw_dy_transform(Stream& s, const TView& dy, int Th, int Tw, int Npad, float* dM, float* amax_out) {
+void tailw_dy_transform(Stream& s, const TView& dy, int Th, int Tw, int Npad, float* dM, float* amax_out, const float* in_amax,
+                        int* kscale_out) {
   if (Npad % 4 || dy.cs % 4 || dy.C < Npad) throw Error(1, "tailw_dy_transform: bad channel counts");
   const size_t total = (size_t)dy.N * Th * Tw * 4 * (Npad / 4);
-  hipLaunchKernelGGL(tailw_dy_kernel, dim3(wgrid(total)), dim3(256), 0, hs(s), dy.p, dy.cs, dy.N, dy.H, dy.W, Th, Tw, Npad, dM, amax_out);
+  hipLaunchKernelGGL(tailw_dy_kernel, dim3(wgrid(total)), dim3(256), 0, hs(s), dy.p, dy.cs, dy.N, dy.H, dy.W, Th, Tw, Npad, dM, amax_out,
+                     in_amax, 225.f, kscale_out);
   check_launch("tailw_dy_transform");
 }
-void wino_s2_input_transform(Stream& s, const TView& x, int Th, int Tw, float* V, float* amax_out) {
+void wino_s2_input_transform(Stream& s, const TView& x, int Th, int Tw, float* V, float* amax_out, const float* in_amax, int* kscale_out) {
   if (x.C % 4 || x.cs % 4) throw Error(1, "wino_s2_input_transform: C must be a multiple of 4");
   const size_t total = (size_t)x.N * Th * Tw * 4 * (x.C / 4);
-  hipLaunchKernelGGL(wino_s2_input_kernel, dim3(wgrid(total)), dim3(256), 0, hs(s), x.p, x.cs, x.N, x.H, x.W, x.C, Th, Tw, V, amax_out);
+  hipLaunchKernelGGL(wino_s2_input_kernel, dim3(wgrid(total)), dim3(256), 0, hs(s), x.p, x.cs, x.N, x.H, x.W, x.C, Th, Tw, V, amax_out,
+                     in_amax, 9.f, kscale_out);
   check_launch("wino_s2_input_transform");
 }
 void wino_s2_input_adjoint(Stream& s, float* dV, int Cf, int Th, int Tw, const TView& dx, const float* bias, int accumulate) {

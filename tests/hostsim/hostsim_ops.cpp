@@ -134,6 +134,9 @@ int conv_precut_tile(int xC, int Npad) {
   return sim_tile_for(Npad);
 }
 int conv_precut_planes() { return 2; }
+bool wino_pair_planes() { return false; }          // the simulator's planes stay fp32: the pair form is a device storage format
+bool conv_fwd_takes_pairs(int, int) { return false; }
+bool conv_wgrad_takes_pairs(size_t, int, int) { return false; }
 const float* conv_precut_amax(Stream&, const float*, size_t, int, int, size_t) { return nullptr; }
 static size_t sim_np(int Npad, int bn) { return (size_t)((Npad + bn - 1) / bn) * bn; }
 size_t conv_precut_elems(int K, int Npad, int bn) { return (size_t)(K / 16) * ((Npad + bn - 1) / bn) * 4 * bn * 8 + 8; }
@@ -1200,21 +1203,26 @@ void tensor_amax(Stream&, const TView& x, float* slot, float floor) {
   slot[0] = floor;
   sim_fold_view(slot, x);
 }
-void wino_input_transform(Stream&, int m, int r, const TView& x, int pad, int pad_mode, int Th, int Tw, float* V, float* amax_out) {
+void wino_input_transform(Stream&, int m, int r, const TView& x, int pad, int pad_mode, int Th, int Tw, float* V, float* amax_out,
+                          const float* in_amax, int*) {
+  if (in_amax) throw Error(1, "hostsim: pair-form planes requested");
   wino_input_transform_impl(m, r, x, pad, pad_mode, Th, Tw, V);
   const int A = m + r - 1;
   if (amax_out && !(m == 2 && r == 3)) sim_slot_fold(amax_out, sim_amax(V, (size_t)A * A * x.N * Th * Tw * x.C));
 }
-void wino_dy_transform(Stream&, int m, int r, const TView& dy, int Th, int Tw, float* dM, float* amax_out) {
+void wino_dy_transform(Stream&, int m, int r, const TView& dy, int Th, int Tw, float* dM, float* amax_out, const float* in_amax, int*) {
+  if (in_amax) throw Error(1, "hostsim: pair-form planes requested");
   wino_dy_transform_impl(m, r, dy, Th, Tw, dM);
   const int A = m + r - 1;
   if (amax_out && !(m == 2 && r == 3)) sim_slot_fold(amax_out, sim_amax(dM, (size_t)A * A * dy.N * Th * Tw * dy.C));
 }
-void tailw_dy_transform(Stream&, const TView& dy, int Th, int Tw, int Npad, float* dM, float* amax_out) {
+void tailw_dy_transform(Stream&, const TView& dy, int Th, int Tw, int Npad, float* dM, float* amax_out, const float* in_amax, int*) {
+  if (in_amax) throw Error(1, "hostsim: pair-form planes requested");
   tailw_dy_transform_impl(dy, Th, Tw, Npad, dM);
   sim_slot_fold(amax_out, sim_amax(dM, (size_t)36 * dy.N * Th * Tw * 4 * Npad));
 }
-void wino_s2_input_transform(Stream&, const TView& x, int Th, int Tw, float* V, float* amax_out) {
+void wino_s2_input_transform(Stream&, const TView& x, int Th, int Tw, float* V, float* amax_out, const float* in_amax, int*) {
+  if (in_amax) throw Error(1, "hostsim: pair-form planes requested");
   wino_s2_input_transform_impl(x, Th, Tw, V);
   sim_slot_fold(amax_out, sim_amax(V, (size_t)25 * x.N * Th * Tw * 4 * x.C));
 }
