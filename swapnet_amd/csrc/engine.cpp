@@ -234,7 +234,7 @@ TView plane_mat(float* p, size_t T, int C) {
 // ---- Conv2d ---------------------------------------------------------------------------
 // y.v receives act(conv(x)+bias).  In backward y.g is the gradient w.r.t. that output.
 void Net::conv(const std::string& name, const Var& x, const Var& y, ConvKind kind, int Ci, int Co, bool bias,
-               int actf, const std::vector<int32_t>* cimap, bool x_is_input) {
+               int actf, const std::vector<int32_t>* cimap, bool x_is_input, int dgrad_C) {
   const int KH = (kind == CK_K3S1_REFLECT || kind == CK_K3S1_ZERO) ? 3 : 4;
   const ConvGeom geo = conv_geom(kind, x.v.H, x.v.W);
   if (y.v.H != geo.Ho || y.v.W != geo.Wo) throw Error(1, "conv " + name + ": output view has the wrong size");
@@ -640,7 +640,11 @@ void Net::conv(const std::string& name, const Var& x, const Var& y, ConvKind kin
   const bool want_dx = x.has_grad && y.has_grad;
   size_t dg_off = 0, pcd_off = 0;
   int pc_d = 0, dpanels = 1, dKp = 0;
-  const int Ndg = Cip;   // dgrad output channels = input buffer channels
+  // dgrad output channels = input buffer channels -- or, for a layer that reads a network input of which only the leading
+  // channels are anyone's output (the generator's image inside the conditional discriminator's input), just those
+  const bool narrow_dx = dgrad_C > 0 && dgrad_C % 4 == 0 && dgrad_C < Cip && !wino && kind == CK_K4S2;
+  const int Ndg = narrow_dx ? dgrad_C : Cip;
+  const Var xg_target = narrow_dx ? x.slice(0, Ndg) : x;
   if (want_dx) {
     if (wino) {
       pcwt = (wm != 2 && wino_pc) ? conv_precut_tile(Cop, Cip) : 0;
@@ -650,7 +654,7 @@ void Net::conv(const std::string& name, const Var& x, const Var& y, ConvKind kin
     }
     else dg_off = reserve_dg(self, dgrad_elems(arena.params[wi].ws, dg_mode, CopD, Ndg));
     if (kind == CK_K3S1_REFLECT && !(wino && wadj)) dxpad = alloc_var(x.v.N, dHo, dWo, Cip, false);
-    op->grad_targets.push_back(x);
+    op->grad_targets.push_back(xg_target);
     if (!wino) {
       // K4S2: four phase panels of 2x2 taps; stride-1: one panel of KH x KW taps over dY (Cop channels)
       dpanels = kind == CK_K4S2 ? 4 : 1;
@@ -695,7 +699,7 @@ void Net::conv(const std::string& name, const Var& x, const Var& y, ConvKind kin
     };
   }
   const int pcd_k = pc_d; const size_t pcd_o = pcd_off, pcd_bs = pc_d ? conv_precut_elems(dKp, Ndg, pc_d) : 0;
-  const TView ygv = y.g, xgv = x.g, scr = CopD != Cop ? scratch.v.slice(0, Cop) : scratch.v, scr_full = scratch.v, dxp = dxpad.v;
+  const TView ygv = y.g, xgv = narrow_dx ? x.g.slice(0, Ndg) : x.g, scr = CopD != Cop ? scratch.v.slice(0, Cop) : scratch.v, scr_full = scratch.v, dxp = dxpad.v;
   const bool has_ygrad = y.has_grad;
   // dY as a GEMM operand: dR from act_bwd (which folds its amax into the scratch buffer's slot) or y.g itself, whose slot --
   // if it has one -- the norm_act behind this conv fills in its backward

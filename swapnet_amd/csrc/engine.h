@@ -209,8 +209,9 @@ class Net {
   Var alloc_var(int N, int H, int W, int C, bool need_grad);
   // layers
   // Ci = logical input channels of the reference layer (<= x.v.C, the padded buffer channels)
+  // dgrad_C > 0 (k4 s2 layers reading a network input): the input gradient is formed for the first dgrad_C buffer channels only
   void conv(const std::string& name, const Var& x, const Var& y, ConvKind kind, int Ci, int Co, bool bias, int act,
-            const std::vector<int32_t>* cimap = nullptr, bool x_is_input = false);
+            const std::vector<int32_t>* cimap = nullptr, bool x_is_input = false, int dgrad_C = 0);
   void convT(const std::string& name, const Var& x, const Var& y, int Co, bool bias);
   void norm_act(const Var& raw, const Var& y, bool norm, int act, float drop_p, const Var* residual = nullptr);
   void act(const Var& x, const Var& y, int act);
@@ -244,7 +245,8 @@ class Net {
 // ---- network builders (reference layouts in the .cpp) ----------------------------------
 void build_warp_generator(Net& net, const Var& body, const Var& cloth, const Var& out, float dropout, int body_channels = 3,
                           int cloth_channels = 19);
-Var build_patchgan(Net& net, const Var& x, int n_layers, const std::vector<int32_t>& cimap);
+// in_grad_channels > 0: only the first that many channels of the conditional input need a gradient (the generator's output)
+Var build_patchgan(Net& net, const Var& x, int n_layers, const std::vector<int32_t>& cimap, int in_grad_channels = 0);
 void build_texture_generator(Net& net, const Var& tex, const float* rois_dev, int num_roi, const Var& cloth_cat,
                              const Var& unet_in, const Var& out, int img_size, int cloth_channels = 19);
 std::vector<Var> build_vgg16_slices(Net& net, const Var& img);

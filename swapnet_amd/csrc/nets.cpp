@@ -95,7 +95,7 @@ void build_warp_generator(Net& n, const Var& body, const Var& cloth, const Var& 
 // NLayerDiscriminator under instance norm (modules/discriminators.py:91-136): all convs
 // carry a bias (:103-106).  Returns the 1-channel prediction map (C padded to 4).
 // ---------------------------------------------------------------------------------------
-Var build_patchgan(Net& n, const Var& x, int n_layers, const std::vector<int32_t>& cimap) {
+Var build_patchgan(Net& n, const Var& x, int n_layers, const std::vector<int32_t>& cimap, int in_grad_channels) {
   const int N = x.v.N;
   int ci = 0;
   for (int v : cimap) ci += v >= 0;
@@ -105,7 +105,7 @@ Var build_patchgan(Net& n, const Var& x, int n_layers, const std::vector<int32_t
     throw Error(1, "PatchGAN: the input is too small for " + std::to_string(n_layers) + " stride-2 levels followed by two 4x4 stride-1 convs");
   int H = x.v.H / 2, W = x.v.W / 2;
   Var a = n.alloc_var(N, H, W, ndf, true);
-  n.conv("model.0", x, a, CK_K4S2, ci, ndf, true, ACT_LRELU, &cimap, true);       // :110
+  n.conv("model.0", x, a, CK_K4S2, ci, ndf, true, ACT_LRELU, &cimap, true, in_grad_channels);       // :110
   n.taps["d0"] = a;
   int idx = 2, mult = 1;
   for (int l = 1; l < n_layers; ++l) {                                            // :113-120
@@ -209,7 +209,7 @@ class WarpModel final : public Model {
       // second instance over the first B images, bound to the same (now frozen) arena
       D1 = std::make_unique<Net>(c, arenaD);
       D1->set_external_slot(Dx.vbase, slot_dx);
-      pred1 = build_patchgan(*D1, Dx.batch(0, B), c.patchgan_layers, cimap);
+      pred1 = build_patchgan(*D1, Dx.batch(0, B), c.patchgan_layers, cimap, Ccp);      // d(fakes) only: the condition is data
       D1->finalize({pred1});
     }
   }

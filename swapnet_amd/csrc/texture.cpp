@@ -168,7 +168,7 @@ class TextureModel final : public Model {
     arenaD.allocate(c);
     D2->finalize({pred2});
     D1 = std::make_unique<Net>(c, arenaD);
-    pred1 = build_patchgan(*D1, Dx.batch(0, B), c.patchgan_layers, cimap);
+    pred1 = build_patchgan(*D1, Dx.batch(0, B), c.patchgan_layers, cimap, 4);        // d(fakes) only: the condition is data
     D1->finalize({pred1});
     // perceptual network: one instance with gradients (fakes), one without (targets, no_grad :52-53)
     VF = std::make_unique<Net>(c, arenaV);

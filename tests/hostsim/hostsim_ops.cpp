@@ -1148,7 +1148,8 @@ void repack_dgrad(Stream&, const WShape& w, int mode, int Cop, int Ndg, const fl
     const int a = (3 - ky) & 1, dy = (3 - ky) >> 1, b = (3 - kx) & 1, dx = (3 - kx) >> 1;
     return src[((size_t)(a * 2 + b) * 4 * w.Cip + (dy * 2 + dx) * w.Cip + ci) * w.Npad + co];
   };
-  for (int ky = 0; ky < w.KH; ++ky) for (int kx = 0; kx < w.KW; ++kx) for (int ci = 0; ci < w.Cip; ++ci) for (int co = 0; co < w.Co; ++co) {
+  // (Ndg < Cip: the operand of an input gradient formed for the leading channels only, ops.h repack_dgrad)
+  for (int ky = 0; ky < w.KH; ++ky) for (int kx = 0; kx < w.KW; ++kx) for (int ci = 0; ci < std::min(w.Cip, Ndg); ++ci) for (int co = 0; co < w.Co; ++co) {
     const float v = W(ky, kx, ci, co);
     if (mode == 0) {          // dX[2i+a] += dY[i + a - 1 + dy] * W[3 - a - 2dy]
       const int a = (3 - ky) & 1, dy = (3 - ky) >> 1, b = (3 - kx) & 1, dx = (3 - kx) >> 1;

@@ -122,8 +122,9 @@ def test_texture_stage_rejects_gradient_penalty_modes(tmp_path):
 
 @pytest.mark.parametrize("backend", BACKENDS)
 def test_library_rng_keeps_the_layout_pad_channels_out_of_the_penalty(backend):
-    """dragan-gp with the LIBRARY's random draws (the default: no set_gp_random): beta is drawn on the device for the 24-channel
-    buffer layout of D's conditional input, whose channels 19 and 23 are layout pads.  They must stay exactly zero -- a non-zero
+    """dragan-gp with the LIBRARY's random draws (the default: no set_gp_random): beta is drawn on the device for the 32-channel
+    buffer layout of D's conditional input ([cloth 19 + 1 pad | body 3 + 1 pad | 8 pads]: round 4 rounds the buffer up to the
+    ring kernel's 16-channel stages), whose channels 19 and 23..31 are layout pads.  They must stay exactly zero -- a non-zero
     pad channel of x_hat puts a gradient on the pad rows of model.0.weight, AdamW then moves those weights off zero and every
     later penalty sees noise x W_pad (advisor finding, round 2).  Checked on the raw gradient arena (state_dict() would hide it)."""
     ctx = _ctx(backend)
@@ -140,8 +141,8 @@ def test_library_rng_keeps_the_layout_pad_channels_out_of_the_penalty(backend):
     m.backward_D(0.9, 0.8)
     assert m.losses()["D_gp"] > 0
     g = m.grad_arena(engine.NET_D).cpu()
-    # model.0.weight is the arena's first tensor: packed [(kh*4+kw) * 24 + ci][64], ci = buffer channel (19 and 23 are pads)
-    w0 = g[:16 * 24 * 64].view(16, 24, 64)
-    assert float(w0[:, [19, 23], :].abs().max()) == 0.0
-    assert float(w0[:, :19, :].abs().max()) > 0
+    # model.0.weight is the arena's first tensor: packed [(kh*4+kw) * 32 + ci][64], ci = buffer channel (19 and 23..31 are pads)
+    w0 = g[:16 * 32 * 64].view(16, 32, 64)
+    assert float(w0[:, [19] + list(range(23, 32)), :].abs().max()) == 0.0
+    assert float(w0[:, :19, :].abs().max()) > 0 and float(w0[:, 20:23, :].abs().max()) > 0
     m.set_hyper()
