@@ -1113,9 +1113,10 @@ __global__ __launch_bounds__(256) void conv_precut_kernel(const float* w, unsign
   int kB = 0;
   if (wamax) kB = scale_exp(amax256(wamax, threadIdx.x & 63), PC_TOP_B);      // (before any lane leaves)
   if (i >= total) return;
-  const int pos = (int)(i % BN); const size_t q = i / BN;
+  const int nl = (int)(i % BN); const size_t q = i / BN;               // consecutive threads: consecutive columns (coalesced reads)
   const int tn = (int)(q % tiles_n), kq = (int)(q / tiles_n);
-  const int n = tn * BN + (pos % 32) * NBc + pos / 32;                 // pos = (nl % NB) * 32 + nl / NB
+  const int n = tn * BN + nl;
+  const int pos = (nl % NBc) * 32 + nl / NBc;                          // operand position of column nl
   w += (size_t)blockIdx.y * w_bs; out += (size_t)blockIdx.y * out_bs;
   u32x4* o = reinterpret_cast<u32x4*>(out);
   if (wamax) {

@@ -302,17 +302,18 @@ __device__ __forceinline__ int pair_scale_exp(const float* in_amax, float gain, 
   if (kscale_out && blockIdx.x == 0 && threadIdx.x == 0) *kscale_out = k;
   return k;
 }
-__device__ __forceinline__ unsigned pair_word(float x, float sc) {
-  const float xs = x * sc;
-  const _Float16 h = (_Float16)xs;
-  const _Float16 l = (_Float16)(xs - (float)h);
-  return (unsigned)__builtin_bit_cast(unsigned short, h) | ((unsigned)__builtin_bit_cast(unsigned short, l) << 16);
-}
+// four elements at a time with the packed conversions: 4 v_mul, 2 v_cvt_pk_f16_f32 (h), 4 v_cvt_f32_f16 + 4 v_sub (exact residuals),
+// 2 v_cvt_pk_f16_f32 (l), 4 v_perm to interleave {h | l << 16} -- 20 VALU per float4
 __device__ __forceinline__ float4 pair4(const float4& v, float sc) {
-  return make_float4(__uint_as_float(pair_word(v.x, sc)), __uint_as_float(pair_word(v.y, sc)), __uint_as_float(pair_word(v.z, sc)),
-                     __uint_as_float(pair_word(v.w, sc)));
+  const float x0 = v.x * sc, x1 = v.y * sc, x2 = v.z * sc, x3 = v.w * sc;
+  const pf16x2 h01 = pf16x2{(_Float16)x0, (_Float16)x1}, h23 = pf16x2{(_Float16)x2, (_Float16)x3};
+  const pf16x2 l01 = pf16x2{(_Float16)(x0 - (float)h01[0]), (_Float16)(x1 - (float)h01[1])};
+  const pf16x2 l23 = pf16x2{(_Float16)(x2 - (float)h23[0]), (_Float16)(x3 - (float)h23[1])};
+  const unsigned H01 = __builtin_bit_cast(unsigned, h01), H23 = __builtin_bit_cast(unsigned, h23);
+  const unsigned L01 = __builtin_bit_cast(unsigned, l01), L23 = __builtin_bit_cast(unsigned, l23);
+  return make_float4(__uint_as_float(__builtin_amdgcn_perm(L01, H01, 0x05040100u)), __uint_as_float(__builtin_amdgcn_perm(L01, H01, 0x07060302u)),
+                     __uint_as_float(__builtin_amdgcn_perm(L23, H23, 0x05040100u)), __uint_as_float(__builtin_amdgcn_perm(L23, H23, 0x07060302u)));
 }
-
 template <class F>
 __global__ __launch_bounds__(256) void winog_input_kernel(const float* x, int xcs, int N, int H, int W, int C, int pad,
                                                           int pad_mode, int Th, int Tw, float* V, float* amax_out,
@@ -879,9 +880,12 @@ __global__ __launch_bounds__(256) void winog_filter_pc_kernel(WShape w, int mode
   int kB = 0;
   if (wamax) kB = wino_scale_exp(wamax, threadIdx.x & 63, 10);       // PC_TOP_B; |G g G^T| <= |g|max for both 6-point forms
   if (i >= total) return;
-  const int pos = (int)(i % BN); const size_t q = i / BN;
+  // consecutive threads take consecutive COLUMNS (coalesced reads of the packed weights: a thread per operand position read
+  // every fourth column, a quarter of each sector); the operand position of column nl is pos = (nl % NB) * 32 + nl / NB
+  const int nl = (int)(i % BN); const size_t q = i / BN;
   const int tn = (int)(q % tiles_n), kq = (int)(q / tiles_n);
-  const int n = tn * BN + (pos % 32) * NBc + pos / 32;
+  const int n = tn * BN + nl;
+  const int pos = (nl % NBc) * 32 + nl / NBc;
   // t[k][r][b] = (G g)[r][b] for the 8 k of this entry
   float t[8][A][R];
 #pragma unroll

@@ -62,13 +62,15 @@ FLIP_SLICES = 3        # single activation sign flips tolerated per tensor at th
 FLIP_CAP = 1e-2        # ... and what they may cost the whole tensor
 
 
-def assert_grads_vs_fp64(got, ref32, ref64, skip, what, floor=1e-3):
+def assert_grads_vs_fp64(got, ref32, ref64, skip, what, floor=1e-3, mult=2.0, cap=None):
     """The UN-PINNED gradient bar: per tensor, rel-L2(native, fp64 oracle) <= max(floor, 2 x rel-L2(torch fp32 oracle,
     fp64 oracle)).  floor = 1e-3 (north_star) at the small sizes.  At 256x256 a handful of LeakyReLU / ReLU sign flips
     between ANY two fp32 evaluations (2-6 elements out of 2M on PatchGAN's 31x31 map) are the whole distance to the fp64
     gradient -- a Poisson count proportional to the forward round-off, 0.4e-3 .. 4e-3 for torch's own fp32 backward,
-    1.5e-3 .. 4e-3 here -- so those call sites pass floor = 5e-3 and the rigorous comparison is the pinned one
-    (tests/test_pattern_replay.py: activation pattern replayed in the oracle, tolerance 1e-4).
+    1.1e-3 .. 3.9e-3 here under the default kernel routing (round 4: PatchGAN 2.0-2.6 x torch's own distance, the generator
+    0.9-1.05 x) -- so those call sites pass mult = 4, cap = 5e-3: per tensor four times torch-fp32's distance, never more than
+    the old flat 5e-3; the rigorous comparison is the pinned one (tests/test_pattern_replay.py: activation pattern replayed in
+    the oracle, tolerance 1e-4).
     At the small sizes flips are rare but not impossible (test_pattern_replay counts 0-2 per network at 64x64): ONE flipped
     element of a layer's output changes that layer's weight / bias gradient in ONE output channel by O(1) of that channel,
     2e-3 .. 6e-3 of the tensor for PatchGAN's first 64-channel layer.  A tensor over the bar therefore still passes if the
@@ -85,7 +87,9 @@ def assert_grads_vs_fp64(got, ref32, ref64, skip, what, floor=1e-3):
         rows.append((e_hip, e_t32, k))
     bad = []
     for e_hip, e_t32, k in rows:
-        bar = max(floor, 2.0 * e_t32)
+        bar = max(floor, mult * e_t32)
+        if cap is not None:
+            bar = min(bar, cap)
         if e_hip <= bar:
             continue
         rest = rel_l2_without_worst_slices(got[k], ref64[k], FLIP_SLICES)
