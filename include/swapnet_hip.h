@@ -38,7 +38,7 @@ extern "C" {
 typedef struct swn_ctx swn_ctx;
 typedef struct swn_model swn_model;
 
-int swn_abi_version(void);   /* 2: swn_hyper gained d_b1, d_b2; 3: gp_mode, lambda_gp; 4: swn_route_*, swn_comm_* */
+int swn_abi_version(void);   /* 2: swn_hyper gained d_b1, d_b2; 3: gp_mode, lambda_gp; 4: swn_route_*, swn_model_step_captured, swn_model_create_shared */
 const char* swn_last_error(void);
 /* 1 when this library executes on a HIP device (libswapnet_hip.so), 0 for the CI simulator */
 int swn_is_device_build(void);
@@ -99,6 +99,13 @@ int swn_warp_model_create_ex(swn_ctx* ctx, int batch, int height, int width, int
                              int body_channels, int cloth_channels, swn_model** out);
 int swn_texture_model_create_ex(swn_ctx* ctx, int batch, int height, int width, int is_train, int num_roi,
                                 int cloth_channels, swn_model** out);
+/* A second model on the SAME training state: it uses `sharer`'s parameter arenas (weights, gradients, both Adam moments, step
+ * counters -- per network one flat buffer each) and owns only its activations and derived operands.  For the reference's loops
+ * that is the model of another batch size: the last, smaller batch of an epoch (train.py:62-64 with drop_last off) or the batch-1
+ * pass of inference.py:67 beside a training model -- without a second copy of the state and without copying it back and forth.
+ * Same kind, channel options and PatchGAN depth as the sharer; hyper-parameters are copied at creation (set them on both
+ * afterwards).  The sharer's buffers live until the last sharing model is destroyed, whatever the order of swn_model_destroy. */
+int swn_model_create_shared(swn_model* sharer, int batch, int height, int width, swn_model** out);
 int swn_model_destroy(swn_model* m);
 
 /* hyper-parameters = the opt.* fields read by the step (models/base_gan.py:87-120,

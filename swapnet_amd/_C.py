@@ -47,6 +47,7 @@ _PROTOS = {
     "swn_texture_model_create": ([_vp, _i, _i, _i, _i, _i, C.POINTER(_vp)], _i),
     "swn_warp_model_create_ex": ([_vp, _i, _i, _i, _i, _f, _i, _i, C.POINTER(_vp)], _i),
     "swn_texture_model_create_ex": ([_vp, _i, _i, _i, _i, _i, _i, C.POINTER(_vp)], _i),
+    "swn_model_create_shared": ([_vp, _i, _i, _i, C.POINTER(_vp)], _i),
     "swn_model_destroy": ([_vp], _i),
     "swn_model_set_hyper": ([_vp, C.POINTER(SwnHyper)], _i),
     "swn_model_param_count": ([_vp, _i, C.POINTER(_i)], _i),

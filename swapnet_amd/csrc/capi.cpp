@@ -23,7 +23,11 @@ struct swn_ctx {
 };
 struct swn_model {
   std::shared_ptr<CtxBox> keep;     // declared first: released after the model
-  std::unique_ptr<Model> m;
+  std::shared_ptr<Model> sharer;    // the model whose arenas this one uses (swn_model_create_shared): outlives it
+  std::shared_ptr<Model> m;
+  // what it was created with (a sharing model is created like its sharer, at another batch size)
+  int kind = 0, is_train = 1, num_roi = 12, body_channels = 3, cloth_channels = 19, patchgan_layers = 3;
+  float dropout = 0.5f;
 };
 struct swn_pipeline {
   std::shared_ptr<CtxBox> keep;
@@ -114,6 +118,8 @@ int swn_warp_model_create_ex(swn_ctx* ctx, int batch, int height, int width, int
     auto h = std::make_unique<swn_model>();
     h->keep = ctx->box;
     h->m.reset(create_warp_model(*ctx->c, batch, height, width, is_train != 0, dropout, body_channels, cloth_channels));
+    h->kind = 0; h->is_train = is_train != 0; h->dropout = dropout; h->body_channels = body_channels; h->cloth_channels = cloth_channels;
+    h->patchgan_layers = ctx->c->patchgan_layers;
     *out = h.release();
   });
 }
@@ -128,12 +134,38 @@ int swn_texture_model_create_ex(swn_ctx* ctx, int batch, int height, int width, 
     auto h = std::make_unique<swn_model>();
     h->keep = ctx->box;
     h->m.reset(create_texture_model(*ctx->c, batch, height, width, is_train != 0, num_roi, cloth_channels));
+    h->kind = 1; h->is_train = is_train != 0; h->num_roi = num_roi; h->cloth_channels = cloth_channels;
+    h->patchgan_layers = ctx->c->patchgan_layers;
     *out = h.release();
   });
 }
 int swn_texture_model_create(swn_ctx* ctx, int batch, int height, int width, int is_train, int num_roi,
                              swn_model** out) {
   return swn_texture_model_create_ex(ctx, batch, height, width, is_train, num_roi, 19, out);
+}
+int swn_model_create_shared(swn_model* sharer, int batch, int height, int width, swn_model** out) {
+  return guard([&] {
+    REQUIRE(sharer && out, "NULL argument");
+    REQUIRE(batch > 0 && height > 0 && width > 0, "bad shape");
+    std::shared_ptr<Model> root = sharer->sharer ? sharer->sharer : sharer->m;        // always the owner of the arenas
+    Ctx& c = *root->ctx;
+    auto h = std::make_unique<swn_model>();
+    h->keep = sharer->keep;
+    h->sharer = root;
+    h->kind = sharer->kind; h->is_train = sharer->is_train; h->dropout = sharer->dropout; h->num_roi = sharer->num_roi;
+    h->body_channels = sharer->body_channels; h->cloth_channels = sharer->cloth_channels; h->patchgan_layers = sharer->patchgan_layers;
+    const int layers_was = c.patchgan_layers;
+    c.patchgan_layers = sharer->patchgan_layers;
+    try {
+      if (h->kind == 0)
+        h->m.reset(create_warp_model(c, batch, height, width, h->is_train != 0, h->dropout, h->body_channels, h->cloth_channels, root.get()));
+      else
+        h->m.reset(create_texture_model(c, batch, height, width, h->is_train != 0, h->num_roi, h->cloth_channels, root.get()));
+    } catch (...) { c.patchgan_layers = layers_was; throw; }
+    c.patchgan_layers = layers_was;
+    h->m->hyper = root->hyper;
+    *out = h.release();
+  });
 }
 int swn_model_destroy(swn_model* m) {
   return guard([&] { delete m; });

@@ -309,12 +309,20 @@ enum LossSlot {
 
 class Model {
  public:
+  // share != NULL: this model uses `share`'s parameter arenas -- weights, gradients, both Adam moments, step counters -- and owns
+  // only its activations and derived operands: the model of another batch size (an epoch's last partial batch, batch-1 inference
+  // beside training) without a second copy of the training state or copies between the two (swn_model_create_shared).  The
+  // sharer must outlive this model (the C ABI's handles see to that).
+  explicit Model(Model* share = nullptr)
+      : share_(share), arenaG(share ? share->arenaG : ownG_), arenaD(share ? share->arenaD : ownD_) {}
   virtual ~Model();                // derived destructors run first (nets, graphs), then the buffers go
+  Model* share_ = nullptr;
+  ParamArena ownG_, ownD_;
   Ctx::AllocList owned_allocs;     // every device buffer this model allocated (AllocScope in its entry points)
   Ctx* ctx = nullptr;
   int B = 0, H = 0, W = 0;
   bool is_train = true;
-  ParamArena arenaG, arenaD;
+  ParamArena &arenaG, &arenaD;
   std::unique_ptr<Net> G, D2, D1;
   float* losses = nullptr;       // device [L_COUNT]
   Hyper hyper;
@@ -425,7 +433,8 @@ class Pipeline {
 
 // body_channels / cloth_channels: --body_representation / --cloth_representation / --body_channels / --cloth_channels
 // of the reference (models/warp_model.py:49-55, options/base_options.py:75-105); defaults 3 (rgb) / 19 (labels)
-Model* create_warp_model(Ctx& ctx, int B, int H, int W, bool is_train, float dropout, int body_channels = 3, int cloth_channels = 19);
-Model* create_texture_model(Ctx& ctx, int B, int H, int W, bool is_train, int num_roi, int cloth_channels = 19);
+Model* create_warp_model(Ctx& ctx, int B, int H, int W, bool is_train, float dropout, int body_channels = 3, int cloth_channels = 19,
+                         Model* share = nullptr);
+Model* create_texture_model(Ctx& ctx, int B, int H, int W, bool is_train, int num_roi, int cloth_channels = 19, Model* share = nullptr);
 
 }  // namespace swn

@@ -175,7 +175,8 @@ class WarpModel final : public Model {
   // conditional-D buffer also receives the generator's tanh output each step: its slot is floored at 1 = sup |tanh|.
   float *slot_body = nullptr, *slot_cloth = nullptr, *slot_dx = nullptr;
 
-  WarpModel(Ctx& c, int B_, int H_, int W_, bool train, float drop, int body_channels, int cloth_channels) {
+  WarpModel(Ctx& c, int B_, int H_, int W_, bool train, float drop, int body_channels, int cloth_channels, Model* share = nullptr)
+      : Model(share) {
     ctx = &c; B = B_; H = H_; W = W_; is_train = train; dropout = drop;
     Cb = body_channels; Cc = cloth_channels; Cbp = round_up(Cb, 4); Ccp = round_up(Cc, 4);
     if (Cb < 1 || Cc < 2 || Cb > 64 || Cc > 64) throw Error(1, "WarpModel: body_channels in [1,64], cloth_channels in [2,64]");
@@ -192,7 +193,7 @@ class WarpModel final : public Model {
     G->set_external_slot(cloth.vbase, slot_cloth);
     Var fake_slot = Dx.batch(0, B).slice(0, Ccp);
     build_warp_generator(*G, body, cloth, fake_slot, dropout, Cb, Cc);
-    arenaG.allocate(c);
+    if (!arenaG.frozen) arenaG.allocate(c);          // (a sharing model binds the sharer's frozen arena: shapes were checked)
     G->finalize({fake_slot});
     losses = static_cast<float*>(c.alloc(L_COUNT * sizeof(float)));
     if (train) {
@@ -204,7 +205,7 @@ class WarpModel final : public Model {
       D2->keep_wino_inputs = true;
       D2->set_external_slot(Dx.vbase, slot_dx);
       pred2 = build_patchgan(*D2, Dx, c.patchgan_layers, cimap);
-      arenaD.allocate(c);
+      if (!arenaD.frozen) arenaD.allocate(c);
       D2->finalize({pred2});
       // second instance over the first B images, bound to the same (now frozen) arena
       D1 = std::make_unique<Net>(c, arenaD);
@@ -299,8 +300,9 @@ class WarpModel final : public Model {
   }
 };
 
-Model* create_warp_model(Ctx& ctx, int B, int H, int W, bool is_train, float dropout, int body_channels, int cloth_channels) {
-  return new WarpModel(ctx, B, H, W, is_train, dropout, body_channels, cloth_channels);
+Model* create_warp_model(Ctx& ctx, int B, int H, int W, bool is_train, float dropout, int body_channels, int cloth_channels, Model* share) {
+  if (share && !dynamic_cast<WarpModel*>(share)) throw Error(1, "shared model: the sharer is not a warp model");
+  return new WarpModel(ctx, B, H, W, is_train, dropout, body_channels, cloth_channels, share);
 }
 
 }  // namespace swn

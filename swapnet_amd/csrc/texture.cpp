@@ -129,7 +129,8 @@ class TextureModel final : public Model {
   Var tex, unet_in, Dx, pred2, pred1, vin_f, vin_t;
   float* rois = nullptr;
   int num_roi = 12;
-  ParamArena arenaV;
+  ParamArena ownV_;
+  ParamArena& arenaV;
   std::unique_ptr<Net> VF, VT;
   Net* net_for_patterns(int net) override { return net == 3 ? VF.get() : Model::net_for_patterns(net); }
   std::vector<Var> feat_f, feat_t;
@@ -140,7 +141,8 @@ class TextureModel final : public Model {
   }
 
   int Cc = 19, Ccp = 20, RC = 36;       // cloth channels (logical / padded), ROI-pooled texture channels 3 * num_roi
-  TextureModel(Ctx& c, int B_, int H_, int W_, bool train, int nroi, int cloth_channels) {
+  TextureModel(Ctx& c, int B_, int H_, int W_, bool train, int nroi, int cloth_channels, TextureModel* share = nullptr)
+      : Model(share), arenaV(share ? share->arenaV : ownV_) {
     ctx = &c; B = B_; H = H_; W = W_; is_train = train; num_roi = nroi;
     Cc = cloth_channels; Ccp = round_up(Cc, 4); RC = 3 * num_roi;
     if (Cc < 1 || Cc > 64) throw Error(1, "TextureModel: cloth_channels in [1,64]");
@@ -154,7 +156,7 @@ class TextureModel final : public Model {
     rois = static_cast<float*>(c.alloc((size_t)B * num_roi * 4 * sizeof(float)));
     Var fake_slot = Dx.batch(0, B).slice(0, 4);
     build_texture_generator(*G, tex, rois, num_roi, unet_in.slice(RC, Ccp), unet_in, fake_slot, H, Cc);
-    arenaG.allocate(c);
+    if (!arenaG.frozen) arenaG.allocate(c);
     G->finalize({fake_slot});
     losses = static_cast<float*>(c.alloc(L_COUNT * sizeof(float)));
     if (!train) return;
@@ -165,7 +167,7 @@ class TextureModel final : public Model {
     D2 = std::make_unique<Net>(c, arenaD);
     D2->keep_wino_inputs = true;
     pred2 = build_patchgan(*D2, Dx, c.patchgan_layers, cimap);
-    arenaD.allocate(c);
+    if (!arenaD.frozen) arenaD.allocate(c);
     D2->finalize({pred2});
     D1 = std::make_unique<Net>(c, arenaD);
     pred1 = build_patchgan(*D1, Dx.batch(0, B), c.patchgan_layers, cimap, 4);        // d(fakes) only: the condition is data
@@ -175,7 +177,7 @@ class TextureModel final : public Model {
     vin_f = VF->alloc_var(B, H, W, 4, true);
     VF->affine(fake_slot, vin_f, 2.f, -1.f);              // x <- 2x - 1 (perceptual.py:70)
     feat_f = build_vgg16_slices(*VF, vin_f);
-    arenaV.allocate(c);
+    if (!arenaV.frozen) arenaV.allocate(c);
     VT = std::make_unique<Net>(c, arenaV);
     vin_t = VT->alloc_var(B, H, W, 4, false);
     VT->affine(Dx.batch(B, B).slice(0, 4), vin_t, 2.f, -1.f);
@@ -352,8 +354,10 @@ class TextureModel final : public Model {
   }
 };
 
-Model* create_texture_model(Ctx& ctx, int B, int H, int W, bool is_train, int num_roi, int cloth_channels) {
-  return new TextureModel(ctx, B, H, W, is_train, num_roi, cloth_channels);
+Model* create_texture_model(Ctx& ctx, int B, int H, int W, bool is_train, int num_roi, int cloth_channels, Model* share) {
+  TextureModel* sh = dynamic_cast<TextureModel*>(share);
+  if (share && !sh) throw Error(1, "shared model: the sharer is not a texture model");
+  return new TextureModel(ctx, B, H, W, is_train, num_roi, cloth_channels, sh);
 }
 
 }  // namespace swn

@@ -132,11 +132,25 @@ class NativeModel:
     NHWC arenas.  Tensors cross the boundary as NCHW fp32, exactly as the reference holds them."""
 
     def __init__(self, ctx, kind, batch, height, width, is_train=True, dropout=0.5, num_roi=12, body_channels=3,
-                 cloth_channels=19, n_layers_D=3):
+                 cloth_channels=19, n_layers_D=3, share=None):
+        """share = another NativeModel of the same kind: the new model uses ITS parameter arenas (weights, gradients, Adam
+        moments, step counters) and owns only activations -- the model of another batch size on the same training state
+        (swn_model_create_shared)."""
         self.ctx, self.lib, self.kind = ctx, ctx.lib, kind
         self.B, self.H, self.W, self.is_train = batch, height, width, is_train
         self.body_channels, self.cloth_channels = body_channels, cloth_channels
         self.n_layers_D = int(n_layers_D)
+        self.share = share
+        if share is not None:
+            if share.kind != kind:
+                raise ValueError("a sharing model must be of its sharer's kind")
+            h = C.c_void_p()
+            self.lib.call("swn_model_create_shared", share.handle, batch, height, width, C.byref(h))
+            self.is_train, self.body_channels, self.cloth_channels = share.is_train, share.body_channels, share.cloth_channels
+            self.n_layers_D, self.out_channels = share.n_layers_D, share.out_channels
+            self.handle = h
+            self._keep = []
+            return
         # a context-level option read at model construction (define_D's n_layers_D, base_gan.py:147): set it for this model,
         # whatever an earlier model on the same context asked for
         self.lib.call("swn_ctx_set_patchgan_layers", ctx.handle, self.n_layers_D)

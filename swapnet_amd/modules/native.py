@@ -11,10 +11,10 @@ from .. import engine
 
 
 class NativeBackend:
-    """Owns the native model(s) of one GAN stage.  The arena layout of a network does not
-    depend on the batch size, so when a differently-sized batch arrives (last batch of an
-    epoch, batch_size=1 inference) a second swn_model is created and the complete training
-    state is moved over with four flat device-to-device copies per network."""
+    """Owns the native model(s) of one GAN stage.  The arena layout of a network does not depend on the batch size, so when a
+    differently-sized batch arrives (last batch of an epoch, batch_size=1 inference) a second swn_model is created ON THE FIRST
+    ONE'S ARENAS (swn_model_create_shared): it adds its own activations only, and weights, gradients, Adam moments and step
+    counters are simply the same memory -- nothing is copied when the batch size changes back and forth."""
 
     def __init__(self, kind, is_train=True, dropout=0.5, num_roi=12, ctx=None, lib=None, device=None,
                  default_shape=(1, 64, 64), body_channels=3, cloth_channels=19):
@@ -34,15 +34,12 @@ class NativeBackend:
         key = (int(B), int(H), int(W))
         m = self.models.get(key)
         if m is None:
+            root = next(iter(self.models.values()), None)          # the first model owns the arenas, every later one shares them
             m = engine.NativeModel(self.ctx, self.kind, key[0], key[1], key[2], is_train=self.is_train,
                                    dropout=self.dropout, num_roi=self.num_roi, body_channels=self.body_channels,
-                                   cloth_channels=self.cloth_channels, n_layers_D=self.n_layers_D)
+                                   cloth_channels=self.cloth_channels, n_layers_D=self.n_layers_D, share=root)
             m.set_hyper(**self.hyper)
             self.models[key] = m
-            if self.cur is not None:
-                self._transfer(self.cur, m)
-        elif m is not self.cur and self.cur is not None:
-            self._transfer(self.cur, m)
         if self.cur is None and self._pending:
             for (net, which), sd in list(self._pending.items()):
                 m.load_state_dict(net, sd, which=which)
@@ -53,17 +50,6 @@ class NativeBackend:
     def _nets(self):
         return [engine.NET_G] + ([engine.NET_D] if self.is_train else []) + \
             ([engine.NET_VGG] if self.is_train and self.kind == "texture" else [])
-
-    def _transfer(self, src, dst):
-        for net in self._nets():
-            for which in (engine.W_WEIGHT, engine.W_EXP_AVG, engine.W_EXP_AVG_SQ):
-                if net == engine.NET_VGG and which != engine.W_WEIGHT:
-                    continue
-                dst.arena(net, which).copy_(src.arena(net, which))
-            dst.weight_arena(net)          # marks the weights dirty (dgrad operands follow)
-            if net != engine.NET_VGG:
-                dst.optim_step_count(net, src.optim_step_count(net))
-        self.ctx.sync()
 
     def any_model(self):
         """A model to answer shape-independent queries (parameter names / shapes)."""

@@ -333,3 +333,61 @@ def test_ce_mode_draws_no_labels_and_skips_D(tmp_path):
     torch.manual_seed(5)
     assert torch.equal(nxt, torch.rand(1))                        # no draws happened
     assert all(torch.equal(v, d0[k]) for k, v in model.net_discriminator.state_dict().items())
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_a_model_of_another_batch_size_shares_the_training_state(backend):
+    """swn_model_create_shared (round 4): the model NativeBackend builds for an epoch's last, smaller batch
+    uses the first model's parameter arenas instead of a second copy of weights, gradients and Adam moments plus transfers.
+    One step on the small model IS a step of the shared state (same memory, same counters); it allocates far less than a
+    model of its own; and it keeps working after the sharer's handle is gone."""
+    from oracle import swapnet_oracle as O
+    from swapnet_amd import engine
+    ctx = backends.gpu_ctx() if backend == "gpu" else backends.hostsim_ctx()
+    torch.manual_seed(1)
+    G, D = O.warp_module_params(), O.patchgan_params(22)
+    root = engine.NativeModel(ctx, "warp", 2, 64, 64)
+    backends.reset_state(root, {engine.NET_G: G, engine.NET_D: D})
+    before = ctx.bytes_allocated()
+    small = engine.NativeModel(ctx, "warp", 1, 64, 64, share=root)
+    added_shared = ctx.bytes_allocated() - before
+    own = engine.NativeModel(ctx, "warp", 1, 64, 64)
+    added_own = ctx.bytes_allocated() - before - added_shared
+    try:
+        # same memory: the arenas of the sharing model ARE the sharer's
+        for net in (engine.NET_G, engine.NET_D):
+            for which in (engine.W_WEIGHT, engine.W_GRAD, engine.W_EXP_AVG, engine.W_EXP_AVG_SQ):
+                assert small.arena(net, which).data_ptr() == root.arena(net, which).data_ptr()
+                assert own.arena(net, which).data_ptr() != root.arena(net, which).data_ptr()
+        # a step on the small model against the same step on an independent model loaded with the same state
+        backends.reset_state(own, {engine.NET_G: G, engine.NET_D: D})
+        batch = O.synth_warp_batch(1, 64, 64, seed=3)
+        for m in (small, own):
+            m.set_hyper()
+            for i, t in enumerate(batch):
+                m.set_input(i, t)
+            m.step([0.9, 0.8, 1.0], training=False, seed=0)
+        assert small.losses() == own.losses()
+        assert torch.equal(root.arena(engine.NET_G, engine.W_WEIGHT).cpu(), own.arena(engine.NET_G, engine.W_WEIGHT).cpu())
+        assert root.optim_step_count(engine.NET_G) == 1 and root.optim_step_count(engine.NET_D) == 1
+        # ... and the sharer trains on from there at its own batch size
+        b2 = O.synth_warp_batch(2, 64, 64, seed=4)
+        for i, t in enumerate(b2):
+            root.set_input(i, t)
+        root.step([0.9, 0.8, 1.0], training=False, seed=0)
+        assert small.optim_step_count(engine.NET_G) == 2
+        # the sharing model holds the shared buffers alive
+        w = small.arena(engine.NET_G, engine.W_WEIGHT).clone()
+        root.close()
+        for i, t in enumerate(batch):
+            small.set_input(i, t)
+        small.step([0.9, 0.8, 1.0], training=False, seed=0)
+        assert small.optim_step_count(engine.NET_G) == 3
+        assert not torch.equal(small.arena(engine.NET_G, engine.W_WEIGHT), w)
+        # footprint: activations and derived operands only -- no second set of four arenas (2.2 GB of the warp stage's ~2.25 GB state)
+        state_bytes = 4 * 4 * (small.arena(engine.NET_G, engine.W_WEIGHT).numel() + small.arena(engine.NET_D, engine.W_WEIGHT).numel())
+        assert 0 < added_shared <= added_own - 0.99 * state_bytes, (added_shared, added_own, state_bytes)
+        print("shared model added %.1f MB, an independent one %.1f MB; four arenas of both networks are %.1f MB"
+              % (added_shared / 1e6, added_own / 1e6, state_bytes / 1e6))
+    finally:
+        small.close(); own.close(); root.close()
