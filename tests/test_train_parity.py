@@ -69,7 +69,7 @@ def _check_step(m, st, gD, gG, tol_loss=1e-3, tol_out=1e-3, tol_gD=5e-3, tol_gG=
             worst[name] = max(worst.get(name, 0.0), e)
             assert e < tol, (what, name, k, e)
     # post-step weights.  The first AdamW step moves every element by lr * g / (|g| + eps): an element whose gradient
-    # is round-off-sized relative to its tensor (|g| < 1e-2 rms(g)) gets a sign-like update of arbitrary sign in the
+    # is round-off-sized relative to its tensor (|g| < 5e-2 rms(g)) gets a sign-like update of arbitrary sign in the
     # reference too, so those elements are compared on the un-amplified quantity only (their gradient, above) and
     # the weight check covers the rest -- at the full-size shapes a few such elements exist in otherwise clean
     # tensors (e.g. one unit of the innermost U-Net conv bias), unlike the "noise biases" which are noise throughout.
@@ -79,7 +79,11 @@ def _check_step(m, st, gD, gG, tol_loss=1e-3, tol_out=1e-3, tol_gD=5e-3, tol_gG=
             if noise_bias(k, list(ref)):
                 continue
             g = gref[k].double()
-            solid = g.abs() >= 1e-2 * g.pow(2).mean().sqrt()
+            # "solid" = well above what the gradient check itself tolerates: a gradient tensor may differ by tol_g (<= 1e-2) in
+            # rel-L2, i.e. an element's error can reach a few 1e-2 of the tensor's rms -- below 5e-2 rms the SIGN Adam's first
+            # step turns into +-lr is not determined (round 4: one bias element of the innermost U-Net conv at 1.3e-2 rms flipped
+            # at C3 bs 16 in training mode while its gradient tensor agreed to 3.6e-3)
+            solid = g.abs() >= 5e-2 * g.pow(2).mean().sqrt()
             if not bool(solid.any()):
                 continue
             a, b = got[k].double().cpu()[solid], v.double()[solid]
