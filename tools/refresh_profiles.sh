@@ -1,22 +1,24 @@
 # Produces everything under profiles/ for one round: run on the GPU box as
-#   gpurun --timeout 2400 -- 'bash tools/refresh_profiles.sh r03'
+#   gpurun --timeout 2400 -- 'bash tools/refresh_profiles.sh r04'
 # then copy the condensed files from gpurun_out/<tag>/ into profiles/ (README there lists the names).
 # Per-kernel profiles are taken with the library's second stream off (SWN_OVERLAP=0): with it on, kernels of the two
 # streams share the GPU and their individual durations / counters are not attributable.  Counter passes (--pmc) are
-# separate runs without any trace domain, one step each.  (The GPU test suite is a separate call: pytest tests -m gpu.)
-TAG=${1:-r03}
+# separate runs without any trace domain, one step each (bench.py --no-roofline runs exactly the timed steps).
+TAG=${1:-r04}
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/$TAG
 mkdir -p $O
 cd $R
 python bench.py --steps 20 --warmup 5 --with-h2d > $O/bench_c2.json 2> $O/bench_c2.err
-python -c "import json;d=json.load(open('$O/bench_c2.json'));print(d['value'],d['ms_per_step'],d['roofline']['achieved'],d['roofline']['frac'],d.get('cpu_baseline'))"
-python bench.py --stage texture --steps 10 --warmup 3 > $O/bench_c3.json 2> $O/bench_c3.err
+python -c "import json;d=json.load(open('$O/bench_c2.json'));print(d['value'],d['ms_per_step'],d['roofline']['achieved'],d['roofline']['frac'],d['roofline']['pipe_util_nominal_step'],d.get('cpu_baseline'))"
+python bench.py --stage texture --steps 12 --warmup 4 > $O/bench_c3.json 2> $O/bench_c3.err
+python bench.py --precision f16 --steps 12 --warmup 4 --no-cpu-baseline > $O/bench_c2_f16.json 2> $O/bench_c2_f16.err
+python bench.py --captured --steps 20 --warmup 5 --no-cpu-baseline --no-roofline > $O/bench_c2_captured.json 2> $O/bench_c2_captured.err
 python bench.py --stage infer > $O/bench_infer.json 2> $O/bench_infer.err
 SWAPNET_BENCH_RCCL1=1 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-roofline > $O/bench_c2_rccl_world1.json 2> $O/bench_c2_rccl_world1.err
 # same-box A/B of this round's switches (ms/step)
-for V in X=default SWN_PC_PLANES=3 SWN_PRECUT=0 SWN_WINO_S2=0 SWN_TAIL_WINO=0 SWN_FUSED_IN=0 SWN_WINO_ADJOINT=0 SWN_PREFETCH=0 SWN_OVERLAP=0; do
-  env $V python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-roofline 2> /dev/null | python -c "import sys,json;d=json.loads(sys.stdin.read());print('$V', d['ms_per_step'], d['value'])" >> $O/ab_switches.txt
+for V in X=default SWN_WGRAD_PLANES=3 SWN_WGRAD_PLANE=0 SWN_PAIR=0 SWN_AMAX_FUSED=0 SWN_SHARE_DY=0 SWN_FIRST_RING=0 SWN_PC_STAGES=3 SWN_OVERLAP=0 X=default2; do
+  env $V python bench.py --steps 12 --warmup 4 --no-cpu-baseline --no-roofline 2> /dev/null | python -c "import sys,json;d=json.loads(sys.stdin.read());print('$V', d['ms_per_step'], d['value'])" >> $O/ab_switches.txt
 done
 cat $O/ab_switches.txt
 cd /tmp && export TMPDIR=/tmp
@@ -27,11 +29,14 @@ SWN_OVERLAP=0 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_INSTS_VALU SQ_INSTS_LDS SQ_INST
 SWN_OVERLAP=0 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o warp -- $B --steps 1 --warmup 0 > $O/pmc_fetch.log 2>&1
 SWN_OVERLAP=0 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o warp -- $B --steps 1 --warmup 0 > $O/pmc_write.log 2>&1
 SWN_OVERLAP=0 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_tex -o tex -- $B --stage texture --steps 3 --warmup 1 > $O/prof_tex.log 2>&1
+SWN_OVERLAP=0 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch_tex -o tex -- $B --stage texture --steps 1 --warmup 0 > $O/pmc_fetch_tex.log 2>&1
+SWN_OVERLAP=0 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write_tex -o tex -- $B --stage texture --steps 1 --warmup 0 > $O/pmc_write_tex.log 2>&1
 # keep the merge small: the raw per-dispatch CSVs are condensed on the box
 cd $R
-for d in prof_warp prof_tex pmc_fetch pmc_write pmc_sq pmc_sq2; do
+for d in prof_warp prof_tex pmc_fetch pmc_write pmc_sq pmc_sq2 pmc_fetch_tex pmc_write_tex; do
   python profiles/summarize_rocprof.py $O/$d ${TAG}_$d --out $O > /dev/null 2>&1
   rm -rf $O/$d
 done
 python profiles/summarize_rocprof.py traffic ${TAG}_pmc_fetch ${TAG}_pmc_write ${TAG} --out $O
+python profiles/summarize_rocprof.py traffic ${TAG}_pmc_fetch_tex ${TAG}_pmc_write_tex ${TAG}_texture --out $O
 ls $O
