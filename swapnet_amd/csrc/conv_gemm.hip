@@ -2907,7 +2907,8 @@ static void launch_wgrad_dma(Stream& s, GemmP& p, int nb, const ConvWgradArgs& a
 // storage form of a layer's Winograd planes with these when the layer is built; the launchers re-check and throw on a mismatch.)
 bool conv_fwd_takes_pairs(int xC, int Npad) { return wino_pair_planes() && conv_precut_tile(xC, Npad) != 0; }
 bool conv_wgrad_takes_pairs(size_t T, int K, int Npad) {
-  if (!wino_pair_planes() || wgrad_planes() != 2 || Npad <= 32 || K % 4 || Npad % 4 || T % 16 || T * (size_t)std::max(K, Npad) * 4 >= ((size_t)1 << 31))
+  static const bool plane_off = getenv("SWN_WGRAD_PLANE") && atoi(getenv("SWN_WGRAD_PLANE")) == 0;   // pair words: plane loader only
+  if (plane_off || !wino_pair_planes() || wgrad_planes() != 2 || Npad <= 32 || K % 4 || Npad % 4 || T % 16 || T * (size_t)std::max(K, Npad) * 4 >= ((size_t)1 << 31))
     return false;
   const int bmk = Npad > 64 ? 128 : 256;
   const double fillf = (double)K / (double)(ceil_div(K, bmk) * bmk);

@@ -314,39 +314,64 @@ __device__ __forceinline__ float4 pair4(const float4& v, float sc) {
   return make_float4(__uint_as_float(__builtin_amdgcn_perm(L01, H01, 0x05040100u)), __uint_as_float(__builtin_amdgcn_perm(L01, H01, 0x07060302u)),
                      __uint_as_float(__builtin_amdgcn_perm(L23, H23, 0x05040100u)), __uint_as_float(__builtin_amdgcn_perm(L23, H23, 0x07060302u)));
 }
-template <class F>
+template <int VW> using fvec = float __attribute__((ext_vector_type(VW)));
+template <int VW> __device__ __forceinline__ float fvamax(const fvec<VW>& v) {
+  float m = 0.f;
+#pragma unroll
+  for (int i = 0; i < VW; ++i) m = fmaxf(m, fabsf(v[i]));
+  return m;
+}
+// {h | l << 16} words of VW (2 or 4) elements, two at a time with the packed conversions
+template <int VW> __device__ __forceinline__ fvec<VW> pairv(const fvec<VW>& v, float sc) {
+  fvec<VW> o;
+#pragma unroll
+  for (int i = 0; i < VW; i += 2) {
+    const float x0 = v[i] * sc, x1 = v[i + 1] * sc;
+    const pf16x2 h = pf16x2{(_Float16)x0, (_Float16)x1};
+    const pf16x2 l = pf16x2{(_Float16)(x0 - (float)h[0]), (_Float16)(x1 - (float)h[1])};
+    const unsigned Hh = __builtin_bit_cast(unsigned, h), Ll = __builtin_bit_cast(unsigned, l);
+    o[i] = __uint_as_float(__builtin_amdgcn_perm(Ll, Hh, 0x05040100u));
+    o[i + 1] = __uint_as_float(__builtin_amdgcn_perm(Ll, Hh, 0x07060302u));
+  }
+  return o;
+}
+// One thread per (tile, VW channels).  The A x A intermediate lives in registers (A*A*VW floats), so VW decides the occupancy:
+// 4 channels per thread is 256 VGPRs and ONE wave per SIMD for the 6-point forms, 2 channels is half of that -- and this kernel
+// is pure HBM streaming, where waves in flight are what hides the latency.
+template <class F, int VW>
 __global__ __launch_bounds__(256) void winog_input_kernel(const float* x, int xcs, int N, int H, int W, int C, int pad,
                                                           int pad_mode, int Th, int Tw, float* V, float* amax_out,
                                                           const float* in_amax, float gain, int* kscale_out) {
   constexpr int A = F::A, M = F::M;
-  const int C4 = C >> 2;
+  typedef fvec<VW> vt;
+  const int Cv = C / VW;
   const size_t T = (size_t)N * Th * Tw;
-  const size_t total = T * C4;
+  const size_t total = T * Cv;
   float am = 0.f;
   const bool pair = in_amax != nullptr;
   const float psc = pair ? __uint_as_float((unsigned)(127 + pair_scale_exp(in_amax, gain, kscale_out)) << 23) : 1.f;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-    const size_t tile = i / C4;
-    const int c = (int)(i - tile * C4) * 4;
+    const size_t tile = i / Cv;
+    const int c = (int)(i - tile * Cv) * VW;
     const int tx = (int)(tile % Tw); size_t q = tile / Tw;
     const int ty = (int)(q % Th); const int n = (int)(q / Th);
     int sy[A];
 #pragma unroll
     for (int a = 0; a < A; ++a) sy[a] = wsrc(M * ty - pad + a, H, pad_mode);
-    float4 t[A][A];
+    vt t[A][A];
 #pragma unroll
     for (int b = 0; b < A; ++b) {            // B^T d, one input column at a time
       const int sx = wsrc(M * tx - pad + b, W, pad_mode);
-      float4 d[A];
+      vt d[A];
 #pragma unroll
       for (int a = 0; a < A; ++a)
-        d[a] = (sy[a] >= 0 && sx >= 0) ? *reinterpret_cast<const float4*>(x + ((size_t)(n * H + sy[a]) * W + sx) * xcs + c)
-                                       : F4ZERO;
+        d[a] = (sy[a] >= 0 && sx >= 0) ? *reinterpret_cast<const vt*>(x + ((size_t)(n * H + sy[a]) * W + sx) * xcs + c) : vt(0.f);
 #pragma unroll
       for (int r = 0; r < A; ++r) {
-        float4 s = F4ZERO;
+        vt s = vt(0.f);
 #pragma unroll
-        for (int k = 0; k < A; ++k) f4mac(s, F::BT[r][k], d[k]);
+        for (int k = 0; k < A; ++k)
+          if (F::BT[r][k] != 0.f) s += F::BT[r][k] * d[k];
         t[r][b] = s;
       }
     }
@@ -354,11 +379,12 @@ __global__ __launch_bounds__(256) void winog_input_kernel(const float* x, int xc
     for (int a = 0; a < A; ++a)              // (.) B
 #pragma unroll
       for (int j = 0; j < A; ++j) {
-        float4 s = F4ZERO;
+        vt s = vt(0.f);
 #pragma unroll
-        for (int k = 0; k < A; ++k) f4mac(s, F::BT[j][k], t[a][k]);
-        *reinterpret_cast<float4*>(V + ((size_t)(a * A + j) * T + tile) * C + c) = pair ? pair4(s, psc) : s;
-        am = fmaxf(am, f4amax(s));
+        for (int k = 0; k < A; ++k)
+          if (F::BT[j][k] != 0.f) s += F::BT[j][k] * t[a][k];
+        *reinterpret_cast<vt*>(V + ((size_t)(a * A + j) * T + tile) * C + c) = pair ? pairv<VW>(s, psc) : s;
+        am = fmaxf(am, fvamax<VW>(s));
       }
   }
   if (!pair) amax_fold(am, amax_out);
@@ -461,35 +487,37 @@ __global__ __launch_bounds__(256) void winog_output_kernel(const float* Mx, int 
 }
 
 // dM = A dY A^T : m x m -> (m+2) x (m+2)   (A = AT^T)
-template <class F>
+template <class F, int VW>
 __global__ __launch_bounds__(256) void winog_dy_kernel(const float* dy, int dcs, int N, int H, int W, int C, int Th, int Tw,
                                                        float* dM, float* amax_out, const float* in_amax, float gain, int* kscale_out) {
   constexpr int A = F::A, M = F::M;
-  const int C4 = C >> 2;
+  typedef fvec<VW> vt;
+  const int Cv = C / VW;
   const size_t T = (size_t)N * Th * Tw;
-  const size_t total = T * C4;
+  const size_t total = T * Cv;
   float am = 0.f;
   const bool pair = in_amax != nullptr;
   const float psc = pair ? __uint_as_float((unsigned)(127 + pair_scale_exp(in_amax, gain, kscale_out)) << 23) : 1.f;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-    const size_t tile = i / C4;
-    const int c = (int)(i - tile * C4) * 4;
+    const size_t tile = i / Cv;
+    const int c = (int)(i - tile * Cv) * VW;
     const int tx = (int)(tile % Tw); size_t q = tile / Tw;
     const int ty = (int)(q % Th); const int n = (int)(q / Th);
-    float4 r[A][M];
+    vt r[A][M];
 #pragma unroll
     for (int b = 0; b < M; ++b) {
-      float4 g[M];
+      vt g[M];
 #pragma unroll
       for (int a = 0; a < M; ++a) {
         const int oy = M * ty + a, ox = M * tx + b;
-        g[a] = (oy < H && ox < W) ? *reinterpret_cast<const float4*>(dy + ((size_t)(n * H + oy) * W + ox) * dcs + c) : F4ZERO;
+        g[a] = (oy < H && ox < W) ? *reinterpret_cast<const vt*>(dy + ((size_t)(n * H + oy) * W + ox) * dcs + c) : vt(0.f);
       }
 #pragma unroll
       for (int p = 0; p < A; ++p) {
-        float4 s = F4ZERO;
+        vt s = vt(0.f);
 #pragma unroll
-        for (int a = 0; a < M; ++a) f4mac(s, F::AT[a][p], g[a]);
+        for (int a = 0; a < M; ++a)
+          if (F::AT[a][p] != 0.f) s += F::AT[a][p] * g[a];
         r[p][b] = s;
       }
     }
@@ -497,11 +525,12 @@ __global__ __launch_bounds__(256) void winog_dy_kernel(const float* dy, int dcs,
     for (int p = 0; p < A; ++p)
 #pragma unroll
       for (int j = 0; j < A; ++j) {
-        float4 s = F4ZERO;
+        vt s = vt(0.f);
 #pragma unroll
-        for (int b = 0; b < M; ++b) f4mac(s, F::AT[b][j], r[p][b]);
-        *reinterpret_cast<float4*>(dM + ((size_t)(p * A + j) * T + tile) * C + c) = pair ? pair4(s, psc) : s;
-        am = fmaxf(am, f4amax(s));
+        for (int b = 0; b < M; ++b)
+          if (F::AT[b][j] != 0.f) s += F::AT[b][j] * r[p][b];
+        *reinterpret_cast<vt*>(dM + ((size_t)(p * A + j) * T + tile) * C + c) = pair ? pairv<VW>(s, psc) : s;
+        am = fmaxf(am, fvamax<VW>(s));
       }
   }
   if (!pair) amax_fold(am, amax_out);
@@ -662,10 +691,12 @@ struct F42 {
 };
 
 // V[(a*5+j)][tile][q*C + c] = (BT d_q BT^T)[a][j],  d_q[i][j] = x[2 (4 ty + i) - 1 + s][2 (4 tx + j) - 1 + t],  q = 2 s + t
+template <int VW>
 __global__ __launch_bounds__(256) void wino_s2_input_kernel(const float* x, int xcs, int N, int H, int W, int C, int Th, int Tw,
                                                             float* V, float* amax_out, const float* in_amax, float gain, int* kscale_out) {
   constexpr int A = 5;
-  const int C4 = C >> 2;
+  typedef fvec<VW> vt;
+  const int C4 = C / VW;
   const size_t T = (size_t)N * Th * Tw;
   const size_t total = T * 4 * C4;
   const int CV = 4 * C;
@@ -673,7 +704,7 @@ __global__ __launch_bounds__(256) void wino_s2_input_kernel(const float* x, int 
   const bool pair = in_amax != nullptr;
   const float psc = pair ? __uint_as_float((unsigned)(127 + pair_scale_exp(in_amax, gain, kscale_out)) << 23) : 1.f;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-    const int c = (int)(i % C4) * 4; size_t r = i / C4;
+    const int c = (int)(i % C4) * VW; size_t r = i / C4;
     const int q = (int)(r & 3); const size_t tile = r >> 2;
     const int s = q >> 1, t = q & 1;
     const int tx = (int)(tile % Tw); size_t u = tile / Tw;
@@ -681,20 +712,21 @@ __global__ __launch_bounds__(256) void wino_s2_input_kernel(const float* x, int 
     int sy[A];
 #pragma unroll
     for (int a = 0; a < A; ++a) { const int e = 2 * (4 * ty + a) - 1 + s; sy[a] = (e >= 0 && e < H) ? e : -1; }
-    float4 tt[A][A];
+    vt tt[A][A];
 #pragma unroll
     for (int b = 0; b < A; ++b) {
       const int e = 2 * (4 * tx + b) - 1 + t;
       const int sx = (e >= 0 && e < W) ? e : -1;
-      float4 d[A];
+      vt d[A];
 #pragma unroll
       for (int a = 0; a < A; ++a)
-        d[a] = (sy[a] >= 0 && sx >= 0) ? *reinterpret_cast<const float4*>(x + ((size_t)(n * H + sy[a]) * W + sx) * xcs + c) : F4ZERO;
+        d[a] = (sy[a] >= 0 && sx >= 0) ? *reinterpret_cast<const vt*>(x + ((size_t)(n * H + sy[a]) * W + sx) * xcs + c) : vt(0.f);
 #pragma unroll
       for (int rr = 0; rr < A; ++rr) {
-        float4 acc = F4ZERO;
+        vt acc = vt(0.f);
 #pragma unroll
-        for (int k = 0; k < A; ++k) f4mac(acc, F42::BT[rr][k], d[k]);
+        for (int k = 0; k < A; ++k)
+          if (F42::BT[rr][k] != 0.f) acc += F42::BT[rr][k] * d[k];
         tt[rr][b] = acc;
       }
     }
@@ -702,11 +734,12 @@ __global__ __launch_bounds__(256) void wino_s2_input_kernel(const float* x, int 
     for (int a = 0; a < A; ++a)
 #pragma unroll
       for (int j = 0; j < A; ++j) {
-        float4 acc = F4ZERO;
+        vt acc = vt(0.f);
 #pragma unroll
-        for (int k = 0; k < A; ++k) f4mac(acc, F42::BT[j][k], tt[a][k]);
-        *reinterpret_cast<float4*>(V + ((size_t)(a * A + j) * T + tile) * CV + q * C + c) = pair ? pair4(acc, psc) : acc;
-        am = fmaxf(am, f4amax(acc));
+        for (int k = 0; k < A; ++k)
+          if (F42::BT[j][k] != 0.f) acc += F42::BT[j][k] * tt[a][k];
+        *reinterpret_cast<vt*>(V + ((size_t)(a * A + j) * T + tile) * CV + q * C + c) = pair ? pairv<VW>(acc, psc) : acc;
+        am = fmaxf(am, fvamax<VW>(acc));
       }
   }
   if (!pair) amax_fold(am, amax_out);
@@ -875,65 +908,76 @@ __global__ __launch_bounds__(256) void winog_filter_pc_kernel(WShape w, int mode
   constexpr int A = F::A, R = F::R;
   const int NBc = BN / 32, tiles_n = (Nn + BN - 1) / BN;
   const size_t total = (size_t)(K / 8) * tiles_n * BN;
-  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const size_t i = ((size_t)(blockIdx.x / (8 * A)) * 8 + blockIdx.x % 8) * 256 + threadIdx.x;   // slab: see the row index below
   const int PL = planes;               // 3 bf16 planes (wamax == NULL), 2 or 1 fp16 planes of the scaled filter
   int kB = 0;
   if (wamax) kB = wino_scale_exp(wamax, threadIdx.x & 63, 10);       // PC_TOP_B; |G g G^T| <= |g|max for both 6-point forms
   if (i >= total) return;
   // consecutive threads take consecutive COLUMNS (coalesced reads of the packed weights: a thread per operand position read
-  // every fourth column, a quarter of each sector); the operand position of column nl is pos = (nl % NB) * 32 + nl / NB
+  // every fourth column, a quarter of each sector); the operand position of column nl is pos = (nl % NB) * 32 + nl / NB.
+  // The plane ROW a = (blockIdx.x % 8A) / 8: a thread builds (G g)[a][.] for its 8 k and writes the A planes (a, 0..A-1).
+  // The A rows of one 256-thread slab of taps are blocks b, b + 8, ..., b + 8(A-1): dispatched together and, workgroups going
+  // round-robin over the 8 XCDs, onto the SAME XCD, so the re-reads (9 floats per (k, n), A times) meet in that L2 -- with the
+  // row as the slow grid index each of the A passes streamed the 38 MB of a 1024 x 1024 layer again.
   const int nl = (int)(i % BN); const size_t q = i / BN;
   const int tn = (int)(q % tiles_n), kq = (int)(q / tiles_n);
   const int n = tn * BN + nl;
   const int pos = (nl % NBc) * 32 + nl / NBc;
-  // t[k][r][b] = (G g)[r][b] for the 8 k of this entry
-  float t[8][A][R];
+  const int a = (int)(blockIdx.x % (8 * A)) / 8;
+  float Ga[R];
 #pragma unroll
-  for (int kk = 0; kk < 8; ++kk) {
-    const int k = kq * 8 + kk;
-    float g[R][R];
+  for (int qq = 0; qq < R; ++qq) Ga[qq] = F::G[a][qq];
+  // t[kk][b] = (G g)[a][b] for the 8 k of this entry
+  float t[8][R];
 #pragma unroll
-    for (int a = 0; a < R; ++a)
+  for (int kk = 0; kk < 8; ++kk)
 #pragma unroll
-      for (int b = 0; b < R; ++b) {
-        float v = 0.f;
-        if (mode == 0) { if (k < w.Cip && n < w.Npad) v = packed[((size_t)(a * R + b) * w.Cip + k) * w.Npad + n]; }
-        else if (mode == 1) { if (n < w.Cip && k < w.Npad) v = packed[((size_t)((R - 1 - a) * R + (R - 1 - b)) * w.Cip + n) * w.Npad + k]; }
-        else { if (n < w.Cip && k < w.Npad) v = packed[((size_t)(a * R + b) * w.Cip + n) * w.Npad + k]; }
-        g[a][b] = v;
+    for (int b = 0; b < R; ++b) t[kk][b] = 0.f;
+  if (mode == 0) {
+    if (n < w.Npad) {
+#pragma unroll
+      for (int kk = 0; kk < 8; ++kk) {
+        const int k = kq * 8 + kk;
+        if (k < w.Cip) {
+#pragma unroll
+          for (int qq = 0; qq < R; ++qq)
+#pragma unroll
+            for (int b = 0; b < R; ++b) t[kk][b] += Ga[qq] * packed[((size_t)(qq * R + b) * w.Cip + k) * w.Npad + n];
+        }
       }
+    }
+  } else if (n < w.Cip && kq * 8 < w.Npad) {       // transposed forms: the 8 k are consecutive floats of one row (Npad % 8 == 0)
 #pragma unroll
-    for (int r = 0; r < A; ++r)
+    for (int qq = 0; qq < R; ++qq)
 #pragma unroll
       for (int b = 0; b < R; ++b) {
-        float s = 0.f;
-#pragma unroll
-        for (int qq = 0; qq < R; ++qq) f1mac(s, F::G[r][qq], g[qq][b]);
-        t[kk][r][b] = s;
+        const int tap = mode == 1 ? (R - 1 - qq) * R + (R - 1 - b) : qq * R + b;
+        const float4* src = reinterpret_cast<const float4*>(packed + ((size_t)tap * w.Cip + n) * w.Npad + kq * 8);
+        const float4 g0 = src[0], g1 = src[1];
+        t[0][b] += Ga[qq] * g0.x; t[1][b] += Ga[qq] * g0.y; t[2][b] += Ga[qq] * g0.z; t[3][b] += Ga[qq] * g0.w;
+        t[4][b] += Ga[qq] * g1.x; t[5][b] += Ga[qq] * g1.y; t[6][b] += Ga[qq] * g1.z; t[7][b] += Ga[qq] * g1.w;
       }
   }
   const size_t e0 = ((((size_t)(kq >> 1) * tiles_n + tn) * 2 + (kq & 1)) * PL) * BN + pos;     // in 16-byte entries
   const float sb = __uint_as_float((unsigned)(127 + kB) << 23);
 #pragma unroll
-  for (int a = 0; a < A; ++a)
+  for (int j = 0; j < A; ++j) {
+    float u[8];
 #pragma unroll
-    for (int j = 0; j < A; ++j) {
-      float u[8];
+    for (int kk = 0; kk < 8; ++kk) {
+      float s = 0.f;
 #pragma unroll
-      for (int kk = 0; kk < 8; ++kk) {
-        float s = 0.f;
-#pragma unroll
-        for (int qq = 0; qq < R; ++qq) f1mac(s, F::G[j][qq], t[kk][a][qq]);
-        u[kk] = s;
-      }
-      unsigned short* panel = out + (size_t)(a * A + j) * panel_elems;
-      if (wamax) {
-        cut8_store_h(u, sb, reinterpret_cast<wu32x4*>(panel), e0, (size_t)BN, PL == 2);
-        if (i == 0) *reinterpret_cast<int*>(panel + (size_t)(K / 16) * tiles_n * 2 * PL * BN * 8) = kB;  // trailer of every panel
-      } else {
-        cut8_store(u, reinterpret_cast<wu32x4*>(panel), e0, (size_t)BN);
-      }
+      for (int qq = 0; qq < R; ++qq) f1mac(s, F::G[j][qq], t[kk][qq]);
+      u[kk] = s;
     }
+    unsigned short* panel = out + (size_t)(a * A + j) * panel_elems;
+    if (wamax) {
+      cut8_store_h(u, sb, reinterpret_cast<wu32x4*>(panel), e0, (size_t)BN, PL == 2);
+      if (i == 0) *reinterpret_cast<int*>(panel + (size_t)(K / 16) * tiles_n * 2 * PL * BN * 8) = kB;  // trailer of every panel
+    } else {
+      cut8_store(u, reinterpret_cast<wu32x4*>(panel), e0, (size_t)BN);
+    }
+  }
 }
 
 
@@ -1129,6 +1173,11 @@ static int variant(int m, int r) {
   if (m == 4 && r == 2) return 3;            // strided form: output / dy / patch transforms only
   throw Error(1, "winograd: supported forms are F(2,3), F(4,3), F(3,4) and the strided F(4,2)");
 }
+// channels per thread of the 6-point input / dY transforms (SWN_WINO_VW=4: the round-3 form, one wave per SIMD on the input side)
+static int wino_vec_width() {
+  static const int vw = [] { const char* e = getenv("SWN_WINO_VW"); return e && atoi(e) == 4 ? 4 : 2; }();
+  return vw;
+}
 // gains of the pair-form bound (squared largest absolute row sum of the transform matrix)
 static float input_gain(int v) { return v == 3 ? 9.f : 100.f; }                         // B^T of F(4,2): 3; of the 6-point forms: 10
 static float dy_gain(int v) { return v == 1 ? 225.f : (v == 2 ? 49.f : 16.f); }        // A of F(4,3): 15; F(3,4): 7; F(4,2): 4
@@ -1137,17 +1186,18 @@ void wino_input_transform(Stream& s, int m, int r, const TView& x, int pad, int 
   const int v = variant(m, r);
   if (v == 3) throw Error(1, "wino_input_transform: F(4,2) is the strided form (wino_s2_input_transform)");
   if (x.C % 4 || x.cs % 4) throw Error(1, "wino_input_transform: C must be a multiple of 4");
-  const size_t total = (size_t)x.N * Th * Tw * (x.C / 4);
+  const int vw = wino_vec_width();
+  const size_t total = (size_t)x.N * Th * Tw * (x.C / (v == 0 ? 4 : vw));
   const dim3 grid(wgrid(total));
   if (v == 0 && in_amax) throw Error(1, "wino_input_transform: F(2,3) planes have no pair form");
+#define SWN_WIN_LAUNCH(F, VW)                                                                                                  \
+  hipLaunchKernelGGL((winog_input_kernel<F, VW>), grid, dim3(256), 0, hs(s), x.p, x.cs, x.N, x.H, x.W, x.C, pad, pad_mode, Th, \
+                     Tw, V, amax_out, in_amax, input_gain(v), kscale_out)
   if (v == 0)            // (F(2,3) planes feed the fp32-operand kernels only: no slot to fill)
     hipLaunchKernelGGL(wino_input_kernel, grid, dim3(256), 0, hs(s), x.p, x.cs, x.N, x.H, x.W, x.C, pad, pad_mode, Th, Tw, V);
-  else if (v == 1)
-    hipLaunchKernelGGL(winog_input_kernel<F43>, grid, dim3(256), 0, hs(s), x.p, x.cs, x.N, x.H, x.W, x.C, pad, pad_mode, Th,
-                       Tw, V, amax_out, in_amax, input_gain(v), kscale_out);
-  else
-    hipLaunchKernelGGL(winog_input_kernel<F34>, grid, dim3(256), 0, hs(s), x.p, x.cs, x.N, x.H, x.W, x.C, pad, pad_mode, Th,
-                       Tw, V, amax_out, in_amax, input_gain(v), kscale_out);
+  else if (v == 1) { if (vw == 4) SWN_WIN_LAUNCH(F43, 4); else SWN_WIN_LAUNCH(F43, 2); }
+  else { if (vw == 4) SWN_WIN_LAUNCH(F34, 4); else SWN_WIN_LAUNCH(F34, 2); }
+#undef SWN_WIN_LAUNCH
   check_launch("wino_input_transform");
 }
 void wino_filter_transform(Stream& s, int m, int r, const WShape& w, int mode, const float* packed, float* U) {
@@ -1168,7 +1218,7 @@ void wino_filter_transform_pc(Stream& s, int m, int r, const WShape& w, int mode
   const int K = mode == 0 ? w.Cip : w.Npad, Nn = mode == 0 ? w.Npad : w.Cip;
   if (K % 16 || (bn != 64 && bn != 128)) throw Error(1, "wino_filter_transform_pc: K must be a multiple of 16, tile 64 or 128");
   const size_t total = (size_t)(K / 8) * ((Nn + bn - 1) / bn) * bn;
-  const dim3 grid((unsigned)((total + 255) / 256));
+  const dim3 grid((unsigned)((((total + 255) / 256 + 7) / 8) * 8) * (unsigned)(m + r - 1));      // slabs in groups of 8, A rows each
   // two-plane form: the scale comes from the amax of the layer's packed weights ([r * r][Cip][Npad])
   const float* wamax = conv_precut_amax(s, packed, (size_t)r * r * w.Cip, w.Npad, 1, 0);
   if (v == 1)
@@ -1202,20 +1252,19 @@ void wino_dy_transform(Stream& s, int m, int r, const TView& dy, int Th, int Tw,
                        int* kscale_out) {
   const int v = variant(m, r);
   if (dy.C % 4 || dy.cs % 4) throw Error(1, "wino_dy_transform: C must be a multiple of 4");
-  const size_t total = (size_t)dy.N * Th * Tw * (dy.C / 4);
+  const int vw = v == 0 ? 4 : wino_vec_width();
+  const size_t total = (size_t)dy.N * Th * Tw * (dy.C / vw);
   const dim3 grid(wgrid(total));
   if (v == 0 && in_amax) throw Error(1, "wino_dy_transform: F(2,3) planes have no pair form");
+#define SWN_WDY_LAUNCH(F, VW)                                                                                                       \
+  hipLaunchKernelGGL((winog_dy_kernel<F, VW>), grid, dim3(256), 0, hs(s), dy.p, dy.cs, dy.N, dy.H, dy.W, dy.C, Th, Tw, dM, amax_out, \
+                     in_amax, dy_gain(v), kscale_out)
   if (v == 0)
     hipLaunchKernelGGL(wino_dy_kernel, grid, dim3(256), 0, hs(s), dy.p, dy.cs, dy.N, dy.H, dy.W, dy.C, Th, Tw, dM);
-  else if (v == 1)
-    hipLaunchKernelGGL(winog_dy_kernel<F43>, grid, dim3(256), 0, hs(s), dy.p, dy.cs, dy.N, dy.H, dy.W, dy.C, Th, Tw, dM, amax_out, in_amax,
-                       dy_gain(v), kscale_out);
-  else if (v == 2)
-    hipLaunchKernelGGL(winog_dy_kernel<F34>, grid, dim3(256), 0, hs(s), dy.p, dy.cs, dy.N, dy.H, dy.W, dy.C, Th, Tw, dM, amax_out, in_amax,
-                       dy_gain(v), kscale_out);
-  else
-    hipLaunchKernelGGL(winog_dy_kernel<F42>, grid, dim3(256), 0, hs(s), dy.p, dy.cs, dy.N, dy.H, dy.W, dy.C, Th, Tw, dM, amax_out, in_amax,
-                       dy_gain(v), kscale_out);
+  else if (v == 1) { if (vw == 4) SWN_WDY_LAUNCH(F43, 4); else SWN_WDY_LAUNCH(F43, 2); }
+  else if (v == 2) { if (vw == 4) SWN_WDY_LAUNCH(F34, 4); else SWN_WDY_LAUNCH(F34, 2); }
+  else { if (vw == 4) SWN_WDY_LAUNCH(F42, 4); else SWN_WDY_LAUNCH(F42, 2); }
+#undef SWN_WDY_LAUNCH
   check_launch("wino_dy_transform");
 }
 void tailw_filter_transform(Stream& s, const WShape& w, const float* folded, float* U) {
@@ -1244,9 +1293,14 @@ void tailw_dy_transform(Stream& s, const TView& dy, int Th, int Tw, int Npad, fl
 }
 void wino_s2_input_transform(Stream& s, const TView& x, int Th, int Tw, float* V, float* amax_out, const float* in_amax, int* kscale_out) {
   if (x.C % 4 || x.cs % 4) throw Error(1, "wino_s2_input_transform: C must be a multiple of 4");
-  const size_t total = (size_t)x.N * Th * Tw * 4 * (x.C / 4);
-  hipLaunchKernelGGL(wino_s2_input_kernel, dim3(wgrid(total)), dim3(256), 0, hs(s), x.p, x.cs, x.N, x.H, x.W, x.C, Th, Tw, V, amax_out,
-                     in_amax, 9.f, kscale_out);
+  const int vw = wino_vec_width();
+  const size_t total = (size_t)x.N * Th * Tw * 4 * (x.C / vw);
+  if (vw == 4)
+    hipLaunchKernelGGL(wino_s2_input_kernel<4>, dim3(wgrid(total)), dim3(256), 0, hs(s), x.p, x.cs, x.N, x.H, x.W, x.C, Th, Tw, V,
+                       amax_out, in_amax, 9.f, kscale_out);
+  else
+    hipLaunchKernelGGL(wino_s2_input_kernel<2>, dim3(wgrid(total)), dim3(256), 0, hs(s), x.p, x.cs, x.N, x.H, x.W, x.C, Th, Tw, V,
+                       amax_out, in_amax, 9.f, kscale_out);
   check_launch("wino_s2_input_transform");
 }
 void wino_s2_input_adjoint(Stream& s, float* dV, int Cf, int Th, int Tw, const TView& dx, const float* bias, int accumulate) {
