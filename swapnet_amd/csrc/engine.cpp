@@ -1205,9 +1205,9 @@ void Net::refresh_dgrad() {
   dg_version = arena.version;
 }
 void Net::backward(bool wgrad, bool igrad) { backward_range(wgrad, igrad, 0, (int)ops.size()); }
-void Net::backward_range(bool wgrad, bool igrad, int op_begin, int op_end) {
+void Net::backward_range(bool wgrad, bool igrad, int op_begin, int op_end, bool join) {
   for (int i = op_end - 1; i >= op_begin; --i) { if (route_on()) route_label(ops[i]->label.c_str(), 'b'); ops[i]->bwd(*this, *ops[i], wgrad, igrad); }
-  ctx.join_side();      // weight gradients of the range are final for whatever the main stream does next
+  if (join) ctx.join_side();      // weight gradients of the range are final for whatever the main stream does next
 }
 int Net::split_point(double frac, size_t* arena_off) const {
   const size_t want = (size_t)(frac * (double)arena.n);
@@ -1251,7 +1251,7 @@ static std::vector<double> grad_cuts() {
 }
 int Model::backward_G_parts() const { return (int)grad_cuts().size() + 1; }
 
-void Model::backward_G_part(float label_real, int part, size_t* ready_off, size_t* ready_count) {
+void Model::backward_G_part(float label_real, int part, size_t* ready_off, size_t* ready_count, bool join) {
   const int np = backward_G_parts();
   if (part < 0 || part >= np) throw Error(1, "backward_G_part: part out of range");
   size_t hi_off = arenaG.n, lo_off = 0;
@@ -1263,7 +1263,7 @@ void Model::backward_G_part(float label_real, int part, size_t* ready_off, size_
     backward_G_head(label_real);
     G->refresh_dgrad();
   }
-  G->backward_range(true, false, lo_op, hi_op);
+  G->backward_range(true, false, lo_op, hi_op, join);
   if (ready_off) *ready_off = lo_off;
   if (ready_count) *ready_count = hi_off - lo_off;
 }
@@ -1360,7 +1360,8 @@ void Model::perceptual(const float*, const float*, int, float*, float, float, fl
   throw Error(1, "perceptual: only the texture model carries the VGG16 network (not implemented for this model)");
 }
 
-void Model::optimizer_step_range(int net, size_t off, size_t count, int first) {
+void Model::optimizer_step_range(int net, size_t off, size_t count, int first) { optimizer_step_range_on(ctx->s, net, off, count, first); }
+void Model::optimizer_step_range_on(Stream& st, int net, size_t off, size_t count, int first) {
   ParamArena& A = arena(net);
   if (off % 4 || off + count > A.n) throw Error(1, "optimizer_step_range: range outside the arena / not 16-byte aligned");
   if (first) A.step += 1;
@@ -1370,8 +1371,25 @@ void Model::optimizer_step_range(int net, size_t off, size_t count, int first) {
   a.lr = net == 0 ? hyper.lr : hyper.d_lr;
   a.weight_decay = net == 0 ? hyper.weight_decay : hyper.d_weight_decay;
   a.beta1 = net == 0 ? hyper.b1 : hyper.d_b1; a.beta2 = net == 0 ? hyper.b2 : hyper.d_b2; a.eps = 1e-8f; a.step = A.step;
-  adamw_step(ctx->s, a);
+  if (indirect) a.sched_dev = net == 0 ? reinterpret_cast<const float*>(sp_dev) + 6 : reinterpret_cast<const float*>(sp_dev) + 8;
+  adamw_step(st, a);
   A.version += 1;
+}
+
+void Model::backward_G_streamed(float label_real) {
+  const int np = backward_G_parts();
+  const int ver = arenaG.version;
+  for (int part = 0; part < np; ++part) {
+    size_t off = 0, count = 0;
+    backward_G_part(label_real, part, &off, &count, /*join=*/false);
+    // the side stream already carries the bucket's weight gradients; the fork orders it behind the bucket's main-stream work
+    // too (bias sums, the input-gradient chain that produced their operands).  Nothing later on either stream reads the
+    // bucket's weights or gradients again this step: the earlier layers multiply by their own (derived) operands.
+    Stream& sd = ctx->use_side() ? ctx->fork_side() : ctx->s;
+    optimizer_step_range_on(sd, 0, off, count, part == 0);
+  }
+  arenaG.version = ver + 1;      // one optimizer step
+  ctx->join_side();
 }
 
 // BaseGAN.optimize_parameters as a recorded launch sequence (engine.h Model::step_captured)
@@ -1427,6 +1445,14 @@ void Model::step(const float labels[3], bool training, uint64_t seed) {
   if (!hyper.warp_mode_ce_only) {
     backward_D(labels[0], labels[1]);
     optimizer_step(1);
+  }
+  // SWN_STREAM_ADAMW=0: AdamW as one launch behind the whole backward pass; 2: the bucketed order also without a side stream
+  // (what the host simulator can exercise).  Read per step.
+  const char* e = getenv("SWN_STREAM_ADAMW");
+  const int mode = e ? atoi(e) : 1;
+  if (mode == 2 || (mode != 0 && ctx->use_side())) {
+    backward_G_streamed(labels[2]);
+    return;
   }
   backward_G(labels[2]);
   optimizer_step(0);

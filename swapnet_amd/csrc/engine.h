@@ -226,7 +226,8 @@ class Net {
   void forward();
   void forward_from(int op_begin);           // ops [op_begin, end): the caller has filled the inputs of op_begin itself
   void backward(bool wgrad, bool igrad);
-  void backward_range(bool wgrad, bool igrad, int op_begin, int op_end);   // ops [begin,end) in reverse
+  // ops [begin,end) in reverse; join = the main stream waits for the range's weight gradients (false: the caller orders them)
+  void backward_range(bool wgrad, bool igrad, int op_begin, int op_end, bool join = true);
   // first op whose parameters start at or after `frac` of the arena (ops are registered in arena order)
   int split_point(double frac, size_t* arena_off) const;
   void refresh_dgrad();     // no-op when the operands are current (waits for a prefetch in flight)
@@ -338,12 +339,17 @@ class Model {
   // op (its arena range [off, n) is final on return), part 1 = the rest ([0, off)).
   virtual void backward_G_head(float label_real) = 0;
   int backward_G_parts() const;
-  void backward_G_part(float label_real, int part, size_t* ready_off, size_t* ready_count);
+  void backward_G_part(float label_real, int part, size_t* ready_off, size_t* ready_count, bool join = true);
   void optimizer_step(int net);
   // AdamW on the arena range [off, off + count) only (data parallel: a bucket is stepped as soon as its all-reduce
   // has landed, under the back-propagation of the next bucket).  first != 0 opens a new optimizer step (advances
   // the bias-correction counter); the ranges of one step must tile the arena.
   void optimizer_step_range(int net, size_t off, size_t count, int first);
+  void optimizer_step_range_on(Stream& s, int net, size_t off, size_t count, int first);
+  // generator backward pass with each bucket's AdamW enqueued on the side stream behind the bucket's weight gradients, under the
+  // back-propagation of the earlier layers on the main stream (Model::step with a side stream; SWN_STREAM_ADAMW=0: one launch
+  // over the whole arena after the pass).  Same arithmetic per element: results are bit-identical.
+  void backward_G_streamed(float label_real);
   void step(const float labels[3], bool training, uint64_t seed);
   // The same step recorded ONCE into a hipGraph (per value of `training`) and replayed: every per-step scalar -- the three
   // smooth labels (modules/loss.py:77-104), the dropout seed, the bias corrections of both AdamW steps -- lives in a small

@@ -66,3 +66,24 @@ def test_captured_step_at_c2_in_eval_and_train_mode():
         capt = _run(ctx, "warp", 32, 256, True, 3, training)
         assert eager[0] == capt[0]
         assert all(torch.equal(a, b) for a, b in zip(eager[1], capt[1]))
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("kind", ["warp", "texture"])
+def test_adamw_streamed_behind_each_bucket_is_the_same_step(backend, kind, monkeypatch):
+    """swn_model_step applies AdamW bucket by bucket behind each bucket's weight gradients (side stream, under the
+    back-propagation of the earlier layers) instead of once after optimizer_G.step()'s position in
+    models/base_gan.py:200-203.  Same element-wise update from the same gradients: weights, both moments, step counters
+    and losses must be bit-identical to the single launch (SWN_STREAM_ADAMW=0).  The host simulator has no second
+    stream; =2 forces the bucketed order there (what can go wrong on the CPU side is the bucket -> arena-range map)."""
+    ctx = backends.gpu_ctx() if backend == "gpu" else backends.hostsim_ctx()
+    B, H, steps = (2, 64, 3) if backend == "sim" else (4, 128, 4)
+    monkeypatch.setenv("SWN_STREAM_ADAMW", "0")
+    whole = _run(ctx, kind, B, H, False, steps)
+    monkeypatch.setenv("SWN_STREAM_ADAMW", "2" if backend == "sim" else "1")
+    bucketed = _run(ctx, kind, B, H, False, steps)
+    captured = _run(ctx, kind, B, H, True, steps)
+    for other in (bucketed, captured):
+        assert whole[0] == other[0]
+        for i, (a, b) in enumerate(zip(whole[1], other[1])):
+            assert torch.equal(a, b), (kind, "state tensor", i, float((a - b).abs().max()))
