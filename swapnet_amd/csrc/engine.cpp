@@ -642,7 +642,7 @@ void Net::conv(const std::string& name, const Var& x, const Var& y, ConvKind kin
   int pc_d = 0, dpanels = 1, dKp = 0;
   // dgrad output channels = input buffer channels -- or, for a layer that reads a network input of which only the leading
   // channels are anyone's output (the generator's image inside the conditional discriminator's input), just those
-  const bool narrow_dx = dgrad_C > 0 && dgrad_C % 4 == 0 && dgrad_C < Cip && !wino && kind == CK_K4S2;
+  const bool narrow_dx = dgrad_C > 0 && dgrad_C % 4 == 0 && dgrad_C < Cip && !wino && (kind == CK_K4S2 || kind == CK_K3S1_ZERO);
   const int Ndg = narrow_dx ? dgrad_C : Cip;
   const Var xg_target = narrow_dx ? x.slice(0, Ndg) : x;
   if (want_dx) {

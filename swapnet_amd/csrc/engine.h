@@ -250,7 +250,13 @@ void build_warp_generator(Net& net, const Var& body, const Var& cloth, const Var
 Var build_patchgan(Net& net, const Var& x, int n_layers, const std::vector<int32_t>& cimap, int in_grad_channels = 0);
 void build_texture_generator(Net& net, const Var& tex, const float* rois_dev, int num_roi, const Var& cloth_cat,
                              const Var& unet_in, const Var& out, int img_size, int cloth_channels = 19);
+// img: the image buffer (>= 4 channels, RGB in the first three; 16 channels put conv1_1 on the ring kernel) -- its gradient, if any,
+// is formed for the first 4 channels only
 std::vector<Var> build_vgg16_slices(Net& net, const Var& img);
+// buffer channels of a first-layer input with Cp (multiple of 4) channels: the next multiple of 16 when that at most doubles it
+// (nets.cpp; SWN_FIRST_RING=0: Cp)
+int ring_pad(int Cp);
+bool first_ring_on();
 
 // ---- gradient penalty (gp.cpp): second-order pass through PatchGAN for --gan_mode wgan-gp / dragan-gp / dragan-lp ----
 class GradPenalty {

@@ -159,10 +159,13 @@ static void gan_loss_op(Stream& s, int mode, const TView& pred, float label, boo
 // most 2x the channels (20 -> 32, 24 -> 32; the 3-channel body stays at 4: 16 would be 4x the work of a layer that is small
 // anyway).  Pad channels hold zeros (allocation zero-fills, nothing writes them) and meet zero weight rows.  SWN_FIRST_RING=0
 // keeps the round-3 layout (read when a model is built).
-static int ring_pad(int Cp) {
+bool first_ring_on() {
   static const bool on = !(getenv("SWN_FIRST_RING") && atoi(getenv("SWN_FIRST_RING")) == 0);
+  return on;
+}
+int ring_pad(int Cp) {
   const int r = round_up(Cp, 16);
-  return (on && r <= 2 * Cp) ? r : Cp;
+  return (first_ring_on() && r <= 2 * Cp) ? r : Cp;
 }
 
 class WarpModel final : public Model {

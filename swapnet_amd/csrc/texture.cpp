@@ -57,7 +57,8 @@ void build_texture_generator(Net& n, const Var& tex, const float* rois_dev, int 
     R[d] = n.alloc_var(B, hw, hw, 2 * ch, true);
   }
   // down path
-  n.conv(unet_prefix(0) + ".model.0", unet_in, C[1].slice(0, 64), CK_K4S2, RC + cloth_channels, 64, true, ACT_LRELU);
+  // (the input gradient is only wanted for the pooled-texture channels: the cloth channels are data)
+  n.conv(unet_prefix(0) + ".model.0", unet_in, C[1].slice(0, 64), CK_K4S2, RC + cloth_channels, 64, true, ACT_LRELU, nullptr, false, RC);
   Var innermost_mid;
   for (int d = 1; d < depth; ++d) {
     const int cin = inner(d - 1), cout = inner(d), hw = H >> (d + 1);
@@ -112,7 +113,7 @@ std::vector<Var> build_vgg16_slices(Net& n, const Var& img) {
     }
     Var y = n.alloc_var(x.v.N, H, W, cfg[i], grad);
     n.conv("net." + std::to_string(slice_of[i]) + "." + std::to_string(vidx[i]), x, y, CK_K3S1_ZERO, cin, cfg[i], true,
-           ACT_RELU, nullptr, false);
+           ACT_RELU, nullptr, false, i == 0 ? 4 : 0);
     x = y;
     cin = cfg[i];
   }
@@ -151,8 +152,11 @@ class TextureModel final : public Model {
     G->keep_wino_inputs = train;
     G->s2_wino = getenv("SWN_WINO_S2") && atoi(getenv("SWN_WINO_S2")) == 2;
     tex = G->alloc_var(B, H, W, 4, false);
-    unet_in = G->alloc_var(B, H, W, RC + Ccp, true);     // d(unet_in)[0:RC) feeds the encode branch
-    Dx = G->alloc_var(train ? 2 * B : B, H, W, 4 + Ccp, train);
+    // first-layer buffers padded to multiples of 16 channels (zero pads meeting zero weight rows): 56 -> 64, 24 -> 32 and, for
+    // VGG16's conv1_1, 4 -> 16 put those layers on the ring kernels (nets.cpp ring_pad; SWN_FIRST_RING=0: the round-3 layout)
+    unet_in = G->alloc_var(B, H, W, ring_pad(RC + Ccp), true);     // d(unet_in)[0:RC) feeds the encode branch
+    const int CdB = ring_pad(4 + Ccp);
+    Dx = G->alloc_var(train ? 2 * B : B, H, W, CdB, train);
     rois = static_cast<float*>(c.alloc((size_t)B * num_roi * 4 * sizeof(float)));
     Var fake_slot = Dx.batch(0, B).slice(0, 4);
     build_texture_generator(*G, tex, rois, num_roi, unet_in.slice(RC, Ccp), unet_in, fake_slot, H, Cc);
@@ -160,7 +164,7 @@ class TextureModel final : public Model {
     G->finalize({fake_slot});
     losses = static_cast<float*>(c.alloc(L_COUNT * sizeof(float)));
     if (!train) return;
-    std::vector<int32_t> cimap(4 + Ccp, -1);
+    std::vector<int32_t> cimap(CdB, -1);
     for (int i = 0; i < 3; ++i) cimap[i] = Cc + i;       // textures follow the cloth channels (texture_model.py:135)
     for (int i = 0; i < Cc; ++i) cimap[4 + i] = i;
     d_cimap_ = cimap; d_layers_ = c.patchgan_layers;
@@ -174,14 +178,17 @@ class TextureModel final : public Model {
     D1->finalize({pred1});
     // perceptual network: one instance with gradients (fakes), one without (targets, no_grad :52-53)
     VF = std::make_unique<Net>(c, arenaV);
-    vin_f = VF->alloc_var(B, H, W, 4, true);
+    const int CvB = first_ring_on() ? 16 : 4;
+    Var vbuf_f = VF->alloc_var(B, H, W, CvB, true);
+    vin_f = vbuf_f.slice(0, 4);
     VF->affine(fake_slot, vin_f, 2.f, -1.f);              // x <- 2x - 1 (perceptual.py:70)
-    feat_f = build_vgg16_slices(*VF, vin_f);
+    feat_f = build_vgg16_slices(*VF, vbuf_f);
     if (!arenaV.frozen) arenaV.allocate(c);
     VT = std::make_unique<Net>(c, arenaV);
-    vin_t = VT->alloc_var(B, H, W, 4, false);
+    Var vbuf_t = VT->alloc_var(B, H, W, CvB, false);
+    vin_t = vbuf_t.slice(0, 4);
     VT->affine(Dx.batch(B, B).slice(0, 4), vin_t, 2.f, -1.f);
-    feat_t = build_vgg16_slices(*VT, vin_t);
+    feat_t = build_vgg16_slices(*VT, vbuf_t);
     VT->finalize({});
     // backward_G writes d(content)/d(feature_k) into every slice output and d(GAN + L1)/d(fakes)
     // into the fake slot BEFORE VF->backward(): register them as pre-initialised so the tape

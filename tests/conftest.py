@@ -28,8 +28,9 @@ def pytest_configure(config):
 
 @pytest.fixture(autouse=True)
 def kernel_routing(request, monkeypatch):
-    for k in ROUTING_SWITCHES:
-        monkeypatch.delenv(k, raising=False)          # nothing leaks in from the invoking shell
+    if os.environ.get("SWAPNET_TEST_KEEP_SWITCHES") != "1":       # (tools/r04_bisect.sh: a failing test under one switch at a time)
+        for k in ROUTING_SWITCHES:
+            monkeypatch.delenv(k, raising=False)      # nothing leaks in from the invoking shell
     if request.node.get_closest_marker("small_channel_winograd"):
         monkeypatch.setenv("SWN_WINO_MINC", "32")
     yield

@@ -134,9 +134,20 @@ int conv_precut_tile(int xC, int Npad) {
   return sim_tile_for(Npad);
 }
 int conv_precut_planes() { return 2; }
-bool wino_pair_planes() { return false; }          // the simulator's planes stay fp32: the pair form is a device storage format
-bool conv_fwd_takes_pairs(int, int) { return false; }
-bool conv_wgrad_takes_pairs(size_t, int, int) { return false; }
+// Pair-form planes (ops.h wino_input_transform): a device storage format -- by default the simulator's planes stay fp32 and no
+// pair form is announced.  SWN_SIM_PAIR=1 announces it with the device's predicates and ROUNDS the planes the way the device
+// stores them (x 2^k -> h = fp16 RN, l = fp16 RN of the residual, k from the gain bound x the input's amax slot), so the CPU
+// suite sees the engine's pair plumbing (which slot bounds which transform) and the precision the bound leaves; the GEMMs then
+// multiply the rounded fp32 values.
+static bool sim_pair_on() { const char* e = getenv("SWN_SIM_PAIR"); return e && atoi(e) != 0; }
+bool wino_pair_planes() { return sim_pair_on(); }
+bool conv_fwd_takes_pairs(int xC, int Npad) { return sim_pair_on() && conv_precut_tile(xC, Npad) != 0; }
+bool conv_wgrad_takes_pairs(size_t T, int K, int Npad) {
+  if (!sim_pair_on() || Npad <= 32 || K % 4 || Npad % 4 || T % 16 || T * (size_t)std::max(K, Npad) * 4 >= ((size_t)1 << 31)) return false;
+  const int bmk = Npad > 64 ? 128 : 256;
+  const double fillf = (double)K / (double)(((K + bmk - 1) / bmk) * bmk);
+  return fillf > 0.8 || (bmk == 128 && fillf >= 0.75);
+}
 const float* conv_precut_amax(Stream&, const float*, size_t, int, int, size_t) { return nullptr; }
 static size_t sim_np(int Npad, int bn) { return (size_t)((Npad + bn - 1) / bn) * bn; }
 size_t conv_precut_elems(int K, int Npad, int bn) { return (size_t)(K / 16) * ((Npad + bn - 1) / bn) * 4 * bn * 8 + 8; }
@@ -1188,6 +1199,8 @@ void sim_slot_check(const float* slot, const float* x, size_t rows, int C, size_
   for (int b = 0; b < batch; ++b)
     for (size_t r = 0; r < rows; ++r) actual = std::max(actual, sim_amax(x + (size_t)b * bs + r * rs, (size_t)C));
   const float have = sim_slot_max(slot);
+  if (getenv("SWN_SIM_SLOT_REPORT") && actual > 0.f && have > (float)atof(getenv("SWN_SIM_SLOT_REPORT")) * actual)
+    fprintf(stderr, "[slot] %-16s slot %.4e  operand amax %.4e  ratio %.1f  rows %zu C %d batch %d\n", what, have, actual, have / actual, rows, C, batch);
   // a slot BOUNDS its operand: equal for a tensor with one producer, larger for a slice of a concatenation buffer whose slot
   // covers all slices -- but never smaller (overflow of the fp16 planes on the device) and never absurdly larger (a stale slot)
   if (!(have >= actual) || (actual > 0.f && have > 4096.f * actual))
@@ -1204,28 +1217,63 @@ void tensor_amax(Stream&, const TView& x, float* slot, float floor) {
   slot[0] = floor;
   sim_fold_view(slot, x);
 }
+// nearest fp16 value of x, as a float (round to nearest even; subnormals below 2^-14; overflow -> inf)
+static float sim_f16_rn(float x) {
+  if (x == 0.f || !std::isfinite(x)) return x;
+  int e;
+  std::frexp(std::fabs(x), &e);                       // |x| = m 2^e, m in [0.5, 1)
+  const int ue = std::max(e - 11, -24);               // exponent of the ulp
+  const float r = std::ldexp((float)std::nearbyint(std::ldexp((double)x, -ue)), ue);
+  return std::fabs(r) > 65504.f ? std::copysign(INFINITY, x) : r;
+}
+// what the device's pair-form store keeps of a plane tensor: k from the bound gain * amax(input slot) (wino.hip pair_scale_exp)
+static void sim_pair_round(float* P, size_t n, const float* in_amax, float gain, int* kscale_out, const TView& src, const char* what) {
+  const float have = sim_slot_max(in_amax);
+  float actual = 0.f;
+  for (size_t e = 0; e < src.pixels(); ++e) actual = std::max(actual, sim_amax(src.p + e * src.cs, (size_t)src.C));
+  if (!(have >= actual) || (actual > 0.f && have > 4096.f * actual))
+    throw Error(1, std::string("hostsim ") + what + ": the input's amax slot holds " + std::to_string(have) + ", its amax is " + std::to_string(actual));
+  const float m = have * gain;
+  int k = 0;
+  if (m > 0.f && m <= 3.0e38f) { int e; std::frexp(m, &e); k = 14 - (e - 1); k = std::max(-100, std::min(100, k)); }
+  if (kscale_out) *kscale_out = k;
+  const float pm = sim_amax(P, n);
+  if (std::ldexp(pm, k) >= 65504.f) throw Error(1, std::string("hostsim ") + what + ": pair-form plane overflows fp16 under its bound");
+  if (getenv("SWN_SIM_SLOT_REPORT"))
+    fprintf(stderr, "[pair] %-24s slot/input %.1f  plane amax * 2^k = 2^%.1f (top 2^15)  n %zu\n", what, actual > 0 ? have / actual : 0.f,
+            pm > 0 ? std::log2(std::ldexp(pm, k)) : 0.f, n);
+  for (size_t i = 0; i < n; ++i) {
+    const float x = std::ldexp(P[i], k);
+    const float h = sim_f16_rn(x), l = sim_f16_rn(x - h);
+    P[i] = std::ldexp(h + l, -k);
+  }
+}
 void wino_input_transform(Stream&, int m, int r, const TView& x, int pad, int pad_mode, int Th, int Tw, float* V, float* amax_out,
-                          const float* in_amax, int*) {
-  if (in_amax) throw Error(1, "hostsim: pair-form planes requested");
+                          const float* in_amax, int* kscale_out) {
   wino_input_transform_impl(m, r, x, pad, pad_mode, Th, Tw, V);
   const int A = m + r - 1;
-  if (amax_out && !(m == 2 && r == 3)) sim_slot_fold(amax_out, sim_amax(V, (size_t)A * A * x.N * Th * Tw * x.C));
+  const size_t n = (size_t)A * A * x.N * Th * Tw * x.C;
+  if (in_amax) { sim_pair_round(V, n, in_amax, 100.f, kscale_out, x, "wino_input_transform"); return; }
+  if (amax_out && !(m == 2 && r == 3)) sim_slot_fold(amax_out, sim_amax(V, n));
 }
-void wino_dy_transform(Stream&, int m, int r, const TView& dy, int Th, int Tw, float* dM, float* amax_out, const float* in_amax, int*) {
-  if (in_amax) throw Error(1, "hostsim: pair-form planes requested");
+void wino_dy_transform(Stream&, int m, int r, const TView& dy, int Th, int Tw, float* dM, float* amax_out, const float* in_amax, int* kscale_out) {
   wino_dy_transform_impl(m, r, dy, Th, Tw, dM);
   const int A = m + r - 1;
-  if (amax_out && !(m == 2 && r == 3)) sim_slot_fold(amax_out, sim_amax(dM, (size_t)A * A * dy.N * Th * Tw * dy.C));
+  const size_t n = (size_t)A * A * dy.N * Th * Tw * dy.C;
+  if (in_amax) { sim_pair_round(dM, n, in_amax, (m == 4 && r == 3) ? 225.f : ((m == 3 && r == 4) ? 49.f : 16.f), kscale_out, dy, "wino_dy_transform"); return; }
+  if (amax_out && !(m == 2 && r == 3)) sim_slot_fold(amax_out, sim_amax(dM, n));
 }
-void tailw_dy_transform(Stream&, const TView& dy, int Th, int Tw, int Npad, float* dM, float* amax_out, const float* in_amax, int*) {
-  if (in_amax) throw Error(1, "hostsim: pair-form planes requested");
+void tailw_dy_transform(Stream&, const TView& dy, int Th, int Tw, int Npad, float* dM, float* amax_out, const float* in_amax, int* kscale_out) {
   tailw_dy_transform_impl(dy, Th, Tw, Npad, dM);
-  sim_slot_fold(amax_out, sim_amax(dM, (size_t)36 * dy.N * Th * Tw * 4 * Npad));
+  const size_t n = (size_t)36 * dy.N * Th * Tw * 4 * Npad;
+  if (in_amax) { sim_pair_round(dM, n, in_amax, 225.f, kscale_out, dy, "tailw_dy_transform"); return; }
+  sim_slot_fold(amax_out, sim_amax(dM, n));
 }
-void wino_s2_input_transform(Stream&, const TView& x, int Th, int Tw, float* V, float* amax_out, const float* in_amax, int*) {
-  if (in_amax) throw Error(1, "hostsim: pair-form planes requested");
+void wino_s2_input_transform(Stream&, const TView& x, int Th, int Tw, float* V, float* amax_out, const float* in_amax, int* kscale_out) {
   wino_s2_input_transform_impl(x, Th, Tw, V);
-  sim_slot_fold(amax_out, sim_amax(V, (size_t)25 * x.N * Th * Tw * 4 * x.C));
+  const size_t n = (size_t)25 * x.N * Th * Tw * 4 * x.C;
+  if (in_amax) { sim_pair_round(V, n, in_amax, 9.f, kscale_out, x, "wino_s2_input_transform"); return; }
+  sim_slot_fold(amax_out, sim_amax(V, n));
 }
 
 }  // namespace swn

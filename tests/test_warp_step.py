@@ -93,6 +93,41 @@ def test_warp_forward_levels(backend, oracle_run, gold):
         assert torch.equal(sd[k], G[k]), k
 
 
+def _accept_only_an_evidenced_sign_flip(m, G0, D0, steps, si, batch, gD, gG, unpinned):
+    """The un-pinned bar failed.  The one legitimate cause is a LeakyReLU / ReLU branch taken differently for a
+    pre-activation within round-off of zero: the element's layer sees it in one output channel (what the slice exemption
+    of assert_grads_vs_fp64 covers), but every layer UPSTREAM receives it spread over all channels (observed on the
+    MI355X in round 4: PatchGAN model.0 weight / bias 1.5e-3 at step 1 from one flip in model.1's 16x16 map, identical
+    under six kernel-routing switches, gone under the two that change model.1's rounding).  So the excuse must be
+    EVIDENCED, not assumed: replay the native pass's branch pattern in the float64 oracle started from the same
+    pre-step state; accept only if (a) the replay counts at least one branch that differs from the oracle's own and
+    (b) with the pattern pinned every gradient tensor is within 1e-4 of float64.  No flip, or a pinned mismatch,
+    re-raises the original failure."""
+    from collections import OrderedDict
+    if si == 0:
+        o = O.WarpStepOracle(G0, D0, dtype=torch.float64)
+    else:
+        p = steps[si - 1]
+        o = O.WarpStepOracle(p["pG"], p["pD"], dtype=torch.float64)
+        for opt, mk, vk in ((o.optG, "mG", "vG"), (o.optD, "mD", "vD")):
+            opt.m = OrderedDict((k, v.double().clone()) for k, v in p[mk].items())
+            opt.v = OrderedDict((k, v.double().clone()) for k, v in p[vk].items())
+            opt.step = si
+    replay = O.PatternReplay(backends.collect_patterns(m))
+    o.patterns = replay
+    o.step(*batch, labels=steps[si]["labels"])
+    flips = replay.check()
+    if sum(flips.values()) == 0 and unpinned.args != ("forced",):
+        raise unpinned
+    try:
+        wD = backends.assert_grads_replayed(gD, o.grads_D, noise_bias, 1e-4, (si, "gradD pinned"))
+        wG = backends.assert_grads_replayed(gG, o.grads_G, noise_bias, 1e-4, (si, "gradG pinned"))
+    except AssertionError as pinned:
+        raise AssertionError((unpinned.args, "and with the pattern pinned:", pinned.args))
+    print("step %d: un-pinned bar missed (%s); %s branch flips against the float64 oracle, pinned gradients within %.1e (D) / %.1e (G)"
+          % (si, str(unpinned.args)[:200], flips, wD, wG))
+
+
 @pytest.mark.small_channel_winograd
 @pytest.mark.parametrize("backend", BACKENDS)
 def test_warp_two_steps_match_oracle_and_reference(backend, oracle_run, gold):
@@ -133,8 +168,13 @@ def test_warp_two_steps_match_oracle_and_reference(backend, oracle_run, gold):
         assert rel(out, s["fakes"]) < 1e-3
         ok, msg = compare(gold, pre + "fakes", out, 1e-3, 1e-3)
         assert ok, msg
-        backends.assert_grads_vs_fp64(gD, s["gD"], s["g64D"], noise_bias, (si, "gradD"))
-        backends.assert_grads_vs_fp64(gG, s["gG"], s["g64G"], noise_bias, (si, "gradG"))
+        try:
+            if os.environ.get("SWAPNET_TEST_FORCE_PINNED") == "1":        # (exercises the fall-back below where nothing flips)
+                raise AssertionError("forced")
+            backends.assert_grads_vs_fp64(gD, s["gD"], s["g64D"], noise_bias, (si, "gradD"))
+            backends.assert_grads_vs_fp64(gG, s["gG"], s["g64G"], noise_bias, (si, "gradG"))
+        except AssertionError as unpinned:
+            _accept_only_an_evidenced_sign_flip(m, G, D, steps, si, batch, gD, gG, unpinned)
         pG = m.state_dict(engine.NET_G, to_cpu=True)
         pD = m.state_dict(engine.NET_D, to_cpu=True)
         for k, v in s["pG"].items():
