@@ -1,5 +1,7 @@
 // swapnet_amd -- device memory / stream primitives of ops.h (HIP implementation).
 #include "hip_util.h"
+#include <algorithm>
+#include <cstdint>
 
 namespace swn {
 
@@ -13,7 +15,25 @@ void* dev_alloc(size_t bytes) {
 void dev_free(void* p) {
   if (p) (void)hipFree(p);
 }
-void dev_memset(Stream& s, void* p, int v, size_t bytes) { SWN_HIP_CHECK(hipMemsetAsync(p, v, bytes, hs(s))); }
+// Fill as an ordinary kernel launch of ours, not hipMemsetAsync: the fills of this library sit inside sequences that are recorded into
+// hipGraphs (the amax slots at the top of every forward pass, loss accumulators), and a recorded MEMSET node was observed to
+// misbehave on replay once another model of the same context had issued eager hipMemsetAsync calls in between (round 4:
+// tools/r04_pipe_probe3.py -- the replayed texture stage read garbage scales; the kernel node is immune).
+__global__ __launch_bounds__(256) void fill32_kernel(uint32_t* p, uint32_t v, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) p[i] = v;
+}
+void dev_memset(Stream& s, void* p, int v, size_t bytes) {
+  if (bytes == 0) return;
+  if (bytes % 4 == 0 && ((uintptr_t)p & 3) == 0) {
+    const uint32_t b = (uint32_t)(v & 0xff), pat = b | (b << 8) | (b << 16) | (b << 24);
+    const size_t n = bytes / 4;
+    const unsigned grid = (unsigned)std::min<size_t>((n + 255) / 256, 2048);
+    hipLaunchKernelGGL(fill32_kernel, dim3(grid), dim3(256), 0, hs(s), static_cast<uint32_t*>(p), pat, n);
+    SWN_HIP_CHECK(hipGetLastError());
+    return;
+  }
+  SWN_HIP_CHECK(hipMemsetAsync(p, v, bytes, hs(s)));
+}
 void dev_copy(Stream& s, void* dst, const void* src, size_t bytes) {
   SWN_HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, hs(s)));
 }

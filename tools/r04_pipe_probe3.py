@@ -26,7 +26,7 @@ def taps(pipe):
     out["warp_out"] = w.output().clone()
     return out
 
-for trial in range(6):
+for trial in range(int(os.environ.get("PROBE_TRIALS", "2"))):
     pipe = TwoStagePipeline(Gw, Gt, img_size=64, ctx=ctx)
     o1, l1 = pipe(b1, i1, t1, r1, return_labels=True); o1 = o1.clone(); T1 = taps(pipe)
     time.sleep(0.5)
