@@ -389,9 +389,12 @@ def main():
                     # HBM bytes per launch from the committed rocprofv3 PMC passes of this same command
                     # (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE; see profiles/README.md)
                     tk = json.load(open(tpath))["kernels"]
-                    t = tk.get(rp_name)
-                    if t:
-                        traffic = t["fetch_bytes_per_launch"] + t["write_bytes_per_launch"]
+                    # (a family = every instantiation that extends the name's template arguments: the pair-form / plane-form
+                    # variants of round 4 are further arguments of the same tile's kernel; launch-weighted mean)
+                    fam = [v for kname, v in tk.items() if kname == rp_name or kname.startswith(rp_name[:-1] + ",")]
+                    if fam:
+                        nl = sum(v["launches"] for v in fam)
+                        traffic = int(sum((v["fetch_bytes_per_launch"] + v["write_bytes_per_launch"]) * v["launches"] for v in fam) / max(nl, 1))
                         traffic_src = "profiles/" + tname + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command; not collected in this run)"
                         # whole step: the pass profiles ONE step from process start, so allocation-time work (zero fills, the
                         # initial weight packing, the NCHW -> NHWC upload of the resident batch) is in the file; excluded here
@@ -509,11 +512,17 @@ def main():
                                     "switches": sorted(k + "=" + v for k, v in os.environ.items() if k.startswith("SWN_"))}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline_texture() if texture else cpu_baseline()
-    if rank == 0:
-        print(json.dumps(out), flush=True)
+    # the JSON line is the LAST thing on stdout: RCCL writes its version banner through C stdio, which (not a tty) sits in a
+    # buffer until the process exits -- flush it, and tear the process group down, before printing
+    import ctypes
+    libc = ctypes.CDLL(None)
+    libc.fflush(None)
     if world > 1 or rccl1:
         dist.barrier()
         dist.destroy_process_group()
+        libc.fflush(None)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":
