@@ -227,7 +227,10 @@ int swn_model_optimizer_step(swn_model* m, int net);
  * under data parallelism a bucket is stepped as soon as its all-reduce has landed, while the next bucket is still
  * being back-propagated.  first != 0 on the first range of an optimizer step (advances AdamW's step counter). */
 int swn_model_optimizer_step_range(swn_model* m, int net, size_t off, size_t count, int first);
-/* BaseGAN.optimize_parameters (models/base_gan.py:194-203; warp_model.py:169-183) in one call */
+/* BaseGAN.optimize_parameters (models/base_gan.py:194-203; warp_model.py:169-183) in one call.  With the context's second
+ * stream on, optimizer_G.step() (:203) is applied bucket by bucket behind each bucket's weight gradients, under the
+ * back-propagation of the earlier layers -- the same element-wise update from the same gradients: bit-identical to the
+ * phased calls above (SWN_STREAM_ADAMW=0: one launch after the pass). */
 int swn_model_step(swn_model* m, const float labels[3], int training, uint64_t dropout_seed);
 /* The same step recorded once into a hipGraph and replayed (BASELINE.json C5's "hipGraph-captured step"): the three label
  * draws of GANLoss (modules/loss.py:77-104), the dropout seed and both AdamW bias corrections travel through a 40-byte device
