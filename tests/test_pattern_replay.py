@@ -59,6 +59,21 @@ def test_warp_gradients_with_pinned_pattern(backend, mode):
     print("warp 64x64", mode, "flips", flips, "worst D %.2e G %.2e" % (wD, wG))
 
 
+@pytest.mark.small_channel_winograd
+def test_warp_gradients_with_pinned_pattern_under_simulated_pair_form_planes(monkeypatch, capfd):
+    """The device stores the Winograd-domain planes its own transforms write as fp16 pairs {h | l << 16} of x 2^k, k from the
+    transform's gain bound times the input's amax slot (DESIGN.md section 4 "Pair-form planes").  The host simulator can round its
+    fp32 planes exactly that way (SWN_SIM_PAIR=1, software fp16 round-to-nearest) and then announces the pair form with the
+    device's predicates, so the engine's pair plumbing -- which slot bounds which transform, fp16 range under the bound -- and
+    the precision the bound leaves run in CPU CI: pinned gradients must stay within the same 1e-4 of float64."""
+    monkeypatch.setenv("SWN_SIM_PAIR", "1")
+    monkeypatch.setenv("SWN_SIM_SLOT_REPORT", "1e30")          # ([pair] lines on stderr: proof that planes were rounded)
+    flips, wD, wG = _warp_replay(backends.hostsim_ctx(), 2, 64, 0, True)
+    err = capfd.readouterr().err
+    assert "[pair] wino_input_transform" in err and "[pair] wino_dy_transform" in err and "[pair] wino_s2_input_transform" in err, err[-400:]
+    print("warp 64x64 train, simulated pair-form planes: flips", flips, "worst D %.2e G %.2e" % (wD, wG))
+
+
 def _texture_replay(ctx, B, H, training, labels=(0.85, 0.95, 0.75), drop_seed=99, check_route=False):
     m, G, D, vgg, batch, masks = _texture_case(ctx, B, H, drop_seed)
     try:
