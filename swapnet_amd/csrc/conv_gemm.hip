@@ -2638,11 +2638,12 @@ const float* conv_precut_amax(Stream& s, const float* src, size_t rows, int C, i
   amax_partials(s, src, rows, C, (size_t)C, batch, bs, part);
   return part;
 }
-void conv_precut(Stream& s, const float* w, int K, int Npad, int bn, int batch, size_t w_bs, uint16_t* out) {
+void conv_precut(Stream& s, const float* w, int K, int Npad, int bn, int batch, size_t w_bs, uint16_t* out, const float** amax_io) {
   if (K % 16 || (bn != 64 && bn != 128 && bn != 192)) throw Error(1, "conv_precut: K must be a multiple of 16, tile 64, 128 or 192");
   const size_t total = (size_t)(K / 8) * ceil_div(Npad, bn) * bn;
   // two-plane form: one scale for all `batch` panels of the launch (they are cut from one weight tensor)
-  const float* wamax = conv_precut_amax(s, w, (size_t)K, Npad, batch, w_bs);
+  const float* wamax = (amax_io && *amax_io) ? *amax_io : conv_precut_amax(s, w, (size_t)K, Npad, batch, w_bs);
+  if (amax_io) *amax_io = wamax;
   hipLaunchKernelGGL(conv_precut_kernel, dim3((unsigned)((total + 255) / 256), batch), dim3(256), 0, hs(s), w, out, K, Npad, bn, w_bs,
                      conv_precut_elems(K, Npad, bn), wamax, pc_planes());
   check_launch("conv_precut");

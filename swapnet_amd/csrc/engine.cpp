@@ -1,5 +1,6 @@
 // swapnet_amd -- engine core: arenas, op tape, accumulate planner.
 #include "engine.h"
+#include <memory>
 
 #include <algorithm>
 #include <cstddef>
@@ -327,11 +328,12 @@ void Net::conv(const std::string& name, const Var& x, const Var& y, ConvKind kin
     float* keepdM = (y.has_grad && want_dx && share_dy()) ? static_cast<float*>(ctx.alloc(sP * sT * Cop * sizeof(float))) : nullptr;
     op->repack = [=](Net& n) {
       const ParamDesc& wd = A->params[wi];
+      const float* wmax = nullptr;       // U^T holds U's values: one amax pass serves both operands (ops.h conv_precut amax_io)
       wino_s2_filter_transform(n.ctx.s, wd.ws, 0, A->w + wd.off, n.dg + uf_off);
-      if (pcf) conv_precut(n.ctx.s, n.dg + uf_off, CV, Cop, pcf, sP, (size_t)CV * Cop, n.dgp + pcf_off);
+      if (pcf) conv_precut(n.ctx.s, n.dg + uf_off, CV, Cop, pcf, sP, (size_t)CV * Cop, n.dgp + pcf_off, &wmax);
       if (want_dx) {
         wino_s2_filter_transform(n.ctx.s, wd.ws, 1, A->w + wd.off, n.dg + ut_off);
-        if (pct) conv_precut(n.ctx.s, n.dg + ut_off, Cop, CV, pct, sP, (size_t)Cop * CV, n.dgp + pct_off);
+        if (pct) conv_precut(n.ctx.s, n.dg + ut_off, Cop, CV, pct, sP, (size_t)Cop * CV, n.dgp + pct_off, &wmax);
       }
     };
     op->fwd = [=](Net& n) {
@@ -640,6 +642,8 @@ void Net::conv(const std::string& name, const Var& x, const Var& y, ConvKind kin
   const bool want_dx = x.has_grad && y.has_grad;
   size_t dg_off = 0, pcd_off = 0;
   int pc_d = 0, dpanels = 1, dKp = 0;
+  // the forward operand's weight amax, handed from the pc_f re-pack to the input-gradient operand's (ops.h conv_precut amax_io)
+  auto fwd_wmax = std::make_shared<const float*>(nullptr);
   // dgrad output channels = input buffer channels -- or, for a layer that reads a network input of which only the leading
   // channels are anyone's output (the generator's image inside the conditional discriminator's input), just those
   const bool narrow_dx = dgrad_C > 0 && dgrad_C % 4 == 0 && dgrad_C < Cip && !wino && (kind == CK_K4S2 || kind == CK_K3S1_ZERO);
@@ -665,7 +669,11 @@ void Net::conv(const std::string& name, const Var& x, const Var& y, ConvKind kin
       op->repack = [=](Net& n) {
         const ParamDesc& wd = A->params[wi];
         repack_dgrad(n.ctx.s, wd.ws, dg_mode, CopD, Ndg, A->w + wd.off, n.dg + dg_off);
-        if (pcd) conv_precut(n.ctx.s, n.dg + dg_off, dK, Ndg, pcd, dP, (size_t)dK * Ndg, n.dgp + pcdo);
+        // (the re-pack is a permutation of the parameter -- of its leading input channels if the gradient is narrow: the partial
+        // maxima the forward operand's pre-cut just took, if it ran in front of us, bound it)
+        const float* wmax = *fwd_wmax;
+        if (pcd) conv_precut(n.ctx.s, n.dg + dg_off, dK, Ndg, pcd, dP, (size_t)dK * Ndg, n.dgp + pcdo, &wmax);
+        *fwd_wmax = nullptr;
       };
     }
   }
@@ -674,10 +682,11 @@ void Net::conv(const std::string& name, const Var& x, const Var& y, ConvKind kin
     const int pcwt_c = pcwt; const size_t pcwt_o = pcwt_off, pcwt_b = pcwt_bs;
     op->repack = [=](Net& n) {
       const ParamDesc& wd = A->params[wi];
-      if (pcw) wino_filter_transform_pc(n.ctx.s, wm, wr, wd.ws, 0, A->w + wd.off, pcw, n.dgp + pcw_off, pcw_bs);
+      const float* wmax = nullptr;       // both directions transform the same packed parameter: one amax pass
+      if (pcw) wino_filter_transform_pc(n.ctx.s, wm, wr, wd.ws, 0, A->w + wd.off, pcw, n.dgp + pcw_off, pcw_bs, &wmax);
       else wino_filter_transform(n.ctx.s, wm, wr, wd.ws, 0, A->w + wd.off, n.dg + uf_off);
       if (wdx) {
-        if (pcwt_c) wino_filter_transform_pc(n.ctx.s, wm, wr, wd.ws, wadj ? 2 : 1, A->w + wd.off, pcwt_c, n.dgp + pcwt_o, pcwt_b);
+        if (pcwt_c) wino_filter_transform_pc(n.ctx.s, wm, wr, wd.ws, wadj ? 2 : 1, A->w + wd.off, pcwt_c, n.dgp + pcwt_o, pcwt_b, &wmax);
         else wino_filter_transform(n.ctx.s, wm, wr, wd.ws, wadj ? 2 : 1, A->w + wd.off, n.dg + ub_off);
       }
     };
@@ -694,8 +703,13 @@ void Net::conv(const std::string& name, const Var& x, const Var& y, ConvKind kin
     auto prev = op->repack;
     op->repack = [=](Net& n) {
       const ParamDesc& wd = A->params[wi];
-      conv_precut(n.ctx.s, A->w + wd.off, Kf, wd.ws.Npad, pc_f, 1, 0, n.dgp + pcf_off);     // forward operand first
+      const float* wmax = nullptr;
+      conv_precut(n.ctx.s, A->w + wd.off, Kf, wd.ws.Npad, pc_f, 1, 0, n.dgp + pcf_off, &wmax);     // forward operand first
+      // handed to the input-gradient operand's pre-cut -- only where that is the whole of `prev` (a folded / Winograd layer runs
+      // other amax passes in between, which reuse the scratch the partials live in)
+      *fwd_wmax = (!wino && !folded) ? wmax : nullptr;
       if (prev) prev(n);
+      *fwd_wmax = nullptr;
     };
   }
   const int pcd_k = pc_d; const size_t pcd_o = pcd_off, pcd_bs = pc_d ? conv_precut_elems(dKp, Ndg, pc_d) : 0;
@@ -858,10 +872,11 @@ void Net::convT(const std::string& name, const Var& x, const Var& y, int Co, boo
     op->repack = [=](Net& n) {
       const ParamDesc& wd = A->params[wi];
       wino_s2_filter_transform(n.ctx.s, wd.ws, 1, A->w + wd.off, n.dg + ut_off);
-      if (pct) conv_precut(n.ctx.s, n.dg + ut_off, Cip, CV, pct, sP, (size_t)Cip * CV, n.dgp + pct_off);
+      const float* wmax = nullptr;
+      if (pct) conv_precut(n.ctx.s, n.dg + ut_off, Cip, CV, pct, sP, (size_t)Cip * CV, n.dgp + pct_off, &wmax);
       if (want_dx) {
         wino_s2_filter_transform(n.ctx.s, wd.ws, 0, A->w + wd.off, n.dg + uf_off);
-        if (pcf) conv_precut(n.ctx.s, n.dg + uf_off, CV, Cip, pcf, sP, (size_t)CV * Cip, n.dgp + pcf_off);
+        if (pcf) conv_precut(n.ctx.s, n.dg + uf_off, CV, Cip, pcf, sP, (size_t)CV * Cip, n.dgp + pcf_off, &wmax);
       }
     };
     op->fwd = [=](Net& n) {
@@ -952,10 +967,11 @@ void Net::convT(const std::string& name, const Var& x, const Var& y, int Co, boo
   if (want_dx || pc_f)
     op->repack = [=](Net& n) {
       const ParamDesc& wd = A->params[wi];
-      if (pc_f) conv_precut(n.ctx.s, A->w + wd.off, 4 * Cip, Cop, pc_f, 4, phase_elems, n.dgp + pcf_off);
+      const float* wmax = nullptr;       // the k4 s2 re-pack permutes the four phase panels: one amax pass
+      if (pc_f) conv_precut(n.ctx.s, A->w + wd.off, 4 * Cip, Cop, pc_f, 4, phase_elems, n.dgp + pcf_off, &wmax);
       if (want_dx) {
         repack_dgrad(n.ctx.s, wd.ws, 2, Cop, Cip, A->w + wd.off, n.dg + dg_off);
-        if (pc_d) conv_precut(n.ctx.s, n.dg + dg_off, 16 * Cop, Cip, pc_d, 1, 0, n.dgp + pcd_off);
+        if (pc_d) conv_precut(n.ctx.s, n.dg + dg_off, 16 * Cop, Cip, pc_d, 1, 0, n.dgp + pcd_off, &wmax);
       }
     };
   const bool has_ygrad = y.has_grad;

@@ -115,7 +115,11 @@ void conv_fwd(Stream& s, const ConvFwdArgs& a);
 // simulator, narrow / first-layer launches, SWN_PRECUT=0): callers then need not produce one.
 int conv_precut_tile(int xC, int Npad);
 size_t conv_precut_elems(int K, int Npad, int bn);       // uint16 elements of one [K][Npad] panel
-void conv_precut(Stream& s, const float* w, int K, int Npad, int bn, int batch, size_t w_bs, uint16_t* out);
+// amax_io (two-plane form, optional): a layer's forward and input-gradient operands are permutations (transposes, flips, leading
+// channels) of ONE parameter tensor, so the 256 partial maxima taken for the first bound the second.  *amax_io == NULL on entry: the
+// launch takes its own and leaves the pointer; != NULL: it uses them -- valid only back to back on one stream (the partials live in the
+// stream scratch until the next pass) and for sources whose values are a subset of what the partials were taken over.
+void conv_precut(Stream& s, const float* w, int K, int Npad, int bn, int batch, size_t w_bs, uint16_t* out, const float** amax_io = nullptr);
 // Plane format of the pre-cut operands: 3 = three bf16 planes (six MFMAs per product), 2 = two fp16 planes of the operand times a
 // power of two chosen from its amax (three MFMAs; conv_gemm.hip "two fp16 planes").  In the two-plane form a panel carries a
 // 16-byte trailer with the scale exponent (counted by conv_precut_elems) and a producer first takes the 256 partial maxima of its
@@ -179,7 +183,7 @@ void wino_filter_transform(Stream& s, int m, int r, const WShape& w, int mode, c
 // the same transform (modes 0 and 2, 6-point forms) written straight into the pre-cut operand layout of the ring kernel
 // (conv_precut's, one panel of `panel_elems` = conv_precut_elems(K, N, bn) uint16 per Winograd plane): no fp32 U at all
 void wino_filter_transform_pc(Stream& s, int m, int r, const WShape& w, int mode, const float* packed, int bn, uint16_t* out,
-                              size_t panel_elems);
+                              size_t panel_elems, const float** amax_io = nullptr);       // amax_io: as conv_precut's
 // Input gradient in the forward tiling: dV[P][T][C] = dM U^T (dM = wino_dy_transform of dY, T = dx.N * Th * Tw forward tiles).
 // dx (+)= sum over tiles of the patches BT^T dV_t BT placed where wino_input_transform(pad, pad_mode, Th, Tw) gathered them
 // (reflected / dropped exactly like the forward gather).  dV is overwritten (scratch).

@@ -1211,7 +1211,7 @@ void wino_filter_transform(Stream& s, int m, int r, const WShape& w, int mode, c
   check_launch("wino_filter_transform");
 }
 void wino_filter_transform_pc(Stream& s, int m, int r, const WShape& w, int mode, const float* packed, int bn, uint16_t* out,
-                              size_t panel_elems) {
+                              size_t panel_elems, const float** amax_io) {
   const int v = variant(m, r);
   if (v != 1 && v != 2) throw Error(1, "wino_filter_transform_pc: the 6-point forms F(4,3) / F(3,4) only");
   if (mode < 0 || mode > 2) throw Error(1, "wino_filter_transform_pc: mode 0, 1 or 2");
@@ -1220,7 +1220,8 @@ void wino_filter_transform_pc(Stream& s, int m, int r, const WShape& w, int mode
   const size_t total = (size_t)(K / 8) * ((Nn + bn - 1) / bn) * bn;
   const dim3 grid((unsigned)((((total + 255) / 256 + 7) / 8) * 8) * (unsigned)(m + r - 1));      // slabs in groups of 8, A rows each
   // two-plane form: the scale comes from the amax of the layer's packed weights ([r * r][Cip][Npad])
-  const float* wamax = conv_precut_amax(s, packed, (size_t)r * r * w.Cip, w.Npad, 1, 0);
+  const float* wamax = (amax_io && *amax_io) ? *amax_io : conv_precut_amax(s, packed, (size_t)r * r * w.Cip, w.Npad, 1, 0);
+  if (amax_io) *amax_io = wamax;
   if (v == 1)
     hipLaunchKernelGGL(winog_filter_pc_kernel<F43>, grid, dim3(256), 0, hs(s), w, mode, K, Nn, bn, packed, out, panel_elems, wamax,
                        conv_precut_planes());

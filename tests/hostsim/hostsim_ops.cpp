@@ -163,14 +163,36 @@ static void sim_store_panel(const float* w, int K, int Npad, int bn, uint16_t* o
       for (size_t n = 0; n < NP; ++n) f[(size_t)k * NP + n] = n < (size_t)Npad ? w[(size_t)k * Npad + n] : 0.f;
   sim_trailer(out, K, Npad, bn);
 }
-void conv_precut(Stream&, const float* w, int K, int Npad, int bn, int batch, size_t w_bs, uint16_t* out) {
+// amax_io (ops.h conv_precut): the simulator keeps the "partial maxima" of the last pass in one static slot -- exactly the lifetime the
+// device's stream scratch gives them -- and CHECKS a handed-in pointer against the source it is now claimed to bound
+static float g_sim_wamax[AMAX_SLOT];
+static int g_sim_wamax_owner = 0, g_sim_wamax_handed = -1;   // bumped by every pass: a stale hand-over (another pass in between) is an engine bug
+static void sim_weight_amax(const float* src, size_t rows, int C, int batch, size_t bs, const float** amax_io, const char* what) {
+  float actual = 0.f;
+  for (int b = 0; b < batch; ++b) actual = std::max(actual, [&] { float m = 0.f; for (size_t i = 0; i < rows * (size_t)C; ++i) m = std::max(m, std::fabs(src[(size_t)b * bs + i])); return m; }());
+  if (amax_io && *amax_io) {
+    if (*amax_io != g_sim_wamax || g_sim_wamax_handed != g_sim_wamax_owner)
+      throw Error(1, std::string("hostsim ") + what + ": handed-in weight amax is not the last pass's (another pass reused the scratch)");
+    const float have = g_sim_wamax[0];
+    if (!(have >= actual) || (actual > 0.f && have > 4096.f * actual))
+      throw Error(1, std::string("hostsim ") + what + ": handed-in weight amax " + std::to_string(have) + " does not bound the source (amax " + std::to_string(actual) + ")");
+    return;
+  }
+  for (int i = 0; i < AMAX_SLOT; ++i) g_sim_wamax[i] = 0.f;
+  g_sim_wamax[0] = actual;
+  ++g_sim_wamax_owner;
+  if (amax_io) { *amax_io = g_sim_wamax; g_sim_wamax_handed = g_sim_wamax_owner; }
+}
+void conv_precut(Stream&, const float* w, int K, int Npad, int bn, int batch, size_t w_bs, uint16_t* out, const float** amax_io) {
   if (K % 16 || (bn != 64 && bn != 128 && bn != 192)) throw Error(1, "conv_precut: K must be a multiple of 16, tile 64, 128 or 192");
+  sim_weight_amax(w, (size_t)K, Npad, batch, w_bs, amax_io, "conv_precut");
   const size_t pe = conv_precut_elems(K, Npad, bn);
   for (int z = 0; z < batch; ++z) sim_store_panel(w + (size_t)z * w_bs, K, Npad, bn, out + (size_t)z * pe);
 }
 static void wino_filter_transform_strided(int m, int r, const WShape& w, int mode, const float* packed, float* U, size_t total);
 void wino_filter_transform_pc(Stream&, int m, int r, const WShape& w, int mode, const float* packed, int bn, uint16_t* out,
-                              size_t panel_elems) {
+                              size_t panel_elems, const float** amax_io) {
+  sim_weight_amax(packed, (size_t)r * r * w.Cip, w.Npad, 1, 0, amax_io, "wino_filter_transform_pc");
   const int K = mode == 0 ? w.Cip : w.Npad, Nn = mode == 0 ? w.Npad : w.Cip;
   if (K % 16 || (bn != 64 && bn != 128)) throw Error(1, "wino_filter_transform_pc: K must be a multiple of 16, tile 64 or 128");
   if (panel_elems != conv_precut_elems(K, Nn, bn)) throw Error(1, "wino_filter_transform_pc: panel stride does not match conv_precut_elems");
