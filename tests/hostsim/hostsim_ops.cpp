@@ -140,6 +140,35 @@ int conv_precut_planes() { return 2; }
 // suite sees the engine's pair plumbing (which slot bounds which transform) and the precision the bound leaves; the GEMMs then
 // multiply the rounded fp32 values.
 static bool sim_pair_on() { const char* e = getenv("SWN_SIM_PAIR"); return e && atoi(e) != 0; }
+// ---- the 16-bit operand formats of the device's ring kernels, as a rounding model (SWN_SIM_PAIR=1 only) ------------------------------
+// An operand element x enters the MFMAs as h + l, two fp16 values of x 2^k, k from the tensor's amax (top 2^12 for activations /
+// gradients, 2^10 for weights: conv_gemm.hip PC_TOP_A / PC_TOP_B).  Pre-cut weights and pair-form planes round h to nearest; an
+// activation cut in the loop truncates h (split8h), the weight gradient's dY operand rounds it (split8h_rn).  The simulator applies the
+// same cut to the fp32 value and multiplies the result -- what CPU CI then sees is the 22-bit operand arithmetic with the engine's
+// own choice of scales (slots, bounds, hand-overs), not the accumulation order of the MFMAs.
+float sim_slot_max(const float* slot);
+static float sim_f16_rn(float x);
+static float sim_f16_trunc(float x) {
+  if (x == 0.f || !std::isfinite(x)) return x;
+  int e;
+  std::frexp(std::fabs(x), &e);
+  const int ue = std::max(e - 11, -24);
+  return std::ldexp((float)std::trunc(std::ldexp((double)x, -ue)), ue);
+}
+static int sim_scale_exp(float amax, int top) {                 // as conv_gemm.hip scale_exp / wino.hip wino_scale_exp
+  if (!(amax > 0.f) || amax > 3.0e38f) return 0;
+  int e;
+  std::frexp(amax, &e);                                          // amax = m 2^e, m in [0.5, 1): binary exponent e - 1
+  return std::max(-100, std::min(100, top - 1 - (e - 1)));
+}
+static inline float sim_cut(float v, int k, bool trunc_h) {
+  const float x = std::ldexp(v, k);
+  const float h = trunc_h ? sim_f16_trunc(x) : sim_f16_rn(x);
+  return std::ldexp(h + sim_f16_rn(x - h), -k);
+}
+static void sim_cut_dense(float* f, size_t n, int k, bool trunc_h) {
+  for (size_t i = 0; i < n; ++i) f[i] = sim_cut(f[i], k, trunc_h);
+}
 bool wino_pair_planes() { return sim_pair_on(); }
 bool conv_fwd_takes_pairs(int xC, int Npad) { return sim_pair_on() && conv_precut_tile(xC, Npad) != 0; }
 bool conv_wgrad_takes_pairs(size_t T, int K, int Npad) {
@@ -187,7 +216,11 @@ void conv_precut(Stream&, const float* w, int K, int Npad, int bn, int batch, si
   if (K % 16 || (bn != 64 && bn != 128 && bn != 192)) throw Error(1, "conv_precut: K must be a multiple of 16, tile 64, 128 or 192");
   sim_weight_amax(w, (size_t)K, Npad, batch, w_bs, amax_io, "conv_precut");
   const size_t pe = conv_precut_elems(K, Npad, bn);
-  for (int z = 0; z < batch; ++z) sim_store_panel(w + (size_t)z * w_bs, K, Npad, bn, out + (size_t)z * pe);
+  for (int z = 0; z < batch; ++z) {
+    sim_store_panel(w + (size_t)z * w_bs, K, Npad, bn, out + (size_t)z * pe);
+    if (sim_pair_on())           // two fp16 planes of w 2^kB, one scale for all panels of the launch (conv_precut_kernel)
+      sim_cut_dense(reinterpret_cast<float*>(out + (size_t)z * pe), (size_t)K * sim_np(Npad, bn), sim_scale_exp(g_sim_wamax[0], 10), false);
+  }
 }
 static void wino_filter_transform_strided(int m, int r, const WShape& w, int mode, const float* packed, float* U, size_t total);
 void wino_filter_transform_pc(Stream&, int m, int r, const WShape& w, int mode, const float* packed, int bn, uint16_t* out,
@@ -199,12 +232,19 @@ void wino_filter_transform_pc(Stream&, int m, int r, const WShape& w, int mode, 
   const int A = m + r - 1, P = A * A;
   if (sim_np(Nn, bn) == (size_t)Nn) {             // dense panels: transform straight into them (plane stride = the panel stride)
     wino_filter_transform_strided(m, r, w, mode, packed, reinterpret_cast<float*>(out), panel_elems / 2);
-    for (int p = 0; p < P; ++p) sim_trailer(out + (size_t)p * panel_elems, K, Nn, bn);
+    for (int p = 0; p < P; ++p) {
+      sim_trailer(out + (size_t)p * panel_elems, K, Nn, bn);
+      // (the scale of the transformed planes comes from the amax of the PACKED filter: |G g G^T| <= |g|max for the 6-point forms)
+      if (sim_pair_on()) sim_cut_dense(reinterpret_cast<float*>(out + (size_t)p * panel_elems), (size_t)K * Nn, sim_scale_exp(g_sim_wamax[0], 10), false);
+    }
     return;
   }
   std::vector<float> U((size_t)P * K * Nn);
   wino_filter_transform_strided(m, r, w, mode, packed, U.data(), (size_t)K * Nn);
-  for (int p = 0; p < P; ++p) sim_store_panel(U.data() + (size_t)p * K * Nn, K, Nn, bn, out + (size_t)p * panel_elems);
+  for (int p = 0; p < P; ++p) {
+    sim_store_panel(U.data() + (size_t)p * K * Nn, K, Nn, bn, out + (size_t)p * panel_elems);
+    if (sim_pair_on()) sim_cut_dense(reinterpret_cast<float*>(out + (size_t)p * panel_elems), (size_t)K * sim_np(Nn, bn), sim_scale_exp(g_sim_wamax[0], 10), false);
+  }
 }
 
 void sim_slot_check(const float* slot, const float* x, size_t rows, int C, size_t rs, int batch, size_t bs, const char* what);
@@ -239,6 +279,28 @@ void conv_fwd(Stream& s, const ConvFwdArgs& a) {
     }
     ConvFwdArgs c = a;
     c.wpc = nullptr; c.x_amax = nullptr;
+    // SWN_SIM_PAIR: the activation operand of the two-plane ring kernel, cut in its loop (h by truncation) with the scale of the slot
+    // it was handed or of its own amax pass -- unless it arrives in pair form (its producer rounded it already)
+    std::vector<float> xf;
+    if (sim_pair_on() && !a.x_pair_k) {
+      const int nbx = a.phases ? 1 : nb;
+      const size_t rows = (size_t)a.x.N * a.x.H * a.x.W;
+      float am = 0.f;
+      if (a.x_amax) am = sim_slot_max(a.x_amax);
+      else
+        for (int z = 0; z < nbx; ++z)
+          for (size_t r = 0; r < rows; ++r)
+            for (int ch = 0; ch < a.x.C; ++ch) am = std::max(am, std::fabs(a.x.p[(size_t)z * a.x_bs + r * a.x.cs + ch]));
+      const int kA = sim_scale_exp(am, 12);
+      xf.resize((size_t)nbx * rows * a.x.C);
+      for (int z = 0; z < nbx; ++z)
+        for (size_t r = 0; r < rows; ++r)
+          for (int ch = 0; ch < a.x.C; ++ch)
+            xf[((size_t)z * rows + r) * a.x.C + ch] = sim_cut(a.x.p[(size_t)z * a.x_bs + r * a.x.cs + ch], kA, true);
+      c.x.p = xf.data(); c.x.cs = a.x.C;
+      if (!a.phases) c.x_bs = rows * (size_t)a.x.C;          // (the phases of one launch read the same input)
+    }
+    c.x_pair_k = nullptr;
     std::vector<float> wf;
     if (NP == (size_t)a.Npad) {                     // dense panel = the fp32 operand itself
       c.w = reinterpret_cast<const float*>(a.wpc); c.w_bs = a.wpc_bs / 2;
@@ -326,6 +388,35 @@ void conv_wgrad(Stream& s, const ConvWgradArgs& a) {
     char nm[128];
     snprintf(nm, sizeof nm, "sim_conv_wgrad[M%d,N%d,K%d,b%d]", a.x.N * a.g.Ho * a.g.Wo, a.Cout, a.g.KH * a.g.KW * a.x.C, nb);
     route_note(nm);
+  }
+  // SWN_SIM_PAIR: the ring kernel's two fp16 planes of both operands (x cut by truncation, dY by rounding; pair-form operands were
+  // rounded by their producers).  Which launches the device sends to that kernel is approximated by its main condition (Npad > 32).
+  if (sim_pair_on() && a.Npad > 32 && a.x.C % 4 == 0 && a.dy.C % 4 == 0 && !(a.x_pair_k && a.dy_pair_k)) {
+    ConvWgradArgs c = a;
+    const int nbx = a.phases ? 1 : nb;
+    auto cut_copy = [&](const TView& v, size_t bs, const float* slot, bool trunc_h, std::vector<float>& store, TView& out, size_t& out_bs) {
+      const size_t rows = (size_t)v.N * v.H * v.W;
+      float am = 0.f;
+      if (slot) am = sim_slot_max(slot);
+      else
+        for (int z = 0; z < nbx; ++z)
+          for (size_t r = 0; r < rows; ++r)
+            for (int ch = 0; ch < v.C; ++ch) am = std::max(am, std::fabs(v.p[(size_t)z * bs + r * v.cs + ch]));
+      const int k = sim_scale_exp(am, 12);
+      store.resize((size_t)nbx * rows * v.C);
+      for (int z = 0; z < nbx; ++z)
+        for (size_t r = 0; r < rows; ++r)
+          for (int ch = 0; ch < v.C; ++ch) store[((size_t)z * rows + r) * v.C + ch] = sim_cut(v.p[(size_t)z * bs + r * v.cs + ch], k, trunc_h);
+      out = v; out.p = store.data(); out.cs = v.C;
+      if (!a.phases) out_bs = rows * (size_t)v.C;
+    };
+    std::vector<float> xs, ds;
+    if (!a.x_pair_k) cut_copy(a.x, a.x_bs, a.x_amax, true, xs, c.x, c.x_bs);
+    if (!a.dy_pair_k) cut_copy(a.dy, a.dy_bs, a.dy_amax, false, ds, c.dy, c.dy_bs);
+    c.x_pair_k = c.dy_pair_k = reinterpret_cast<const int*>(&c);      // (marks "already cut" for the recursion below)
+    c.x_amax = c.dy_amax = nullptr;
+    conv_wgrad(s, c);
+    return;
   }
 #pragma omp parallel for schedule(dynamic, 1) if (nb >= 8)
   for (int b = 0; b < nb; ++b) {
