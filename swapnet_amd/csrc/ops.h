@@ -37,7 +37,7 @@ void graph_destroy(void* exec);
 // ---- memory -------------------------------------------------------------------------
 void* dev_alloc(size_t bytes);            // zero-filled
 void dev_free(void* p);
-void dev_memset(Stream& s, void* p, int v, size_t bytes);
+void dev_memset(Stream& s, void* p, int v, size_t bytes);     // a kernel launch (a recordable KERNEL node, not a memset node: device.hip)
 void dev_copy(Stream& s, void* dst, const void* src, size_t bytes);        // device->device
 void dev_upload(Stream& s, void* dst, const void* src, size_t bytes);      // host->device
 void dev_download(Stream& s, void* dst, const void* src, size_t bytes);    // device->host (syncs)
