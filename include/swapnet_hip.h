@@ -38,7 +38,8 @@ extern "C" {
 typedef struct swn_ctx swn_ctx;
 typedef struct swn_model swn_model;
 
-int swn_abi_version(void);   /* 2: swn_hyper gained d_b1, d_b2; 3: gp_mode, lambda_gp; 4: swn_route_*, swn_model_step_captured, swn_model_create_shared */
+int swn_abi_version(void);   /* 2: swn_hyper gained d_b1, d_b2; 3: gp_mode, lambda_gp; 4: swn_route_*, swn_model_step_captured, swn_model_create_shared;
+                                5: swn_ctx_attach_comm, swn_model_step_dp */
 const char* swn_last_error(void);
 /* 1 when this library executes on a HIP device (libswapnet_hip.so), 0 for the CI simulator */
 int swn_is_device_build(void);
@@ -232,6 +233,20 @@ int swn_model_optimizer_step_range(swn_model* m, int net, size_t off, size_t cou
  * back-propagation of the earlier layers -- the same element-wise update from the same gradients: bit-identical to the
  * phased calls above (SWN_STREAM_ADAMW=0: one launch after the pass). */
 int swn_model_step(swn_model* m, const float labels[3], int training, uint64_t dropout_seed);
+/* Data parallelism with the exchange owned by this library (SURVEY.md 8(b) "allreduce_attach(rccl_comm)", 8(e); the reference has no
+ * multi-GPU code: models/base_gan.py:194-203 is the step being sharded).  swn_ctx_attach_comm hands over an all-reduce entry point
+ * with ncclAllReduce's signature -- RCCL's own symbol, taken from the librccl the process already holds, so no second copy of RCCL
+ * is linked -- and the communicator to call it on (one rank per GPU, ncclCommInitRank done by the caller: swapnet_amd/parallel.py
+ * NativeComm).  The library gives the exchange a HIP stream of its own and orders it against its compute streams with events it
+ * records itself.  swn_model_step_dp is optimize_parameters under data parallelism in one call: backward_D, all-reduce(SUM) of D's
+ * gradient arena, optimizer_D, then the generator's backward pass bucket by bucket, each bucket's all-reduce enqueued on the
+ * exchange stream the moment its gradients are final and its AdamW on the same stream behind it; the compute stream joins the
+ * exchange stream once, at the end of the step.  swn_hyper.grad_scale = 1 / world makes SUM the mean.  after_forward != 0: the
+ * caller ran swn_model_forward itself (texture stage with the style term: swn_model_set_style_context goes in between).
+ * fn == NULL detaches.  dtype / op are passed as ncclFloat32 (7) / ncclSum (0). */
+typedef int (*swn_allreduce_fn)(const void* sendbuf, void* recvbuf, size_t count, int dtype, int op, void* comm, void* stream);
+int swn_ctx_attach_comm(swn_ctx* ctx, swn_allreduce_fn fn, void* comm, int world_size);
+int swn_model_step_dp(swn_model* m, const float labels[3], int training, uint64_t dropout_seed, int after_forward);
 /* The same step recorded once into a hipGraph and replayed (BASELINE.json C5's "hipGraph-captured step"): the three label
  * draws of GANLoss (modules/loss.py:77-104), the dropout seed and both AdamW bias corrections travel through a 40-byte device
  * block uploaded in stream order, so one recorded launch sequence serves every step; the loss read-back of train.py:74

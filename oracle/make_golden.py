@@ -210,6 +210,38 @@ def golden_warp_modes(path, H=64, B=2, init_seed=0, step_seed=100):
     print("wrote", path, len(out), "entries")
 
 
+def golden_warp_depths_gp(path, H=64, B=2, init_seed=0, step_seed=100):
+    """--gan_mode wgan-gp / dragan-gp with --discriminator n_layers --n_layers_D 2 / 4 (modules/loss.py:133-184 through
+    modules/discriminators.py:91-136 at other depths): one step of the REAL reference's WarpModel -- losses, fakes, every
+    post-step D weight (they carry the second-order gradient of the penalty)."""
+    from oracle.swapnet_oracle import synth_warp_batch
+    from models.warp_model import WarpModel
+    out = OrderedDict()
+    bodys, inputs, targets = synth_warp_batch(B, H, H, seed=1234)
+    for n in (2, 4):
+        for mode in ("wgan-gp", "dragan-gp"):
+            with tempfile.TemporaryDirectory() as tmp:
+                opt = base_opt(tmp, lambda_ce=100.0, model="warp", gan_mode=mode, warp_mode="gan", discriminator="n_layers", n_layers_D=n)
+                torch.manual_seed(init_seed)
+                model = WarpModel(opt)
+                model.eval()
+                model.set_input(dict(bodys=bodys, input_cloths=inputs, target_cloths=targets,
+                                     cloth_paths=[""] * B, body_paths=[""] * B))
+                torch.manual_seed(step_seed)
+                model.optimize_parameters()
+                pre = "n%d/%s/" % (n, mode)
+                for k, v in model.get_current_losses().items():
+                    out[pre + "loss/" + k] = np.float64(v)
+                summarize(out, pre + "fakes", model.fakes)
+                for k, v in model.net_discriminator.state_dict().items():
+                    if k.endswith(".weight"):
+                        summarize(out, pre + "postD/" + k, v)
+    out["meta/init_seed"] = np.int64(init_seed); out["meta/step_seed"] = np.int64(step_seed)
+    out["meta/B"] = np.int64(B); out["meta/H"] = np.int64(H)
+    np.savez_compressed(path, **out)
+    print("wrote", path, len(out), "entries")
+
+
 def golden_warp_depths(path, H=64, B=2, init_seed=0, step_seed=100):
     """--discriminator n_layers --n_layers_D 2 / 4 (modules/discriminators.py:45-88,91-136; models/base_gan.py:147-149): the
     REAL reference's discriminator at other depths -- its parameter names / shapes after init, its prediction map on the
@@ -375,7 +407,7 @@ if __name__ == "__main__":
     torch.set_num_threads(8)
     gold = os.path.join(REPO, "tests", "golden")
     os.makedirs(gold, exist_ok=True)
-    which = sys.argv[1:] or ["warp", "texture", "roi", "cloth", "roiops", "modes", "channels", "depths"]
+    which = sys.argv[1:] or ["warp", "texture", "roi", "cloth", "roiops", "modes", "channels", "depths", "depths_gp"]
     if "warp" in which:
         golden_warp(os.path.join(gold, "warp_step_64.npz"))
     if "texture" in which:
@@ -388,6 +420,8 @@ if __name__ == "__main__":
         golden_warp_channels(os.path.join(gold, "warp_channels_64.npz"))
     if "depths" in which:
         golden_warp_depths(os.path.join(gold, "warp_depths_64.npz"))
+    if "depths_gp" in which:
+        golden_warp_depths_gp(os.path.join(gold, "warp_depths_gp_64.npz"))
     if "roiops" in which:
         golden_roi_ops(os.path.join(gold, "roi_ops_reference.npz"))
     if "cloth" in which:

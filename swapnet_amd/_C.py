@@ -82,6 +82,8 @@ _PROTOS = {
     "swn_model_optimizer_step_range": ([_vp, _i, C.c_size_t, C.c_size_t, _i], _i),
     "swn_model_step": ([_vp, C.POINTER(_f * 3), _i, C.c_uint64], _i),
     "swn_model_step_captured": ([_vp, C.POINTER(_f * 3), _i, C.c_uint64], _i),
+    "swn_model_step_dp": ([_vp, C.POINTER(_f * 3), _i, C.c_uint64, _i], _i),
+    "swn_ctx_attach_comm": ([_vp, _vp, _vp, _i], _i),
     "swn_model_get_losses": ([_vp, C.POINTER(_f), _i], _i),
     "swn_model_grad_arena": ([_vp, _i, C.POINTER(_vp), C.POINTER(C.c_size_t)], _i),
     "swn_model_weight_arena": ([_vp, _i, C.POINTER(_vp), C.POINTER(C.c_size_t)], _i),

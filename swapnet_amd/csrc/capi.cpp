@@ -57,7 +57,7 @@ static int guard(F f) {
 
 extern "C" {
 
-int swn_abi_version(void) { return 4; }
+int swn_abi_version(void) { return 5; }
 const char* swn_last_error(void) { return g_err.c_str(); }
 int swn_is_device_build(void) { return is_device_build(); }
 
@@ -72,6 +72,7 @@ int swn_ctx_create(int device, void* hip_stream, int create_stream, size_t works
     if (workspace_bytes < (size_t)64 << 20) workspace_bytes = (size_t)64 << 20;
     h->box->c = std::make_unique<Ctx>(st, workspace_bytes);
     h->c = h->box->c.get();
+    h->c->device_index = device;
     if (!(getenv("SWN_OVERLAP") && atoi(getenv("SWN_OVERLAP")) == 0)) h->c->enable_side(device);
     *out = h.release();
   });
@@ -88,6 +89,13 @@ int swn_ctx_set_overlap(swn_ctx* ctx, int on) {
     ctx->c->join_side();
     stream_sync(ctx->c->s);
     ctx->c->side_enabled = on != 0;
+  });
+}
+int swn_ctx_attach_comm(swn_ctx* ctx, swn_allreduce_fn fn, void* comm, int world_size) {
+  return guard([&] {
+    REQUIRE(ctx, "ctx is NULL");
+    ctx->c->join_side();
+    ctx->c->attach_comm(reinterpret_cast<Ctx::AllReduceFn>(fn), comm, fn ? world_size : 1);
   });
 }
 int swn_ctx_set_patchgan_layers(swn_ctx* ctx, int n_layers) {
@@ -191,9 +199,6 @@ int swn_model_set_hyper(swn_model* m, const swn_hyper* h) {
     REQUIRE(h->gp_mode >= 0 && h->gp_mode <= 3, "gradient penalty mode not implemented");
     REQUIRE(h->gp_mode == 0 || m->m->supports_gradient_penalty(),
             "gradient penalty modes are not implemented for the texture model (the reference's call fails there too)");
-    if (h->gp_mode != 0 && m->m->patchgan_layers() != 3)          // at configuration time, not in the middle of the first step
-      throw Error(3, "gradient penalty with n_layers_D = " + std::to_string(m->m->patchgan_layers()) +
-                         " is not implemented (3-level PatchGAN only)");
     y.gp_mode = h->gp_mode; y.lambda_gp = h->lambda_gp;
   });
 }
@@ -413,6 +418,12 @@ int swn_model_step(swn_model* m, const float labels[3], int training, uint64_t s
   return guard([&] {
     REQUIRE(m && labels && m->m->is_train, "model was not created for training");
     m->m->step(labels, training != 0, seed);
+  });
+}
+int swn_model_step_dp(swn_model* m, const float labels[3], int training, uint64_t seed, int after_forward) {
+  return guard([&] {
+    REQUIRE(m && labels && m->m->is_train, "model was not created for training");
+    m->m->step_dp(labels, training != 0, seed, after_forward != 0);
   });
 }
 int swn_model_step_captured(swn_model* m, const float labels[3], int training, uint64_t seed) {

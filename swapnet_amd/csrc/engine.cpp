@@ -48,6 +48,11 @@ Ctx::Ctx(const Stream& shared) : s(shared), owns_ws(false) {}
 Ctx::~Ctx() {
   release(allocs);
   if (owns_ws) dev_free(s.ws);
+  if (owned_comm_stream) {
+    for (void* e : comm_events) event_destroy(e);
+    event_destroy(comm_join_event);
+    stream_destroy(owned_comm_stream);
+  }
   if (has_side) {
     dev_free(side.ws);
     for (void* e : fork_events) event_destroy(e);
@@ -77,6 +82,39 @@ void Ctx::join_side() {
   event_record(join_event, side);
   stream_wait_event(s, join_event);
   side_dirty = false;
+}
+void Ctx::attach_comm(AllReduceFn fn, void* comm, int world) {
+  comm_join();
+  if (!fn) { comm_fn = nullptr; comm_handle = nullptr; comm_world = 1; return; }
+  if (world < 1) throw Error(1, "attach_comm: world size must be >= 1");
+  comm_fn = fn; comm_handle = comm; comm_world = world;
+  if (is_device_build() && !owned_comm_stream) {
+    owned_comm_stream = stream_create(device_index);
+    comm_stream.handle = owned_comm_stream;       // no scratch: nothing launched there uses the split-K workspace
+    for (int i = 0; i < 8; ++i) comm_events.push_back(event_create());
+    comm_join_event = event_create();
+  }
+}
+Stream& Ctx::comm_fork() {
+  if (!owned_comm_stream) return s;               // host simulator: one in-order stream
+  void* ev = comm_events[comm_ev_i++ % comm_events.size()];
+  event_record(ev, s);
+  stream_wait_event(comm_stream, ev);
+  comm_dirty = true;
+  return comm_stream;
+}
+void Ctx::comm_join() {
+  if (!owned_comm_stream || !comm_dirty) return;
+  event_record(comm_join_event, comm_stream);
+  stream_wait_event(s, comm_join_event);
+  comm_dirty = false;
+}
+void Ctx::all_reduce_sum(Stream& on, float* buf, size_t count) {
+  if (!comm_fn) throw Error(1, "all_reduce: no communicator attached (swn_ctx_attach_comm)");
+  if (count == 0) return;
+  // ncclFloat32 = 7, ncclSum = 0 (nccl.h / rccl.h)
+  const int rc = comm_fn(buf, buf, count, 7, 0, comm_handle, on.handle);
+  if (rc != 0) throw Error(2, "all_reduce: the attached all-reduce returned " + std::to_string(rc));
 }
 void* Ctx::alloc(size_t bytes) {
   void* p = dev_alloc(bytes);
@@ -1332,8 +1370,7 @@ void Model::discriminate(const float* x_nchw, float* pred_nchw) {
 void Model::set_gp_random(const float* alpha_dev, const float* beta_nchw_dev) {
   if (!is_train || d_cimap_.empty()) throw Error(1, "set_gp_random: the model has no discriminator");
   if (!gp_) {
-    if (d_layers_ != 3) throw Error(3, "gradient penalty with n_layers_D = " + std::to_string(d_layers_) + " is not implemented (3-level PatchGAN only)");
-    AllocScope mine(*ctx, owned_allocs); gp_ = std::make_unique<GradPenalty>(*ctx, arenaD, B, H, W);
+    AllocScope mine(*ctx, owned_allocs); gp_ = std::make_unique<GradPenalty>(*ctx, arenaD, B, H, W, d_layers_);
   }
   if (alpha_dev) { dev_copy(ctx->s, gp_->alpha_buffer(), alpha_dev, (size_t)B * sizeof(float)); gp_alpha_set_ = true; }
   if (beta_nchw_dev) {                       // reference channel order (B, 22, H, W) -> buffer order, pads stay 0
@@ -1357,8 +1394,7 @@ void Model::set_gp_random(const float* alpha_dev, const float* beta_nchw_dev) {
 }
 void Model::run_gradient_penalty(const TView& real, const TView& fake) {
   if (!gp_) {
-    if (d_layers_ != 3) throw Error(3, "gradient penalty with n_layers_D = " + std::to_string(d_layers_) + " is not implemented (3-level PatchGAN only)");
-    AllocScope mine(*ctx, owned_allocs); gp_ = std::make_unique<GradPenalty>(*ctx, arenaD, B, H, W);
+    AllocScope mine(*ctx, owned_allocs); gp_ = std::make_unique<GradPenalty>(*ctx, arenaD, B, H, W, d_layers_);
   }
   const TView beta = gp_->beta_buffer();
   // library RNG: a function of the step seed the caller handed to forward() (torch.initial_seed(), the step counter and --
@@ -1453,6 +1489,35 @@ void Model::step_captured(const float labels[3], bool training, uint64_t seed) {
   graph_launch(step_graph_[gi], ctx->s);
   if (!hyper.warp_mode_ce_only) { arenaD.step += 1; arenaD.version += 1; }
   arenaG.step += 1; arenaG.version += 1;
+}
+
+// Data-parallel optimize_parameters with the library's own exchange (engine.h Model::step_dp)
+void Model::step_dp(const float labels[3], bool training, uint64_t seed, bool after_forward) {
+  if (!ctx->comm_fn) throw Error(1, "step_dp: no communicator attached (swn_ctx_attach_comm)");
+  if (!after_forward) forward(training, seed);
+  if (!hyper.warp_mode_ce_only) {
+    backward_D(labels[0], labels[1]);            // ends joined: every D gradient is ordered on the main stream
+    // D's update precedes the D pass of backward_G by data dependence (base_gan.py:199): this exchange is serial
+    Stream& cs = ctx->comm_fork();
+    ctx->all_reduce_sum(cs, arenaD.g, arenaD.n);
+    ctx->comm_join();
+    optimizer_step(1);
+  }
+  const int np = backward_G_parts();
+  const int ver = arenaG.version;
+  for (int part = 0; part < np; ++part) {
+    size_t off = 0, count = 0;
+    backward_G_part(labels[2], part, &off, &count, /*join=*/true);      // the bucket's weight gradients are final on the main stream
+    // exchange stream: after the bucket's gradients, behind the previous bucket's all-reduce and AdamW (stream order).  Nothing
+    // later on the compute streams reads this bucket's weights or gradients again this step (backward_G_streamed's argument):
+    // the earlier layers multiply by their own derived operands, which are refreshed from the weights at the next forward --
+    // after the join below.
+    Stream& cs = ctx->comm_fork();
+    ctx->all_reduce_sum(cs, arenaG.g + off, count);
+    optimizer_step_range_on(cs, 0, off, count, part == 0);
+  }
+  arenaG.version = ver + 1;        // one optimizer step
+  ctx->comm_join();
 }
 
 // BaseGAN.optimize_parameters (models/base_gan.py:194-203): forward, D step, G step.

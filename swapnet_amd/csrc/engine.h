@@ -37,6 +37,26 @@ struct Ctx {
   AllocList* sink = nullptr;
   void release(AllocList& list);          // frees the list's buffers (device-synchronising) and empties it
   size_t bytes_allocated = 0;
+  // ---- library-owned gradient exchange (swn_ctx_attach_comm, Model::step_dp) ---------------------------
+  // The caller hands over an all-reduce entry point with ncclAllReduce's signature and the communicator it runs on (RCCL's
+  // own symbol from the library the process already holds: no second copy is linked here).  The exchange gets a stream of
+  // its own; ordering against the compute streams is by explicit events, recorded and waited for by this library -- nothing
+  // depends on which stream the host framework considers current.
+  typedef int (*AllReduceFn)(const void* sendbuf, void* recvbuf, size_t count, int dtype, int op, void* comm, void* stream);
+  AllReduceFn comm_fn = nullptr;
+  void* comm_handle = nullptr;
+  int comm_world = 1;
+  int device_index = 0;
+  Stream comm_stream;                // (the main stream itself on the host simulator: everything is in order there)
+  void* owned_comm_stream = nullptr;
+  std::vector<void*> comm_events;
+  size_t comm_ev_i = 0;
+  void* comm_join_event = nullptr;
+  bool comm_dirty = false;
+  void attach_comm(AllReduceFn fn, void* comm, int world);     // fn == NULL detaches
+  Stream& comm_fork();               // the exchange stream, ordered after everything enqueued on `s` so far
+  void comm_join();                  // `s` continues after the exchange stream's work (no-op if nothing was forked)
+  void all_reduce_sum(Stream& on, float* buf, size_t count);   // in place, SUM over the communicator's ranks
   // discriminators.define_D(..., n_layers_D) (modules/discriminators.py:45-88, base_gan.py:147): stride-2 levels of the PatchGAN of
   // every model created on this context afterwards (3 = the reference's "basic" 70x70 PatchGAN)
   int patchgan_layers = 3;
@@ -261,7 +281,7 @@ bool first_ring_on();
 // ---- gradient penalty (gp.cpp): second-order pass through PatchGAN for --gan_mode wgan-gp / dragan-gp / dragan-lp ----
 class GradPenalty {
  public:
-  GradPenalty(Ctx& c, ParamArena& arenaD, int B, int H, int W);
+  GradPenalty(Ctx& c, ParamArena& arenaD, int B, int H, int W, int n_layers = 3);
   ~GradPenalty();
   // real / fake: the conditioned (B, H, W, 24) halves of the discriminator's input buffer.  gp_mode 1 wgan-gp,
   // 2 dragan-gp, 3 dragan-lp.  Adds grad_scale * lambda_gp * d gp / d theta to the discriminator's gradient arena and
@@ -279,7 +299,7 @@ class GradPenalty {
     bool norm = false;
     float* stats = nullptr;
     float* dg = nullptr;           // input-gradient operand (repack_dgrad), refreshed every run
-    Var raw, h;                    // conv output (l = 1..3) and activation; .g = first-backward gradients
+    Var raw, h;                    // conv output (l = 1..n_layers) and activation; .g = first-backward gradients
     TView u_raw, u_h, a_raw, a_h, tmp, gr0;
   };
   void conv(int l, const TView& x, const TView& y, bool bias, int act);
@@ -288,6 +308,7 @@ class GradPenalty {
   Ctx& ctx_;
   ParamArena& A_;
   int B_;
+  int nl_ = 3, NL_ = 5;                // stride-2 levels of the PatchGAN; its convs (n_layers + 2)
   int Cd_ = 24, Cd_logical_ = 22;      // D input buffer channels / the reference's channel count
  
   std::unique_ptr<Net> net_;
@@ -357,6 +378,14 @@ class Model {
   // over the whole arena after the pass).  Same arithmetic per element: results are bit-identical.
   void backward_G_streamed(float label_real);
   void step(const float labels[3], bool training, uint64_t seed);
+  // The data-parallel step with the exchange owned by the library (Ctx::attach_comm): forward; backward_D, all-reduce of D's
+  // gradient arena, optimizer_D; backward_G bucket by bucket (backward_G_part), each bucket's all-reduce on the exchange
+  // stream as soon as its gradients are final, its AdamW enqueued on the SAME stream behind the all-reduce -- the main
+  // stream never waits for a collective before the end of the step, where it joins the exchange stream.  Every loss gradient
+  // is pre-scaled by hyper.grad_scale = 1 / world, so SUM is the mean.  after_forward: the caller has run forward() already
+  // (texture stage with the style term: the global-batch style context is set between the two).  With one rank attached the
+  // collectives are identities and the result equals step()'s.
+  void step_dp(const float labels[3], bool training, uint64_t seed, bool after_forward);
   // The same step recorded ONCE into a hipGraph (per value of `training`) and replayed: every per-step scalar -- the three
   // smooth labels (modules/loss.py:77-104), the dropout seed, the bias corrections of both AdamW steps -- lives in a small
   // device block (StepParams) that is uploaded in stream order before each launch, so the recorded launch sequence (two

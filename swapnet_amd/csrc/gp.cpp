@@ -26,25 +26,32 @@ TView flat_view(float* p, size_t n) {
 }
 }  // namespace
 
-GradPenalty::GradPenalty(Ctx& c, ParamArena& arenaD, int B, int H, int W) : ctx_(c), A_(arenaD), B_(B) {
+// n_layers = the PatchGAN's stride-2 levels (define_D's n_layers_D, modules/discriminators.py:110-131): conv k of its
+// nn.Sequential sits at index 0, then 2 + 3 (k - 1) -- [conv, norm, lrelu] triples behind [conv, lrelu]; layers 0 .. n_layers - 1
+// are k4 s2, layer n_layers the k4 s1 conv with a norm, layer n_layers + 1 the k4 s1 prediction conv; norms on 1 .. n_layers.
+GradPenalty::GradPenalty(Ctx& c, ParamArena& arenaD, int B, int H, int W, int n_layers)
+    : ctx_(c), A_(arenaD), B_(B), nl_(n_layers), NL_(n_layers + 2) {
+  if (n_layers < 1 || n_layers > 5) throw Error(1, "GradPenalty: n_layers_D must be in [1, 5]");
   net_ = std::make_unique<Net>(c, arenaD);
   Net& n = *net_;
-  static const char* names[5] = {"model.0", "model.2", "model.5", "model.8", "model.11"};
+  const int nl = nl_, NL = NL_;
+  std::vector<std::string> names(NL);
+  for (int l = 0; l < NL; ++l) names[l] = "model." + std::to_string(l == 0 ? 0 : 2 + 3 * (l - 1));
   int h = H, w = W;
   const ParamDesc& w0 = arenaD.params[arenaD.index.at("model.0.weight")];
   Cd_ = w0.ws.Cip;                        // channels of D's conditional input buffer (padded layout of the model)
   Cd_logical_ = w0.ws.Ci;
   xh_ = n.alloc_var(B, H, W, Cd_, true);
   u0_ = n.alloc_var(B, H, W, Cd_, false).v;
-  L_.resize(5);
-  for (int l = 0; l < 5; ++l) {
+  L_.resize(NL);
+  for (int l = 0; l < NL; ++l) {
     Layer& y = L_[l];
-    const ParamDesc& wd = arenaD.params[arenaD.index.at(std::string(names[l]) + ".weight")];
-    const ParamDesc& bd = arenaD.params[arenaD.index.at(std::string(names[l]) + ".bias")];
+    const ParamDesc& wd = arenaD.params[arenaD.index.at(names[l] + ".weight")];
+    const ParamDesc& bd = arenaD.params[arenaD.index.at(names[l] + ".bias")];
     y.ws = wd.ws; y.woff = wd.off; y.boff = bd.off;
-    y.kind = l < 3 ? 0 : 1;
+    y.kind = l < nl ? 0 : 1;
     y.Cin = wd.ws.Cip; y.Co = wd.ws.Co; y.Cop = round_up(wd.ws.Co, 4);
-    y.norm = l >= 1 && l <= 3;
+    y.norm = l >= 1 && l <= nl;
     if (y.kind == 0) { h /= 2; w /= 2; } else { h -= 1; w -= 1; }
     y.h = n.alloc_var(B, h, w, y.Cop, true);
     if (y.norm) {
@@ -53,11 +60,11 @@ GradPenalty::GradPenalty(Ctx& c, ParamArena& arenaD, int B, int H, int W) : ctx_
       y.tmp = n.alloc_var(B, h, w, y.Cop, false).v;
     }
     if (l == 0) y.gr0 = n.alloc_var(B, h, w, y.Cop, false).v;
-    if (l < 4) {
+    if (l < NL - 1) {
       y.u_raw = n.alloc_var(B, h, w, y.Cop, false).v;
       y.u_h = n.alloc_var(B, h, w, y.Cop, false).v;
       y.a_raw = n.alloc_var(B, h, w, y.Cop, false).v;
-      if (l < 3) y.a_h = n.alloc_var(B, h, w, y.Cop, false).v;
+      if (l < nl) y.a_h = n.alloc_var(B, h, w, y.Cop, false).v;
     }
     y.dg = static_cast<float*>(c.alloc(dgrad_elems(y.ws, y.kind == 0 ? 0 : 1, y.Cop, y.Cin) * sizeof(float)));
   }
@@ -127,22 +134,23 @@ void GradPenalty::run(const TView& real, const TView& fake, int gp_mode, float g
   } else {
     gp_interpolate(s, real, &fake, alpha, nullptr, nullptr, xh_.v);
   }
-  for (int l = 0; l < 5; ++l) repack_dgrad(s, L_[l].ws, L_[l].kind == 0 ? 0 : 1, L_[l].Cop, L_[l].Cin, A_.w + L_[l].woff, L_[l].dg);
+  const int nl = nl_, P = NL_ - 1;          // P: the prediction conv
+  for (int l = 0; l < NL_; ++l) repack_dgrad(s, L_[l].ws, L_[l].kind == 0 ? 0 : 1, L_[l].Cop, L_[l].Cin, A_.w + L_[l].woff, L_[l].dg);
 
   // ---- forward
   conv(0, xh_.v, L_[0].h.v, true, ACT_LRELU);
-  for (int l = 1; l <= 3; ++l) {
+  for (int l = 1; l <= nl; ++l) {
     conv(l, L_[l - 1].h.v, L_[l].raw.v, true, ACT_NONE);
     NormActArgs a;
     a.x = L_[l].raw.v; a.y = L_[l].h.v; a.stats = L_[l].stats; a.norm = 1; a.act = ACT_LRELU;
     norm_act_fwd(s, a);
   }
-  conv(4, L_[3].h.v, L_[4].h.v, true, ACT_NONE);
+  conv(P, L_[nl].h.v, L_[P].h.v, true, ACT_NONE);
   // ---- first backward with grad_outputs = ones (loss.py:160-162)
-  const TView pred = L_[4].h.v, gpred = L_[4].h.g;
+  const TView pred = L_[P].h.v, gpred = L_[P].h.g;
   wgan_loss(s, pred, 1.f, (float)pred.pixels(), tmp_loss_, &gpred);          // d(sum pred)/d pred = 1 on channel 0
-  dgrad(4, gpred, L_[3].h.g);
-  for (int l = 3; l >= 1; --l) {
+  dgrad(P, gpred, L_[nl].h.g);
+  for (int l = nl; l >= 1; --l) {
     NormActBwdArgs b;
     b.dy = L_[l].h.g; b.x = L_[l].raw.v; b.stats = L_[l].stats; b.dx = L_[l].raw.g; b.norm = 1; b.act = ACT_LRELU;
     norm_act_bwd(s, b);
@@ -159,7 +167,7 @@ void GradPenalty::run(const TView& real, const TView& fake, int gp_mode, float g
   conv(0, u0_, L_[0].u_raw, false, ACT_NONE);
   wgrad(0, u0_, L_[0].gr0, gA_);
   act_bwd(s, L_[0].u_raw, L_[0].h.v, L_[0].u_h, ACT_LRELU, 0);
-  for (int l = 1; l <= 3; ++l) {
+  for (int l = 1; l <= nl; ++l) {
     conv(l, L_[l - 1].u_h, L_[l].u_raw, false, ACT_NONE);
     wgrad(l, L_[l - 1].u_h, L_[l].raw.g, gA_);
     NormActBwd2Args b2;
@@ -167,9 +175,9 @@ void GradPenalty::run(const TView& real, const TView& fake, int gp_mode, float g
     b2.uy = L_[l].u_h; b2.ax = L_[l].a_raw; b2.act = ACT_LRELU;
     norm_act_bwd2(s, b2);
   }
-  wgrad(4, L_[3].u_h, gpred, gA_);
+  wgrad(P, L_[nl].u_h, gpred, gA_);
   // ---- down pass of the injected adjoints
-  for (int l = 3; l >= 1; --l) {
+  for (int l = nl; l >= 1; --l) {
     wgrad(l, L_[l - 1].h.v, L_[l].a_raw, gB_);
     bias_grad(s, L_[l].a_raw, gB_ + L_[l].boff);
     dgrad(l, L_[l].a_raw, L_[l - 1].a_h);

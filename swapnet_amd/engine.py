@@ -89,6 +89,12 @@ class Context:
     def sync(self):
         self.lib.call("swn_ctx_sync", self.handle)
 
+    def attach_comm(self, fn_ptr, comm, world):
+        """swn_ctx_attach_comm: hand the library an all-reduce entry point (address of a function with ncclAllReduce's signature)
+        and the communicator to call it on; fn_ptr None detaches.  See swapnet_amd.parallel.NativeComm."""
+        self.lib.call("swn_ctx_attach_comm", self.handle, C.c_void_p(fn_ptr) if fn_ptr else None,
+                      comm if comm is not None else None, int(world))
+
     def route_trace(self, on):
         """Start (clears the log) / stop recording which kernel every layer launches (swn_route_trace)."""
         self.lib.call("swn_route_trace", int(bool(on)))
@@ -384,6 +390,12 @@ class NativeModel:
         arr = (C.c_float * 3)(*[float(x) for x in labels])
         self.lib.call("swn_model_step_captured" if captured else "swn_model_step", self.handle, C.byref(arr), int(training),
                       C.c_uint64(seed))
+
+    def step_dp(self, labels, training=True, seed=0, after_forward=False):
+        """One data-parallel G+D step with the exchange owned by the library (swn_model_step_dp; the context needs a communicator:
+        Context.attach_comm / parallel.NativeComm)."""
+        arr = (C.c_float * 3)(*[float(x) for x in labels])
+        self.lib.call("swn_model_step_dp", self.handle, C.byref(arr), int(training), C.c_uint64(seed), int(bool(after_forward)))
 
     def losses(self):
         buf = (C.c_float * len(_C.LOSS_NAMES))()

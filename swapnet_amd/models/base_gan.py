@@ -89,9 +89,6 @@ class BaseGAN(BaseModel, ABC):
                 raise NotImplementedError("gan mode %s: the gradient-penalty objectives are implemented for the warp "
                                           "stage (the reference's texture-stage call passes unconditioned tensors to "
                                           "the conditional discriminator and fails)" % opt.gan_mode)
-            if self.criterion_GAN.gp_mode and getattr(self.backend, "n_layers_D", 3) != 3:
-                raise NotImplementedError("gan mode %s with --n_layers_D %d: the gradient-penalty objectives exist for the "
-                                          "3-level PatchGAN only" % (opt.gan_mode, self.backend.n_layers_D))
             self.backend.set_hyper(gan_mode=self.criterion_GAN.native_mode, lambda_gan=opt.lambda_gan,
                                    gp_mode=self.criterion_GAN.gp_mode, lambda_gp=getattr(opt, "lambda_gp", 10.0))
             for n in ("D", "D_real", "D_fake", "G", "G_gan", "G_ce", "G_l1", "G_content", "G_style", "D_gp"):

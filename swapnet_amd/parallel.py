@@ -12,6 +12,7 @@ two-rank step equals the big-batch step with the term on and off.  The only othe
 gradient of each optimizer's arena, which is ONE flat fp32 buffer per network (G 550 MB, D 11 MB) ->
 bucketed all-reduces, no per-tensor launches.  The reference has no multi-GPU code at all; this is
 new design."""
+import ctypes as C
 import os
 
 import torch
@@ -133,3 +134,115 @@ def generator_backward_with_exchange(model, label_real, xchg, net_g=0):
 def broadcast_arena(flat, src=0):
     if dist.is_initialized() and dist.get_world_size() > 1:
         dist.broadcast(flat, src=src)
+
+
+# ---- library-owned exchange (swn_ctx_attach_comm / swn_model_step_dp) -----------------------------------------------------------
+class _NcclUniqueId(C.Structure):
+    _fields_ = [("internal", C.c_char * 128)]        # rccl.h: NCCL_UNIQUE_ID_BYTES
+
+
+def _loaded_rccl():
+    """The librccl this process ALREADY holds (torch's): dlopen by the path of the mapped file returns the same handle, so the
+    communicator created here and the ncclAllReduce handed to the library belong to the one RCCL instance in the process."""
+    paths = []
+    try:
+        with open("/proc/self/maps") as f:
+            for line in f:
+                if "librccl" in line or "libnccl" in line:
+                    paths.append(line.split()[-1])
+    except OSError:
+        pass
+    libdir = os.path.join(os.path.dirname(torch.__file__), "lib")
+    for cand in paths + [os.path.join(libdir, "librccl.so"), "/opt/rocm/lib/librccl.so", "librccl.so"]:
+        try:
+            return C.CDLL(cand)
+        except OSError:
+            continue
+    raise RuntimeError("librccl not found (torch.distributed's nccl backend loads it)")
+
+
+class NativeComm:
+    """A communicator for the library's own gradient exchange (allreduce_attach(rccl_comm)).
+
+    backend "rccl": ncclGetUniqueId on rank 0, broadcast through the default process group, ncclCommInitRank on every rank --
+    through ctypes on the RCCL the process already holds -- and the ADDRESS of that library's ncclAllReduce handed to
+    swn_ctx_attach_comm together with the communicator: from then on the library enqueues the collectives itself, on a stream of
+    its own, ordered against its compute streams by its own events (swn_model_step_dp).  No tensor of the host framework and none
+    of its streams take part in the exchange.
+
+    backend "gloo" (CPU tests, host simulator): the same C-ABI hook driven by a Python callback that all-reduces the host buffer
+    through torch.distributed -- it exercises the library-side sequencing (bucket ranges, ranged AdamW, step counters), not
+    stream ordering."""
+
+    def __init__(self, ctx, backend=None):
+        self.ctx = ctx
+        self.world = dist.get_world_size() if dist.is_initialized() else 1
+        self.rank = dist.get_rank() if dist.is_initialized() else 0
+        self.backend = backend or ("rccl" if ctx.lib.is_device else "gloo")
+        self._keep = []
+        if self.backend == "rccl":
+            self._init_rccl()
+        else:
+            self._init_callback()
+
+    def _init_rccl(self):
+        dll = self.dll = _loaded_rccl()
+        dll.ncclGetUniqueId.argtypes = [C.POINTER(_NcclUniqueId)]
+        dll.ncclGetUniqueId.restype = C.c_int
+        dll.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, _NcclUniqueId, C.c_int]
+        dll.ncclCommInitRank.restype = C.c_int
+        dll.ncclCommDestroy.argtypes = [C.c_void_p]
+        dll.ncclCommDestroy.restype = C.c_int
+        uid = _NcclUniqueId()
+        if self.rank == 0:
+            rc = dll.ncclGetUniqueId(C.byref(uid))
+            if rc != 0:
+                raise RuntimeError("ncclGetUniqueId failed: %d" % rc)
+        if self.world > 1:
+            box = [C.string_at(C.addressof(uid), 128)] if self.rank == 0 else [None]      # (raw memory: c_char arrays truncate at NUL)
+            dist.broadcast_object_list(box, src=0)
+            C.memmove(C.addressof(uid), box[0], 128)
+        torch.cuda.set_device(self.ctx.device)
+        comm = C.c_void_p()
+        rc = dll.ncclCommInitRank(C.byref(comm), self.world, uid, self.rank)
+        if rc != 0:
+            raise RuntimeError("ncclCommInitRank failed: %d" % rc)
+        self.comm = comm
+        fn = C.cast(dll.ncclAllReduce, C.c_void_p).value
+        self.ctx.attach_comm(fn, comm, self.world)
+
+    def _init_callback(self):
+        proto = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p)
+        self.calls = []
+
+        def allreduce(send, recv, count, dtype, op, comm, stream):
+            try:
+                if dtype != 7 or op != 0:
+                    return 100
+                if send != recv:
+                    C.memmove(recv, send, count * 4)
+                t = torch.frombuffer((C.c_float * count).from_address(recv), dtype=torch.float32)
+                self.calls.append(int(count))
+                if dist.is_initialized() and dist.get_world_size() > 1:
+                    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+                return 0
+            except Exception:                                  # never unwind through the C caller
+                return 101
+        cb = proto(allreduce)
+        self._keep.append(cb)
+        self.comm = None
+        self.ctx.attach_comm(C.cast(cb, C.c_void_p).value, None, self.world)
+
+    def close(self):
+        self.ctx.attach_comm(None, None, 1)
+        if self.backend == "rccl" and self.comm:
+            self.ctx.sync()
+            self.dll.ncclCommDestroy(self.comm)
+            self.comm = None
+
+
+def native_comm_requested():
+    """SWAPNET_NATIVE_COMM=1: the data-parallel step goes through swn_model_step_dp (library-owned exchange) instead of the
+    torch.distributed calls of GradExchange.  Opt-in: the RCCL form has not run on hardware yet (round 4 had no GPU minutes left when
+    it was written); the callback form is what the CPU tests exercise."""
+    return os.environ.get("SWAPNET_NATIVE_COMM") == "1"

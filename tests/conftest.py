@@ -17,13 +17,20 @@ if REPO not in sys.path:
 ROUTING_SWITCHES = ("SWN_WINO_MINC", "SWN_WINOGRAD", "SWN_WINO_S2", "SWN_WINO_M", "SWN_WINO_K4", "SWN_WINO_ADJOINT", "SWN_WINO_PC",
                     "SWN_TAIL_WINO", "SWN_TAIL4", "SWN_HEAD_TAPN", "SWN_NARROW", "SWN_DMA", "SWN_DMA_WIDE", "SWN_SPLIT", "SWN_PRECUT",
                     "SWN_PC_PLANES", "SWN_WGRAD_PLANES", "SWN_TILE256", "SWN_WGRAD256", "SWN_TILE192", "SWN_FUSED_IN", "SWN_PC_STAGES",
-                    "SWN_AMAX_FUSED", "SWN_SHARE_DY", "SWN_PAIR", "SWN_WGRAD_PLANE", "SWN_FIRST_RING", "SWN_WINO_VW", "SWN_STREAM_ADAMW", "SWN_SIM_PAIR", "SWN_SIM_SLOT_REPORT")
+                    "SWN_AMAX_FUSED", "SWN_SHARE_DY", "SWN_PAIR", "SWN_WGRAD_PLANE", "SWN_FIRST_RING", "SWN_WINO_VW", "SWN_STREAM_ADAMW", "SWN_SIM_PAIR", "SWN_SIM_SLOT_REPORT",
+                    "SWN_PC_MI", "SWN_PC_MI_MIN_TILES")
 
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     config.addinivalue_line("markers", "small_channel_winograd: run with SWN_WINO_MINC=32 (Winograd forms from 32 channels up, "
                                        "any map size) instead of the product's routing thresholds")
+
+
+# GPU cases written after a round's GPU budget was spent have never executed on an MI355X, and the driver runs the GPU suite with -x:
+# they carry this mark and join the suite only with SWAPNET_UNVERIFIED_GPU=1 (tools/r05_first_call.sh runs them first).
+unverified_gpu = pytest.mark.skipif(os.environ.get("SWAPNET_UNVERIFIED_GPU") != "1",
+                                    reason="never run on the GPU yet (SWAPNET_UNVERIFIED_GPU=1 to include)")
 
 
 @pytest.fixture(autouse=True)

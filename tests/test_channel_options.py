@@ -242,10 +242,7 @@ def test_patchgan_depth_option_reproduces_the_reference(backend, golden_dir):
                     assert rel(pD[k], st.D[k]) < 1e-3, (n, k, rel(pD[k], st.D[k]))
                     ok, msg = compare(gold, pre + "postD/" + k, st.D[k], 1e-3, 3e-3)
                     assert ok, ("oracle", msg)
-            # gradient-penalty objectives exist for the 3-level PatchGAN only: refused when the mode is CONFIGURED, not in the
-            # middle of the first training step (advisor, round 3)
-            with pytest.raises(NotImplementedError):
-                m.set_hyper(gan_mode=2, gp_mode=1)                  # wgan-gp (tests/test_gradient_penalty.py)
+            # (the gradient-penalty objectives at these depths: tests/test_gradient_penalty.py::test_gradient_penalty_at_other_patchgan_depths)
         finally:
             m.close()
     with pytest.raises(ValueError):

@@ -262,3 +262,157 @@ def test_one_rank_rccl_exchange_equals_the_fused_step():
         assert torch.equal(out[0][1], out[1][1]) and torch.equal(out[0][2], out[1][2])
     finally:
         dist.destroy_process_group()
+
+
+# ---- library-owned exchange: swn_ctx_attach_comm + swn_model_step_dp (round 4) --------------------------------------------------
+def test_library_owned_exchange_with_one_rank_equals_the_fused_step():
+    """swn_model_step_dp with a one-rank communicator attached (callback form of parallel.NativeComm: every all-reduce is an
+    identity) must reproduce swn_model_step bit for bit -- weights, both Adam moments, step counters -- over two steps, and the
+    collectives it issues are one over D's arena plus one per generator bucket, whose ranges tile the generator's arena."""
+    from oracle import swapnet_oracle as O
+    from swapnet_amd import engine, parallel
+    from tests import backends
+    ctx = backends.hostsim_ctx(fresh=True)
+    torch.manual_seed(1)
+    G, D = O.warp_module_params(), O.patchgan_params(22)
+    batch = O.synth_warp_batch(1, 64, 64, seed=11)
+    m = engine.NativeModel(ctx, "warp", 1, 64, 64, is_train=True)
+    comm = None
+    try:
+        out = []
+        for mode in ("fused", "native"):
+            backends.reset_state(m, {engine.NET_G: G, engine.NET_D: D})
+            for i, t in enumerate(batch):
+                m.set_input(i, t)
+            if mode == "native":
+                with pytest.raises(Exception):
+                    m.step_dp([0.9, 0.8, 1.0])                     # nothing attached yet: refused, not silently local
+                comm = parallel.NativeComm(ctx, backend="gloo")
+            for step in range(2):
+                (m.step if mode == "fused" else m.step_dp)([0.9, 0.8, 1.0], training=True, seed=5 + step)
+            out.append((m.losses(), m.weight_arena(0).clone(), m.weight_arena(1).clone(),
+                        m.state_dict(0, which=engine.W_EXP_AVG_SQ, to_cpu=True), m.optim_step_count(0), m.optim_step_count(1)))
+        assert out[0][0] == out[1][0]
+        assert torch.equal(out[0][1], out[1][1]) and torch.equal(out[0][2], out[1][2])
+        assert all(torch.equal(out[0][3][k], out[1][3][k]) for k in out[0][3])
+        assert out[0][4:] == out[1][4:] == (2, 2)
+        nG, nD, parts = m.grad_arena(0).numel(), m.grad_arena(1).numel(), m.backward_G_parts()
+        per_step = comm.calls[:1 + parts]
+        assert len(comm.calls) == 2 * (1 + parts) and per_step[0] == nD and sum(per_step[1:]) == nG, (comm.calls, nG, nD)
+    finally:
+        if comm:
+            comm.close()
+        m.close()
+    with pytest.raises(Exception):
+        m2 = engine.NativeModel(ctx, "warp", 1, 64, 64, is_train=True)
+        try:
+            m2.step_dp([0.9, 0.8, 1.0])                            # detached again
+        finally:
+            m2.close()
+
+
+def _native_worker(rank, world, port, out_dir, stage, lambda_style):
+    sys.path.insert(0, REPO)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(2)
+    from oracle import swapnet_oracle as O
+    from swapnet_amd import engine, parallel
+    from tests import backends
+    parallel.init_from_env(backend="gloo")
+    ctx = backends.hostsim_ctx()
+    torch.manual_seed(0)
+    D = O.patchgan_params(22)
+    if stage == "warp":
+        G, full = O.warp_module_params(), O.synth_warp_batch(world, 64, 64, seed=1234)
+    else:
+        from tests.test_texture_step import vgg_state_dict
+        G, full = O.texture_module_params(img_size=64), O.synth_texture_batch(world, 64, 64, seed=77)
+        vgg = O.vgg16_feature_params()
+    lab = [0.9, 0.8, 1.0]
+    res = []
+    for mode in ("torch", "native"):
+        m = engine.NativeModel(ctx, stage, 1, 64, 64, is_train=True)
+        m.load_state_dict(0, G); m.load_state_dict(1, D)
+        if stage == "texture":
+            m.load_state_dict(2, vgg_state_dict(m, vgg))
+            m.set_hyper(grad_scale=1.0 / world, lambda_style=lambda_style)
+        else:
+            m.set_hyper(grad_scale=1.0 / world)
+        for i, t in enumerate(full):
+            m.set_input(i, t[rank:rank + 1])
+        comm = None
+        for step in range(2):
+            if mode == "torch":                  # the phased calls around torch.distributed collectives (GradExchange)
+                x = parallel.GradExchange(world)
+                m.forward(False, 0)
+                m.backward_D(lab[0], lab[1])
+                x.allreduce_mean(m.grad_arena(engine.NET_D))
+                m.optimizer_step(engine.NET_D)
+                if stage == "texture" and lambda_style != 0:
+                    parallel.gather_style_context(m, full[3][rank:rank + 1])
+                parallel.generator_backward_with_exchange(m, lab[2], x)
+            else:                                # one call, the library drives the attached all-reduce itself
+                comm = comm or parallel.NativeComm(ctx, backend="gloo")
+                if stage == "texture" and lambda_style != 0:
+                    m.forward(False, 0)
+                    parallel.gather_style_context(m, full[3][rank:rank + 1])
+                    m.step_dp(lab, training=False, seed=0, after_forward=True)
+                else:
+                    m.step_dp(lab, training=False, seed=0)
+        res.append((m.weight_arena(0).clone(), m.weight_arena(1).clone(), m.losses(), m.optim_step_count(0)))
+        if comm:
+            comm.close()
+        m.close()
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1]), "native exchange differs from the torch path"
+    assert res[0][2] == res[1][2] and res[0][3] == res[1][3] == 2
+    wsum = res[1][0].clone()
+    dist.all_reduce(wsum)
+    assert torch.equal(wsum / world, res[1][0])                       # replicas stay identical
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("stage,lambda_style", [("warp", 0.0), ("texture", 1e-8)])
+def test_two_rank_library_owned_exchange_equals_the_torch_path(tmp_path, stage, lambda_style):
+    """2 gloo ranks x 1 sample, two steps: swn_model_step_dp (exchange driven by the library through the attached all-reduce,
+    AdamW of a bucket behind its all-reduce) gives bitwise the weights of the phased torch.distributed path -- which
+    test_two_rank_gloo_step_equals_single_process_big_batch holds against the one-process big-batch step.  Texture stage with the
+    style term: forward by the caller, global-batch style context, then swn_model_step_dp(after_forward)."""
+    from tests import backends
+    backends.build_hostsim()
+    port = 33500 + os.getpid() % 2000 + (7 if stage == "texture" else 0)
+    mp.spawn(_native_worker, args=(2, port, str(tmp_path), stage, lambda_style), nprocs=2, join=True)
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(os.environ.get("SWAPNET_UNVERIFIED_GPU") != "1", reason="never run on the GPU yet (SWAPNET_UNVERIFIED_GPU=1 to include)")
+def test_one_rank_native_rccl_exchange_equals_the_fused_step():
+    """parallel.NativeComm(backend="rccl") at world size 1: ncclCommInitRank through ctypes on the RCCL the process holds, RCCL's own
+    ncclAllReduce driven by the library on its exchange stream (swn_model_step_dp), AdamW per bucket on that stream -- bit-identical
+    to swn_model_step over two training-mode steps.  Written without a GPU (round 4): opt-in until it has run once."""
+    from oracle import swapnet_oracle as O
+    from swapnet_amd import engine, parallel
+    from tests import backends
+    ctx = backends.gpu_ctx()
+    torch.manual_seed(1)
+    G, D = O.warp_module_params(), O.patchgan_params(22)
+    batch = O.synth_warp_batch(4, 128, 128, seed=11)
+    m = engine.NativeModel(ctx, "warp", 4, 128, 128, is_train=True)
+    comm = None
+    try:
+        out = []
+        for mode in ("fused", "native"):
+            backends.reset_state(m, {engine.NET_G: G, engine.NET_D: D})
+            for i, t in enumerate(batch):
+                m.set_input(i, t)
+            if mode == "native":
+                comm = parallel.NativeComm(ctx, backend="rccl")
+            for step in range(2):
+                (m.step if mode == "fused" else m.step_dp)([0.9, 0.8, 1.0], training=True, seed=5 + step)
+            out.append((m.losses(), m.weight_arena(0).clone().cpu(), m.weight_arena(1).clone().cpu(), m.optim_step_count(0)))
+        assert out[0][0] == out[1][0] and out[0][3] == out[1][3] == 2
+        assert torch.equal(out[0][1], out[1][1]) and torch.equal(out[0][2], out[1][2])
+    finally:
+        if comm:
+            comm.close()
+        m.close()
