@@ -259,6 +259,7 @@ def main():
         return [float(torch.rand(1, generator=label_rng) * 0.4 + 0.7) for _ in range(3)]
 
     step_no = [0]
+    native_comm = [parallel.NativeComm(ctx) if (parallel.native_comm_requested() and (world > 1 or rccl1)) else None]
 
     def one_step():
         lab = draw_labels()
@@ -266,6 +267,10 @@ def main():
         seed = step_no[0] * 1000 + rank
         if world == 1 and not os.environ.get("SWAPNET_BENCH_PHASED") and not rccl1:
             model.step(lab, training=True, seed=seed, captured=args.captured)
+            return
+        if native_comm[0] is not None:
+            # SWAPNET_NATIVE_COMM=1: the library drives RCCL's all-reduce itself (swn_model_step_dp; opt-in, see parallel.NativeComm)
+            model.step_dp(lab, training=True, seed=seed)
             return
         # (SWAPNET_BENCH_PHASED=1 runs this multi-GPU call sequence on one GPU, exchanges being no-ops, to
         # price the phased / bucketed form against the fused swn_model_step)
@@ -335,6 +340,8 @@ def main():
         "ranks": ([{"rank": rank, "device": torch.cuda.current_device(), "name": torch.cuda.get_device_name()}] if world == 1 else None),
         "rccl_version": _rccl_version(),
         "dist_backend": (dist.get_backend() if dist.is_initialized() else None),
+        "exchange": ("library-owned (swn_model_step_dp over the attached ncclAllReduce)" if native_comm[0] is not None
+                     else ("torch.distributed all_reduce per bucket" if (world > 1 or rccl1) else None)),
         "hbm_allocated_gb": round(ctx.bytes_allocated() / 1e9, 2),      # arenas + activations (+ 2 x 1 GB split workspaces)
     }
 

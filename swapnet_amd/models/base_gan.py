@@ -166,6 +166,19 @@ class BaseGAN(BaseModel, ABC):
         if self.world == 1:
             # SWAPNET_CAPTURED_STEP=1: the step as a recorded hipGraph (swn_model_step_captured; bit-identical results)
             m.step(labels, training=training, seed=seed, captured=os.environ.get("SWAPNET_CAPTURED_STEP") == "1")
+        elif parallel.native_comm_requested():
+            # SWAPNET_NATIVE_COMM=1: the library drives the exchange itself (swn_model_step_dp: RCCL's all-reduce on a stream and
+            # with events the library owns, AdamW of each bucket behind its all-reduce)
+            rank = torch.distributed.get_rank()
+            labels = parallel.broadcast_floats(labels)
+            if getattr(self, "_native_comm", None) is None:
+                self._native_comm = parallel.NativeComm(self.backend.ctx)
+            if self.KIND == "texture" and getattr(self.opt, "lambda_style", 0) != 0:
+                m.forward(training, seed + rank)
+                parallel.gather_style_context(m, self.targets)      # the style Gram spans the global batch
+                m.step_dp(labels, training=training, seed=seed + rank, after_forward=True)
+            else:
+                m.step_dp(labels, training=training, seed=seed + rank)
         else:
             rank = torch.distributed.get_rank()
             labels = parallel.broadcast_floats(labels)          # rank 0's smooth-label draws on every rank

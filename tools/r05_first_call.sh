@@ -1,0 +1,35 @@
+# Round 5, FIRST GPU call (≈ 12 GPU-minutes): everything round 4 wrote after its GPU budget was spent, before anything else is built on it.
+#   gpurun --timeout 1100 -- 'bash tools/r05_first_call.sh'
+# 1. the opt-in GPU tests (SWAPNET_UNVERIFIED_GPU=1): 256 x 128 tile of 64-row wave tiles (conv_fwd_pcm_kernel) against the shipped
+#    128 x 128 kernel; gradient penalty at PatchGAN depths 2 / 4; the library-owned exchange with real RCCL at world size 1
+# 2. smoke() + the default bench line (the product path did not change: same ISA for every shipped kernel, tools/isa_diff.py)
+# 3. same-box A/B, ms/step of C2: default | SWN_PC_MI=2 | native exchange at world 1 (SWAPNET_BENCH_RCCL1=1 with / without
+#    SWAPNET_NATIVE_COMM=1)
+# 4. kernel-trace of the SWN_PC_MI=2 run: conv_fwd_pcm_kernel vs conv_fwd_pc_kernel<4,4,2,4,2,true> average launch time
+# If (1) is green: drop the skipif marks of those tests; if SWN_PC_MI=2 wins in (3): make it the default for launches with
+# >= pcm_min_tiles() tiles (conv_gemm.hip conv_fwd) and re-record the routing digest.
+R=$GRAFT_REPO_ROOT
+O=$R/gpurun_out/r05first
+mkdir -p $O
+cd $R
+export SWAPNET_UNVERIFIED_GPU=1
+timeout 420 python -m pytest -m gpu -q -x \
+  "tests/test_ops.py::test_64_row_wave_tiles_match_the_128x128_ring_kernel" \
+  "tests/test_data_parallel.py::test_one_rank_native_rccl_exchange_equals_the_fused_step" \
+  "tests/test_gradient_penalty.py::test_gradient_penalty_at_other_patchgan_depths" \
+  -s > $O/t_unverified.log 2>&1; echo "unverified-tests rc $?" | tee -a $O/rc.txt
+tail -15 $O/t_unverified.log
+unset SWAPNET_UNVERIFIED_GPU
+timeout 120 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; echo "smoke rc $?" | tee -a $O/rc.txt
+timeout 300 python bench.py > $O/bench_default.json 2> $O/bench_default.err; echo "bench rc $?" | tee -a $O/rc.txt
+tail -c 600 $O/bench_default.json
+for V in "X=0" "SWN_PC_MI=2" "X=1" "SWN_PC_MI=2 SWN_PC_MI_MIN_TILES=256" "SWAPNET_BENCH_RCCL1=1" "SWAPNET_BENCH_RCCL1=1 SWAPNET_NATIVE_COMM=1"; do
+  env $V timeout 200 python bench.py --steps 15 --warmup 4 --no-cpu-baseline --no-roofline 2> $O/ab.err | tail -1 | \
+    python -c "import sys,json;d=json.loads(sys.stdin.read());print('$V', d['ms_per_step'], d['value'], d.get('exchange'))" >> $O/ab.txt
+done
+cat $O/ab.txt
+cd /tmp && export TMPDIR=/tmp
+SWN_PC_MI=2 SWN_OVERLAP=0 timeout 300 rocprofv3 --kernel-trace --stats -d $O/prof_mi2 -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline > $O/prof_mi2.log 2>&1
+cd $R
+python profiles/summarize_rocprof.py --out $O $O/prof_mi2 r05_mi2 > /dev/null 2>&1 || true
+grep -m6 'conv_fwd_pc' $O/rocprof_r05_mi2_kernel_stats.md
