@@ -155,7 +155,8 @@ int main(int argc, char** argv) {
   SW(swn_ctx_create(0, nullptr, 1, (size_t)1024 << 20, &ctx));
   SAY("ctx up at %.1f s\n", now() - t00);
 
-  if (!getenv("NATIVE_AB_SKIP_OPS")) {
+  const bool generic = argc > 5 && (!strcmp(argv[5], "bench") || !strcmp(argv[5], "ab"));
+  if (!getenv("NATIVE_AB_SKIP_OPS") && !generic) {
     int big = H >= 256;
     op_case(ctx, "k4s2 64->128 (body_down2 / PatchGAN model.2 shape)", 0, big ? 8 : 2, 64, big ? 128 : 16, 128, big ? 64 : 8);
     op_case(ctx, "k3 reflect 1024->1024 @16x16 (resblock: 36 Winograd planes, pair-form operand)", 1, big ? 32 : 1, big ? 1024 : 256, 16, big ? 1024 : 256, 16);
@@ -203,6 +204,53 @@ int main(int argc, char** argv) {
     SAY("step %-22s %8.3f ms/step  %8.1f img/s   (at %.1f s)\n", what, ms, B / ms * 1e3, now() - t00);
     return ms;
   };
+
+  // ---- generic modes for the next rounds' short GPU calls ----------------------------------------------------------------------
+  //   native_ab B H K rounds bench                      one line: ms/step of K steps after 5 warm-up steps, under the caller's environment
+  //                                                     (for switches a process reads once: `env SWN_X=1 native_ab 32 256 40 0 bench`)
+  //   native_ab B H K rounds ab "A=1 B=2" "C=3" ...     alternating blocks of K steps in ONE process: no switch | each configuration,
+  //                                                     `rounds` times (switches the library reads per launch / per step)
+  auto plain_steps = [&](int steps) {
+    SW(swn_ctx_sync(ctx));
+    double t0 = now();
+    for (int i = 0; i < steps; i++) SW(swn_model_step(m, labels, 1, ++seed));
+    SW(swn_ctx_sync(ctx));
+    return (now() - t0) * 1e3 / steps;
+  };
+  if (argc > 5 && !strcmp(argv[5], "bench")) {
+    plain_steps(5);
+    double ms = plain_steps(K);
+    say_losses(m, "bench");
+    SAY("bench %.3f ms/step %.1f img/s (B %d, %d x %d, %d steps)\n", ms, B / ms * 1e3, B, H, H, K);
+    SW(swn_model_destroy(m)); SW(swn_ctx_destroy(ctx));
+    return 0;
+  }
+  if (argc > 5 && !strcmp(argv[5], "ab")) {
+    std::vector<std::vector<std::pair<std::string, std::string>>> cfg(1);       // cfg[0] = no switch
+    for (int a = 6; a < argc; a++) {
+      std::vector<std::pair<std::string, std::string>> kv; std::string t = argv[a]; size_t p = 0;
+      while (p < t.size()) {
+        size_t e = t.find(' ', p); if (e == std::string::npos) e = t.size();
+        std::string tok = t.substr(p, e - p); size_t q = tok.find('=');
+        if (q != std::string::npos) kv.push_back({tok.substr(0, q), tok.substr(q + 1)});
+        p = e + 1;
+      }
+      cfg.push_back(kv);
+    }
+    std::vector<double> sum(cfg.size(), 0.0);
+    auto apply = [&](size_t c, bool on) { for (auto& kv : cfg[c]) { if (on) setenv(kv.first.c_str(), kv.second.c_str(), 1); else unsetenv(kv.first.c_str()); } };
+    for (size_t c = 0; c < cfg.size(); c++) { apply(c, true); plain_steps(3); apply(c, false); }       // every configuration warm
+    for (int r = 0; r < rounds; r++)
+      for (size_t c = 0; c < cfg.size(); c++) {
+        apply(c, true); double ms = plain_steps(K); apply(c, false); sum[c] += ms;
+        SAY("ab round %d  %-40s %8.3f ms/step\n", r, c ? argv[5 + c] : "(default)", ms);
+      }
+    say_losses(m, "ab");
+    for (size_t c = 0; c < cfg.size() && rounds; c++)
+      SAY("ab mean   %-40s %8.3f ms/step  %+.3f\n", c ? argv[5 + c] : "(default)", sum[c] / rounds, (sum[c] - sum[0]) / rounds);
+    SW(swn_model_destroy(m)); SW(swn_ctx_destroy(ctx));
+    return 0;
+  }
 
   // ---- 2. whole-step A/B -------------------------------------------------------------------------------------------------
   block("warm-up default", 1, 3);

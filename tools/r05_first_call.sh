@@ -1,3 +1,10 @@
+# (Round 4, third session: items 3 / 4 below are ANSWERED -- tools/native_ab.cpp ran the 64-row wave tiles (bit-equal, +0.59 ms/step:
+#  stays off) and the library-owned exchange with RCCL at world 1 from plain C++ (profiles/native_ab_r04.txt, native_diag_r04.txt).
+#  What is left for this call: the three opt-in PYTHON tests, smoke(), the default bench line, the native exchange through
+#  parallel.NativeComm.  For switch A/Bs use the torch-free driver: a C2 model is up in a second --
+#      tools/_bin/native_ab 32 256 20 3 ab "SWN_X=1" "SWN_Y=2 SWN_Z=0"       (alternating blocks in one process)
+#      env SWN_ONCE=1 tools/_bin/native_ab 32 256 40 0 bench                  (switches a process reads once)
+#  build: hipcc -O2 -std=c++17 tools/native_ab.cpp -Iinclude -Lswapnet_amd/csrc -lswapnet_hip -ldl -Wl,-rpath,'$ORIGIN/../../swapnet_amd/csrc' -o tools/_bin/native_ab)
 # Round 5, FIRST GPU call (≈ 12 GPU-minutes): everything round 4 wrote after its GPU budget was spent, before anything else is built on it.
 #   gpurun --timeout 1100 -- 'bash tools/r05_first_call.sh'
 # 1. the opt-in GPU tests (SWAPNET_UNVERIFIED_GPU=1): 256 x 128 tile of 64-row wave tiles (conv_fwd_pcm_kernel) against the shipped
