@@ -54,5 +54,25 @@ def build(force=False, verbose=True):
     return OUT
 
 
+def build_native_driver(verbose=True):
+    """tools/native_ab.cpp -> tools/_bin/native_ab: the torch-free C++ driver of the C-ABI (no Python in the process: a C2 model is
+    up a second after exec, which is what short GPU calls need).  Links the in-tree library by relative rpath, so the binary
+    travels with a snapshot like the .so does."""
+    repo = os.path.dirname(HERE)
+    src = os.path.join(repo, "tools", "native_ab.cpp")
+    out = os.path.join(repo, "tools", "_bin", "native_ab")
+    if not os.path.exists(src):
+        return None
+    if _newer(out, [src, OUT, os.path.join(repo, "include", "swapnet_hip.h")]):
+        os.makedirs(os.path.dirname(out), exist_ok=True)
+        cmd = [os.environ.get("HIPCC", "/opt/rocm/bin/hipcc"), "-O2", "-std=c++17", src, "-I" + os.path.join(repo, "include"), "-L" + CSRC,
+               "-lswapnet_hip", "-ldl", "-Wl,-rpath,$ORIGIN/../../swapnet_amd/csrc", "-o", out]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    return out
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv))
+    print(build_native_driver())
