@@ -16,10 +16,31 @@
 #include "../../swapnet_amd/csrc/ops.h"
 
 namespace swn {
+// SWN_SIM_TIMES=1: wall time per simulated operator, printed at exit (where does a CPU-suite step go?)
+struct SimTimes {
+  struct Row { const char* name; double s; long calls; };
+  std::vector<Row> rows;
+  bool on = getenv("SWN_SIM_TIMES") != nullptr;
+  int slot(const char* n) { for (size_t i = 0; i < rows.size(); ++i) if (rows[i].name == n) return (int)i; rows.push_back({n, 0.0, 0}); return (int)rows.size() - 1; }
+  ~SimTimes() {
+    if (!on) return;
+    double tot = 0; for (auto& r : rows) tot += r.s;
+    for (auto& r : rows) fprintf(stderr, "[sim-times] %-34s %8.3f s %7ld calls %5.1f %%\n", r.name, r.s, r.calls, 100.0 * r.s / (tot + 1e-30));
+  }
+};
+static SimTimes g_sim_times;
+struct SimTimer {
+  int i = -1; double t0 = 0;
+  static double now() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
+  explicit SimTimer(const char* n) { if (g_sim_times.on) { i = g_sim_times.slot(n); t0 = now(); } }
+  ~SimTimer() { if (i >= 0) { g_sim_times.rows[i].s += now() - t0; g_sim_times.rows[i].calls++; } }
+};
+#define SIM_TIMED SimTimer sim_timer_(__func__)
+
 
 void* dev_alloc(size_t bytes) { if (!bytes) bytes = 16; void* p = std::calloc(1, bytes); if (!p) throw Error(2, "hostsim: out of memory"); return p; }
 void dev_free(void* p) { std::free(p); }
-void dev_memset(Stream&, void* p, int v, size_t bytes) { std::memset(p, v, bytes); }
+void dev_memset(Stream&, void* p, int v, size_t bytes) { SIM_TIMED; std::memset(p, v, bytes); }
 void dev_copy(Stream&, void* d, const void* s, size_t b) { std::memcpy(d, s, b); }
 void dev_upload(Stream&, void* d, const void* s, size_t b) { std::memcpy(d, s, b); }
 void dev_download(Stream&, void* d, const void* s, size_t b) { std::memcpy(d, s, b); }
@@ -196,9 +217,16 @@ static void sim_store_panel(const float* w, int K, int Npad, int bn, uint16_t* o
 // device's stream scratch gives them -- and CHECKS a handed-in pointer against the source it is now claimed to bound
 static float g_sim_wamax[AMAX_SLOT];
 static int g_sim_wamax_owner = 0, g_sim_wamax_handed = -1;   // bumped by every pass: a stale hand-over (another pass in between) is an engine bug
-static void sim_weight_amax(const float* src, size_t rows, int C, int batch, size_t bs, const float** amax_io, const char* what) {
+static void sim_weight_amax(const float* src, size_t rows, int C, int batch, size_t bs, const float** amax_io, const char* what) { SIM_TIMED;
   float actual = 0.f;
-  for (int b = 0; b < batch; ++b) actual = std::max(actual, [&] { float m = 0.f; for (size_t i = 0; i < rows * (size_t)C; ++i) m = std::max(m, std::fabs(src[(size_t)b * bs + i])); return m; }());
+  for (int b = 0; b < batch; ++b) {
+    const float* sp = src + (size_t)b * bs;
+    const long n = (long)(rows * (size_t)C);
+    float m = 0.f;
+#pragma omp parallel for reduction(max : m)
+    for (long i = 0; i < n; ++i) m = std::max(m, std::fabs(sp[i]));
+    actual = std::max(actual, m);
+  }
   if (amax_io && *amax_io) {
     if (*amax_io != g_sim_wamax || g_sim_wamax_handed != g_sim_wamax_owner)
       throw Error(1, std::string("hostsim ") + what + ": handed-in weight amax is not the last pass's (another pass reused the scratch)");
@@ -212,7 +240,7 @@ static void sim_weight_amax(const float* src, size_t rows, int C, int batch, siz
   ++g_sim_wamax_owner;
   if (amax_io) { *amax_io = g_sim_wamax; g_sim_wamax_handed = g_sim_wamax_owner; }
 }
-void conv_precut(Stream&, const float* w, int K, int Npad, int bn, int batch, size_t w_bs, uint16_t* out, const float** amax_io) {
+void conv_precut(Stream&, const float* w, int K, int Npad, int bn, int batch, size_t w_bs, uint16_t* out, const float** amax_io) { SIM_TIMED;
   if (K % 16 || (bn != 64 && bn != 128 && bn != 192)) throw Error(1, "conv_precut: K must be a multiple of 16, tile 64, 128 or 192");
   sim_weight_amax(w, (size_t)K, Npad, batch, w_bs, amax_io, "conv_precut");
   const size_t pe = conv_precut_elems(K, Npad, bn);
@@ -224,7 +252,7 @@ void conv_precut(Stream&, const float* w, int K, int Npad, int bn, int batch, si
 }
 static void wino_filter_transform_strided(int m, int r, const WShape& w, int mode, const float* packed, float* U, size_t total);
 void wino_filter_transform_pc(Stream&, int m, int r, const WShape& w, int mode, const float* packed, int bn, uint16_t* out,
-                              size_t panel_elems, const float** amax_io) {
+                              size_t panel_elems, const float** amax_io) { SIM_TIMED;
   sim_weight_amax(packed, (size_t)r * r * w.Cip, w.Npad, 1, 0, amax_io, "wino_filter_transform_pc");
   const int K = mode == 0 ? w.Cip : w.Npad, Nn = mode == 0 ? w.Npad : w.Cip;
   if (K % 16 || (bn != 64 && bn != 128)) throw Error(1, "wino_filter_transform_pc: K must be a multiple of 16, tile 64 or 128");
@@ -257,6 +285,7 @@ void conv_fwd(Stream& s, const ConvFwdArgs& a) {
     sim_fold_view(a.y_amax, a.y);
     return;
   }
+  SIM_TIMED;
   if (a.x_amax) {
     const int nbb = a.phases ? 1 : (a.batch > 0 ? a.batch : 1);
     sim_slot_check(a.x_amax, a.x.p, (size_t)a.x.N * a.x.H * a.x.W, a.x.C, (size_t)a.x.cs, nbb, a.x_bs, "conv_fwd");
@@ -369,7 +398,7 @@ static void conv_wgrad_one(const ConvWgradArgs& a) {
       for (int co = 0; co < a.Npad; ++co) o[co] = (float)acc[co];
     }
 }
-void conv_wgrad(Stream& s, const ConvWgradArgs& a) {
+void conv_wgrad(Stream& s, const ConvWgradArgs& a) { SIM_TIMED;
   if (a.x_amax || a.dy_amax) {
     const int nbb = a.phases ? 1 : (a.batch > 0 ? a.batch : 1);
     sim_slot_check(a.x_amax, a.x.p, (size_t)a.x.N * a.x.H * a.x.W, a.x.C, (size_t)a.x.cs, nbb, a.x_bs, "conv_wgrad x");
@@ -472,27 +501,58 @@ static void wino_input_transform_impl(int m, int r, const TView& x, int pad, int
 }
 static void wino_filter_transform_strided(int m, int r, const WShape& w, int mode, const float* packed, float* U, size_t total) {
   // total = floats between consecutive transform-point planes (K * Nn when dense)
+  // Weight-sized work (36 planes of 1024 x 1024 for a resblock conv, both directions, every step): it was 1/3 of the simulator's
+  // step time as a scalar loop with stride-Npad reads in the transposed modes.  Same arithmetic per element, in the same order
+  // (bit-identical results); the tap planes of the transposed modes are transposed once (blocked), and 64 columns go through the
+  // two small products together so that the compiler can keep them in vector registers.
   const WinoMats wm = wino_mats(m, r);
   const int A = wm.A, R = wm.r;
   const int K = mode == 0 ? w.Cip : w.Npad, Nn = mode == 0 ? w.Npad : w.Cip;
+  std::vector<float> tr;
+  const float* src = packed;                       // [tap][K][Nn] from here on
+  if (mode != 0) {
+    tr.resize((size_t)R * R * K * Nn);
+    const int TB = 32;
+#pragma omp parallel for collapse(3)
+    for (int t = 0; t < R * R; ++t) for (int k0 = 0; k0 < K; k0 += TB) for (int n0 = 0; n0 < Nn; n0 += TB) {
+      const int a = t / R, b = t % R;
+      const int st = mode == 1 ? (R - 1 - a) * R + (R - 1 - b) : t;
+      const float* sp = packed + (size_t)st * w.Cip * w.Npad;         // [n][k]
+      float* dp = tr.data() + (size_t)t * K * Nn;                     // [k][n]
+      const int k1 = std::min(K, k0 + TB), n1 = std::min(Nn, n0 + TB);
+      for (int n = n0; n < n1; ++n) for (int k = k0; k < k1; ++k) dp[(size_t)k * Nn + n] = sp[(size_t)n * w.Npad + k];
+    }
+    src = tr.data();
+  }
+  const int NB = 64;
 #pragma omp parallel for
-  for (int k = 0; k < K; ++k) for (int n = 0; n < Nn; ++n) {
-    float g[4][4], t[6][4];
-    for (int a = 0; a < R; ++a) for (int b = 0; b < R; ++b)
-      g[a][b] = mode == 0 ? packed[((size_t)(a * R + b) * w.Cip + k) * w.Npad + n]
-              : mode == 1 ? packed[((size_t)((R - 1 - a) * R + (R - 1 - b)) * w.Cip + n) * w.Npad + k]
-                          : packed[((size_t)(a * R + b) * w.Cip + n) * w.Npad + k];
-    for (int a = 0; a < A; ++a) for (int b = 0; b < R; ++b) { float s = 0; for (int q = 0; q < R; ++q) s += wm.G[a * R + q] * g[q][b]; t[a][b] = s; }
-    for (int a = 0; a < A; ++a) for (int b = 0; b < A; ++b) { float s = 0; for (int q = 0; q < R; ++q) s += t[a][q] * wm.G[b * R + q];
-      U[(size_t)(a * A + b) * total + (size_t)k * Nn + n] = s; }
+  for (int k = 0; k < K; ++k) for (int n0 = 0; n0 < Nn; n0 += NB) {
+    const int nb = std::min(NB, Nn - n0);
+    float g[4][4][NB], t[6][4][NB];
+    for (int a = 0; a < R; ++a) for (int b = 0; b < R; ++b) {
+      const float* sp = src + ((size_t)(a * R + b) * K + k) * Nn + n0;
+      for (int j = 0; j < nb; ++j) g[a][b][j] = sp[j];
+    }
+    for (int a = 0; a < A; ++a) for (int b = 0; b < R; ++b) {
+      float* tp = t[a][b];
+      for (int j = 0; j < nb; ++j) tp[j] = 0.f;
+      for (int q = 0; q < R; ++q) { const float c = wm.G[a * R + q]; const float* gp = g[q][b]; for (int j = 0; j < nb; ++j) tp[j] += c * gp[j]; }
+    }
+    for (int a = 0; a < A; ++a) for (int b = 0; b < A; ++b) {
+      float acc[NB];
+      for (int j = 0; j < nb; ++j) acc[j] = 0.f;
+      for (int q = 0; q < R; ++q) { const float c = wm.G[b * R + q]; const float* tp = t[a][q]; for (int j = 0; j < nb; ++j) acc[j] += tp[j] * c; }
+      float* up = U + (size_t)(a * A + b) * total + (size_t)k * Nn + n0;
+      for (int j = 0; j < nb; ++j) up[j] = acc[j];
+    }
   }
 }
-void wino_filter_transform(Stream&, int m, int r, const WShape& w, int mode, const float* packed, float* U) {
+void wino_filter_transform(Stream&, int m, int r, const WShape& w, int mode, const float* packed, float* U) { SIM_TIMED;
   const int K = mode == 0 ? w.Cip : w.Npad, Nn = mode == 0 ? w.Npad : w.Cip;
   wino_filter_transform_strided(m, r, w, mode, packed, U, (size_t)K * Nn);
 }
 void wino_output_transform(Stream&, int m, int r, const float* M, int Cm, int Th, int Tw, const float* bias, int act,
-                           const TView& y, int Cout, int accumulate) {
+                           const TView& y, int Cout, int accumulate) { SIM_TIMED;
   const WinoMats wm = wino_mats(m, r);
   const int A = wm.A;
   const size_t T = (size_t)y.N * Th * Tw;
@@ -538,7 +598,7 @@ static void wino_dy_transform_impl(int m, int r, const TView& dy, int Th, int Tw
 }
 // ---- folded tail conv in Winograd form (ops.h tailw_*): plain loops
 static size_t tailw_off(int Cip, int Npad, int ph) { static const int pre[4] = {0, 4, 10, 16}; return (size_t)pre[ph] * Cip * Npad; }
-void tailw_filter_transform(Stream&, const WShape& w, const float* folded, float* U) {
+void tailw_filter_transform(Stream&, const WShape& w, const float* folded, float* U) { SIM_TIMED;
   const WinoMats wm = wino_mats(4, 3);
   const int A = 6, R = 3, N4 = 4 * w.Npad;
   const size_t total = (size_t)w.Cip * N4;
@@ -553,7 +613,7 @@ void tailw_filter_transform(Stream&, const WShape& w, const float* folded, float
       U[(size_t)(r * A + j) * total + (size_t)ci * N4 + n] = s; }
   }
 }
-void tailw_filter_grad(Stream&, const WShape& w, const float* dU, float* dfolded) {
+void tailw_filter_grad(Stream&, const WShape& w, const float* dU, float* dfolded) { SIM_TIMED;
   const WinoMats wm = wino_mats(4, 3);
   const int A = 6, R = 3, N4 = 4 * w.Npad;
   const size_t total = (size_t)w.Cip * N4;
@@ -662,7 +722,7 @@ static size_t s2_widx(const WShape& w, int kh, int kw, int cf, int cc) {
   const int a = (3 - kh) & 1, dy = (3 - kh - a) >> 1, b = (3 - kw) & 1, dx = (3 - kw - b) >> 1;
   return (size_t)(a * 2 + b) * 4 * w.Cip * w.Npad + ((size_t)(dy * 2 + dx) * w.Cip + cc) * w.Npad + cf;
 }
-void wino_s2_filter_transform(Stream&, const WShape& w, int mode, const float* packed, float* U) {
+void wino_s2_filter_transform(Stream&, const WShape& w, int mode, const float* packed, float* U) { SIM_TIMED;
   const WinoMats wm = wino_mats(4, 2);
   const int A = 5, Cf = w.kind == WK_CONV ? w.Cip : w.Npad, Cc = w.kind == WK_CONV ? w.Npad : w.Cip;
   const size_t plane = (size_t)4 * Cf * Cc;
@@ -676,7 +736,7 @@ void wino_s2_filter_transform(Stream&, const WShape& w, int mode, const float* p
     for (int a = 0; a < A; ++a) for (int b = 0; b < A; ++b) U[(size_t)(a * A + b) * plane + o] = u[a][0] * wm.G[b * 2] + u[a][1] * wm.G[b * 2 + 1];
   }
 }
-void wino_s2_filter_grad(Stream&, const WShape& w, const float* dU, float* dpacked) {
+void wino_s2_filter_grad(Stream&, const WShape& w, const float* dU, float* dpacked) { SIM_TIMED;
   const WinoMats wm = wino_mats(4, 2);
   const int A = 5, Cf = w.kind == WK_CONV ? w.Cip : w.Npad, Cc = w.kind == WK_CONV ? w.Npad : w.Cip;
   const size_t plane = (size_t)4 * Cf * Cc;
@@ -692,7 +752,7 @@ void wino_s2_filter_grad(Stream&, const WShape& w, const float* dU, float* dpack
   }
 }
 // adjoint of wino_input_transform as a plain scatter over (tile, a, b): the second opinion on the HIP gather kernel
-void wino_input_adjoint(Stream&, int m, int r, float* dV, int C, int pad, int pad_mode, int Th, int Tw, const TView& dx, int accumulate) {
+void wino_input_adjoint(Stream&, int m, int r, float* dV, int C, int pad, int pad_mode, int Th, int Tw, const TView& dx, int accumulate) { SIM_TIMED;
   const WinoMats wm = wino_mats(m, r);
   const int A = wm.A;
   const size_t T = (size_t)dx.N * Th * Tw;
@@ -718,17 +778,29 @@ void wino_input_adjoint(Stream&, int m, int r, float* dV, int C, int pad, int pa
     }
   }
 }
-void wino_filter_grad(Stream&, int m, int r, const WShape& w, const float* dU, float* dpacked) {
+void wino_filter_grad(Stream&, int m, int r, const WShape& w, const float* dU, float* dpacked) { SIM_TIMED;
+  // dg = G^T dU G per (ci, co) pair; 64 pairs at a time (the 36 plane values of a pair are 36 separate streams), the sum of a
+  // tap in the original order: p-major, q-minor, (G[p][a] * dU) * G[q][b]
   const WinoMats wm = wino_mats(m, r);
   const int A = wm.A, R = wm.r;
   const size_t total = (size_t)w.Cip * w.Npad;
+  const long NB = 64;
 #pragma omp parallel for
-  for (long i = 0; i < (long)total; ++i)
-    for (int a = 0; a < R; ++a) for (int b = 0; b < R; ++b) {       // dg = G^T dU G
-      float s = 0;
-      for (int p = 0; p < A; ++p) for (int q = 0; q < A; ++q) s += wm.G[p * R + a] * dU[(size_t)(p * A + q) * total + i] * wm.G[q * R + b];
-      dpacked[(size_t)(a * R + b) * total + i] = s;
+  for (long i0 = 0; i0 < (long)total; i0 += NB) {
+    const int nb = (int)std::min<long>(NB, (long)total - i0);
+    float d[36][NB];
+    for (int pq = 0; pq < A * A; ++pq) { const float* sp = dU + (size_t)pq * total + i0; for (int j = 0; j < nb; ++j) d[pq][j] = sp[j]; }
+    for (int a = 0; a < R; ++a) for (int b = 0; b < R; ++b) {
+      float acc[NB];
+      for (int j = 0; j < nb; ++j) acc[j] = 0.f;
+      for (int p = 0; p < A; ++p) for (int q = 0; q < A; ++q) {
+        const float ga = wm.G[p * R + a], gb = wm.G[q * R + b]; const float* dp = d[p * A + q];
+        for (int j = 0; j < nb; ++j) acc[j] += ga * dp[j] * gb;
+      }
+      float* op = dpacked + (size_t)(a * R + b) * total + i0;
+      for (int j = 0; j < nb; ++j) op[j] = acc[j];
     }
+  }
 }
 
 void bias_grad(Stream&, const TView& dy, float* db) {
@@ -789,7 +861,7 @@ void pool_pattern(Stream&, const TView& x, const TView& y, uint8_t* out) {
         }
 }
 
-void norm_act_fwd(Stream&, const NormActArgs& a0) {
+void norm_act_fwd(Stream&, const NormActArgs& a0) { SIM_TIMED;
   NormActArgs a = a0;
   if (a.seed_base) a.seed = *a.seed_base * 0x9E3779B1ull + a.salt;       // captured-step form of the seed (ops.h)
   const int N = a.x.N, HW = a.x.H * a.x.W, C = a.x.C;
@@ -814,7 +886,7 @@ void norm_act_fwd(Stream&, const NormActArgs& a0) {
     }
   sim_fold_view(a.amax_out, a.y);
 }
-void norm_act_bwd(Stream&, const NormActBwdArgs& a0) {
+void norm_act_bwd(Stream&, const NormActBwdArgs& a0) { SIM_TIMED;
   NormActBwdArgs a = a0;
   if (a.seed_base) a.seed = *a.seed_base * 0x9E3779B1ull + a.salt;
   const int N = a.x.N, HW = a.x.H * a.x.W, C = a.x.C;
@@ -1183,7 +1255,7 @@ void adamw_schedule(float lr, float beta1, float beta2, int step, float out[2]) 
   const double bc1 = 1.0 - std::pow((double)beta1, step), bc2 = 1.0 - std::pow((double)beta2, step);
   out[0] = (float)(lr / bc1); out[1] = (float)(1.0 / std::sqrt(bc2));
 }
-void adamw_step(Stream&, const AdamWArgs& a) {  // (elementwise: threads split the arena)
+void adamw_step(Stream&, const AdamWArgs& a) { SIM_TIMED;  // (elementwise: threads split the arena)
   float sched[2];
   adamw_schedule(a.lr, a.beta1, a.beta2, a.step, sched);
   if (a.sched_dev) { sched[0] = a.sched_dev[0]; sched[1] = a.sched_dev[1]; }
@@ -1201,7 +1273,7 @@ size_t packed_elems(const WShape& w) {
   return w.kind == WK_CONV ? (size_t)w.KH * w.KW * w.Cip * w.Npad : (size_t)16 * w.Cip * w.Npad;
 }
 static int refch(const WShape& w, int cb) { return w.cimap ? w.cimap[cb] : (cb < w.Ci ? cb : -1); }
-void pack_weight(Stream&, const WShape& w, const float* src, float* dst) {
+void pack_weight(Stream&, const WShape& w, const float* src, float* dst) { SIM_TIMED;
   std::memset(dst, 0, packed_elems(w) * sizeof(float));
 #pragma omp parallel for
   for (int cb = 0; cb < w.Cip; ++cb) {
@@ -1218,7 +1290,7 @@ void pack_weight(Stream&, const WShape& w, const float* src, float* dst) {
     }
   }
 }
-void unpack_weight(Stream&, const WShape& w, const float* src, float* dst) {
+void unpack_weight(Stream&, const WShape& w, const float* src, float* dst) { SIM_TIMED;
 #pragma omp parallel for
   for (int cb = 0; cb < w.Cip; ++cb) {
     const int ci = refch(w, cb);
@@ -1265,7 +1337,7 @@ size_t dgrad_elems(const WShape& w, int mode, int Cop, int Ndg) {
                   case 2: return (size_t)16 * Cop * Ndg; default: return (size_t)25 * Cop * Ndg; }
 }
 // source-indexed scatter (the HIP kernel is destination-indexed)
-void repack_dgrad(Stream&, const WShape& w, int mode, int Cop, int Ndg, const float* src, float* dg) {
+void repack_dgrad(Stream&, const WShape& w, int mode, int Cop, int Ndg, const float* src, float* dg) { SIM_TIMED;
   std::memset(dg, 0, dgrad_elems(w, mode, Cop, Ndg) * sizeof(float));
   auto W = [&](int ky, int kx, int ci, int co) -> float {
     if (w.kind == WK_CONV) return src[((size_t)(ky * w.KW + kx) * w.Cip + ci) * w.Npad + co];
@@ -1273,6 +1345,9 @@ void repack_dgrad(Stream&, const WShape& w, int mode, int Cop, int Ndg, const fl
     return src[((size_t)(a * 2 + b) * 4 * w.Cip + (dy * 2 + dx) * w.Cip + ci) * w.Npad + co];
   };
   // (Ndg < Cip: the operand of an input gradient formed for the leading channels only, ops.h repack_dgrad)
+  // (modes 0-2 are permutations: every element has its own destination, the taps can go to different threads; the tail's folded
+  // taps overlap -- serial, and small)
+#pragma omp parallel for collapse(2) if (mode != 3)
   for (int ky = 0; ky < w.KH; ++ky) for (int kx = 0; kx < w.KW; ++kx) for (int ci = 0; ci < std::min(w.Cip, Ndg); ++ci) for (int co = 0; co < w.Co; ++co) {
     const float v = W(ky, kx, ci, co);
     if (mode == 0) {          // dX[2i+a] += dY[i + a - 1 + dy] * W[3 - a - 2dy]
@@ -1362,14 +1437,14 @@ static void sim_pair_round(float* P, size_t n, const float* in_amax, float gain,
   }
 }
 void wino_input_transform(Stream&, int m, int r, const TView& x, int pad, int pad_mode, int Th, int Tw, float* V, float* amax_out,
-                          const float* in_amax, int* kscale_out) {
+                          const float* in_amax, int* kscale_out) { SIM_TIMED;
   wino_input_transform_impl(m, r, x, pad, pad_mode, Th, Tw, V);
   const int A = m + r - 1;
   const size_t n = (size_t)A * A * x.N * Th * Tw * x.C;
   if (in_amax) { sim_pair_round(V, n, in_amax, 100.f, kscale_out, x, "wino_input_transform"); return; }
   if (amax_out && !(m == 2 && r == 3)) sim_slot_fold(amax_out, sim_amax(V, n));
 }
-void wino_dy_transform(Stream&, int m, int r, const TView& dy, int Th, int Tw, float* dM, float* amax_out, const float* in_amax, int* kscale_out) {
+void wino_dy_transform(Stream&, int m, int r, const TView& dy, int Th, int Tw, float* dM, float* amax_out, const float* in_amax, int* kscale_out) { SIM_TIMED;
   wino_dy_transform_impl(m, r, dy, Th, Tw, dM);
   const int A = m + r - 1;
   const size_t n = (size_t)A * A * dy.N * Th * Tw * dy.C;
