@@ -184,6 +184,61 @@ def bench_infer(args):
     print(json.dumps(out), flush=True)
 
 
+def bench_joint(args):
+    """BASELINE.json config C5's shape on ONE GPU: both G/D pairs in one process -- the warp stage at DeepFashion's 4:3 (256 x 192)
+    and the texture stage at the square crop (its U-Net depth follows a square img_size: SURVEY.md section 5 caveat), bs 16 each,
+    training mode, alternating swn_model_step (or swn_model_step_captured with --captured) on one context.  Not the headline
+    (that is C2); the parity side of this configuration is tests/test_joint_step.py.  A "step" = one optimize_parameters of EACH
+    model; value = images through both stages per second."""
+    from swapnet_amd import engine, synthetic
+    from swapnet_amd.modules import init_tensor
+    torch.cuda.set_device(0)
+    ctx = engine.Context(device=0, workspace_mb=1024)
+    B = 16 if args.batch == 32 else args.batch
+    H, W, S = args.size, args.size * 3 // 4, args.size
+    warp = engine.NativeModel(ctx, "warp", B, H, W, is_train=True, dropout=0.5)
+    tex = engine.NativeModel(ctx, "texture", B, S, S, is_train=True, dropout=0.5)
+    torch.manual_seed(0)
+    for m, nets in ((warp, (engine.NET_G, engine.NET_D)), (tex, (engine.NET_G, engine.NET_D, engine.NET_VGG))):
+        for net in nets:
+            m.load_state_dict(net, {n: (torch.zeros(sh) if n.endswith(".bias") else init_tensor(torch.empty(sh), "kaiming"))
+                                    for n, sh in m.param_infos(net).items()})
+        m.set_hyper()
+    synthetic.fill_inputs(warp, "warp", B, H, W, seed=1234)
+    synthetic.fill_inputs(tex, "texture", B, S, S, seed=1235)
+    rng = torch.Generator().manual_seed(4321)
+    n = [0]
+
+    def one_step():
+        n[0] += 1
+        for m, salt in ((warp, 0), (tex, 500)):
+            lab = [float(torch.rand(1, generator=rng) * 0.4 + 0.7) for _ in range(3)]
+            m.step(lab, training=True, seed=n[0] * 1000 + salt, captured=args.captured)
+
+    for _ in range(args.warmup):
+        one_step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one_step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    ms = dt / args.steps * 1e3
+    lw, lt = warp.losses(), tex.losses()
+    out = {"metric": "images/sec, joint warp + texture G+D steps (both GAN pairs in one process), 256x192 / 256x256, bs=16/GPU",
+           "value": round(B * args.steps / dt, 3), "unit": "images/sec", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+           "data": "synthetic",
+           "config": {"workload": f"BASELINE.json C5's shape on one GPU: warp-stage step at {H}x{W} then texture-stage step at {S}x{S} "
+                                  f"(12 ROIs, L1 + VGG16 content + style), bs {B} each, train mode, fp32 storage, same kernels and "
+                                  f"arithmetic as the C2 / C3 lines; one step = one optimize_parameters of each model",
+                      "step_form": "hipGraph replay (swn_model_step_captured)" if args.captured else "eager launches",
+                      "global_batch": B, "parallelism": "dp1"},
+           "losses_finite": all(v == v and abs(v) < 1e30 for v in list(lw.values()) + list(lt.values())),
+           "hbm_allocated_gb": round(ctx.bytes_allocated() / 1e9, 2)}
+    print(json.dumps(out), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -191,7 +246,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=32, help="per-GPU batch (config C2: 32)")
     ap.add_argument("--size", type=int, default=256)
-    ap.add_argument("--stage", choices=("warp", "texture", "infer"), default="warp",
+    ap.add_argument("--stage", choices=("warp", "texture", "infer", "joint"), default="warp",
                     help="warp = config C2 (the headline metric); texture = config C3 (256x256, bs 16, ROIs, "
                          "perceptual + style losses on), reported for reference")
     ap.add_argument("--precision", choices=("f32", "f16"), default="f32",
@@ -214,6 +269,8 @@ def main():
         PEAK_PC_TFLOPS = PEAK_BF16_MFMA_TFLOPS
     if args.stage == "infer":
         return bench_infer(args)
+    if args.stage == "joint":           # BASELINE.json C5's shape on one GPU (never the headline)
+        return bench_joint(args)
 
     from swapnet_amd import engine, parallel, synthetic
     from swapnet_amd.modules import init_tensor

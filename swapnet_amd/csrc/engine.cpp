@@ -272,6 +272,17 @@ TView plane_mat(float* p, size_t T, int C) {
 
 // ---- Conv2d ---------------------------------------------------------------------------
 // y.v receives act(conv(x)+bias).  In backward y.g is the gradient w.r.t. that output.
+// Column tile of a pre-cut operand written by the 6-point FILTER TRANSFORM (ops.h wino_filter_transform_pc): that kernel lays out
+// tiles of 64 or 128 columns only.  conv_precut_tile answers 192 for widths in (128, 192] (the tile of the tail conv's input
+// gradient, produced by conv_precut) -- a stride-1 Winograd layer of such a width keeps its fp32 U and the kernels that read it,
+// and with them fp32 planes: planning and launch agree instead of failing at the first operand refresh (latent: no network of
+// the reference has a 3x3 / 4x4 stride-1 conv between 129 and 192 channels; swn_op_conv can ask for one).
+static int wino_precut_tile(int xC, int Npad) {
+  const int t = conv_precut_tile(xC, Npad);
+  return (t == 64 || t == 128) ? t : 0;
+}
+static bool wino_fwd_takes_pairs(int xC, int Npad) { return wino_precut_tile(xC, Npad) != 0 && conv_fwd_takes_pairs(xC, Npad); }
+
 void Net::conv(const std::string& name, const Var& x, const Var& y, ConvKind kind, int Ci, int Co, bool bias,
                int actf, const std::vector<int32_t>* cimap, bool x_is_input, int dgrad_C) {
   const int KH = (kind == CK_K3S1_REFLECT || kind == CK_K3S1_ZERO) ? 3 : 4;
@@ -585,7 +596,7 @@ void Net::conv(const std::string& name, const Var& x, const Var& y, ConvKind kin
   if (wino && keep_wino_inputs && y.has_grad) keepV = static_cast<float*>(ctx.alloc((size_t)wP * wT * Cip * sizeof(float)));
   // 6-point forms: the transformed filters go straight into the pre-cut operand layout of the ring kernel (no fp32 U)
   static const int wino_pc = getenv("SWN_WINO_PC") ? atoi(getenv("SWN_WINO_PC")) : 1;
-  const int pcw = (wino && wm != 2 && wino_pc) ? conv_precut_tile(Cip, Cop) : 0;
+  const int pcw = (wino && wm != 2 && wino_pc) ? wino_precut_tile(Cip, Cop) : 0;
   const size_t pcw_bs = pcw ? conv_precut_elems(Cip, Cop, pcw) : 0;
   size_t pcw_off = 0, pcwt_off = 0;
   int pcwt = 0;
@@ -597,9 +608,9 @@ void Net::conv(const std::string& name, const Var& x, const Var& y, ConvKind kin
   // pair-form planes (ops.h wino_input_transform): V feeds the forward GEMM and the weight gradient, dM the weight gradient and
   // the adjoint-form input gradient, dX (transposed-conv form of the input gradient) its one GEMM
   const bool wgrad_pairs = wslots && conv_wgrad_takes_pairs(wT, Cip, Cop);
-  const bool pairV_ok = wslots && conv_fwd_takes_pairs(Cip, Cop) && (!y.has_grad || wgrad_pairs);
-  const bool pairD_ok = wslots && wgrad_pairs && (!(wadj && x.has_grad && y.has_grad) || conv_fwd_takes_pairs(Cop, Cip));
-  const bool pairX_ok = wslots && conv_fwd_takes_pairs(Cop, Cip);
+  const bool pairV_ok = wslots && wino_fwd_takes_pairs(Cip, Cop) && (!y.has_grad || wgrad_pairs);
+  const bool pairD_ok = wslots && wgrad_pairs && (!(wadj && x.has_grad && y.has_grad) || wino_fwd_takes_pairs(Cop, Cip));
+  const bool pairX_ok = wslots && wino_fwd_takes_pairs(Cop, Cip);
   const size_t kV = wslots ? reserve_k() : 0, kD = wslots ? reserve_k() : 0, kX = wslots ? reserve_k() : 0;
   float* keepdM = nullptr;        // dM = A dY A^T, shared by the weight gradient (side stream) and the adjoint-form input gradient
   if (wino && wadj && y.has_grad && x.has_grad && share_dy()) keepdM = static_cast<float*>(ctx.alloc((size_t)wP * wT * Cop * sizeof(float)));
@@ -689,7 +700,7 @@ void Net::conv(const std::string& name, const Var& x, const Var& y, ConvKind kin
   const Var xg_target = narrow_dx ? x.slice(0, Ndg) : x;
   if (want_dx) {
     if (wino) {
-      pcwt = (wm != 2 && wino_pc) ? conv_precut_tile(Cop, Cip) : 0;
+      pcwt = (wm != 2 && wino_pc) ? wino_precut_tile(Cop, Cip) : 0;
       pcwt_bs = pcwt ? conv_precut_elems(Cop, Cip, pcwt) : 0;
       if (pcwt) pcwt_off = reserve_dgp(pcwt_bs * wP);
       else ub_off = reserve_dg(self, (size_t)wP * Cop * Cip);

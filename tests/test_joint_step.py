@@ -1,0 +1,137 @@
+"""BASELINE.json config C5: "Warp+Texture joint (both G/D pairs), DeepFashion-shaped 256x192 synthetic".
+
+The reference trains one stage per process (train.py builds ONE model, models/__init__.py:33-44); "joint" is both G/D pairs alive in one
+process -- here: two swn_model objects on ONE context, stepping alternately, sharing the context's streams, split-K / reduction
+scratch, the per-stream amax scratch and the operand-refresh machinery.  What can go wrong is exactly that sharing (round 4 found
+one such bug on the GPU: recorded hipMemset nodes of one model misbehaving after another model's eager memsets), so the test
+interleaves the two models' PHASES, not just their steps, and holds every loss, the outputs and every gradient of both pairs to the
+CPU oracle's independent steps over two iterations.
+
+Geometry: the warp generator only needs H and W to be multiples of 64 -- 256 x 192 is DeepFashion's 4:3 at the benchmark height.  The
+texture U-Net derives its depth from a square img_size (modules/swapnet_modules.py:178; 8 stride-2 levels at 256 would take width
+192 to zero: SURVEY.md section 5 caveat) -- it runs at the square crop, 256 x 256 on the GPU, 64 x 64 on the host simulator."""
+import pytest
+import torch
+
+from oracle import swapnet_oracle as O
+from swapnet_amd import engine
+from tests import backends
+from tests.conftest import unverified_gpu
+from tests.test_texture_step import vgg_state_dict
+from tests.test_train_parity import _check_step, _ctx, rel
+
+SIM = pytest.param("sim", id="hostsim")
+GPU = pytest.param("gpu", id="mi355x", marks=[pytest.mark.gpu, unverified_gpu])
+
+
+def _interleaved_iteration(mw, mt, lw, lt):
+    """One optimize_parameters of each model (models/base_gan.py:194-203), the phases of the two interleaved."""
+    mw.forward(False, 0)
+    mt.forward(False, 0)
+    mw.backward_D(lw[0], lw[1])
+    gDw = mw.state_dict(engine.NET_D, which=engine.W_GRAD, to_cpu=True)
+    mt.backward_D(lt[0], lt[1])
+    gDt = mt.state_dict(engine.NET_D, which=engine.W_GRAD, to_cpu=True)
+    mw.optimizer_step(engine.NET_D)
+    mt.optimizer_step(engine.NET_D)
+    mt.backward_G(lt[2])
+    gGt = mt.state_dict(engine.NET_G, which=engine.W_GRAD, to_cpu=True)
+    mw.backward_G(lw[2])
+    gGw = mw.state_dict(engine.NET_G, which=engine.W_GRAD, to_cpu=True)
+    mt.optimizer_step(engine.NET_G)
+    mw.optimizer_step(engine.NET_G)
+    return (gDw, gGw), (gDt, gGt)
+
+
+@pytest.mark.parametrize("backend", [SIM, GPU])
+def test_c5_shaped_joint_step_of_both_gan_pairs(backend):
+    ctx = _ctx(backend)
+    on_gpu = backend == "gpu"
+    Bw, Hw, Ww = (16, 256, 192) if on_gpu else (1, 256, 192)            # the warp stage at C5's geometry on both backends
+    Bt, St = (16, 256) if on_gpu else (1, 64)
+    torch.manual_seed(21)
+    Gw, Dw = O.warp_module_params(), O.patchgan_params(22)
+    Gt, Dt, vgg = O.texture_module_params(img_size=St), O.patchgan_params(22), O.vgg16_feature_params()
+    wb = O.synth_warp_batch(Bw, Hw, Ww, seed=5)
+    tb = O.synth_texture_batch(Bt, St, St, seed=6)
+    mw = engine.NativeModel(ctx, "warp", Bw, Hw, Ww)
+    mt = engine.NativeModel(ctx, "texture", Bt, St, St)
+    try:
+        backends.reset_state(mw, {engine.NET_G: Gw, engine.NET_D: Dw})
+        backends.reset_state(mt, {engine.NET_G: Gt, engine.NET_D: Dt})
+        mt.load_state_dict(engine.NET_VGG, vgg_state_dict(mt, vgg))
+        for i, t in enumerate(wb):
+            mw.set_input(i, t)
+        for i, t in enumerate(tb):
+            mt.set_input(i, t)
+        sw, st = O.WarpStepOracle(Gw, Dw), O.TextureStepOracle(Gt, Dt, vgg)
+        for it, (lw, lt) in enumerate((([0.9, 0.8, 1.0], [0.85, 0.95, 0.75]), ([0.75, 1.05, 0.9], [1.0, 0.7, 0.8]))):
+            if it > 0:
+                # Adam's first update is +-lr sign(g): a free-running second step would compare GAN trajectories, not kernels
+                # (tests/test_warp_step.py).  Both models restart from the oracle's state -- weights, both moments, step counts.
+                for m, o in ((mw, sw), (mt, st)):
+                    for net, P, opt in ((engine.NET_G, o.G, o.optG), (engine.NET_D, o.D, o.optD)):
+                        m.load_state_dict(net, P)
+                        m.load_state_dict(net, opt.m, which=engine.W_EXP_AVG)
+                        m.load_state_dict(net, opt.v, which=engine.W_EXP_AVG_SQ)
+                        m.optim_step_count(net, opt.step)
+            sw.step(*wb, labels=lw)
+            st.step(*tb, labels=lt)
+            (gDw, gGw), (gDt, gGt) = _interleaved_iteration(mw, mt, lw, lt)
+            assert tuple(mw.output().shape) == (Bw, 19, Hw, Ww) and tuple(mt.output().shape) == (Bt, 3, St, St)
+            ww = _check_step(mw, sw, gDw, gGw, what="joint iteration %d, warp %dx%d" % (it, Hw, Ww))
+            wt = _check_step(mt, st, gDt, gGt, what="joint iteration %d, texture %dx%d" % (it, St, St))
+            print("joint iteration", it, "warp", {k: "%.1e" % v for k, v in ww.items()}, "texture", {k: "%.1e" % v for k, v in wt.items()})
+        assert rel(mw.output(), sw.fakes) < 1e-3 and rel(mt.output(), st.fakes) < 1e-3
+    finally:
+        mw.close()
+        mt.close()
+
+
+@pytest.mark.parametrize("backend", [SIM, GPU])
+def test_joint_fused_steps_equal_each_models_own_steps(backend):
+    """swn_model_step of the two models alternating on one context (what `bench.py --stage joint` times) leaves each model
+    bit-identical to the same model stepped alone: nothing of one model's step leaks into the other's through the shared context."""
+    ctx = _ctx(backend)
+    on_gpu = backend == "gpu"
+    Bw, Hw, Ww = (4, 256, 192) if on_gpu else (1, 128, 64)
+    Bt, St = (4, 256) if on_gpu else (1, 64)
+    torch.manual_seed(3)
+    Gw, Dw = O.warp_module_params(), O.patchgan_params(22)
+    Gt, Dt, vgg = O.texture_module_params(img_size=St), O.patchgan_params(22), O.vgg16_feature_params()
+    wb = O.synth_warp_batch(Bw, Hw, Ww, seed=8)
+    tb = O.synth_texture_batch(Bt, St, St, seed=9)
+    labels = ([0.9, 0.8, 1.0], [0.85, 0.95, 0.75], [0.7, 1.1, 0.9])
+
+    def run(joint):
+        mw = engine.NativeModel(ctx, "warp", Bw, Hw, Ww)
+        mt = engine.NativeModel(ctx, "texture", Bt, St, St)
+        try:
+            backends.reset_state(mw, {engine.NET_G: Gw, engine.NET_D: Dw})
+            backends.reset_state(mt, {engine.NET_G: Gt, engine.NET_D: Dt})
+            mt.load_state_dict(engine.NET_VGG, vgg_state_dict(mt, vgg))
+            for i, t in enumerate(wb):
+                mw.set_input(i, t)
+            for i, t in enumerate(tb):
+                mt.set_input(i, t)
+            if joint:
+                for k, lab in enumerate(labels):
+                    mw.step(lab, training=True, seed=100 + k)
+                    mt.step(lab, training=True, seed=200 + k)
+            else:
+                for k, lab in enumerate(labels):
+                    mw.step(lab, training=True, seed=100 + k)
+                for k, lab in enumerate(labels):
+                    mt.step(lab, training=True, seed=200 + k)
+            ctx.sync()
+            return ([mw.state_dict(n, to_cpu=True) for n in (engine.NET_G, engine.NET_D)], mw.losses(),
+                    [mt.state_dict(n, to_cpu=True) for n in (engine.NET_G, engine.NET_D)], mt.losses())
+        finally:
+            mw.close()
+            mt.close()
+
+    a, b = run(True), run(False)
+    for sa, sb in zip(a[0] + a[2], b[0] + b[2]):
+        for k in sa:
+            assert torch.equal(sa[k], sb[k]), k
+    assert a[1] == b[1] and a[3] == b[3]

@@ -17,6 +17,11 @@ from oracle import swapnet_oracle as O
 from swapnet_amd import _C
 from tests import backends
 
+
+def backends_unverified_gpu():
+    from tests.conftest import unverified_gpu
+    return unverified_gpu
+
 pytestmark = pytest.mark.small_channel_winograd      # tests/conftest.py: small shapes on the Winograd forms
 
 K4S2, K3REFL, K4S1, K3ZERO, TAIL = 0, 1, 2, 3, 4
@@ -123,6 +128,31 @@ def test_conv_forward(backend):
             if backend == "gpu":       # tiled MFMA kernel vs the one-thread-per-output checker
                 chk = run_conv(ctx, kind, tr, 0, True, x, w, b, act, ref.shape)
                 assert rel(out, chk) < 1e-5, ("tiled vs naive", kind, tr, n, ci, h, co)
+
+
+@pytest.mark.small_channel_winograd
+@pytest.mark.parametrize("backend", [pytest.param("sim", id="hostsim"),
+                                     pytest.param("gpu", id="mi355x", marks=[pytest.mark.gpu, backends_unverified_gpu()])])
+def test_winograd_layers_of_129_to_192_channels(backend):
+    """Stride-1 Winograd layers whose output (or, for the input gradient, input) width falls in (128, 192]: conv_precut_tile answers
+    192 there -- the tile of the tail conv's input gradient -- but the 6-point filter transform writes tiles of 64 / 128 only, and
+    planning used to fail at the first operand refresh ("wino_filter_transform_pc: ... tile 64 or 128"; advisor, round 3).  Such a
+    layer now keeps its fp32 filter planes (engine.cpp wino_precut_tile).  No network of the reference has one; swn_op_conv does."""
+    ctx = _ctx(backend)
+    g = torch.Generator().manual_seed(3)
+    for kind, k, ci, co, h in ((K3REFL, 3, 32, 160, 8), (K3ZERO, 3, 160, 32, 8), (K3REFL, 3, 176, 176, 12), (K4S1, 4, 48, 176, 9)):
+        x = torch.randn(2, ci, h, h, generator=g)
+        w = torch.randn(co, ci, k, k, generator=g) * (2.0 / (ci * k * k)) ** 0.5
+        b = torch.randn(co, generator=g) * 0.1
+        ref = ref_conv(x.double(), w.double(), b.double(), kind, 0)
+        out = run_conv(ctx, kind, 0, 0, False, x, w, b, 0, ref.shape)
+        dy = torch.randn(ref.shape, generator=g)
+        xr, wr = x.double().requires_grad_(True), w.double().requires_grad_(True)
+        ref_conv(xr, wr, None, kind, 0).backward(dy.double())
+        dx = run_conv(ctx, kind, 0, 2, False, torch.zeros_like(x), w, None, 0, dy=dy)
+        dw = run_conv(ctx, kind, 0, 1, False, x, torch.zeros_like(w), None, 0, dy=dy)
+        for what, a, r in (("fwd", out, ref), ("dgrad", dx, xr.grad), ("wgrad", dw, wr.grad)):
+            assert rel(a, r) < 1e-5, (kind, ci, co, what, rel(a, r))
 
 
 @pytest.mark.parametrize("backend", BACKENDS)
