@@ -155,7 +155,7 @@ int main(int argc, char** argv) {
   SW(swn_ctx_create(0, nullptr, 1, (size_t)1024 << 20, &ctx));
   SAY("ctx up at %.1f s\n", now() - t00);
 
-  const bool generic = argc > 5 && (!strcmp(argv[5], "bench") || !strcmp(argv[5], "ab"));
+  const bool generic = argc > 5 && (!strcmp(argv[5], "bench") || !strcmp(argv[5], "ab") || !strcmp(argv[5], "prof"));
   if (!getenv("NATIVE_AB_SKIP_OPS") && !generic) {
     int big = H >= 256;
     op_case(ctx, "k4s2 64->128 (body_down2 / PatchGAN model.2 shape)", 0, big ? 8 : 2, 64, big ? 128 : 16, 128, big ? 64 : 8);
@@ -208,6 +208,7 @@ int main(int argc, char** argv) {
   // ---- generic modes for the next rounds' short GPU calls ----------------------------------------------------------------------
   //   native_ab B H K rounds bench                      one line: ms/step of K steps after 5 warm-up steps, under the caller's environment
   //                                                     (for switches a process reads once: `env SWN_X=1 native_ab 32 256 40 0 bench`)
+  //   native_ab B H K rounds prof                       per GEMM kernel family: launches, ms per step, TFLOP/s (HIP events, one stream)
   //   native_ab B H K rounds ab "A=1 B=2" "C=3" ...     alternating blocks of K steps in ONE process: no switch | each configuration,
   //                                                     `rounds` times (switches the library reads per launch / per step)
   auto plain_steps = [&](int steps) {
@@ -222,6 +223,35 @@ int main(int argc, char** argv) {
     double ms = plain_steps(K);
     say_losses(m, "bench");
     SAY("bench %.3f ms/step %.1f img/s (B %d, %d x %d, %d steps)\n", ms, B / ms * 1e3, B, H, H, K);
+    SW(swn_model_destroy(m)); SW(swn_ctx_destroy(ctx));
+    return 0;
+  }
+  if (argc > 5 && !strcmp(argv[5], "prof")) {
+    // per-kernel-family timing of the implicit-GEMM launches with HIP events (swn_prof_*: what bench.py's roofline leg uses), in
+    // order on one stream: K steps, "<kernel> <launches> <total ms> <flops>" -> ms per step and TFLOP/s.  Two seconds instead of a
+    // rocprofv3 run when only the GEMM families are in question.
+    plain_steps(3);
+    SW(swn_ctx_set_overlap(ctx, 0));
+    plain_steps(1);
+    SW(swn_prof_reset()); SW(swn_prof_enable(1));
+    double ms = plain_steps(K);
+    SW(swn_prof_enable(0)); SW(swn_ctx_set_overlap(ctx, 1));
+    int need = swn_prof_report(nullptr, 0);
+    std::vector<char> buf((size_t)need + 16); swn_prof_report(buf.data(), need + 16);
+    SAY("prof: %d steps in order on one stream, %.3f ms/step (events included)\n", K, ms);
+    std::string rep(buf.data()); size_t p0 = 0; double tot = 0;
+    while (p0 < rep.size()) {
+      size_t e = rep.find('\n', p0); if (e == std::string::npos) e = rep.size();
+      std::string line = rep.substr(p0, e - p0); p0 = e + 1;
+      size_t a = line.rfind(' '); if (a == std::string::npos) continue;
+      size_t b = line.rfind(' ', a - 1); size_t c = line.rfind(' ', b - 1);
+      if (b == std::string::npos || c == std::string::npos) continue;
+      double flops = atof(line.c_str() + a + 1), tms = atof(line.c_str() + b + 1); long launches = atol(line.c_str() + c + 1);
+      tot += tms;
+      SAY("prof %-56s %5ld launches/step %8.3f ms/step %8.1f us/launch %8.1f TFLOP/s\n", line.substr(0, c).c_str(), launches / K, tms / K,
+          launches ? tms / launches * 1e3 : 0.0, tms > 0 ? flops / (tms * 1e-3) / 1e12 : 0.0);
+    }
+    SAY("prof GEMM families total %.3f ms/step\n", tot / K);
     SW(swn_model_destroy(m)); SW(swn_ctx_destroy(ctx));
     return 0;
   }
