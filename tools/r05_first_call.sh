@@ -24,12 +24,17 @@ timeout 420 python -m pytest -m gpu -q -x \
   "tests/test_ops.py::test_64_row_wave_tiles_match_the_128x128_ring_kernel" \
   "tests/test_data_parallel.py::test_one_rank_native_rccl_exchange_equals_the_fused_step" \
   "tests/test_gradient_penalty.py::test_gradient_penalty_at_other_patchgan_depths" \
+  "tests/test_joint_step.py" \
+  "tests/test_ops.py::test_winograd_layers_of_129_to_192_channels" \
   -s > $O/t_unverified.log 2>&1; echo "unverified-tests rc $?" | tee -a $O/rc.txt
 tail -15 $O/t_unverified.log
 unset SWAPNET_UNVERIFIED_GPU
 timeout 120 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; echo "smoke rc $?" | tee -a $O/rc.txt
 timeout 300 python bench.py > $O/bench_default.json 2> $O/bench_default.err; echo "bench rc $?" | tee -a $O/rc.txt
 tail -c 600 $O/bench_default.json
+timeout 200 python bench.py --stage joint --steps 10 --warmup 3 > $O/bench_joint.json 2> $O/bench_joint.err; echo "bench joint rc $?" | tee -a $O/rc.txt
+tail -c 400 $O/bench_joint.json
+timeout 60 tools/_bin/native_ab 32 256 10 0 prof > $O/native_prof.txt 2>&1; tail -30 $O/native_prof.txt
 for V in "X=0" "SWN_PC_MI=2" "X=1" "SWN_PC_MI=2 SWN_PC_MI_MIN_TILES=256" "SWAPNET_BENCH_RCCL1=1" "SWAPNET_BENCH_RCCL1=1 SWAPNET_NATIVE_COMM=1"; do
   env $V timeout 200 python bench.py --steps 15 --warmup 4 --no-cpu-baseline --no-roofline 2> $O/ab.err | tail -1 | \
     python -c "import sys,json;d=json.loads(sys.stdin.read());print('$V', d['ms_per_step'], d['value'], d.get('exchange'))" >> $O/ab.txt
