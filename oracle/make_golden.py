@@ -210,6 +210,38 @@ def golden_warp_modes(path, H=64, B=2, init_seed=0, step_seed=100):
     print("wrote", path, len(out), "entries")
 
 
+def golden_warp_nonsquare(path, H=128, W=64, B=1, init_seed=0, step_seed=100):
+    """One step of the REAL WarpModel on a 2:1 batch (BASELINE.json C5 is DeepFashion's 4:3, 256 x 192: the warp generator is fully
+    convolutional -- modules/swapnet_modules.py:92-151 -- and the conditional PatchGAN -- modules/discriminators.py:111-131 -- takes any
+    map): losses, fakes, post-step weights of both networks.  Pins the oracle (and through it the library) at H != W."""
+    from oracle.swapnet_oracle import synth_warp_batch
+    from models.warp_model import WarpModel
+    out = OrderedDict()
+    bodys, inputs, targets = synth_warp_batch(B, H, W, seed=1234)
+    with tempfile.TemporaryDirectory() as tmp:
+        opt = base_opt(tmp, lambda_ce=100.0, model="warp", warp_mode="gan")
+        torch.manual_seed(init_seed)
+        model = WarpModel(opt)
+        model.eval()
+        model.set_input(dict(bodys=bodys, input_cloths=inputs, target_cloths=targets, cloth_paths=[""] * B, body_paths=[""] * B))
+        torch.manual_seed(step_seed)
+        model.optimize_parameters()
+        for k, v in model.get_current_losses().items():
+            out["loss/" + k] = np.float64(v)
+        assert tuple(model.fakes.shape) == (B, 19, H, W)
+        summarize(out, "fakes", model.fakes)
+        sd = model.net_generator.state_dict()
+        for k in ("upsample_and_pad.2.weight", "resblocks.3.conv_block.6.weight", "body_down1.model.0.weight", "cloth_down6.model.0.weight"):
+            summarize(out, "postG/" + k, sd[k])
+        dsd = model.net_discriminator.state_dict()
+        for k in ("model.0.weight", "model.8.weight", "model.11.weight"):
+            summarize(out, "postD/" + k, dsd[k])
+    out["meta/init_seed"] = np.int64(init_seed); out["meta/step_seed"] = np.int64(step_seed)
+    out["meta/B"] = np.int64(B); out["meta/H"] = np.int64(H); out["meta/W"] = np.int64(W)
+    np.savez_compressed(path, **out)
+    print("wrote", path, len(out), "entries")
+
+
 def golden_warp_depths_gp(path, H=64, B=2, init_seed=0, step_seed=100):
     """--gan_mode wgan-gp / dragan-gp with --discriminator n_layers --n_layers_D 2 / 4 (modules/loss.py:133-184 through
     modules/discriminators.py:91-136 at other depths): one step of the REAL reference's WarpModel -- losses, fakes, every
@@ -407,7 +439,7 @@ if __name__ == "__main__":
     torch.set_num_threads(8)
     gold = os.path.join(REPO, "tests", "golden")
     os.makedirs(gold, exist_ok=True)
-    which = sys.argv[1:] or ["warp", "texture", "roi", "cloth", "roiops", "modes", "channels", "depths", "depths_gp"]
+    which = sys.argv[1:] or ["warp", "texture", "roi", "cloth", "roiops", "modes", "channels", "depths", "depths_gp", "nonsquare"]
     if "warp" in which:
         golden_warp(os.path.join(gold, "warp_step_64.npz"))
     if "texture" in which:
@@ -422,6 +454,8 @@ if __name__ == "__main__":
         golden_warp_depths(os.path.join(gold, "warp_depths_64.npz"))
     if "depths_gp" in which:
         golden_warp_depths_gp(os.path.join(gold, "warp_depths_gp_64.npz"))
+    if "nonsquare" in which:
+        golden_warp_nonsquare(os.path.join(gold, "warp_nonsquare_128x64.npz"))
     if "roiops" in which:
         golden_roi_ops(os.path.join(gold, "roi_ops_reference.npz"))
     if "cloth" in which:

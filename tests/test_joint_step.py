@@ -10,10 +10,14 @@ CPU oracle's independent steps over two iterations.
 Geometry: the warp generator only needs H and W to be multiples of 64 -- 256 x 192 is DeepFashion's 4:3 at the benchmark height.  The
 texture U-Net derives its depth from a square img_size (modules/swapnet_modules.py:178; 8 stride-2 levels at 256 would take width
 192 to zero: SURVEY.md section 5 caveat) -- it runs at the square crop, 256 x 256 on the GPU, 64 x 64 on the host simulator."""
+import os
+
+import numpy as np
 import pytest
 import torch
 
 from oracle import swapnet_oracle as O
+from oracle.golden_io import compare
 from swapnet_amd import engine
 from tests import backends
 from tests.conftest import unverified_gpu
@@ -135,3 +139,39 @@ def test_joint_fused_steps_equal_each_models_own_steps(backend):
         for k in sa:
             assert torch.equal(sa[k], sb[k]), k
     assert a[1] == b[1] and a[3] == b[3]
+
+
+@pytest.mark.parametrize("backend", [SIM, GPU])
+def test_non_square_warp_step_reproduces_the_reference(backend, golden_dir):
+    """One G+D step of the warp stage at H != W against a step of the REAL reference model recorded at 128 x 64
+    (tests/golden/warp_nonsquare_128x64.npz, oracle/make_golden.py::golden_warp_nonsquare): losses, generated batch and
+    post-step weights of both networks through the C-ABI."""
+    g = np.load(os.path.join(golden_dir, "warp_nonsquare_128x64.npz"))
+    B, H, W = int(g["meta/B"]), int(g["meta/H"]), int(g["meta/W"])
+    torch.manual_seed(int(g["meta/init_seed"]))
+    G, D = O.warp_module_params(), O.patchgan_params(22)
+    batch = O.synth_warp_batch(B, H, W, seed=1234)
+    st = O.WarpStepOracle(G, D)
+    torch.manual_seed(int(g["meta/step_seed"]))
+    st.step(*batch)                                   # (draws the three smooth labels in the reference's order)
+    m = engine.NativeModel(_ctx(backend), "warp", B, H, W)
+    try:
+        backends.reset_state(m, {engine.NET_G: G, engine.NET_D: D})
+        for i, t in enumerate(batch):
+            m.set_input(i, t)
+        m.step(st.labels, training=False, seed=0)
+        L = m.losses()
+        for k in [f[5:] for f in g.files if f.startswith("loss/")]:
+            ref = float(g["loss/" + k])
+            assert abs(L[k] - ref) <= 1e-3 * abs(ref) + 1e-6, (k, L[k], ref)
+        assert tuple(m.output().shape) == (B, 19, H, W)
+        ok, msg = compare(g, "fakes", m.output(), 1e-3, 1e-3)
+        assert ok, msg
+        for grp, net in (("postG/", engine.NET_G), ("postD/", engine.NET_D)):
+            sd = m.state_dict(net, to_cpu=True)
+            for f in g.files:
+                if f.startswith(grp) and f.endswith("/norm"):
+                    ok, msg = compare(g, f[:-5], sd[f[len(grp):-5]], 1e-3, 3e-3)
+                    assert ok, msg
+    finally:
+        m.close()
