@@ -60,7 +60,9 @@ int swn_ctx_set_overlap(swn_ctx* ctx, int on);
 /* discriminators.define_D(input_nc, 64, opt.discriminator, opt.n_layers_D, opt.norm) (modules/discriminators.py:45-88,
  * models/base_gan.py:147-149): the number of stride-2 levels of the NLayerDiscriminator (:91-136) of every model created on
  * this context AFTERWARDS; 3 = "basic", the 70x70 PatchGAN (default).  1..5; the input must keep >= 3 pixels per side after
- * the stride-2 levels.  The gradient-penalty modes exist for n_layers = 3 only (NotImplementedError otherwise). */
+ * the stride-2 levels.  0 = --discriminator pixel: the 1x1 PixelDiscriminator (:139-170; three 1x1 convs, a prediction per
+ * pixel, state_dict keys net.{0,2,5}.{weight,bias}).  The gradient-penalty modes exist for every PatchGAN depth, not for the
+ * PixelDiscriminator (swn_model_set_hyper fails). */
 int swn_ctx_set_patchgan_layers(swn_ctx* ctx, int n_layers);
 int swn_ctx_sync(swn_ctx* ctx);
 int swn_ctx_bytes_allocated(swn_ctx* ctx, size_t* out);
@@ -280,7 +282,7 @@ int swn_op_decode_labels(swn_ctx* ctx, const float* x, int b, int c, int h, int 
 int swn_op_argmax_labels(swn_ctx* ctx, const float* x, int b, int c, int h, int w, int32_t* labels);
 int swn_op_labels_to_onehot(swn_ctx* ctx, const int32_t* labels, int b, int c, int h, int w, float* out);
 /* a single convolution through the MFMA implicit-GEMM kernel (or the naive checker):
- * kind 0 k4s2p1, 1 k3s1 reflect, 2 k4s1p1, 3 k3s1 zero-pad, 4 upsample-pad-conv tail;
+ * kind 0 k4s2p1, 1 k3s1 reflect, 2 k4s1p1, 3 k3s1 zero-pad, 4 upsample-pad-conv tail, 5 k1s1 (PixelDiscriminator);
  * transposed!=0 -> ConvTranspose2d k4s2p1 (weight (Ci,Co,4,4)).  x (N,Ci,H,W), y NCHW.
  * what: 0 forward, 1 weight gradient (y = dY in, w = dW out), 2 input gradient (y = dY in, x = dX out) */
 int swn_op_conv(swn_ctx* ctx, int kind, int transposed, int what, int naive, float* x, int n, int ci, int h, int w,

@@ -312,6 +312,43 @@ def golden_warp_depths(path, H=64, B=2, init_seed=0, step_seed=100):
     print("wrote", path, len(out), "entries")
 
 
+def golden_warp_pixel(path, H=64, B=2, init_seed=0, step_seed=100):
+    """--discriminator pixel (models/base_gan.py:61-65 -> modules/discriminators.py:39-41,139-175): the REAL reference's
+    PixelDiscriminator -- parameter names / shapes after init, its per-pixel prediction map on the conditioned target batch, and one
+    WarpModel step against it (losses, fakes, every post-step D weight, one G weight)."""
+    from oracle.swapnet_oracle import synth_warp_batch
+    from models.warp_model import WarpModel
+    out = OrderedDict()
+    bodys, inputs, targets = synth_warp_batch(B, H, H, seed=1234)
+    with tempfile.TemporaryDirectory() as tmp:
+        opt = base_opt(tmp, lambda_ce=100.0, model="warp", gan_mode="vanilla", warp_mode="gan", discriminator="pixel")
+        torch.manual_seed(init_seed)
+        model = WarpModel(opt)
+        model.eval()
+        pre = "pixel/"
+        dsd = model.net_discriminator.state_dict()
+        out[pre + "D_keys"] = np.array(list(dsd.keys()))
+        for k, v in dsd.items():
+            out[pre + "D_shape/" + k] = np.array(v.shape, dtype=np.int64)
+            summarize(out, pre + "initD/" + k, v)
+        with torch.no_grad():
+            summarize(out, pre + "pred_real", model.net_discriminator(torch.cat((bodys, targets), 1)))
+        model.set_input(dict(bodys=bodys, input_cloths=inputs, target_cloths=targets, cloth_paths=[""] * B, body_paths=[""] * B))
+        torch.manual_seed(step_seed)
+        model.optimize_parameters()
+        for k, v in model.get_current_losses().items():
+            out[pre + "loss/" + k] = np.float64(v)
+        summarize(out, pre + "fakes", model.fakes)
+        for k, v in model.net_discriminator.state_dict().items():
+            summarize(out, pre + "postD/" + k, v)
+        for k in ("body_down1.model.0.weight", "upsample_and_pad.2.weight"):
+            summarize(out, pre + "postG/" + k, model.net_generator.state_dict()[k])
+    out["meta/init_seed"] = np.int64(init_seed); out["meta/step_seed"] = np.int64(step_seed)
+    out["meta/B"] = np.int64(B); out["meta/H"] = np.int64(H)
+    np.savez_compressed(path, **out)
+    print("wrote", path, len(out), "entries")
+
+
 def golden_warp_channels(path, H=64, B=2, init_seed=0, step_seed=100):
     """One reference step of WarpModel under the representation options (options/base_options.py:75-105,
     models/warp_model.py:49-55): --body_representation labels (12 body channels), --cloth_representation rgb (3 cloth
@@ -439,7 +476,7 @@ if __name__ == "__main__":
     torch.set_num_threads(8)
     gold = os.path.join(REPO, "tests", "golden")
     os.makedirs(gold, exist_ok=True)
-    which = sys.argv[1:] or ["warp", "texture", "roi", "cloth", "roiops", "modes", "channels", "depths", "depths_gp", "nonsquare"]
+    which = sys.argv[1:] or ["warp", "texture", "roi", "cloth", "roiops", "modes", "channels", "depths", "depths_gp", "nonsquare", "pixel"]
     if "warp" in which:
         golden_warp(os.path.join(gold, "warp_step_64.npz"))
     if "texture" in which:
@@ -454,6 +491,8 @@ if __name__ == "__main__":
         golden_warp_depths(os.path.join(gold, "warp_depths_64.npz"))
     if "depths_gp" in which:
         golden_warp_depths_gp(os.path.join(gold, "warp_depths_gp_64.npz"))
+    if "pixel" in which:
+        golden_warp_pixel(os.path.join(gold, "warp_pixel_64.npz"))
     if "nonsquare" in which:
         golden_warp_nonsquare(os.path.join(gold, "warp_nonsquare_128x64.npz"))
     if "roiops" in which:

@@ -127,6 +127,18 @@ def patchgan_params(input_nc, ndf=64, n_layers=3, init_type="kaiming", init_gain
     return P.state_dict(order)
 
 
+def pixelgan_params(input_nc, ndf=64, init_type="kaiming", init_gain=0.02):
+    """PixelDiscriminator.__init__ under instance norm (modules/discriminators.py:139-168; --discriminator pixel,
+    models/base_gan.py:61-65): three 1x1 convs, use_bias True (:152-155)."""
+    P = _ParamFactory()
+    P.conv("net.0", input_nc, ndf, 1, True)                        # :158
+    P.conv("net.2", ndf, ndf * 2, 1, True)                         # :160
+    P.conv("net.5", ndf * 2, 1, 1, True)                           # :163
+    order = list(P.layers)
+    P.init_weights(order, init_type, init_gain)
+    return P.state_dict(order)
+
+
 def texture_module_params(texture_channels=3, cloth_channels=19, num_roi=12,
                           img_size=128, ngf=64, init_type="kaiming", init_gain=0.02):
     """TextureModule.__init__ with unet_type="pix2pix" under instance norm
@@ -455,6 +467,10 @@ def patchgan_forward(P, x, n_layers=None, taps=None):
     """NLayerDiscriminator.forward (modules/discriminators.py:110-136).  n_layers None: read off the parameter set
     (n_layers stride-2 convs + the stride-1 conv + the prediction conv)."""
     t = taps if taps is not None else {}
+    if "net.0.weight" in P:            # PixelDiscriminator.forward (:172-174): conv1x1 - LeakyReLU - conv1x1 - IN - LeakyReLU - conv1x1
+        x = t["d0"] = _lrelu(F.conv2d(x, P["net.0.weight"], P["net.0.bias"]))
+        x = t["d1"] = _lrelu(_inorm(F.conv2d(x, P["net.2.weight"], P["net.2.bias"])))
+        return F.conv2d(x, P["net.5.weight"], P["net.5.bias"])
     if n_layers is None:
         n_layers = sum(1 for k in P if k.endswith(".weight")) - 2
     x = t["d0"] = _lrelu(F.conv2d(x, P["model.0.weight"], P["model.0.bias"], stride=2, padding=1))

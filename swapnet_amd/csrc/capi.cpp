@@ -101,7 +101,7 @@ int swn_ctx_attach_comm(swn_ctx* ctx, swn_allreduce_fn fn, void* comm, int world
 int swn_ctx_set_patchgan_layers(swn_ctx* ctx, int n_layers) {
   return guard([&] {
     REQUIRE(ctx, "ctx is NULL");
-    REQUIRE(n_layers >= 1 && n_layers <= 5, "n_layers_D must be in [1, 5]");
+    REQUIRE(n_layers >= 0 && n_layers <= 5, "n_layers_D must be in [1, 5], or 0 for the 1x1 PixelDiscriminator");
     ctx->c->patchgan_layers = n_layers;
   });
 }
@@ -198,7 +198,8 @@ int swn_model_set_hyper(swn_model* m, const swn_hyper* h) {
     y.d_b1 = h->d_b1 >= 0.f ? h->d_b1 : h->b1; y.d_b2 = h->d_b2 >= 0.f ? h->d_b2 : h->b2;
     REQUIRE(h->gp_mode >= 0 && h->gp_mode <= 3, "gradient penalty mode not implemented");
     REQUIRE(h->gp_mode == 0 || m->m->supports_gradient_penalty(),
-            "gradient penalty modes are not implemented for the texture model (the reference's call fails there too)");
+            "gradient penalty modes are not implemented for the texture model (the reference's call fails there too) nor for the "
+            "1x1 PixelDiscriminator");
     y.gp_mode = h->gp_mode; y.lambda_gp = h->lambda_gp;
   });
 }
@@ -515,7 +516,7 @@ int swn_op_conv(swn_ctx* ctx, int kind, int transposed, int what, int naive, flo
                 float* wgt, int co, const float* bias, int act, float* y) {
   return guard([&] {
     REQUIRE(ctx && x && wgt && y, "NULL argument");
-    REQUIRE(kind >= 0 && kind <= 4 && what >= 0 && what <= 2, "bad kind/what");
+    REQUIRE(kind >= 0 && kind <= 5 && what >= 0 && what <= 2, "bad kind/what");
     REQUIRE(what == 0 || act == ACT_NONE, "backward entry points take the gradient of the pre-activation output");
     // (set before the net is built: with the checkers forced no pre-cut-only operands are planned)
     struct Restore { ~Restore() { conv_force_naive(0); } } restore;

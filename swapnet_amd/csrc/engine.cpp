@@ -238,6 +238,7 @@ ConvGeom conv_geom(ConvKind kind, int H, int W) {
     case CK_K3S1_REFLECT: g.KH = g.KW = 3; g.stride = 1; g.pad_t = g.pad_l = 1; g.pad_mode = PAD_REFLECT; c.Ho = H; c.Wo = W; break;
     case CK_K3S1_ZERO: g.KH = g.KW = 3; g.stride = 1; g.pad_t = g.pad_l = 1; c.Ho = H; c.Wo = W; break;
     case CK_K4S1: g.KH = g.KW = 4; g.stride = 1; g.pad_t = g.pad_l = 1; c.Ho = H - 1; c.Wo = W - 1; break;
+    case CK_K1S1: g.KH = g.KW = 1; g.stride = 1; g.pad_t = g.pad_l = 0; c.Ho = H; c.Wo = W; break;
     case CK_TAIL_UP:   // Upsample(x2) + ZeroPad2d((1,0,1,0)) + Conv(k4,p1): pad 2 top/left in upsampled coords
       g.KH = g.KW = 4; g.stride = 1; g.pad_t = g.pad_l = 2; g.ups = 1; c.Ho = H * 2; c.Wo = W * 2; break;
   }
@@ -285,7 +286,7 @@ static bool wino_fwd_takes_pairs(int xC, int Npad) { return wino_precut_tile(xC,
 
 void Net::conv(const std::string& name, const Var& x, const Var& y, ConvKind kind, int Ci, int Co, bool bias,
                int actf, const std::vector<int32_t>* cimap, bool x_is_input, int dgrad_C) {
-  const int KH = (kind == CK_K3S1_REFLECT || kind == CK_K3S1_ZERO) ? 3 : 4;
+  const int KH = kind == CK_K1S1 ? 1 : ((kind == CK_K3S1_REFLECT || kind == CK_K3S1_ZERO) ? 3 : 4);
   const ConvGeom geo = conv_geom(kind, x.v.H, x.v.W);
   if (y.v.H != geo.Ho || y.v.W != geo.Wo) throw Error(1, "conv " + name + ": output view has the wrong size");
   const int Cip = x.v.C;
@@ -685,6 +686,7 @@ void Net::conv(const std::string& name, const Var& x, const Var& y, ConvKind kin
       dg_mode = 1; gd.KH = gd.KW = 3; gd.stride = 1; gd.pad_t = gd.pad_l = 2; dHo = x.v.H + 2; dWo = x.v.W + 2; break;
     case CK_K3S1_ZERO: dg_mode = 1; gd.KH = gd.KW = 3; gd.stride = 1; gd.pad_t = gd.pad_l = 1; break;
     case CK_K4S1: dg_mode = 1; gd.KH = gd.KW = 4; gd.stride = 1; gd.pad_t = gd.pad_l = 2; break;
+    case CK_K1S1: dg_mode = 1; gd.KH = gd.KW = 1; gd.stride = 1; gd.pad_t = gd.pad_l = 0; break;
     case CK_TAIL_UP: dg_mode = 3; gd.KH = gd.KW = 5; gd.stride = 2; gd.pad_t = gd.pad_l = 1; break;
   }
   gd.Ho = dHo; gd.Wo = dWo;

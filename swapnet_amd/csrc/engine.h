@@ -114,7 +114,7 @@ struct ParamArena {
   float* base(int which) const { return which == 0 ? w : which == 1 ? g : which == 2 ? m : v; }
 };
 
-enum ConvKind { CK_K4S2 = 0, CK_K3S1_REFLECT, CK_K4S1, CK_K3S1_ZERO, CK_TAIL_UP };
+enum ConvKind { CK_K4S2 = 0, CK_K3S1_REFLECT, CK_K4S1, CK_K3S1_ZERO, CK_TAIL_UP, CK_K1S1 /* 1x1, stride 1, no padding: PixelDiscriminator */ };
 
 class Net;
 struct Op {

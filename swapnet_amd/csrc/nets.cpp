@@ -100,7 +100,23 @@ Var build_patchgan(Net& n, const Var& x, int n_layers, const std::vector<int32_t
   int ci = 0;
   for (int v : cimap) ci += v >= 0;
   const int ndf = 64;
-  if (n_layers < 1 || n_layers > 5) throw Error(1, "PatchGAN: n_layers_D must be in [1, 5]");
+  if (n_layers == 0) {
+    // PixelDiscriminator under instance norm (modules/discriminators.py:139-170; --discriminator pixel, models/base_gan.py:61-65): three
+    // 1x1 convs, all with a bias (use_bias is true under InstanceNorm2d, :152-155), a prediction per PIXEL.  state_dict keys net.{0,2,5}.
+    Var a = n.alloc_var(N, x.v.H, x.v.W, ndf, true);
+    n.conv("net.0", x, a, CK_K1S1, ci, ndf, true, ACT_LRELU, &cimap, true, in_grad_channels);          // :158-159
+    n.taps["d0"] = a;
+    Var raw = n.alloc_var(N, x.v.H, x.v.W, ndf * 2, true);
+    Var act = n.alloc_var(N, x.v.H, x.v.W, ndf * 2, true);
+    n.conv("net.2", a, raw, CK_K1S1, ndf, ndf * 2, true, ACT_NONE);                                   // :160
+    n.norm_act(raw, act, true, ACT_LRELU, 0.f);                                                        // :161-162
+    n.taps["d1"] = act;
+    Var pred = n.alloc_var(N, x.v.H, x.v.W, 4, true);
+    n.conv("net.5", act, pred, CK_K1S1, ndf * 2, 1, true, ACT_NONE);                                   // :163
+    n.taps["pred"] = pred;
+    return pred;
+  }
+  if (n_layers < 1 || n_layers > 5) throw Error(1, "PatchGAN: n_layers_D must be in [1, 5] (0 = the 1x1 PixelDiscriminator)");
   if ((x.v.H >> n_layers) < 3 || (x.v.W >> n_layers) < 3)
     throw Error(1, "PatchGAN: the input is too small for " + std::to_string(n_layers) + " stride-2 levels followed by two 4x4 stride-1 convs");
   int H = x.v.H / 2, W = x.v.W / 2;
@@ -256,7 +272,7 @@ class WarpModel final : public Model {
   }
   TView output_view() override { return Dx.batch(0, B).v.slice(0, Ccp); }
   int output_channels() const override { return Cc; }
-  bool supports_gradient_penalty() const override { return true; }
+  bool supports_gradient_penalty() const override { return d_layers_ >= 1; }      // (the reverse-over-reverse pass of gp.cpp walks the PatchGAN)
   void forward(bool training, uint64_t seed) override {       // warp_model.py:106-107
     G->training = training; G->seed = seed;
     G->forward();

@@ -319,7 +319,8 @@ class NativeModel:
         if tuple(xd.shape) != (self.B, cd, self.H, self.W):
             raise ValueError("discriminator input must be (%d, %d, %d, %d), got %s" % (self.B, cd, self.H, self.W, tuple(xd.shape)))
         k = self.n_layers_D                     # n stride-2 levels, then two 4x4 stride-1 convs with padding 1 (-1 pixel each)
-        pred = torch.empty((self.B, 1, (self.H >> k) - 2, (self.W >> k) - 2), dtype=torch.float32, device=self.ctx.device)
+        shape = (self.B, 1, (self.H >> k) - 2, (self.W >> k) - 2) if k > 0 else (self.B, 1, self.H, self.W)     # 0: PixelDiscriminator
+        pred = torch.empty(shape, dtype=torch.float32, device=self.ctx.device)
         self.lib.call("swn_model_discriminate", self.handle, _C.ptr(xd), _C.ptr(pred))
         self.ctx.sync()
         return pred

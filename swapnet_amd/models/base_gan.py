@@ -61,6 +61,8 @@ class BaseGAN(BaseModel, ABC):
         if self.is_train and getattr(opt, "discriminator", "basic") == "n_layers":
             # define_D(..., opt.n_layers_D) (base_gan.py:147): the native networks of a stage are built together, on first use
             self.backend.n_layers_D = int(opt.n_layers_D)
+        elif self.is_train and getattr(opt, "discriminator", "basic") == "pixel":
+            self.backend.n_layers_D = 0             # --discriminator pixel (base_gan.py:61-65): the 1x1 PixelDiscriminator
         self.net_generator = self.define_G()
         modules.init_weights(self.net_generator, opt.init_type, opt.init_gain)      # base_gan.py:141
         self.model_names = ["generator"]
@@ -89,6 +91,9 @@ class BaseGAN(BaseModel, ABC):
                 raise NotImplementedError("gan mode %s: the gradient-penalty objectives are implemented for the warp "
                                           "stage (the reference's texture-stage call passes unconditioned tensors to "
                                           "the conditional discriminator and fails)" % opt.gan_mode)
+            if self.criterion_GAN.gp_mode and opt.discriminator == "pixel":
+                raise NotImplementedError("gan mode %s with --discriminator pixel: the native gradient penalty walks the "
+                                          "NLayerDiscriminator (basic / n_layers)" % opt.gan_mode)
             self.backend.set_hyper(gan_mode=self.criterion_GAN.native_mode, lambda_gan=opt.lambda_gan,
                                    gp_mode=self.criterion_GAN.gp_mode, lambda_gp=getattr(opt, "lambda_gp", 10.0))
             for n in ("D", "D_real", "D_fake", "G", "G_gan", "G_ce", "G_l1", "G_content", "G_style", "D_gp"):

@@ -33,6 +33,29 @@ class NLayerDiscriminator(NativeNet):
     __call__ = forward
 
 
+class PixelDiscriminator(NativeNet):
+    """1x1 PatchGAN ("pixelGAN", :139-175): Conv1x1(input_nc, 64) - LeakyReLU - Conv1x1(64, 128) - InstanceNorm - LeakyReLU -
+    Conv1x1(128, 1); every conv carries a bias under instance norm (:152-155); state_dict keys net.{0,2,5}.{weight,bias}.  On the
+    native side it is PatchGAN "depth 0" of the stage's context (swn_ctx_set_patchgan_layers(ctx, 0))."""
+
+    def __init__(self, backend, input_nc=22, ndf=64):
+        want = backend.cloth_channels + (backend.body_channels if backend.kind == "warp" else 3)
+        if input_nc != want or ndf != 64:
+            raise NotImplementedError("native PixelDiscriminator: ndf 64, input channels = the stage's conditional "
+                                      "input (%d here), got input_nc=%d ndf=%d" % (want, input_nc, ndf))
+        if backend.models and backend.n_layers_D != 0:
+            raise RuntimeError("the stage's networks already exist with n_layers_D = %d" % backend.n_layers_D)
+        backend.n_layers_D = 0
+        super().__init__(backend, engine.NET_D)
+
+    def forward(self, input):
+        """PixelDiscriminator.forward (:172-174): (B, input_nc, H, W) -> (B, 1, H, W).  Inference-only call on the current weights."""
+        b, c, h, w = input.shape
+        return self._backend.ensure(b, h, w).discriminate(input)
+
+    __call__ = forward
+
+
 def define_D(input_nc, ndf, netD, n_layers_D=3, norm="batch", init_type="normal", init_gain=0.02, gpu_ids=[],
              backend=None):
     """discriminators.define_D (:45-88)."""
@@ -43,5 +66,5 @@ def define_D(input_nc, ndf, netD, n_layers_D=3, norm="batch", init_type="normal"
     if netD == "n_layers":
         return NLayerDiscriminator(backend, input_nc, ndf, n_layers_D)
     if netD == "pixel":
-        raise NotImplementedError("Discriminator model name [pixel] is not implemented natively")
+        return PixelDiscriminator(backend, input_nc, ndf)
     raise NotImplementedError("Discriminator model name [%s] is not recognized" % netD)

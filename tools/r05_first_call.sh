@@ -25,6 +25,7 @@ timeout 420 python -m pytest -m gpu -q -x \
   "tests/test_data_parallel.py::test_one_rank_native_rccl_exchange_equals_the_fused_step" \
   "tests/test_gradient_penalty.py::test_gradient_penalty_at_other_patchgan_depths" \
   "tests/test_joint_step.py" \
+  "tests/test_pixel_discriminator.py" \
   "tests/test_ops.py::test_winograd_layers_of_129_to_192_channels" \
   -s > $O/t_unverified.log 2>&1; echo "unverified-tests rc $?" | tee -a $O/rc.txt
 tail -15 $O/t_unverified.log
