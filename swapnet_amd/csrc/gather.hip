@@ -64,6 +64,61 @@ __global__ __launch_bounds__(256) void roi_align_kernel(const float* tex, int tc
   }
 }
 
+// The same gather with wavefront primitives (north_star: "ROIAlign/texture-pool as a wavefront-primitive gather kernel"; OPT-IN,
+// SWN_ROI_WAVE=1: written in round 4 without a GPU, never executed).  One wavefront per (image, output row ph, 64 output columns),
+// the ROIs of the pixel in a loop.  Per ROI the sample ROW is wave-uniform (y, yl, yh and the row weights depend on (roi, ph)
+// only) and the lanes' source columns xl grow with pw, so the texels the wave needs from rows yl / yh are one contiguous run
+// starting at lane 0's xl.  The wave loads that run 64 texels at a time -- ONE coalesced 16-byte load per lane and row (NHWC, C
+// padded to 4) -- and every lane takes its four corners out of its neighbours' registers with ds_bpermute (__shfl): no per-lane
+// scattered loads, each texel of the run fetched once per wave instead of up to four times per lane.  Same roi_sample(), same
+// left-to-right unfused weighted sum of the same four values: bit-identical to roi_align_kernel by construction.
+__global__ __launch_bounds__(256) void roi_align_wave_kernel(const float* tex, int tcs, int H, int W, int C, const float* rois, int B,
+                                                             int R, float* out, int ocs, int PH, int PW) {
+  const int lane = threadIdx.x & 63;
+  const int nblk = (PW + 63) >> 6;
+  const size_t nwork = (size_t)B * PH * nblk;
+  for (size_t wv = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6); wv < nwork; wv += (size_t)gridDim.x * 4) {
+    const int blk = (int)(wv % nblk); size_t q = wv / nblk;
+    const int ph = (int)(q % PH); const int b = (int)(q / PH);
+    const int pw = blk * 64 + lane;
+    const bool active = pw < PW;
+    const int pwc = active ? pw : PW - 1;                  // idle lanes shadow the last column: every lane stays in the shuffles
+    const float* img = tex + (size_t)b * H * W * tcs;
+    float* o = out + (((size_t)b * PH + ph) * PW + pwc) * ocs;
+    for (int r = 0; r < R; ++r) {
+      const RoiSample sm = roi_sample(rois + ((size_t)b * R + r) * 4, ph, pwc, PH, PW, H, W);
+      const float* rowl = img + (size_t)sm.yl * W * tcs;
+      const float* rowh = img + (size_t)sm.yh * W * tcs;
+      const int x0 = __shfl(sm.xl, 0), x1 = __shfl(sm.xh, 63);        // the run [x0, x1]: xl / xh are monotonic in pw
+      float a1[3] = {0.f, 0.f, 0.f}, a2[3] = {0.f, 0.f, 0.f}, a3[3] = {0.f, 0.f, 0.f}, a4[3] = {0.f, 0.f, 0.f};
+      for (int seg = x0; seg <= x1; seg += 64) {
+        const int xs = min(seg + lane, W - 1);
+        const float4 tl = *reinterpret_cast<const float4*>(rowl + (size_t)xs * tcs);
+        const float4 th = *reinterpret_cast<const float4*>(rowh + (size_t)xs * tcs);
+        const int il = sm.xl - seg, ih = sm.xh - seg;
+        const bool inl = il >= 0 && il < 64, inh = ih >= 0 && ih < 64;
+        const float l0 = __shfl(tl.x, il & 63), l1 = __shfl(tl.y, il & 63), l2 = __shfl(tl.z, il & 63);      // (yl, xl)
+        const float m0 = __shfl(tl.x, ih & 63), m1 = __shfl(tl.y, ih & 63), m2 = __shfl(tl.z, ih & 63);      // (yl, xh)
+        const float n0 = __shfl(th.x, il & 63), n1 = __shfl(th.y, il & 63), n2 = __shfl(th.z, il & 63);      // (yh, xl)
+        const float p0 = __shfl(th.x, ih & 63), p1 = __shfl(th.y, ih & 63), p2 = __shfl(th.z, ih & 63);      // (yh, xh)
+        if (inl) { a1[0] = l0; a1[1] = l1; a1[2] = l2; a3[0] = n0; a3[1] = n1; a3[2] = n2; }
+        if (inh) { a2[0] = m0; a2[1] = m1; a2[2] = m2; a4[0] = p0; a4[1] = p1; a4[2] = p2; }
+      }
+      if (active) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+          if (c < C) {
+            float v = 0.f;
+            if (sm.valid)
+              v = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(sm.w1, a1[c]), __fmul_rn(sm.w2, a2[c])), __fmul_rn(sm.w3, a3[c])),
+                            __fmul_rn(sm.w4, a4[c]));
+            o[r * C + c] = v;
+          }
+      }
+    }
+  }
+}
+
 __global__ void roi_indices_kernel(const float* rois, int K, int H, int W, int PH, int PW, int32_t* idx,
                                    uint8_t* valid) {
   const size_t total = (size_t)K * PH * PW;
@@ -233,6 +288,15 @@ __global__ __launch_bounds__(256) void onehot_kernel(const int32_t* labels, size
 void roi_align_fwd(Stream& s, const TView& tex, int C, const float* rois, int R, const TView& out) {
   if (out.C < R * C || out.N != tex.N) throw Error(1, "roi_align_fwd: output view too small");
   const size_t total = (size_t)tex.N * out.H * out.W * R;
+  // SWN_ROI_WAVE=1 (read per launch): the wavefront-primitive form (opt-in until it has run: roi_align_wave_kernel)
+  const char* e = getenv("SWN_ROI_WAVE");
+  if (e && atoi(e) == 1 && C <= 3 && tex.cs % 4 == 0 && tex.cs >= 4) {
+    const size_t nwork = (size_t)tex.N * out.H * ((out.W + 63) / 64);
+    hipLaunchKernelGGL(roi_align_wave_kernel, dim3((unsigned)std::min<size_t>((nwork + 3) / 4, 256 * 32)), dim3(256), 0, hs(s), tex.p, tex.cs,
+                       tex.H, tex.W, C, rois, tex.N, R, out.p, out.cs, out.H, out.W);
+    check_launch("roi_align_fwd (wave)");
+    return;
+  }
   hipLaunchKernelGGL(roi_align_kernel, dim3(egrid(total)), dim3(256), 0, hs(s), tex.p, tex.cs, tex.H, tex.W, C, rois,
                      tex.N, R, out.p, out.cs, out.H, out.W);
   check_launch("roi_align_fwd");

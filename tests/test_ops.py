@@ -245,6 +245,34 @@ def test_roi_align_bit_exact_indices_and_values(backend, golden_dir):
         assert torch.equal(out.cpu(), ref)
 
 
+@pytest.mark.gpu
+@pytest.mark.skipif(os.environ.get("SWAPNET_UNVERIFIED_GPU") != "1", reason="never run on the GPU yet (SWAPNET_UNVERIFIED_GPU=1 to include)")
+def test_wavefront_gather_roi_align_is_bit_identical(golden_dir, monkeypatch):
+    """roi_align_wave_kernel (SWN_ROI_WAVE=1; gather.hip): one wavefront per output row segment, the texel run of the row loaded
+    coalesced and the four corners of every lane taken from its neighbours' registers with ds_bpermute -- against the scalar
+    one-thread-per-sample kernel and the oracle, bit for bit: the notebook's ROIs (degenerate boxes), full-image and sub-pixel
+    boxes, 1-pixel boxes at the border, ROIs wider than 64 / 128 source pixels (several 64-texel segments per row), a pooled
+    width that is not a multiple of 64, and a non-square image.  Written without a GPU (round 4): opt-in until it has run."""
+    ctx = _ctx("gpu")
+    rois = torch.from_numpy(np.load(os.path.join(golden_dir, "notebook_rois.npz"))["rois"])
+    extra = torch.tensor([[[0, 0, 255, 255], [255, 0, 255, 0], [10.5, 3.25, 200.75, 77.5], [254, 254, 255, 255],
+                           [3, 200, 250, 201], [100, 0, 101, 255], [0, 0, 63, 63], [-5, -7, 40, 300]]])
+    g = torch.Generator().manual_seed(9)
+    for r, H, W, PH, PW in ((rois, 256, 256, 128, 128), (extra, 256, 256, 128, 128), (extra, 256, 256, 32, 96), (extra[:, :4] * 0.5, 128, 192, 128, 128)):
+        B, R = r.shape[0], r.shape[1]
+        x = torch.randn(B, 3, H, W, generator=g)
+        ref = O.roi_align(x, O.reshape_rois(r), (PH, PW), 1.0, 1).view(B, R * 3, PH, PW)
+        xd, rd = x.to(ctx.device).contiguous(), r.to(ctx.device).contiguous()
+        got = {}
+        for wave in ("0", "1"):
+            monkeypatch.setenv("SWN_ROI_WAVE", wave)
+            out = torch.full((B, R * 3, PH, PW), float("nan"), device=ctx.device)
+            ctx.lib.call("swn_op_roi_align", ctx.handle, _C.ptr(xd), B, 3, H, W, _C.ptr(rd), R, PH, PW, _C.ptr(out))
+            got[wave] = out.cpu()
+        assert torch.equal(got["0"], ref), ("scalar kernel", H, W, PH, PW)
+        assert torch.equal(got["1"], got["0"]), ("wave kernel", H, W, PH, PW, int((got["1"] != got["0"]).sum()))
+
+
 @pytest.mark.parametrize("backend", BACKENDS)
 def test_label_decode_and_onehot_bit_exact(backend):
     ctx = _ctx(backend)

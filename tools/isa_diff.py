@@ -31,6 +31,11 @@ def disassemble(obj, tmp, tag):
             continue
         if cur is not None:
             t = re.sub(r"//.*$", "", line).strip()
+            # the literal of the s_add_u32 / s_addc_u32 pair behind s_getpc_b64 is the distance to a constant table or another
+            # function: it moves when a kernel is added to the translation unit, the instruction does not change
+            if cur is not None and funcs[cur] and re.match(r"s_addc?_u32 s\d+, s\d+, 0x[0-9a-f]+$", t) and \
+                    any(p.startswith("s_getpc_b64") for p in funcs[cur][-3:]):
+                t = re.sub(r"0x[0-9a-f]+$", "<pc-relative>", t)
             if t:
                 funcs[cur].append(t)
     return funcs

@@ -26,6 +26,7 @@ timeout 420 python -m pytest -m gpu -q -x \
   "tests/test_gradient_penalty.py::test_gradient_penalty_at_other_patchgan_depths" \
   "tests/test_joint_step.py" \
   "tests/test_pixel_discriminator.py" \
+  "tests/test_ops.py::test_wavefront_gather_roi_align_is_bit_identical" \
   "tests/test_ops.py::test_winograd_layers_of_129_to_192_channels" \
   -s > $O/t_unverified.log 2>&1; echo "unverified-tests rc $?" | tee -a $O/rc.txt
 tail -15 $O/t_unverified.log
