@@ -276,14 +276,25 @@ def main():
     from swapnet_amd.modules import init_tensor
 
     local_rank = int(os.environ.get("SWAPNET_FORCE_DEVICE", os.environ.get("LOCAL_RANK", "0")))
-    if not torch.cuda.is_available():
+    # SWAPNET_BENCH_HOSTSIM=1 is a TEST HOOK (tests/test_data_parallel.py): the launch / exchange / reporting code of this file for
+    # N > 1 -- which no 1-GPU box ever executes -- run by two gloo ranks against the CI-only host simulator.  Never a measurement:
+    # the line says so, and nothing else in this file or the package selects the simulator.
+    sim = os.environ.get("SWAPNET_BENCH_HOSTSIM") == "1"
+    if not sim and not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (swapnet_amd has no CPU path)")
-    torch.cuda.set_device(local_rank)            # before the process group: RCCL binds to the current device
+    if not sim:
+        torch.cuda.set_device(local_rank)            # before the process group: RCCL binds to the current device
     rank, world = parallel.init_from_env()
     assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     import torch.distributed as dist
 
-    ctx = engine.Context(device=local_rank, workspace_mb=1024)
+    if sim:
+        from swapnet_amd import _C
+        from tests import backends as _test_backends
+        ctx = engine.Context(lib=_C.Lib(_test_backends.build_hostsim()), workspace_mb=64)
+    else:
+        ctx = engine.Context(device=local_rank, workspace_mb=1024)
+    device_sync = ctx.sync if sim else torch.cuda.synchronize
     texture = args.stage == "texture"
     B, S = (16 if texture and args.batch == 32 else args.batch), args.size
     model = engine.NativeModel(ctx, args.stage, B, S, S, is_train=True, dropout=0.5)
@@ -343,7 +354,7 @@ def main():
     def fence():
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+        device_sync()
 
     for _ in range(args.warmup):
         one_step()
@@ -354,11 +365,11 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], device="cuda")
+        t = torch.tensor([dt], device="cpu" if sim else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     if world > 1:          # every rank reports the device it drove (rank 0 prints them)
-        mine = [rank, torch.cuda.current_device()]
+        mine = [rank, local_rank if sim else torch.cuda.current_device()]
         gathered = [None] * world
         dist.all_gather_object(gathered, mine)
     losses = model.losses()
@@ -394,7 +405,8 @@ def main():
         "losses_finite": all(v == v and abs(v) < 1e30 for v in losses.values()),
         # proof of the launch shape for the driver's scaling table: ranks, the device each rank drives, the collective library
         "world": world,
-        "ranks": ([{"rank": rank, "device": torch.cuda.current_device(), "name": torch.cuda.get_device_name()}] if world == 1 else None),
+        "ranks": ([{"rank": rank, "device": local_rank if sim else torch.cuda.current_device(),
+                    "name": "HOST SIMULATOR (test hook, not a measurement)" if sim else torch.cuda.get_device_name()}] if world == 1 else None),
         "rccl_version": _rccl_version(),
         "dist_backend": (dist.get_backend() if dist.is_initialized() else None),
         "exchange": ("library-owned (swn_model_step_dp over the attached ncclAllReduce)" if native_comm[0] is not None
@@ -511,7 +523,9 @@ def main():
                 "all_gemm_kernels": {n: {"tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2),
                                          "ms_per_step": round(v["ms"] / nprof, 3)} for n, v in sorted(kernels.items())},
             }
-    if rank == 0 and (world > 1 or os.environ.get("SWAPNET_BENCH_PHASED") or rccl1):
+    if sim:
+        out["data"] = "synthetic; HOST SIMULATOR (SWAPNET_BENCH_HOSTSIM test hook): NOT a measurement"
+    if rank == 0 and (world > 1 or os.environ.get("SWAPNET_BENCH_PHASED") or rccl1) and not sim:
         # measured back-propagation time and gradient bytes of each exchange bucket (what engine.cpp's bucket boundaries are
         # sized on): HIP events around swn_model_backward_G_part, no exchange in between
         lab = draw_labels()
