@@ -192,10 +192,18 @@ def bench_joint(args):
     model; value = images through both stages per second."""
     from swapnet_amd import engine, synthetic
     from swapnet_amd.modules import init_tensor
-    torch.cuda.set_device(0)
-    ctx = engine.Context(device=0, workspace_mb=1024)
+    sim = os.environ.get("SWAPNET_BENCH_HOSTSIM") == "1"        # test hook (see main): this function's code path on the CI-only simulator
+    if sim:
+        from swapnet_amd import _C
+        from tests import backends as _test_backends
+        ctx = engine.Context(lib=_C.Lib(_test_backends.build_hostsim()), workspace_mb=64)
+    else:
+        torch.cuda.set_device(0)
+        ctx = engine.Context(device=0, workspace_mb=1024)
+    device_sync = ctx.sync if sim else torch.cuda.synchronize
     B = 16 if args.batch == 32 else args.batch
-    H, W, S = args.size, args.size * 3 // 4, args.size
+    H, S = args.size, args.size
+    W = args.size * 3 // 4 if (args.size * 3 // 4) % 64 == 0 else args.size // 2       # 4:3 at 256 (192); 2:1 where 4:3 is no multiple of 64
     warp = engine.NativeModel(ctx, "warp", B, H, W, is_train=True, dropout=0.5)
     tex = engine.NativeModel(ctx, "texture", B, S, S, is_train=True, dropout=0.5)
     torch.manual_seed(0)
@@ -217,18 +225,18 @@ def bench_joint(args):
 
     for _ in range(args.warmup):
         one_step()
-    torch.cuda.synchronize()
+    device_sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         one_step()
-    torch.cuda.synchronize()
+    device_sync()
     dt = time.perf_counter() - t0
     ms = dt / args.steps * 1e3
     lw, lt = warp.losses(), tex.losses()
-    out = {"metric": "images/sec, joint warp + texture G+D steps (both GAN pairs in one process), 256x192 / 256x256, bs=16/GPU",
+    out = {"metric": f"images/sec, joint warp + texture G+D steps (both GAN pairs in one process), {H}x{W} / {S}x{S}, bs={B}/GPU",
            "value": round(B * args.steps / dt, 3), "unit": "images/sec", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
            "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
-           "data": "synthetic",
+           "data": "synthetic" + ("; HOST SIMULATOR (SWAPNET_BENCH_HOSTSIM test hook): NOT a measurement" if sim else ""),
            "config": {"workload": f"BASELINE.json C5's shape on one GPU: warp-stage step at {H}x{W} then texture-stage step at {S}x{S} "
                                   f"(12 ROIs, L1 + VGG16 content + style), bs {B} each, train mode, fp32 storage, same kernels and "
                                   f"arithmetic as the C2 / C3 lines; one step = one optimize_parameters of each model",
