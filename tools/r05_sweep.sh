@@ -11,7 +11,7 @@ run() { env $1 timeout 60 tools/_bin/native_ab 32 256 ${STEPS:-30} 0 bench 2>&1 
   run "X=default"
   for CFG in "SWN_PC_STAGES=3" "SWN_PC_MI=2" "SWN_TILE256=0" "SWN_WGRAD256=0" "SWN_TILE192=0" "SWN_WINO_VW=4" "SWN_STREAM_ADAMW=0" \
              "SWN_SHARE_DY=0" "SWN_PAIR=0" "SWN_AMAX_FUSED=0" "SWN_FIRST_RING=0" "SWN_WGRAD_PLANES=3" "SWN_PC_PLANES=3" "SWN_PREFETCH=0" \
-             "SWN_OVERLAP=0" "SWN_WINO_S2=0" "SWN_TAIL_WINO=0" "SWN_FUSED_IN=0" "SWN_WINO_ADJOINT=0" "SWN_HEAD_TAPN=0" "SWN_WINO_MINC=128" \
+             "SWN_OVERLAP=0" "SWN_WINO_S2=0" "SWN_TAIL_WINO=0" "SWN_FUSED_IN=0" "SWN_WINO_ADJOINT=0" "SWN_HEAD_TAPN=0" "SWN_WINO_MINC=128" "SWN_WINO_MINC=64" "SWN_WINO_MINC=32" \
              "SWN_PC_PLANES=1 SWN_WGRAD_PLANES=1" ${EXTRA_CFGS}; do
     run "$CFG"
     run "X=default"
