@@ -125,9 +125,11 @@ def reset_state(m, state_dicts):
     for net, sd in state_dicts.items():
         m.load_state_dict(net, sd)
         if net != engine.NET_VGG and m.is_train:
-            zeros = {k: torch.zeros_like(v) for k, v in sd.items()}
-            m.load_state_dict(net, zeros, which=engine.W_EXP_AVG)
-            m.load_state_dict(net, zeros, which=engine.W_EXP_AVG_SQ)
+            # both Adam moments := 0 on the flat arenas (one fill each instead of one packed upload per parameter; it also clears the
+            # alignment pads between parameters, which no named parameter covers)
+            m.arena(net, engine.W_EXP_AVG).zero_()
+            m.arena(net, engine.W_EXP_AVG_SQ).zero_()
+            m.ctx.sync()
             m.optim_step_count(net, 0)
     if m.is_train:
         m.set_hyper()
