@@ -103,3 +103,21 @@ def test_shape_and_argument_errors_are_reported_not_crashed():
         m.set_param(engine.NET_G, "no.such.weight", torch.zeros(1))
     with pytest.raises(ValueError, match="no such network"):
         m.param_infos(engine.NET_D)                                         # D exists only when is_train
+
+
+def test_the_c_abi_drives_a_training_step_from_plain_cpp(tmp_path):
+    """include/swapnet_hip.h from a host that is not Python: tools/native_ab.cpp (no torch, no Python in the process) compiled against
+    the CI-only host-simulator build of the same C-ABI, one warp-stage G+D training step at 64 x 64 -- model creation, parameter
+    enumeration / loading by state-dict name, label-map inputs, swn_model_step, the loss read-back.  (On the MI355X the same file
+    links libswapnet_hip.so: profiles/native_ab_r04.txt.)"""
+    from tests import backends
+    so = backends.build_hostsim()
+    exe = os.path.join(str(tmp_path), "native_ab_sim")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-DHOSTSIM", os.path.join(REPO, "tools", "native_ab.cpp"), "-I" + os.path.join(REPO, "include"),
+                           "-L" + os.path.dirname(so), "-lswapnet_hostsim", "-ldl", "-fopenmp", "-Wl,-rpath," + os.path.dirname(so), "-o", exe])
+    out = subprocess.run([exe, "1", "64", "1", "0", "bench"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("bench losses")][-1]
+    assert "finite 1" in line, line
+    g_ce = float(line.split("G_ce")[1].split()[0])
+    assert 150.0 < g_ce < 450.0, line              # 100 x the cross entropy of 19 near-uniform classes (ln 19 = 2.94) after a few steps
