@@ -192,15 +192,8 @@ def bench_joint(args):
     model; value = images through both stages per second."""
     from swapnet_amd import engine, synthetic
     from swapnet_amd.modules import init_tensor
-    sim = os.environ.get("SWAPNET_BENCH_HOSTSIM") == "1"        # test hook (see main): this function's code path on the CI-only simulator
-    if sim:
-        from swapnet_amd import _C
-        from tests import backends as _test_backends
-        ctx = engine.Context(lib=_C.Lib(_test_backends.build_hostsim()), workspace_mb=64)
-    else:
-        torch.cuda.set_device(0)
-        ctx = engine.Context(device=0, workspace_mb=1024)
-    device_sync = ctx.sync if sim else torch.cuda.synchronize
+    torch.cuda.set_device(0)
+    ctx = engine.Context(device=0, workspace_mb=1024)
     B = 16 if args.batch == 32 else args.batch
     H, S = args.size, args.size
     W = args.size * 3 // 4 if (args.size * 3 // 4) % 64 == 0 else args.size // 2       # 4:3 at 256 (192); 2:1 where 4:3 is no multiple of 64
@@ -225,18 +218,18 @@ def bench_joint(args):
 
     for _ in range(args.warmup):
         one_step()
-    device_sync()
+    torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         one_step()
-    device_sync()
+    torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     ms = dt / args.steps * 1e3
     lw, lt = warp.losses(), tex.losses()
     out = {"metric": f"images/sec, joint warp + texture G+D steps (both GAN pairs in one process), {H}x{W} / {S}x{S}, bs={B}/GPU",
            "value": round(B * args.steps / dt, 3), "unit": "images/sec", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
            "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
-           "data": "synthetic" + ("; HOST SIMULATOR (SWAPNET_BENCH_HOSTSIM test hook): NOT a measurement" if sim else ""),
+           "data": "synthetic",
            "config": {"workload": f"BASELINE.json C5's shape on one GPU: warp-stage step at {H}x{W} then texture-stage step at {S}x{S} "
                                   f"(12 ROIs, L1 + VGG16 content + style), bs {B} each, train mode, fp32 storage, same kernels and "
                                   f"arithmetic as the C2 / C3 lines; one step = one optimize_parameters of each model",
@@ -284,25 +277,14 @@ def main():
     from swapnet_amd.modules import init_tensor
 
     local_rank = int(os.environ.get("SWAPNET_FORCE_DEVICE", os.environ.get("LOCAL_RANK", "0")))
-    # SWAPNET_BENCH_HOSTSIM=1 is a TEST HOOK (tests/test_data_parallel.py): the launch / exchange / reporting code of this file for
-    # N > 1 -- which no 1-GPU box ever executes -- run by two gloo ranks against the CI-only host simulator.  Never a measurement:
-    # the line says so, and nothing else in this file or the package selects the simulator.
-    sim = os.environ.get("SWAPNET_BENCH_HOSTSIM") == "1"
-    if not sim and not torch.cuda.is_available():
+    if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (swapnet_amd has no CPU path)")
-    if not sim:
-        torch.cuda.set_device(local_rank)            # before the process group: RCCL binds to the current device
+    torch.cuda.set_device(local_rank)            # before the process group: RCCL binds to the current device
     rank, world = parallel.init_from_env()
     assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     import torch.distributed as dist
 
-    if sim:
-        from swapnet_amd import _C
-        from tests import backends as _test_backends
-        ctx = engine.Context(lib=_C.Lib(_test_backends.build_hostsim()), workspace_mb=64)
-    else:
-        ctx = engine.Context(device=local_rank, workspace_mb=1024)
-    device_sync = ctx.sync if sim else torch.cuda.synchronize
+    ctx = engine.Context(device=local_rank, workspace_mb=1024)
     texture = args.stage == "texture"
     B, S = (16 if texture and args.batch == 32 else args.batch), args.size
     model = engine.NativeModel(ctx, args.stage, B, S, S, is_train=True, dropout=0.5)
@@ -362,7 +344,7 @@ def main():
     def fence():
         if world > 1:
             dist.barrier()
-        device_sync()
+        torch.cuda.synchronize()
 
     for _ in range(args.warmup):
         one_step()
@@ -373,11 +355,11 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], device="cpu" if sim else "cuda")
+        t = torch.tensor([dt], device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     if world > 1:          # every rank reports the device it drove (rank 0 prints them)
-        mine = [rank, local_rank if sim else torch.cuda.current_device()]
+        mine = [rank, torch.cuda.current_device()]
         gathered = [None] * world
         dist.all_gather_object(gathered, mine)
     losses = model.losses()
@@ -413,8 +395,7 @@ def main():
         "losses_finite": all(v == v and abs(v) < 1e30 for v in losses.values()),
         # proof of the launch shape for the driver's scaling table: ranks, the device each rank drives, the collective library
         "world": world,
-        "ranks": ([{"rank": rank, "device": local_rank if sim else torch.cuda.current_device(),
-                    "name": "HOST SIMULATOR (test hook, not a measurement)" if sim else torch.cuda.get_device_name()}] if world == 1 else None),
+        "ranks": ([{"rank": rank, "device": torch.cuda.current_device(), "name": torch.cuda.get_device_name()}] if world == 1 else None),
         "rccl_version": _rccl_version(),
         "dist_backend": (dist.get_backend() if dist.is_initialized() else None),
         "exchange": ("library-owned (swn_model_step_dp over the attached ncclAllReduce)" if native_comm[0] is not None
@@ -531,9 +512,7 @@ def main():
                 "all_gemm_kernels": {n: {"tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2),
                                          "ms_per_step": round(v["ms"] / nprof, 3)} for n, v in sorted(kernels.items())},
             }
-    if sim:
-        out["data"] = "synthetic; HOST SIMULATOR (SWAPNET_BENCH_HOSTSIM test hook): NOT a measurement"
-    if rank == 0 and (world > 1 or os.environ.get("SWAPNET_BENCH_PHASED") or rccl1) and not sim:
+    if rank == 0 and (world > 1 or os.environ.get("SWAPNET_BENCH_PHASED") or rccl1):
         # measured back-propagation time and gradient bytes of each exchange bucket (what engine.cpp's bucket boundaries are
         # sized on): HIP events around swn_model_backward_G_part, no exchange in between
         lab = draw_labels()
