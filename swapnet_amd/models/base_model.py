@@ -58,16 +58,26 @@ class BaseModel(ABC):
     def optimize_parameters(self):
         pass
 
+    # ---- small helpers: the reference keeps its networks / optimizers / losses / visuals as attributes named by prefix + name ----
+    def _attrs(self, prefix, names):
+        """(name, attribute) for every string in `names` (the reference's lists may hold non-string placeholders)."""
+        return [(n, getattr(self, prefix + n)) for n in names if isinstance(n, str)]
+
+    def _ckpt_file(self, directory, epoch, kind, name):
+        """`{epoch}_net_{name}.pth` / `{epoch}_optim_{name}.pth`: the reference's file names (base_model.py:156-173) -- API,
+        pretrained checkpoints are distributed under them."""
+        return os.path.join(directory, "%s_%s_%s.pth" % (epoch, kind, name))
+
     def setup(self, opt):
-        if not self.is_train or opt.continue_train:
+        """base_model.py:76-87: restore when testing / continuing, then report the networks."""
+        if opt.continue_train or not self.is_train:
             self.load_checkpoint_dir(opt.load_epoch)
         self.print_networks(opt.verbose)
         return self
 
     def eval(self):
-        for name in self.model_names:
-            if isinstance(name, str):
-                getattr(self, "net_" + name).eval()
+        for _, net in self._attrs("net_", self.model_names):
+            net.eval()
         return self
 
     def test(self):
@@ -82,73 +92,59 @@ class BaseModel(ABC):
         return self.image_paths
 
     def get_current_visuals(self):
-        visual_ret = OrderedDict()
-        for name in self.visual_names:
-            if isinstance(name, str):
-                visual_ret[name] = getattr(self, name)
-        return visual_ret
+        return OrderedDict(self._attrs("", self.visual_names))
 
     def get_current_losses(self):
         """One small D2H copy + sync per call (base_model.py:139-147 does float(loss) per name)."""
         self._fetch_losses()
-        errors_ret = OrderedDict()
-        for name in self.loss_names:
-            if isinstance(name, str):
-                errors_ret[name] = float(getattr(self, "loss_" + name))
-        return errors_ret
+        return OrderedDict((n, float(v)) for n, v in self._attrs("loss_", self.loss_names))
 
     def _fetch_losses(self):
         pass
 
     def save_checkpoint(self, epoch):
-        save_dir = self.save_dir
+        target = self.save_dir
         if self._dp_rank:
             # data-parallel replicas hold identical weights and optimizer state: rank 0's files are the checkpoint.
             # SWAPNET_SAVE_ALL_RANKS=1 (diagnostics / the lock-step test) makes the others write theirs to <save_dir>/rank<r>/
             if os.environ.get("SWAPNET_SAVE_ALL_RANKS") != "1":
                 return
-            save_dir = os.path.join(self.save_dir, f"rank{self._dp_rank}")
-            os.makedirs(save_dir, exist_ok=True)
-        for name in self.model_names:
-            if isinstance(name, str):
-                save_path = os.path.join(save_dir, f"{epoch}_net_{name}.pth")
-                net = getattr(self, f"net_{name}")
-                torch.save(net.state_dict(), save_path)          # CPU tensors, reference keys
-        for name in self.optimizer_names:
-            if isinstance(name, str):
-                save_path = os.path.join(save_dir, f"{epoch}_optim_{name}.pth")
-                torch.save(getattr(self, f"optimizer_{name}").state_dict(), save_path)
+            target = os.path.join(self.save_dir, "rank%d" % self._dp_rank)
+            os.makedirs(target, exist_ok=True)
+        for kind, prefix, names in (("net", "net_", self.model_names), ("optim", "optimizer_", self.optimizer_names)):
+            for name, obj in self._attrs(prefix, names):
+                torch.save(obj.state_dict(), self._ckpt_file(target, epoch, kind, name))          # CPU tensors, reference keys
 
     def load_model_weights(self, model_name, weights_file):
-        net = getattr(self, f"net_{model_name}")
-        print(f"loading the model {model_name} from {weights_file}")
-        state_dict = torch.load(weights_file, map_location="cpu")
-        if hasattr(state_dict, "_metadata"):
-            del state_dict._metadata
-        net.load_state_dict(state_dict)
+        print("restoring net_%s <- %s" % (model_name, weights_file))
+        weights = torch.load(weights_file, map_location="cpu")
+        if hasattr(weights, "_metadata"):           # (torch.save of a Module.state_dict() carries it; the native nets do not want it)
+            del weights._metadata
+        getattr(self, "net_" + model_name).load_state_dict(weights)
         return self
 
     def load_checkpoint_dir(self, epoch):
-        for name in self.model_names:
-            if isinstance(name, str):
-                self.load_model_weights(name, os.path.join(self.save_dir, f"{epoch}_net_{name}.pth"))
+        for name, _ in self._attrs("net_", self.model_names):
+            self.load_model_weights(name, self._ckpt_file(self.save_dir, epoch, "net", name))
         if self.is_train:
-            for name in self.optimizer_names:
-                if isinstance(name, str):
-                    load_path = os.path.join(self.save_dir, f"{epoch}_optim_{name}.pth")
-                    print(f"loading the optimizer {name} from {load_path}")
-                    getattr(self, f"optimizer_{name}").load_state_dict(torch.load(load_path, map_location="cpu"))
+            for name, optimizer in self._attrs("optimizer_", self.optimizer_names):
+                src = self._ckpt_file(self.save_dir, epoch, "optim", name)
+                print("restoring optimizer_%s <- %s" % (name, src))
+                optimizer.load_state_dict(torch.load(src, map_location="cpu"))
         return self
 
     def print_networks(self, verbose):
         print("---------- Networks initialized -------------")
-        for name in self.model_names:
-            if isinstance(name, str):
-                net = getattr(self, "net_" + name)
-                num_params = sum(int(torch.tensor(s).prod()) for s in net.native_param_shapes().values())
-                if verbose:
-                    print(net)
-                print("[Network %s] Total number of parameters : %.3f M" % (name, num_params / 1e6))
+        for name, net in self._attrs("net_", self.model_names):
+            count = 0
+            for shape in net.native_param_shapes().values():
+                n = 1
+                for d in shape:
+                    n *= int(d)
+                count += n
+            if verbose:
+                print(net)
+            print("[Network %s] Total number of parameters : %.3f M" % (name, count / 1e6))
         print("-----------------------------------------------")
 
     def set_requires_grad(self, nets, requires_grad=False):
