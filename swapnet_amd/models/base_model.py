@@ -2,10 +2,10 @@
 and inference.py call on a model.  Behaviour kept: attribute names, checkpoint file names
 (`{epoch}_net_{name}.pth`, `{epoch}_optim_{name}.pth`) and their state-dict key layout.
 
-This file is a RESTATEMENT of the reference's boundary class ("KEEP"): pure control plane --
-getters, checkpoint file naming, `setup` / `eval` / `test` / `print_networks` -- that the reference's unchanged train.py and
-inference.py call by name, so most of its methods necessarily read like the reference's.  Nothing here is on the hot path;
-it is not to grow (the step, the networks and the losses live behind the C ABI)."""
+This file restates the reference's boundary class ("KEEP"): pure control plane -- getters, checkpoint
+file naming, `setup` / `eval` / `test` / `print_networks` -- that the reference's unchanged train.py and inference.py call by
+name: the method names and signatures are the reference's, the bodies go through two small helpers (`_attrs`, `_ckpt_file`).
+Nothing here is on the hot path; it is not to grow (the step, the networks and the losses live behind the C ABI)."""
 import os
 from abc import ABC, abstractmethod
 from collections import OrderedDict
