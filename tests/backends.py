@@ -17,7 +17,15 @@ def build_hostsim():
     if os.path.exists(HOSTSIM_SO) and all(os.path.getmtime(d) <= os.path.getmtime(HOSTSIM_SO) for d in deps):
         return HOSTSIM_SO
     os.makedirs(os.path.dirname(HOSTSIM_SO), exist_ok=True)
-    subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-fopenmp", "-shared", "-o", HOSTSIM_SO] + _HOST_SOURCES)
+    # linked under a per-process name and renamed into place: concurrent builders (pytest-xdist workers, the two gloo ranks of the
+    # data-parallel tests) each publish a complete file, and nobody dlopens one that is still being written ("file too short")
+    tmp = "%s.%d.tmp" % (HOSTSIM_SO, os.getpid())
+    try:
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-fopenmp", "-shared", "-o", tmp] + _HOST_SOURCES)
+        os.replace(tmp, HOSTSIM_SO)
+    finally:
+        if os.path.exists(tmp):
+            os.unlink(tmp)
     return HOSTSIM_SO
 
 
