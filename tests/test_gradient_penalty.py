@@ -194,7 +194,15 @@ def test_gradient_penalty_at_other_patchgan_depths(backend, n_layers, tmp_path, 
         model.optimize_parameters()
         for k, v in model.get_current_losses().items():
             ref = float(gm[pre + "loss/" + k])
-            assert abs(v - ref) <= 1e-3 * abs(ref) + 1e-6, ("native", n_layers, mode, k, v, ref)
+            # G_gan = -mean(D_new(fake)) is taken with the discriminator AFTER its AdamW step: the first Adam step is lr * sign(g) for
+            # every element, so gradient elements near zero move their weight by +-lr whichever way rounding tips them (the post-step
+            # weights below are held to 2e-3 / 5e-3 for the same reason), and the mean of raw critic outputs cancels.  Measured on the
+            # MI355X at depth 2: 2.4e-3 of |G_gan|.  Losses formed BEFORE the update (D, D_real, D_fake, D_gp) and G_ce keep 1e-3.
+            tol = 5e-3 if k == "G_gan" else 1e-3
+            bound = tol * abs(ref) + 1e-6
+            if k == "G":
+                bound += 5e-3 * abs(float(gm[pre + "loss/G_gan"]))
+            assert abs(v - ref) <= bound, ("native", n_layers, mode, k, v, ref)
         dsd = model.net_discriminator.state_dict()
         for k in D:
             if k.endswith(".weight"):

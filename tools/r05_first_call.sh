@@ -37,13 +37,10 @@ tail -c 600 $O/bench_default.json
 timeout 200 python bench.py --stage joint --steps 10 --warmup 3 > $O/bench_joint.json 2> $O/bench_joint.err; echo "bench joint rc $?" | tee -a $O/rc.txt
 tail -c 400 $O/bench_joint.json
 timeout 60 tools/_bin/native_ab 32 256 10 0 prof > $O/native_prof.txt 2>&1; tail -30 $O/native_prof.txt
-for V in "X=0" "SWN_PC_MI=2" "X=1" "SWN_PC_MI=2 SWN_PC_MI_MIN_TILES=256" "SWAPNET_BENCH_RCCL1=1" "SWAPNET_BENCH_RCCL1=1 SWAPNET_NATIVE_COMM=1"; do
+timeout 200 python bench.py --stage joint --captured --steps 10 --warmup 3 > $O/bench_joint_cap.json 2> $O/bench_joint_cap.err; echo "bench joint captured rc $?" | tee -a $O/rc.txt
+tail -c 400 $O/bench_joint_cap.json
+for V in "X=0" "SWAPNET_BENCH_RCCL1=1" "SWAPNET_BENCH_RCCL1=1 SWAPNET_NATIVE_COMM=1"; do
   env $V timeout 200 python bench.py --steps 15 --warmup 4 --no-cpu-baseline --no-roofline 2> $O/ab.err | tail -1 | \
     python -c "import sys,json;d=json.loads(sys.stdin.read());print('$V', d['ms_per_step'], d['value'], d.get('exchange'))" >> $O/ab.txt
 done
 cat $O/ab.txt
-cd /tmp && export TMPDIR=/tmp
-SWN_PC_MI=2 SWN_OVERLAP=0 timeout 300 rocprofv3 --kernel-trace --stats -d $O/prof_mi2 -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline > $O/prof_mi2.log 2>&1
-cd $R
-python profiles/summarize_rocprof.py --out $O $O/prof_mi2 r05_mi2 > /dev/null 2>&1 || true
-grep -m6 'conv_fwd_pc' $O/rocprof_r05_mi2_kernel_stats.md
