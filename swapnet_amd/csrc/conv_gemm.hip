@@ -2673,6 +2673,20 @@ static DmaSched plan_dma(int tiles_total, int tiles_per_z, int work, int slots, 
   sc.full = rounds * slots; sc.tail_tiles = rem; sc.tail_s = 1; sc.per_split = work;
   if (cost_out) *cost_out = rounds * (work + 4.0) * unit;
   if (rem == 0) return sc;
+  // A remainder behind at least one whole round runs UN-SPLIT (round 5).  The two-plane loops are bound by the chip's power, not
+  // by issue (tools/tile_lab.hip: 1.13-1.24 GHz at > 85 % matrix-pipe occupancy on random operands, 2.1-2.4 GHz for the same
+  // launch with the matrix instructions removed): a last round that occupies few CUs runs at nearly twice the clock, and the
+  // split's slab round trip + reduce launch cost what it saves (36 Winograd planes of 512 x 1024 x 1024 = 1152 tiles on 1024
+  // slots: 128 us un-split in the lab, 135 + 13 us split in the product; whole C2 step -0.29 ms, profiles/native_ab_r05.txt).
+  // SWN_TAIL_SPLIT=0 restores the split (A/B; read per launch).
+  {
+    const char* e = getenv("SWN_TAIL_SPLIT");
+    if (rounds >= 1 && !(e && atoi(e) == 0)) {
+      sc.full = tiles_total; sc.tail_tiles = 0;
+      if (cost_out) *cost_out += (work + 4.0) * unit * 0.6;
+      return sc;
+    }
+  }
   // cost in units of one stage-time of a resident workgroup (32 MFMAs per wave, three waves sharing a SIMD: ~2.7 us):
   // tail rounds x (stages per unit + ~4 of prologue / epilogue) + the slab round trip of the split tiles at ~5 TB/s
   // (13.5 MB per unit) + the reduce launch.  Calibrated on the Winograd-plane launches of the warp step (M 800 x 36

@@ -155,7 +155,7 @@ int main(int argc, char** argv) {
   SW(swn_ctx_create(0, nullptr, 1, (size_t)1024 << 20, &ctx));
   SAY("ctx up at %.1f s\n", now() - t00);
 
-  const bool generic = argc > 5 && (!strcmp(argv[5], "bench") || !strcmp(argv[5], "ab") || !strcmp(argv[5], "prof"));
+  const bool generic = argc > 5 && (!strcmp(argv[5], "bench") || !strcmp(argv[5], "ab") || !strcmp(argv[5], "prof") || !strcmp(argv[5], "host"));
   if (!getenv("NATIVE_AB_SKIP_OPS") && !generic) {
     int big = H >= 256;
     op_case(ctx, "k4s2 64->128 (body_down2 / PatchGAN model.2 shape)", 0, big ? 8 : 2, 64, big ? 128 : 16, 128, big ? 64 : 8);
@@ -223,6 +223,24 @@ int main(int argc, char** argv) {
     double ms = plain_steps(K);
     say_losses(m, "bench");
     SAY("bench %.3f ms/step %.1f img/s (B %d, %d x %d, %d steps)\n", ms, B / ms * 1e3, B, H, H, K);
+    SW(swn_model_destroy(m)); SW(swn_ctx_destroy(ctx));
+    return 0;
+  }
+  if (argc > 5 && !strcmp(argv[5], "host")) {
+    // how long the HOST takes to enqueue one step (swn_model_step returning) against the GPU's time per step: host-bound or not
+    plain_steps(5);
+    SW(swn_ctx_sync(ctx));
+    double enq = 0, t0 = now();
+    for (int i = 0; i < K; i++) { const double a = now(); SW(swn_model_step(m, labels, 1, ++seed)); enq += now() - a; }
+    const double t_enq_done = now() - t0;
+    SW(swn_ctx_sync(ctx));
+    const double total = now() - t0;
+    SAY("host: %d steps: enqueue %.3f ms/step (all enqueued after %.3f ms), GPU done after %.3f ms = %.3f ms/step\n", K, enq * 1e3 / K, t_enq_done * 1e3,
+        total * 1e3, total * 1e3 / K);
+    // and from an idle GPU: one step enqueued after a sync (what a per-step host read-back of the losses sees)
+    double s1 = 0;
+    for (int i = 0; i < K; i++) { SW(swn_ctx_sync(ctx)); const double a = now(); SW(swn_model_step(m, labels, 1, ++seed)); SW(swn_ctx_sync(ctx)); s1 += now() - a; }
+    SAY("host: synchronised every step: %.3f ms/step\n", s1 * 1e3 / K);
     SW(swn_model_destroy(m)); SW(swn_ctx_destroy(ctx));
     return 0;
   }
