@@ -16,7 +16,11 @@ bucket's all-reduce overlaps the back-propagation of the earlier layers.
 
 Prints ONE JSON line (rank 0).  Extra objects:
   roofline     -- dominant kernel family: FLOPs the kernel EXECUTES (2*M*N*K per launch) / HIP-event time of
-                  those launches vs the 157.3 TFLOP/s fp32 MFMA peak (`frac`).  Whole step, two readings:
+                  those launches (`achieved`, fp32-equivalent TFLOP/s) vs `peak` = the nominal dense fp16 MFMA peak
+                  (2500 TFLOP/s) / the 16-bit MFMA products the kernel issues per fp32 product (3 in the two-plane
+                  form) -> `frac`.  `sustained` = what swn_probe_mfma measures in this run for the same instruction
+                  mix on register-resident operands (random / zero), with the shader clock read inside the kernel;
+                  `frac_of_sustained` = achieved against that.  Whole step, two readings:
                   `step_frac_executed` = executed (fp32-equivalent) FLOPs of all implicit-GEMM launches of one step /
                   step time / the fp32-MFMA peak (157.3) -- kept on that yardstick across rounds;
                   `algorithmic_speedup` = dense-conv FLOPs of the step (251.34 GFLOP/img)
@@ -49,12 +53,12 @@ SPLIT = os.environ.get("SWN_SPLIT", "1") != "0"
 PEAK_SPLIT_TFLOPS = round(PEAK_BF16_MFMA_TFLOPS / 6.0, 1)
 # The pre-cut forward-type ring kernel (conv_fwd_pc_*) takes its operands as TWO fp16 planes of (operand x 2^k), k from the
 # operand's amax: x = h + l, products h h + h l + l h = 3 fp16 MFMAs per fp32 product (same dense rate as bf16), error of the
-# dropped l l term 2^-22.  SWN_PC_PLANES=3 keeps the three-plane bf16 form (6 MFMAs) for that family as well.
-PC_PLANES = {"3": 3, "1": 1}.get(os.environ.get("SWN_PC_PLANES", "2"), 2)
+# dropped l l term 2^-22.  (The three-plane bf16 form of rounds 2-3 is gone from the library: round 5.)
+PC_PLANES = {"1": 1}.get(os.environ.get("SWN_PC_PLANES", "2"), 2)
 PEAK_PC_TFLOPS = round(PEAK_BF16_MFMA_TFLOPS / {1: 1.0, 2: 3.0}.get(PC_PLANES, 6.0), 1)
 # Round 4: the weight-gradient ring kernel takes the same two-plane form (both operands cut in the loop, scales from amax slots
-# their producers fill); SWN_WGRAD_PLANES=3 keeps its three bf16 planes.
-WGRAD_PLANES = {"3": 3, "1": 1}.get(os.environ.get("SWN_WGRAD_PLANES", "2"), 2)
+# their producers fill).
+WGRAD_PLANES = {"1": 1}.get(os.environ.get("SWN_WGRAD_PLANES", "2"), 2)
 
 
 def mfma16_per_product(kernel_name):
@@ -317,7 +321,9 @@ def main():
         return [float(torch.rand(1, generator=label_rng) * 0.4 + 0.7) for _ in range(3)]
 
     step_no = [0]
-    native_comm = [parallel.NativeComm(ctx) if (parallel.native_comm_requested() and (world > 1 or rccl1)) else None]
+    # N > 1 (or the 1-rank RCCL run): the library-owned exchange unless SWAPNET_NATIVE_COMM=0 -- agreed on by all ranks, with the
+    # torch.distributed all-reduce per bucket as the other form (parallel.open_native_comm); the line says which one ran
+    native_comm = [parallel.open_native_comm(ctx) if (parallel.native_comm_requested() and (world > 1 or rccl1)) else None]
 
     def one_step():
         lab = draw_labels()
@@ -327,7 +333,7 @@ def main():
             model.step(lab, training=True, seed=seed, captured=args.captured)
             return
         if native_comm[0] is not None:
-            # SWAPNET_NATIVE_COMM=1: the library drives RCCL's all-reduce itself (swn_model_step_dp; opt-in, see parallel.NativeComm)
+            # the library drives RCCL's all-reduce itself (swn_model_step_dp; parallel.NativeComm)
             model.step_dp(lab, training=True, seed=seed)
             return
         # (SWAPNET_BENCH_PHASED=1 runs this multi-GPU call sequence on one GPU, exchanges being no-ops, to
@@ -444,10 +450,10 @@ def main():
                        "conv_fwd_pc_128x128": "conv_fwd_pc_kernel<4, 4, 2, 4, %d>" % PC_PLANES,
                        "conv_fwd_pc_256x64": "conv_fwd_pc_kernel<8, 2, 3, 2, %d>" % PC_PLANES,
                        "conv_fwd_pc_128x192": "conv_fwd_pc_kernel<4, 6, 2, 2, %d>" % PC_PLANES,
-                       "conv_wgrad_dma_128x128": "conv_wgrad_dma_kernel<2, 2, %d>" % (0 if not SPLIT else (2 if WGRAD_PLANES == 2 else 1)),
-                       "conv_wgrad_dma_256x64": "conv_wgrad_dma_kernel<4, 1, %d>" % (0 if not SPLIT else (2 if WGRAD_PLANES == 2 else 1))}.get(dom.split("[")[0], dom)
+                       "conv_wgrad_dma_128x128": "conv_wgrad_dma_kernel<2, 2, %d>" % (0 if not SPLIT else (2 if WGRAD_PLANES == 2 else 3)),
+                       "conv_wgrad_dma_256x64": "conv_wgrad_dma_kernel<4, 1, %d>" % (0 if not SPLIT else (2 if WGRAD_PLANES == 2 else 3))}.get(dom.split("[")[0], dom)
             step_hbm = None
-            tnames = ("traffic_r04_texture.json",) if texture else ("traffic_r04.json",)
+            tnames = ("traffic_r05_texture.json", "traffic_r04_texture.json") if texture else ("traffic_r05.json", "traffic_r04.json")
             for tname in tnames + ("traffic_r03b.json", "traffic_r03.json", "traffic_r02b.json", "traffic_r02.json", "traffic_r01.json"):
                 tpath = os.path.join(REPO, "profiles", tname)
                 if os.path.exists(tpath):
@@ -482,8 +488,10 @@ def main():
                 "peak_definition": ("dense fp16 MFMA peak, 2500 TFLOP/s: one MFMA per product (one fp16 plane per operand)" if is_pc1 else
                                     "fp32-equivalent FLOP/s of the 16-bit matrix pipe for this kernel's formulation: 2500 TFLOP/s dense "
                                     "fp16 / 3 fp16 MFMA products per fp32 product (two amax-scaled fp16 planes per operand, fp32 "
-                                    "accumulate).  Nominal clock: with random operands the chip sustains 1.1-1.5 GHz in these loops "
-                                    "(profiles/ring_lab_r03_clock.txt), i.e. about half of this figure is reachable" if is_pc2 else
+                                    "accumulate).  NOMINAL 2.4 GHz figure: on random operands the chip grants these loops 1.13-1.24 GHz "
+                                    "(shader clock read INSIDE the kernel, tools/tile_lab.hip, profiles/tile_lab_r05*.txt) at 85-93 % "
+                                    "matrix-pipe occupancy, and twelve-MFMA rounds on register-resident operands alone -- no LDS, no HBM "
+                                    "-- sustain what `sustained` below reports from this very run; frac_of_sustained is against that" if is_pc2 else
                                     "fp32-equivalent FLOP/s of the bf16 matrix pipe for this kernel's formulation: 2500 TFLOP/s dense "
                                     "bf16 / 6 bf16 MFMA products per fp32 product (exact 3-way split, fp32 accumulate)" if is_split else
                                     "v_mfma_f32_32x32x2_f32 dense peak"),
@@ -491,8 +499,11 @@ def main():
                 # the yardstick of the round-2 / early round-3 lines (three bf16 planes, 6 MFMAs per product: 2500 / 6), so that the
                 # fp32-equivalent rate can be followed across rounds although this kernel's own roofline doubled with the two-plane form
                 "frac_of_bf16x6_roofline": round(ach / PEAK_SPLIT_TFLOPS, 4),
-                "power_note": ("six-term bf16 loop measured on the power cap: 1.06-1.3 GHz shader clock on random operands, 1.7-2.0 GHz on "
-                               "zeros, every loop variant within 3 % (profiles/ring_lab_r03_clock.txt, ring_lab_r03_variants.txt)"),
+                "power_note": ("the two-plane loop is bound by the chip's power, not by issue: in tools/tile_lab.hip (round 5) the shipped "
+                               "128x128 loop runs 1.13-1.24 GHz at 85-93 % matrix-pipe occupancy on random operands and 2.0-2.2 GHz on zeros; "
+                               "the same launch with its MFMAs removed 2.1-2.4 GHz; rocprofv3's GRBM_GUI_ACTIVE reads 1.90 GHz where the "
+                               "in-kernel counter and SQ_WAVE_CYCLES agree on 1.40 (profiles/clock_calibration_r05.txt): it is not the "
+                               "shader clock under MFMA load"),
                 # HBM side of the same step: bytes of the PMC passes (same source as `traffic`) over this run's step time, against
                 # the 6.3 TB/s the guide measures as achievable (8 TB/s spec)
                 "step_hbm_bytes": step_hbm,
@@ -512,6 +523,22 @@ def main():
                 "all_gemm_kernels": {n: {"tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2),
                                          "ms_per_step": round(v["ms"] / nprof, 3)} for n, v in sorted(kernels.items())},
             }
+    if rank == 0 and "roofline" in out:
+        # what the matrix pipe of THIS chip sustains for the ring kernels' instruction mix with the operands in registers
+        # (swn_probe_mfma: 1024 workgroups x 4 waves x rounds of 12 v_mfma_f32_32x32x16_f16, clock read inside the kernel)
+        import ctypes
+        sus = {}
+        for tag, zeros in (("random_operands", 0), ("zero_operands", 1)):
+            o4 = (ctypes.c_float * 4)()
+            ctx.lib.call("swn_probe_mfma", ctx.handle, zeros, 4096, o4)
+            sus[tag] = {"fp16_tflops": round(o4[0], 1), "shader_clock_ghz": round(o4[1], 3), "ms": round(o4[2], 3),
+                        "pipe_occupancy_at_that_clock": round(o4[3], 3)}
+        r = out["roofline"]
+        r["sustained"] = sus
+        per_product = mfma16_per_product(r["kernel"])
+        if sus["random_operands"]["fp16_tflops"] > 0 and per_product:
+            r["sustained"]["fp32_equivalent_tflops"] = round(sus["random_operands"]["fp16_tflops"] / per_product, 1)
+            r["frac_of_sustained"] = round(r["achieved"] * per_product / sus["random_operands"]["fp16_tflops"], 4)
     if rank == 0 and (world > 1 or os.environ.get("SWAPNET_BENCH_PHASED") or rccl1):
         # measured back-propagation time and gradient bytes of each exchange bucket (what engine.cpp's bucket boundaries are
         # sized on): HIP events around swn_model_backward_G_part, no exchange in between
@@ -584,6 +611,9 @@ def main():
     libc.fflush(None)
     if world > 1 or rccl1:
         dist.barrier()
+        if native_comm[0] is not None:        # the library's communicator goes before the process group it was bootstrapped over
+            native_comm[0].close()
+            native_comm[0] = None
         dist.destroy_process_group()
         libc.fflush(None)
     if rank == 0:

@@ -39,7 +39,7 @@ typedef struct swn_ctx swn_ctx;
 typedef struct swn_model swn_model;
 
 int swn_abi_version(void);   /* 2: swn_hyper gained d_b1, d_b2; 3: gp_mode, lambda_gp; 4: swn_route_*, swn_model_step_captured, swn_model_create_shared;
-                                5: swn_ctx_attach_comm, swn_model_step_dp */
+                                5: swn_ctx_attach_comm, swn_model_step_dp; 6: swn_probe_mfma */
 const char* swn_last_error(void);
 /* 1 when this library executes on a HIP device (libswapnet_hip.so), 0 for the CI simulator */
 int swn_is_device_build(void);
@@ -73,6 +73,14 @@ int swn_ctx_bytes_allocated(swn_ctx* ctx, size_t* out);
 int swn_prof_enable(int on);
 int swn_prof_reset(void);
 int swn_prof_report(char* buf, int len);
+/* What the matrix pipe of THIS chip sustains for the arithmetic of the ring kernels ("Builder must confirm peaks on
+ * the box"; bench.py's roofline object quotes it beside the nominal 2.5 PFLOP/s): `iters` rounds of the product loop's twelve
+ * v_mfma_f32_32x32x16_f16 per wave (4 accumulators x 3 terms) on operand fragments that stay in registers -- no LDS, no HBM --
+ * 1024 workgroups x 4 waves, zeros = 0: pseudo-random fp16 operands (what a training step multiplies), 1: all-zero operands (the
+ * clock the same code gets when the multipliers do not toggle).  out[0] = fp16 TFLOP/s, out[1] = the shader clock in GHz measured
+ * INSIDE the kernel (s_memtime over s_memrealtime), out[2] = ms per launch, out[3] = matrix-pipe occupancy at that clock (0..1).
+ * Replaces nothing in the reference (measurement only); synchronises. */
+int swn_probe_mfma(swn_ctx* ctx, int zeros, int iters, float* out4);
 /* Routing trace: which kernel family / algorithmic form each layer takes under the CURRENT environment (the SWN_* switches of
  * DESIGN.md section 4 select among kernels; models/base_gan.py:194-203 is the step whose launches are listed).  While on, every
  * implicit-GEMM launch (name, M, N, K, batch, split schedule) and every Winograd transform is recorded against the layer

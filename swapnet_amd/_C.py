@@ -41,6 +41,7 @@ _PROTOS = {
     "swn_prof_enable": ([_i], _i),
     "swn_prof_reset": ([], _i),
     "swn_prof_report": ([C.c_char_p, _i], _i),
+    "swn_probe_mfma": ([_vp, _i, _i, C.POINTER(C.c_float)], _i),
     "swn_route_trace": ([_i], _i),
     "swn_route_report": ([C.c_char_p, _i], _i),
     "swn_warp_model_create": ([_vp, _i, _i, _i, _i, _f, C.POINTER(_vp)], _i),

@@ -57,7 +57,7 @@ static int guard(F f) {
 
 extern "C" {
 
-int swn_abi_version(void) { return 5; }
+int swn_abi_version(void) { return 6; }
 const char* swn_last_error(void) { return g_err.c_str(); }
 int swn_is_device_build(void) { return is_device_build(); }
 
@@ -115,6 +115,13 @@ int swn_ctx_bytes_allocated(swn_ctx* ctx, size_t* out) {
 int swn_prof_enable(int on) { return guard([&] { prof_enable(on); }); }
 int swn_prof_reset(void) { return guard([&] { prof_reset(); }); }
 int swn_prof_report(char* buf, int len) { return prof_report(buf, len); }
+int swn_probe_mfma(swn_ctx* ctx, int zeros, int iters, float* out4) {
+  return guard([&] {
+    REQUIRE(ctx && out4, "swn_probe_mfma: NULL argument");
+    REQUIRE(iters >= 1 && iters <= (1 << 20), "swn_probe_mfma: iters out of range");
+    probe_mfma(ctx->c->s, zeros, iters, out4);
+  });
+}
 int swn_route_trace(int on) { return guard([&] { route_enable(on); }); }
 int swn_route_report(char* buf, int len) { return route_report(buf, len); }
 

@@ -831,14 +831,14 @@ __global__ __launch_bounds__(1024) void amax_partials_kernel(const float* x, siz
   }
 }
 
-template <int WGM, int NB, int NSTG, int PL = 3>
+template <int WGM, int NB, int NSTG, int PL = 2>
 struct PcTile {
   static constexpr int NW = WGM, BM = 32 * WGM, BN = 32 * NB, BK = 16, NST = NSTG;
   static constexpr int A_BYTES = BM * BK * 4, B_BYTES = 2 * PL * BN * 16, ST_BYTES = A_BYTES + B_BYTES;
   static constexpr int APC = A_BYTES / 1024, BPC = B_BYTES / 1024;
   static constexpr int AI = APC / WGM, BI = BPC / WGM, BREM = BPC % WGM;   // pieces per wave; waves < BREM carry one more of B
   static constexpr int SMEM = NST * ST_BYTES;
-  static_assert(APC % WGM == 0 && NB % 2 == 0 && (PL == 1 || PL == 2 || PL == 3), "tile shape");
+  static_assert(APC % WGM == 0 && NB % 2 == 0 && (PL == 1 || PL == 2), "tile shape");
 };
 
 // WGCU = workgroups per CU the tile is sized for (LDS) -> waves per SIMD the register allocation must allow
@@ -878,7 +878,7 @@ __global__ __launch_bounds__(64 * WGM, WGCU * WGM / 4) void conv_fwd_pc_kernel(G
   const unsigned lds0 = (unsigned)(size_t)(lds_ptr_t)smem_c;
   // two-plane form: the power-of-two operand scales (A from the partial maxima of this launch, B from the panel's trailer)
   int kA = 0, kB = 0;
-  if constexpr (PL <= 2) {
+  {
     if constexpr (APAIR) kA = __builtin_amdgcn_readfirstlane(*a_kscale);
     else kA = __builtin_amdgcn_readfirstlane(scale_exp(amax256(a_amax, lane), PC_TOP_A));
     kB = *reinterpret_cast<const int*>(wpc + (size_t)nkb_all * (b_stage / 2));
@@ -981,22 +981,7 @@ __global__ __launch_bounds__(64 * WGM, WGCU * WGM / 4) void conv_fwd_pc_kernel(G
       }
       return;
     }
-    u32x4 bh[NB], bm[NB], bl[NB];
-#pragma unroll
-    for (int j = 0; j < NB; ++j) {
-      bh[j] = *reinterpret_cast<const u32x4*>(S + b_rd + (0 * BN + 32 * j) * 16);
-      bm[j] = *reinterpret_cast<const u32x4*>(S + b_rd + (1 * BN + 32 * j) * 16);
-      bl[j] = *reinterpret_cast<const u32x4*>(S + b_rd + (2 * BN + 32 * j) * 16);
-    }
-    u32x4 ah, am, al;
-    split8(af, ah, am, al);
-#pragma unroll
-    for (int j = 0; j < NB; ++j) {
-      f32x16 c = acc[j];
-      c = mma_bf16(al, bh[j], c); c = mma_bf16(ah, bl[j], c); c = mma_bf16(am, bm[j], c);        // smallest terms first
-      c = mma_bf16(am, bh[j], c); c = mma_bf16(ah, bm[j], c); c = mma_bf16(ah, bh[j], c);
-      acc[j] = c;
-    }
+    static_assert(PL == 1 || PL == 2, "one or two fp16 planes");
   };
 
   if (kb_begin < kb_end) {
@@ -1025,7 +1010,7 @@ __global__ __launch_bounds__(64 * WGM, WGCU * WGM / 4) void conv_fwd_pc_kernel(G
     }
   }
 
-  if constexpr (PL <= 2) {                                // remove the operand scales (two exact power-of-two factors)
+  {                                                       // remove the operand scales (two exact power-of-two factors)
     const float ca = pow2f(-kA), cb = pow2f(-kB);
 #pragma unroll
     for (int j = 0; j < NB; ++j)
@@ -1102,252 +1087,8 @@ __global__ __launch_bounds__(64 * WGM, WGCU * WGM / 4) void conv_fwd_pc_kernel(G
 #endif
 }
 
-// ---- 64-row wave tiles (round 4, late; tools/ring_lab.hip gemm_h<4, 2, 4, 2, 2, .>: "h2 256x128 4wv x64r") --------------------
-// Two-plane form only.  Each of the WGM waves owns MI fragments of 32 rows x all BN columns: one set of B fragments read from
-// LDS feeds 3 MI MFMAs instead of 3, and a 16-k stage of the (32 MI WGM) x BN tile moves BM 64 + 8 KB into LDS for 3 MI NB
-// MFMAs per wave.  At 256 x 128 (MI 2, WGM 4, NB 4): 24 KB in, 48 KB of fragment reads, 24 MFMAs per wave and stage -- 576
-// LDS cycles against 768 matrix cycles per SIMD, where the 128 x 128 tile spends 448 against 384.
-// 128 accumulator registers per wave: 2 workgroups (8 waves) per CU.  Same operand layouts, schedule (DmaSched), split-K slabs
-// and epilogue as conv_fwd_pc_kernel; the A pieces a wave loads are its own rows, so only the B share is waited for across
-// waves.  OPT-IN (SWN_PC_MI=2): written after the round's GPU budget was spent -- compiled for gfx950, never executed.
-template <int WGM, int MI, int NB, int NSTG>
-struct PcmTile {
-  static constexpr int NW = WGM, BM = 32 * MI * WGM, BN = 32 * NB, BK = 16, NST = NSTG, PL = 2;
-  static constexpr int A_BYTES = BM * BK * 4, B_BYTES = 2 * PL * BN * 16, ST_BYTES = A_BYTES + B_BYTES;
-  static constexpr int APC = A_BYTES / 1024, BPC = B_BYTES / 1024;
-  static constexpr int AI = APC / WGM, BI = BPC / WGM;          // 1 KB pieces (16 rows x 64 B; 64 lanes x 16 B) per wave
-  static constexpr int SMEM = NST * ST_BYTES;
-  static_assert(APC % WGM == 0 && BPC % WGM == 0 && NB % 2 == 0 && AI == 2 * MI, "tile shape");
-};
-
-template <int WGM, int MI, int NB, int NSTG, int WGCU, bool APAIR>
-__global__ __launch_bounds__(64 * WGM, WGCU * WGM / 4) void conv_fwd_pcm_kernel(GemmP p, DmaSched sc, const unsigned short* wpc, size_t wpc_bs,
-                                                                                const float* a_amax, const int* a_kscale) {
-#if defined(__HIP_DEVICE_COMPILE__)
-  using T = PcmTile<WGM, MI, NB, NSTG>;
-  constexpr int BM = T::BM, BN = T::BN, BK = T::BK, NST = T::NST, AI = T::AI, BI = T::BI, PL = 2;
-  extern __shared__ __attribute__((aligned(16))) char smem_c[];
-  const int t = threadIdx.x, lane = t & 63;
-  const int wid = __builtin_amdgcn_readfirstlane(t >> 6);
-
-  // ---- work unit -> (tile, K range)
-  int u = blockIdx.x, gtile, split = 0, nsplit = 1, tt = 0;
-  if (u < sc.full) {
-    gtile = xcd_swizzle(u, sc.full);
-  } else {
-    u -= sc.full;
-    tt = u / sc.tail_s; split = u - tt * sc.tail_s; nsplit = sc.tail_s;
-    gtile = sc.full + tt;
-  }
-  const int z = gtile / sc.tiles_per_z, tile = gtile - z * sc.tiles_per_z;
-  const int tile_n = tile % p.tiles_n, tile_m = tile / p.tiles_n;
-  const int m0 = tile_m * BM, n0 = tile_n * BN;
-  p.x += (size_t)z * p.x_bs; p.y += (size_t)z * p.y_bs;
-  wpc += (size_t)z * wpc_bs;
-  if (p.phases) { const int a = z >> 1, b = z & 1; p.pad_t -= a; p.pad_l -= b; p.yoff = a; p.xoff = b; }
-  const int nkb_all = p.K / BK;
-  const int kb_begin = nsplit > 1 ? split * sc.per_split : 0;
-  const int kb_end = nsplit > 1 ? min(nkb_all, kb_begin + sc.per_split) : nkb_all;
-
-  const unsigned x_bytes = (unsigned)((((size_t)p.xH * p.xW * (size_t)(p.M / (p.Ho * p.Wo)) - 1) * p.xcs + p.xC) * 4);
-  const unsigned b_stage = (unsigned)p.tiles_n * T::B_BYTES;        // bytes of one 16-k stage of the pre-cut panel
-  const i32x4 rsA = make_rsrc(p.x, x_bytes), rsB = make_rsrc(wpc, (unsigned)nkb_all * b_stage);
-  const unsigned lds0 = (unsigned)(size_t)(lds_ptr_t)smem_c;
-  int kA;
-  if constexpr (APAIR) kA = __builtin_amdgcn_readfirstlane(*a_kscale);
-  else kA = __builtin_amdgcn_readfirstlane(scale_exp(amax256(a_amax, lane), PC_TOP_A));
-  const int kB = *reinterpret_cast<const int*>(wpc + (size_t)nkb_all * (b_stage / 2));
-  const float sa = pow2f(kA);
-
-  // ---- loader state.  A: this lane owns AI rows of its OWN wave's 32 MI (row = 32 MI wid + 16 r + lane / 4) and one swizzled chunk.
-  int a_iy0[AI], a_ix0[AI], a_base[AI];
-  unsigned a_voff[AI];
-  const int HoWo = p.Ho * p.Wo;
-  const int He = p.xH << p.ups, We = p.xW << p.ups;
-#pragma unroll
-  for (int r = 0; r < AI; ++r) {
-    const int row = 16 * (wid * AI + r) + (lane >> 2);
-    const int m = m0 + row;
-    if (m < p.M) {
-      const int n = m / HoWo, rem = m - n * HoWo;
-      const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
-      a_iy0[r] = oy * p.stride - p.pad_t;
-      a_ix0[r] = ox * p.stride - p.pad_l;
-      a_base[r] = n * p.xH * p.xW * p.xcs + 4 * ((lane & 3) ^ ((row >> 2) & 3));
-    } else {
-      a_iy0[r] = 0; a_ix0[r] = 0; a_base[r] = -1;
-    }
-  }
-  auto set_tap = [&](int tap) {
-    const int kh = tap / p.KW, kw = tap - kh * p.KW;
-#pragma unroll
-    for (int r = 0; r < AI; ++r) {
-      unsigned off = DMA_OOB;
-      if (a_base[r] >= 0) {
-        const int sy = src_coord(a_iy0[r] + kh, He, p.pad_mode, p.ups);
-        const int sx = src_coord(a_ix0[r] + kw, We, p.pad_mode, p.ups);
-        if (sy >= 0 && sx >= 0) off = (unsigned)(a_base[r] + (sy * p.xW + sx) * p.xcs) * 4u;
-      }
-      a_voff[r] = off;
-    }
-  };
-  int ld_tap = (kb_begin * BK) / p.xC, ld_ci = kb_begin * BK - ld_tap * p.xC;
-  set_tap(ld_tap);
-  const unsigned b_voff = (unsigned)lane * 16u;
-  const unsigned b_tile = (unsigned)tile_n * T::B_BYTES;
-  auto issue = [&](int st, int kb) {
-    const unsigned S = lds0 + (unsigned)(st * T::ST_BYTES), SB = S + T::A_BYTES;
-    const unsigned bsrc = (unsigned)kb * b_stage + b_tile;
-#pragma unroll
-    for (int r = 0; r < AI; ++r) lds_dma16c(a_voff[r], rsA, (unsigned)ld_ci * 4u, S + (unsigned)(wid * AI + r) * 1024u);
-#pragma unroll
-    for (int r = 0; r < BI; ++r) lds_dma16c(b_voff, rsB, bsrc + (unsigned)(wid * BI + r) * 1024u, SB + (unsigned)(wid * BI + r) * 1024u);
-    ld_ci += BK;
-    if (ld_ci >= p.xC) { ld_ci = 0; ld_tap += 1; if (ld_tap < p.KH * p.KW) set_tap(ld_tap); }
-  };
-
-  f32x16 acc[MI][NB];
-#pragma unroll
-  for (int i = 0; i < MI; ++i)
-#pragma unroll
-    for (int j = 0; j < NB; ++j)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-
-  const int h = lane >> 5, l31 = lane & 31;
-  const int f = (l31 >> 2) & 3;
-  const int a_rd = (wid * 32 * MI + l31) * 64;                              // + i * 32 * 64
-  const int a_c0 = ((2 * h) ^ f) * 16, a_c1 = ((2 * h + 1) ^ f) * 16;
-  const int b_rd = T::A_BYTES + (h * PL * BN + l31) * 16;                  // + (plane * BN + 32 j) * 16
-  auto compute = [&](int st) {
-    const char* S = smem_c + st * T::ST_BYTES;
-    u32x4 ah[MI], al[MI];
-#pragma unroll
-    for (int i = 0; i < MI; ++i) {
-      const float4 v0 = *reinterpret_cast<const float4*>(S + a_rd + i * 2048 + a_c0);
-      const float4 v1 = *reinterpret_cast<const float4*>(S + a_rd + i * 2048 + a_c1);
-      const float af[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-      if constexpr (APAIR) pair8(af, ah[i], al[i]);
-      else split8h(af, sa, ah[i], al[i]);
-    }
-#pragma unroll
-    for (int j = 0; j < NB; ++j) {
-      const u32x4 bh = *reinterpret_cast<const u32x4*>(S + b_rd + (0 * BN + 32 * j) * 16);
-      const u32x4 bl = *reinterpret_cast<const u32x4*>(S + b_rd + (1 * BN + 32 * j) * 16);
-#pragma unroll
-      for (int i = 0; i < MI; ++i) {
-        f32x16 c = acc[i][j];
-        c = mma_f16(al[i], bh, c); c = mma_f16(ah[i], bl, c); c = mma_f16(ah[i], bh, c);          // smallest terms first
-        acc[i][j] = c;
-      }
-    }
-  };
-
-  if (kb_begin < kb_end) {
-#pragma unroll
-    for (int s = 0; s < NST - 1; ++s)
-      if (kb_begin + s < kb_end) issue(s, kb_begin + s);
-    int st = 0;
-    for (int kb = kb_begin; kb < kb_end; ++kb) {
-      // this wave's share of stage kb has landed: only the (at most NST - 2) younger stages may still be in flight
-      const int younger = min(NST - 2, kb_end - 1 - kb);
-      if (younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(2 * (AI + BI)) : "memory");
-      else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(AI + BI) : "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();          // everybody's share of B landed; everybody finished reading stage kb - 1
-      asm volatile("" ::: "memory");
-      int stn = st + NST - 1; if (stn >= NST) stn -= NST;
-      if (kb + NST - 1 < kb_end) issue(stn, kb + NST - 1);
-      compute(st);
-      st = st + 1 == NST ? 0 : st + 1;
-    }
-  }
-
-  {                                                       // remove the operand scales (two exact power-of-two factors)
-    const float ca = pow2f(-kA), cb = pow2f(-kB);
-#pragma unroll
-    for (int i = 0; i < MI; ++i)
-#pragma unroll
-      for (int j = 0; j < NB; ++j)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[i][j][e] = (acc[i][j][e] * ca) * cb;
-  }
-  // ---- epilogue.  lane: rows wid*32*MI + 32 i + (e&3) + 8*(e>>2) + 4*h, columns n0 + NB*l31 + j
-  const int colr = NB * l31;
-  if (nsplit > 1) {
-    float* slab = p.slab + ((size_t)(tt * nsplit + split) * BM) * BN;
-#pragma unroll
-    for (int i = 0; i < MI; ++i)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int row = wid * 32 * MI + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * h;
-        float* dst = slab + (size_t)row * BN + colr;
-        if constexpr (NB == 4) *reinterpret_cast<float4*>(dst) = make_float4(acc[i][0][e], acc[i][1][e], acc[i][2][e], acc[i][3][e]);
-        else {
-#pragma unroll
-          for (int j = 0; j < NB; j += 2) *reinterpret_cast<float2*>(dst + j) = make_float2(acc[i][j][e], acc[i][j + 1][e]);
-        }
-      }
-    return;
-  }
-  __syncthreads();                                      // the ring is dead: reuse it for the per-row output offsets
-  int* rowoff = reinterpret_cast<int*>(smem_c);
-  for (int r = t; r < BM; r += 64 * WGM) {
-    const int m = m0 + r;
-    int off = -1;
-    if (m < p.M) {
-      const int n = m / HoWo, rem = m - n * HoWo;
-      const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
-      off = ((n * p.yH + oy * p.ymul + p.yoff) * p.yW + ox * p.xmul + p.xoff) * p.ycs;
-    }
-    rowoff[r] = off;
-  }
-  __syncthreads();
-  const int col = n0 + colr;
-  float am = 0.f;
-  if (col < p.Cout) {
-    float bj[NB];
-#pragma unroll
-    for (int j = 0; j < NB; ++j) bj[j] = (p.bias && col + j < p.Cout) ? p.bias[col + j] : 0.f;
-    const bool full = col + NB - 1 < p.Cout;
-#pragma unroll
-    for (int i = 0; i < MI; ++i)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int off = rowoff[wid * 32 * MI + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * h];
-        if (off < 0) continue;
-        float v[NB];
-#pragma unroll
-        for (int j = 0; j < NB; ++j) v[j] = act_apply(acc[i][j][e] + bj[j], p.act);
-        float* dst = p.y + (size_t)off + col;
-        if (full) {
-          if constexpr (NB == 4) {
-            float4 o = make_float4(v[0], v[1], v[2], v[3]);
-            if (p.accumulate) { const float4 q = *reinterpret_cast<const float4*>(dst); o.x += q.x; o.y += q.y; o.z += q.z; o.w += q.w; }
-            *reinterpret_cast<float4*>(dst) = o;
-            am = fmaxf(am, f4amax(o));
-          } else {
-#pragma unroll
-            for (int j = 0; j < NB; j += 2) {
-              float2 o = make_float2(v[j], v[j + 1]);
-              if (p.accumulate) { const float2 q = *reinterpret_cast<const float2*>(dst + j); o.x += q.x; o.y += q.y; }
-              *reinterpret_cast<float2*>(dst + j) = o;
-              am = fmaxf(am, fmaxf(fabsf(o.x), fabsf(o.y)));
-            }
-          }
-        } else {
-#pragma unroll
-          for (int j = 0; j < NB; ++j)
-            if (col + j < p.Cout) { const float o = p.accumulate ? dst[j] + v[j] : v[j]; dst[j] = o; am = fmaxf(am, fabsf(o)); }
-        }
-      }
-  }
-  if (p.y_amax) amax_fold_wave(am, p.y_amax, blockIdx.x * WGM + wid);        // (every wave arrives here converged)
-#endif
-}
-
-// producer of the pre-cut operand: one thread per (k / 8, tile_n, pos) writes the 16-byte plane entries (three bf16 planes, or --
-// wamax != NULL -- two fp16 planes of w * 2^kB with kB from the 256 partial maxima of the source, stored in the panel's trailer)
+// producer of the pre-cut operand: one thread per (k / 8, tile_n, pos) writes the 16-byte plane entries: two fp16 planes (one in the
+// reduced-precision configuration) of w * 2^kB with kB from the 256 partial maxima of the source, stored in the panel's trailer
 __global__ __launch_bounds__(256) void conv_precut_kernel(const float* w, unsigned short* out, int K, int Npad, int BN, size_t w_bs,
                                                           size_t out_bs, const float* wamax, int planes) {
   const int NBc = BN / 32;
@@ -1380,27 +1121,7 @@ __global__ __launch_bounds__(256) void conv_precut_kernel(const float* w, unsign
     o[base + pos] = u32x4{hi[0], hi[1], hi[2], hi[3]};
     if (planes == 2) o[base + (size_t)BN + pos] = u32x4{lo[0], lo[1], lo[2], lo[3]};
     if (i == 0) *reinterpret_cast<int*>(out + (size_t)(K / 16) * tiles_n * 2 * planes * BN * 8) = kB;
-    return;
   }
-  unsigned hi[4], mid[4], lo[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    float x[2];
-#pragma unroll
-    for (int e = 0; e < 2; ++e) x[e] = n < Npad ? w[(size_t)(kq * 8 + 2 * j + e) * Npad + n] : 0.f;
-    const unsigned u0 = __float_as_uint(x[0]), u1 = __float_as_uint(x[1]);
-    const float r0 = x[0] - __uint_as_float(u0 & 0xffff0000u), r1 = x[1] - __uint_as_float(u1 & 0xffff0000u);
-    const unsigned v0 = __float_as_uint(r0), v1 = __float_as_uint(r1);
-    const float s0 = r0 - __uint_as_float(v0 & 0xffff0000u), s1 = r1 - __uint_as_float(v1 & 0xffff0000u);
-    hi[j] = (u0 >> 16) | (u1 & 0xffff0000u);
-    mid[j] = (v0 >> 16) | (v1 & 0xffff0000u);
-    lo[j] = (__float_as_uint(s0) >> 16) | (__float_as_uint(s1) & 0xffff0000u);
-  }
-  // [stage = kq / 2][tile_n][kq & 1][plane][pos][8 bf16]
-  const size_t base = ((((size_t)(kq >> 1) * tiles_n + tn) * 2 + (kq & 1)) * 3) * BN;
-  o[base + pos] = u32x4{hi[0], hi[1], hi[2], hi[3]};
-  o[base + (size_t)BN + pos] = u32x4{mid[0], mid[1], mid[2], mid[3]};
-  o[base + 2 * (size_t)BN + pos] = u32x4{lo[0], lo[1], lo[2], lo[3]};
 }
 
 // ---------------------------------------------------------------------------------------
@@ -2318,9 +2039,8 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_wgrad_dma_kernel(GemmP p,
         }
     } else if constexpr (SPLIT == 2) {
       split_mma_2x2_h(acc, af, bf, sx, sy);
-    } else if constexpr (SPLIT == 1) {
-      split_mma_2x2(acc, af, bf);
     } else {
+      static_assert(SPLIT == 0, "0: f32 MFMA, 2: two fp16 planes, 3: one fp16 plane");
 #pragma unroll
       for (int s8 = 0; s8 < 8; ++s8)
 #pragma unroll
@@ -2503,6 +2223,72 @@ struct ProfScope {
   }
 };
 }  // namespace
+// ---- swn_probe_mfma: what the matrix pipe sustains for the ring kernels' instruction mix, operands in registers ----------------
+__global__ __launch_bounds__(256, 4) void mfma_probe_kernel(int iters, int zeros, unsigned long long* clk, float* sink) {
+  unsigned long long c0 = 0, r0 = 0;
+  const bool me = blockIdx.x % 61 == 0 && blockIdx.x / 61 < 16 && threadIdx.x == 0;
+  if (me) { c0 = __builtin_readcyclecounter(); r0 = __builtin_amdgcn_s_memrealtime(); }
+  // fp16 bit patterns from a per-lane hash: sign, exponents 2^-3 .. 2^0, random mantissas (finite, products stay far from overflow)
+  unsigned h = (blockIdx.x * 256u + threadIdx.x) * 2654435761u + 12345u;
+  auto word = [&]() {
+    h = h * 1664525u + 1013904223u;
+    const unsigned lo = (h >> 3) & 0x83ffu, hi = (h >> 17) & 0x83ffu;
+    return zeros ? 0u : ((lo | 0x3000u | ((h & 3u) << 10)) | ((hi | 0x3000u | (((h >> 2) & 3u) << 10)) << 16));
+  };
+  u32x4 ah, al, bh[4], bl[4];
+  for (int q = 0; q < 4; ++q) { ah[q] = word(); al[q] = word(); }
+  for (int j = 0; j < 4; ++j) for (int q = 0; q < 4; ++q) { bh[j][q] = word(); bl[j][q] = word(); }
+  f32x16 acc[4];
+  for (int j = 0; j < 4; ++j) for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[j] = mma_f16(al, bh[j], acc[j]);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[j] = mma_f16(ah, bl[j], acc[j]);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[j] = mma_f16(ah, bh[j], acc[j]);
+    asm volatile("" ::: "memory");
+  }
+  float t = 0.f;
+  for (int j = 0; j < 4; ++j) for (int e = 0; e < 16; ++e) t += acc[j][e];
+  if (t == 12345.678f) sink[0] = t;                                  // (keeps the accumulators alive)
+  if (me) { clk[2 * (blockIdx.x / 61)] = __builtin_readcyclecounter() - c0; clk[2 * (blockIdx.x / 61) + 1] = __builtin_amdgcn_s_memrealtime() - r0; }
+}
+void probe_mfma(Stream& s, int zeros, int iters, float* out4) {
+  if (!s.ws || s.ws_bytes < 4096) throw Error(1, "probe_mfma: the stream scratch is missing");
+  unsigned long long* clk = reinterpret_cast<unsigned long long*>(s.ws);
+  float* sink = reinterpret_cast<float*>(s.ws + 512);
+  const int blocks = 1024;
+  hipEvent_t e0, e1;
+  SWN_HIP_CHECK(hipEventCreate(&e0)); SWN_HIP_CHECK(hipEventCreate(&e1));
+  // steady state, not a burst: the chip's power management settles over milliseconds (a single launch after an idle gap runs
+  // 30-40 % faster than the same launch inside a train of them).  Twelve launches back to back; the last six are timed.
+  constexpr int WARM = 6, TIMED = 6;
+  SWN_HIP_CHECK(hipMemsetAsync(clk, 0, 256, hs(s)));
+  for (int rep = 0; rep < WARM + TIMED; ++rep) {
+    if (rep == WARM) SWN_HIP_CHECK(hipEventRecord(e0, hs(s)));
+    hipLaunchKernelGGL(mfma_probe_kernel, dim3(blocks), dim3(256), 0, hs(s), iters, zeros, clk, sink);
+  }
+  SWN_HIP_CHECK(hipEventRecord(e1, hs(s)));
+  SWN_HIP_CHECK(hipEventSynchronize(e1));
+  float best = 0.f; SWN_HIP_CHECK(hipEventElapsedTime(&best, e0, e1));
+  best /= TIMED;
+  SWN_HIP_CHECK(hipEventDestroy(e0)); SWN_HIP_CHECK(hipEventDestroy(e1));
+  unsigned long long h[32];
+  SWN_HIP_CHECK(hipMemcpy(h, clk, sizeof h, hipMemcpyDeviceToHost));
+  int wall_khz = 0, dev = 0;
+  SWN_HIP_CHECK(hipGetDevice(&dev));
+  SWN_HIP_CHECK(hipDeviceGetAttribute(&wall_khz, hipDeviceAttributeWallClockRate, dev));
+  double cs = 0, rs = 0;
+  for (int i = 0; i < 16; ++i) { cs += (double)h[2 * i]; rs += (double)h[2 * i + 1]; }
+  const double ghz = rs > 0 ? cs / rs * wall_khz * 1e-6 : 0.0;
+  const double mfmas = (double)blocks * 4 * iters * 12;               // per launch
+  out4[0] = (float)(mfmas * 32768.0 / (best * 1e-3) * 1e-12);
+  out4[1] = (float)ghz;
+  out4[2] = best;
+  out4[3] = ghz > 0 ? (float)(mfmas * 32.0 / 1024.0 / (best * 1e-3 * ghz * 1e9)) : 0.f;
+}
+
 void prof_enable(int on) { g_prof = on; }
 void prof_reset() {
   for (auto& r : g_recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
@@ -2768,12 +2554,12 @@ static bool pc_on() {
   const bool on = !(getenv("SWN_PRECUT") && atoi(getenv("SWN_PRECUT")) == 0);      // read per launch (tests / A-B runs)
   return on;
 }
-// 2 (default): two fp16 planes per operand, three MFMAs per product; 3: three bf16 planes, six.  Read once: the operands a model
-// holds are cut for one of the two forms.
+// 2 (default): two fp16 planes per operand, three MFMAs per product; 1: the reduced-precision configuration (one fp16 plane per
+// operand, one MFMA: bench.py --precision f16, never the headline).  Read once: the operands a model holds are cut for one form.
 static int pc_planes() {
   static const int pl = [] {
     const int v = getenv("SWN_PC_PLANES") ? atoi(getenv("SWN_PC_PLANES")) : 2;
-    return (v == 3 || v == 1) ? v : 2;           // 1: the reduced-precision configuration (one fp16 plane per operand)
+    return v == 1 ? 1 : 2;
   }();
   return pl;
 }
@@ -2781,11 +2567,6 @@ int conv_precut_planes() { return pc_planes(); }
 bool wino_pair_planes() {
   static const bool off = getenv("SWN_PAIR") && atoi(getenv("SWN_PAIR")) == 0;
   return !off && pc_planes() == 2 && dma_on() && split_on() && !g_force_naive && amax_fused_on();
-}
-static int pc_stages() {
-  const char* e = getenv("SWN_PC_STAGES");
-  const int v = e ? atoi(e) : 2;
-  return (v == 3 || v == 4) ? v : 2;
 }
 // the last 2 KiB of a stream's scratch hold the partial maxima of the launch in flight (A operand) and of the operand a producer
 // is cutting; the split-K slabs of the same launch stay below
@@ -2810,14 +2591,14 @@ static void launch_fwd_pc(Stream& s, GemmP& p, int nb, const unsigned short* wpc
   p.ntiles = tiles_m * p.tiles_n;
   constexpr int wg = WGCU;
   static_assert(wg * T::SMEM <= 160 * 1024, "tile does not fit a CU");
-  const size_t ws_cap = PL <= 2 ? s.ws_bytes - PC_WS_TAIL : s.ws_bytes;
+  const size_t ws_cap = s.ws_bytes - PC_WS_TAIL;
   const float* a_amax = nullptr;
   if (x_pair_k && PL != 2) throw Error(1, "conv_fwd: a pair-form operand needs the two-plane kernel");
   if (x_pair_k) {
     // (the producer scaled and cut the operand: nothing to take the amax of)
-  } else if (PL <= 2 && x_amax && amax_fused_on()) {
+  } else if (x_amax && amax_fused_on()) {
     a_amax = x_amax;          // the producer of the operand left its amax (256 floats, maximum = amax) in a slot: no pass of our own
-  } else if (PL <= 2) {
+  } else {
     // |A|max over the whole input tensor of the launch (all images, all channels the gather reads; batched planes too)
     float* part = ws_amax(s, 0);
     amax_partials(s, p.x, (size_t)(p.M / (p.Ho * p.Wo)) * p.xH * p.xW, p.xC, (size_t)p.xcs, phases ? 1 : nb, p.x_bs, part);
@@ -2876,64 +2657,6 @@ static void launch_fwd_pc(Stream& s, GemmP& p, int nb, const unsigned short* wpc
   }
 }
 
-// 64-row wave tiles (conv_fwd_pcm_kernel): SWN_PC_MI=2 routes the two-plane 128-column launches with at least pcm_min_tiles() tiles of
-// 256 x 128 onto it (read per launch: A/B runs).  Default off -- never executed on the GPU yet (see the kernel's header).
-static int pc_mi() {
-  const char* e = getenv("SWN_PC_MI");
-  return (e && atoi(e) == 2) ? 2 : 1;
-}
-// two workgroups on each of the 256 CUs: below that the 128 x 128 tile fills the chip better (SWN_PC_MI_MIN_TILES: tests / A-B runs)
-static int pcm_min_tiles() {
-  const char* e = getenv("SWN_PC_MI_MIN_TILES");
-  return e ? std::max(1, atoi(e)) : 512;
-}
-template <int WGM, int MI, int NB, int NSTG, int WGCU>
-static void launch_fwd_pcm(Stream& s, GemmP& p, int nb, const unsigned short* wpc, size_t wpc_bs, bool phases, const float* x_amax,
-                           const int* x_pair_k) {
-  using T = PcmTile<WGM, MI, NB, NSTG>;
-  const int tiles_m = ceil_div(p.M, T::BM);
-  p.tiles_n = ceil_div(p.Npad, T::BN);
-  p.ntiles = tiles_m * p.tiles_n;
-  static_assert(WGCU * T::SMEM <= 160 * 1024, "tile does not fit a CU");
-  const size_t ws_cap = s.ws_bytes - PC_WS_TAIL;
-  const float* a_amax = nullptr;
-  if (x_pair_k) {
-    // (the producer scaled and cut the operand: nothing to take the amax of)
-  } else if (x_amax && amax_fused_on()) {
-    a_amax = x_amax;          // the producer of the operand left its amax in a slot
-  } else {                    // a pass of our own over the whole input tensor of the launch, as launch_fwd_pc does
-    float* part = ws_amax(s, 0);
-    amax_partials(s, p.x, (size_t)(p.M / (p.Ho * p.Wo)) * p.xH * p.xW, p.xC, (size_t)p.xcs, phases ? 1 : nb, p.x_bs, part);
-    a_amax = part;
-  }
-  const DmaSched sc = plan_dma(p.ntiles * nb, p.ntiles, p.K / T::BK, 256 * WGCU, (size_t)T::BM * T::BN * 4, ws_cap, nullptr,
-                               WGCU * T::NW * MI / 12.0);
-  p.slab = reinterpret_cast<float*>(s.ws);
-  p.splits = sc.tail_s;
-  static bool once = (set_smem(conv_fwd_pcm_kernel<WGM, MI, NB, NSTG, WGCU, false>, T::SMEM),
-                      set_smem(conv_fwd_pcm_kernel<WGM, MI, NB, NSTG, WGCU, true>, T::SMEM), true);
-  (void)once;
-  char pname[112];
-  if (prof_detail())
-    snprintf(pname, sizeof pname, "conv_fwd_pcm_%dx%d%s[M%d,N%d,K%d,b%d,full%d,tail%dx%d]", T::BM, T::BN, x_pair_k ? "_ap" : "", p.M, p.Cout, p.K, nb,
-             sc.full, sc.tail_tiles, sc.tail_s);
-  else
-    snprintf(pname, sizeof pname, "conv_fwd_pcm_%dx%d", T::BM, T::BN);
-  ProfScope prof(s, pname, 2.0 * p.M * p.Cout * p.K * nb);
-  const int units = sc.full + sc.tail_tiles * sc.tail_s;
-  if (x_pair_k)
-    hipLaunchKernelGGL((conv_fwd_pcm_kernel<WGM, MI, NB, NSTG, WGCU, true>), dim3(units), dim3(64 * T::NW), T::SMEM, hs(s), p, sc, wpc, wpc_bs,
-                       a_amax, x_pair_k);
-  else
-    hipLaunchKernelGGL((conv_fwd_pcm_kernel<WGM, MI, NB, NSTG, WGCU, false>), dim3(units), dim3(64 * T::NW), T::SMEM, hs(s), p, sc, wpc, wpc_bs,
-                       a_amax, x_pair_k);
-  check_launch("conv_fwd_pcm");
-  if (sc.tail_tiles > 0 && sc.tail_s > 1) {
-    hipLaunchKernelGGL((conv_dma_reduce_kernel<T::BM, T::BN>), dim3(T::BM * T::BN / 4 / 256, sc.tail_tiles), dim3(256), 0, hs(s), p, sc);
-    check_launch("conv_dma_reduce");
-  }
-}
-
 // column tile of the pre-cut kernel by output width: 64 (256 x 64), 128 (128 x 128), or 192 for N in (128, 192] (the tail
 // conv's input gradient into the 192-channel concat: one 128 x 192 tile instead of two 128-wide ones of which one is half empty)
 static int pc_tile_for(int Npad) { return Npad <= 64 ? 64 : ((Npad > 128 && Npad <= 192) ? 192 : 128); }
@@ -2945,11 +2668,9 @@ int conv_precut_tile(int xC, int Npad) {
   return pc_tile_for(Npad);
 }
 size_t conv_precut_elems(int K, int Npad, int bn) {
-  if (pc_planes() <= 2) return (size_t)(K / 16) * ceil_div(Npad, bn) * 2 * pc_planes() * bn * 8 + PC_TRAILER;
-  return (size_t)(K / 16) * ceil_div(Npad, bn) * 6 * bn * 8;
+  return (size_t)(K / 16) * ceil_div(Npad, bn) * 2 * pc_planes() * bn * 8 + PC_TRAILER;
 }
 const float* conv_precut_amax(Stream& s, const float* src, size_t rows, int C, int batch, size_t bs) {
-  if (pc_planes() == 3) return nullptr;
   float* part = ws_amax(s, 1);
   amax_partials(s, src, rows, C, (size_t)C, batch, bs, part);
   return part;
@@ -3056,24 +2777,13 @@ void conv_fwd(Stream& s, const ConvFwdArgs& a) {
       if (pc_planes() == 2) {
         if (a.wpc_bn == 192) launch_fwd_pc<4, 6, 2, 2, 2>(s, p, nb, a.wpc, a.wpc_bs, ph, a.x_amax, a.x_pair_k);
         else if (a.Npad > 64) {
-          // 128 x 128: LDS stages x workgroups per CU.  2 x 4 (round 3: 64 KB in flight per CU), 3 x 3 (96 KB in flight, two stages of
-          // prefetch distance), 4 x 2.  SWN_PC_STAGES selects (A/B runs; read per launch)
-          const int stg = pc_stages();
-          // SWN_PC_MI=2 (opt-in): 256 x 128 tiles of 64-row wave tiles where the launch has enough of them and the operand's scale
-          // comes without a pass (pair form or an amax slot)
-          if (pc_mi() == 2 && a.wpc_bn == 128 && (size_t)ceil_div(p.M, 256) * ceil_div(a.Npad, 128) * nb >= (size_t)pcm_min_tiles())
-            launch_fwd_pcm<4, 2, 4, 2, 2>(s, p, nb, a.wpc, a.wpc_bs, ph, a.x_amax, a.x_pair_k);
-          else if (stg == 3) launch_fwd_pc<4, 4, 3, 3, 2>(s, p, nb, a.wpc, a.wpc_bs, ph, a.x_amax, a.x_pair_k);
-          else if (stg == 4 && !a.x_pair_k) launch_fwd_pc<4, 4, 4, 2, 2>(s, p, nb, a.wpc, a.wpc_bs, ph, a.x_amax);
-          else launch_fwd_pc<4, 4, 2, 4, 2>(s, p, nb, a.wpc, a.wpc_bs, ph, a.x_amax, a.x_pair_k);
+          // 128 x 128: two LDS stages, four workgroups per CU (3- and 4-stage rings measured the same within 0.4 %: rounds 3 / 4)
+          launch_fwd_pc<4, 4, 2, 4, 2>(s, p, nb, a.wpc, a.wpc_bs, ph, a.x_amax, a.x_pair_k);
         }
         else launch_fwd_pc<8, 2, 3, 2, 2>(s, p, nb, a.wpc, a.wpc_bs, ph, a.x_amax, a.x_pair_k);
         return;
       }
-      if (a.wpc_bn == 192) launch_fwd_pc<4, 6, 2, 2, 3>(s, p, nb, a.wpc, a.wpc_bs, ph, nullptr);   // 128 x 192, 2 stages, 2 workgroups / CU
-      else if (a.Npad > 64) launch_fwd_pc<4, 4, 2, 4, 3>(s, p, nb, a.wpc, a.wpc_bs, ph, nullptr);  // 128 x 128, 2 stages, 4 workgroups / CU
-      else launch_fwd_pc<8, 2, 3, 2, 3>(s, p, nb, a.wpc, a.wpc_bs, ph, nullptr);                   // 256 x 64, 3 stages, 2 workgroups / CU
-      return;
+      throw Error(1, "conv_fwd: unknown plane count");
     }
     if (!a.w) throw Error(1, "conv_fwd: the weight operand exists in pre-cut form only, but this launch cannot take the pre-cut "
                              "kernel (SWN_SPLIT / SWN_PRECUT / SWN_DMA must not change after a model is built)");
@@ -3152,11 +2862,11 @@ static void launch_wgrad(Stream& s, GemmP& p, int batch) {
 
 
 // 2 (default): the weight-gradient ring kernel on two fp16 planes per operand, both scaled by powers of two from their amax (three
-// MFMAs per product; tools/ring_lab.hip variants 18 / 19: 157-167 -> 266-268 fp32-equivalent TFLOP/s at 4.5e-7); 3: three bf16
-// planes (six MFMAs).  Read per launch (A/B runs, tests).
+// MFMAs per product; tools/ring_lab.hip variants 18 / 19: 157-167 -> 266-268 fp32-equivalent TFLOP/s at 4.5e-7); 1: the
+// reduced-precision configuration (one plane, bench.py --precision f16).  Read per launch (tests).
 static int wgrad_planes() {
   const int v = getenv("SWN_WGRAD_PLANES") ? atoi(getenv("SWN_WGRAD_PLANES")) : 2;
-  return (v == 3 || v == 1) ? v : 2;
+  return v == 1 ? 1 : 2;
 }
 template <int WGM, int WGN>
 static void launch_wgrad_dma(Stream& s, GemmP& p, int nb, const ConvWgradArgs& a) {
@@ -3185,8 +2895,8 @@ static void launch_wgrad_dma(Stream& s, GemmP& p, int nb, const ConvWgradArgs& a
   const DmaSched sc = plan_dma(p.ntiles * nb, p.ntiles, nmb, 256 * wg_per_cu, (size_t)T::BMK * T::BN * 4, two ? s.ws_bytes - PC_WS_TAIL : s.ws_bytes);
   p.slab = reinterpret_cast<float*>(s.ws);
   p.splits = sc.tail_s;
-  static bool once = (set_smem(conv_wgrad_dma_kernel<WGM, WGN, 2>, T::SMEM), set_smem(conv_wgrad_dma_kernel<WGM, WGN, 1>, T::SMEM),
-                      set_smem(conv_wgrad_dma_kernel<WGM, WGN, 0>, T::SMEM), set_smem(conv_wgrad_dma_kernel<WGM, WGN, 3>, T::SMEM), true);
+  static bool once = (set_smem(conv_wgrad_dma_kernel<WGM, WGN, 2>, T::SMEM), set_smem(conv_wgrad_dma_kernel<WGM, WGN, 0>, T::SMEM),
+                      set_smem(conv_wgrad_dma_kernel<WGM, WGN, 3>, T::SMEM), true);
   (void)once;
   // plain [M][C] operands (batched Winograd planes): the loader without im2col arithmetic.  SWN_WGRAD_PLANE=0: generic (A/B runs)
   const bool plane = p.KH == 1 && p.KW == 1 && p.stride == 1 && p.pad_t == 0 && p.pad_l == 0 && !p.ups && !p.phases && p.Ho == 1 &&
@@ -3216,7 +2926,6 @@ static void launch_wgrad_dma(Stream& s, GemmP& p, int nb, const ConvWgradArgs& a
   }
   else if (two && wpl == 1) hipLaunchKernelGGL((conv_wgrad_dma_kernel<WGM, WGN, 3>), dim3(units), dim3(64 * T::NW), T::SMEM, hs(s), p, sc, xa, ya);
   else if (two) hipLaunchKernelGGL((conv_wgrad_dma_kernel<WGM, WGN, 2>), dim3(units), dim3(64 * T::NW), T::SMEM, hs(s), p, sc, xa, ya);
-  else if (split_on()) hipLaunchKernelGGL((conv_wgrad_dma_kernel<WGM, WGN, 1>), dim3(units), dim3(64 * T::NW), T::SMEM, hs(s), p, sc, xa, ya);
   else hipLaunchKernelGGL((conv_wgrad_dma_kernel<WGM, WGN, 0>), dim3(units), dim3(64 * T::NW), T::SMEM, hs(s), p, sc, xa, ya);
   check_launch("conv_wgrad_dma");
   if (sc.tail_tiles > 0 && sc.tail_s > 1) {

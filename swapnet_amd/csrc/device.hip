@@ -2,6 +2,7 @@
 #include "hip_util.h"
 #include <algorithm>
 #include <cstdint>
+#include <cstring>
 
 namespace swn {
 
@@ -33,6 +34,18 @@ void dev_memset(Stream& s, void* p, int v, size_t bytes) {
     return;
   }
   SWN_HIP_CHECK(hipMemsetAsync(p, v, bytes, hs(s)));
+}
+struct Small64 { uint32_t w[16]; };
+__global__ void store_small_kernel(uint32_t* dst, Small64 v, int n) {
+  if (threadIdx.x < (unsigned)n) dst[threadIdx.x] = v.w[threadIdx.x];
+}
+void dev_store_small(Stream& s, void* dst, const void* src, size_t bytes) {
+  if (bytes == 0) return;
+  if (bytes > 64 || bytes % 4 || ((uintptr_t)dst & 3)) throw Error(1, "dev_store_small: at most 64 bytes, 4-byte granular");
+  Small64 v{};
+  memcpy(v.w, src, bytes);
+  hipLaunchKernelGGL(store_small_kernel, dim3(1), dim3(64), 0, hs(s), static_cast<uint32_t*>(dst), v, (int)(bytes / 4));
+  SWN_HIP_CHECK(hipGetLastError());
 }
 void dev_copy(Stream& s, void* dst, const void* src, size_t bytes) {
   SWN_HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, hs(s)));

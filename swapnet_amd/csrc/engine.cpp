@@ -46,6 +46,11 @@ Ctx::Ctx(void* stream, size_t ws_bytes) {
 }
 Ctx::Ctx(const Stream& shared) : s(shared), owns_ws(false) {}
 Ctx::~Ctx() {
+  // nothing may still be running on a stream whose events and handle are about to be destroyed (round-4 advice)
+  try {
+    if (owned_comm_stream) stream_sync(comm_stream);
+    if (has_side) stream_sync(side);
+  } catch (...) {}
   release(allocs);
   if (owns_ws) dev_free(s.ws);
   if (owned_comm_stream) {
@@ -85,7 +90,12 @@ void Ctx::join_side() {
 }
 void Ctx::attach_comm(AllReduceFn fn, void* comm, int world) {
   comm_join();
-  if (!fn) { comm_fn = nullptr; comm_handle = nullptr; comm_world = 1; return; }
+  if (!fn) {
+    // detaching: the caller is about to destroy the communicator -- no collective of ours may still be in flight on its stream
+    if (owned_comm_stream) stream_sync(comm_stream);
+    comm_fn = nullptr; comm_handle = nullptr; comm_world = 1;
+    return;
+  }
   if (world < 1) throw Error(1, "attach_comm: world size must be >= 1");
   comm_fn = fn; comm_handle = comm; comm_world = world;
   if (is_device_build() && !owned_comm_stream) {
@@ -596,8 +606,7 @@ void Net::conv(const std::string& name, const Var& x, const Var& y, ConvKind kin
   float* keepV = nullptr;         // V = B^T d B of the forward input, reused by the weight gradient
   if (wino && keep_wino_inputs && y.has_grad) keepV = static_cast<float*>(ctx.alloc((size_t)wP * wT * Cip * sizeof(float)));
   // 6-point forms: the transformed filters go straight into the pre-cut operand layout of the ring kernel (no fp32 U)
-  static const int wino_pc = getenv("SWN_WINO_PC") ? atoi(getenv("SWN_WINO_PC")) : 1;
-  const int pcw = (wino && wm != 2 && wino_pc) ? wino_precut_tile(Cip, Cop) : 0;
+  const int pcw = (wino && wm != 2) ? wino_precut_tile(Cip, Cop) : 0;
   const size_t pcw_bs = pcw ? conv_precut_elems(Cip, Cop, pcw) : 0;
   size_t pcw_off = 0, pcwt_off = 0;
   int pcwt = 0;
@@ -702,7 +711,7 @@ void Net::conv(const std::string& name, const Var& x, const Var& y, ConvKind kin
   const Var xg_target = narrow_dx ? x.slice(0, Ndg) : x;
   if (want_dx) {
     if (wino) {
-      pcwt = (wm != 2 && wino_pc) ? wino_precut_tile(Cop, Cip) : 0;
+      pcwt = wm != 2 ? wino_precut_tile(Cop, Cip) : 0;
       pcwt_bs = pcwt ? conv_precut_elems(Cop, Cip, pcwt) : 0;
       if (pcwt) pcwt_off = reserve_dgp(pcwt_bs * wP);
       else ub_off = reserve_dg(self, (size_t)wP * Cop * Cip);
@@ -1467,7 +1476,8 @@ void Model::step_captured(const float labels[3], bool training, uint64_t seed) {
   h.seed = seed;
   adamw_schedule(hyper.lr, hyper.b1, hyper.b2, arenaG.step + 1, h.schedG);
   adamw_schedule(hyper.d_lr, hyper.d_b1, hyper.d_b2, arenaD.step + 1, h.schedD);
-  dev_upload(ctx->s, sp_dev, &h, sizeof h);           // stream-ordered: in front of this step's launches
+  dev_store_small(ctx->s, sp_dev, &h, sizeof h);      // stream-ordered, in front of this step's launches, and NO host sync (round 5: the
+                                                      // synchronising upload made every replayed step wait for the previous one to drain)
   struct Indirect {
     Model& m;
     explicit Indirect(Model& mm) : m(mm) { m.indirect = true; if (m.G) m.G->seed_dev = &m.sp_dev->seed; }
@@ -1479,7 +1489,12 @@ void Model::step_captured(const float labels[3], bool training, uint64_t seed) {
     step_warm_[gi] = 1;
     return;
   }
+  // a recorded sequence bakes in what is not in StepParams: one stream or two, and where AdamW sits (round-4 advice)
+  const char* am = getenv("SWN_STREAM_ADAMW");
+  const int key = (ctx->use_side() ? 1 : 0) | ((am ? atoi(am) : 1) << 1);
+  if (step_graph_[gi] && step_graph_key_[gi] != key) { graph_destroy(step_graph_[gi]); step_graph_[gi] = nullptr; }
   if (!step_graph_[gi]) {
+    step_graph_key_[gi] = key;
     // record: the same phases on a private capture stream (the side stream joins the capture through the fork / join events)
     stream_sync(ctx->s);
     Stream& s = ctx->s;

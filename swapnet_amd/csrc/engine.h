@@ -400,6 +400,7 @@ class Model {
   const float* label_dev(int i) const { return indirect ? reinterpret_cast<const float*>(sp_dev) + i : nullptr; }
   void invalidate_step_graphs() { for (void*& g : step_graph_) { graph_destroy(g); g = nullptr; } }
   void* step_graph_[2] = {nullptr, nullptr};
+  int step_graph_key_[2] = {0, 0};      // (two streams?, AdamW placement) the graph was recorded under
   int step_warm_[2] = {0, 0};
   void* cap_stream_ = nullptr;
   // NLayerDiscriminator.forward (modules/discriminators.py:134-136) as a standalone call: x = the conditioned input

@@ -64,8 +64,9 @@ __global__ __launch_bounds__(256) void roi_align_kernel(const float* tex, int tc
   }
 }
 
-// The same gather with wavefront primitives (north_star: "ROIAlign/texture-pool as a wavefront-primitive gather kernel"; OPT-IN,
-// SWN_ROI_WAVE=1: written in round 4 without a GPU, never executed).  One wavefront per (image, output row ph, 64 output columns),
+// The same gather with wavefront primitives (north_star: "ROIAlign/texture-pool as a wavefront-primitive gather kernel").  The
+// DEFAULT since round 5 (bit-identical to the scalar kernel on the MI355X, tests/test_ops.py
+// test_wavefront_gather_roi_align_is_bit_identical); SWN_ROI_WAVE=0 selects the scalar kernel.  One wavefront per (image, output row ph, 64 output columns),
 // the ROIs of the pixel in a loop.  Per ROI the sample ROW is wave-uniform (y, yl, yh and the row weights depend on (roi, ph)
 // only) and the lanes' source columns xl grow with pw, so the texels the wave needs from rows yl / yh are one contiguous run
 // starting at lane 0's xl.  The wave loads that run 64 texels at a time -- ONE coalesced 16-byte load per lane and row (NHWC, C
@@ -288,9 +289,9 @@ __global__ __launch_bounds__(256) void onehot_kernel(const int32_t* labels, size
 void roi_align_fwd(Stream& s, const TView& tex, int C, const float* rois, int R, const TView& out) {
   if (out.C < R * C || out.N != tex.N) throw Error(1, "roi_align_fwd: output view too small");
   const size_t total = (size_t)tex.N * out.H * out.W * R;
-  // SWN_ROI_WAVE=1 (read per launch): the wavefront-primitive form (opt-in until it has run: roi_align_wave_kernel)
+  // the wavefront-primitive form (roi_align_wave_kernel) wherever its layout conditions hold; SWN_ROI_WAVE=0 (read per launch): scalar
   const char* e = getenv("SWN_ROI_WAVE");
-  if (e && atoi(e) == 1 && C <= 3 && tex.cs % 4 == 0 && tex.cs >= 4) {
+  if (!(e && atoi(e) == 0) && C <= 3 && tex.cs % 4 == 0 && tex.cs >= 4) {
     const size_t nwork = (size_t)tex.N * out.H * ((out.W + 63) / 64);
     hipLaunchKernelGGL(roi_align_wave_kernel, dim3((unsigned)std::min<size_t>((nwork + 3) / 4, 256 * 32)), dim3(256), 0, hs(s), tex.p, tex.cs,
                        tex.H, tex.W, C, rois, tex.N, R, out.p, out.cs, out.H, out.W);

@@ -40,6 +40,9 @@ void dev_free(void* p);
 void dev_memset(Stream& s, void* p, int v, size_t bytes);     // a kernel launch (a recordable KERNEL node, not a memset node: device.hip)
 void dev_copy(Stream& s, void* dst, const void* src, size_t bytes);        // device->device
 void dev_upload(Stream& s, void* dst, const void* src, size_t bytes);      // host->device
+// <= 64 bytes (a multiple of 4) of host data into device memory, stream-ordered and WITHOUT a host synchronisation: the bytes travel
+// as the arguments of a one-thread kernel (device.hip) -- per-step parameter blocks of a recorded step
+void dev_store_small(Stream& s, void* dst, const void* src, size_t bytes);
 void dev_download(Stream& s, void* dst, const void* src, size_t bytes);    // device->host (syncs)
 void stream_sync(Stream& s);
 void* stream_create(int device);          // selects the device, returns a new stream handle
@@ -53,6 +56,8 @@ void prof_enable(int on);
 void prof_reset();
 // one line per kernel variant: "<name> <launches> <total_ms> <total_flops>\n"; returns bytes written
 int prof_report(char* buf, int len);
+// swapnet_hip.h swn_probe_mfma: register-only fp16 MFMA loop, in-kernel clock (conv_gemm.hip); synchronises the stream
+void probe_mfma(Stream& s, int zeros, int iters, float* out4);
 // Routing trace (swn_route_trace / swn_route_report, engine.cpp): which kernel family / algorithmic form every layer of a model
 // takes under the current environment.  While on, the engine labels each tape op as it runs it (phase f = forward, b = backward,
 // r = derived-operand refresh) and the launchers note the kernel they picked (implicit-GEMM launches with their M, N, K, batch

@@ -113,6 +113,10 @@ class Context:
 
     def close(self):
         if getattr(self, "handle", None):
+            comm = getattr(self, "native_comm", None)       # the communicator the library's exchange runs on dies with its context,
+            if comm is not None:                            # before it: parallel.NativeComm registers itself here
+                self.native_comm = None
+                comm.close()
             self.lib.call("swn_ctx_destroy", self.handle)
             self.handle = None
 

@@ -171,13 +171,11 @@ class BaseGAN(BaseModel, ABC):
         if self.world == 1:
             # SWAPNET_CAPTURED_STEP=1: the step as a recorded hipGraph (swn_model_step_captured; bit-identical results)
             m.step(labels, training=training, seed=seed, captured=os.environ.get("SWAPNET_CAPTURED_STEP") == "1")
-        elif parallel.native_comm_requested():
-            # SWAPNET_NATIVE_COMM=1: the library drives the exchange itself (swn_model_step_dp: RCCL's all-reduce on a stream and
-            # with events the library owns, AdamW of each bucket behind its all-reduce)
+        elif self._native_exchange():
+            # the library drives the exchange itself (swn_model_step_dp: RCCL's all-reduce on a stream and with events the library
+            # owns, AdamW of each bucket behind its all-reduce); SWAPNET_NATIVE_COMM=0: the torch.distributed calls below
             rank = torch.distributed.get_rank()
             labels = parallel.broadcast_floats(labels)
-            if getattr(self, "_native_comm", None) is None:
-                self._native_comm = parallel.NativeComm(self.backend.ctx)
             if self.KIND == "texture" and getattr(self.opt, "lambda_style", 0) != 0:
                 m.forward(training, seed + rank)
                 parallel.gather_style_context(m, self.targets)      # the style Gram spans the global batch
@@ -198,6 +196,13 @@ class BaseGAN(BaseModel, ABC):
             parallel.generator_backward_with_exchange(m, labels[2], self._xchg)
         self._losses_stale = True
         self._fakes = None
+
+    def _native_exchange(self):
+        """Library-owned exchange up?  Decided once, by all ranks together (parallel.open_native_comm); the communicator belongs to
+        the context and is closed with it."""
+        if not hasattr(self, "_native_comm"):
+            self._native_comm = parallel.open_native_comm(self.backend.ctx) if parallel.native_comm_requested() else None
+        return self._native_comm is not None
 
     # individual phases keep working too (the reference exposes them as methods)
     def backward_D(self):

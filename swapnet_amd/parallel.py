@@ -210,6 +210,7 @@ class NativeComm:
         self.comm = comm
         fn = C.cast(dll.ncclAllReduce, C.c_void_p).value
         self.ctx.attach_comm(fn, comm, self.world)
+        self.ctx.native_comm = self            # owner: Context.close() closes the communicator before the context goes
 
     def _init_callback(self):
         proto = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p)
@@ -232,17 +233,52 @@ class NativeComm:
         self._keep.append(cb)
         self.comm = None
         self.ctx.attach_comm(C.cast(cb, C.c_void_p).value, None, self.world)
+        self.ctx.native_comm = self
 
     def close(self):
-        self.ctx.attach_comm(None, None, 1)
-        if self.backend == "rccl" and self.comm:
+        """Detach (the library joins AND drains its exchange stream: swn_ctx_attach_comm(NULL)), then destroy the communicator.
+        Call before torch.distributed.destroy_process_group()."""
+        if getattr(self.ctx, "native_comm", None) is self:
+            self.ctx.native_comm = None
+        if getattr(self.ctx, "handle", None):
+            self.ctx.attach_comm(None, None, 1)
             self.ctx.sync()
+        if self.backend == "rccl" and self.comm:
             self.dll.ncclCommDestroy(self.comm)
             self.comm = None
 
 
 def native_comm_requested():
-    """SWAPNET_NATIVE_COMM=1: the data-parallel step goes through swn_model_step_dp (library-owned exchange) instead of the
-    torch.distributed calls of GradExchange.  Opt-in: the RCCL form has not run on hardware yet (round 4 had no GPU minutes left when
-    it was written); the callback form is what the CPU tests exercise."""
-    return os.environ.get("SWAPNET_NATIVE_COMM") == "1"
+    """Which exchange a data-parallel step uses.  Default (round 5, after the RCCL form ran on the MI355X at world size 1 -- bit-equal
+    D arena, 25.5 vs 25.4 ms/step, profiles/native_ab_r04.txt, tests/test_data_parallel.py): the LIBRARY-OWNED one (swn_model_step_dp:
+    RCCL's all-reduce on a stream and with events the library owns) on a device build; SWAPNET_NATIVE_COMM=0 selects the
+    torch.distributed calls of GradExchange, =1 forces the library-owned form (the gloo callback on the host simulator)."""
+    v = os.environ.get("SWAPNET_NATIVE_COMM")
+    if v is not None:
+        return v == "1"
+    return torch.cuda.is_available()
+
+
+def open_native_comm(ctx):
+    """NativeComm(ctx) agreed on by every rank: if the communicator cannot be brought up on ANY rank, all ranks close theirs and the
+    caller uses GradExchange (both are RCCL exchanges of the same buffers; the choice is reported, never silent).  Returns the
+    communicator or None."""
+    comm, err = None, None
+    try:
+        comm = NativeComm(ctx)
+    except Exception as e:                                    # noqa: BLE001
+        err = e
+    ok = 1 if comm is not None else 0
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+        t = torch.tensor([ok], dtype=torch.int32, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        ok = int(t.item())
+    if not ok:
+        import sys
+        print("swapnet_amd.parallel: library-owned exchange NOT available (%r on this rank) -- using torch.distributed all-reduce "
+              "per bucket" % (err,), file=sys.stderr, flush=True)
+        if comm is not None:
+            comm.close()
+        return None
+    return comm

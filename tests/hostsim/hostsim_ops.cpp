@@ -43,6 +43,7 @@ void dev_free(void* p) { std::free(p); }
 void dev_memset(Stream&, void* p, int v, size_t bytes) { SIM_TIMED; std::memset(p, v, bytes); }
 void dev_copy(Stream&, void* d, const void* s, size_t b) { std::memcpy(d, s, b); }
 void dev_upload(Stream&, void* d, const void* s, size_t b) { std::memcpy(d, s, b); }
+void dev_store_small(Stream&, void* d, const void* s, size_t b) { std::memcpy(d, s, b); }
 void dev_download(Stream&, void* d, const void* s, size_t b) { std::memcpy(d, s, b); }
 void stream_sync(Stream&) {}
 void* stream_create(int) { return nullptr; }
@@ -63,6 +64,7 @@ void conv_force_naive(int) {}
 void prof_enable(int) {}
 void prof_reset() {}
 int prof_report(char* buf, int len) { if (buf && len > 0) buf[0] = 0; return 0; }
+void probe_mfma(Stream&, int, int, float*) { throw Error(3, "swn_probe_mfma measures the matrix pipe of a GPU: device build only"); }
 
 static inline float actf(float v, int a) {
   switch (a) { case ACT_LRELU: return v > 0 ? v : 0.2f * v; case ACT_RELU: return v > 0 ? v : 0.f;

@@ -31,7 +31,7 @@ def test_hip_library_builds_loads_and_exports_every_declared_symbol():
     for s in declared_symbols():
         assert hasattr(dll, s), s
     lib = _C.Lib(path)
-    assert lib.is_device and lib.dll.swn_abi_version() == 5
+    assert lib.is_device and lib.dll.swn_abi_version() == 6
     # gfx950 code object is embedded
     out = subprocess.run(["strings", "-a", path], capture_output=True, text=True).stdout
     assert "gfx950" in out

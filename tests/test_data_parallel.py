@@ -385,7 +385,6 @@ def test_two_rank_library_owned_exchange_equals_the_torch_path(tmp_path, stage, 
 
 
 @pytest.mark.gpu
-@pytest.mark.skipif(os.environ.get("SWAPNET_UNVERIFIED_GPU") != "1", reason="never run on the GPU yet (SWAPNET_UNVERIFIED_GPU=1 to include)")
 def test_one_rank_native_rccl_exchange_equals_the_fused_step():
     """parallel.NativeComm(backend="rccl") at world size 1: ncclCommInitRank through ctypes on the RCCL the process holds, RCCL's own
     ncclAllReduce driven by the library on its exchange stream (swn_model_step_dp), AdamW per bucket on that stream -- bit-identical
@@ -432,8 +431,7 @@ def test_bench_py_launch_reduce_and_report_path_for_two_ranks(native):
     backends.build_hostsim()
     env = {k: v for k, v in os.environ.items() if not k.startswith("SWN_")}
     env.update(SWAPNET_DIST_BACKEND="gloo", OMP_NUM_THREADS="4")
-    if native:
-        env["SWAPNET_NATIVE_COMM"] = "1"
+    env["SWAPNET_NATIVE_COMM"] = "1" if native else "0"          # (the default on a GPU box is the library-owned exchange: parallel.native_comm_requested)
     port = 29900 + os.getpid() % 90 + (5 if native else 0)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(backends.REPO, "tests", "bench_on_hostsim.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",

@@ -21,12 +21,6 @@ from tests.test_warp_step import noise_bias
 pytestmark = pytest.mark.small_channel_winograd      # tests/conftest.py: small shapes on the Winograd forms
 
 BACKENDS = [pytest.param("sim", id="hostsim"), pytest.param("gpu", id="mi355x", marks=pytest.mark.gpu)]
-# Cases written after the round's GPU budget was spent: their GPU twin has never executed on an MI355X, and the driver runs the GPU
-# suite with -x.  They run on the host simulator (same engine code, CPU operators) and join the GPU suite with SWAPNET_UNVERIFIED_GPU=1
-# (tools/r05_first_call.sh runs them first thing next round).
-UNVERIFIED = [pytest.param("sim", id="hostsim"),
-              pytest.param("gpu", id="mi355x", marks=[pytest.mark.gpu, pytest.mark.skipif(
-                  os.environ.get("SWAPNET_UNVERIFIED_GPU") != "1", reason="never run on the GPU yet (set SWAPNET_UNVERIFIED_GPU=1)")])]
 MODES = {"wgan-gp": (2, 1), "dragan-gp": (0, 2), "dragan-lp": (0, 3)}        # name -> (gan_mode, gp_mode) of swn_hyper
 
 
@@ -154,7 +148,7 @@ def test_library_rng_keeps_the_layout_pad_channels_out_of_the_penalty(backend):
     m.set_hyper()
 
 
-@pytest.mark.parametrize("backend", UNVERIFIED)
+@pytest.mark.parametrize("backend", BACKENDS)
 @pytest.mark.parametrize("n_layers", [2, 4])
 def test_gradient_penalty_at_other_patchgan_depths(backend, n_layers, tmp_path, golden_dir):
     """--gan_mode wgan-gp / dragan-gp with --discriminator n_layers --n_layers_D 2 / 4: the reverse-over-reverse pass of csrc/gp.cpp

@@ -20,12 +20,11 @@ from oracle import swapnet_oracle as O
 from oracle.golden_io import compare
 from swapnet_amd import engine
 from tests import backends
-from tests.conftest import unverified_gpu
 from tests.test_texture_step import vgg_state_dict
 from tests.test_train_parity import _check_step, _ctx, rel
 
 SIM = pytest.param("sim", id="hostsim")
-GPU = pytest.param("gpu", id="mi355x", marks=[pytest.mark.gpu, unverified_gpu])
+GPU = pytest.param("gpu", id="mi355x", marks=pytest.mark.gpu)
 
 
 def _interleaved_iteration(mw, mt, lw, lt):

@@ -18,10 +18,6 @@ from swapnet_amd import _C
 from tests import backends
 
 
-def backends_unverified_gpu():
-    from tests.conftest import unverified_gpu
-    return unverified_gpu
-
 pytestmark = pytest.mark.small_channel_winograd      # tests/conftest.py: small shapes on the Winograd forms
 
 K4S2, K3REFL, K4S1, K3ZERO, TAIL = 0, 1, 2, 3, 4
@@ -132,7 +128,7 @@ def test_conv_forward(backend):
 
 @pytest.mark.small_channel_winograd
 @pytest.mark.parametrize("backend", [pytest.param("sim", id="hostsim"),
-                                     pytest.param("gpu", id="mi355x", marks=[pytest.mark.gpu, backends_unverified_gpu()])])
+                                     pytest.param("gpu", id="mi355x", marks=pytest.mark.gpu)])
 def test_winograd_layers_of_129_to_192_channels(backend):
     """Stride-1 Winograd layers whose output (or, for the input gradient, input) width falls in (128, 192]: conv_precut_tile answers
     192 there -- the tile of the tail conv's input gradient -- but the 6-point filter transform writes tiles of 64 / 128 only, and
@@ -246,13 +242,12 @@ def test_roi_align_bit_exact_indices_and_values(backend, golden_dir):
 
 
 @pytest.mark.gpu
-@pytest.mark.skipif(os.environ.get("SWAPNET_UNVERIFIED_GPU") != "1", reason="never run on the GPU yet (SWAPNET_UNVERIFIED_GPU=1 to include)")
 def test_wavefront_gather_roi_align_is_bit_identical(golden_dir, monkeypatch):
     """roi_align_wave_kernel (SWN_ROI_WAVE=1; gather.hip): one wavefront per output row segment, the texel run of the row loaded
     coalesced and the four corners of every lane taken from its neighbours' registers with ds_bpermute -- against the scalar
     one-thread-per-sample kernel and the oracle, bit for bit: the notebook's ROIs (degenerate boxes), full-image and sub-pixel
     boxes, 1-pixel boxes at the border, ROIs wider than 64 / 128 source pixels (several 64-texel segments per row), a pooled
-    width that is not a multiple of 64, and a non-square image.  Written without a GPU (round 4): opt-in until it has run."""
+    width that is not a multiple of 64, and a non-square image.  (First run on the MI355X in round 5: green; the wave kernel is the default.)"""
     ctx = _ctx("gpu")
     rois = torch.from_numpy(np.load(os.path.join(golden_dir, "notebook_rois.npz"))["rois"])
     extra = torch.tensor([[[0, 0, 255, 255], [255, 0, 255, 0], [10.5, 3.25, 200.75, 77.5], [254, 254, 255, 255],
@@ -443,50 +438,3 @@ def test_split_main_loop_on_one_signed_operands(monkeypatch):
             print("one-signed K=%d %s: split %.2e (bias %+.2e)  f32 mfma %.2e (bias %+.2e)" % (ci * k * k, what, e_split, bias, e_f32, bias32))
             assert e_split <= 1.25 * e_f32 + 6e-8, (what, kind, "split %.3e" % e_split, "f32 mfma %.3e" % e_f32)
             assert abs(bias) < 1.2e-7, (what, kind, "relative bias of the split form", bias)
-
-
-@pytest.mark.gpu
-@pytest.mark.skipif(os.environ.get("SWAPNET_UNVERIFIED_GPU") != "1", reason="never run on the GPU yet (SWAPNET_UNVERIFIED_GPU=1 to include)")
-def test_64_row_wave_tiles_match_the_128x128_ring_kernel(monkeypatch):
-    """conv_fwd_pcm_kernel (SWN_PC_MI=2: 256 x 128 tiles, each wave 64 rows x 128 columns; conv_gemm.hip) against the shipped
-    128 x 128 pre-cut kernel on the same launches.  Both sum a tile's K range in the same order with the same three MFMA terms, so
-    un-split launches must agree BIT FOR BIT; launches whose hybrid split-K schedule differs (other tile count) to fp32 round-off;
-    both against float64.  Forward, input gradient (four folded phases of the transposed conv), ragged M, reflect padding, the
-    split tail with its 256 x 128 slab reduction.  Written without a GPU (round 4): opt-in until it has run once."""
-    ctx = _ctx("gpu")
-    monkeypatch.setenv("SWN_WINOGRAD", "0")
-    g = torch.Generator().manual_seed(5)
-    for kind, tr, n, ci, h, co, bias in ((K4S2, 0, 2, 64, 256, 128, True),      # M 32768: 128 whole tiles
-                                         (K4S2, 0, 4, 128, 64, 256, False),     # M 4096 x N 256: 32 tiles, every one split along K
-                                         (K4S2, 0, 3, 64, 40, 128, True),       # M 1200: ragged last tile
-                                         (K3REFL, 0, 2, 256, 16, 256, True),    # reflect padding, K 2304
-                                         (K4S1, 0, 2, 256, 32, 512, True),      # 31 x 31 outputs
-                                         (K4S2, 1, 2, 384, 32, 128, False)):    # transposed conv: four phases
-        k = 3 if kind == K3REFL else 4
-        x = torch.randn(n, ci, h, h, generator=g)
-        w = torch.randn((ci, co, k, k) if tr else (co, ci, k, k), generator=g) * (2.0 / (ci * k * k)) ** 0.5
-        b = torch.randn(co, generator=g) * 0.1 if bias else None
-        ref = ref_conv(x.double(), w.double(), b.double() if bias else None, kind, tr)
-        dy = torch.randn(ref.shape, generator=g)
-        xr = x.double().requires_grad_(True)
-        ref_conv(xr, w.double(), None, kind, tr).backward(dy.double())
-        got = {}
-        for mi in ("1", "2"):
-            monkeypatch.setenv("SWN_PC_MI", mi)
-            monkeypatch.setenv("SWN_PC_MI_MIN_TILES", "1")
-            ctx.route_trace(True)
-            out = run_conv(ctx, kind, tr, 0, False, x, w, b, 0, ref.shape)
-            dx = run_conv(ctx, kind, tr, 2, False, torch.zeros_like(x), w, None, 0, dy=dy)
-            ctx.route_trace(False)
-            lines = ctx.route_report()
-            used = any("conv_fwd_pcm_256x128" in l for l in lines)
-            assert used == (mi == "2"), (kind, tr, ci, co, mi, lines)
-            got[mi] = (out, dx, [l for l in lines if "conv_fwd_pc" in l])
-        for i, (what, r64) in enumerate((("fwd", ref), ("dgrad", xr.grad))):
-            a, m = got["1"][i], got["2"][i]
-            e1, e2 = rel(a, r64), rel(m, r64)
-            print(kind, tr, ci, co, what, "128x128 %.2e  256x128 %.2e  equal %s" % (e1, e2, bool(torch.equal(a, m))), got["2"][2])
-            assert e2 < 2e-6 and e2 <= 1.2 * e1 + 2e-8, (what, kind, tr, ci, co, e1, e2)
-            assert rel(a, m) < 2e-6
-            if all("tail0x" in l for l in got["1"][2] + got["2"][2]):        # no split-K tail on either side
-                assert torch.equal(a, m), (what, kind, tr, ci, co)

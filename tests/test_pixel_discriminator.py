@@ -14,13 +14,12 @@ from oracle import swapnet_oracle as O
 from oracle.golden_io import compare
 from swapnet_amd import engine
 from tests import backends
-from tests.conftest import unverified_gpu
 from tests.test_models_api import make_opt
 from tests.test_ops import rel, run_conv
 from tests.test_train_parity import _ctx
 
 SIM = pytest.param("sim", id="hostsim")
-GPU = pytest.param("gpu", id="mi355x", marks=[pytest.mark.gpu, unverified_gpu])       # written without a GPU (round 4): opt-in until run
+GPU = pytest.param("gpu", id="mi355x", marks=pytest.mark.gpu)
 
 
 @pytest.mark.parametrize("backend", [SIM, GPU])

@@ -79,11 +79,13 @@ def _check_step(m, st, gD, gG, tol_loss=1e-3, tol_out=1e-3, tol_gD=5e-3, tol_gG=
             if noise_bias(k, list(ref)):
                 continue
             g = gref[k].double()
-            # "solid" = well above what the gradient check itself tolerates: a gradient tensor may differ by tol_g (<= 1e-2) in
-            # rel-L2, i.e. an element's error can reach a few 1e-2 of the tensor's rms -- below 5e-2 rms the SIGN Adam's first
-            # step turns into +-lr is not determined (round 4: one bias element of the innermost U-Net conv at 1.3e-2 rms flipped
-            # at C3 bs 16 in training mode while its gradient tensor agreed to 3.6e-3)
-            solid = g.abs() >= 5e-2 * g.pow(2).mean().sqrt()
+            # "solid" = above what the gradient check itself tolerates: |g| >= 1e-2 rms(g).  Below that the SIGN that Adam's first
+            # step turns into +-lr is not determined.  One tensor is known to need more room and is named instead of widening the
+            # mask for everybody (round-4 advice): the bias of the innermost U-Net conv (1 x 1 map, 512 units, no norm behind it) --
+            # at C3 bs 16 in training mode one unit at 1.3e-2 rms flipped while the gradient tensor agreed to 3.6e-3.
+            innermost = k.startswith("unet.") and k.endswith(".model.1.bias") and \
+                k.count("model.3") == max(q.count("model.3") for q in ref if q.endswith(".model.1.bias"))
+            solid = g.abs() >= (5e-2 if innermost else 1e-2) * g.pow(2).mean().sqrt()
             if not bool(solid.any()):
                 continue
             a, b = got[k].double().cpu()[solid], v.double()[solid]
@@ -200,8 +202,8 @@ def test_warp_training_mode_step_matches_oracle(backend):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("mode", ["eval", "train"])
-def test_warp_c2_full_batch_step_matches_oracle(mode):
+@pytest.mark.parametrize("mode", ["train"])        # bench.py's mode; eval mode at bs 32 was a second CPU-oracle step of the same kernels
+def test_warp_c2_full_batch_step_matches_oracle(mode):   # (round 5: the suite has to fit the driver's 1 200 s; eval mode runs at 256 x 256 bs 2 and at 64 x 64)
     """BASELINE.json config C2 exactly: warp 256x256, bs 32, fp32 -- the shapes bench.py times (256x128 MFMA tiles
     with M >= 2048, the bs-32 split-K plans, Winograd planes of 512 tiles) under bench.py's kernel routing (default
     environment; the launch list of the checked step is compared with a scrubbed-environment process).  One phased G+D
@@ -229,17 +231,17 @@ def test_warp_c2_full_batch_step_with_winograd_forms_on_every_level():
     """The harder-numerics variant of the C2 step: SWN_WINO_MINC=32 moves body/cloth_down2 and PatchGAN's model.2
     (64 -> 128 channels at 64x64, the largest-M launches of the direct ring kernel) onto strided Winograd as well.  NOT the
     routing bench.py times (the test above is); kept so that the Winograd forms are held to the oracle at bs 32 on every
-    level they can serve."""
+    level they can serve (bs 8 since round 5)."""
     ctx = backends.gpu_ctx()
     labels = [0.85, 0.95, 0.75]
-    m, G, D, batch, masks = _warp_train_case(ctx, 32, 256, 5, 77, 1234)
+    m, G, D, batch, masks = _warp_train_case(ctx, 8, 256, 5, 77, 1234)       # (bs 8: a non-default routing does not need the bs-32 oracle step)
     try:
         st = O.WarpStepOracle(G, D, training=O.MaskReplay(masks))
         st.step(*batch, labels=labels)
         with backends.traced_route(ctx) as route:
             gD, gG = _phased_step(m, labels, True, 1234)
-        worst = _check_step(m, st, gD, gG, what="warp C2 bs32 train, Winograd everywhere")
-        print("warp C2 bs32 (SWN_WINO_MINC=32) worst rel-L2:", {k: "%.2e" % v for k, v in worst.items()})
+        worst = _check_step(m, st, gD, gG, what="warp 256x256 bs8 train, Winograd everywhere")
+        print("warp 256x256 bs8 (SWN_WINO_MINC=32) worst rel-L2:", {k: "%.2e" % v for k, v in worst.items()})
         assert any(l.startswith("body_down2.model.0 f ") and ",b25," in l for l in route.lines), route.lines[:12]
     finally:
         m.close()
@@ -260,7 +262,7 @@ def _texture_case(ctx, B, H, drop_seed):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("mode", ["eval", "train"])
+@pytest.mark.parametrize("mode", ["train"])        # (as above: the benchmarked mode)
 def test_texture_c3_full_batch_step_matches_oracle(mode):
     """BASELINE.json config C3 exactly: texture 256x256, bs 16, 12 ROIs, L1 + VGG16 content + style on."""
     ctx = backends.gpu_ctx()
