@@ -155,7 +155,7 @@ int main(int argc, char** argv) {
   SW(swn_ctx_create(0, nullptr, 1, (size_t)1024 << 20, &ctx));
   SAY("ctx up at %.1f s\n", now() - t00);
 
-  const bool generic = argc > 5 && (!strcmp(argv[5], "bench") || !strcmp(argv[5], "ab") || !strcmp(argv[5], "prof") || !strcmp(argv[5], "host"));
+  const bool generic = argc > 5 && (!strcmp(argv[5], "bench") || !strcmp(argv[5], "ab") || !strcmp(argv[5], "prof") || !strcmp(argv[5], "host") || !strcmp(argv[5], "phases"));
   if (!getenv("NATIVE_AB_SKIP_OPS") && !generic) {
     int big = H >= 256;
     op_case(ctx, "k4s2 64->128 (body_down2 / PatchGAN model.2 shape)", 0, big ? 8 : 2, 64, big ? 128 : 16, 128, big ? 64 : 8);
@@ -223,6 +223,27 @@ int main(int argc, char** argv) {
     double ms = plain_steps(K);
     say_losses(m, "bench");
     SAY("bench %.3f ms/step %.1f img/s (B %d, %d x %d, %d steps)\n", ms, B / ms * 1e3, B, H, H, K);
+    SW(swn_model_destroy(m)); SW(swn_ctx_destroy(ctx));
+    return 0;
+  }
+  if (argc > 5 && !strcmp(argv[5], "phases")) {
+    // wall time of the four phases of the step, each synchronised (un-profiled): forward | backward_D + optimizer_D | backward_G + optimizer_G
+    plain_steps(5);
+    double t[3] = {0, 0, 0};
+    for (int i = 0; i < K; i++) {
+      SW(swn_ctx_sync(ctx)); double a = now();
+      SW(swn_model_forward(m, 1, ++seed)); SW(swn_ctx_sync(ctx)); double b = now();
+      SW(swn_model_backward_D(m, labels[0], labels[1])); SW(swn_model_optimizer_step(m, 1)); SW(swn_ctx_sync(ctx)); double c = now();
+      SW(swn_model_backward_G(m, labels[2])); SW(swn_model_optimizer_step(m, 0)); SW(swn_ctx_sync(ctx)); double d = now();
+      t[0] += b - a; t[1] += c - b; t[2] += d - c;
+    }
+    {   // the forward pass again with nothing to refresh (weights unchanged since the last refresh): the chain alone
+      double f2 = 0;
+      for (int i = 0; i < K; i++) { SW(swn_ctx_sync(ctx)); double a = now(); SW(swn_model_forward(m, 1, ++seed)); SW(swn_ctx_sync(ctx)); f2 += now() - a; }
+      SAY("phases: forward with current operands (no refresh) %.3f ms\n", f2 * 1e3 / K);
+    }
+    SAY("phases: forward %.3f ms | backward_D + AdamW(D) %.3f ms | backward_G + AdamW(G) %.3f ms | sum %.3f ms  (fused step: %.3f ms)\n", t[0] * 1e3 / K,
+        t[1] * 1e3 / K, t[2] * 1e3 / K, (t[0] + t[1] + t[2]) * 1e3 / K, plain_steps(K));
     SW(swn_model_destroy(m)); SW(swn_ctx_destroy(ctx));
     return 0;
   }
