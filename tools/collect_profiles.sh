@@ -2,7 +2,7 @@
 # Copy what tools/refresh_profiles.sh left under gpurun_out/<tag>/ into the tracked profiles/ directory under the
 # names DESIGN.md, profiles/README.md and bench.py refer to.   usage: tools/collect_profiles.sh r04
 set -e
-TAG=${1:-r04}
+TAG=${1:-r05}
 S=gpurun_out/$TAG
 D=profiles
 cp $S/bench_c2.json                              $D/bench_${TAG}_c2.json
@@ -10,6 +10,8 @@ cp $S/bench_c3.json                              $D/bench_${TAG}_c3_texture.json
 cp $S/bench_c2_f16.json                          $D/bench_${TAG}_c2_f16.json
 cp $S/bench_c2_captured.json                     $D/bench_${TAG}_c2_captured.json
 cp $S/bench_infer.json                           $D/bench_${TAG}_infer.json
+cp $S/bench_joint.json                           $D/bench_${TAG}_joint.json
+cp $S/bench_joint_captured.json                  $D/bench_${TAG}_joint_captured.json
 cp $S/bench_c2_rccl_world1.json                  $D/bench_${TAG}_c2_rccl_world1.json
 cp $S/ab_switches.txt                            $D/ab_switches_${TAG}.txt
 cp $S/rocprof_${TAG}_prof_warp_kernel_stats.md   $D/rocprof_${TAG}_warp_c2_kernel_stats.md

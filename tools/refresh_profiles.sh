@@ -1,10 +1,10 @@
 # Produces everything under profiles/ for one round: run on the GPU box as
-#   gpurun --timeout 2400 -- 'bash tools/refresh_profiles.sh r04'
+#   gpurun --timeout 2400 -- 'bash tools/refresh_profiles.sh r05'
 # then copy the condensed files from gpurun_out/<tag>/ into profiles/ (README there lists the names).
 # Per-kernel profiles are taken with the library's second stream off (SWN_OVERLAP=0): with it on, kernels of the two
 # streams share the GPU and their individual durations / counters are not attributable.  Counter passes (--pmc) are
 # separate runs without any trace domain, one step each (bench.py --no-roofline runs exactly the timed steps).
-TAG=${1:-r04}
+TAG=${1:-r05}
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/$TAG
 mkdir -p $O
@@ -15,9 +15,11 @@ python bench.py --stage texture --steps 12 --warmup 4 > $O/bench_c3.json 2> $O/b
 python bench.py --precision f16 --steps 12 --warmup 4 --no-cpu-baseline > $O/bench_c2_f16.json 2> $O/bench_c2_f16.err
 python bench.py --captured --steps 20 --warmup 5 --no-cpu-baseline --no-roofline > $O/bench_c2_captured.json 2> $O/bench_c2_captured.err
 python bench.py --stage infer > $O/bench_infer.json 2> $O/bench_infer.err
+python bench.py --stage joint --steps 12 --warmup 4 > $O/bench_joint.json 2> $O/bench_joint.err
+python bench.py --stage joint --captured --steps 12 --warmup 4 > $O/bench_joint_captured.json 2> $O/bench_joint_captured.err
 SWAPNET_BENCH_RCCL1=1 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-roofline > $O/bench_c2_rccl_world1.json 2> $O/bench_c2_rccl_world1.err
 # same-box A/B of this round's switches (ms/step)
-for V in X=default SWN_WGRAD_PLANES=3 SWN_PAIR=0 SWN_AMAX_FUSED=0 SWN_SHARE_DY=0 SWN_FIRST_RING=0 SWN_WINO_VW=4 SWN_STREAM_ADAMW=0 SWN_OVERLAP=0 X=default2; do
+for V in X=default SWN_TAIL_SPLIT=0 SWN_PAIR=0 SWN_AMAX_FUSED=0 SWN_SHARE_DY=0 SWN_FIRST_RING=0 SWN_PREFETCH=0 SWN_STREAM_ADAMW=0 SWN_OVERLAP=0 X=default2; do
   env $V python bench.py --steps 12 --warmup 4 --no-cpu-baseline --no-roofline 2> /dev/null | python -c "import sys,json;d=json.loads(sys.stdin.read());print('$V', d['ms_per_step'], d['value'])" >> $O/ab_switches.txt
 done
 cat $O/ab_switches.txt
