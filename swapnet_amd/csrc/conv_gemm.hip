@@ -2603,23 +2603,6 @@ static void launch_fwd_pc(Stream& s, GemmP& p, int nb, const unsigned short* wpc
     float* part = ws_amax(s, 0);
     amax_partials(s, p.x, (size_t)(p.M / (p.Ho * p.Wo)) * p.xH * p.xW, p.xC, (size_t)p.xcs, phases ? 1 : nb, p.x_bs, part);
     a_amax = part;
-    if (getenv("SWN_PC_DEBUG")) {       // diagnostics: the operand's amax against its rms (how much of fp16's range the scale spends)
-      SWN_HIP_CHECK(hipStreamSynchronize(hs(s)));
-      const size_t rows = (size_t)(p.M / (p.Ho * p.Wo)) * p.xH * p.xW; const int nbb = phases ? 1 : nb;
-      std::vector<float> h(256);
-      SWN_HIP_CHECK(hipMemcpy(h.data(), part, 1024, hipMemcpyDeviceToHost));
-      float am = 0.f; for (float v : h) am = std::max(am, v);
-      double ss = 0; size_t cnt = 0, big = 0;
-      std::vector<float> row(p.xC);
-      for (int b = 0; b < nbb; ++b)
-        for (size_t r = 0; r < rows; r += std::max<size_t>(1, rows / 512)) {
-          SWN_HIP_CHECK(hipMemcpy(row.data(), p.x + (size_t)b * p.x_bs + r * p.xcs, (size_t)p.xC * 4, hipMemcpyDeviceToHost));
-          for (float v : row) { ss += (double)v * v; ++cnt; if (std::fabs(v) > am / 1024.f) ++big; }
-        }
-      fprintf(stderr, "[pc] M %d N %d K %d xC %d xcs %d xH %d xW %d nb %d ph %d  amax %.3e  rms(sampled) %.3e  ratio %.1f  frac>amax/1024 %.4f\n", p.M,
-              p.Cout, p.K, p.xC, p.xcs, p.xH, p.xW, nb, (int)phases, am, std::sqrt(ss / std::max<size_t>(cnt, 1)),
-              am / std::max(1e-30, std::sqrt(ss / std::max<size_t>(cnt, 1))), (double)big / std::max<size_t>(cnt, 1));
-    }
   }
   const DmaSched sc = plan_dma(p.ntiles * nb, p.ntiles, p.K / T::BK, 256 * wg, (size_t)T::BM * T::BN * 4, ws_cap, nullptr,
                                wg * T::NW / 12.0);
