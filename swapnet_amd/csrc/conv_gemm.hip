@@ -2464,12 +2464,17 @@ static DmaSched plan_dma(int tiles_total, int tiles_per_z, int work, int slots, 
   // launch with the matrix instructions removed): a last round that occupies few CUs runs at nearly twice the clock, and the
   // split's slab round trip + reduce launch cost what it saves (36 Winograd planes of 512 x 1024 x 1024 = 1152 tiles on 1024
   // slots: 128 us un-split in the lab, 135 + 13 us split in the product; whole C2 step -0.29 ms, profiles/native_ab_r05.txt).
-  // SWN_TAIL_SPLIT=0 restores the split (A/B; read per launch).
+  // The same holds for a launch that fills at least half of the slots (two workgroups per CU in the 4-per-CU configuration): in the
+  // lab 512 / 768 / 1024 tiles of the resblock shape take 51 / 72 / 95 us un-split -- the same 340-360 fp32-equivalent TFLOP/s, at
+  // 1.51 / 1.36 / 1.10 GHz -- so splitting K to "fill the chip" buys nothing there either (below half, a CU runs too few waves to
+  // keep its matrix pipe fed and the split still pays: 128 tiles 33 us).  SWN_TAIL_SPLIT=0 restores every split, =2 only the
+  // behind-a-whole-round rule (A/B; read per launch).
   {
     const char* e = getenv("SWN_TAIL_SPLIT");
-    if (rounds >= 1 && !(e && atoi(e) == 0)) {
+    const int mode = e ? atoi(e) : 1;
+    if (mode != 0 && (rounds >= 1 || (mode == 1 && 2 * rem >= slots))) {
       sc.full = tiles_total; sc.tail_tiles = 0;
-      if (cost_out) *cost_out += (work + 4.0) * unit * 0.6;
+      if (cost_out) *cost_out += (work + 4.0) * unit * (rounds >= 1 ? 0.6 : (double)rem / slots);
       return sc;
     }
   }

@@ -325,6 +325,10 @@ int main(int argc, char** argv) {
       {"exact fit: 32 planes 512x1024x1024", 512, 1024, 1024, 32},
       {"wino_resblock: 36 planes 512x1024x1024", 512, 1024, 1024, 36},
       {"down4 (8192x512x4096)", 8192, 512, 4096, 1},
+      {"partial occupancy: 8 planes (256 tiles of 128x128)", 512, 1024, 1024, 8},
+      {"partial occupancy: 16 planes (512 tiles)", 512, 1024, 1024, 16},
+      {"partial occupancy: 24 planes (768 tiles)", 512, 1024, 1024, 24},
+      {"partial occupancy: 4 planes (128 tiles)", 512, 1024, 1024, 4},
       {"down2 (131072x128x1024)", 131072, 128, 1024, 1},
   };
   hipStream_t st; CK(hipStreamCreate(&st));
