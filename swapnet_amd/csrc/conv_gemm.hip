@@ -1326,7 +1326,17 @@ struct TailTile {
   static constexpr int SMEM = (2 * A_FLOATS + 2 * 4 * B_FLOATS) * 4;
 };
 
-template <int NG>
+// PH = true (round 5): the same walk for the four sub-pixel phases of a k4 s2 TRANSPOSED conv run as 2x2 stride-1 convs (`phases`
+// launches: ConvTranspose forward, the input gradient of a k4 s2 conv).  Phase (a, b) multiplies the taps u in {a, a+1}, v in
+// {b, b+1} of the same 3x3 neighbourhood, its weight panel sits at p.w + ph * p.w_bs with rows ((u-a) * 2 + (v-b)) * Cin + ci.
+// As four launches of conv_fwd_narrow_kernel every phase streamed the operand again -- the 20-channel input gradient of
+// PatchGAN's model.0 fetched 16 x its operand (2.1 GB, profiles/traffic_r05.json), the largest single over-fetch of the step.
+template <bool PH>
+__device__ __forceinline__ bool phase_active(int ph, int u, int v) {
+  if constexpr (!PH) return tail_active(ph, u, v);
+  else { const int du = u - (ph >> 1), dv = v - (ph & 1); return du >= 0 && du <= 1 && dv >= 0 && dv <= 1; }
+}
+template <int NG, bool PH = false>
 __global__ __launch_bounds__(256) void tail_fwd4_kernel(GemmP p) {
   using T = TailTile;
   constexpr int AS = T::AS, RA = 4;
@@ -1346,7 +1356,7 @@ __global__ __launch_bounds__(256) void tail_fwd4_kernel(GemmP p) {
     if (m < p.M) {
       const int n = m / HoWo, rem = m - n * HoWo;
       const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
-      a_iy0[r] = oy - 1; a_ix0[r] = ox - 1;
+      a_iy0[r] = oy - (PH ? p.pad_t : 1); a_ix0[r] = ox - (PH ? p.pad_l : 1);
       a_base[r] = n * p.xH * p.xW * p.xcs;
     } else {
       a_iy0[r] = 0; a_ix0[r] = 0; a_base[r] = -1;
@@ -1386,8 +1396,11 @@ __global__ __launch_bounds__(256) void tail_fwd4_kernel(GemmP p) {
 #pragma unroll
     for (int ph = 0; ph < 4; ++ph) {
       rb[ph] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (t < 128 && tail_active(ph, u, v) && bcol < p.Npad)
-        rb[ph] = *reinterpret_cast<const float4*>(p.w + (size_t)(tail_row0(ph, u, v, p.xC) + c0 + brow) * p.Npad + bcol);
+      if (t < 128 && phase_active<PH>(ph, u, v) && bcol < p.Npad) {
+        const float* wp = PH ? p.w + (size_t)ph * p.w_bs + (size_t)(((u - (ph >> 1)) * 2 + (v - (ph & 1))) * p.xC) * p.Npad
+                             : p.w + (size_t)tail_row0(ph, u, v, p.xC) * p.Npad;
+        rb[ph] = *reinterpret_cast<const float4*>(wp + (size_t)(c0 + brow) * p.Npad + bcol);
+      }
     }
   };
   auto store_tiles = [&](int buf) {
@@ -1421,7 +1434,7 @@ __global__ __launch_bounds__(256) void tail_fwd4_kernel(GemmP p) {
     }
 #pragma unroll
     for (int ph = 0; ph < 4; ++ph) {
-      if (!tail_active(ph, u, v)) continue;        // block-uniform
+      if (!phase_active<PH>(ph, u, v)) continue;   // block-uniform
       const float* B = Bt + (buf * 4 + ph) * T::B_FLOATS + (lane & 31) * AS;
       float wv[16];
 #pragma unroll
@@ -1466,9 +1479,11 @@ __global__ __launch_bounds__(256) void tail_fwd4_kernel(GemmP p) {
         val[j] = act_apply(val[j], p.act);
       }
       if (col + 3 < p.Cout) {
-        *reinterpret_cast<float4*>(dst + col) = make_float4(val[0], val[1], val[2], val[3]);
+        float4 o = make_float4(val[0], val[1], val[2], val[3]);
+        if (PH && p.accumulate) { const float4 old = *reinterpret_cast<const float4*>(dst + col); o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w; }
+        *reinterpret_cast<float4*>(dst + col) = o;
       } else {
-        for (int j = 0; j < 4 && col + j < p.Cout; ++j) dst[col + j] = val[j];
+        for (int j = 0; j < 4 && col + j < p.Cout; ++j) dst[col + j] = (PH && p.accumulate) ? dst[col + j] + val[j] : val[j];
       }
     }
   }
@@ -2443,6 +2458,20 @@ static void launch_fwd_narrow(Stream& s, GemmP& p, bool fast, int batch) {
 }
 
 
+// the four sub-pixel phases of a narrow (Cout <= 20) transposed conv in one launch: tail_fwd4_kernel<NG, true>
+template <int NG>
+static void launch_fwd_phase4(Stream& s, GemmP& p) {
+  p.tiles_n = 1; p.ntiles = ceil_div(p.M, TailTile::BM);
+  static bool once = (set_smem(tail_fwd4_kernel<NG, true>, TailTile::SMEM), true);
+  (void)once;
+  char pname[96];
+  if (prof_detail()) snprintf(pname, sizeof pname, "conv_fwd_phase4_narrow%d[M%d,N%d,K%d]", 4 * NG, p.M, p.Cout, p.K);
+  else snprintf(pname, sizeof pname, "conv_fwd_phase4_narrow%d", 4 * NG);
+  ProfScope prof(s, pname, 2.0 * p.M * p.Cout * p.K * 4);
+  hipLaunchKernelGGL((tail_fwd4_kernel<NG, true>), dim3(p.ntiles), dim3(256), TailTile::SMEM, hs(s), p);
+  check_launch("conv_fwd_phase4");
+}
+
 // read per launch (tests and A/B measurements toggle it): 0 = v_mfma_f32_32x32x2_f32 main loop, default = bf16 split
 static bool split_on() { return !(getenv("SWN_SPLIT") && atoi(getenv("SWN_SPLIT")) == 0); }
 // ---- LDS-DMA forward kernel: schedule + launch ------------------------------------------------------------------
@@ -2801,6 +2830,14 @@ void conv_fwd(Stream& s, const ConvFwdArgs& a) {
   else if (a.Npad > 64) launch_fwd<2, 2, 2, 2>(s, p, fast, nb);
   else if (a.Npad > 32) launch_fwd<2, 1, 2, 2>(s, p, fast, nb);   // (a 2-wave 128x64 tile with 64x64 wave tiles measured 4 % slower)
   else if (!narrow_on()) launch_fwd<1, 1, 4, 1>(s, p, fast, nb);
+  else if (a.phases == 4 && a.Npad <= 20 && p.KH == 2 && p.KW == 2 && p.stride == 1 && !p.ups && p.pad_mode == PAD_ZERO && a.x.C % 16 == 0 &&
+           !(getenv("SWN_PHASE4") && atoi(getenv("SWN_PHASE4")) == 0)) {
+    // (SWN_PHASE4=0, read per launch: one narrow launch per phase, as before round 5)
+    if (a.Npad <= 4) launch_fwd_phase4<1>(s, p);
+    else if (a.Npad <= 8) launch_fwd_phase4<2>(s, p);
+    else if (a.Npad <= 16) launch_fwd_phase4<4>(s, p);
+    else launch_fwd_phase4<5>(s, p);
+  }
   else if (a.Npad <= 4) launch_fwd_narrow<1>(s, p, fast, nb);
   else if (a.Npad <= 8) launch_fwd_narrow<2>(s, p, fast, nb);
   else if (a.Npad <= 16) launch_fwd_narrow<4>(s, p, fast, nb);

@@ -91,7 +91,8 @@ CONV_CASES_GPU = CONV_CASES_SIM + [
     (TAIL, 0, 1, 192, 32, 19, True),         # upsample_and_pad, N = 19
     (K4S2, 1, 2, 1024, 4, 512, False),       # convT, split-K per phase
     (K4S2, 1, 2, 384, 32, 64, False),        # dual_up3
-    (K4S2, 1, 1, 128, 64, 3, True),          # texture outermost up conv
+    (K4S2, 1, 1, 128, 64, 3, True),          # texture outermost up conv (round 5: four phases in one launch, tail_fwd4_kernel<1, true>)
+    (K4S2, 1, 2, 64, 16, 19, True), (K4S2, 1, 1, 32, 8, 8, False), (K4S2, 1, 1, 48, 6, 16, True), (K4S2, 1, 2, 16, 5, 12, True),   # the same for 20 / 8 / 16 / 12 columns, ragged 256-pixel tiles
     # LDS-DMA ring kernel corner cases: Ci % 16 == 0 but not % 32, N = 64 (256x64 tile), N = 96 / 80 / 48 (columns of
     # the 128-wide tile past Npad are fetched out of range), ragged M, zero / reflect padding rows out of range
     (K4S2, 0, 2, 48, 24, 96, True), (K4S2, 0, 1, 16, 32, 64, True), (K3ZERO, 0, 2, 48, 12, 80, True),
