@@ -641,7 +641,8 @@ void Net::conv(const std::string& name, const Var& x, const Var& y, ConvKind kin
   // amax slot of the output buffer: a direct conv with a fused activation feeds the next GEMM without a normalisation in
   // between (UNetDown without InstanceNorm, PatchGAN model.0), so it folds its output's amax (in the ring kernel's epilogue, else
   // by a pass: ops.h ConvFwdArgs::y_amax); everything else here is followed by a norm_act, which folds for its own output
-  const bool y_folds = !wino && !folded && actf != ACT_NONE && actf != ACT_TANH;
+  // (round 5: the 6-point Winograd output transform folds too -- VGG16's conv + ReLU layers feed the next conv directly)
+  const bool y_folds = !folded && actf != ACT_NONE && actf != ACT_TANH && (!wino || wm != 2);
   const size_t ySlot = note_writer(y.vbase, y_folds);
   const float* xbase = x.vbase;
   op->fwd = [=](Net& n) {
@@ -666,7 +667,7 @@ void Net::conv(const std::string& name, const Var& x, const Var& y, ConvKind kin
       g.y = plane_view(n.wsM, wT, Cop);
       g.batch = wP; g.x_bs = wT * Cip; g.w_bs = (size_t)Cip * Cop; g.y_bs = wT * Cop;
       conv_fwd(n.ctx.s, g);
-      wino_output_transform(n.ctx.s, wm, wr, n.wsM, Cop, wTh, wTw, a.bias, actf, yv, Co, 0);
+      wino_output_transform(n.ctx.s, wm, wr, n.wsM, Cop, wTh, wTw, a.bias, actf, yv, Co, 0, y_folds ? n.amax + ySlot : nullptr);
       return;
     }
     if (!folded) { conv_fwd(n.ctx.s, a); return; }
@@ -1107,10 +1108,10 @@ void Net::norm_act(const Var& raw, const Var& y, bool norm, int actf, float drop
 void Net::act(const Var& x, const Var& y, int actf) {
   auto op = std::make_unique<Op>();
   op->label = "act";
-  note_writer(y.vbase, false);
+  const size_t ySlot = note_writer(y.vbase, true);        // (round 5: the element-wise kernel folds its output's amax like every other producer)
   note_act(actf, y.v);
   const TView xv = x.v, yv = y.v, xg = x.g, yg = y.g;
-  op->fwd = [=](Net& n) { act_fwd(n.ctx.s, xv, yv, actf); };
+  op->fwd = [=](Net& n) { act_fwd(n.ctx.s, xv, yv, actf, n.amax + ySlot); };
   const bool do_bwd = x.has_grad && y.has_grad;
   if (do_bwd) op->grad_targets.push_back(x);
   op->bwd = [=](Net& n, Op& me, bool, bool) {
@@ -1122,7 +1123,8 @@ void Net::act(const Var& x, const Var& y, int actf) {
 void Net::affine(const Var& x, const Var& y, float alpha, float shift) {
   auto op = std::make_unique<Op>();
   op->label = "affine";
-  note_writer(y.vbase, false);
+  note_writer(y.vbase, false);        // (not a folding writer: forward_from() may skip this op -- the VGG slices are entered behind it with
+                                      // a buffer the caller filled -- so its consumer takes the amax itself)
   const TView xv = x.v, yv = y.v, xg = x.g, yg = y.g;
   op->fwd = [=](Net& n) { axpy(n.ctx.s, xv, yv, alpha, 0, shift); };
   const bool do_bwd = x.has_grad && y.has_grad;
@@ -1136,9 +1138,9 @@ void Net::affine(const Var& x, const Var& y, float alpha, float shift) {
 void Net::upsample(const Var& x, const Var& y, int f) {
   auto op = std::make_unique<Op>();
   op->label = "upsample";
-  note_writer(y.vbase, false);
+  const size_t ySlot = note_writer(y.vbase, true);
   const TView xv = x.v, yv = y.v, xg = x.g, yg = y.g;
-  op->fwd = [=](Net& n) { upsample_nearest_fwd(n.ctx.s, xv, yv, f); };
+  op->fwd = [=](Net& n) { upsample_nearest_fwd(n.ctx.s, xv, yv, f, n.amax + ySlot); };
   const bool do_bwd = x.has_grad && y.has_grad;
   if (do_bwd) op->grad_targets.push_back(x);
   op->bwd = [=](Net& n, Op& me, bool, bool) {
@@ -1150,10 +1152,10 @@ void Net::upsample(const Var& x, const Var& y, int f) {
 void Net::maxpool(const Var& x, const Var& y) {
   auto op = std::make_unique<Op>();
   op->label = "maxpool";
-  note_writer(y.vbase, false);
+  const size_t ySlot = note_writer(y.vbase, true);
   act_sites.push_back({2, y.v, x.v});
   const TView xv = x.v, yv = y.v, xg = x.g, yg = y.g;
-  op->fwd = [=](Net& n) { maxpool2_fwd(n.ctx.s, xv, yv); };
+  op->fwd = [=](Net& n) { maxpool2_fwd(n.ctx.s, xv, yv, n.amax + ySlot); };
   const bool do_bwd = x.has_grad && y.has_grad;
   if (do_bwd) op->grad_targets.push_back(x);
   op->bwd = [=](Net& n, Op& me, bool, bool) {

@@ -133,16 +133,19 @@ __global__ void roi_indices_kernel(const float* rois, int K, int H, int W, int P
 }
 
 __global__ __launch_bounds__(256) void upsample_fwd_kernel(const float* x, int xcs, float* y, int ycs, int N, int Ho,
-                                                           int Wo, int C, int f) {
+                                                           int Wo, int C, int f, float* amax_out) {
   const int C4 = C >> 2, Hi = Ho / f, Wi = Wo / f;
   const size_t total = (size_t)N * Ho * Wo * C4;
+  float amx = 0.f;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
     const int c = (int)(i % C4) * 4; size_t q = i / C4;
     const int ox = (int)(q % Wo); q /= Wo;
     const int oy = (int)(q % Ho); const int n = (int)(q / Ho);
     const float4 v = *reinterpret_cast<const float4*>(x + (((size_t)n * Hi + oy / f) * Wi + ox / f) * xcs + c);
     *reinterpret_cast<float4*>(y + (((size_t)n * Ho + oy) * Wo + ox) * ycs + c) = v;
+    amx = fmaxf(amx, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
   }
+  amax_fold(amx, amax_out);
 }
 __global__ __launch_bounds__(256) void upsample_bwd_kernel(const float* dy, int dycs, float* dx, int dxcs, int N,
                                                            int Hi, int Wi, int C, int f, int accumulate) {
@@ -169,9 +172,10 @@ __global__ __launch_bounds__(256) void upsample_bwd_kernel(const float* dy, int 
 // strict '>' so ties go to the first element, like ATen's max_pool2d.
 __global__ __launch_bounds__(256) void maxpool_kernel(const float* x, int xcs, float* y, int ycs, const float* dy,
                                                       int dycs, float* dx, int dxcs, int N, int Ho, int Wo, int C,
-                                                      int bwd, int accumulate) {
+                                                      int bwd, int accumulate, float* amax_out) {
   const int C4 = C >> 2, Hi = Ho * 2, Wi = Wo * 2;
   const size_t total = (size_t)N * Ho * Wo * C4;
+  float amx = 0.f;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
     const int c = (int)(i % C4) * 4; size_t q = i / C4;
     const int ox = (int)(q % Wo); q /= Wo;
@@ -193,6 +197,7 @@ __global__ __launch_bounds__(256) void maxpool_kernel(const float* x, int xcs, f
     }
     if (!bwd) {
       *reinterpret_cast<float4*>(y + (((size_t)n * Ho + oy) * Wo + ox) * ycs + c) = make_float4(m[0], m[1], m[2], m[3]);
+      amx = fmaxf(amx, fmaxf(fmaxf(fabsf(m[0]), fabsf(m[1])), fmaxf(fabsf(m[2]), fabsf(m[3]))));
     } else {
       const float4 g = *reinterpret_cast<const float4*>(dy + (((size_t)n * Ho + oy) * Wo + ox) * dycs + c);
       const float ga[4] = {g.x, g.y, g.z, g.w};
@@ -207,6 +212,7 @@ __global__ __launch_bounds__(256) void maxpool_kernel(const float* x, int xcs, f
       }
     }
   }
+  amax_fold(amx, amax_out);            // (forward: the pooled map's amax for the GEMM that reads it; NULL in backward)
 }
 
 __global__ __launch_bounds__(256) void act_pattern_kernel(const float* y, int ycs, int N, int HW, int C, uint8_t* out) {
@@ -309,10 +315,10 @@ void roi_align_indices(Stream& s, const float* rois, int K, int H, int W, int PH
   check_launch("roi_align_indices");
 }
 
-void upsample_nearest_fwd(Stream& s, const TView& x, const TView& y, int f) {
+void upsample_nearest_fwd(Stream& s, const TView& x, const TView& y, int f, float* amax_out) {
   if (y.H != x.H * f || y.W != x.W * f || x.C % 4 || y.C != x.C) throw Error(1, "upsample_nearest_fwd: shape mismatch");
   hipLaunchKernelGGL(upsample_fwd_kernel, dim3(egrid(y.pixels() * (x.C / 4))), dim3(256), 0, hs(s), x.p, x.cs, y.p, y.cs,
-                     x.N, y.H, y.W, x.C, f);
+                     x.N, y.H, y.W, x.C, f, amax_out);
   check_launch("upsample_nearest_fwd");
 }
 void upsample_nearest_bwd(Stream& s, const TView& dy, const TView& dx, int f, int accumulate) {
@@ -321,10 +327,10 @@ void upsample_nearest_bwd(Stream& s, const TView& dy, const TView& dx, int f, in
                      dx.cs, dx.N, dx.H, dx.W, dx.C, f, accumulate);
   check_launch("upsample_nearest_bwd");
 }
-void maxpool2_fwd(Stream& s, const TView& x, const TView& y) {
+void maxpool2_fwd(Stream& s, const TView& x, const TView& y, float* amax_out) {
   if (x.H != y.H * 2 || x.W != y.W * 2 || x.C % 4 || x.C != y.C) throw Error(1, "maxpool2_fwd: shape mismatch");
   hipLaunchKernelGGL(maxpool_kernel, dim3(egrid(y.pixels() * (y.C / 4))), dim3(256), 0, hs(s), x.p, x.cs, y.p, y.cs,
-                     (const float*)nullptr, 0, (float*)nullptr, 0, y.N, y.H, y.W, y.C, 0, 0);
+                     (const float*)nullptr, 0, (float*)nullptr, 0, y.N, y.H, y.W, y.C, 0, 0, amax_out);
   check_launch("maxpool2_fwd");
 }
 void act_pattern(Stream& s, const TView& y, uint8_t* out_nchw) {
@@ -338,7 +344,7 @@ void pool_pattern(Stream& s, const TView& x, const TView& y, uint8_t* out_nchw) 
 }
 void maxpool2_bwd(Stream& s, const TView& dy, const TView& x, const TView& y, const TView& dx, int accumulate) {
   hipLaunchKernelGGL(maxpool_kernel, dim3(egrid(y.pixels() * (y.C / 4))), dim3(256), 0, hs(s), x.p, x.cs, y.p, y.cs, dy.p,
-                     dy.cs, dx.p, dx.cs, y.N, y.H, y.W, y.C, 1, accumulate);
+                     dy.cs, dx.p, dx.cs, y.N, y.H, y.W, y.C, 1, accumulate, (float*)nullptr);
   check_launch("maxpool2_bwd");
 }
 

@@ -675,8 +675,8 @@ static EWp ew_params(const TView& a, const TView* b, const TView& o) {
   return p;
 }
 
-void act_fwd(Stream& s, const TView& x, const TView& y, int act) {
-  EWp p = ew_params(x, nullptr, y); p.act = act;
+void act_fwd(Stream& s, const TView& x, const TView& y, int act, float* amax_out) {
+  EWp p = ew_params(x, nullptr, y); p.act = act; p.amax_out = amax_out;
   hipLaunchKernelGGL(ew_kernel<0>, dim3(ew_grid(p.pixels * (p.C / 4))), dim3(256), 0, hs(s), p);
   check_launch("act_fwd");
 }
@@ -685,8 +685,8 @@ void act_bwd(Stream& s, const TView& dy, const TView& y, const TView& dx, int ac
   hipLaunchKernelGGL(ew_kernel<1>, dim3(ew_grid(p.pixels * (p.C / 4))), dim3(256), 0, hs(s), p);
   check_launch("act_bwd");
 }
-void axpy(Stream& s, const TView& src, const TView& dst, float alpha, int accumulate, float shift) {
-  EWp p = ew_params(src, nullptr, dst); p.alpha = alpha; p.accumulate = accumulate; p.shift = shift;
+void axpy(Stream& s, const TView& src, const TView& dst, float alpha, int accumulate, float shift, float* amax_out) {
+  EWp p = ew_params(src, nullptr, dst); p.alpha = alpha; p.accumulate = accumulate; p.shift = shift; p.amax_out = amax_out;
   hipLaunchKernelGGL(ew_kernel<2>, dim3(ew_grid(p.pixels * (p.C / 4))), dim3(256), 0, hs(s), p);
   check_launch("axpy");
 }

@@ -195,7 +195,7 @@ void wino_filter_transform_pc(Stream& s, int m, int r, const WShape& w, int mode
 void wino_input_adjoint(Stream& s, int m, int r, float* dV, int C, int pad, int pad_mode, int Th, int Tw, const TView& dx,
                         int accumulate);
 void wino_output_transform(Stream& s, int m, int r, const float* M, int Cm, int Th, int Tw, const float* bias, int act,
-                           const TView& y, int Cout, int accumulate);                                      // M[P][T][Cm]
+                           const TView& y, int Cout, int accumulate, float* amax_out = nullptr);    // amax_out: 6-point forms only                                      // M[P][T][Cm]
 void wino_dy_transform(Stream& s, int m, int r, const TView& dy, int Th, int Tw, float* dM, float* amax_out = nullptr,
                        const float* in_amax = nullptr, int* kscale_out = nullptr);                                     // dM[P][T][dy.C]
 // ---- the folded tail conv (tail_fold_weights below) in Winograd form: its four sub-pixel phases are (2+a)x(2+b)-tap stride-1
@@ -276,15 +276,15 @@ void pool_pattern(Stream& s, const TView& x, const TView& y, uint8_t* out_nchw);
 
 // y = act(x) elementwise on views; bwd: dx (+)= dy * act'  (derivative expressed through the
 // activation OUTPUT y: lrelu y>0?1:.2, relu y>0, tanh 1-y^2)
-void act_fwd(Stream& s, const TView& x, const TView& y, int act);
+void act_fwd(Stream& s, const TView& x, const TView& y, int act, float* amax_out = nullptr);     // amax_out: fold max|y| into the slot
 void act_bwd(Stream& s, const TView& dy, const TView& y, const TView& dx, int act, int accumulate, float* amax_out = nullptr);
 // dst (+)= alpha * src + shift   (views)
-void axpy(Stream& s, const TView& src, const TView& dst, float alpha, int accumulate, float shift = 0.f);
+void axpy(Stream& s, const TView& src, const TView& dst, float alpha, int accumulate, float shift = 0.f, float* amax_out = nullptr);
 
 // ---- resampling / gather ---------------------------------------------------------------
-void upsample_nearest_fwd(Stream& s, const TView& x, const TView& y, int factor);
+void upsample_nearest_fwd(Stream& s, const TView& x, const TView& y, int factor, float* amax_out = nullptr);
 void upsample_nearest_bwd(Stream& s, const TView& dy, const TView& dx, int factor, int accumulate);
-void maxpool2_fwd(Stream& s, const TView& x, const TView& y);
+void maxpool2_fwd(Stream& s, const TView& x, const TView& y, float* amax_out = nullptr);
 void maxpool2_bwd(Stream& s, const TView& dy, const TView& x, const TView& y, const TView& dx, int accumulate);
 // legacy RoIAlign (torchvision 0.4.0), sampling_ratio 1, spatial_scale 1.  tex: (B,H,W,C);
 // rois: device float [B*R][4] = x1,y1,x2,y2 (batch index = k / R); out: (B,PH,PW,R*C) with

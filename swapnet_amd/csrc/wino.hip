@@ -436,11 +436,12 @@ __global__ __launch_bounds__(256) void winog_filter_kernel(WShape w, int mode, i
 template <class F>
 __global__ __launch_bounds__(256) void winog_output_kernel(const float* Mx, int Cm, int N, int Th, int Tw, const float* bias,
                                                            int act, float* y, int ycs, int yH, int yW, int Cout,
-                                                           int accumulate) {
+                                                           int accumulate, float* amax_out) {
   constexpr int A = F::A, M = F::M;
   const int C4 = (Cout + 3) >> 2;
   const size_t T = (size_t)N * Th * Tw;
   const size_t total = T * C4;
+  float amx = 0.f;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
     const size_t tile = i / C4;
     const int c = (int)(i - tile * C4) * 4;
@@ -478,12 +479,14 @@ __global__ __launch_bounds__(256) void winog_output_kernel(const float* Mx, int 
         if (accumulate) v = f4add(v, *reinterpret_cast<const float4*>(dst));
         if (c + 3 < Cout) {
           *reinterpret_cast<float4*>(dst) = v;
+          amx = fmaxf(amx, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
         } else {
           const float vv[4] = {v.x, v.y, v.z, v.w};
-          for (int j = 0; j < 4 && c + j < Cout; ++j) dst[j] = vv[j];
+          for (int j = 0; j < 4 && c + j < Cout; ++j) { dst[j] = vv[j]; amx = fmaxf(amx, fabsf(vv[j])); }
         }
       }
   }
+  amax_fold(amx, amax_out);            // (the layer's output with its fused activation feeds the next GEMM: round 5)
 }
 
 // dM = A dY A^T : m x m -> (m+2) x (m+2)   (A = AT^T)
@@ -1231,8 +1234,9 @@ void wino_filter_transform_pc(Stream& s, int m, int r, const WShape& w, int mode
   check_launch("wino_filter_transform_pc");
 }
 void wino_output_transform(Stream& s, int m, int r, const float* M, int Cm, int Th, int Tw, const float* bias, int act,
-                           const TView& y, int Cout, int accumulate) {
+                           const TView& y, int Cout, int accumulate, float* amax_out) {
   const int v = variant(m, r);
+  if (v == 0 && amax_out) throw Error(1, "wino_output_transform: the F(2,3) kernel has no amax fold");
   const size_t total = (size_t)y.N * Th * Tw * ((Cout + 3) / 4);
   const dim3 grid(wgrid(total));
   if (v == 0)
@@ -1240,13 +1244,13 @@ void wino_output_transform(Stream& s, int m, int r, const float* M, int Cm, int 
                        Cout, accumulate);
   else if (v == 1)
     hipLaunchKernelGGL(winog_output_kernel<F43>, grid, dim3(256), 0, hs(s), M, Cm, y.N, Th, Tw, bias, act, y.p, y.cs, y.H,
-                       y.W, Cout, accumulate);
+                       y.W, Cout, accumulate, amax_out);
   else if (v == 2)
     hipLaunchKernelGGL(winog_output_kernel<F34>, grid, dim3(256), 0, hs(s), M, Cm, y.N, Th, Tw, bias, act, y.p, y.cs, y.H,
-                       y.W, Cout, accumulate);
+                       y.W, Cout, accumulate, amax_out);
   else
     hipLaunchKernelGGL(winog_output_kernel<F42>, grid, dim3(256), 0, hs(s), M, Cm, y.N, Th, Tw, bias, act, y.p, y.cs, y.H,
-                       y.W, Cout, accumulate);
+                       y.W, Cout, accumulate, amax_out);
   check_launch("wino_output_transform");
 }
 void wino_dy_transform(Stream& s, int m, int r, const TView& dy, int Th, int Tw, float* dM, float* amax_out, const float* in_amax,

@@ -554,7 +554,7 @@ void wino_filter_transform(Stream&, int m, int r, const WShape& w, int mode, con
   wino_filter_transform_strided(m, r, w, mode, packed, U, (size_t)K * Nn);
 }
 void wino_output_transform(Stream&, int m, int r, const float* M, int Cm, int Th, int Tw, const float* bias, int act,
-                           const TView& y, int Cout, int accumulate) { SIM_TIMED;
+                           const TView& y, int Cout, int accumulate, float* amax_out) { SIM_TIMED;
   const WinoMats wm = wino_mats(m, r);
   const int A = wm.A;
   const size_t T = (size_t)y.N * Th * Tw;
@@ -576,6 +576,7 @@ void wino_output_transform(Stream&, int m, int r, const float* M, int Cm, int Th
       }
     }
   }
+  if (amax_out) { TView yc = y; yc.C = Cout; sim_fold_view(amax_out, yc); }
 }
 static void wino_dy_transform_impl(int m, int r, const TView& dy, int Th, int Tw, float* dM) {
   const WinoMats wm = wino_mats(m, r);
@@ -918,9 +919,10 @@ bool norm_act_bwd_emits_colsum(int, int) { return false; }
 void bias_grad_from_colsums(Stream&, const double* partial, int N, int C, float* db) {
   for (int c = 0; c < C; ++c) { double a = 0; for (int n = 0; n < N; ++n) a += partial[(size_t)n * C + c]; db[c] = (float)a; }
 }
-void act_fwd(Stream&, const TView& x, const TView& y, int act) {
+void act_fwd(Stream&, const TView& x, const TView& y, int act, float* amax_out) {
   for (size_t e = 0; e < x.pixels(); ++e)
     for (int c = 0; c < x.C; ++c) y.p[e * y.cs + c] = actf(x.p[e * x.cs + c], act);
+  sim_fold_view(amax_out, y);
 }
 void act_bwd(Stream&, const TView& dy, const TView& y, const TView& dx, int act, int accumulate, float* amax_out) {
   for (size_t e = 0; e < dy.pixels(); ++e)
@@ -931,18 +933,20 @@ void act_bwd(Stream&, const TView& dy, const TView& y, const TView& dx, int act,
     }
   sim_fold_view(amax_out, dx);
 }
-void axpy(Stream&, const TView& src, const TView& dst, float alpha, int accumulate, float shift) {
+void axpy(Stream&, const TView& src, const TView& dst, float alpha, int accumulate, float shift, float* amax_out) {
   for (size_t e = 0; e < src.pixels(); ++e)
     for (int c = 0; c < src.C; ++c) {
       float v = src.p[e * src.cs + c] * alpha + shift;
       if (accumulate) v += dst.p[e * dst.cs + c];
       dst.p[e * dst.cs + c] = v;
     }
+  sim_fold_view(amax_out, dst);
 }
 
-void upsample_nearest_fwd(Stream&, const TView& x, const TView& y, int f) {
+void upsample_nearest_fwd(Stream&, const TView& x, const TView& y, int f, float* amax_out) {
   for (int n = 0; n < y.N; ++n) for (int oy = 0; oy < y.H; ++oy) for (int ox = 0; ox < y.W; ++ox)
     std::memcpy(at(y, n, oy, ox), at(x, n, oy / f, ox / f), x.C * sizeof(float));
+  sim_fold_view(amax_out, y);
 }
 void upsample_nearest_bwd(Stream&, const TView& dy, const TView& dx, int f, int accumulate) {
   for (int n = 0; n < dx.N; ++n) for (int iy = 0; iy < dx.H; ++iy) for (int ix = 0; ix < dx.W; ++ix) {
@@ -954,13 +958,14 @@ void upsample_nearest_bwd(Stream&, const TView& dy, const TView& dx, int f, int 
     }
   }
 }
-void maxpool2_fwd(Stream&, const TView& x, const TView& y) {
+void maxpool2_fwd(Stream&, const TView& x, const TView& y, float* amax_out) {
   for (int n = 0; n < y.N; ++n) for (int oy = 0; oy < y.H; ++oy) for (int ox = 0; ox < y.W; ++ox)
     for (int c = 0; c < y.C; ++c) {
       float m = at(x, n, oy * 2, ox * 2)[c];
       for (int t = 1; t < 4; ++t) { const float v = at(x, n, oy * 2 + (t >> 1), ox * 2 + (t & 1))[c]; if (v > m) m = v; }
       at(y, n, oy, ox)[c] = m;
     }
+  sim_fold_view(amax_out, y);
 }
 void maxpool2_bwd(Stream&, const TView& dy, const TView& x, const TView& y, const TView& dx, int accumulate) {
   for (int n = 0; n < y.N; ++n) for (int oy = 0; oy < y.H; ++oy) for (int ox = 0; ox < y.W; ++ox)
