@@ -1,3 +1,4 @@
+# (HISTORY: the first GPU call of round 5 as prepared by round 4; the 64-row-tile kernel and the SWAPNET_UNVERIFIED_GPU gate it names are gone since.)
 # (Round 4, third session: items 3 / 4 below are ANSWERED -- tools/native_ab.cpp ran the 64-row wave tiles (bit-equal, +0.59 ms/step:
 #  stays off) and the library-owned exchange with RCCL at world 1 from plain C++ (profiles/native_ab_r04.txt, native_diag_r04.txt).
 #  What is left for this call: the three opt-in PYTHON tests, smoke(), the default bench line, the native exchange through
