@@ -384,6 +384,56 @@ def test_two_rank_library_owned_exchange_equals_the_torch_path(tmp_path, stage, 
     mp.spawn(_native_worker, args=(2, port, str(tmp_path), stage, lambda_style), nprocs=2, join=True)
 
 
+def _agree_worker(rank, world, port, out_dir):
+    sys.path.insert(0, REPO)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(2)
+    from swapnet_amd import parallel
+    from tests import backends
+    parallel.init_from_env(backend="gloo")
+    ctx = backends.hostsim_ctx()
+    # (a) every rank can bring its communicator up: all get one
+    comm = parallel.open_native_comm(ctx)
+    assert comm is not None and ctx.native_comm is comm
+    comm.close()
+    assert ctx.native_comm is None
+    # (b) ONE rank cannot (here: rank 1's constructor raises): every rank must end up without one, the able rank's closed again
+    real = parallel.NativeComm
+    made = []
+
+    class Flaky(real):
+        def __init__(self, c, backend=None):
+            if rank == 1:
+                raise RuntimeError("ncclCommInitRank failed: 5 (simulated)")
+            super().__init__(c, backend)
+            made.append(self)
+    parallel.NativeComm = Flaky
+    try:
+        got = parallel.open_native_comm(ctx)
+    finally:
+        parallel.NativeComm = real
+    assert got is None and ctx.native_comm is None
+    if rank == 0:
+        assert len(made) == 1 and made[0].comm is None              # brought up, then closed by the agreement
+    with open(os.path.join(out_dir, "ok%d" % rank), "w") as f:
+        f.write("ok")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_ranks_agree_on_the_exchange_form(tmp_path):
+    """parallel.open_native_comm (round 5: the library-owned exchange is the default on a GPU box): if ANY rank cannot bring its
+    communicator up, EVERY rank falls back to the torch.distributed all-reduce per bucket -- a rank stepping through
+    swn_model_step_dp while another waits in dist.all_reduce would hang the job.  Two gloo ranks, the callback form of NativeComm
+    on the host simulator; on the MI355X the same agreement ran with two ranks on one device, where RCCL refuses the second
+    (profiles/two_ranks_one_gpu_r05.txt)."""
+    from tests import backends
+    backends.build_hostsim()
+    port = 34600 + os.getpid() % 2000
+    mp.spawn(_agree_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert sorted(os.listdir(tmp_path)) == ["ok0", "ok1"]
+
+
 @pytest.mark.gpu
 def test_one_rank_native_rccl_exchange_equals_the_fused_step():
     """parallel.NativeComm(backend="rccl") at world size 1: ncclCommInitRank through ctypes on the RCCL the process holds, RCCL's own
