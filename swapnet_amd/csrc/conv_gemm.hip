@@ -2774,10 +2774,10 @@ void conv_fwd(Stream& s, const ConvFwdArgs& a) {
   if (a.Npad % 4 || a.Cout > a.Npad) throw Error(1, "conv_fwd: bad Npad/Cout");
   if (a.accumulate && a.act != ACT_NONE) throw Error(1, "conv_fwd: accumulate with activation");
   const bool fast = (a.x.C % 32) == 0;
-  static const int big = getenv("SWN_TILE256") ? atoi(getenv("SWN_TILE256")) : 1;
+  constexpr int big = 1;
   p.x_bs = a.x_bs; p.w_bs = a.w_bs; p.y_bs = a.y_bs;
   const int nb = a.phases ? a.phases : std::max(a.batch, 1);
-  static const int t192 = getenv("SWN_TILE192") ? atoi(getenv("SWN_TILE192")) : 1;
+  constexpr int t192 = 1;
   // N in (128, 192] (the tail conv's input gradient into the 192-channel concat): a 128x192 tile instead
   // of two 128-wide column tiles of which the second is half empty
   if (dma_ok(a, p)) {
@@ -2926,7 +2926,7 @@ static void launch_wgrad_dma(Stream& s, GemmP& p, int nb, const ConvWgradArgs& a
   // plain [M][C] operands (batched Winograd planes): the loader without im2col arithmetic.  SWN_WGRAD_PLANE=0: generic (A/B runs)
   const bool plane = p.KH == 1 && p.KW == 1 && p.stride == 1 && p.pad_t == 0 && p.pad_l == 0 && !p.ups && !p.phases && p.Ho == 1 &&
                      p.Wo % T::PX == 0 && p.xH == 1 && p.yH == 1 && p.xW == p.Wo && p.yW == p.Wo && p.ymul == 1 && p.xmul == 1 &&
-                     p.yoff == 0 && p.xoff == 0 && p.M == p.Wo && !(getenv("SWN_WGRAD_PLANE") && atoi(getenv("SWN_WGRAD_PLANE")) == 0);
+                     p.yoff == 0 && p.xoff == 0 && p.M == p.Wo;
   const bool plane_name = two && wpl == 2 && plane;
   const int pair_name = (a.x_pair_k ? 1 : 0) | (a.dy_pair_k ? 2 : 0);
   char pname[128];
@@ -2962,7 +2962,7 @@ static void launch_wgrad_dma(Stream& s, GemmP& p, int nb, const ConvWgradArgs& a
 // storage form of a layer's Winograd planes with these when the layer is built; the launchers re-check and throw on a mismatch.)
 bool conv_fwd_takes_pairs(int xC, int Npad) { return wino_pair_planes() && conv_precut_tile(xC, Npad) != 0; }
 bool conv_wgrad_takes_pairs(size_t T, int K, int Npad) {
-  static const bool plane_off = getenv("SWN_WGRAD_PLANE") && atoi(getenv("SWN_WGRAD_PLANE")) == 0;   // pair words: plane loader only
+  constexpr bool plane_off = false;
   if (plane_off || !wino_pair_planes() || wgrad_planes() != 2 || Npad <= 32 || K % 4 || Npad % 4 || T % 16 || T * (size_t)std::max(K, Npad) * 4 >= ((size_t)1 << 31))
     return false;
   const int bmk = Npad > 64 ? 128 : 256;
@@ -3025,7 +3025,7 @@ void conv_wgrad(Stream& s, const ConvWgradArgs& a) {
   if (a.Npad % 4 || a.Cout > a.Npad || a.dy.C % 4) throw Error(1, "conv_wgrad: bad Npad/Cout");
   p.x_bs = a.x_bs; p.y_bs = a.dy_bs; p.w_bs = a.dw_bs;
   const int nb = a.phases ? a.phases : std::max(a.batch, 1);
-  static const int big = getenv("SWN_WGRAD256") ? atoi(getenv("SWN_WGRAD256")) : 1;
+  constexpr int big = 1;
   if (wgrad_dma_ok(a, p)) {
     if (a.Npad > 64) launch_wgrad_dma<2, 2>(s, p, nb, a);    // 128 k-rows x 128 columns
     else launch_wgrad_dma<4, 1>(s, p, nb, a);                // 256 x 64

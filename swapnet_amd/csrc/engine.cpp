@@ -465,7 +465,7 @@ void Net::conv(const std::string& name, const Var& x, const Var& y, ConvKind kin
   // 5x5 stride-2 conv on the ring kernel: its Winograd form would be bound by the adjoint transform of a 0.9 GB operand)
   if (kind == CK_TAIL_UP) {
     const int twminc_env = getenv("SWN_WINO_MINC") ? atoi(getenv("SWN_WINO_MINC")) : 0;
-    const bool tw_on = !(getenv("SWN_WINOGRAD") && atoi(getenv("SWN_WINOGRAD")) == 0) && !(getenv("SWN_TAIL_WINO") && atoi(getenv("SWN_TAIL_WINO")) == 0);
+    const bool tw_on = !(getenv("SWN_WINOGRAD") && atoi(getenv("SWN_WINOGRAD")) == 0);
     if (tw_on && Cip % 32 == 0 && Cip >= (twminc_env > 0 ? twminc_env : 64) && x.v.H >= 4 && x.v.W >= 4 && Cop <= 32) {
       const ParamDesc wd0 = arena.params[wi];
       const int tP = 36, tTh = ceil_div(x.v.H, 4), tTw = ceil_div(x.v.W, 4), N4 = 4 * Cop;
@@ -580,7 +580,7 @@ void Net::conv(const std::string& name, const Var& x, const Var& y, ConvKind kin
   // from 64 channels up, F(2x2,3x3) (4x instead of 2.25x transform data per input) only from 256
   const int wino_minc_env = getenv("SWN_WINO_MINC") ? atoi(getenv("SWN_WINO_MINC")) : 0;
   const int wino_force_m = getenv("SWN_WINO_M") ? atoi(getenv("SWN_WINO_M")) : 0;
-  const bool wino_k4 = !(getenv("SWN_WINO_K4") && atoi(getenv("SWN_WINO_K4")) == 0);
+  const bool wino_k4 = true;
   const bool is_k3 = kind == CK_K3S1_REFLECT || kind == CK_K3S1_ZERO;
   const bool is_k4 = kind == CK_K4S1 && wino_k4;
   const int wr = is_k4 ? 4 : 3;
@@ -596,7 +596,7 @@ void Net::conv(const std::string& name, const Var& x, const Var& y, ConvKind kin
   // transposed-conv form below walks the 18x18 padded gradient grid in 25.  The zero-padded convs (VGG16, PatchGAN's k4 s1)
   // keep the transposed stride-1 conv over dY (pad r-1-p): same tile count either way, and it is the better-conditioned form
   // (its large-entry matrices B^T / A^T act on data, not on the GEMM's output).  SWN_WINO_ADJOINT=0/2: never / always adjoint.
-  const int wadj_env = getenv("SWN_WINO_ADJOINT") ? atoi(getenv("SWN_WINO_ADJOINT")) : 1;
+  const int wadj_env = 1;
   const bool wadj = wadj_env == 2 || (wadj_env == 1 && kind == CK_K3S1_REFLECT);
   const int wpad2 = kind == CK_K3S1_ZERO ? 1 : 2;
   const int wTh2 = ceil_div(x.v.H + (kind == CK_K3S1_REFLECT ? 2 : 0), wm);
@@ -1222,7 +1222,7 @@ void Net::finalize(const std::vector<Var>& pre) {
 
 // SWN_SHARE_DY=0: the weight gradient transforms dY for itself on the side stream (the round-3 behaviour); read once
 bool Net::share_dy() const {
-  static const bool on = !(getenv("SWN_SHARE_DY") && atoi(getenv("SWN_SHARE_DY")) == 0);
+  static const bool on = true;
   return on && keep_wino_inputs && ctx.has_side;
 }
 void Net::forward() {

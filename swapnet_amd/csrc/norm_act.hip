@@ -419,7 +419,7 @@ __global__ __launch_bounds__(256) void in_fused_bwd_kernel(NAp p) {
 }
 
 static bool fused_in_on() {
-  static const bool on = !(getenv("SWN_FUSED_IN") && atoi(getenv("SWN_FUSED_IN")) == 0);  // fixed per process (buffers are planned on it)
+  static const bool on = true;        // (the round-3 A/B switch SWN_FUSED_IN is gone)
   return on;
 }
 
@@ -635,7 +635,7 @@ void norm_act_bwd(Stream& s, const NormActBwdArgs& a) {
 }
 
 bool norm_act_bwd_emits_colsum(int HW, int C) {
-  static const bool on = !(getenv("SWN_FUSED_IN") && atoi(getenv("SWN_FUSED_IN")) == 0);     // (fixed per process: buffers are planned on it)
+  static const bool on = true;
   return on && HW <= 1024 && C % 32 == 0;
 }
 void bias_grad_from_colsums(Stream& s, const double* partial, int N, int C, float* db) {

@@ -1178,7 +1178,7 @@ static int variant(int m, int r) {
 }
 // channels per thread of the 6-point input / dY transforms (SWN_WINO_VW=4: the round-3 form, one wave per SIMD on the input side)
 static int wino_vec_width() {
-  static const int vw = [] { const char* e = getenv("SWN_WINO_VW"); return e && atoi(e) == 4 ? 4 : 2; }();
+  static const int vw = 2;            // (two channels per thread: the register-friendly form measured faster in round 4; SWN_WINO_VW is gone)
   return vw;
 }
 // gains of the pair-form bound (squared largest absolute row sum of the transform matrix)

@@ -17,11 +17,9 @@ if REPO not in sys.path:
 # by the product thresholds (>= 256 coarse channels on >= 16x16 maps), and SWN_WINO_MINC=32 puts them on those forms anyway
 # (harder numerics, same kernels).  The full-size tests (256x256; BASELINE.json C2 / C3) never carry the marker and
 # additionally assert their launch list against a scrubbed-environment run (tests/backends.py default_route).
-ROUTING_SWITCHES = ("SWN_WINO_MINC", "SWN_WINOGRAD", "SWN_WINO_S2", "SWN_WINO_M", "SWN_WINO_K4", "SWN_WINO_ADJOINT",
-                    "SWN_TAIL_WINO", "SWN_TAIL4", "SWN_PHASE4", "SWN_HEAD_TAPN", "SWN_NARROW", "SWN_DMA", "SWN_DMA_WIDE", "SWN_SPLIT", "SWN_PRECUT",
-                    "SWN_PC_PLANES", "SWN_WGRAD_PLANES", "SWN_TILE256", "SWN_WGRAD256", "SWN_TILE192", "SWN_FUSED_IN", "SWN_TAIL_SPLIT",
-                    "SWN_AMAX_FUSED", "SWN_SHARE_DY", "SWN_PAIR", "SWN_WGRAD_PLANE", "SWN_FIRST_RING", "SWN_WINO_VW", "SWN_STREAM_ADAMW", "SWN_SIM_PAIR", "SWN_SIM_SLOT_REPORT",
-                    "SWN_ROI_WAVE")
+ROUTING_SWITCHES = ("SWN_WINO_MINC", "SWN_WINOGRAD", "SWN_WINO_S2", "SWN_WINO_M", "SWN_TAIL4", "SWN_PHASE4", "SWN_HEAD_TAPN", "SWN_NARROW",
+                    "SWN_DMA", "SWN_DMA_WIDE", "SWN_SPLIT", "SWN_PRECUT", "SWN_PC_PLANES", "SWN_WGRAD_PLANES", "SWN_TAIL_SPLIT", "SWN_AMAX_FUSED",
+                    "SWN_PAIR", "SWN_PREFETCH", "SWN_STREAM_ADAMW", "SWN_OVERLAP", "SWN_SIM_PAIR", "SWN_SIM_SLOT_REPORT", "SWN_ROI_WAVE")
 
 
 def pytest_configure(config):

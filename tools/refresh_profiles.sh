@@ -19,7 +19,7 @@ python bench.py --stage joint --steps 12 --warmup 4 > $O/bench_joint.json 2> $O/
 python bench.py --stage joint --captured --steps 12 --warmup 4 > $O/bench_joint_captured.json 2> $O/bench_joint_captured.err
 SWAPNET_BENCH_RCCL1=1 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-roofline > $O/bench_c2_rccl_world1.json 2> $O/bench_c2_rccl_world1.err
 # same-box A/B of this round's switches (ms/step)
-for V in X=default SWN_TAIL_SPLIT=0 SWN_PAIR=0 SWN_AMAX_FUSED=0 SWN_SHARE_DY=0 SWN_FIRST_RING=0 SWN_PREFETCH=0 SWN_STREAM_ADAMW=0 SWN_OVERLAP=0 X=default2; do
+for V in X=default SWN_TAIL_SPLIT=0 SWN_PAIR=0 SWN_AMAX_FUSED=0 SWN_PREFETCH=0 SWN_STREAM_ADAMW=0 SWN_OVERLAP=0 X=default2; do
   env $V python bench.py --steps 12 --warmup 4 --no-cpu-baseline --no-roofline 2> /dev/null | python -c "import sys,json;d=json.loads(sys.stdin.read());print('$V', d['ms_per_step'], d['value'])" >> $O/ab_switches.txt
 done
 cat $O/ab_switches.txt
