@@ -1176,11 +1176,9 @@ static int variant(int m, int r) {
   if (m == 4 && r == 2) return 3;            // strided form: output / dy / patch transforms only
   throw Error(1, "winograd: supported forms are F(2,3), F(4,3), F(3,4) and the strided F(4,2)");
 }
-// channels per thread of the 6-point input / dY transforms (SWN_WINO_VW=4: the round-3 form, one wave per SIMD on the input side)
-static int wino_vec_width() {
-  static const int vw = 2;            // (two channels per thread: the register-friendly form measured faster in round 4; SWN_WINO_VW is gone)
-  return vw;
-}
+// channels per thread of the 6-point input / dY transforms: two (round 4: the register-friendly form; the four-channel
+// instantiations of round 3 and their switch are gone)
+static constexpr int wino_vec_width() { return 2; }
 // gains of the pair-form bound (squared largest absolute row sum of the transform matrix)
 static float input_gain(int v) { return v == 3 ? 9.f : 100.f; }                         // B^T of F(4,2): 3; of the 6-point forms: 10
 static float dy_gain(int v) { return v == 1 ? 225.f : (v == 2 ? 49.f : 16.f); }        // A of F(4,3): 15; F(3,4): 7; F(4,2): 4
@@ -1198,8 +1196,8 @@ void wino_input_transform(Stream& s, int m, int r, const TView& x, int pad, int 
                      Tw, V, amax_out, in_amax, input_gain(v), kscale_out)
   if (v == 0)            // (F(2,3) planes feed the fp32-operand kernels only: no slot to fill)
     hipLaunchKernelGGL(wino_input_kernel, grid, dim3(256), 0, hs(s), x.p, x.cs, x.N, x.H, x.W, x.C, pad, pad_mode, Th, Tw, V);
-  else if (v == 1) { if (vw == 4) SWN_WIN_LAUNCH(F43, 4); else SWN_WIN_LAUNCH(F43, 2); }
-  else { if (vw == 4) SWN_WIN_LAUNCH(F34, 4); else SWN_WIN_LAUNCH(F34, 2); }
+  else if (v == 1) SWN_WIN_LAUNCH(F43, 2);
+  else SWN_WIN_LAUNCH(F34, 2);
 #undef SWN_WIN_LAUNCH
   check_launch("wino_input_transform");
 }
@@ -1266,9 +1264,9 @@ void wino_dy_transform(Stream& s, int m, int r, const TView& dy, int Th, int Tw,
                      in_amax, dy_gain(v), kscale_out)
   if (v == 0)
     hipLaunchKernelGGL(wino_dy_kernel, grid, dim3(256), 0, hs(s), dy.p, dy.cs, dy.N, dy.H, dy.W, dy.C, Th, Tw, dM);
-  else if (v == 1) { if (vw == 4) SWN_WDY_LAUNCH(F43, 4); else SWN_WDY_LAUNCH(F43, 2); }
-  else if (v == 2) { if (vw == 4) SWN_WDY_LAUNCH(F34, 4); else SWN_WDY_LAUNCH(F34, 2); }
-  else { if (vw == 4) SWN_WDY_LAUNCH(F42, 4); else SWN_WDY_LAUNCH(F42, 2); }
+  else if (v == 1) SWN_WDY_LAUNCH(F43, 2);
+  else if (v == 2) SWN_WDY_LAUNCH(F34, 2);
+  else SWN_WDY_LAUNCH(F42, 2);
 #undef SWN_WDY_LAUNCH
   check_launch("wino_dy_transform");
 }
@@ -1300,11 +1298,7 @@ void wino_s2_input_transform(Stream& s, const TView& x, int Th, int Tw, float* V
   if (x.C % 4 || x.cs % 4) throw Error(1, "wino_s2_input_transform: C must be a multiple of 4");
   const int vw = wino_vec_width();
   const size_t total = (size_t)x.N * Th * Tw * 4 * (x.C / vw);
-  if (vw == 4)
-    hipLaunchKernelGGL(wino_s2_input_kernel<4>, dim3(wgrid(total)), dim3(256), 0, hs(s), x.p, x.cs, x.N, x.H, x.W, x.C, Th, Tw, V,
-                       amax_out, in_amax, 9.f, kscale_out);
-  else
-    hipLaunchKernelGGL(wino_s2_input_kernel<2>, dim3(wgrid(total)), dim3(256), 0, hs(s), x.p, x.cs, x.N, x.H, x.W, x.C, Th, Tw, V,
+  hipLaunchKernelGGL(wino_s2_input_kernel<2>, dim3(wgrid(total)), dim3(256), 0, hs(s), x.p, x.cs, x.N, x.H, x.W, x.C, Th, Tw, V,
                        amax_out, in_amax, 9.f, kscale_out);
   check_launch("wino_s2_input_transform");
 }
