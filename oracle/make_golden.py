@@ -26,12 +26,13 @@ from oracle import ref_stubs  # noqa: E402
 from oracle.golden_io import summarize as _summarize, store_full, FULL_TENSORS  # noqa: E402
 
 _FULL = set()
+_FULL_STRIDE = [1]
 
 
 def summarize(out, key, t):
     _summarize(out, key, t)
     if key in _FULL:
-        store_full(out, key, t)
+        store_full(out, key, t, stride=_FULL_STRIDE[0] if key.endswith("/fakes") else 1)
 
 
 def base_opt(tmp, **kw):
@@ -96,11 +97,15 @@ def golden_roi_ops(path, seed=11):
     print("wrote", path)
 
 
-def golden_warp(path, H=64, B=2, init_seed=0, step_seeds=(100, 101)):
+def golden_warp(path, H=64, B=2, init_seed=0, step_seeds=(100, 101), full="warp"):
+    """Steps of the REAL WarpModel (models/warp_model.py:106-183 under models/base_gan.py:194-203).  full = which FULL_TENSORS set is
+    stored whole: "warp" (64 x 64, bs 2), "warp_256" (BASELINE.json C2's resolution: 256 x 256, the resblocks on 16 x 16 maps, PatchGAN on
+    31 x 31 -- fakes at stride 4), "warp_c1" (C1: 64 x 64, bs 4)."""
     from oracle.swapnet_oracle import synth_warp_batch
     from models.warp_model import WarpModel
+    from oracle.golden_io import FULL_STRIDE
     out = OrderedDict()
-    _FULL.clear(); _FULL.update(FULL_TENSORS["warp"])
+    _FULL.clear(); _FULL.update(FULL_TENSORS[full]); _FULL_STRIDE[0] = FULL_STRIDE.get(full, 1)
     with tempfile.TemporaryDirectory() as tmp:
         opt = base_opt(tmp, warp_mode="gan", lambda_ce=100.0, model="warp")
         torch.manual_seed(init_seed)
@@ -390,11 +395,15 @@ def golden_warp_channels(path, H=64, B=2, init_seed=0, step_seed=100):
     print("wrote", path, len(out), "entries")
 
 
-def golden_texture(path, H=64, B=2, init_seed=1, step_seeds=(200, 201)):
+def golden_texture(path, H=64, B=2, init_seed=1, step_seeds=(200, 201), full="texture"):
+    """Steps of the REAL TextureModel (models/texture_model.py:121-180).  full="texture_256": BASELINE.json C3's resolution -- the
+    U-Net's depth follows the image size (modules/swapnet_modules.py:178: num_downs = frexp(img_size)[1] - 1 = 8 at 256, three
+    dropout-carrying inner blocks, modules/pix2pix_modules.py:147-154), RoIAlign 256 -> 128, VGG16 at 256 x 256."""
     from oracle.swapnet_oracle import synth_texture_batch
     from models.texture_model import TextureModel
+    from oracle.golden_io import FULL_STRIDE
     out = OrderedDict()
-    _FULL.clear(); _FULL.update(FULL_TENSORS["texture"])
+    _FULL.clear(); _FULL.update(FULL_TENSORS[full]); _FULL_STRIDE[0] = FULL_STRIDE.get(full, 1)
     with tempfile.TemporaryDirectory() as tmp:
         opt = base_opt(tmp, model="texture", netG="swapnet", crop_size=H, lambda_l1=10.0,
                        lambda_content=20.0, lambda_style=1e-8)
@@ -476,11 +485,17 @@ if __name__ == "__main__":
     torch.set_num_threads(8)
     gold = os.path.join(REPO, "tests", "golden")
     os.makedirs(gold, exist_ok=True)
-    which = sys.argv[1:] or ["warp", "texture", "roi", "cloth", "roiops", "modes", "channels", "depths", "depths_gp", "nonsquare", "pixel"]
+    which = sys.argv[1:] or ["warp", "texture", "warp256", "warp_c1", "texture256", "roi", "cloth", "roiops", "modes", "channels", "depths", "depths_gp", "nonsquare", "pixel"]
     if "warp" in which:
         golden_warp(os.path.join(gold, "warp_step_64.npz"))
     if "texture" in which:
         golden_texture(os.path.join(gold, "texture_step_64.npz"))
+    if "warp256" in which:          # BASELINE.json C2's resolution (bs 2: seconds on the CPU)
+        golden_warp(os.path.join(gold, "warp_step_256.npz"), H=256, B=2, step_seeds=(100,), full="warp_256")
+    if "warp_c1" in which:          # BASELINE.json C1: 64 x 64, bs 4
+        golden_warp(os.path.join(gold, "warp_step_c1.npz"), H=64, B=4, step_seeds=(100, 101), full="warp_c1")
+    if "texture256" in which:       # BASELINE.json C3's resolution: the depth-8 U-Net, 12 ROIs incl. a degenerate box
+        golden_texture(os.path.join(gold, "texture_step_256.npz"), H=256, B=1, step_seeds=(200,), full="texture_256")
     if "roi" in which:
         golden_roi(os.path.join(gold, "notebook_rois.npz"))
     if "modes" in which:
