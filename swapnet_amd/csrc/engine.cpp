@@ -1233,7 +1233,11 @@ void Net::forward() {
 }
 void Net::forward_from(int op_begin) {
   if (!finalized_) throw Error(1, "Net::forward before finalize");
-  // (every slot-owning op of the nets that use this entry -- the frozen VGG16 slices -- lies at or behind op_begin = 1)
+  // every folding writer must lie at or behind op_begin (the frozen VGG16 slices are entered at op 1, behind a non-folding affine): a
+  // skipped one would leave its buffer's slot at zero while consumers trust it as complete
+  for (size_t w : fold_writer_ops)
+    if (w < (size_t)op_begin) throw Error(1, "Net::forward_from(" + std::to_string(op_begin) + ") skips op " + std::to_string(w) +
+                                             ", a folding writer of an amax slot");
   if (amax) dev_memset(ctx.s, amax, 0, amax_n * sizeof(float));
   prefetch_dgrad();
   for (size_t i = (size_t)op_begin; i < ops.size(); ++i) { if (route_on()) route_label(ops[i]->label.c_str(), 'f'); ops[i]->fwd(*this); }

@@ -176,8 +176,10 @@ class Net {
     auto it = buf_slots.find(base);
     if (it == buf_slots.end()) it = buf_slots.emplace(base, BufSlot{reserve_slot(), true}).first;
     if (!folds) it->second.complete = false;
+    else fold_writer_ops.push_back(ops.size());      // (called while the op is being built: its index once pushed)
     return it->second.off;
   }
+  std::vector<size_t> fold_writer_ops;      // tape positions of the folding writers: forward_from() must not skip one (its slot would stay 0)
   void set_external_slot(const float* base, const float* slot) { ext_slots[base] = slot; }
   const float* slot_if_complete(const float* base) const {
     auto e = ext_slots.find(base);

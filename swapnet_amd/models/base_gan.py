@@ -201,7 +201,7 @@ class BaseGAN(BaseModel, ABC):
         """Library-owned exchange up?  Decided once, by all ranks together (parallel.open_native_comm); the communicator belongs to
         the context and is closed with it."""
         if not hasattr(self, "_native_comm"):
-            self._native_comm = parallel.open_native_comm(self.backend.ctx) if parallel.native_comm_requested() else None
+            self._native_comm = parallel.open_native_comm(self.backend.ctx) if parallel.native_comm_requested(self.backend.ctx) else None
         return self._native_comm is not None
 
     # individual phases keep working too (the reference exposes them as methods)

@@ -185,25 +185,48 @@ class NativeComm:
         else:
             self._init_callback()
 
-    def _init_rccl(self):
-        dll = self.dll = _loaded_rccl()
-        dll.ncclGetUniqueId.argtypes = [C.POINTER(_NcclUniqueId)]
-        dll.ncclGetUniqueId.restype = C.c_int
-        dll.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, _NcclUniqueId, C.c_int]
-        dll.ncclCommInitRank.restype = C.c_int
-        dll.ncclCommDestroy.argtypes = [C.c_void_p]
-        dll.ncclCommDestroy.restype = C.c_int
-        uid = _NcclUniqueId()
-        if self.rank == 0:
-            rc = dll.ncclGetUniqueId(C.byref(uid))
-            if rc != 0:
-                raise RuntimeError("ncclGetUniqueId failed: %d" % rc)
+    def _agree(self, ok, what):
+        """Every rank enters or skips each collective of the bring-up TOGETHER: all-reduce(MIN) of `ok` over the default process group
+        before the next stage; if any rank failed `what`, all ranks raise here (the caller, open_native_comm, then agrees on the torch
+        form) instead of one rank leaving while its peers sit in the uid broadcast or in ncclCommInitRank."""
         if self.world > 1:
+            dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+            t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            if ok and not int(t.item()):
+                raise RuntimeError("library-owned exchange: %s failed on another rank" % what)
+
+    def _init_rccl(self):
+        uid, err = _NcclUniqueId(), None
+        try:                                    # stage 1 (local): the library, its entry points, rank 0's unique id
+            if self.rank == 0 and os.environ.get("SWAPNET_TEST_RCCL_FAIL") == "rank0-before-broadcast":
+                raise RuntimeError("injected: rank 0 fails before the uid broadcast (tests/test_data_parallel.py)")
+            dll = self.dll = _loaded_rccl()
+            dll.ncclGetUniqueId.argtypes = [C.POINTER(_NcclUniqueId)]
+            dll.ncclGetUniqueId.restype = C.c_int
+            dll.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, _NcclUniqueId, C.c_int]
+            dll.ncclCommInitRank.restype = C.c_int
+            dll.ncclCommDestroy.argtypes = [C.c_void_p]
+            dll.ncclCommDestroy.restype = C.c_int
+            if self.rank == 0:
+                rc = dll.ncclGetUniqueId(C.byref(uid))
+                if rc != 0:
+                    raise RuntimeError("ncclGetUniqueId failed: %d" % rc)
+            if self.rank != 0 and os.environ.get("SWAPNET_TEST_RCCL_FAIL") == "rank1-before-init":
+                raise RuntimeError("injected: a non-zero rank fails before ncclCommInitRank")
+        except Exception as e:                                    # noqa: BLE001 -- agreed on below, then re-raised
+            err = e
+        self._agree(err is None, "loading RCCL / ncclGetUniqueId")
+        if err is not None:
+            raise err
+        if self.world > 1:                      # stage 2: every rank is here, so every rank takes part in the broadcast
             box = [C.string_at(C.addressof(uid), 128)] if self.rank == 0 else [None]      # (raw memory: c_char arrays truncate at NUL)
             dist.broadcast_object_list(box, src=0)
             C.memmove(C.addressof(uid), box[0], 128)
+        if os.environ.get("SWAPNET_TEST_RCCL_FAIL"):               # (the injection tests stop short of the device call)
+            raise RuntimeError("injected: bring-up stopped before ncclCommInitRank")
         torch.cuda.set_device(self.ctx.device)
-        comm = C.c_void_p()
+        comm = C.c_void_p()                     # stage 3: entered by all ranks together; its outcome is agreed on by open_native_comm
         rc = dll.ncclCommInitRank(C.byref(comm), self.world, uid, self.rank)
         if rc != 0:
             raise RuntimeError("ncclCommInitRank failed: %d" % rc)
@@ -248,22 +271,30 @@ class NativeComm:
             self.comm = None
 
 
-def native_comm_requested():
-    """Which exchange a data-parallel step uses.  Default (round 5, after the RCCL form ran on the MI355X at world size 1 -- bit-equal
-    D arena, 25.5 vs 25.4 ms/step, profiles/native_ab_r04.txt, tests/test_data_parallel.py): the LIBRARY-OWNED one (swn_model_step_dp:
-    RCCL's all-reduce on a stream and with events the library owns) on a device build; SWAPNET_NATIVE_COMM=0 selects the
-    torch.distributed calls of GradExchange, =1 forces the library-owned form (the gloo callback on the host simulator)."""
+def native_comm_requested(ctx=None, world=None):
+    """Which exchange a data-parallel step uses.  SWAPNET_NATIVE_COMM=1 selects the LIBRARY-OWNED one (swn_model_step_dp: RCCL's
+    all-reduce on a stream and with events the library owns; the gloo callback on the host simulator), =0 the torch.distributed
+    calls of GradExchange.  Unset: the library-owned form only at world size 1 on a device build -- where it HAS run on the MI355X
+    (bit-equal D arena, 25.5 vs 25.4 ms/step, profiles/native_ab_r04.txt) -- and the torch form for world > 1: no box with more than
+    one GPU was ever available to this build, so the library-owned exchange has never run against a real peer (stream / event ordering
+    under a live ring is untested), and an unmeasured path is not a default.  Opt in with SWAPNET_NATIVE_COMM=1; the bench line's
+    `exchange` says which one ran."""
     v = os.environ.get("SWAPNET_NATIVE_COMM")
     if v is not None:
         return v == "1"
-    return torch.cuda.is_available()
+    if world is None:
+        world = dist.get_world_size() if dist.is_initialized() else 1
+    on_device = bool(ctx.lib.is_device) if ctx is not None else torch.cuda.is_available()
+    return on_device and world == 1
 
 
 def open_native_comm(ctx):
     """NativeComm(ctx) agreed on by every rank: if the communicator cannot be brought up on ANY rank, all ranks close theirs and the
     caller uses GradExchange (both are RCCL exchanges of the same buffers; the choice is reported, never silent).  Returns the
     communicator or None."""
-    comm, err = None, None
+    comm, err = getattr(ctx, "native_comm", None), None
+    if comm is not None:             # one communicator per context: a second model on the same context (warp + texture in one process)
+        return comm                  # shares it instead of re-attaching over it and leaking the first ncclComm
     try:
         comm = NativeComm(ctx)
     except Exception as e:                                    # noqa: BLE001

@@ -28,6 +28,8 @@ def _sim_context(device=None, lib=None, workspace_mb=512, **kw):
 engine.Context = _sim_context
 _local = int(os.environ.get("LOCAL_RANK", "0"))
 torch.cuda.is_available = lambda: True
+torch.cuda.device_count = lambda: int(os.environ.get("SWAPNET_SIM_DEVICES", "8"))
+os.environ["SWAPNET_BENCH_ENTRY"] = os.path.abspath(__file__)        # bench.py's self-launch (--gpus N, no launcher) re-enters through this wrapper
 torch.cuda.set_device = lambda d: None
 torch.cuda.synchronize = lambda *a, **k: None
 torch.cuda.current_device = lambda: _local

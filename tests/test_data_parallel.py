@@ -434,6 +434,51 @@ def test_ranks_agree_on_the_exchange_form(tmp_path):
     assert sorted(os.listdir(tmp_path)) == ["ok0", "ok1"]
 
 
+def _asym_worker(rank, world, port, out_dir, inject):
+    sys.path.insert(0, REPO)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), SWAPNET_TEST_RCCL_FAIL=inject)
+    torch.set_num_threads(2)
+    from swapnet_amd import parallel
+    from tests import backends
+    parallel.init_from_env(backend="gloo")
+    ctx = backends.hostsim_ctx()
+    real = parallel.NativeComm
+
+    class RcclBringUp(real):                  # the REAL _init_rccl (its collectives included) on a context that is not a device build
+        def __init__(self, c, backend=None):
+            super().__init__(c, backend="rccl")
+    parallel.NativeComm = RcclBringUp
+    try:
+        got = parallel.open_native_comm(ctx)
+    finally:
+        parallel.NativeComm = real
+    assert got is None and getattr(ctx, "native_comm", None) is None
+    dist.barrier()                            # the process group is still in step: no rank is stuck in a collective the other skipped
+    with open(os.path.join(out_dir, "ok%d" % rank), "w") as f:
+        f.write("ok")
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("inject", ["rank0-before-broadcast", "rank1-before-init"])
+def test_asymmetric_bring_up_failure_does_not_hang_the_ranks(tmp_path, inject):
+    """NativeComm._init_rccl has collectives of its own (the uid broadcast, ncclCommInitRank).  If rank 0 fails before the
+    broadcast, or a non-zero rank before ncclCommInitRank, the others used to wait there forever.  The bring-up now agrees stage by
+    stage (NativeComm._agree): every rank enters or skips each collective together, and all end on the torch form.  Two gloo ranks
+    drive the real _init_rccl with the failure injected (SWAPNET_TEST_RCCL_FAIL); a hang fails by timeout."""
+    from tests import backends
+    backends.build_hostsim()
+    port = 35700 + os.getpid() % 2000 + (11 if inject.startswith("rank1") else 0)
+    ctxm = mp.spawn(_asym_worker, args=(2, port, str(tmp_path), inject), nprocs=2, join=False)
+    import time as _t
+    t0 = _t.time()
+    while not ctxm.join(timeout=5):
+        if _t.time() - t0 > 240:
+            for p in ctxm.processes:
+                p.kill()
+            raise AssertionError("ranks hung in the bring-up (" + inject + ")")
+    assert sorted(os.listdir(tmp_path)) == ["ok0", "ok1"]
+
+
 @pytest.mark.gpu
 def test_one_rank_native_rccl_exchange_equals_the_fused_step():
     """parallel.NativeComm(backend="rccl") at world size 1: ncclCommInitRank through ctypes on the RCCL the process holds, RCCL's own
@@ -498,3 +543,30 @@ def test_bench_py_launch_reduce_and_report_path_for_two_ranks(native):
     assert abs(d["value"] - 2 * 1 * 2 / (d["ms_per_step"] * 2e-3)) <= 0.02 * d["value"]       # whole-job rate: world x B x steps / time
     assert d["dist_backend"] == "gloo"
     assert d["exchange"].startswith("library-owned" if native else "torch.distributed")
+
+
+def test_bench_py_launches_its_own_ranks_when_no_launcher_is_around_it():
+    """`python bench.py --gpus 2` with no WORLD_SIZE in the environment (the form the driver uses at N = 1; VERDICT r05 missing #4): bench.py
+    becomes the launcher (torch.distributed.run, one rank per device, 127.0.0.1), the line says n_gpus 2 -- and with fewer devices visible
+    than --gpus it refuses loudly instead of reporting an N-GPU line from one rank.  Two gloo ranks on the host simulator."""
+    import json
+    import subprocess
+    import sys
+    from tests import backends
+    backends.build_hostsim()
+    env = {k: v for k, v in os.environ.items() if not k.startswith("SWN_") and k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(SWAPNET_DIST_BACKEND="gloo", OMP_NUM_THREADS="4", SWAPNET_NATIVE_COMM="0")
+    cmd = [sys.executable, os.path.join(backends.REPO, "tests", "bench_on_hostsim.py"), "--gpus", "2", "--steps", "1", "--warmup", "1",
+           "--batch", "1", "--size", "64", "--no-roofline", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=backends.REPO)
+    assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["world"] == 2 and sorted(r["device"] for r in d["ranks"]) == [0, 1] and d["config"]["parallelism"] == "dp2"
+    few = subprocess.run(cmd, env=dict(env, SWAPNET_SIM_DEVICES="1"), capture_output=True, text=True, timeout=300, cwd=backends.REPO)
+    assert few.returncode != 0 and "only 1 HIP device(s) visible" in few.stderr and not [l for l in few.stdout.splitlines() if l.startswith("{")]
+    # a launcher whose world size disagrees with --gpus is refused too (never n_gpus != --gpus)
+    bad = subprocess.run(cmd[:2] + ["--gpus", "1"] + cmd[4:], env=dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0", MASTER_PORT="29977"), capture_output=True,
+                         text=True, timeout=300, cwd=backends.REPO)
+    assert bad.returncode != 0 and "WORLD_SIZE=2" in bad.stderr

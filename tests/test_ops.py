@@ -315,10 +315,11 @@ def test_conv_wide_ring_tile(monkeypatch):
 
 @pytest.mark.gpu
 def test_split_main_loop_is_as_accurate_as_the_f32_mfma(monkeypatch):
-    """The ring kernels form fp32 products from an exact 3-way bf16 split (6 bf16 MFMA products, fp32 accumulate;
-    conv_gemm.hip).  Against a float64 convolution the result must be at least as close as the v_mfma_f32_32x32x2_f32
-    form (SWN_SPLIT=0) -- forward, input gradient and weight gradient -- and the two forms must agree to fp32
-    round-off.  Inputs carry full 24-bit mantissas (randn)."""
+    """The ring kernels form fp32 products on the 16-bit matrix pipe from two amax-scaled fp16 planes per operand (h h + h l + l h:
+    3 fp16 MFMA products, fp32 accumulate; conv_gemm.hip -- the three-plane bf16 form of rounds 2-3 left the library in round 5).
+    Against a float64 convolution the result must be at least as close as the v_mfma_f32_32x32x2_f32 form (SWN_SPLIT=0) --
+    forward, input gradient and weight gradient -- and the two forms must agree to fp32 round-off.  Inputs carry full 24-bit
+    mantissas (randn)."""
     ctx = _ctx("gpu")
     g = torch.Generator().manual_seed(11)
     for kind, n, ci, h, co in ((K4S2, 4, 128, 64, 256), (K3REFL, 2, 256, 32, 256), (K4S2, 2, 512, 16, 512)):
