@@ -56,13 +56,16 @@ def store_full(out, key, t, stride=1):
     out[key + "/full"] = t.numpy()
 
 
-def compare_full(gold, key, t, rtol=1e-3, flip_slices=0, flip_cap=1e-2):
+def compare_full(gold, key, t, rtol=1e-3, flip_slices=0, flip_cap=1e-2, outlier_frac=0.0):
     """Whole-tensor check against key/full: rel-L2 <= rtol AND every element within
     rtol*|ref| + 4*rtol*rms(ref) (round-off outliers of a few sigma pass, a wrong tile / channel -- an error
     of order rms -- cannot).  flip_slices > 0 (gradient tensors): if that fails, the same two criteria are applied
     with the `flip_slices` output-channel slices (dim 0) of largest squared error left out, and the whole tensor must
     stay within flip_cap -- the signature of single LeakyReLU / ReLU sign flips between two fp32 evaluations
-    (tests/backends.py assert_grads_vs_fp64), not of a diffuse error.  Returns (ok, message)."""
+    (tests/backends.py assert_grads_vs_fp64), not of a diffuse error.  outlier_frac > 0 (un-pinned gradients at 256 x 256 only): that
+    fraction of the elements may sit outside the per-element bar -- at the far end of the backward chain every upstream flip arrives
+    spread over all channels, a heavy-tailed error whose rel-L2 stays inside rtol -- and the message counts them.
+    Returns (ok, message)."""
     ref = torch.from_numpy(np.asarray(gold[key + "/full"])).double()
     t = t.detach().double().cpu()
     if key + "/stride" in gold:
@@ -75,7 +78,7 @@ def compare_full(gold, key, t, rtol=1e-3, flip_slices=0, flip_cap=1e-2):
     tol = rtol * ref.abs() + 4 * rtol * rms
     rl2 = float((t - ref).norm() / (ref.norm() + 1e-30))
     bad = int((err > tol).sum())
-    ok = rl2 <= rtol and bad == 0
+    ok = rl2 <= rtol and bad <= outlier_frac * ref.numel()
     msg = "%s: rel-L2 %.2e (tol %.0e), %d / %d elements outside tol, worst |d| %.3e" % (
         key, rl2, rtol, bad, ref.numel(), float(err.max()))
     if not ok and flip_slices > 0 and t.dim() >= 1 and t.shape[0] > flip_slices and rl2 <= flip_cap:
@@ -83,7 +86,7 @@ def compare_full(gold, key, t, rtol=1e-3, flip_slices=0, flip_cap=1e-2):
         keep = d2.argsort()[: t.shape[0] - flip_slices]
         rl2k = float(d2[keep].sum().sqrt() / (ref.norm() + 1e-30))
         badk = int((err[keep] > tol[keep]).sum())
-        ok = rl2k <= rtol and badk == 0
+        ok = rl2k <= rtol and badk <= outlier_frac * ref.numel()
         msg += "; without the %d worst output channels: rel-L2 %.2e, %d outside tol (sign-flip signature %s)" % (
             flip_slices, rl2k, badk, "accepted" if ok else "NOT met")
     return ok, msg
