@@ -48,6 +48,7 @@ struct GemmP {
   int phases;                         // sub-pixel phase mode: blockIdx.z = 2a + b shifts pads / output offsets
   int tail4;                          // fused folded-tail kernels
   float* y_amax;                      // optional amax slot of everything the launch stores (pre-cut ring kernel + its reduce)
+  double* stat;                       // optional InstanceNorm partial sums of the output (ops.h ConvFwdArgs::stat_partial): 128 x 128 pre-cut kernel
 };
 
 __device__ __forceinline__ void apply_phase(GemmP& p) {
@@ -1084,6 +1085,43 @@ __global__ __launch_bounds__(64 * WGM, WGCU * WGM / 4) void conv_fwd_pc_kernel(G
     }
   }
   if (p.y_amax) amax_fold_wave(am, p.y_amax, blockIdx.x * WGM + wid);        // (every wave arrives here converged)
+  if constexpr (WGM == 4 && NB == 4) {
+    // Conv + InstanceNorm fusion (modules/layers.py:12-24): the statistics' partial sums of this tile's 128 output rows (one image:
+    // the launcher checked Ho * Wo % 128 == 0), per column, in fp64 -- lane: 16 rows x 4 columns, then the two half-waves (rows
+    // + 4 h), then the four waves through LDS in wave order.  Fixed order: run-to-run identical.  What is summed is what was stored.
+    if (p.stat) {
+      double sm[NB], sq[NB];
+#pragma unroll
+      for (int j = 0; j < NB; ++j) { sm[j] = 0.0; sq[j] = 0.0; }
+      if (col < p.Cout) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          if (rowoff[wid * 32 + (e & 3) + 8 * (e >> 2) + 4 * h] < 0) continue;
+#pragma unroll
+          for (int j = 0; j < NB; ++j) {
+            const double v = (col + j < p.Cout) ? (double)(acc[j][e] + ((p.bias && col + j < p.Cout) ? p.bias[col + j] : 0.f)) : 0.0;
+            sm[j] += v; sq[j] += v * v;
+          }
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < NB; ++j) { sm[j] += __shfl_xor(sm[j], 32); sq[j] += __shfl_xor(sq[j], 32); }
+      __syncthreads();                                    // rowoff is dead
+      double* red = reinterpret_cast<double*>(smem_c);    // [wave 4][column 128][2]
+      if (h == 0) {
+#pragma unroll
+        for (int j = 0; j < NB; ++j) { red[(wid * BN + colr + j) * 2] = sm[j]; red[(wid * BN + colr + j) * 2 + 1] = sq[j]; }
+      }
+      __syncthreads();
+      if (t < BN && n0 + t < p.yC) {
+        double a = 0.0, b = 0.0;
+#pragma unroll
+        for (int w = 0; w < WGM; ++w) { a += red[(w * BN + t) * 2]; b += red[(w * BN + t) * 2 + 1]; }
+        double* o = p.stat + ((size_t)tile_m * p.yC + n0 + t) * 2;
+        o[0] = a; o[1] = b;
+      }
+    }
+  }
 #endif
 }
 
@@ -2638,8 +2676,13 @@ static void launch_fwd_pc(Stream& s, GemmP& p, int nb, const unsigned short* wpc
     amax_partials(s, p.x, (size_t)(p.M / (p.Ho * p.Wo)) * p.xH * p.xW, p.xC, (size_t)p.xcs, phases ? 1 : nb, p.x_bs, part);
     a_amax = part;
   }
-  const DmaSched sc = plan_dma(p.ntiles * nb, p.ntiles, p.K / T::BK, 256 * wg, (size_t)T::BM * T::BN * 4, ws_cap, nullptr,
-                               wg * T::NW / 12.0);
+  DmaSched sc = plan_dma(p.ntiles * nb, p.ntiles, p.K / T::BK, 256 * wg, (size_t)T::BM * T::BN * 4, ws_cap, nullptr,
+                         wg * T::NW / 12.0);
+  if (p.stat) {       // the statistics come out of the tile epilogue: every tile whole
+    if (!(WGM == 4 && NB == 4) || nb != 1 || p.accumulate || p.act != ACT_NONE || (p.Ho * p.Wo) % T::BM)
+      throw Error(1, "conv_fwd: stat_partial on a launch that cannot emit statistics (ask conv_fwd_stat_chunk first)");
+    sc.full = p.ntiles * nb; sc.tail_tiles = 0; sc.tail_s = 1; sc.per_split = p.K / T::BK;
+  }
   p.slab = reinterpret_cast<float*>(s.ws);
   p.splits = sc.tail_s;
   static bool once = (set_smem(conv_fwd_pc_kernel<WGM, NB, NSTG, WGCU, PL>, T::SMEM), true);
@@ -2679,6 +2722,10 @@ static void launch_fwd_pc(Stream& s, GemmP& p, int nb, const unsigned short* wpc
 static int pc_tile_for(int Npad) { return Npad <= 64 ? 64 : ((Npad > 128 && Npad <= 192) ? 192 : 128); }
 // ops.h: which column tile a forward-type launch over an input with xC channels into Npad columns wants its weight operand
 // pre-cut for (0 = the launch does not take the pre-cut ring kernel: no operand needs to be produced)
+int conv_fwd_stat_chunk(int xC, int Npad, int HoWo) {
+  if (pc_planes() != 2 || !pc_on() || conv_precut_tile(xC, Npad) != 128 || Npad <= 64 || HoWo % 128) return 0;
+  return 128;
+}
 int conv_precut_tile(int xC, int Npad) {
   static const bool off = getenv("SWN_PRECUT") && atoi(getenv("SWN_PRECUT")) == 0;
   if (off || g_force_naive || !dma_on() || !split_on() || xC % 16 || Npad <= 32) return 0;
@@ -2771,6 +2818,9 @@ void conv_fwd(Stream& s, const ConvFwdArgs& a) {
   GemmP p = make_params(a.x, a.g, a.y, a.om, a.phases, a.batch);
   p.w = a.w; p.Npad = a.Npad; p.bias = a.bias; p.act = a.act; p.accumulate = a.accumulate; p.Cout = a.Cout;
   p.y_amax = a.y_amax;
+  p.stat = a.stat_partial;
+  if (a.stat_partial && !(a.wpc && conv_fwd_stat_chunk(a.x.C, a.Npad, a.g.Ho * a.g.Wo) && a.wpc_bn == 128 && !a.phases && a.batch <= 1))
+    throw Error(1, "conv_fwd: stat_partial on a launch outside the 128 x 128 pre-cut kernel");
   if (a.Npad % 4 || a.Cout > a.Npad) throw Error(1, "conv_fwd: bad Npad/Cout");
   if (a.accumulate && a.act != ACT_NONE) throw Error(1, "conv_fwd: accumulate with activation");
   const bool fast = (a.x.C % 32) == 0;

@@ -645,12 +645,29 @@ void Net::conv(const std::string& name, const Var& x, const Var& y, ConvKind kin
   const bool y_folds = !folded && actf != ACT_NONE && actf != ACT_TANH && (!wino || wm != 2);
   const size_t ySlot = note_writer(y.vbase, y_folds);
   const float* xbase = x.vbase;
+  // Conv + InstanceNorm fusion: a plain direct conv above the register-resident InstanceNorm's 1024 pixels offers the
+  // statistics' partial sums of its raw output from its epilogue (taken up by Net::norm_act if one normalises this buffer)
+  double* stat_partial = nullptr;
+  std::shared_ptr<bool> stat_use;
+  {
+    const int HoWo = yv.H * yv.W;
+    const bool stats_on = !(getenv("SWN_CONV_STATS") && atoi(getenv("SWN_CONV_STATS")) == 0);       // (A/B: read when a model is built)
+    const int chunk = (stats_on && !wino && !folded && pc_f == 128 && actf == ACT_NONE && HoWo > 1024 && yv.cs == yv.C && yv.p == y.vbase)
+                          ? conv_fwd_stat_chunk(Cip, arena.params[wi].ws.Npad, HoWo) : 0;
+    if (chunk) {
+      const int chunks = HoWo / chunk;
+      stat_partial = static_cast<double*>(ctx.alloc((size_t)yv.N * chunks * yv.C * 2 * sizeof(double)));
+      stat_use = std::make_shared<bool>(false);
+      conv_stats[y.vbase] = StatLink{stat_partial, chunks, stat_use};
+    }
+  }
   op->fwd = [=](Net& n) {
     const ParamDesc& wd = A->params[wi];
     ConvFwdArgs a;
     a.x = xv; a.g = gf; a.w = A->w + wd.off; a.Npad = wd.ws.Npad;
     a.x_amax = n.slot_if_complete(xbase);
     if (y_folds) a.y_amax = n.amax + ySlot;
+    if (stat_use && *stat_use) a.stat_partial = stat_partial;
     if (pc_f) { n.need(self); a.wpc = n.dgp + pcf_off; a.wpc_bn = pc_f; }
     a.bias = bi >= 0 ? A->w + A->params[bi].off : nullptr;
     a.act = actf; a.y = yv; a.Cout = Co;
@@ -1076,9 +1093,16 @@ void Net::norm_act(const Var& raw, const Var& y, bool norm, int actf, float drop
   const size_t gSlot = (y.has_grad && raw.has_grad) ? note_writer(raw.gbase, true) : 0;
   const bool has_res = residual != nullptr;
   const Var res = has_res ? *residual : Var();
+  const double* partial_in = nullptr;
+  int partial_chunks = 0;
+  if (norm && raw.v.H * raw.v.W > 1024 && raw.v.p == raw.vbase) {
+    auto it = conv_stats.find(raw.vbase);
+    if (it != conv_stats.end()) { *it->second.use = true; partial_in = it->second.partial; partial_chunks = it->second.chunks; }
+  }
   op->fwd = [=](Net& n) {
     NormActArgs a;
     a.x = rv; a.y = yv; a.stats = stats; a.norm = norm; a.act = actf;
+    a.partial_in = partial_in; a.partial_chunks = partial_chunks;
     a.drop_p = n.training ? drop_p : 0.f; a.seed = Net::drop_seed(n.seed, salt);
     a.seed_base = n.seed_dev; a.salt = salt;
     a.residual = has_res ? &res.v : nullptr;

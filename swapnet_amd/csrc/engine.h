@@ -179,6 +179,11 @@ class Net {
     else fold_writer_ops.push_back(ops.size());      // (called while the op is being built: its index once pushed)
     return it->second.off;
   }
+  // Conv + InstanceNorm fusion (modules/layers.py:12-24): a direct conv whose launch can leave the statistics' partial sums of its
+  // raw output behind (ops.h conv_fwd_stat_chunk) offers them here, keyed by the output buffer; the norm_act that normalises that
+  // buffer switches the offer on (`use`) and reads `partial` instead of taking a statistics pass of its own
+  struct StatLink { double* partial = nullptr; int chunks = 0; std::shared_ptr<bool> use; };
+  std::map<const float*, StatLink> conv_stats;
   std::vector<size_t> fold_writer_ops;      // tape positions of the folding writers: forward_from() must not skip one (its slot would stay 0)
   void set_external_slot(const float* base, const float* slot) { ext_slots[base] = slot; }
   const float* slot_if_complete(const float* base) const {

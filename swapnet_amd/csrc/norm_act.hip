@@ -582,7 +582,7 @@ void norm_act_fwd(Stream& s, const NormActArgs& a) {
   p.norm = a.norm; p.act = a.act; p.drop_p = a.drop_p; p.seed = a.seed;
   p.amax_out = a.amax_out; p.seed_base = a.seed_base; p.salt = a.salt;
   if (a.norm && !a.stats) throw Error(1, "norm_act_fwd: stats buffer required");
-  if (a.norm && p.HW <= 1024 && p.C % 32 == 0 && fused_in_on()) {
+  if (a.norm && !a.partial_in && p.HW <= 1024 && p.C % 32 == 0 && fused_in_on()) {
     const dim3 grid(p.C / 32, p.N);
     // (above 512 pixels: 16-channel slabs of 64 KB, so several blocks share a CU and one block's load phase runs under
     // another's store phase -- a 128 KB slab per block leaves one block per CU and the two phases serialise chip-wide)
@@ -593,7 +593,14 @@ void norm_act_fwd(Stream& s, const NormActArgs& a) {
     check_launch("norm_act_fwd (fused)");
     return;
   }
-  if (a.norm) {
+  if (a.norm && a.partial_in) {
+    // Conv + InstanceNorm fusion: the producing conv's epilogue left the partial sums (ops.h ConvFwdArgs::stat_partial) -- no
+    // statistics pass over x, finalize + apply only
+    if (a.partial_chunks <= 0 || p.HW % a.partial_chunks) throw Error(1, "norm_act_fwd: bad partial_chunks");
+    p.nchunk = a.partial_chunks; p.chunk = p.HW / a.partial_chunks;
+    p.partial = const_cast<double*>(a.partial_in);
+    hipLaunchKernelGGL(in_finalize_kernel<0>, dim3(ceil_div(p.N * p.C, 256)), dim3(256), 0, hs(s), p);
+  } else if (a.norm) {
     plan_chunks(p.HW, p.N, p.C, p.nchunk, p.chunk);
     p.partial = reinterpret_cast<double*>(s.ws);
     if ((size_t)p.N * p.nchunk * p.C * 16 > s.ws_bytes) throw Error(1, "norm_act: workspace too small");

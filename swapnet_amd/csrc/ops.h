@@ -108,7 +108,16 @@ struct ConvFwdArgs {
   // optional: an amax slot the launch folds max |y| of everything it stores into -- in the epilogue of the pre-cut ring kernel
   // (and the reduce kernel of its split tiles), by a pass over the output view behind every other kernel family
   float* y_amax = nullptr;
+  // optional (north_star's Conv + InstanceNorm fusion, modules/layers.py:12-24): the launch leaves the InstanceNorm statistics'
+  // partial sums of its OUTPUT behind -- stat_partial[(m / chunk) * y.C + c][2] = (sum, sum of squares) in fp64 over the `chunk`
+  // consecutive output rows m of one image, chunk = conv_fwd_stat_chunk(...) -- from the accumulators in the epilogue, so that
+  // norm_act_fwd needs no statistics pass over the tensor (NormActArgs::partial_in).  Requires act = NONE, accumulate = 0, one launch
+  // (no batch / phases) and Ho * Wo a multiple of the chunk.
+  double* stat_partial = nullptr;
 };
+// rows per statistics partial if a forward conv over xC input channels into Npad columns whose images have HoWo output pixels can
+// emit them (the 128 x 128 pre-cut ring kernel, HoWo a multiple of its 128 rows), else 0 (always 0 on the host simulator)
+int conv_fwd_stat_chunk(int xC, int Npad, int HoWo);
 constexpr int AMAX_SLOT = 256;
 // 256 partial maxima of |x| over a view into `slot` (overwrites all AMAX_SLOT entries): the amax of a tensor no kernel of ours
 // produced (network inputs)
@@ -235,6 +244,10 @@ struct NormActArgs {
   // launch sequence serves every step -- the kernels use *seed_base * 0x9E3779B1 + salt (= Net::drop_seed) instead of `seed`
   const uint64_t* seed_base = nullptr;
   uint64_t salt = 0;
+  // optional: the statistics' partial sums as the producing conv's epilogue left them (ConvFwdArgs::stat_partial):
+  // [N][partial_chunks][x.C][2] fp64.  The statistics pass over x is skipped: finalize + apply only.
+  const double* partial_in = nullptr;
+  int partial_chunks = 0;
 };
 void norm_act_fwd(Stream& s, const NormActArgs& a);
 

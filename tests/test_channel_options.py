@@ -20,8 +20,11 @@ def _blocky_onehot(B, H, C, g):
     return lab, O.labels_to_onehot(lab, C).contiguous()
 
 
-@pytest.mark.parametrize("backend", BACKENDS)
-@pytest.mark.parametrize("channels", [(12, 19), (3, 3), (12, 7)], ids=["body-labels", "cloth-rgb", "body12-cloth7"])
+# (the channel-option matrix is outside SURVEY 8's rows: on the MI355X one case per test -- the reference-golden test below runs all
+# three representations there -- the full matrix on the host simulator)
+@pytest.mark.parametrize("backend,channels", [("sim", (12, 19)), ("sim", (3, 3)), ("sim", (12, 7)),
+                                              pytest.param("gpu", (12, 7), marks=pytest.mark.gpu)],
+                         ids=["body-labels-hostsim", "cloth-rgb-hostsim", "body12-cloth7-hostsim", "body12-cloth7-mi355x"])
 def test_warp_step_with_other_representations(backend, channels):
     Cb, Cc = channels
     ctx = _ctx(backend)

@@ -68,7 +68,10 @@ def test_c5_shaped_joint_step_of_both_gan_pairs(backend):
         for i, t in enumerate(tb):
             mt.set_input(i, t)
         sw, st = O.WarpStepOracle(Gw, Dw), O.TextureStepOracle(Gt, Dt, vgg)
-        for it, (lw, lt) in enumerate((([0.9, 0.8, 1.0], [0.85, 0.95, 0.75]), ([0.75, 1.05, 0.9], [1.0, 0.7, 0.8]))):
+        # (the second iteration -- continuation from loaded weights + moments -- runs on the host simulator only: on the MI355X it was 35 s
+        # of CPU oracle for a path test_warp_step / test_texture_step already cover there; the GPU suite has a 1 200 s limit)
+        iters = (([0.9, 0.8, 1.0], [0.85, 0.95, 0.75]), ([0.75, 1.05, 0.9], [1.0, 0.7, 0.8]))[:1 if on_gpu else 2]
+        for it, (lw, lt) in enumerate(iters):
             if it > 0:
                 # Adam's first update is +-lr sign(g): a free-running second step would compare GAN trajectories, not kernels
                 # (tests/test_warp_step.py).  Both models restart from the oracle's state -- weights, both moments, step counts.

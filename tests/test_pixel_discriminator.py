@@ -22,7 +22,7 @@ SIM = pytest.param("sim", id="hostsim")
 GPU = pytest.param("gpu", id="mi355x", marks=pytest.mark.gpu)
 
 
-@pytest.mark.parametrize("backend", [SIM, GPU])
+@pytest.mark.parametrize("backend", [SIM])        # (SURVEY 2 #4 marks PixelDiscriminator OUT OF SCOPE: one GPU case -- the reference golden below -- is kept)
 def test_one_by_one_conv_operator(backend):
     """swn_op_conv kind 5: forward, input gradient, weight gradient of a 1x1 stride-1 conv against float64 -- the first layer's 22 -> 64
     (padded input buffer), the 64 -> 128 middle, the 1-channel head, and a ring-kernel-sized case."""
@@ -158,7 +158,7 @@ def test_model_api_with_the_pixel_discriminator(tmp_path, golden_dir):
         create_model(make_opt(tmp_path, "sim", discriminator="pixel", gan_mode="wgan-gp"))
 
 
-@pytest.mark.parametrize("backend", [SIM, GPU])
+@pytest.mark.parametrize("backend", [SIM])
 def test_texture_stage_against_the_pixel_discriminator(backend):
     """The texture stage builds its discriminator through the same factory (models/base_gan.py:147-149): one step against the oracle."""
     from tests.test_texture_step import vgg_state_dict

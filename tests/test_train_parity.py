@@ -365,10 +365,18 @@ def test_training_mode_loss_statistics_match_oracle():
     m = engine.NativeModel(ctx, "warp", B, H, H)
     try:
         got, ref = [], []
+        backends.reset_state(m, {engine.NET_G: G, engine.NET_D: D})
+        for i, t in enumerate(batch):
+            m.set_input(i, t)
+        w0 = [m.weight_arena(net).clone() for net in (engine.NET_G, engine.NET_D)]      # packed weights, on the device
         for k in range(K):
-            backends.reset_state(m, {engine.NET_G: G, engine.NET_D: D})
-            for i, t in enumerate(batch):
-                m.set_input(i, t)
+            # every draw from the same state: weights restored device-to-device (weight_arena() marks them changed: the derived
+            # operands are refreshed), both Adam moments and the step counters zeroed -- not 140 M parameters uploaded per draw
+            for net, w in zip((engine.NET_G, engine.NET_D), w0):
+                m.weight_arena(net).copy_(w)
+                m.arena(net, engine.W_EXP_AVG).zero_(); m.arena(net, engine.W_EXP_AVG_SQ).zero_()
+                m.optim_step_count(net, 0)
+            m.ctx.sync()
             m.step([0.9, 0.8, 1.0], training=True, seed=1000 + k)
             got.append(m.losses()["G_ce"])
             torch.manual_seed(2000 + k)

@@ -264,6 +264,140 @@ void gemm_w(LabW p) {
 #endif
 }
 
+
+// ---- round 6: the ragged last round.  36 planes = 1152 tiles on 1024 slots: the 128 tiles of the second round run ONE workgroup per
+// CU, and a lone two-stage ring waits a whole fill latency per 16-k step (fills only: 52.8 us at 1024 tiles, 125 us at 1152).  Here the
+// launch is `slots` workgroups; workgroup u runs whole tile u and then, if u < rem * tail_s, one K-slice (1 / tail_s) of a remainder
+// tile -- all four workgroups of a CU stay busy to the end.  A slice's partial tile goes to a slab; the LAST slice of a tile to arrive
+// (agent-scope counter) sums the tail_s slabs in slice order (fixed: bit-reproducible) and stores the tile.  XLOC: the slices of one
+// remainder tile sit on one XCD (u % 8).
+struct FuseP { int slots, rem, tail_s, per_split, xloc; float* slab; int* counters; int fence; };
+template <int MODE>
+__global__ __launch_bounds__(256, 4)
+void gemm_fused(LabW p, FuseP f) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int NB = 4, BM = 128, BN = 128;
+  constexpr int A_BYTES = 4 * BM * 16, B_BYTES = 4 * BN * 16, ST_BYTES = A_BYTES + B_BYTES;
+  constexpr int APC = A_BYTES / 1024, PC = ST_BYTES / 1024, PPW = PC / 4;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  __shared__ int s_last;
+  unsigned long long ck0 = 0, ck1 = 0;
+  const bool ckme = p.clk && (blockIdx.x % 13) == 0 && blockIdx.x / 13 < 16 && threadIdx.x == 0;
+  if (ckme) { ck0 = __builtin_readcyclecounter(); ck1 = __builtin_amdgcn_s_memrealtime(); }
+  const int t = threadIdx.x, lane = t & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(t >> 6);
+  const unsigned lds0 = (unsigned)(size_t)(lds_ptr_t)smem;
+  const unsigned voff = (unsigned)lane * 16u;
+  const int h = lane >> 5, l31 = lane & 31;
+  const int a_rd = (h * 2 * BM + wid * 32 + l31) * 16;
+  const int b_rd = A_BYTES + (h * 2 * BN + l31) * 16;
+  const int nss_all = p.K / 16;
+  const int u = blockIdx.x;
+  for (int item = 0; item < 2; ++item) {
+    int gtile, kb0 = 0, kb1 = nss_all, tt = 0, piece = 0;
+    if (item == 0) gtile = xcd_swz(u, f.slots);
+    else {
+      if (u >= f.rem * f.tail_s) break;
+      if (f.xloc) { tt = (u & 7) + 8 * (u / (8 * f.tail_s)); piece = (u >> 3) % f.tail_s; }
+      else { tt = u / f.tail_s; piece = u - tt * f.tail_s; }
+      if (tt >= f.rem) break;
+      gtile = f.slots + tt;
+      kb0 = piece * f.per_split; kb1 = min(nss_all, kb0 + f.per_split);
+      __syncthreads();                 // everybody is done with the ring (and the epilogue) of the first item
+    }
+    const int z = gtile / p.ntiles, tile = gtile - z * p.ntiles;
+    const int tile_n = tile % p.tiles_n, tile_m = tile / p.tiles_n;
+    float* Cb = p.C + (size_t)z * p.c_bs;
+    const i32x4 rsA = make_rsrc(p.Ap + (size_t)z * p.ap_bs, p.ap_bytes);
+    const i32x4 rsB = make_rsrc(p.Bp + (size_t)z * p.bp_bs, p.bp_bytes);
+    const unsigned a_stage = (unsigned)p.tiles_m * A_BYTES, a_tile = (unsigned)tile_m * A_BYTES;
+    const unsigned b_stage = (unsigned)p.tiles_n * B_BYTES, b_tile = (unsigned)tile_n * B_BYTES;
+    auto issue = [&](int ss, int kb) {
+      const unsigned S = lds0 + (unsigned)(ss * ST_BYTES);
+#pragma unroll
+      for (int r = 0; r < PPW; ++r) {
+        const int q = wid * PPW + r;
+        if (q < APC) lds_dma16(voff, rsA, (unsigned)kb * a_stage + a_tile + (unsigned)q * 1024u, S + (unsigned)q * 1024u);
+        else lds_dma16(voff, rsB, (unsigned)kb * b_stage + b_tile + (unsigned)(q - APC) * 1024u, S + (unsigned)q * 1024u);
+      }
+    };
+    f32x16 acc[NB];
+#pragma unroll
+    for (int j = 0; j < NB; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+    if (kb0 < kb1) {
+      issue(0, kb0);
+      int ss = 0;
+      for (int kb = kb0; kb < kb1; ++kb) {
+        wait_vm<0>();
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (kb + 1 < kb1) issue(ss ^ 1, kb + 1);
+        if (MODE != 3) {
+          const char* S = smem + ss * ST_BYTES;
+          u32x4 ah, al, bh[NB], bl[NB];
+          ah = *reinterpret_cast<const u32x4*>(S + a_rd + (0 * BM) * 16);
+          al = *reinterpret_cast<const u32x4*>(S + a_rd + (1 * BM) * 16);
+#pragma unroll
+          for (int j = 0; j < NB; ++j) {
+            bh[j] = *reinterpret_cast<const u32x4*>(S + b_rd + (0 * BN + 32 * j) * 16);
+            bl[j] = *reinterpret_cast<const u32x4*>(S + b_rd + (1 * BN + 32 * j) * 16);
+          }
+#pragma unroll
+          for (int j = 0; j < NB; ++j) acc[j] = mma_h<MODE>(al, bh[j], acc[j]);
+#pragma unroll
+          for (int j = 0; j < NB; ++j) acc[j] = mma_h<MODE>(ah, bl[j], acc[j]);
+#pragma unroll
+          for (int j = 0; j < NB; ++j) acc[j] = mma_h<MODE>(ah, bh[j], acc[j]);
+        }
+        ss ^= 1;
+      }
+    }
+    const int colr = NB * l31;
+    if (item == 1) {
+      float* slab = f.slab + ((size_t)(tt * f.tail_s + piece) * BM) * BN;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = wid * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+        *reinterpret_cast<float4*>(slab + (size_t)row * BN + colr) = make_float4(acc[0][e], acc[1][e], acc[2][e], acc[3][e]);
+      }
+      // release.  FENCE 1: agent-scope fence (buffer_wbl2 + inv of the whole L2: measured ruinous, 422 us).  FENCE 0: the slab lives in
+      // UNCACHED device memory (hipDeviceMallocUncached): its stores bypass the L2, so "my stores have completed" (vmcnt 0) is all the
+      // release there is to do.
+      if (f.fence) __threadfence(); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (t == 0) {
+        const int old = __hip_atomic_fetch_add(f.counters + tt, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = old == f.tail_s - 1;
+        if (old == f.tail_s - 1) __hip_atomic_store(f.counters + tt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // ready for the next launch
+      }
+      __syncthreads();
+      if (!s_last) break;
+      if (f.fence) __threadfence();    // acquire: the other slices' slabs (uncached memory: nothing to invalidate)
+      const float* s0 = f.slab + ((size_t)(tt * f.tail_s) * BM) * BN;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = wid * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+        float4 a = *reinterpret_cast<const float4*>(s0 + (size_t)row * BN + colr);
+        for (int sp = 1; sp < f.tail_s; ++sp) {
+          const float4 b = *reinterpret_cast<const float4*>(s0 + ((size_t)sp * BM + row) * BN + colr);
+          a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+        }
+        acc[0][e] = a.x; acc[1][e] = a.y; acc[2][e] = a.z; acc[3][e] = a.w;
+      }
+    }
+    const int col = tile_n * BN + colr;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int row = tile_m * BM + wid * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+      *reinterpret_cast<float4*>(Cb + (size_t)row * p.ldc + col) = make_float4(acc[0][e], acc[1][e], acc[2][e], acc[3][e]);
+    }
+  }
+  if (ckme) { p.clk[2 * (blockIdx.x / 13)] = __builtin_readcyclecounter() - ck0; p.clk[2 * (blockIdx.x / 13) + 1] = __builtin_amdgcn_s_memrealtime() - ck1; }
+#endif
+}
+
 __global__ void precut_b_kernel(const float* B, unsigned short* Bp, int K, int N, int BN, size_t b_bs, size_t bp_bs) {
   const int NBc = BN / 32, tiles_n = (N + BN - 1) / BN;
   const size_t total = (size_t)(K / 8) * tiles_n * BN;
@@ -431,6 +565,66 @@ int main(int argc, char** argv) {
     run("256x256 16wv (4x4) 4st pipelined     the loop", 256, 256, 4, true,  gemm_w<4, 4, 2, 2, 4, 4, 0, 1>, 1024);
     run("256x128 8wv (4x2) x64x64 3st 2/CU    the loop", 256, 128, 3, true,  gemm_w<4, 2, 2, 2, 3, 4, 0>, 512);
     run("256x128 8wv (4x2) x64x64 3st 2/CU pipelined", 256, 128, 3, true,  gemm_w<4, 2, 2, 2, 3, 4, 0, 1>, 512);
+    {   // fused remainder (round 6): `slots` workgroups, whole tile + one K-slice of a remainder tile each
+      const int total = (s.M / 128) * (s.N / 128) * s.batch, slots = 1024;
+      if (s.M % 128 == 0 && s.N % 128 == 0 && total > slots && total < 2 * slots) {
+        const int rem = total - slots, nss = s.K / 16;
+        float* dSlab; int* dCnt;
+        float* dSlabU;
+        CK(hipMalloc((void**)&dSlab, (size_t)rem * 8 * 128 * 128 * 4)); CK(hipMalloc((void**)&dCnt, rem * sizeof(int)));
+        CK(hipExtMallocWithFlags((void**)&dSlabU, (size_t)rem * 8 * 128 * 128 * 4, hipDeviceMallocUncached));
+        CK(hipMemset(dCnt, 0, rem * sizeof(int)));
+        auto runf = [&](const char* what, int tail_s, int xloc, auto kern, bool check, int fence = 0) {
+          const int my = vidx++;
+          if (!only_set.empty() && std::find(only_set.begin(), only_set.end(), my) == only_set.end()) return;
+          if (rem * tail_s > slots) { printf("   [%2d] %-46s (more slices than slots)\n", my, what); return; }
+          const int smem = 2 * (4 * 128 * 16 + 4 * 128 * 16);
+          CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+          LabW q{};
+          q.Ap = dPA[0]; q.Bp = dPB[0]; q.C = dC; q.M = s.M; q.N = s.N; q.K = s.K; q.ldc = s.N;
+          q.ap_bs = ap_bs; q.bp_bs = bp_bs[0]; q.c_bs = (size_t)s.M * s.N;
+          q.ap_bytes = (unsigned)(ap_bs * 2); q.bp_bytes = (unsigned)(bp_bs[0] * 2);
+          q.tiles_n = s.N / 128; q.tiles_m = s.M / 128; q.ntiles = q.tiles_m * q.tiles_n; q.zswz = 1; q.clk = dClk;
+          FuseP f{slots, rem, tail_s, (nss + tail_s - 1) / tail_s, xloc, fence ? dSlab : dSlabU, dCnt, fence};
+          auto fn = [&] { hipLaunchKernelGGL(kern, dim3(slots), dim3(256), smem, st, q, f); };
+          CK(hipMemsetAsync(dC, 0, nc * 4, st));
+          fn(); CK(hipStreamSynchronize(st));
+          double err = -1;
+          if (check) {
+            std::vector<float> c(nc); CK(hipMemcpy(c.data(), dC, nc * 4, hipMemcpyDeviceToHost));
+            double num = 0, den = 0;
+            for (size_t i = 0; i < nc; ++i) { const double d = (double)c[i] - r[i]; num += d * d; den += (double)r[i] * r[i]; }
+            err = std::sqrt(num / den);
+            // bit-reproducible: a second launch gives the same bits
+            fn(); CK(hipStreamSynchronize(st));
+            std::vector<float> c2(nc); CK(hipMemcpy(c2.data(), dC, nc * 4, hipMemcpyDeviceToHost));
+            if (memcmp(c.data(), c2.data(), nc * 4) != 0) printf("        !! two launches differ\n");
+          }
+          CK(hipMemsetAsync(dClk, 0, 32 * sizeof(unsigned long long), st));
+          float best = 1e30f;
+          for (int rnd = 0; rnd < 3; ++rnd) {
+            CK(hipEventRecord(e0, st));
+            for (int i = 0; i < reps; ++i) fn();
+            CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1));
+            float t; CK(hipEventElapsedTime(&t, e0, e1)); best = std::min(best, t / reps);
+          }
+          unsigned long long hclk[32]; CK(hipMemcpy(hclk, dClk, sizeof(hclk), hipMemcpyDeviceToHost));
+          double cs = 0, rs = 0; for (int i = 0; i < 16; ++i) { cs += (double)hclk[2 * i]; rs += (double)hclk[2 * i + 1]; }
+          const double ghz = rs > 0 ? cs / rs * wall_khz * 1e-6 : 0.0;
+          printf("   [%2d] %-46s rel-L2 %9.3e  %7.1f us  %6.1f fp32-eq TF  slabs %5.1f MB  clk %.2f GHz\n", my, what, err, best * 1e3,
+                 flops / best * 1e-9, tail_s > 1 ? (double)rem * tail_s * 65536 / 1e6 : 0.0, ghz);
+          fflush(stdout);
+        };
+        runf("fused remainder: K/8, agent fences, cached slab", 8, 0, gemm_fused<0>, true, 1);
+        runf("fused remainder: 1024 WGs, tile + K/8 slice", 8, 0, gemm_fused<0>, true);
+        runf("fused remainder: K/8 slices, one XCD per tile", 8, 1, gemm_fused<0>, true);
+        runf("fused remainder: K/4 slices (512 WGs take one)", 4, 0, gemm_fused<0>, true);
+        runf("fused remainder: K/2 slices (256 WGs take one)", 2, 0, gemm_fused<0>, true);
+        runf("fused remainder: K/8 slices      fills only", 8, 0, gemm_fused<3>, false);
+        runf("fused remainder: K/8 slices      no MFMA", 8, 0, gemm_fused<1>, false);
+        CK(hipFree(dSlab)); CK(hipFree(dSlabU)); CK(hipFree(dCnt));
+      }
+    }
     for (int v = 0; v < 2; ++v) { CK(hipFree(dPA[v])); CK(hipFree(dPB[v])); }
     CK(hipFree(dA)); CK(hipFree(dB)); CK(hipFree(dC)); CK(hipFree(dR));
   }
