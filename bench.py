@@ -522,7 +522,8 @@ def main():
                        "conv_wgrad_dma_128x128": "conv_wgrad_dma_kernel<2, 2, %d>" % (0 if not SPLIT else (2 if WGRAD_PLANES == 2 else 3)),
                        "conv_wgrad_dma_256x64": "conv_wgrad_dma_kernel<4, 1, %d>" % (0 if not SPLIT else (2 if WGRAD_PLANES == 2 else 3))}.get(dom.split("[")[0], dom)
             step_hbm = None
-            tnames = ("traffic_r05_texture.json", "traffic_r04_texture.json") if texture else ("traffic_r05.json", "traffic_r04.json")
+            tnames = (("traffic_r06_texture.json", "traffic_r05_texture.json", "traffic_r04_texture.json") if texture else
+                      ("traffic_r06.json", "traffic_r05.json", "traffic_r04.json"))
             for tname in tnames + ("traffic_r03b.json", "traffic_r03.json", "traffic_r02b.json", "traffic_r02.json", "traffic_r01.json"):
                 tpath = os.path.join(REPO, "profiles", tname)
                 if os.path.exists(tpath):
@@ -572,7 +573,12 @@ def main():
                                "128x128 loop runs 1.13-1.24 GHz at 85-93 % matrix-pipe occupancy on random operands and 2.0-2.2 GHz on zeros; "
                                "the same launch with its MFMAs removed 2.1-2.4 GHz; rocprofv3's GRBM_GUI_ACTIVE reads 1.90 GHz where the "
                                "in-kernel counter and SQ_WAVE_CYCLES agree on 1.40 (profiles/clock_calibration_r05.txt): it is not the "
-                               "shader clock under MFMA load"),
+                               "shader clock under MFMA load.  That holds for launches that fill whole rounds; a launch with a ragged last "
+                               "round (16 of this family's 51: 36 Winograd planes = 1152 tiles on 1024 slots) runs that round one workgroup "
+                               "per CU, where the two-stage ring waits a fill latency (~1.1 us) per 16-k step: 127 us with or without its MFMAs "
+                               "against 103 us balanced (profiles/tile_lab_r05.txt).  Round 6 measured the remedies and kept none: K-slices of "
+                               "the remainder fused into the first round with an in-kernel fix-up 229-433 us (the cross-XCD slab exchange), "
+                               "five workgroups per CU 128 us, a third ring stage does not fit four per CU (profiles/tile_lab_r06_ragged.txt)"),
                 # HBM side of the same step: bytes of the PMC passes (same source as `traffic`) over this run's step time, against
                 # the 6.3 TB/s the guide measures as achievable (8 TB/s spec)
                 "step_hbm_bytes": step_hbm,

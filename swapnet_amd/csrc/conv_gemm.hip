@@ -2722,8 +2722,15 @@ static void launch_fwd_pc(Stream& s, GemmP& p, int nb, const unsigned short* wpc
 static int pc_tile_for(int Npad) { return Npad <= 64 ? 64 : ((Npad > 128 && Npad <= 192) ? 192 : 128); }
 // ops.h: which column tile a forward-type launch over an input with xC channels into Npad columns wants its weight operand
 // pre-cut for (0 = the launch does not take the pre-cut ring kernel: no operand needs to be produced)
-int conv_fwd_stat_chunk(int xC, int Npad, int HoWo) {
-  if (pc_planes() != 2 || !pc_on() || conv_precut_tile(xC, Npad) != 128 || Npad <= 64 || HoWo % 128) return 0;
+int conv_fwd_stat_chunk(int xC, int Npad, int HoWo, int nimg, int K) {
+  if (pc_planes() != 2 || !pc_on() || conv_precut_tile(xC, Npad) != 128 || Npad <= 64 || HoWo % 128 || K % 16) return 0;
+  // only where the launch runs every tile WHOLE anyway (C2 bs 32: 1024 / 2048 tiles; C3 bs 16: 512): the statistics come out of the
+  // tile epilogue, and forcing a launch the planner would split along K onto whole tiles would trade its shorter fp32 accumulation
+  // chains for one of K / 16 x 3 MFMAs per output -- measured on the MI355X at bs 2: the normalised output 4.3e-7 instead of 2.5e-7 from
+  // float64, and the pinned gradients of the texture U-Net's deep levels 1e-4 instead of 2e-5 (tools/r06_stats_probe.py)
+  const int tiles = (int)((size_t)nimg * HoWo / 128) * ceil_div(Npad, 128);
+  const DmaSched sc = plan_dma(tiles, tiles, K / 16, 256 * 4, (size_t)128 * 128 * 4, (size_t)1 << 30, nullptr, 4 * 4 / 12.0);
+  if (sc.tail_tiles > 0 && sc.tail_s > 1) return 0;
   return 128;
 }
 int conv_precut_tile(int xC, int Npad) {
@@ -2819,7 +2826,7 @@ void conv_fwd(Stream& s, const ConvFwdArgs& a) {
   p.w = a.w; p.Npad = a.Npad; p.bias = a.bias; p.act = a.act; p.accumulate = a.accumulate; p.Cout = a.Cout;
   p.y_amax = a.y_amax;
   p.stat = a.stat_partial;
-  if (a.stat_partial && !(a.wpc && conv_fwd_stat_chunk(a.x.C, a.Npad, a.g.Ho * a.g.Wo) && a.wpc_bn == 128 && !a.phases && a.batch <= 1))
+  if (a.stat_partial && !(a.wpc && pc_planes() == 2 && pc_on() && a.Npad > 64 && (a.g.Ho * a.g.Wo) % 128 == 0 && a.wpc_bn == 128 && !a.phases && a.batch <= 1))
     throw Error(1, "conv_fwd: stat_partial on a launch outside the 128 x 128 pre-cut kernel");
   if (a.Npad % 4 || a.Cout > a.Npad) throw Error(1, "conv_fwd: bad Npad/Cout");
   if (a.accumulate && a.act != ACT_NONE) throw Error(1, "conv_fwd: accumulate with activation");

@@ -653,7 +653,7 @@ void Net::conv(const std::string& name, const Var& x, const Var& y, ConvKind kin
     const int HoWo = yv.H * yv.W;
     const bool stats_on = !(getenv("SWN_CONV_STATS") && atoi(getenv("SWN_CONV_STATS")) == 0);       // (A/B: read when a model is built)
     const int chunk = (stats_on && !wino && !folded && pc_f == 128 && actf == ACT_NONE && HoWo > 1024 && yv.cs == yv.C && yv.p == y.vbase)
-                          ? conv_fwd_stat_chunk(Cip, arena.params[wi].ws.Npad, HoWo) : 0;
+                          ? conv_fwd_stat_chunk(Cip, arena.params[wi].ws.Npad, HoWo, yv.N, Kf) : 0;
     if (chunk) {
       const int chunks = HoWo / chunk;
       stat_partial = static_cast<double*>(ctx.alloc((size_t)yv.N * chunks * yv.C * 2 * sizeof(double)));

@@ -115,9 +115,10 @@ struct ConvFwdArgs {
   // (no batch / phases) and Ho * Wo a multiple of the chunk.
   double* stat_partial = nullptr;
 };
-// rows per statistics partial if a forward conv over xC input channels into Npad columns whose images have HoWo output pixels can
-// emit them (the 128 x 128 pre-cut ring kernel, HoWo a multiple of its 128 rows), else 0 (always 0 on the host simulator)
-int conv_fwd_stat_chunk(int xC, int Npad, int HoWo);
+// rows per statistics partial if a forward conv (K = taps x xC) over xC input channels into Npad columns, nimg images of HoWo output
+// pixels each, can emit them -- the 128 x 128 pre-cut ring kernel, HoWo a multiple of its 128 rows, and a launch the planner runs in
+// whole tiles anyway (no K split to give up) -- else 0 (always 0 on the host simulator)
+int conv_fwd_stat_chunk(int xC, int Npad, int HoWo, int nimg, int K);
 constexpr int AMAX_SLOT = 256;
 // 256 partial maxima of |x| over a view into `slot` (overwrites all AMAX_SLOT entries): the amax of a tensor no kernel of ours
 // produced (network inputs)

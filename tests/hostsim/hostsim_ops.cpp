@@ -151,7 +151,7 @@ static size_t tail_panel(int ph, int xC, int Npad) {
 // A consumer checks the trailer's magic (a wrong offset / stride / tile shows up as an error, not as a silently different result).
 static const int kPanelMagic = 0x5EC07E00;
 static int sim_tile_for(int Npad) { return Npad <= 64 ? 64 : ((Npad > 128 && Npad <= 192) ? 192 : 128); }
-int conv_fwd_stat_chunk(int, int, int) { return 0; }      // (the epilogue statistics are the device kernel's: never offered here)
+int conv_fwd_stat_chunk(int, int, int, int, int) { return 0; }      // (the epilogue statistics are the device kernel's: never offered here)
 int conv_precut_tile(int xC, int Npad) {
   const char* e = getenv("SWN_PRECUT");
   if ((e && atoi(e) == 0) || xC % 16 || Npad <= 32) return 0;
