@@ -322,6 +322,10 @@ def main():
                     help="f32 (the headline, BASELINE.json C2): fp32-equivalent products from two fp16 planes per operand; "
                          "f16 (the arithmetic of C4 on however many GPUs are given): ONE fp16 plane per amax-scaled operand, "
                          "one MFMA per product, fp32 accumulation and storage -- reported with its own dtype, never as the headline")
+    ap.add_argument("--grad-wire", choices=("f32", "bf16"), default=os.environ.get("SWAPNET_GRAD_WIRE", "f32"),
+                    help="N > 1: the format gradient buckets travel in (parallel.GradExchange).  bf16 = BASELINE.json C4 / C5's exchange "
+                         "(275 MB per generator step instead of 550 MB), rounded on the device, widened back into the fp32 arena; an "
+                         "option, reported in the line, never the parity configuration")
     ap.add_argument("--captured", action="store_true",
                     help="run the step as a recorded hipGraph (swn_model_step_captured, BASELINE.json C5's captured step); "
                          "N = 1 only, bit-identical results")
@@ -381,7 +385,7 @@ def main():
     if rccl1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group(backend="nccl", rank=0, world_size=1)
-    xchg = parallel.GradExchange(world, force=rccl1)
+    xchg = parallel.GradExchange(world, force=rccl1, wire=args.grad_wire)
     label_rng = torch.Generator().manual_seed(4321)        # same on every rank (SURVEY.md 8(e) caveat 2)
 
     def draw_labels():
@@ -392,7 +396,9 @@ def main():
     # the library-owned exchange at N > 1 only with SWAPNET_NATIVE_COMM=1 (never run against a real peer: parallel.native_comm_requested),
     # by default in the 1-rank RCCL run -- agreed on by all ranks, with the
     # torch.distributed all-reduce per bucket as the other form (parallel.open_native_comm); the line says which one ran
-    native_comm = [parallel.open_native_comm(ctx) if (parallel.native_comm_requested(ctx, world) and (world > 1 or rccl1)) else None]
+    # (the library-owned exchange moves fp32: a bf16 wire format selects the torch form)
+    native_comm = [parallel.open_native_comm(ctx) if (parallel.native_comm_requested(ctx, world) and (world > 1 or rccl1) and
+                                                      args.grad_wire == "f32") else None]
 
     def one_step():
         lab = draw_labels()
@@ -475,6 +481,8 @@ def main():
         "dist_backend": (dist.get_backend() if dist.is_initialized() else None),
         "exchange": ("library-owned (swn_model_step_dp over the attached ncclAllReduce)" if native_comm[0] is not None
                      else ("torch.distributed all_reduce per bucket" if (world > 1 or rccl1) else None)),
+        "exchange_wire": (args.grad_wire if (world > 1 or rccl1) else None),
+        "exchange_bytes_per_step": (int(xchg.bytes_sent / max(args.steps + args.warmup, 1)) if (world > 1 or rccl1) and native_comm[0] is None else None),
         "hbm_allocated_gb": round(ctx.bytes_allocated() / 1e9, 2),      # arenas + activations (+ 2 x 1 GB split workspaces)
     }
 

@@ -593,6 +593,7 @@ void norm_act_fwd(Stream& s, const NormActArgs& a) {
     check_launch("norm_act_fwd (fused)");
     return;
   }
+  if (a.norm && route_on()) route_note(a.partial_in ? "norm_act[statistics from the conv epilogue]" : "norm_act[statistics pass]");
   if (a.norm && a.partial_in) {
     // Conv + InstanceNorm fusion: the producing conv's epilogue left the partial sums (ops.h ConvFwdArgs::stat_partial) -- no
     // statistics pass over x, finalize + apply only

@@ -63,31 +63,52 @@ class GradExchange:
     `finish()` makes the compute stream wait for it -- work enqueued between the two calls
     (the other network's forward/backward) overlaps with the transfer."""
 
-    def __init__(self, world=None, force=False):
+    def __init__(self, world=None, force=False, wire=None):
         """force=True issues the collectives even at world size 1 (a 1-rank RCCL all-reduce is an identity that still
-        exercises pointer wrapping of the arena slices and the stream ordering with the library's side stream)."""
+        exercises pointer wrapping of the arena slices and the stream ordering with the library's side stream).
+        wire = "bf16" (or SWAPNET_GRAD_WIRE=bf16; BASELINE.json C4 / C5 "bf16", SURVEY 8(d): 275 MB instead of 550 MB per generator
+        exchange): a bucket travels as bfloat16 -- rounded to nearest on the device, summed by the collective in bfloat16, widened back
+        into the fp32 gradient arena, AdamW and the master weights stay fp32.  An OPTION, never the parity configuration: the reference
+        has no reduced-precision path, and the rounding (8 mantissa bits per gradient element, before the sum) is a property of this
+        wire format, bounded by tests/test_data_parallel.py against the fp32 exchange."""
         self.world = world if world is not None else (dist.get_world_size() if dist.is_initialized() else 1)
         self.force = force and dist.is_initialized()
+        self.wire = (wire or os.environ.get("SWAPNET_GRAD_WIRE", "f32")).lower()
+        if self.wire not in ("f32", "bf16"):
+            raise ValueError("GradExchange wire format must be f32 or bf16, got %r" % self.wire)
+        self.bytes_sent = 0                     # what this rank handed to the collectives (the bench line reports it per step)
         self._pending = []
 
     def begin(self, flat):
         if self.world <= 1 and not self.force:
             return
-        self._pending.append((dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True), flat))
+        if self.wire == "bf16":
+            buf = flat.to(torch.bfloat16)       # (torch elementwise kernel on the current stream, behind the bucket's gradients)
+            self.bytes_sent += buf.numel() * 2
+            self._pending.append((dist.all_reduce(buf, op=dist.ReduceOp.SUM, async_op=True), flat, buf))
+            return
+        self.bytes_sent += flat.numel() * 4
+        self._pending.append((dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True), flat, None))
+
+    @staticmethod
+    def _land(work, flat, buf):
+        work.wait()
+        if buf is not None:
+            flat.copy_(buf)                     # bfloat16 -> fp32 into the arena slice AdamW reads
 
     def wait_oldest(self):
         """Make the compute stream wait for the oldest outstanding collective only; returns its buffer (or None)."""
         if not self._pending:
             return None
-        work, flat = self._pending.pop(0)
-        work.wait()
+        work, flat, buf = self._pending.pop(0)
+        self._land(work, flat, buf)
         return flat
 
     def finish(self):
         # the mean needs no extra pass: every loss gradient is pre-scaled by 1/world
         # (swn_hyper.grad_scale), so SUM over ranks is already the average
-        for work, _ in self._pending:
-            work.wait()
+        for work, flat, buf in self._pending:
+            self._land(work, flat, buf)
         self._pending = []
 
     def allreduce_mean(self, flat):

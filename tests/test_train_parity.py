@@ -358,7 +358,7 @@ def test_training_mode_loss_statistics_match_oracle():
     """Train-mode statistics without replaying masks: the mean generator loss over K independent dropout draws
     (library RNG) against the oracle's mean over K draws of torch's RNG -- same distribution, different streams."""
     ctx = backends.gpu_ctx()
-    B, H, K = 4, 64, 12          # (12 draws per side: the bar below scales with the standard error; 24 cost 70-100 s of CPU oracle on the GPU box)
+    B, H, K = 4, 64, 24
     torch.manual_seed(0)
     G, D = O.warp_module_params(), O.patchgan_params(22)
     batch = O.synth_warp_batch(B, H, H, seed=5)
@@ -369,6 +369,7 @@ def test_training_mode_loss_statistics_match_oracle():
         for i, t in enumerate(batch):
             m.set_input(i, t)
         w0 = [m.weight_arena(net).clone() for net in (engine.NET_G, engine.NET_D)]      # packed weights, on the device
+        lambda_ce = O.WarpStepOracle(G, D).h["lambda_ce"]
         for k in range(K):
             # every draw from the same state: weights restored device-to-device (weight_arena() marks them changed: the derived
             # operands are refreshed), both Adam moments and the step counters zeroed -- not 140 M parameters uploaded per draw
@@ -379,10 +380,12 @@ def test_training_mode_loss_statistics_match_oracle():
             m.ctx.sync()
             m.step([0.9, 0.8, 1.0], training=True, seed=1000 + k)
             got.append(m.losses()["G_ce"])
+            # the oracle's G_ce needs the train-mode FORWARD only (warp_model.py:141-147: lambda_ce x CE of the generated batch): a whole
+            # optimize_parameters of the 140 M-parameter port per draw was 3-7 s of CPU on the GPU box, 70-100 s of the suite
             torch.manual_seed(2000 + k)
-            st = O.WarpStepOracle(G, D, training=True)
-            st.step(*batch, labels=[0.9, 0.8, 1.0])
-            ref.append(st.losses["G_ce"])
+            with torch.no_grad():
+                fakes = O.warp_module_forward(G, batch[0], batch[1], training=True)
+                ref.append(float(torch.nn.functional.cross_entropy(fakes, torch.argmax(batch[2], dim=1))) * lambda_ce)
         got, ref = np.array(got), np.array(ref)
         se = math.sqrt(got.var(ddof=1) / K + ref.var(ddof=1) / K)
         assert abs(got.mean() - ref.mean()) < 4 * se + 1e-3 * abs(ref.mean()), (got.mean(), ref.mean(), se)
@@ -415,3 +418,37 @@ def test_destroying_a_model_returns_its_memory(backend):
     m = engine.NativeModel(c2, "warp", 1, 64, 64)
     c2.close()
     m.close()
+
+
+@pytest.mark.gpu
+def test_conv_epilogue_instance_norm_statistics_match_the_statistics_pass(monkeypatch):
+    """north_star's Conv + InstanceNorm fusion (modules/layers.py:12-24): above 1024 pixels per plane the 128 x 128 ring
+    kernel's epilogue leaves the statistics' partial sums and norm_act_fwd skips its statistics pass -- where the launch runs whole tiles
+    anyway (bs 16 at 256 x 256: body_down2 / cloth_down2 are 512 tiles).  The same forward with SWN_CONV_STATS=0 (statistics pass) must give
+    the same normalised levels to fp32 round-off of the two statistics (fp64 sums either way), the route must say which form ran, and a batch
+    the planner would split along K (bs 2) must NOT take the fused form (it would trade short accumulation chains for one long one)."""
+    ctx = backends.gpu_ctx()
+    torch.manual_seed(4)
+    G = O.warp_module_params()
+    taps, routes = {}, {}
+    for B in (16, 2):
+        batch = O.synth_warp_batch(B, 256, 256, seed=31)
+        for stats in ("1", "0"):
+            monkeypatch.setenv("SWN_CONV_STATS", stats)
+            m = engine.NativeModel(ctx, "warp", B, 256, 256, is_train=False)
+            try:
+                m.load_state_dict(engine.NET_G, G)
+                m.set_input(0, batch[0]); m.set_input(1, batch[1])
+                with backends.traced_route(ctx) as r:
+                    m.forward(False, 0)
+                routes[B, stats] = [l for l in r.lines if "norm_act[" in l]
+                taps[B, stats] = {k: m.tap(engine.NET_G, k).cpu() for k in ("body_d2", "cloth_d2", "body_d3", "dual_u3")}
+            finally:
+                m.close()
+    fused = [l for l in routes[16, "1"] if "conv epilogue" in l]
+    assert len(fused) >= 1, routes[16, "1"]          # body_down2, cloth_down2 (the report lists distinct (label, phase, kernel) triples)
+    assert not [l for l in routes[16, "0"] if "conv epilogue" in l] and not [l for l in routes[2, "1"] if "conv epilogue" in l]
+    for k in taps[16, "1"]:
+        e = rel(taps[16, "1"][k], taps[16, "0"][k])
+        assert e < 2e-6, (k, e)
+    assert all(torch.equal(taps[2, "1"][k], taps[2, "0"][k]) for k in taps[2, "1"])        # bs 2: the same kernels either way
