@@ -28,8 +28,11 @@ def _ctx(kind):
     return backends.gpu_ctx() if kind == "gpu" else backends.hostsim_ctx()
 
 
-@pytest.mark.parametrize("backend", BACKENDS)
-@pytest.mark.parametrize("mode", list(MODES))
+# (--gan_mode *-gp / *-lp are SURVEY 8(f) rank 4, a "next" row: all three modes on the host simulator, two of them -- one per penalty
+# form, gp and lp -- on the MI355X; the GPU suite runs under a 1 200 s limit most of which is CPU oracle)
+@pytest.mark.parametrize("backend,mode", [("sim", m_) for m_ in MODES] +
+                         [pytest.param("gpu", m_, marks=pytest.mark.gpu) for m_ in MODES if m_ != "dragan-gp"],
+                         ids=[m_ + "-hostsim" for m_ in MODES] + [m_ + "-mi355x" for m_ in MODES if m_ != "dragan-gp"])
 def test_warp_step_with_gradient_penalty_matches_oracle(backend, mode):
     ctx = _ctx(backend)
     B, H = 2, 64
@@ -148,8 +151,8 @@ def test_library_rng_keeps_the_layout_pad_channels_out_of_the_penalty(backend):
     m.set_hyper()
 
 
-@pytest.mark.parametrize("backend", BACKENDS)
-@pytest.mark.parametrize("n_layers", [2, 4])
+@pytest.mark.parametrize("backend,n_layers", [("sim", 2), ("sim", 4), pytest.param("gpu", 4, marks=pytest.mark.gpu)],
+                         ids=["2-hostsim", "4-hostsim", "4-mi355x"])       # (depth 2 ran on the MI355X in round 5; the simulator keeps it)
 def test_gradient_penalty_at_other_patchgan_depths(backend, n_layers, tmp_path, golden_dir):
     """--gan_mode wgan-gp / dragan-gp with --discriminator n_layers --n_layers_D 2 / 4: the reverse-over-reverse pass of csrc/gp.cpp
     follows the discriminator's depth (modules/loss.py:133-184 through modules/discriminators.py:91-136).  tests/golden/

@@ -14,7 +14,7 @@ import torch
 from oracle import swapnet_oracle as O
 from swapnet_amd import engine
 from tests import backends
-from tests.test_train_parity import BACKENDS, _ctx, _phased_step, _texture_case, noise_bias, rel
+from tests.test_train_parity import BACKENDS, _check_post_step, _ctx, _phased_step, _texture_case, noise_bias, rel
 
 TOL = 1e-4
 
@@ -46,6 +46,8 @@ def _warp_replay(ctx, B, H, seed, training, labels=(0.9, 0.8, 1.0), drop_seed=77
         for k, v in s64.losses.items():
             assert abs(L[k] - v) <= tol_fwd * abs(v) + 1e-7, (k, L[k], v)
         _warp_replay.last_forward_error = rel(m.output(), s64.fakes)
+        if check_route:            # the full-batch case also holds the post-step weights (AdamW on the pinned float64 gradients) to 1e-3
+            print("post-step weights", {k: "%.1e" % v for k, v in _check_post_step(m, s64, 1e-3, ("warp", H, "post")).items()})
         return flips, wD, wG
     finally:
         m.close()
@@ -97,6 +99,11 @@ def _texture_replay(ctx, B, H, training, labels=(0.85, 0.95, 0.75), drop_seed=99
         wD = backends.assert_grads_replayed(gD, s64.grads_D, lambda k: noise_bias(k, list(s64.grads_D)), TOL, ("texture", H, "D"))
         wG = backends.assert_grads_replayed(gG, s64.grads_G, lambda k: noise_bias(k, list(s64.grads_G)), TOL, ("texture", H, "G"))
         assert rel(m.output(), s64.fakes) < 2e-5
+        L = m.losses()
+        for k, v in s64.losses.items():
+            assert abs(L[k] - v) <= 1e-4 * abs(v) + 1e-7, (k, L[k], v)
+        if check_route:
+            print("post-step weights", {k: "%.1e" % v for k, v in _check_post_step(m, s64, 1e-3, ("texture", H, "post")).items()})
         return flips, wD, wG
     finally:
         m.close()
@@ -130,7 +137,7 @@ def test_texture_gradients_with_pinned_pattern_at_full_resolution(mode):
 def test_warp_c2_full_batch_training_step_with_pinned_pattern():
     """BASELINE.json C2 exactly as bench.py times it (256x256, bs 32, TRAINING mode, default kernel routing -- the launch list
     is compared with a scrubbed-environment process): dropout masks and activation pattern replayed in the float64 oracle,
-    every gradient tensor within 1e-4."""
+    losses and the generated batch within 2e-5, every gradient tensor within 1e-4, the post-step weights within 1e-3."""
     flips, wD, wG = _warp_replay(backends.gpu_ctx(), 32, 256, 3, True, check_route=True)
     print("warp C2 bs32 train", "flips", flips, "worst D %.2e G %.2e" % (wD, wG))
 
