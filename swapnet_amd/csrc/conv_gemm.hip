@@ -712,28 +712,41 @@ typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f32x16 mma_f16(u32x4 a, u32x4 b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
 }
-// h by truncation (one v_cvt_pkrtz for two elements; x - h is exact whatever the rounding), l rounded to nearest
+// The low plane of two elements, l = fp16(x - h), as one v_fma_mix{lo,hi}_f16 each (round 6).  x - h is exact in fp32 whatever the rounding
+// of h (h holds x's leading 11 bits: the difference has at most 13 significant bits), so the single rounding of the fused x * 1 - h equals
+// the v_cvt_f32_f16 / v_sub_f32 / v_cvt_f16_f32 sequence bit for bit (tools/mix_cut_check.hip on the MI355X: 0 mismatches over
+// truncated and nearest h, normal and subnormal values) -- 4 VALU per pair with the packed multiply instead of the 8 the compiler
+// emitted for most elements: the loops that cut an operand per 16-k step are VALU-bound (the generic weight-gradient loader:
+// 146 VALU against 12 MFMAs per wave and stage).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned resid_pack(float x0, float x1, unsigned h) {
+  unsigned l;
+  asm("v_fma_mixlo_f16 %0, %1, 1.0, -%2 op_sel_hi:[0,0,1]" : "=v"(l) : "v"(x0), "v"(h));
+  asm("v_fma_mixhi_f16 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(l) : "v"(x1), "v"(h));
+  return l;
+}
+// h by truncation (one v_cvt_pkrtz for two elements), l rounded to nearest
 __device__ __forceinline__ void split8h(const float* v, float sa, u32x4& hi, u32x4& lo) {
+  const f32x2 s2 = f32x2{sa, sa};
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
-    const float x0 = v[2 * q] * sa, x1 = v[2 * q + 1] * sa;
-    const f16x2 h = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(x0, x1));
-    const float r0 = x0 - (float)h[0], r1 = x1 - (float)h[1];
-    hi[q] = __builtin_bit_cast(unsigned, h);
-    lo[q] = __builtin_bit_cast(unsigned, f16x2{(_Float16)r0, (_Float16)r1});
+    const f32x2 x = f32x2{v[2 * q], v[2 * q + 1]} * s2;
+    const unsigned h = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(x[0], x[1]));
+    hi[q] = h;
+    lo[q] = resid_pack(x[0], x[1], h);
   }
 }
 // h rounded to NEAREST (v_cvt_pk_f16_f32): the residual l then has no preferred sign.  With both operands cut by truncation the
 // dropped l_a l_b term always carries the sign of a b -- a relative bias of ~2^-22.6 on one-signed operands (measured: -1.5e-7 on
 // post-ReLU x against positive dY); one operand rounded to nearest makes the term zero-mean.
 __device__ __forceinline__ void split8h_rn(const float* v, float sa, u32x4& hi, u32x4& lo) {
+  const f32x2 s2 = f32x2{sa, sa};
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
-    const float x0 = v[2 * q] * sa, x1 = v[2 * q + 1] * sa;
-    const f16x2 h = f16x2{(_Float16)x0, (_Float16)x1};
-    const float r0 = x0 - (float)h[0], r1 = x1 - (float)h[1];
-    hi[q] = __builtin_bit_cast(unsigned, h);
-    lo[q] = __builtin_bit_cast(unsigned, f16x2{(_Float16)r0, (_Float16)r1});
+    const f32x2 x = f32x2{v[2 * q], v[2 * q + 1]} * s2;
+    const unsigned h = __builtin_bit_cast(unsigned, f16x2{(_Float16)x[0], (_Float16)x[1]});
+    hi[q] = h;
+    lo[q] = resid_pack(x[0], x[1], h);
   }
 }
 // operand stored in PAIR form by its producer (wino.hip pair_word: {h | l << 16} per element): the two MFMA operands of 8

@@ -155,7 +155,7 @@ int main(int argc, char** argv) {
   SW(swn_ctx_create(0, nullptr, 1, (size_t)1024 << 20, &ctx));
   SAY("ctx up at %.1f s\n", now() - t00);
 
-  const bool generic = argc > 5 && (!strcmp(argv[5], "bench") || !strcmp(argv[5], "ab") || !strcmp(argv[5], "prof") || !strcmp(argv[5], "host") || !strcmp(argv[5], "phases"));
+  const bool generic = argc > 5 && (!strcmp(argv[5], "bench") || !strcmp(argv[5], "ab") || !strcmp(argv[5], "prof") || !strcmp(argv[5], "host") || !strcmp(argv[5], "phases") || !strcmp(argv[5], "hash"));
   if (!getenv("NATIVE_AB_SKIP_OPS") && !generic) {
     int big = H >= 256;
     op_case(ctx, "k4s2 64->128 (body_down2 / PatchGAN model.2 shape)", 0, big ? 8 : 2, 64, big ? 128 : 16, 128, big ? 64 : 8);
@@ -218,6 +218,16 @@ int main(int argc, char** argv) {
     SW(swn_ctx_sync(ctx));
     return (now() - t0) * 1e3 / steps;
   };
+  if (argc > 5 && !strcmp(argv[5], "hash")) {
+    // K training-mode steps from the seeded state, then the FNV hashes of both weight arenas: two builds of the library that claim
+    // to compute the same bits (a re-scheduled kernel, a cheaper instruction sequence for the same arithmetic) print the same line
+    plain_steps(K);
+    uint64_t hh[2]; arena_hashes(ctx, m, hh);
+    say_losses(m, "hash");
+    SAY("hash after %d steps: G %016llx D %016llx\n", K, (unsigned long long)hh[0], (unsigned long long)hh[1]);
+    SW(swn_model_destroy(m)); SW(swn_ctx_destroy(ctx));
+    return 0;
+  }
   if (argc > 5 && !strcmp(argv[5], "bench")) {
     plain_steps(5);
     double ms = plain_steps(K);
