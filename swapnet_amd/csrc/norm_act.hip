@@ -37,6 +37,7 @@ struct NAp {
   float* amax_out;              // optional amax slot of what the apply kernels write (fwd: y, bwd: dx)
   const uint64_t* seed_base;    // captured step: the step seed lives in device memory; seed = *seed_base * 0x9E3779B1 + salt
   uint64_t salt;
+  int pair_xcd;                 // in_fused_group
 };
 __device__ __forceinline__ uint64_t na_seed(const NAp& p) { return p.seed_base ? *p.seed_base * 0x9E3779B1ull + p.salt : p.seed; }
 
@@ -285,13 +286,26 @@ __device__ __forceinline__ void block_tree_sum(double* red, double (&v)[NV], int
   for (int j = 0; j < NV; ++j) v[j] = red[tx * NV + j];
 }
 
+// Channel group of a block.  A 16-channel slab reads 64 bytes per pixel: half a 128-byte line, whose other half belongs to the
+// neighbouring group.  Workgroups go round-robin over the 8 XCDs in launch order, so groups g and g + 1 land on different L2s and the
+// line is fetched twice (FETCH_SIZE: 2.0 x the operands of the <16, 16> launches, 1.0 x for the contiguous apply kernels).  Within
+// every 16 consecutive blocks the order is permuted so that line partners are 8 launches apart -- the same XCD, microseconds apart.
+// SWN_IN_PAIR_XCD=0 (A/B, read per launch) keeps the plain order.
+template <int CG>
+__device__ __forceinline__ int in_fused_group(int pair_xcd) {
+  const int x = blockIdx.x;
+  if (CG != 16 || !pair_xcd) return x;
+  const int r = x & 15;
+  return (x & ~15) + ((r & 7) << 1) + (r >> 3);
+}
+
 template <int CG, int NP>
 __global__ __launch_bounds__(256) void in_fused_fwd_kernel(NAp p) {
   const uint64_t drop_seed_v = na_seed(p);
   constexpr int C4 = CG / 4, ROWS = 256 / C4;
   __shared__ double red[256 * 8];
   const int t = threadIdx.x, tx = t % C4, ty = t / C4;
-  const int n = blockIdx.y, c = blockIdx.x * CG + tx * 4;
+  const int n = blockIdx.y, c = in_fused_group<CG>(p.pair_xcd) * CG + tx * 4;
   float4 v[NP];
   double s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   // all loads first, unconditionally (rows past the map re-read its last pixel and are masked below): inside `if (pix < HW)`
@@ -351,7 +365,7 @@ __global__ __launch_bounds__(256) void in_fused_bwd_kernel(NAp p) {
   constexpr int C4 = CG / 4, ROWS = 256 / C4;
   __shared__ double red[256 * 8];
   const int t = threadIdx.x, tx = t % C4, ty = t / C4;
-  const int n = blockIdx.y, c = blockIdx.x * CG + tx * 4;
+  const int n = blockIdx.y, c = in_fused_group<CG>(p.pair_xcd) * CG + tx * 4;
   float mean[4], rstd[4];
   {
     const float* st = p.stats + ((size_t)n * p.C + c) * 2;
@@ -582,6 +596,7 @@ void norm_act_fwd(Stream& s, const NormActArgs& a) {
   p.norm = a.norm; p.act = a.act; p.drop_p = a.drop_p; p.seed = a.seed;
   p.amax_out = a.amax_out; p.seed_base = a.seed_base; p.salt = a.salt;
   if (a.norm && !a.stats) throw Error(1, "norm_act_fwd: stats buffer required");
+  p.pair_xcd = (p.C % 256 == 0 && !(getenv("SWN_IN_PAIR_XCD") && atoi(getenv("SWN_IN_PAIR_XCD")) == 0)) ? 1 : 0;
   if (a.norm && !a.partial_in && p.HW <= 1024 && p.C % 32 == 0 && fused_in_on()) {
     const dim3 grid(p.C / 32, p.N);
     // (above 512 pixels: 16-channel slabs of 64 KB, so several blocks share a CU and one block's load phase runs under
@@ -621,6 +636,7 @@ void norm_act_bwd(Stream& s, const NormActBwdArgs& a) {
   p.colsum = a.colsum;
   p.amax_out = a.amax_out; p.seed_base = a.seed_base; p.salt = a.salt;
   if (a.colsum && !(a.norm && norm_act_bwd_emits_colsum(p.HW, p.C))) throw Error(1, "norm_act_bwd: colsum requested on the chunked path");
+  p.pair_xcd = (p.C % 256 == 0 && !(getenv("SWN_IN_PAIR_XCD") && atoi(getenv("SWN_IN_PAIR_XCD")) == 0)) ? 1 : 0;
   if (a.norm && p.HW <= 1024 && p.C % 32 == 0 && fused_in_on()) {
     if (p.HW <= 64) hipLaunchKernelGGL((in_fused_bwd_kernel<32, 2>), dim3(p.C / 32, p.N), dim3(256), 0, hs(s), p);
     else if (p.HW <= 256) hipLaunchKernelGGL((in_fused_bwd_kernel<32, 8>), dim3(p.C / 32, p.N), dim3(256), 0, hs(s), p);
