@@ -417,6 +417,10 @@ struct DmaSched {            // hybrid schedule, computed by the launcher
   int tail_tiles, tail_s;    // then tail_tiles tiles split tail_s ways along K
   int per_split;             // stages per split of a tail tile
   int tiles_per_z;           // tiles of one batch element / phase
+  // > 0 (the four sub-pixel phases of one launch, pre-cut ring kernel): z is the FAST index of the tile order, gtile = tile * zfast + z.
+  // The phases of a launch gather the same input through different tap offsets: with z slow, an XCD's contiguous run of tiles
+  // (xcd_swizzle) is part of ONE phase and the same input region is fetched by the four XCDs that hold its four phases
+  int zfast;
 };
 
 template <int WGM, int WGN>
@@ -632,7 +636,7 @@ __global__ __launch_bounds__(256) void conv_dma_reduce_kernel(GemmP p, DmaSched 
   if (e4 >= BM * BN / 4) return;
   const int r = e4 / (BN / 4), c4 = (e4 - r * (BN / 4)) * 4;
   const int gtile = sc.full + tt;
-  const int z = gtile / sc.tiles_per_z, tile = gtile - z * sc.tiles_per_z;
+  const int z = sc.zfast ? gtile % sc.zfast : gtile / sc.tiles_per_z, tile = sc.zfast ? gtile / sc.zfast : gtile - z * sc.tiles_per_z;
   const int tile_n = tile % p.tiles_n, tile_m = tile / p.tiles_n;
   const int m = tile_m * BM + r, col = tile_n * BN + c4;
   if (m >= p.M || col >= p.Cout) return;
@@ -876,7 +880,7 @@ __global__ __launch_bounds__(64 * WGM, WGCU * WGM / 4) void conv_fwd_pc_kernel(G
     tt = u / sc.tail_s; split = u - tt * sc.tail_s; nsplit = sc.tail_s;
     gtile = sc.full + tt;
   }
-  const int z = gtile / sc.tiles_per_z, tile = gtile - z * sc.tiles_per_z;
+  const int z = sc.zfast ? gtile % sc.zfast : gtile / sc.tiles_per_z, tile = sc.zfast ? gtile / sc.zfast : gtile - z * sc.tiles_per_z;
   const int tile_n = tile % p.tiles_n, tile_m = tile / p.tiles_n;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
   p.x += (size_t)z * p.x_bs; p.y += (size_t)z * p.y_bs;
@@ -2691,6 +2695,7 @@ static void launch_fwd_pc(Stream& s, GemmP& p, int nb, const unsigned short* wpc
   }
   DmaSched sc = plan_dma(p.ntiles * nb, p.ntiles, p.K / T::BK, 256 * wg, (size_t)T::BM * T::BN * 4, ws_cap, nullptr,
                          wg * T::NW / 12.0);
+  if (phases && !(getenv("SWN_PHASE_ZFAST") && atoi(getenv("SWN_PHASE_ZFAST")) == 0)) sc.zfast = nb;     // (A/B, read per launch)
   if (p.stat) {       // the statistics come out of the tile epilogue: every tile whole
     if (!(WGM == 4 && NB == 4) || nb != 1 || p.accumulate || p.act != ACT_NONE || (p.Ho * p.Wo) % T::BM)
       throw Error(1, "conv_fwd: stat_partial on a launch that cannot emit statistics (ask conv_fwd_stat_chunk first)");
