@@ -11,6 +11,13 @@ void* dev_alloc(size_t bytes) {
   if (bytes == 0) bytes = 16;
   SWN_HIP_CHECK(hipMalloc(&p, bytes));
   SWN_HIP_CHECK(hipMemset(p, 0, bytes));
+  // hipMemset on device memory returns before the fill has run (it is a launch on the null stream), and the library's streams are
+  // hipStreamNonBlocking: they do NOT order behind the null stream.  Without this wait a stream operation issued right behind the
+  // allocation could land BEFORE the fill and be zeroed by it -- observed in round 6 (tools/native_ab ... trace, first process of a
+  // call, where the first fill also pays the runtime's lazy start-up): the conditional-input channel map of PatchGAN's first layer
+  // (ParamArena::allocate: alloc + upload on the context's stream) arrived zeroed, pack_weight dropped ten input channels of
+  // model.0.weight and the whole run computed with another discriminator (profiles/alloc_fill_race_r06.txt).
+  SWN_HIP_CHECK(hipStreamSynchronize(nullptr));
   return p;
 }
 void dev_free(void* p) {

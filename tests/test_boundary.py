@@ -121,3 +121,42 @@ def test_the_c_abi_drives_a_training_step_from_plain_cpp(tmp_path):
     assert "finite 1" in line, line
     g_ce = float(line.split("G_ce")[1].split()[0])
     assert 150.0 < g_ce < 450.0, line              # 100 x the cross entropy of 19 near-uniform classes (ln 19 = 2.94) after a few steps
+
+
+@pytest.mark.gpu
+def test_a_context_that_owns_its_stream_packs_and_computes_what_the_callers_stream_does():
+    """swn_ctx_create(create_stream = 1) -- the form a host without torch uses (tools/native_ab.cpp) -- runs on
+    hipStreamNonBlocking streams, which do not order behind the null stream the allocator's zero-fill runs on.  Round 6 found the
+    conditional-input channel map of PatchGAN's first layer (uploaded right behind its allocation inside swn_warp_model_create)
+    zeroed by a fill that landed after the upload at the benchmark's size (24.6 GB of fills in flight): model.0.weight lost ten
+    input channels and every C++-driven run computed with another discriminator (profiles/alloc_fill_race_r06.txt).  The python
+    path was never affected (torch's current stream is the null stream here).  Held at C2's size, where the race was deterministic:
+    both kinds of context hand back the weights they were given and compute the same step, bit for bit."""
+    import torch
+    from oracle import swapnet_oracle as O              # seeded weights and batch only (the checker's generators)
+    from swapnet_amd import engine
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU visible")
+    B, H = 32, 256
+    torch.manual_seed(0)
+    G, D = O.warp_module_params(), O.patchgan_params(22)
+    batch = O.synth_warp_batch(B, H, H, seed=4321)
+    results = []
+    for own in (True, False):
+        ctx = engine.Context(workspace_mb=1024, use_torch_stream=not own)
+        m = engine.NativeModel(ctx, "warp", B, H, H, is_train=True)
+        m.load_state_dict(engine.NET_G, G)
+        m.load_state_dict(engine.NET_D, D)
+        back = m.state_dict(engine.NET_D, to_cpu=True)
+        for k, v in D.items():
+            assert torch.equal(back[k], v), ("own stream" if own else "caller's stream", k)
+        m.set_hyper()
+        for i, t in enumerate(batch):
+            m.set_input(i, t)
+        m.step((0.9, 0.8, 1.0), training=False, seed=0)
+        ctx.sync()
+        results.append((m.losses(), m.arena(engine.NET_D, engine.W_WEIGHT).clone(), m.output().clone()))
+        m.close(); ctx.close()
+    (la, wa, oa), (lb, wb, ob) = results
+    assert la == lb, (la, lb)
+    assert torch.equal(wa, wb) and torch.equal(oa, ob)

@@ -155,7 +155,7 @@ int main(int argc, char** argv) {
   SW(swn_ctx_create(0, nullptr, 1, (size_t)1024 << 20, &ctx));
   SAY("ctx up at %.1f s\n", now() - t00);
 
-  const bool generic = argc > 5 && (!strcmp(argv[5], "bench") || !strcmp(argv[5], "ab") || !strcmp(argv[5], "prof") || !strcmp(argv[5], "host") || !strcmp(argv[5], "phases") || !strcmp(argv[5], "hash"));
+  const bool generic = argc > 5 && (!strcmp(argv[5], "bench") || !strcmp(argv[5], "ab") || !strcmp(argv[5], "prof") || !strcmp(argv[5], "host") || !strcmp(argv[5], "phases") || !strcmp(argv[5], "hash") || !strcmp(argv[5], "trace") || !strcmp(argv[5], "truth"));
   if (!getenv("NATIVE_AB_SKIP_OPS") && !generic) {
     int big = H >= 256;
     op_case(ctx, "k4s2 64->128 (body_down2 / PatchGAN model.2 shape)", 0, big ? 8 : 2, 64, big ? 128 : 16, 128, big ? 64 : 8);
@@ -218,6 +218,113 @@ int main(int argc, char** argv) {
     SW(swn_ctx_sync(ctx));
     return (now() - t0) * 1e3 / steps;
   };
+  if (argc > 5 && !strcmp(argv[5], "truth")) {
+    // K steps three ways from the same state, weight-arena hashes of each: (a) phase by phase with the device drained after every phase
+    // and the second stream off (nothing can overtake anything: the reference outcome), (b) phase by phase, two streams, no draining,
+    // (c) the fused swn_model_step.  All three must print the same hashes.
+    // who owns an arena element: every parameter's LOGICAL elements marked through swn_model_param_set on the gradient arena; what stays
+    // unmarked is layout padding (columns Co .. Npad, channels Ci .. Cip of the packed panels), which no state_dict ever sees
+    std::vector<float> first[2][4]; std::vector<int> owner[2];
+    for (int net = 0; net < 2; net++) {
+      float* g = nullptr; size_t n = 0; SW(swn_model_arena(m, net, 1, &g, &n));
+      dzero(g, n * 4);
+      float* marks = (float*)dalloc(st.zeros_n * 4);
+      for (size_t i = 0; i < st.p[net].size(); i++) {
+        std::vector<float> h(st.p[net][i].n, (float)(i + 1)); h2d(marks, h.data(), h.size() * 4);
+        SW(swn_model_param_set(m, net, 1, st.p[net][i].name.c_str(), marks));
+      }
+      SW(swn_ctx_sync(ctx));
+      std::vector<float> h(n); d2h(h.data(), g, n * 4);
+      owner[net].resize(n); size_t pad = 0;
+      for (size_t i = 0; i < n; i++) { owner[net][i] = (int)h[i] - 1; pad += h[i] == 0.f; }
+      SAY("truth net %d: arena of %zu elements, %zu of them layout padding\n", net, n, pad);
+      dfree(marks); dzero(g, n * 4);
+    }
+    int run_no = 0;
+    auto compare = [&](const char* what) {
+      static const char* arena_name[4] = {"weight", "grad", "exp_avg", "exp_avg_sq"};
+      for (int net = 0; net < 2; net++) for (int which = 0; which < 4; which++) {
+        float* p = nullptr; size_t n = 0; SW(swn_model_arena(m, net, which, &p, &n));
+        std::vector<float> h(n); d2h(h.data(), p, n * 4);
+        if (run_no == 0) { first[net][which] = h; continue; }
+        size_t diff = 0, diff_pad = 0, shown = 0;
+        for (size_t i = 0; i < n; i++) if (memcmp(&h[i], &first[net][which][i], 4)) {
+          diff++; const int o = owner[net][i]; diff_pad += o < 0;
+          if (o < 0 && diff_pad <= 4) {
+            size_t j = i; while (j > 0 && owner[net][j] < 0) j--;
+            SAY("truth   %s net %d %s[%zu] (padding, %zu behind the last element of %s): %.9g against %.9g in the first run\n", what, net, arena_name[which], i, i - j,
+                owner[net][j] >= 0 ? st.p[net][owner[net][j]].name.c_str() : "?", h[i], first[net][which][i]);
+          }
+          if (o >= 0 && shown++ < 12) SAY("truth   %s net %d %s[%zu] of %s: %.9g against %.9g in the first run\n", what, net, arena_name[which], i, st.p[net][o].name.c_str(), h[i], first[net][which][i]);
+        }
+        if (diff) SAY("truth   %s net %d %s arena: %zu elements differ from the first run, %zu of them layout padding\n", what, net, arena_name[which], diff, diff_pad);
+      }
+      run_no++;
+    };
+    auto run = [&](const char* what, int mode) {
+      reset_state(m, st); SW(swn_ctx_sync(ctx));
+      uint64_t sd = 1000;
+      if (mode == 0) SW(swn_ctx_set_overlap(ctx, 0));
+      for (int k = 0; k < K; k++) {
+        ++sd;
+        if (mode == 2) { SW(swn_model_step(m, labels, 1, sd)); continue; }
+        SW(swn_model_forward(m, 1, sd)); if (mode == 0) SW(swn_ctx_sync(ctx));
+        SW(swn_model_backward_D(m, labels[0], labels[1])); if (mode == 0) SW(swn_ctx_sync(ctx));
+        SW(swn_model_optimizer_step(m, 1)); if (mode == 0) SW(swn_ctx_sync(ctx));
+        SW(swn_model_backward_G(m, labels[2])); if (mode == 0) SW(swn_ctx_sync(ctx));
+        SW(swn_model_optimizer_step(m, 0)); if (mode == 0) SW(swn_ctx_sync(ctx));
+      }
+      if (mode == 0) SW(swn_ctx_set_overlap(ctx, 1));
+      uint64_t hh[2]; arena_hashes(ctx, m, hh);
+      SAY("truth %-58s G %016llx D %016llx\n", what, (unsigned long long)hh[0], (unsigned long long)hh[1]);
+      say_losses(m, "truth");
+      compare(what);
+    };
+    run("phases, one stream, drained after every phase", 0);
+    run("phases, two streams, not drained", 1);
+    run("fused swn_model_step", 2);
+    run("phases, one stream, drained after every phase (again)", 0);
+    SW(swn_model_destroy(m)); SW(swn_ctx_destroy(ctx));
+    return 0;
+  }
+  if (argc > 5 && !strcmp(argv[5], "trace")) {
+    // FNV hashes of all four arenas of both networks after initialisation and after each of K training-mode steps, with the losses: two
+    // processes that should compute the same bits print the same lines, and the first line that differs says where they part
+    auto dump = [&](const char* what) {
+      SW(swn_ctx_sync(ctx));
+      for (int net = 0; net < 2; net++) {
+        unsigned long long hh[4];
+        for (int which = 0; which < 4; which++) {
+          float* p = nullptr; size_t n = 0; SW(swn_model_arena(m, net, which, &p, &n));
+          std::vector<float> h(n); d2h(h.data(), p, n * 4); hh[which] = fnv(h.data(), n * 4);
+        }
+        SAY("trace %-8s net %d  w %016llx  g %016llx  m %016llx  v %016llx\n", what, net, hh[0], hh[1], hh[2], hh[3]);
+      }
+    };
+    // TRACE_PRELUDE: pieces of the truth mode's ownership prelude in front of the first step (which of them changes the outcome?)
+    //   1 zero both gradient arenas through hipMemset   2 write marks into the gradient arenas (param_set which = 1), not cleared
+    //   3 hipMalloc + hipFree of a parameter-sized buffer   4 = 2, then 1 (the truth mode's prelude)
+    const int prelude = getenv("TRACE_PRELUDE") ? atoi(getenv("TRACE_PRELUDE")) : 0;
+    if (prelude == 3) { void* q = dalloc(st.zeros_n * 4); dfree(q); }
+    if (prelude == 2 || prelude == 4) {
+      float* marks = (float*)dalloc(st.zeros_n * 4);
+      for (int net = 0; net < 2; net++) for (size_t i = 0; i < st.p[net].size(); i++) {
+        std::vector<float> h(st.p[net][i].n, (float)(i + 1)); h2d(marks, h.data(), h.size() * 4);
+        SW(swn_model_param_set(m, net, 1, st.p[net][i].name.c_str(), marks));
+      }
+      SW(swn_ctx_sync(ctx)); dfree(marks);
+    }
+    if (prelude == 1 || prelude == 4) for (int net = 0; net < 2; net++) { float* g = nullptr; size_t n = 0; SW(swn_model_arena(m, net, 1, &g, &n)); dzero(g, n * 4); }
+    SAY("trace prelude %d\n", prelude);
+    dump("init");
+    for (int k = 0; k < K; k++) {
+      SW(swn_model_step(m, labels, 1, ++seed));
+      char tag[32]; snprintf(tag, sizeof tag, "step%d", k + 1);
+      dump(tag); say_losses(m, tag);
+    }
+    SW(swn_model_destroy(m)); SW(swn_ctx_destroy(ctx));
+    return 0;
+  }
   if (argc > 5 && !strcmp(argv[5], "hash")) {
     // K training-mode steps from the seeded state, then the FNV hashes of both weight arenas: two builds of the library that claim
     // to compute the same bits (a re-scheduled kernel, a cheaper instruction sequence for the same arithmetic) print the same line
