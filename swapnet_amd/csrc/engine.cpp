@@ -1254,6 +1254,7 @@ void Net::forward() {
   if (amax) dev_memset(ctx.s, amax, 0, amax_n * sizeof(float));       // every slot: the step's producers fold into zeros
   prefetch_dgrad();
   for (auto& op : ops) { if (route_on()) route_label(op->label.c_str(), 'f'); op->fwd(*this); }
+  prefetch_finish();
 }
 void Net::forward_from(int op_begin) {
   if (!finalized_) throw Error(1, "Net::forward before finalize");
@@ -1265,42 +1266,73 @@ void Net::forward_from(int op_begin) {
   if (amax) dev_memset(ctx.s, amax, 0, amax_n * sizeof(float));
   prefetch_dgrad();
   for (size_t i = (size_t)op_begin; i < ops.size(); ++i) { if (route_on()) route_label(ops[i]->label.c_str(), 'f'); ops[i]->fwd(*this); }
+  prefetch_finish();
+}
+// The operand refresh on the second stream, issued PIECEWISE (round 6).  Issuing all of it at the top of the pass -- ~130 launches and
+// ~60 event records on the second stream in front of the pass's first kernel -- kept the main queue idle for 2.2 ms of every step: the
+// runtime lets the host run only a bounded number of commands ahead of a queue, so the host sat inside that loop until the GPU had
+// worked the batch down to its last dozen launches, and only then got to enqueue the forward pass (rocprofv3 --kernel-trace of bench.py,
+// of bench.py on a stream of its own and of tools/native_ab alike: profiles/refresh_issue_order_r06.txt; tools/fork_probe.hip shows the
+// events themselves release with single-kernel granularity when the host is ahead).  Now the pass starts with the operands of its first
+// SWN_PREFETCH_AHEAD layers in flight and every layer, once its own operands are waited for, issues those of the layer that many places
+// further down: both queues are fed in the order the GPU consumes them.  SWN_PREFETCH=3: everything at the top (the old order, for the
+// A/B); 0: in order on the main stream.
+int Net::prefetch_mode() {
+  static const int mode = getenv("SWN_PREFETCH") ? atoi(getenv("SWN_PREFETCH")) : 1;
+  return mode;
+}
+static size_t prefetch_ahead() {
+  static const int n = getenv("SWN_PREFETCH_AHEAD") ? std::max(1, atoi(getenv("SWN_PREFETCH_AHEAD"))) : 4;
+  return (size_t)n;
 }
 void Net::prefetch_dgrad() {
-  static const bool prefetch = !(getenv("SWN_PREFETCH") && atoi(getenv("SWN_PREFETCH")) == 0);    // 0: refresh in order on the main stream
-  if (!prefetch || !ctx.use_side() || dg_version == arena.version || refresh_pending) return;
-  bool any = false;
-  for (auto& op : ops) any = any || (bool)op->repack;
-  if (!any) return;
+  const int mode = prefetch_mode();
+  if (mode == 0 || !ctx.use_side() || dg_version == arena.version || refresh_open_) return;
+  if (repack_ops_.empty())
+    for (size_t i = 0; i < ops.size(); ++i)
+      if (ops[i]->repack) { ops[i]->repack_index = (int)repack_ops_.size(); repack_ops_.push_back(i); }
+  if (repack_ops_.empty()) return;
   ctx.fork_side();                 // after the optimizer step that produced the weights and after every
                                    // main-stream reader of the previous operands
+  refresh_open_ = true; refresh_pending = true; repack_next_ = 0;
+  dg_version = arena.version;
+  prefetch_issue(mode == 3 ? repack_ops_.size() : prefetch_ahead());
+}
+void Net::prefetch_issue(size_t upto) {
+  upto = std::min(upto, repack_ops_.size());
+  if (!refresh_open_ || repack_next_ >= upto) return;
   std::swap(ctx.s, ctx.side);      // the re-pack launchers use ctx.s
   try {
-    for (auto& op : ops)
-      if (op->repack) {
-        if (route_on()) route_label(op->label.c_str(), 'r');
-        op->repack(*this);
-        if (!op->ready) op->ready = event_create();
-        event_record(op->ready, ctx.s);        // (ctx.s is the side stream here)
-        op->ready_pending = true;
-      }
+    for (; repack_next_ < upto; ++repack_next_) {
+      Op* op = ops[repack_ops_[repack_next_]].get();
+      if (route_on()) route_label(op->label.c_str(), 'r');
+      op->repack(*this);
+      if (!op->ready) op->ready = event_create();
+      event_record(op->ready, ctx.s);        // (ctx.s is the side stream here)
+      op->ready_pending = true;
+    }
   } catch (...) { std::swap(ctx.s, ctx.side); throw; }
   std::swap(ctx.s, ctx.side);
-  if (!refresh_event) refresh_event = event_create();
-  event_record(refresh_event, ctx.side);
-  refresh_pending = true;
-  dg_version = arena.version;
+  if (repack_next_ == repack_ops_.size()) {
+    if (!refresh_event) refresh_event = event_create();
+    event_record(refresh_event, ctx.side);
+    refresh_open_ = false;
+  }
 }
+void Net::prefetch_finish() { if (refresh_open_) prefetch_issue(repack_ops_.size()); }
 void Net::need(Op* op) {
+  if (refresh_open_ && op->repack_index >= 0) prefetch_issue((size_t)op->repack_index + 1);      // (its own: normally issued layers ago)
   if (refresh_pending && op->ready_pending) {
     stream_wait_event(ctx.s, op->ready);
     op->ready_pending = false;
+    if (refresh_open_) prefetch_issue((size_t)op->repack_index + 1 + prefetch_ahead());
     return;
   }
   if (!refresh_pending) refresh_dgrad();
 }
 void Net::refresh_dgrad() {
   if (refresh_pending) {
+    prefetch_finish();
     stream_wait_event(ctx.s, refresh_event);
     refresh_pending = false;
     for (auto& op : ops) op->ready_pending = false;

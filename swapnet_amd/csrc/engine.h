@@ -130,6 +130,7 @@ struct Op {
   // share, so the op waits for its own operands only (Net::need)
   void* ready = nullptr;
   bool ready_pending = false;
+  int repack_index = -1;    // position among the net's operand-carrying ops (Net::prefetch_dgrad)
 };
 
 class Net {
@@ -262,6 +263,12 @@ class Net {
   // with a side stream: start the refresh there (forward() calls it, so the HBM-bound re-packs /
   // filter transforms overlap the first layers); refresh_dgrad() is the wait point
   void prefetch_dgrad();
+  static int prefetch_mode();
+  void prefetch_issue(size_t upto);      // re-packs of the first `upto` operand-carrying ops, on the second stream
+  void prefetch_finish();                // whatever the pass did not ask for
+  std::vector<size_t> repack_ops_;       // ops that carry a re-pack, in op order
+  size_t repack_next_ = 0;               // how many of them the current refresh has issued
+  bool refresh_open_ = false;            // a refresh is being issued piecewise
   void* refresh_event = nullptr;
   bool refresh_pending = false;
 

@@ -5,6 +5,7 @@ library) and, in swapnet_amd.parallel, for torch.distributed.  No arithmetic of 
 happens in torch.
 """
 import ctypes as C
+import os
 from collections import OrderedDict
 
 import torch
@@ -29,6 +30,8 @@ class Context:
             # pointers we borrow, and RCCL collectives are then ordered with our kernels for free
             self.torch_stream = torch.cuda.current_stream(self.device)
             stream = C.c_void_p(self.torch_stream.cuda_stream)
+            if os.environ.get("SWAPNET_OWN_STREAM") == "1":     # (experiment: the context's main stream is its own, not torch's current one)
+                use_torch_stream = False
             dev_index, create = self.device.index, int(not use_torch_stream)
         else:                       # CI host simulator (tests only)
             self.device = torch.device("cpu")

@@ -78,3 +78,15 @@ for s_, e, q, k in iv:
 print("time a kernel runs with the other queue idle (queue, name, ms):")
 for (q, k), ms in sorted(alone.items(), key=lambda x: -x[1])[:30]:
     print("  %-3s %-50s %8.3f" % (q, k, ms))
+# --dump-gap: every launch of both queues around the longest gap of the critical queue (what the critical queue waited for)
+if "--dump-gap" in sys.argv:
+    prev = None; best = (0, 0, 0)
+    for s_, e, q, k in win:
+        if q != mainq: continue
+        if prev is not None and s_ - prev > best[0]: best = (s_ - prev, prev, s_)
+        if prev is None or e > prev: prev = e
+    g, ga, gb = best
+    print("launches around the longest gap of queue %s (%.3f ms, from +%.3f ms):" % (mainq, g * 1e-6, (ga - t0) * 1e-6))
+    for s_, e, q, k in rows:
+        if e > ga - 300000 and s_ < gb + 700000:
+            print("  q%-2s +%9.3f .. +%9.3f ms  %7.1f us  %s" % (q, (s_ - t0) * 1e-6, (e - t0) * 1e-6, (e - s_) * 1e-3, short(k)))
