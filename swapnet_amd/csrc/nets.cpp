@@ -193,6 +193,8 @@ class WarpModel final : public Model {
   // amax slots of the buffers filled from outside the tape (engine.h ext_slots): taken when an input is handed over.  The
   // conditional-D buffer also receives the generator's tanh output each step: its slot is floored at 1 = sup |tanh|.
   float *slot_body = nullptr, *slot_cloth = nullptr, *slot_dx = nullptr;
+  bool ce_first_ = false, ce_done_ = false;      // CE gradient written first, PatchGAN input gradient accumulated (see the constructor)
+  float ce_scale_ = 0.f;
 
   WarpModel(Ctx& c, int B_, int H_, int W_, bool train, float drop, int body_channels, int cloth_channels, Model* share = nullptr)
       : Model(share) {
@@ -230,7 +232,22 @@ class WarpModel final : public Model {
       D1 = std::make_unique<Net>(c, arenaD);
       D1->set_external_slot(Dx.vbase, slot_dx);
       pred1 = build_patchgan(*D1, Dx.batch(0, B), c.patchgan_layers, cimap, Ccp);      // d(fakes) only: the condition is data
-      D1->finalize({pred1});
+      // Cross-entropy term first (round 6).  d loss_G / d fakes = the PatchGAN pass's input gradient + the CE gradient; the CE term
+      // needs neither network's update, so it is taken EARLY -- behind the discriminator's backward pass, where the main stream
+      // otherwise waits 0.6 ms for the first layer's weight gradient and AdamW(D) on the second stream -- and writes the buffer; the
+      // PatchGAN's input gradient then accumulates into it (the planner is told the range is pre-written).  a + b = b + a: the sum is
+      // bit-identical to the old order (GAN term written, CE accumulated).  Only where the first layer's gradient covers exactly
+      // the generator's channels (the narrow input gradient); SWN_CE_EARLY=0 keeps the old order (read when a model is built).
+      const bool ce_early_wanted = !(getenv("SWN_CE_EARLY") && atoi(getenv("SWN_CE_EARLY")) == 0);
+      ce_first_ = false;
+      if (ce_early_wanted)
+        for (auto& op : D1->ops)
+          if (!op->grad_targets.empty() && op->grad_targets[0].gbase == Dx.gbase) {
+            ce_first_ = op->grad_targets.size() == 1 && op->grad_targets[0].g.C == Ccp && op->grad_targets[0].g.p == Dx.batch(0, B).g.p;
+            break;
+          }
+      if (ce_first_) D1->finalize({pred1, Dx.batch(0, B).slice(0, Ccp)});
+      else D1->finalize({pred1});
     }
   }
   void refresh_input_slots(int slot) {
@@ -276,6 +293,15 @@ class WarpModel final : public Model {
   void forward(bool training, uint64_t seed) override {       // warp_model.py:106-107
     G->training = training; G->seed = seed;
     G->forward();
+    ce_done_ = false;
+  }
+  // loss_G's cross-entropy term (warp_model.py:150-156): value into the loss slots, gradient WRITTEN to d(fakes)
+  void ce_term() {
+    Stream& s = ctx->s;
+    TView dfakes = Dx.batch(0, B).g.slice(0, Ccp);
+    ce_scale_ = hyper.lambda_ce * hyper.grad_scale;
+    ce_argmax_loss(s, Dx.batch(0, B).v.slice(0, Ccp), Dx.batch(B, B).v.slice(0, Ccp), Cc, ce_scale_, losses + L_TMP1, &dfakes, 0);
+    ce_done_ = true;
   }
   void backward_D(float label_fake, float label_real) override {     // warp_model.py:109-139
     Stream& s = ctx->s;
@@ -288,7 +314,9 @@ class WarpModel final : public Model {
     gan_loss_op(s, hyper.gan_mode, pf, label_fake, false, 0.5f * hyper.grad_scale, losses + L_D_FAKE, &gf, label_dev(0));
     gan_loss_op(s, hyper.gan_mode, pr, label_real, true, 0.5f * hyper.grad_scale, losses + L_D_REAL, &gr, label_dev(1));
     scalar_axpby(s, losses + L_D_FAKE, 0.5f, losses + L_D_REAL, 0.5f, losses + L_D);
-    D2->backward(true, false);
+    D2->backward_range(true, false, 0, (int)D2->ops.size(), /*join=*/false);
+    if (ce_first_ && !hyper.warp_mode_ce_only) ce_term();      // under the tail of the weight gradients on the second stream
+    ctx->join_side();                                          // every D gradient is final for whatever the main stream does next
     if (hyper.gp_mode) run_gradient_penalty(Dx.batch(B, B).v, Dx.batch(0, B).v);     // warp_model.py:126-136
     else dev_memset(s, losses + L_D_GP, 0, sizeof(float));
   }
@@ -303,13 +331,16 @@ class WarpModel final : public Model {
     TView dfakes = Dx.batch(0, B).g.slice(0, Ccp);
     TView targets = Dx.batch(B, B).v.slice(0, Ccp);
     if (!hyper.warp_mode_ce_only) {
+      // (the early CE term stands if it was taken for this forward pass under the weights in force now)
+      if (ce_first_ && !(ce_done_ && ce_scale_ == hyper.lambda_ce * hyper.grad_scale)) ce_term();
       D1->refresh_dgrad();
       D1->training = false;
       D1->forward();                                   // D was just updated (base_gan.py:199)
       gan_loss_op(s, hyper.gan_mode, pred1.v, label_real, true, hyper.lambda_gan * hyper.grad_scale, losses + L_TMP0, &pred1.g, label_dev(2));
       scalar_axpby(s, losses + L_TMP0, hyper.lambda_gan, nullptr, 0.f, losses + L_G_GAN);
-      D1->backward(false, true);                       // D weight grads would be discarded (quirk 5)
-      ce_argmax_loss(s, fakes, targets, Cc, hyper.lambda_ce * hyper.grad_scale, losses + L_TMP1, &dfakes, 1);
+      D1->backward(false, true);                       // D weight grads would be discarded (quirk 5); accumulates onto the CE term if that went first
+      if (!ce_first_) ce_argmax_loss(s, fakes, targets, Cc, hyper.lambda_ce * hyper.grad_scale, losses + L_TMP1, &dfakes, 1);
+      ce_done_ = false;                                // consumed: a second backward_G on the same forward pass takes it again
     } else {
       dev_memset(s, losses + L_G_GAN, 0, sizeof(float));
       ce_argmax_loss(s, fakes, targets, Cc, hyper.lambda_ce * hyper.grad_scale, losses + L_TMP1, &dfakes, 0);
