@@ -1301,6 +1301,8 @@ void Net::prefetch_dgrad() {
 void Net::prefetch_issue(size_t upto) {
   upto = std::min(upto, repack_ops_.size());
   if (!refresh_open_ || repack_next_ >= upto) return;
+  const std::string label_was = g_route_label; const char phase_was = g_route_phase;      // (called from inside a layer's forward)
+  struct Relabel { const std::string& l; char p; ~Relabel() { g_route_label = l; g_route_phase = p; } } relabel{label_was, phase_was};
   std::swap(ctx.s, ctx.side);      // the re-pack launchers use ctx.s
   try {
     for (; repack_next_ < upto; ++repack_next_) {
