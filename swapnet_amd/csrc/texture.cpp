@@ -206,6 +206,7 @@ class TextureModel final : public Model {
                   float style_w, float* d_output_nchw) override {
     if (!is_train) throw Error(1, "perceptual: the model was created without its loss networks (is_train = 0)");
     Stream& s = ctx->s;
+    vt_done_ = false;                      // (the target-feature buffers are about to hold another image's)
     if (!p_out_.v.p) {
       AllocScope mine(*ctx, owned_allocs);
       p_out_ = G->alloc_var(B, H, W, 4, true);
@@ -239,6 +240,10 @@ class TextureModel final : public Model {
   Var g_out_, g_tgt_;            // global batches of the data-parallel style term (lazily sized)
   int style_total_ = 0, style_n0_ = 0;
   bool style_ctx_ = false;
+  // VGG16 features of the TARGETS (perceptual.py:49-57) depend on nothing the step computes: taken early, behind the discriminator's
+  // backward pass where the main stream otherwise waits for the last weight gradients and AdamW(D) on the second stream (round 6;
+  // values only, nothing accumulates: bit-identical).  SWN_VT_EARLY=0: where the reference takes them, inside backward_G.
+  bool vt_done_ = false;
   void set_style_context(const float* all_out, const float* all_tgt, int n_total, int n0) override {
     if (!is_train) throw Error(1, "set_style_context: training model required");
     if (n_total < B || n0 < 0 || n0 + B > n_total) throw Error(1, "set_style_context: local range outside the global batch");
@@ -253,6 +258,7 @@ class TextureModel final : public Model {
   }
 
   void set_input(int slot, const float* src, int N, int C, int Hh, int Ww) override {
+    vt_done_ = false;
     Stream& s = ctx->s;
     if (slot == 1) {                                   // rois (B,R,4)
       if (N != B || C != num_roi || Hh != 4) throw Error(1, "rois must be (B, num_roi, 4)");
@@ -277,6 +283,7 @@ class TextureModel final : public Model {
     }
   }
   void set_input_labels(int slot, const int32_t* lab, int N, int Hh, int Ww) override {
+    vt_done_ = false;
     if (N != B || Hh != H || Ww != W) throw Error(1, "set_input_labels: shape mismatch with the model's (B,H,W)");
     if (slot != 2) throw Error(1, "set_input_labels: slot has no label form");
     labels_to_onehot(ctx->s, lab, unet_in.v.slice(RC, Ccp), Cc);
@@ -292,6 +299,7 @@ class TextureModel final : public Model {
   void forward(bool training, uint64_t seed) override {        // texture_model.py:121-125
     G->training = training; G->seed = seed;
     G->forward();
+    vt_done_ = false;
   }
   void backward_D(float label_fake, float label_real) override {       // texture_model.py:127-155
     Stream& s = ctx->s;
@@ -304,7 +312,14 @@ class TextureModel final : public Model {
     else if (hyper.gan_mode == 1) { lsgan_loss(s, pf, label_fake, gs, losses + L_D_FAKE, &gf, label_dev(0)); lsgan_loss(s, pr, label_real, gs, losses + L_D_REAL, &gr, label_dev(1)); }
     else { wgan_loss(s, pf, 1.f, gs, losses + L_D_FAKE, &gf); wgan_loss(s, pr, -1.f, gs, losses + L_D_REAL, &gr); }
     scalar_axpby(s, losses + L_D_FAKE, 0.5f, losses + L_D_REAL, 0.5f, losses + L_D);
-    D2->backward(true, false);
+    D2->backward_range(true, false, 0, (int)D2->ops.size(), /*join=*/false);
+    static const bool vt_early = !(getenv("SWN_VT_EARLY") && atoi(getenv("SWN_VT_EARLY")) == 0);
+    if (vt_early && VT && (hyper.lambda_content != 0.f || hyper.lambda_style != 0.f)) {
+      VF->refresh_dgrad();                 // (the frozen VGG16's operands: derived once)
+      VT->forward();
+      vt_done_ = true;
+    }
+    ctx->join_side();                      // every D gradient is final for whatever the main stream does next
     // (texture_model.py:148-153 hands the UNconditioned 3-channel targets / fakes to the 22-channel discriminator in the
     // gradient-penalty modes, which raises in the reference; set_hyper rejects gp_mode for this model)
     dev_memset(s, losses + L_D_GP, 0, sizeof(float));
@@ -333,7 +348,8 @@ class TextureModel final : public Model {
     dev_memset(s, losses + L_G_CONTENT, 0, 2 * sizeof(float));
     if (hyper.lambda_content != 0.f || hyper.lambda_style != 0.f) {
       VF->refresh_dgrad();
-      VT->forward();
+      if (!vt_done_) VT->forward();
+      vt_done_ = false;
       VF->forward();
       for (int k = 0; k < 5; ++k) {
         normed_mse_loss(s, feat_f[k].v, feat_t[k].v, hyper.lambda_content * gsc, losses + L_TMP2, &feat_f[k].g, 0);
