@@ -326,6 +326,39 @@ def test_gradients_against_fp64_oracle_at_full_resolution():
 
 
 @pytest.mark.gpu
+def test_warp_c2_eval_mode_forward_matches_oracle_at_the_benchmarked_batch():
+    """Eval-mode routing at BASELINE.json C2's batch (256 x 256, bs 32: the un-split 36-plane resblock launches, the bs-32 split-K plans of
+    the deep cloth levels) held to the oracle's FORWARD pass (round-5 advice: the full-batch oracle STEPS of the suite are train-mode
+    only since round 5; a forward-only oracle pass is ~10 s of CPU).  Generated batch and CE term 1e-3 (north_star), observed ~1e-6; the
+    eval-mode forward launches are a subset of the default-environment training step's forward launches."""
+    ctx = backends.gpu_ctx()
+    B, H = 32, 256
+    torch.manual_seed(3)
+    G, D = O.warp_module_params(), O.patchgan_params(22)
+    batch = O.synth_warp_batch(B, H, H, seed=99)
+    m = backends.get_model(ctx, "warp", B, H)
+    backends.reset_state(m, {engine.NET_G: G, engine.NET_D: D})
+    for i, t in enumerate(batch):
+        m.set_input(i, t)
+    with backends.traced_route(ctx) as route:
+        m.forward(False, 0)
+    got = m.output().cpu()
+    with torch.no_grad():
+        ref = O.warp_module_forward(G, batch[0], batch[1], training=False)
+    err = rel(got, ref)
+    print("warp 256x256 bs32 eval forward: fakes rel-L2 %.2e" % err)
+    assert err < 1e-3, err
+    ce_got = float(torch.nn.functional.cross_entropy(got, torch.argmax(batch[2], dim=1)))
+    ce_ref = float(torch.nn.functional.cross_entropy(ref, torch.argmax(batch[2], dim=1)))
+    assert abs(ce_got - ce_ref) <= 1e-3 * abs(ce_ref), (ce_got, ce_ref)
+    fwd = [l for l in route.lines if " f " in l]
+    assert any(",b36,full1152," in l for l in fwd), fwd[:10]                     # the un-split 36-plane launch of the resblocks
+    want = [l for l in backends.default_route("warp", B, H) if " f " in l and not l.startswith("model.")]
+    extra = [l for l in fwd if l not in want]
+    assert not extra, ("eval-mode forward launched what the default training step's forward does not", extra[:8])
+
+
+@pytest.mark.gpu
 def test_training_mode_loss_statistics_match_oracle():
     """Train-mode statistics without replaying masks: the mean generator loss over K independent dropout draws
     (library RNG) against the oracle's mean over K draws of torch's RNG -- same distribution, different streams."""
