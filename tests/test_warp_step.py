@@ -224,6 +224,41 @@ def test_fused_step_equals_phased_step(backend, oracle_run):
     assert torch.equal(outs[0][1], outs[1][1])
 
 
+@pytest.mark.small_channel_winograd
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_early_cross_entropy_term_is_the_same_step(backend, oracle_run, monkeypatch):
+    """Round 6 takes loss_G's cross-entropy term early (behind the discriminator's backward pass; PatchGAN's input gradient accumulates onto
+    it) instead of accumulating it onto PatchGAN's gradient inside backward_G (warp_model.py:141-167).  a + b = b + a: every gradient of
+    both networks, the losses and the post-step weights are BIT-identical between the two orders, phase by phase, and also when backward_G
+    runs without a backward_D in front of it (the early term is then taken inside backward_G)."""
+    G, D, batch, _, steps = oracle_run
+    ctx = _ctx(backend)
+    B, H = batch[0].shape[0], batch[0].shape[2]
+    lab = steps[0]["labels"]
+    outs = []
+    for early in ("1", "0"):
+        monkeypatch.setenv("SWN_CE_EARLY", early)                    # read when a model is built
+        m = engine.NativeModel(ctx, "warp", B, H, H)
+        try:
+            backends.reset_state(m, {engine.NET_G: G, engine.NET_D: D})
+            for i, t in enumerate(batch):
+                m.set_input(i, t)
+            m.forward(False, 0); m.backward_G(lab[2])                 # no backward_D in front
+            g_alone = m.grad_arena(engine.NET_G).clone()
+            m.forward(False, 0); m.backward_D(lab[0], lab[1]); m.optimizer_step(1); m.backward_G(lab[2])
+            gG, gD = m.grad_arena(engine.NET_G).clone(), m.grad_arena(engine.NET_D).clone()
+            m.optimizer_step(0)
+            m.ctx.sync()
+            outs.append((m.losses(), g_alone.cpu(), gG.cpu(), gD.cpu(), m.weight_arena(engine.NET_G).clone().cpu()))
+        finally:
+            m.close()
+    a, b = outs
+    assert a[0] == b[0], (a[0], b[0])
+    for x, y, what in zip(a[1:], b[1:], ("G gradients, backward_G alone", "G gradients", "D gradients", "G weights after the step")):
+        assert torch.equal(x, y), what
+    assert float(a[2].abs().max()) > 0
+
+
 @pytest.mark.gpu
 def test_warp_full_size_properties():
     """Config C2 shape (256x256, bs 32): size-independent properties the oracle cannot reach.
