@@ -513,7 +513,20 @@ int main(int argc, char** argv) {
       q.ap_bs = ap_bs; q.bp_bs = bp_bs[vb]; q.c_bs = (size_t)s.M * s.N;
       q.ap_bytes = (unsigned)(ap_bs * 2); q.bp_bytes = (unsigned)(bp_bs[vb] * 2);
       q.tiles_n = s.N / BN; q.tiles_m = s.M / BM; q.ntiles = q.tiles_m * q.tiles_n; q.zswz = zswz; q.clk = dClk;
-      auto fn = [&] { hipLaunchKernelGGL(kern, dim3(q.ntiles * s.batch), dim3(nthreads), smem, st, q); };
+      // LAB_ROTATE=n (round 6): n copies of both operands and of the output, one per launch in turn -- 300 MB per copy for the 36-plane
+      // shape, so with n >= 2 no launch finds its operands in the 256 MB Infinity Cache the way back-to-back launches on ONE set do
+      static const int rot = getenv("LAB_ROTATE") ? std::max(1, atoi(getenv("LAB_ROTATE"))) : 1;
+      std::vector<LabW> qs(rot, q); std::vector<void*> extra;
+      for (int r = 1; r < rot; ++r) {
+        unsigned short *a2, *b2; float* c2;
+        CK(hipMalloc((void**)&a2, ap_bs * s.batch * 2)); CK(hipMalloc((void**)&b2, bp_bs[vb] * s.batch * 2)); CK(hipMalloc((void**)&c2, nc * 4));
+        CK(hipMemcpyAsync(a2, dPA[va], ap_bs * s.batch * 2, hipMemcpyDeviceToDevice, st)); CK(hipMemcpyAsync(b2, dPB[vb], bp_bs[vb] * s.batch * 2, hipMemcpyDeviceToDevice, st));
+        qs[r].Ap = a2; qs[r].Bp = b2; qs[r].C = c2; extra.push_back(a2); extra.push_back(b2); extra.push_back(c2);
+      }
+      CK(hipStreamSynchronize(st));
+      int turn = 0;
+      auto fn = [&] { hipLaunchKernelGGL(kern, dim3(q.ntiles * s.batch), dim3(nthreads), smem, st, qs[turn]); turn = (turn + 1) % rot; };
+      struct FreeExtra { std::vector<void*>& v; ~FreeExtra() { for (void* p : v) (void)hipFree(p); } } free_extra{extra};
       CK(hipMemsetAsync(dC, 0, nc * 4, st));
       fn(); CK(hipStreamSynchronize(st));
       double err = -1;
