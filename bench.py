@@ -577,16 +577,17 @@ def main():
                 # the yardstick of the round-2 / early round-3 lines (three bf16 planes, 6 MFMAs per product: 2500 / 6), so that the
                 # fp32-equivalent rate can be followed across rounds although this kernel's own roofline doubled with the two-plane form
                 "frac_of_bf16x6_roofline": round(ach / PEAK_SPLIT_TFLOPS, 4),
-                "power_note": ("the two-plane loop is bound by the chip's power, not by issue: in tools/tile_lab.hip (round 5) the shipped "
-                               "128x128 loop runs 1.13-1.24 GHz at 85-93 % matrix-pipe occupancy on random operands and 2.0-2.2 GHz on zeros; "
-                               "the same launch with its MFMAs removed 2.1-2.4 GHz; rocprofv3's GRBM_GUI_ACTIVE reads 1.90 GHz where the "
-                               "in-kernel counter and SQ_WAVE_CYCLES agree on 1.40 (profiles/clock_calibration_r05.txt): it is not the "
-                               "shader clock under MFMA load.  That holds for launches that fill whole rounds; a launch with a ragged last "
-                               "round (16 of this family's 51: 36 Winograd planes = 1152 tiles on 1024 slots) runs that round one workgroup "
-                               "per CU, where the two-stage ring waits a fill latency (~1.1 us) per 16-k step: 127 us with or without its MFMAs "
-                               "against 103 us balanced (profiles/tile_lab_r05.txt).  Round 6 measured the remedies and kept none: K-slices of "
-                               "the remainder fused into the first round with an in-kernel fix-up 229-433 us (the cross-XCD slab exchange), "
-                               "five workgroups per CU 128 us, a third ring stage does not fit four per CU (profiles/tile_lab_r06_ragged.txt)"),
+                "power_note": ("what bounds this family (DESIGN.md section 4): on operands that sit in the 256 MB Infinity Cache -- every lab figure of "
+                               "round 5: back-to-back launches over one operand set -- the shipped 128x128 loop is bound by the chip's power "
+                               "(tools/tile_lab.hip: 1.13-1.24 GHz at 85-93 % matrix-pipe occupancy on random operands, 2.0-2.2 GHz on zeros; 92 us "
+                               "for 1024 tiles).  With the operand sets rotated so that every launch streams them from HBM, as the product's "
+                               "launches do, the same loop takes 107-108 us and its fills ALONE 88 us (48 cache-resident): one 16-KB stage in "
+                               "flight per workgroup, ~1.7 us per stage (profiles/tile_lab_r06_rotate.txt).  In the step the exact-fit and the "
+                               "ragged launch (36 Winograd planes = 1152 tiles on 1024 places, 16 of this family's 51) both cost 0.132 us per "
+                               "tile; re-issuing the ragged launch as two half launches gains nothing (profiles/ragged_split_r06.txt) and one "
+                               "fp16 plane per operand -- a third of the MFMAs -- makes the family 18 % faster.  The remedies measured for "
+                               "the ragged round (K-slices fused into the first round 229-433 us, five workgroups per CU 128 us, a third "
+                               "ring stage does not fit four per CU: profiles/tile_lab_r06_ragged.txt) were measured cache-resident"),
                 # HBM side of the same step: bytes of the PMC passes (same source as `traffic`) over this run's step time, against
                 # the 6.3 TB/s the guide measures as achievable (8 TB/s spec)
                 "step_hbm_bytes": step_hbm,
