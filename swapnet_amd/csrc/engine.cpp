@@ -841,7 +841,11 @@ void Net::conv(const std::string& name, const Var& x, const Var& y, ConvKind kin
         conv_wgrad(sw, wa);
         tail_unfold_wgrad(sw, wd.ws, n.dg + dfold_off, A->g + wd.off);
       }
-      if (bi >= 0) n.bias_grad_of(sw, dY, A->g + A->params[bi].off);
+      // bias gradient: beside the weight gradient on the second stream -- unless this layer forms no input gradient (the first layer of
+      // a pass: PatchGAN's model.0 in backward_D, whose weight gradient is the step's exposed tail), where the main stream has nothing
+      // else to do and the column sums run there, beside the weight gradient instead of behind it (round 6; same kernel, bit-identical)
+      static const bool bias_on_main = !(getenv("SWN_BIAS_MAIN") && atoi(getenv("SWN_BIAS_MAIN")) == 0);
+      if (bi >= 0) n.bias_grad_of((!dx_now && bias_on_main) ? n.ctx.s : sw, dY, A->g + A->params[bi].off);
     }
     if (!dx_now) return;
     const int accf = me.acc.empty() ? 0 : me.acc[0];

@@ -19,7 +19,7 @@ if REPO not in sys.path:
 # additionally assert their launch list against a scrubbed-environment run (tests/backends.py default_route).
 ROUTING_SWITCHES = ("SWN_WINO_MINC", "SWN_WINOGRAD", "SWN_WINO_S2", "SWN_WINO_M", "SWN_TAIL4", "SWN_PHASE4", "SWN_HEAD_TAPN", "SWN_NARROW",
                     "SWN_DMA", "SWN_DMA_WIDE", "SWN_SPLIT", "SWN_PRECUT", "SWN_PC_PLANES", "SWN_WGRAD_PLANES", "SWN_TAIL_SPLIT", "SWN_AMAX_FUSED",
-                    "SWN_PAIR", "SWN_PREFETCH", "SWN_STREAM_ADAMW", "SWN_OVERLAP", "SWN_SIM_PAIR", "SWN_SIM_SLOT_REPORT", "SWN_ROI_WAVE", "SWN_CONV_STATS", "SWN_IN_PAIR_XCD", "SWN_PHASE_ZFAST", "SWN_PREFETCH_AHEAD", "SWN_CE_EARLY", "SWN_VT_EARLY")
+                    "SWN_PAIR", "SWN_PREFETCH", "SWN_STREAM_ADAMW", "SWN_OVERLAP", "SWN_SIM_PAIR", "SWN_SIM_SLOT_REPORT", "SWN_ROI_WAVE", "SWN_CONV_STATS", "SWN_IN_PAIR_XCD", "SWN_PHASE_ZFAST", "SWN_PREFETCH_AHEAD", "SWN_CE_EARLY", "SWN_VT_EARLY", "SWN_BIAS_MAIN")
 
 
 def pytest_configure(config):
